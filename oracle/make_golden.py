@@ -1,0 +1,268 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference in this container.
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.  Run from the repo root:
+
+    python -m oracle.make_golden
+
+Needs /root/reference (present only in the build container); the produced
+fixtures are small, committed, and are what the GPU box / CI read.  Networks are
+the full-size configs_v1 nets, random-init with torch.manual_seed(1234) in the
+reference's construction order (train.py:118-139); the fixtures store weight
+fingerprints instead of the 25.5 M weights, the tests re-create the weights
+from the same seed and verify the fingerprints first.
+"""
+import json
+import random
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "ubisoft-laforge-zeroeggs_amd"))
+from oracle import ref_shims  # noqa: E402
+from zeggs import synth  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+SEED = 1234
+NET_OPT = {
+    "decoder": {"nhidden": 1024, "num_rnn_layers": 2, "rnn_cond": "normal"},
+    "speech_encoder": {"nhidden": 64, "speech_encoding_size": 64},
+    "style_encoder": {"nhidden": 512, "style_encoding_size": 64, "example_length": 12,
+                      "type": "attn", "use_vae": True},
+}
+
+
+def sample_idx(numel):
+    """Fixed pseudo-random sample of flat indices used for gradient/weight fingerprints."""
+    return np.unique((np.arange(97, dtype=np.int64) * 7919 + 13) % numel)
+
+
+def fingerprint(t):
+    a = t.detach().double().flatten()
+    return np.array([float(a.sum()), float(a.abs().sum())])
+
+
+def build_ref_nets(ref):
+    """Reference construction order and seed (train.py:40-41,118-139)."""
+    torch.manual_seed(SEED)
+    se = ref.modules.SpeechEncoder(synth.N_AUDIO, 64, 64)
+    de = ref.modules.Decoder(pose_input_size=synth.POSE_IN, pose_output_size=synth.POSE_OUT,
+                             speech_encoding_size=64, style_encoding_size=64, hidden_size=1024,
+                             num_rnn_layers=2)
+    st = ref.modules.StyleEncoder(synth.POSE_IN, 512, 64, type="attn", use_vae=True)
+    return se, de, st
+
+
+def gold_nets(ref):
+    se, de, st = build_ref_nets(ref)
+    se.eval(), de.eval(), st.eval()
+    stats = synth.make_stats()
+    B, T, L = 2, 6, 10
+    clips = [synth.make_clip(T + L, seed=50 + b, stats=stats) for b in range(B)]
+    tt = lambda k, sl: torch.as_tensor(np.stack([c[k][sl] for c in clips]))  # noqa: E731
+    W = {k: tt(k, slice(0, T)) for k in clips[0]}
+    in_mean, in_std = torch.as_tensor(stats["anim_input_mean"]), torch.as_tensor(stats["anim_input_std"])
+    out_mean, out_std = torch.as_tensor(stats["anim_output_mean"]), torch.as_tensor(stats["anim_output_std"])
+    a_mean, a_std = torch.as_tensor(stats["audio_input_mean"]), torch.as_tensor(stats["audio_input_std"])
+    ex = []
+    for c in clips:
+        n = L
+        ex.append(np.concatenate([c["Y_root_vel"][T:T + n], c["Y_root_vrt"][T:T + n],
+                                  c["Y_lpos"][T:T + n].reshape(n, -1), c["Y_ltxy"][T:T + n].reshape(n, -1),
+                                  c["Y_lvel"][T:T + n].reshape(n, -1), c["Y_lvrt"][T:T + n].reshape(n, -1),
+                                  np.zeros((n, 3), np.float32)], axis=1))
+    example = torch.as_tensor(np.stack(ex))
+    eps = torch.as_tensor(np.random.default_rng(3).standard_normal((B, 64)).astype(np.float32))
+    parents = torch.LongTensor(synth.PARENTS)
+    out = {}
+    with torch.no_grad():
+        audio_n = (W["X_audio_features"] - a_mean) / a_std
+        speech = se(audio_n)
+        orig = torch.randn_like
+        torch.randn_like = lambda x, *a, **k: eps.to(x.dtype)
+        try:
+            z, mu, logvar = st((example - in_mean) / in_std, 1.3)
+        finally:
+            torch.randn_like = orig
+        O = de(W["Y_root_pos"][:, 0], W["Y_root_rot"][:, 0], W["Y_root_vel"][:, 0], W["Y_root_vrt"][:, 0],
+               W["Y_lpos"][:, 0], W["Y_ltxy"][:, 0], W["Y_lvel"][:, 0], W["Y_lvrt"][:, 0],
+               W["Y_gaze_pos"], speech, z.unsqueeze(1).repeat(1, T, 1), parents,
+               in_mean, in_std, out_mean, out_std, synth.DT)
+    out.update({"in_" + k: v.numpy() for k, v in W.items()})
+    out.update(in_example=example.numpy(), in_eps=eps.numpy(), temperature=np.float32(1.3),
+               speech=speech.numpy(), style_z=z.numpy(), style_mu=mu.numpy(), style_logvar=logvar.numpy())
+    names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
+    out.update({"O_" + n: o.numpy() for n, o in zip(names, O)})
+    for tag, net in (("speech", se), ("decoder", de), ("style", st)):
+        for k, v in net.state_dict().items():
+            out[f"fp_{tag}.{k}"] = fingerprint(v)
+    np.savez_compressed(GOLD / "nets.npz", **out)
+    print("nets.npz", {k: v.shape for k, v in out.items() if k.startswith("O_")})
+
+
+def gold_train_iter(ref):
+    """Two full reference train() iterations, B=2, window=8 (dropout patched to
+    identity, VAE eps injected) -> batches, losses, gradient / weight samples."""
+    import torch.nn.functional as F
+    tmp = Path(tempfile.mkdtemp(prefix="zeggs_gold_"))
+    window, B = 8, 2
+    npz, jsn = synth.write_dataset(tmp / "data", n_train=1, n_valid=1, nframes=window + 4, seed=5)
+    rec = dict(batches=[], eps=[], loss=[], terms=[], grads=[], weights=[])
+
+    class RecDL(torch.utils.data.DataLoader):
+        def __iter__(self):
+            for b in super().__iter__():
+                rec["batches"].append([t.clone() for t in b])
+                yield b
+
+    class RecWriter:
+        def __init__(self, *a, **k): pass
+        def add_hparams(self, *a, **k): pass
+        def add_scalar(self, *a, **k): pass
+        def add_scalars(self, tag, d, it):
+            rec["terms"].append([float(v) for v in d.values()])
+
+    eps_rng = np.random.default_rng(11)
+
+    def fake_randn_like(x, *a, **k):
+        e = torch.as_tensor(eps_rng.standard_normal(tuple(x.shape)).astype(np.float32))
+        if x.shape[0] == B:
+            rec["eps"].append(e.clone())
+        return e
+
+    orig_step = ref.optimizers.RAdam.step
+
+    def rec_step(self, closure=None):
+        ps = [p for g in self.param_groups for p in g["params"]]
+        rec["grads"].append([(fingerprint(p.grad), p.grad.flatten()[sample_idx(p.numel())].clone()) for p in ps])
+        r = orig_step(self, closure)
+        rec["weights"].append([p.detach().flatten()[sample_idx(p.numel())].clone() for p in ps])
+        return r
+
+    orig_backward = torch.Tensor.backward
+
+    def rec_backward(self, *a, **k):
+        rec["loss"].append(float(self.detach()))
+        return orig_backward(self, *a, **k)
+
+    saved = (ref.train.DataLoader, ref.train.SummaryWriter, torch.randn_like, F.dropout)
+    ref.train.DataLoader, ref.train.SummaryWriter = RecDL, RecWriter
+    torch.randn_like = fake_randn_like
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x
+    ref.optimizers.RAdam.step = rec_step
+    ref.train.RAdam.step = rec_step
+    torch.Tensor.backward = rec_backward
+    random.seed(0)
+    train_opt = dict(niterations=0.001, batchsize=B, window=window, change_pace=True, learning_rate=1e-4,
+                     learning_rate_decay=0.995, eps=1e-5, resume=False, use_gpu=False, thread_count=1,
+                     seed=SEED, use_tensorboard=True, style_encoding_type="example",
+                     generate_samples_step=10 ** 9, use_script=False)
+    try:
+        (tmp / "models").mkdir()
+        (tmp / "logs").mkdir()
+        ref.train.train(tmp / "models", tmp / "logs", npz, jsn, train_opt, NET_OPT)
+    finally:
+        ref.train.DataLoader, ref.train.SummaryWriter, torch.randn_like, F.dropout = saved
+        ref.optimizers.RAdam.step = orig_step
+        torch.Tensor.backward = orig_backward
+    out = dict(window=np.int64(window), batch=np.int64(B), loss=np.array(rec["loss"]),
+               terms=np.array(rec["terms"]))
+    data = np.load(npz)
+    out.update({"data_" + k: data[k] for k in data.files})
+    for it, b in enumerate(rec["batches"]):
+        for j, t in enumerate(b):
+            out[f"it{it}_batch{j}"] = t.numpy()
+        out[f"it{it}_eps"] = rec["eps"][it].numpy()
+        out[f"it{it}_grad_fp"] = np.stack([g[0] for g in rec["grads"][it]])
+        out[f"it{it}_grad_samples"] = np.concatenate([g[1].numpy() for g in rec["grads"][it]])
+        out[f"it{it}_weight_samples"] = np.concatenate([w.numpy() for w in rec["weights"][it]])
+    np.savez_compressed(GOLD / "train_iter.npz", **out)
+    print("train_iter.npz: iterations", len(rec["loss"]), "loss", rec["loss"])
+
+
+def gold_mel(ref):
+    conf = json.load(open("/root/reference/data/processed_v1/data_pipeline_conf.json"))
+    conf["audio_conf"]["normalize_loudness"] = False      # pyloudnorm absent: parity unpinned there
+    ac = ref.DictConfig(conf["audio_conf"])
+    out = {}
+    for tag, n in (("a", 16000), ("b", 16123), ("c", 24400)):
+        wav = synth.synth_wav(n, seed=n).astype(np.float32) / 32768.0
+        nfr = int(round(60.0 * (n / 16000)))
+        feat = ref.data_pipeline.preprocess_audio(wav, 60, nfr, ac, feature_type=conf["audio_feature_type"])
+        mel, _ = ref.data_pipeline.extract_mel_spectrogram_for_tts(
+            wav_signal=wav, fs=16000, n_fft=800, step_size=200, n_mels=80, mel_fmin=20, mel_fmax=7600,
+            min_amplitude=1e-5, pre_emphasis=False, pre_emph_coeff=0.97, dynamic_range=None,
+            real_amplitude=True, centered=True, normalize_mel_bins=True, normalize_range=True, logger=None)
+        out[f"{tag}_wav"], out[f"{tag}_feat"], out[f"{tag}_mel"] = wav, feat, mel
+        out[f"{tag}_nframes"] = np.int64(nfr)
+    np.savez_compressed(GOLD / "mel.npz", **out)
+    print("mel.npz", {k: v.shape for k, v in out.items() if k.endswith("feat")})
+
+
+def gold_dataset(ref):
+    """Window table and style-example row sources from the reference SGDataset;
+    Y_root_vel[f] = (f, f, f) encodes the source frame of every returned row."""
+    tmp = Path(tempfile.mkdtemp(prefix="zeggs_gold_ds_"))
+    npz, jsn = synth.write_dataset(tmp, n_train=3, n_valid=1, nframes=40, seed=2)
+    d = dict(np.load(npz))
+    n = len(d["Y_root_vel"])
+    d["Y_root_vel"] = np.repeat(np.arange(n, dtype=np.float32)[:, None], 3, axis=1)
+    np.savez(npz, **d)
+    window = 8
+    out = dict(ranges_train=d["ranges_train"], window=np.int64(window), n_total=np.int64(n))
+    ds = ref.dataset.SGDataset(jsn, npz, window, "example", 12)
+    out["R0"] = ds.R[:, 0].numpy()
+    out["S"] = ds.S.numpy()
+    q = []
+    for ex_len in (8, 12, 20, 30):
+        ds.example_window_length = ex_len
+        for idx in (0, 1, 15, 31, 32, 40, 63, len(ds) - 1):
+            item = ds[idx]
+            rows = item[10][:, 0].numpy().astype(np.int64)
+            rows = np.pad(rows, (0, 30 - len(rows)), constant_values=-1)
+            q.append(np.concatenate([[ex_len, idx, item[10].shape[0]], rows]))
+    out["queries"] = np.array(q, dtype=np.int64)
+    out["split_10_3"] = np.array(ref.helpers.split_by_ratio(10, [0.5, 0.25, 0.25]))
+    out["split_601"] = np.array(ref.helpers.split_by_ratio(601, [0.3, 0.7]))
+    np.savez_compressed(GOLD / "dataset.npz", **out)
+    print("dataset.npz windows", len(ds))
+
+
+def gold_radam(ref):
+    torch.manual_seed(3)
+    p = torch.nn.Parameter(torch.randn(257))
+    opt = ref.optimizers.RAdam([p], lr=1e-2, eps=1e-5)
+    gs, ps = [], [p.detach().clone().numpy()]
+    for _ in range(9):
+        g = torch.randn(257)
+        p.grad = g.clone()
+        opt.step()
+        gs.append(g.numpy())
+        ps.append(p.detach().clone().numpy())
+    np.savez_compressed(GOLD / "radam.npz", grads=np.stack(gs), params=np.stack(ps), lr=1e-2, eps=1e-5)
+    print("radam.npz")
+
+
+def main():
+    assert ref_shims.available(), "/root/reference is required to (re)generate golden vectors"
+    GOLD.mkdir(parents=True, exist_ok=True)
+    ref = ref_shims.load()
+    torch.set_num_threads(1)
+    which = sys.argv[1:] or ["nets", "train", "mel", "dataset", "radam"]
+    if "nets" in which:
+        gold_nets(ref)
+    if "mel" in which:
+        gold_mel(ref)
+    if "dataset" in which:
+        gold_dataset(ref)
+    if "radam" in which:
+        gold_radam(ref)
+    if "train" in which:
+        gold_train_iter(ref)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""Oracle restatement of the audio front-end (numpy float64, vectorised).
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.
+
+Reference (paths relative to /root/reference):
+  ZEGGS/audio/spectrograms.py:216-269  extract_spectrogram (Hann 800, reflect pad 400/400, rfft, |.|/n_fft)
+  ZEGGS/audio/spectrograms.py:386-503  Slaney mel filterbank (_hz_to_mel/_mel_to_hz)
+  ZEGGS/audio/spectrograms.py:57-131   clip at min_amplitude/n_fft, 20 log10, map to [0, 1]
+  ZEGGS/data_pipeline.py:28-84         preprocess_audio: 10**(x/20) -> ln -> linear resample -> + energy
+  ZEGGS/generate.py:170                n_frames = int(round(60 * len / 16000))
+Loudness normalisation (pyloudnorm, data_pipeline.py:34-39) is NOT restated
+here: parity unpinned for that stage (dependency absent), golden vectors use
+normalize_loudness=false.
+"""
+import numpy as np
+
+
+def hann_symmetric(n):
+    """scipy.signal.hann(n) == windows.hann(n, sym=True)"""
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / (n - 1))
+
+
+def stft_frame_count(n_samples, n_fft=800, hop=200):
+    """spectrograms.py:233-246 (integer rule, bit-exact)."""
+    n = max(n_samples, n_fft) + 2 * (n_fft // 2)
+    if n % hop == 0:
+        return int((n - n_fft) // hop)
+    return 1 + int((n - n_fft) // hop)
+
+
+def n_anim_frames(n_samples, fs=16000, fps=60.0):
+    """generate.py:170 (Python round = banker's rounding)."""
+    return int(round(fps * (n_samples / fs)))
+
+
+def hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, mels)
+
+
+def mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    freqs = f_sp * m
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), freqs)
+
+
+def mel_filterbank(n_fft=800, fs=16000, n_mels=80, fmin=20.0, fmax=7600.0, normalize=True):
+    """spectrograms.py:386-443 -> [n_mels, n_fft//2+1] float64"""
+    nb = 1 + n_fft // 2
+    fft_freqs = np.linspace(0, fs / 2.0, nb, endpoint=True)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fft_freqs)
+    w = np.zeros((n_mels, nb))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        w[i] = np.maximum(0, np.minimum(lower, upper))
+    if normalize:
+        w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w
+
+
+def mel_spectrogram(wav, n_fft=800, hop=200, fs=16000, n_mels=80, fmin=20.0, fmax=7600.0,
+                    min_clip=1e-5):
+    """extract_mel_spectrogram_for_tts (spectrograms.py:8-54) with the shipped
+    conf (centered, real_amplitude, normalize_mel_bins, normalize_range, no
+    pre-emphasis): returns [n_mels, M] in [0, ~1]."""
+    x = np.asarray(wav, dtype=np.float64)
+    if len(x) < n_fft:
+        x = np.pad(x, (0, n_fft - len(x)))
+    x = np.pad(x, (n_fft // 2, n_fft // 2), mode="reflect")
+    M = stft_frame_count(len(wav), n_fft, hop)
+    idx = np.arange(M)[:, None] * hop + np.arange(n_fft)[None, :]
+    frames = x[idx] * hann_symmetric(n_fft)[None, :]
+    amp = np.abs(np.fft.rfft(frames, axis=1)).T / n_fft            # [401, M]
+    mel = mel_filterbank(n_fft, fs, n_mels, fmin, fmax) @ amp      # [80, M]
+    amin = min_clip / n_fft
+    mel = np.clip(np.abs(mel), amin, None)
+    db = 20.0 * np.log10(mel)
+    rng = -20.0 * np.log10(amin)
+    return (db + rng) / rng
+
+
+def preprocess_audio(wav, n_frames, fs=16000, hop=200, fps=60.0, **kw):
+    """data_pipeline.py:33-84 with feature_type = [mel_spec, energy], linear
+    resampling, normalize_loudness = false.  -> [n_frames, 81] float32"""
+    mel = mel_spectrogram(wav, hop=hop, fs=fs, **kw).T              # [M, 80]
+    mel = np.log(10.0 ** (mel / 20.0))
+    M = len(mel)
+    t = ((fs / hop) / fps) * np.arange(n_frames)
+    i0 = np.floor(t).astype(np.int64)
+    fr = t - i0
+    # griddata(linear) -> NaN outside the hull [0, M-1]
+    inside = (t >= 0) & (t <= M - 1)
+    i0c = np.clip(i0, 0, M - 1)
+    i1c = np.clip(i0 + 1, 0, M - 1)
+    mel_i = mel[i0c] * (1.0 - fr)[:, None] + mel[i1c] * fr[:, None]
+    mel_i[~inside] = np.nan
+    energy = np.linalg.norm(np.exp(mel), axis=1)                     # [M]
+    # interp1d(linear, fill_value="extrapolate")
+    j0 = np.clip(i0, 0, M - 2)
+    slope = energy[j0 + 1] - energy[j0]
+    en_i = energy[j0] + slope * (t - j0)
+    return np.concatenate([mel_i.astype(np.float32), en_i.astype(np.float32)[:, None]], axis=1)

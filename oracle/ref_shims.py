@@ -1,0 +1,76 @@
+"""Import the UNMODIFIED reference (/root/reference/ZEGGS) in the build container.
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.  Only used by
+oracle/make_golden.py (fixture generation) and by bench.py's optional
+cpu_baseline kind="reference" probe when /root/reference exists; nothing on the
+GPU box reads /root/reference.
+
+The shims replace *missing third-party packages / binaries* only (tensorboard,
+omegaconf, sox, ffmpeg check, scipy.signal.hann alias); no reference source is
+modified or copied.  Recipe documented in SURVEY.md Appendix A.
+"""
+import importlib.util
+import sys
+import types
+from pathlib import Path
+
+REF = Path("/root/reference/ZEGGS")
+
+
+def available():
+    return REF.is_dir()
+
+
+def load():
+    """Returns a namespace with the reference modules (modules, train, ...)."""
+    import scipy.signal as sps
+    import torch
+
+    if "zeggs_ref_loaded" in sys.modules:
+        return sys.modules["zeggs_ref_loaded"]
+    sys.path.insert(0, str(REF))
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = type("SummaryWriter", (), {
+        m: (lambda self, *a, **k: None) for m in ("__init__", "add_scalar", "add_scalars", "add_hparams")})
+    sys.modules["torch.utils.tensorboard"] = tb
+    sys.modules.setdefault("sox", types.ModuleType("sox"))
+    if not hasattr(sps, "hann"):
+        sps.hann = sps.windows.hann
+    pkg = types.ModuleType("audio")
+    pkg.__path__ = [str(REF / "audio")]
+    sys.modules["audio"] = pkg
+    for n in ("logs", "signal_manipulation", "spectrograms", "audio_files"):
+        spec = importlib.util.spec_from_file_location("audio." + n, REF / "audio" / f"{n}.py")
+        m = importlib.util.module_from_spec(spec)
+        sys.modules["audio." + n] = m
+        spec.loader.exec_module(m)
+
+    class DictConfig(dict):
+        def __init__(self, d):
+            super().__init__({k: DictConfig(v) if isinstance(v, dict) else v for k, v in d.items()})
+        __getattr__ = dict.__getitem__
+
+    oc = types.ModuleType("omegaconf")
+    oc.DictConfig = DictConfig
+    sys.modules["omegaconf"] = oc
+
+    import warnings
+    warnings.filterwarnings("ignore")
+    import modules, train, data_pipeline, generate, optimizers, dataset, helpers  # noqa: E401
+    from anim import tquat, txform, bvh, quat
+
+    ns = types.ModuleType("zeggs_ref_loaded")
+    ns.modules, ns.train, ns.data_pipeline, ns.generate = modules, train, data_pipeline, generate
+    ns.optimizers, ns.dataset, ns.helpers = optimizers, dataset, helpers
+    ns.tquat, ns.txform, ns.bvh, ns.quat = tquat, txform, bvh, quat
+    ns.DictConfig = DictConfig
+    # torch >= 2.6 defaults weights_only=True; the reference pickles whole modules
+    _orig_load = torch.load
+
+    def _load(*a, **k):
+        k.setdefault("weights_only", False)
+        return _orig_load(*a, **k)
+
+    ns.torch_load = _load
+    sys.modules["zeggs_ref_loaded"] = ns
+    return ns

@@ -1,0 +1,139 @@
+"""CPU tests: the oracle restatement (oracle/) reproduces golden vectors that
+were produced by the UNMODIFIED reference (oracle/make_golden.py)."""
+import numpy as np
+import torch
+
+from oracle import dataset as ods
+from oracle import loss as oloss
+from oracle import mel as omel
+from oracle import nets as onets
+from oracle import radam as oradam
+from zeggs import synth
+
+import helpers
+
+
+def test_seeded_weights_match_reference_fingerprints(golden_dir):
+    g = np.load(golden_dir / "nets.npz")
+    se, de, st = helpers.build_nets()
+    for tag, net in (("speech", se), ("decoder", de), ("style", st)):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(helpers.fingerprint(v), g[f"fp_{tag}.{k}"], rtol=1e-12, atol=0,
+                                       err_msg=f"{tag}.{k}")
+
+
+def test_oracle_nets_forward_vs_reference(golden_dir):
+    g = np.load(golden_dir / "nets.npz")
+    se, de, st = helpers.build_nets()
+    s = helpers.stats_tensors()
+    t = lambda k: torch.as_tensor(g[k])  # noqa: E731
+    audio_n = (t("in_X_audio_features") - s["a_mean"]) / s["a_std"]
+    speech = onets.speech_encoder(helpers.sd(se), audio_n)
+    np.testing.assert_allclose(speech.numpy(), g["speech"], atol=2e-6)
+    ex = (t("in_example") - s["in_mean"]) / s["in_std"]
+    z, mu, logvar = onets.style_encoder(helpers.sd(st), ex, t("in_eps"), float(g["temperature"]))
+    np.testing.assert_allclose(mu.numpy(), g["style_mu"], atol=2e-6)
+    np.testing.assert_allclose(logvar.numpy(), g["style_logvar"], atol=2e-6)
+    np.testing.assert_allclose(z.numpy(), g["style_z"], atol=5e-6)
+    T = speech.shape[1]
+    O = onets.decoder_rollout(
+        helpers.sd(de), t("in_Y_root_pos")[:, 0], t("in_Y_root_rot")[:, 0], t("in_Y_root_vel")[:, 0],
+        t("in_Y_root_vrt")[:, 0], t("in_Y_lpos")[:, 0], t("in_Y_ltxy")[:, 0], t("in_Y_lvel")[:, 0],
+        t("in_Y_lvrt")[:, 0], t("in_Y_gaze_pos"), t("speech"), t("style_z").unsqueeze(1).repeat(1, T, 1),
+        s["in_mean"], s["in_std"], s["out_mean"], s["out_std"], synth.DT)
+    names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
+    for n, o in zip(names, O):
+        np.testing.assert_allclose(o.numpy(), g["O_" + n], atol=1e-4, rtol=1e-5, err_msg=n)
+
+
+def _oracle_iteration(g, it, nets, s, dtype):
+    """Loss + grads of one training iteration computed by the oracle."""
+    se, de, st = nets
+    b = [torch.as_tensor(g[f"it{it}_batch{j}"]).to(dtype) for j in range(11)]
+    audio, rpos, rrot, rvel, rvrt, lpos, ltxy, lvel, lvrt, gaze, wstyle = b
+    sdd = {k: v.to(dtype) for k, v in s.items()}
+    ws = [helpers.sd(m, dtype) for m in (se, de, st)]
+    for w in ws:
+        for v in w.values():
+            v.requires_grad_(True)
+    speech = onets.speech_encoder(ws[0], (audio - sdd["a_mean"]) / sdd["a_std"])
+    z, mu, logvar = onets.style_encoder(ws[2], (wstyle - sdd["in_mean"]) / sdd["in_std"],
+                                        torch.as_tensor(g[f"it{it}_eps"]).to(dtype))
+    T = audio.shape[1]
+    O = onets.decoder_rollout(ws[1], rpos[:, 0], rrot[:, 0], rvel[:, 0], rvrt[:, 0], lpos[:, 0], ltxy[:, 0],
+                              lvel[:, 0], lvrt[:, 0], gaze, speech, z.unsqueeze(1).repeat(1, T, 1),
+                              sdd["in_mean"], sdd["in_std"], sdd["out_mean"], sdd["out_std"], synth.DT)
+    loss, terms = oloss.training_loss(O, (rpos, rrot, rvel, rvrt, lpos, ltxy, lvel, lvrt), gaze,
+                                      synth.PARENTS, synth.DT, mu, logvar, iteration=it)
+    loss.backward()
+    return loss, terms, ws
+
+
+def test_oracle_train_iteration_vs_reference(golden_dir):
+    """loss, its 18 terms, gradients (fingerprints + samples) and the weights
+    after one RAdam step match the reference's train() iteration 0."""
+    g = np.load(golden_dir / "train_iter.npz")
+    nets = helpers.build_nets()
+    s = helpers.stats_tensors()
+    loss, terms, ws = _oracle_iteration(g, 0, nets, s, torch.float32)
+    np.testing.assert_allclose(float(loss), g["loss"][0], rtol=2e-6)
+    np.testing.assert_allclose(terms.numpy(), g["terms"][0], rtol=2e-5, atol=1e-7)
+    # parameter order of the reference optimizer: speech, decoder, style (train.py:155-159)
+    plist = [v for w in ws for k, v in w.items()]
+    off = 0
+    gs = g["it0_grad_samples"]
+    ws_after = g["it0_weight_samples"]
+    for i, p in enumerate(plist):
+        idx = helpers.sample_idx(p.numel())
+        got = p.grad.flatten()[idx].numpy()
+        ref = gs[off:off + len(idx)]
+        scale = max(1e-6, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got, ref, atol=2e-4 * scale + 1e-8, err_msg=f"grad of param {i}")
+        np.testing.assert_allclose(helpers.fingerprint(p.grad)[1], g["it0_grad_fp"][i][1], rtol=1e-3)
+        # RAdam step 1 (not rectified): p -= lr/(1-beta1) * m, m = (1-beta1) g
+        pn, gn = p.detach().flatten()[idx].numpy().copy(), got.copy()
+        m, v = np.zeros_like(pn), np.zeros_like(pn)
+        oradam.radam_step(pn, gn, m, v, 1, 1e-4, 1e-5)
+        np.testing.assert_allclose(pn, ws_after[off:off + len(idx)], atol=1e-7)
+        off += len(idx)
+    assert off == len(gs)
+
+
+def test_oracle_radam_vs_reference(golden_dir):
+    g = np.load(golden_dir / "radam.npz")
+    p = g["params"][0].copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    for i, gr in enumerate(g["grads"]):
+        oradam.radam_step(p, gr, m, v, i + 1, float(g["lr"]), float(g["eps"]))
+        np.testing.assert_allclose(p, g["params"][i + 1], atol=2e-7, err_msg=f"step {i + 1}")
+    assert oradam.radam_scalars(5, 1.0)[0] is False and oradam.radam_scalars(6, 1.0)[0] is True
+
+
+def test_oracle_mel_vs_reference(golden_dir):
+    g = np.load(golden_dir / "mel.npz")
+    for tag in "abc":
+        wav = g[f"{tag}_wav"]
+        mel = omel.mel_spectrogram(wav)
+        assert mel.shape == g[f"{tag}_mel"].shape               # integer frame count: bit-exact
+        assert omel.n_anim_frames(len(wav)) == int(g[f"{tag}_nframes"])
+        np.testing.assert_allclose(mel, g[f"{tag}_mel"], atol=1e-12)
+        feat = omel.preprocess_audio(wav, int(g[f"{tag}_nframes"]))
+        np.testing.assert_array_equal(np.isnan(feat), np.isnan(g[f"{tag}_feat"]))
+        np.testing.assert_allclose(feat, g[f"{tag}_feat"], atol=1e-6, equal_nan=True)
+
+
+def test_oracle_dataset_indices_vs_reference(golden_dir):
+    g = np.load(golden_dir / "dataset.npz")
+    window, n_total = int(g["window"]), int(g["n_total"])
+    starts, samples = ods.build_windows(g["ranges_train"], window)
+    np.testing.assert_array_equal(starts, g["R0"])
+    np.testing.assert_array_equal(samples, g["S"])
+    for q in g["queries"]:
+        ex_len, idx, nrows = int(q[0]), int(q[1]), int(q[2])
+        rs, re = g["ranges_train"][samples[idx]]
+        a, b = ods.example_range(int(starts[idx]), window, int(rs), int(re), ex_len, n_total)
+        rows = ods.example_rows(a, b, ex_len)
+        assert len(rows) == nrows
+        np.testing.assert_array_equal(rows, q[3:3 + nrows])
+    assert ods.split_by_ratio(10, [0.5, 0.25, 0.25]) == [tuple(x) for x in g["split_10_3"]]
+    assert ods.split_by_ratio(601, [0.3, 0.7]) == [tuple(x) for x in g["split_601"]]

@@ -1,0 +1,185 @@
+"""Drop-in network classes for the ZeroEGGS hot path, executed by the HIP library.
+
+Mirrors the public surface of the reference's `ZEGGS/modules.py` (same class
+names, constructor signatures, forward signatures and `state_dict` keys --
+SURVEY.md section 8(b)) so trained weights move both ways, but every forward /
+backward runs in hand-written gfx950 kernels through the C ABI declared in
+include/zeggs_hip.h (see `zeggs.ops`).  There is NO CPU / eager fallback: a
+forward on a module raises if the HIP library cannot be loaded.
+
+Parameter creation order and initialisers match the reference so that seeded
+construction (`torch.manual_seed(s)`; SpeechEncoder, Decoder, StyleEncoder in
+that order, reference train.py:118-139) gives bit-identical initial weights.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------
+# parameter containers (layout == reference state_dict)
+# ----------------------------------------------------------------------------
+class _RecurrentDecoderNormal(nn.Module):
+    """Parameters of reference RecurrentDecoderNormal (modules.py:165-177)."""
+
+    def __init__(self, pose_input_size, speech_size, style_size, output_size, hidden_size, num_rnn_layers):
+        super().__init__()
+        all_in = pose_input_size + speech_size + style_size
+        self.layer0 = nn.Linear(all_in, hidden_size)
+        self.layer1 = nn.GRU(all_in + hidden_size, hidden_size, num_rnn_layers, batch_first=True)
+        self.layer2 = nn.Linear(hidden_size, output_size)
+
+
+class CellStateEncoder(nn.Module):
+    """Parameters of reference CellStateEncoder (modules.py:230-236)."""
+
+    def __init__(self, input_size, hidden_size, num_rnn_layers):
+        super().__init__()
+        self.num_rnn_layers = num_rnn_layers
+        self.layer0 = nn.Linear(input_size, hidden_size)
+        self.layer1 = nn.Linear(hidden_size, hidden_size)
+        self.layer2 = nn.Linear(hidden_size, hidden_size * num_rnn_layers)
+
+
+class ConvNorm1D(nn.Module):
+    """Conv1d over [B, L, C] with Xavier-uniform weight (reference modules.py:615-641)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=None, dilation=1,
+                 bias=True, w_init_gain="linear"):
+        super().__init__()
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                              padding=padding, dilation=dilation, bias=bias)
+        nn.init.xavier_uniform_(self.conv.weight, gain=nn.init.calculate_gain(w_init_gain))
+
+
+class _MultiHeadAttention(nn.Module):
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.multi_head_attention = nn.MultiheadAttention(hidden_size, 4, 0.1)
+        self.dropout = nn.Dropout(0.1)
+        self.layer_norm = nn.LayerNorm(hidden_size)
+
+
+class _PositionWiseConvFF(nn.Module):
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.convs = nn.Sequential(
+            ConvNorm1D(hidden_size, hidden_size, kernel_size=3, padding=1, w_init_gain="relu"),
+            nn.ReLU(),
+            ConvNorm1D(hidden_size, hidden_size, kernel_size=3, padding=1, w_init_gain="linear"),
+            nn.Dropout(0.1),
+        )
+        self.layer_norm = nn.LayerNorm(hidden_size)
+
+
+class _FFTBlock(nn.Module):
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.attention = _MultiHeadAttention(hidden_size)
+        self.feed_forward = _PositionWiseConvFF(hidden_size)
+
+
+class StyleEncoderAttn(nn.Module):
+    """Parameters of reference StyleEncoderAttn (modules.py:353-389).  The
+    sinusoidal table (reference PositionalEncoding, :450-459) is evaluated
+    inside the HIP kernel, so no 20000x128 attribute is kept."""
+
+    def __init__(self, input_size, hidden_size, style_embedding_size):
+        super().__init__()
+        self.embed_dim = style_embedding_size
+        self.convs = nn.Sequential(
+            ConvNorm1D(input_size, hidden_size, kernel_size=3, padding=1, w_init_gain="relu"),
+            nn.ReLU(), nn.LayerNorm(hidden_size), nn.Dropout(0.2),
+            ConvNorm1D(hidden_size, style_embedding_size, kernel_size=3, padding=1, w_init_gain="relu"),
+            nn.ReLU(), nn.LayerNorm(style_embedding_size), nn.Dropout(0.2),
+        )
+        self.blocks = nn.ModuleList([_FFTBlock(style_embedding_size)])
+
+
+# ----------------------------------------------------------------------------
+# public modules
+# ----------------------------------------------------------------------------
+class SpeechEncoder(nn.Module):
+    """conv1d(k=1)+ELU -> conv1d(k=31, replicate)+ELU -> Linear+ELU, dropout .2
+    after the two convs in training (reference modules.py:249-272)."""
+
+    def __init__(self, input_size, hidden_size, output_size):
+        super().__init__()
+        self.layer0 = nn.Conv1d(input_size, hidden_size, kernel_size=1, padding="same", padding_mode="replicate")
+        self.drop0 = nn.Dropout(p=0.2)
+        self.layer1 = nn.Conv1d(hidden_size, output_size, kernel_size=31, padding="same", padding_mode="replicate")
+        self.drop1 = nn.Dropout(p=0.2)
+        self.layer2 = nn.Linear(output_size, output_size)
+
+    def forward(self, x):
+        p = 0.2 if self.training else 0.0
+        return ops.speech_encoder(x, self.layer0.weight, self.layer0.bias, self.layer1.weight,
+                                  self.layer1.bias, self.layer2.weight, self.layer2.bias, p)
+
+
+class StyleEncoder(nn.Module):
+    """Style encoder + VAE re-parameterisation (reference modules.py:278-304).
+    As in the reference, eval mode still samples eps; `eps` may be injected for
+    testing (otherwise drawn with torch.randn on the input's device)."""
+
+    def __init__(self, input_size, hidden_size, style_embedding_size, type="attn", use_vae=False):
+        super().__init__()
+        self.use_vae = use_vae
+        self.style_embedding_size = style_embedding_size
+        output_size = 2 * style_embedding_size if use_vae else style_embedding_size
+        if type == "attn":
+            self.encoder = StyleEncoderAttn(input_size, hidden_size, output_size)
+        else:
+            raise NotImplementedError(
+                f"style encoder type {type!r}: only 'attn' (the shipped default) has a HIP path yet")
+
+    def forward(self, input, temprature: float = 1.0, eps=None):
+        out = ops.style_encoder_attn(input, self.encoder, self.training)
+        if not self.use_vae:
+            return out, None, None
+        S = self.style_embedding_size
+        if eps is None:
+            eps = torch.randn(out.shape[0], S, device=out.device, dtype=out.dtype)
+        return ops.vae_reparam(out, eps, float(temprature), S)
+
+
+class Decoder(nn.Module):
+    """Autoregressive GRU gesture decoder (reference modules.py:11-162)."""
+
+    def __init__(self, pose_input_size, pose_output_size, speech_encoding_size, style_encoding_size,
+                 hidden_size, num_rnn_layers, rnn_cond="normal"):
+        super().__init__()
+        if rnn_cond != "normal":
+            raise NotImplementedError("rnn_cond='film' is unreachable from the reference train() "
+                                      "(train.py:124-131) and has no HIP path yet")
+        if num_rnn_layers != 2:
+            raise NotImplementedError("the reference hard-codes 2 GRU layers (train.py:130)")
+        self.recurrent_decoder = _RecurrentDecoderNormal(
+            pose_input_size, speech_encoding_size, style_encoding_size, pose_output_size,
+            hidden_size, num_rnn_layers)
+        self.cell_state_encoder = CellStateEncoder(pose_input_size + style_encoding_size,
+                                                   hidden_size, num_rnn_layers)
+        self.dims = (pose_input_size, pose_output_size, speech_encoding_size, style_encoding_size, hidden_size)
+
+    def forward(self, Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos, Z_ltxy, Z_lvel, Z_lvrt,
+                Z_gaze_pos, speech_encoding, style_encoding, parents, anim_input_mean, anim_input_std,
+                anim_output_mean, anim_output_std, dt: float):
+        return ops.decoder_rollout(self, Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos, Z_ltxy,
+                                   Z_lvel, Z_lvrt, Z_gaze_pos, speech_encoding, style_encoding,
+                                   anim_input_mean, anim_input_std, anim_output_mean, anim_output_std,
+                                   float(dt))
+
+
+# ----------------------------------------------------------------------------
+# free functions of the reference module namespace
+# ----------------------------------------------------------------------------
+def generalized_logistic_function(x, center=0.0, B=1.0, A=0.0, K=1.0, C=1.0, Q=1.0, nu=1.0):
+    return A + (K - A) / (C + Q * math.exp(-B * (x - center))) ** (1 / nu)
+
+
+def kl_div_weight(iteration):
+    """KL annealing weight of reference compute_KL_div (modules.py:773-788)."""
+    return min(generalized_logistic_function(iteration, center=7500, B=0.005), 2e-1)
