@@ -1,0 +1,171 @@
+/* C ABI of libzeggs_hip.so -- the MI355X (gfx950) engine for the ZeroEGGS hot path.
+ *
+ * The reference (ubisoft/ubisoft-laforge-ZeroEGGS) has no FFI: its seam is the Python
+ * nn.Module level.  Each entry point below replaces the ATen op sequence of one reference
+ * interface (file:line relative to the reference repo) and is what a binding for that
+ * interface would call (ctypes stub: INTEGRATION.md; shipped binding: zeggs/ops.py).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all tensors contiguous row-major fp32 DEVICE
+ *     memory unless stated; quaternions (w,x,y,z); int64 indices where stated.
+ *   - the caller owns all memory.  The library never allocates, frees or synchronises the
+ *     device; it only enqueues kernels on `stream` (a hipStream_t passed as void*), so every
+ *     call is hipGraph-capturable.
+ *   - scratch + activations saved for backward live in a caller-provided workspace whose
+ *     size is returned by the matching *_workspace_bytes(); fwd and bwd of one module must be
+ *     given the SAME workspace (bwd reads what fwd saved).
+ *   - return 0 on success, -1 on error; zeggs_last_error() returns a thread-local message.
+ *   - gradient outputs are OVERWRITTEN (not accumulated).
+ */
+#ifndef ZEGGS_HIP_H
+#define ZEGGS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int zeggs_version(void);
+const char* zeggs_last_error(void);
+
+/* ---------------------------------------------------------------- generic GEMM (tests / tools)
+ * C(m,n) = act(alpha * sum_k A(m,k) B(k,n) + beta * C(m,n) + bias[n]), element strides, batched. */
+int zeggs_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+               long sam, long sak, long sbk, long sbn, long scm, long scn, int nbatch, long bsA,
+               long bsB, long bsC, float alpha, float beta, int act, void* stream);
+
+/* ---------------------------------------------------------------- SpeechEncoder
+ * replaces SpeechEncoder.forward, ZEGGS/modules.py:265-272 (+ autograd backward).
+ * x [B,T,F] normalised audio features -> out [B,T,O]. dropout_p = 0.2 in training, 0 in eval. */
+typedef struct {
+  int B, T, F, H, O, KW;
+  float dropout_p;
+  uint64_t seed;
+} ZeggsSpeechDims;
+typedef struct {
+  const float *w0, *b0; /* layer0 Conv1d(F->H,k=1): [H,F,1],[H] */
+  const float *w1, *b1; /* layer1 Conv1d(H->O,k=KW,replicate): [O,H,KW],[O] */
+  const float *w2, *b2; /* layer2 Linear(O->O) */
+} ZeggsSpeechParams;
+typedef struct {
+  float *w0, *b0, *w1, *b1, *w2, *b2;
+} ZeggsSpeechGrads;
+size_t zeggs_speech_encoder_workspace_bytes(const ZeggsSpeechDims*);
+int zeggs_speech_encoder_fwd(const ZeggsSpeechDims*, const ZeggsSpeechParams*, const float* x, float* out,
+                             void* ws, size_t ws_bytes, void* stream);
+int zeggs_speech_encoder_bwd(const ZeggsSpeechDims*, const ZeggsSpeechParams*, const float* x,
+                             const float* out, const float* dout, const ZeggsSpeechGrads*, void* ws,
+                             size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- StyleEncoderAttn trunk
+ * replaces StyleEncoderAttn.forward, ZEGGS/modules.py:391-420 (convs :359-384, FFTBlock :484-612).
+ * x [B,L,C] normalised exemplar features, pos [>=L,E] sinusoidal table -> out [B,E] (E = 2*S with VAE). */
+typedef struct {
+  int B, L, C, H, E, NH;
+  int dropout; /* 1: training-mode dropout (.2/.2/.1/.1/.1), 0: eval */
+  uint64_t seed;
+} ZeggsStyleDims;
+typedef struct {
+  const float *c0_w, *c0_b;   /* encoder.convs.0.conv  [H,C,3] */
+  const float *ln0_g, *ln0_b; /* encoder.convs.2       [H] */
+  const float *c4_w, *c4_b;   /* encoder.convs.4.conv  [E,H,3] */
+  const float *ln1_g, *ln1_b; /* encoder.convs.6       [E] */
+  const float *in_w, *in_b;   /* attention in_proj     [3E,E] */
+  const float *out_w, *out_b; /* attention out_proj    [E,E] */
+  const float *lna_g, *lna_b; /* attention.layer_norm */
+  const float *ff0_w, *ff0_b; /* feed_forward.convs.0.conv [E,E,3] */
+  const float *ff2_w, *ff2_b; /* feed_forward.convs.2.conv [E,E,3] */
+  const float *lnf_g, *lnf_b; /* feed_forward.layer_norm */
+} ZeggsStyleParams;
+typedef struct {
+  float *c0_w, *c0_b, *ln0_g, *ln0_b, *c4_w, *c4_b, *ln1_g, *ln1_b, *in_w, *in_b, *out_w, *out_b, *lna_g,
+      *lna_b, *ff0_w, *ff0_b, *ff2_w, *ff2_b, *lnf_g, *lnf_b;
+} ZeggsStyleGrads;
+size_t zeggs_style_encoder_workspace_bytes(const ZeggsStyleDims*);
+int zeggs_style_encoder_fwd(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* x, const float* pos,
+                            float* out, void* ws, size_t ws_bytes, void* stream);
+int zeggs_style_encoder_bwd(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* dout,
+                            const ZeggsStyleGrads*, void* ws, size_t ws_bytes, void* stream);
+/* VAE re-parameterisation, StyleEncoder.forward ZEGGS/modules.py:291-302:
+ * enc [B,2S] -> z = mu + eps*exp(.5 logvar)/temperature ; bwd gives denc from dz, dmu, dlogvar */
+int zeggs_vae_reparam_fwd(const float* enc, const float* eps, float* z, int B, int S, float temperature,
+                          void* stream);
+int zeggs_vae_reparam_bwd(const float* enc, const float* eps, const float* dz, const float* dmu,
+                          const float* dlogvar, float* denc, int B, int S, float temperature, void* stream);
+
+/* ---------------------------------------------------------------- Decoder
+ * replaces Decoder.forward, ZEGGS/modules.py:47-162 (CellStateEncoder :230-243, RecurrentDecoderNormal
+ * :165-185, vectorize_input :677-713, devectorize_output :716-742) and its autograd backward (BPTT).
+ * Pose rows are the reference's output vector layout [root_vel3, root_vrt3, lpos 3J, ltxy 6J, lvel 3J,
+ * lvrt 3J] (PO = 6+15J), de-normalised.  Frame 0 of every output is the given first pose. */
+typedef struct {
+  int B, T, PI, PO, SP, ST, H;
+  float dt;
+} ZeggsDecDims;
+typedef struct {
+  const float *l0_w, *l0_b;                     /* recurrent_decoder.layer0 [H, PI+SP+ST] */
+  const float *w_ih0, *w_hh0, *b_ih0, *b_hh0;   /* layer1 GRU l0: [3H, H+PI+SP+ST], [3H,H] (gates r,z,n) */
+  const float *w_ih1, *w_hh1, *b_ih1, *b_hh1;   /* layer1 GRU l1: [3H,H],[3H,H] */
+  const float *l2_w, *l2_b;                     /* layer2 [PO,H] */
+  const float *c0_w, *c0_b, *c1_w, *c1_b, *c2_w, *c2_b; /* cell_state_encoder [H,PI+ST],[H,H],[2H,H] */
+} ZeggsDecParams;
+typedef struct {
+  float *l0_w, *l0_b, *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1, *l2_w, *l2_b, *c0_w,
+      *c0_b, *c1_w, *c1_b, *c2_w, *c2_b;
+} ZeggsDecGrads;
+typedef struct {
+  const float *in_mean, *in_std;   /* [PI] */
+  const float *out_mean, *out_std; /* [PO] */
+} ZeggsDecStats;
+size_t zeggs_decoder_workspace_bytes(const ZeggsDecDims*, int training);
+/* pose0 [B,PO], rpos0 [B,3], rrot0 [B,4], gaze [B,T,3], speech [B,T,SP], style [B,T,ST]
+ * -> pose [B,T,PO], rpos [B,T,3], rrot [B,T,4].  training=1 saves activations for bwd. */
+int zeggs_decoder_fwd(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDecStats*, const float* pose0,
+                      const float* rpos0, const float* rrot0, const float* gaze, const float* speech,
+                      const float* style, float* pose, float* rpos, float* rrot, int training, void* ws,
+                      size_t ws_bytes, void* stream);
+/* dpose [B,T,PO], drpos [B,T,3], drrot [B,T,4] (frame 0 ignored) -> parameter grads, dspeech [B,T,SP],
+ * dstyle [B,T,ST] */
+int zeggs_decoder_bwd(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDecStats*, const float* gaze,
+                      const float* pose, const float* rpos, const float* rrot, const float* dpose,
+                      const float* drpos, const float* drrot, const ZeggsDecGrads*, float* dspeech,
+                      float* dstyle, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- training loss
+ * replaces the inline loss of ZEGGS/train.py:276-421 (xform_orthogonalize_from_xy, xform_fk_vel of
+ * ZEGGS/anim/txform.py:10-34, 17 weighted L1 terms + KL, sum/18) and its backward.
+ * O = prediction (pose/rpos/rrot as produced by zeggs_decoder_fwd), W = ground truth in the same layout.
+ * terms[18] (weighted, as logged by the reference), loss = sum(terms)/18 in terms[18].
+ * kl_weight <= 0 or mu == NULL disables the KL term.  Gradients are scaled by `gscale` (1/world_size). */
+typedef struct {
+  int B, T, J, S;
+  float dt;
+} ZeggsLossDims;
+size_t zeggs_loss_workspace_bytes(const ZeggsLossDims*);
+int zeggs_loss_fwd_bwd(const ZeggsLossDims*, const int* parents, const float* o_pose, const float* o_rpos,
+                       const float* o_rrot, const float* w_pose, const float* w_rpos, const float* w_rrot,
+                       const float* gaze, const float* mu, const float* logvar, float kl_weight, float* terms,
+                       float* dpose, float* drpos, float* drrot, float* dmu, float* dlogvar, float gscale,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- RAdam
+ * replaces RAdam.step, ZEGGS/optimizers.py:31-99, fused over one flat fp32 buffer.
+ * rectified != 0: p -= step_scale * m / (sqrt(v) + eps), else p -= step_scale * m (host scalars of
+ * optimizers.py:64-84 computed by the caller). */
+int zeggs_radam_step(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
+                     float step_scale, int rectified, void* stream);
+
+/* ---------------------------------------------------------------- batch gather
+ * replaces SGDataset.__getitem__/get_example + default collate, ZEGGS/dataset.py:110-204, reading
+ * HBM-resident dataset arrays.  frames[f] rows of width `width`; window starts int64 [B]. */
+int zeggs_gather_windows(const float* frames, int width, const int64_t* starts, int B, int T, float* out,
+                         void* stream);
+/* style example rows: src_rows int64 [B, L] (precomputed by the host rule of dataset.py:180-203) */
+int zeggs_gather_rows(const float* frames, int width, const int64_t* rows, long nrows, float* out, int out_ld,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

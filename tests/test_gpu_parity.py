@@ -1,0 +1,292 @@
+"""GPU parity tests: the HIP engine (through the C ABI) vs the CPU oracle and the
+golden vectors produced by the reference.  Tolerances: forward outputs 1e-4 absolute
+(north_star), gradients 2e-4 of the tensor's max |grad| (fp32 vs fp64 oracle)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import loss as oloss
+from oracle import nets as onets
+from oracle import radam as oradam
+from zeggs import ops, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def g(t):
+    return t.to(DEV)
+
+
+def relerr(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / max(1e-12, float(ref.abs().max())))
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(32, 3072, 2286), (2, 1131, 1024), (200, 70, 33), (513, 129, 1262), (64, 64, 16),
+                                   (1, 5, 3)])
+def test_gemm_layouts(M, N, K):
+    torch.manual_seed(0)
+    A, B = torch.randn(M, K), torch.randn(K, N)
+    bias = torch.randn(N)
+    ref = A.double() @ B.double()
+    # NN
+    C = torch.zeros(M, N, device=DEV)
+    ops.gemm(g(A), g(B), C, M, N, K, (K, 1), (N, 1), (N, 1))
+    assert relerr(C, ref) < 2e-6
+    # NT (+bias, ELU)
+    Bt = B.t().contiguous()
+    ops.gemm(g(A), g(Bt), C, M, N, K, (K, 1), (1, K), (N, 1), bias=g(bias), act=1)
+    assert relerr(C, torch.nn.functional.elu(ref + bias.double())) < 2e-6
+    # TN with beta
+    At = A.t().contiguous()
+    C0 = torch.randn(M, N)
+    C = g(C0.clone())
+    ops.gemm(g(At), g(B), C, M, N, K, (1, M), (N, 1), (N, 1), beta=0.5, alpha=2.0)
+    assert relerr(C, 2.0 * ref + 0.5 * C0.double()) < 2e-6
+
+
+def test_gemm_batched_and_overlapping_rows():
+    torch.manual_seed(1)
+    nb, T, Cc, Co, kw = 3, 37, 10, 7, 5
+    xp = torch.randn(nb, T + kw - 1, Cc)
+    Wf = torch.randn(kw * Cc, Co)
+    out = torch.zeros(nb, T, Co, device=DEV)
+    # conv as GEMM: rows overlap (sam = C), K = kw*C
+    ops.gemm(g(xp), g(Wf), out, T, Co, kw * Cc, (Cc, 1), (Co, 1), (Co, 1), nbatch=nb,
+             bs=((T + kw - 1) * Cc, 0, T * Co))
+    w = Wf.reshape(kw, Cc, Co).permute(2, 1, 0).contiguous()            # [Co, C, kw]
+    ref = torch.nn.functional.conv1d(xp.transpose(1, 2).double(), w.double()).transpose(1, 2)
+    assert relerr(out, ref) < 2e-6
+
+
+# ----------------------------------------------------------------------------- encoders
+def _golden_nets(golden_dir):
+    gd = np.load(golden_dir / "nets.npz")
+    return gd, helpers.build_nets(), helpers.stats_tensors()
+
+
+def test_speech_encoder_forward_backward(golden_dir):
+    gd, (se, _, _), s = _golden_nets(golden_dir)
+    x = (torch.as_tensor(gd["in_X_audio_features"]) - s["a_mean"]) / s["a_std"]
+    se_g = se.to(DEV).eval()
+    out = se_g(g(x))
+    assert float((out.cpu() - torch.as_tensor(gd["speech"])).abs().max()) < 1e-4       # vs the reference
+    # gradients vs fp64 oracle autograd, longer sequence (exercises the replicate edges)
+    torch.manual_seed(5)
+    x = torch.randn(3, 70, synth.N_AUDIO)
+    wgt = torch.randn(3, 70, 64)
+    w64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in se_g.state_dict().items()}
+    (onets.speech_encoder(w64, x.double()) * wgt.double()).sum().backward()
+    se_g.zero_grad()
+    out = se_g(g(x))
+    assert relerr(out, onets.speech_encoder({k: v.detach() for k, v in w64.items()}, x.double())) < 1e-5
+    (out * g(wgt)).sum().backward()
+    for k, p in se_g.named_parameters():
+        assert relerr(p.grad, w64[k].grad) < 2e-4, k
+
+
+def test_speech_encoder_dropout_training_mode():
+    se, _, _ = helpers.build_nets()
+    se = se.to(DEV).train()
+    x = torch.randn(2, 40, synth.N_AUDIO, device=DEV)
+    a = se(x)
+    b = se(x)
+    assert torch.isfinite(a).all() and not torch.allclose(a, b)      # masks differ call to call
+    a.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in se.parameters())
+
+
+def test_style_encoder_forward_backward(golden_dir):
+    gd, (_, _, st), s = _golden_nets(golden_dir)
+    ex = (torch.as_tensor(gd["in_example"]) - s["in_mean"]) / s["in_std"]
+    st_g = st.to(DEV).eval()
+    z, mu, logvar = st_g(g(ex), float(gd["temperature"]), eps=g(torch.as_tensor(gd["in_eps"])))
+    for got, key in ((z, "style_z"), (mu, "style_mu"), (logvar, "style_logvar")):
+        assert float((got.cpu() - torch.as_tensor(gd[key])).abs().max()) < 1e-4, key     # vs the reference
+    # gradients vs fp64 oracle
+    torch.manual_seed(6)
+    B, L = 3, 21
+    x = torch.randn(B, L, synth.POSE_IN)
+    eps = torch.randn(B, 64)
+    wz, wm, wl = torch.randn(B, 64), torch.randn(B, 64), torch.randn(B, 64)
+    w64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in st_g.state_dict().items()}
+    z, mu, lv = onets.style_encoder(w64, x.double(), eps.double(), 0.9)
+    (z * wz.double() + mu * wm.double() + lv * wl.double()).sum().backward()
+    st_g.zero_grad()
+    zg, mug, lvg = st_g(g(x), 0.9, eps=g(eps))
+    assert relerr(zg, z) < 2e-5 and relerr(mug, mu) < 2e-5 and relerr(lvg, lv) < 2e-5
+    (zg * g(wz) + mug * g(wm) + lvg * g(wl)).sum().backward()
+    for k, p in st_g.named_parameters():
+        assert relerr(p.grad, w64[k].grad) < 3e-4, k
+
+
+def test_style_encoder_dropout_training_mode():
+    _, _, st = helpers.build_nets()
+    st = st.to(DEV).train()
+    x = torch.randn(2, 16, synth.POSE_IN, device=DEV)
+    z, mu, lv = st(x)
+    (z.sum() + mu.sum() + lv.sum()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in st.parameters())
+
+
+# ----------------------------------------------------------------------------- decoder
+def _first_pose(gd, idx=0):
+    t = lambda k: torch.as_tensor(gd[k])  # noqa: E731
+    return [t("in_Y_root_pos")[:, idx], t("in_Y_root_rot")[:, idx], t("in_Y_root_vel")[:, idx],
+            t("in_Y_root_vrt")[:, idx], t("in_Y_lpos")[:, idx], t("in_Y_ltxy")[:, idx], t("in_Y_lvel")[:, idx],
+            t("in_Y_lvrt")[:, idx]]
+
+
+NAMES = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
+
+
+def test_decoder_forward_vs_reference(golden_dir):
+    gd, (_, de, _), s = _golden_nets(golden_dir)
+    de_g = de.to(DEV).eval()
+    T = gd["speech"].shape[1]
+    style = torch.as_tensor(gd["style_z"]).unsqueeze(1).repeat(1, T, 1)
+    with torch.no_grad():
+        out = de_g(*[g(t) for t in _first_pose(gd)], g(torch.as_tensor(gd["in_Y_gaze_pos"])),
+                   g(torch.as_tensor(gd["speech"])), g(style), None, g(s["in_mean"]), g(s["in_std"]), g(s["out_mean"]),
+                   g(s["out_std"]), synth.DT)
+    for n, o in zip(NAMES, out):
+        err = float((o.cpu() - torch.as_tensor(gd["O_" + n])).abs().max())
+        assert err < 1e-4, f"{n}: {err}"
+
+
+def test_decoder_backward_vs_oracle(golden_dir):
+    gd, (_, de, _), s = _golden_nets(golden_dir)
+    de_g = de.to(DEV).train()
+    torch.manual_seed(7)
+    B, T = 2, 6
+    speech = torch.randn(B, T, 64) * 0.5
+    style = torch.randn(B, T, 64) * 0.5
+    gaze = torch.as_tensor(gd["in_Y_gaze_pos"])
+    fp = _first_pose(gd)
+    wts = [torch.randn(B, T, *o.shape[1:]) for o in fp]
+    s64 = {k: v.double() for k, v in s.items()}
+    w64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in de_g.state_dict().items()}
+    sp64, sy64 = speech.double().requires_grad_(True), style.double().requires_grad_(True)
+    O = onets.decoder_rollout(w64, *[t.double() for t in fp], gaze.double(), sp64, sy64, s64["in_mean"], s64["in_std"],
+                              s64["out_mean"], s64["out_std"], synth.DT)
+    sum((o * w.double()).sum() for o, w in zip(O, wts)).backward()
+    de_g.zero_grad()
+    spg, syg = g(speech).requires_grad_(True), g(style).requires_grad_(True)
+    out = de_g(*[g(t) for t in fp], g(gaze), spg, syg, None, g(s["in_mean"]), g(s["in_std"]), g(s["out_mean"]),
+               g(s["out_std"]), synth.DT)
+    for n, o, r in zip(NAMES, out, O):
+        assert float((o.detach().cpu().double() - r.detach()).abs().max()) < 1e-4, n
+    sum((o * g(w)).sum() for o, w in zip(out, wts)).backward()
+    assert relerr(spg.grad, sp64.grad) < 3e-4
+    assert relerr(syg.grad, sy64.grad) < 3e-4
+    for k, p in de_g.named_parameters():
+        assert relerr(p.grad, w64[k].grad) < 3e-4, k
+
+
+# ----------------------------------------------------------------------------- loss
+def _pack_pose(vel, vrt, lpos, ltxy, lvel, lvrt):
+    B, T = vel.shape[:2]
+    return torch.cat([vel, vrt, lpos.reshape(B, T, -1), ltxy.reshape(B, T, -1), lvel.reshape(B, T, -1),
+                      lvrt.reshape(B, T, -1)], dim=-1)
+
+
+def test_loss_forward_backward_vs_oracle():
+    stats = synth.make_stats()
+    B, T = 3, 7
+    rng = np.random.default_rng(4)
+    Wc = [synth.make_clip(T, seed=90 + b, stats=stats) for b in range(B)]
+    Oc = [synth.make_clip(T, seed=190 + b, stats=stats) for b in range(B)]
+    tt = lambda cl, k: torch.as_tensor(np.stack([c[k] for c in cl]))  # noqa: E731
+    keys = ("Y_root_pos", "Y_root_rot", "Y_root_vel", "Y_root_vrt", "Y_lpos", "Y_ltxy", "Y_lvel", "Y_lvrt")
+    W = [tt(Wc, k) for k in keys]
+    O = [tt(Oc, k) for k in keys]
+    # make the prediction a perturbation of the ground truth (and a non-unit root quaternion, as the decoder produces)
+    O = [w + 0.3 * (o - w) for o, w in zip(O, W)]
+    gaze = tt(Wc, "Y_gaze_pos")
+    mu, lv = torch.as_tensor(rng.standard_normal((B, 64)), dtype=torch.float32), \
+        torch.as_tensor(0.3 * rng.standard_normal((B, 64)), dtype=torch.float32)
+    it = 9000
+    O64 = [o.double().requires_grad_(True) for o in O]
+    mu64, lv64 = mu.double().requires_grad_(True), lv.double().requires_grad_(True)
+    loss64, terms64 = oloss.training_loss(O64, [w.double() for w in W], gaze.double(), synth.PARENTS, synth.DT, mu64,
+                                          lv64, iteration=it)
+    loss64.backward()
+    op = g(_pack_pose(*O[2:])).requires_grad_(True)
+    orp, orr = g(O[0]).requires_grad_(True), g(O[1]).requires_grad_(True)
+    mug, lvg = g(mu).requires_grad_(True), g(lv).requires_grad_(True)
+    parents = torch.as_tensor(synth.PARENTS, dtype=torch.int32, device=DEV)
+    loss, terms = ops.training_loss(op, orp, orr, g(_pack_pose(*W[2:])), g(W[0]), g(W[1]), g(gaze), parents, synth.DT,
+                                    mug, lvg, kl_weight=oloss.kl_weight(it))
+    np.testing.assert_allclose(terms[:18].cpu().numpy(), terms64.numpy(), rtol=3e-5, atol=1e-7)
+    assert abs(float(loss) - float(loss64)) < 3e-5 * abs(float(loss64))
+    loss.backward()
+    ref_pose = _pack_pose(*[o.grad for o in O64[2:]])
+    assert relerr(op.grad, ref_pose) < 3e-4
+    assert relerr(orp.grad, O64[0].grad) < 3e-4
+    assert relerr(orr.grad, O64[1].grad) < 3e-4
+    assert relerr(mug.grad, mu64.grad) < 1e-5 and relerr(lvg.grad, lv64.grad) < 1e-5
+
+
+# ----------------------------------------------------------------------------- RAdam + full iteration
+def test_radam_vs_reference(golden_dir):
+    gd = np.load(golden_dir / "radam.npz")
+    p = g(torch.as_tensor(gd["params"][0].copy()))
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for i, gr in enumerate(gd["grads"]):
+        rect, scale = oradam.radam_scalars(i + 1, float(gd["lr"]))
+        ops.radam_step(p, g(torch.as_tensor(gr)), m, v, 0.9, 0.999, float(gd["eps"]), scale, rect)
+        np.testing.assert_allclose(p.cpu().numpy(), gd["params"][i + 1], atol=2e-7)
+
+
+def test_train_iteration_vs_reference(golden_dir):
+    """Full iteration 0 of the reference train(): loss, 18 terms, gradient samples of all 44 tensors and the
+    weights after the RAdam step -- HIP engine vs golden vectors recorded from the reference."""
+    gd = np.load(golden_dir / "train_iter.npz")
+    se, de, st = [m.to(DEV).train() for m in helpers.build_nets()]
+    for m in (se, st):     # dropout was patched to identity when the golden vectors were recorded
+        m.eval()
+    s = {k: g(v) for k, v in helpers.stats_tensors().items()}
+    b = [g(torch.as_tensor(gd[f"it0_batch{j}"])) for j in range(11)]
+    audio, rpos, rrot, rvel, rvrt, lpos, ltxy, lvel, lvrt, gaze, wstyle = b
+    T = audio.shape[1]
+    speech = se((audio - s["a_mean"]) / s["a_std"])
+    z, mu, logvar = st((wstyle - s["in_mean"]) / s["in_std"], eps=g(torch.as_tensor(gd["it0_eps"])))
+    pose0 = _pack_pose(rvel, rvrt, lpos, ltxy, lvel, lvrt)
+    pose, orp, orr = ops.decoder_core(de, pose0[:, 0], rpos[:, 0], rrot[:, 0], gaze, speech,
+                                      z.unsqueeze(1).repeat(1, T, 1), s["in_mean"], s["in_std"], s["out_mean"],
+                                      s["out_std"], synth.DT)
+    parents = torch.as_tensor(synth.PARENTS, dtype=torch.int32, device=DEV)
+    loss, terms = ops.training_loss(pose, orp, orr, pose0, rpos, rrot, gaze, parents, synth.DT, mu, logvar,
+                                    kl_weight=oloss.kl_weight(0))
+    np.testing.assert_allclose(float(loss), gd["loss"][0], rtol=1e-5)
+    np.testing.assert_allclose(terms[:18].cpu().numpy(), gd["terms"][0], rtol=1e-4, atol=1e-6)
+    loss.backward()
+    plist = [p for m in (se, de, st) for p in m.parameters()]
+    off = 0
+    for i, p in enumerate(plist):
+        idx = helpers.sample_idx(p.numel())
+        got = p.grad.flatten()[torch.as_tensor(idx, device=DEV)].cpu().numpy()
+        ref = gd["it0_grad_samples"][off:off + len(idx)]
+        scale = max(1e-6, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() < 5e-4 * scale + 1e-8, f"param {i}"
+        pw = p.detach().flatten()[torch.as_tensor(idx, device=DEV)].clone()
+        gw = p.grad.flatten()[torch.as_tensor(idx, device=DEV)].clone()
+        pad = (-len(idx)) % 4
+        m, v = torch.zeros_like(pw), torch.zeros_like(pw)
+        rect, sc = oradam.radam_scalars(1, 1e-4)
+        ops.radam_step(pw, gw, m, v, 0.9, 0.999, 1e-5, sc, rect)
+        np.testing.assert_allclose(pw.cpu().numpy(), gd["it0_weight_samples"][off:off + len(idx)], atol=2e-7)
+        off += len(idx)
+
+
+def test_gather_windows_and_rows():
+    frames = torch.arange(50 * 7, dtype=torch.float32, device=DEV).reshape(50, 7)
+    starts = torch.tensor([0, 13, 42], device=DEV)
+    out = ops.gather_windows(frames, starts, 8)
+    ref = torch.stack([frames[s:s + 8] for s in (0, 13, 42)])
+    assert torch.equal(out, ref)                                          # indices bit-exact
+    rows = torch.tensor([[3, 4, 4, 49], [0, 0, 1, 2]], device=DEV)
+    assert torch.equal(ops.gather_rows(frames, rows), frames[rows])

@@ -1,0 +1,134 @@
+// Common device/host helpers for the ZeroEGGS gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+// ---------------------------------------------------------------- error state
+// last-error string (thread-local); every extern "C" entry returns 0 or -1.
+extern "C" const char* zeggs_last_error();
+void zeggs_set_error(const char* fmt, ...);
+
+#define ZCHECK(cond, ...)                        \
+  do {                                           \
+    if (!(cond)) {                               \
+      zeggs_set_error(__VA_ARGS__);              \
+      return -1;                                 \
+    }                                            \
+  } while (0)
+
+#define ZLAUNCH_CHECK(name)                                                        \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      zeggs_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return -1;                                                                   \
+    }                                                                              \
+  } while (0)
+
+#define ZTRY(call)                 \
+  do {                             \
+    int r__ = (call);              \
+    if (r__ != 0) return r__;      \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// bump allocator over a caller-provided workspace (no hipMalloc in the library)
+struct Arena {
+  char* base;
+  size_t off, cap;
+  bool dry;  // dry = size query only
+  Arena(void* p, size_t bytes) : base((char*)p), off(0), cap(bytes), dry(p == nullptr) {}
+  float* f(size_t n) { return (float*)raw(n * sizeof(float)); }
+  void* raw(size_t bytes) {
+    size_t o = align_up(off, 256);
+    off = o + bytes;
+    return dry ? nullptr : (void*)(base + o);
+  }
+  bool ok() const { return dry || off <= cap; }
+};
+
+// ---------------------------------------------------------------- device math
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+// 4-byte aligned vector types: rows of PyTorch-shaped weights (K = 1262, 81, ...)
+// are not 16-byte aligned; the compiler picks a legal access for the alignment.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ float d_elu(float x) { return x > 0.f ? x : expm1f(x); }
+// derivative of ELU expressed with the OUTPUT y: y>0 -> 1, else y+1 (= e^x)
+__device__ __forceinline__ float d_elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
+__device__ __forceinline__ float d_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_RELU = 2 };
+__device__ __forceinline__ float d_act(float x, int act) {
+  if (act == ACT_ELU) return d_elu(x);
+  if (act == ACT_RELU) return x > 0.f ? x : 0.f;
+  return x;
+}
+
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+struct Q4 {
+  float w, x, y, z;
+};
+// reference anim/tquat.py:18-20: t = 2 (q_v x v); v + w t + q_v x t
+__device__ __forceinline__ V3 quat_mul_vec(Q4 q, V3 v) {
+  V3 qv = v3(q.x, q.y, q.z);
+  V3 t = 2.0f * cross(qv, v);
+  return v + q.w * t + cross(qv, t);
+}
+__device__ __forceinline__ Q4 quat_inv(Q4 q) { return Q4{q.w, -q.x, -q.y, -q.z}; }
+// reference anim/tquat.py:6-15
+__device__ __forceinline__ Q4 quat_mul(Q4 x, Q4 y) {
+  return Q4{y.w * x.w - y.x * x.x - y.y * x.y - y.z * x.z,
+            y.w * x.x + y.x * x.w - y.y * x.z + y.z * x.y,
+            y.w * x.y + y.x * x.z + y.y * x.w - y.z * x.x,
+            y.w * x.z - y.x * x.y + y.y * x.x + y.z * x.w};
+}
+
+// counter-based RNG for dropout masks: same (seed, index) -> same bit in fwd and bwd
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+// keep-scale for element idx: 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
+  if (p <= 0.f) return 1.f;
+  float u = (float)(hash_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : 1.f / (1.f - p);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum; all threads get the result. blockDim.x multiple of 64, <= 1024.
+__device__ __forceinline__ float block_sum(float v, float* red /* >=16 floats LDS */) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}

@@ -1,0 +1,496 @@
+// Autoregressive gesture decoder: cell-state encoder + T-1 sequential steps of
+//   vectorize_input -> Linear+ELU -> 2-layer GRU (seq len 1) -> Linear -> devectorize_output
+// (reference ZEGGS/modules.py:47-243, 677-742) and the matching BPTT.
+//
+// Data layout (all time-major so that one step's rows are contiguous and the
+// weight-gradient GEMMs contract over the flattened (t, b) axis):
+//   Gin [T][B][GL]   GL = round4(H + XD): per step [hid(H) | x(XD)], x = [pose(PI) | speech | style]
+//   H0/H1 [T][B][H]  hidden states, slot 0 = CellStateEncoder output
+//   R*,Z*,N*,NH*     [T][B][H] saved gates (NH = W_hn h + b_hn) for both layers
+//   D*               [T][B][.] gate/pre-activation gradients produced by the backward sweep
+#include "../../include/zeggs_hip.h"
+#include "common.h"
+#include "gemm.h"
+#include "kernels.h"
+
+namespace {
+
+struct DecWs {
+  float *Gin, *H0, *H1, *R0, *Z0, *N0, *NH0, *R1, *Z1, *N1, *NH1, *Y;
+  float *cse_in, *cse_a, *cse_b;          // cell-state encoder activations
+  float *gi, *gh;                          // per-step gate pre-activations [B,3H]
+  // backward
+  float *DY, *DI0, *DH0, *DI1, *DH1, *D0, *DX;
+  float *dH0c, *dH1c, *dGin, *dXn, *carry, *t0, *t1;
+  int GL, XD, POL;
+};
+
+inline int round4(int x) { return (x + 3) / 4 * 4; }
+
+DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
+  DecWs w;
+  memset(&w, 0, sizeof(w));
+  const long B = d.B, T = d.T, H = d.H;
+  w.XD = d.PI + d.SP + d.ST;
+  w.GL = round4(d.H + w.XD);
+  w.POL = round4(d.PO);
+  const long TS = training ? T : 2;   // inference keeps a 2-slot ring for the step buffers
+  w.Gin = a.f(TS * B * w.GL);
+  w.H0 = a.f(TS * B * H); w.H1 = a.f(TS * B * H);
+  w.Y = a.f(B * (long)w.POL);
+  w.cse_in = a.f(B * (long)(d.PI + d.ST));
+  w.cse_a = a.f(B * H); w.cse_b = a.f(B * H);
+  w.gi = a.f(B * 3 * H); w.gh = a.f(B * 3 * H);
+  if (training) {
+    w.R0 = a.f(T * B * H); w.Z0 = a.f(T * B * H); w.N0 = a.f(T * B * H); w.NH0 = a.f(T * B * H);
+    w.R1 = a.f(T * B * H); w.Z1 = a.f(T * B * H); w.N1 = a.f(T * B * H); w.NH1 = a.f(T * B * H);
+    w.DY = a.f(T * B * (long)w.POL);
+    w.DI0 = a.f(T * B * 3 * H); w.DH0 = a.f(T * B * 3 * H);
+    w.DI1 = a.f(T * B * 3 * H); w.DH1 = a.f(T * B * 3 * H);
+    w.D0 = a.f(T * B * H);
+    w.DX = a.f(T * B * (long)w.XD);
+    w.dH0c = a.f(B * H); w.dH1c = a.f(B * H);
+    w.dGin = a.f(B * (long)w.GL);
+    w.dXn = a.f(B * (long)w.XD);
+    w.carry = a.f(B * 8);
+    w.t0 = a.f(B * 2 * H); w.t1 = a.f(B * (long)(d.PI + d.ST + 2 * H));
+  }
+  return w;
+}
+
+// ------------------------------------------------------------------ device helpers
+// reference anim/tquat.py:94-107: quat_from_helical(x) = quat_exp(x/2)
+__device__ __forceinline__ Q4 quat_exp(V3 x) {
+  float h = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z);
+  if (h < 1e-5f) {
+    float n = sqrtf(1.f + h * h) + 1e-5f;
+    return Q4{1.f / n, x.x / n, x.y / n, x.z / n};
+  }
+  float s = sinf(h) / h;
+  return Q4{cosf(h), x.x * s, x.y * s, x.z * s};
+}
+
+// backward of out = quat_mul_vec(q, v) given upstream g
+__device__ __forceinline__ void qmv_bwd(Q4 q, V3 v, V3 g, Q4& dq, V3& dv) {
+  V3 qv = v3(q.x, q.y, q.z);
+  V3 t = 2.0f * cross(qv, v);
+  float dw = dot(g, t);
+  V3 dt = q.w * g + cross(g, qv);
+  V3 dqv = cross(t, g) + 2.0f * cross(v, dt);
+  dv = g + 2.0f * cross(dt, qv);
+  dq = Q4{dw, dqv.x, dqv.y, dqv.z};
+}
+// backward of out = quat_mul(x, y)
+__device__ __forceinline__ void qmul_bwd(Q4 x, Q4 y, Q4 g, Q4& dx, Q4& dy) {
+  dx.w = g.w * y.w + g.x * y.x + g.y * y.y + g.z * y.z;
+  dx.x = -g.w * y.x + g.x * y.w - g.y * y.z + g.z * y.y;
+  dx.y = -g.w * y.y + g.x * y.z + g.y * y.w - g.z * y.x;
+  dx.z = -g.w * y.z - g.x * y.y + g.y * y.x + g.z * y.w;
+  dy.w = g.w * x.w + g.x * x.x + g.y * x.y + g.z * x.z;
+  dy.x = -g.w * x.x + g.x * x.w + g.y * x.z - g.z * x.y;
+  dy.y = -g.w * x.y - g.x * x.z + g.y * x.w + g.z * x.x;
+  dy.z = -g.w * x.z + g.x * x.y - g.y * x.x + g.z * x.w;
+}
+// backward of out = quat_exp(x)
+__device__ __forceinline__ V3 qexp_bwd(V3 x, Q4 g) {
+  float h = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z);
+  V3 gv = v3(g.x, g.y, g.z);
+  if (h < 1e-5f) {
+    float n = sqrtf(1.f + h * h), ne = n + 1e-5f;
+    float ug = g.w + dot(gv, x);
+    float k = ug / (n * ne * ne);
+    return (1.f / ne) * gv - k * x;
+  }
+  float sh = sinf(h), ch = cosf(h);
+  float s = sh / h, ds = (h * ch - sh) / (h * h);
+  float c = -g.w * s + dot(gv, x) * ds / h;
+  return s * gv + c * x;
+}
+
+// ------------------------------------------------------------------ kernels
+// init: frame-0 outputs, CellStateEncoder input (gaze of frame 0) and the pose part of x_1 (gaze of frame 1)
+__global__ void dec_init_k(ZeggsDecDims d, ZeggsDecStats st, const float* pose0, const float* rp0, const float* rr0,
+                           const float* gaze, const float* style, float* pose, float* rpos, float* rrot,
+                           float* cse_in, float* gin1, int GL) {
+  const int b = blockIdx.x;
+  const float* p0 = pose0 + (long)b * d.PO;
+  for (int c = threadIdx.x; c < d.PO; c += blockDim.x) {
+    float v = p0[c];
+    pose[((long)b * d.T) * d.PO + c] = v;
+    float e = (v - st.in_mean[c]) / st.in_std[c];
+    cse_in[(long)b * (d.PI + d.ST) + c] = e;
+    if (d.T > 1) gin1[(long)b * GL + d.H + c] = e;
+  }
+  for (int c = threadIdx.x; c < d.ST; c += blockDim.x)
+    cse_in[(long)b * (d.PI + d.ST) + d.PI + c] = style[((long)b * d.T) * d.ST + c];
+  if (threadIdx.x == 0) {
+    Q4 q = Q4{rr0[b * 4], rr0[b * 4 + 1], rr0[b * 4 + 2], rr0[b * 4 + 3]};
+    V3 rp = v3(rp0[b * 3], rp0[b * 3 + 1], rp0[b * 3 + 2]);
+    float* o = rpos + ((long)b * d.T) * 3; o[0] = rp.x; o[1] = rp.y; o[2] = rp.z;
+    float* r = rrot + ((long)b * d.T) * 4; r[0] = q.w; r[1] = q.x; r[2] = q.y; r[3] = q.z;
+    for (int f = 0; f < 2 && f < d.T; ++f) {
+      const float* gz = gaze + ((long)b * d.T + f) * 3;
+      V3 gd = quat_mul_vec(quat_inv(q), v3(gz[0], gz[1], gz[2]) - rp);
+      float gv[3] = {gd.x, gd.y, gd.z};
+      for (int k = 0; k < 3; ++k) {
+        float e = (gv[k] - st.in_mean[d.PO + k]) / st.in_std[d.PO + k];
+        if (f == 0) cse_in[(long)b * (d.PI + d.ST) + d.PO + k] = e;
+        else gin1[(long)b * GL + d.H + d.PO + k] = e;
+      }
+    }
+  }
+}
+
+// speech / style columns of x_t for one step (or all steps when nt > 1): Gin[t][b][H+PI ...]
+__global__ void dec_fill_cond_k(ZeggsDecDims d, const float* speech, const float* style, float* gin, int GL, int t0,
+                                int nt, long slot_stride, int ring) {
+  const int XC = d.SP + d.ST;
+  long n = (long)nt * d.B * XC;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % XC);
+    long r = i / XC;
+    int b = (int)(r % d.B);
+    int t = t0 + (int)(r / d.B);
+    float v = c < d.SP ? speech[((long)b * d.T + t) * d.SP + c] : style[((long)b * d.T + t) * d.ST + (c - d.SP)];
+    int slot = ring ? (t & 1) : t;
+    gin[slot * slot_stride + (long)b * GL + d.H + d.PI + c] = v;
+  }
+}
+
+// GRU cell gate math (nn.GRU, gate order r,z,n)
+__global__ void gru_gate_fwd_k(const float* gi, const float* gh, const float* hprev, float* hout, float* R,
+                               float* Z, float* N, float* NH, int B, int H) {
+  long n = (long)B * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int u = (int)(i % H);
+    long b = i / H;
+    const float* gib = gi + b * 3 * H;
+    const float* ghb = gh + b * 3 * H;
+    float r = d_sigmoid(gib[u] + ghb[u]);
+    float z = d_sigmoid(gib[H + u] + ghb[H + u]);
+    float nh = ghb[2 * H + u];
+    float nn = tanhf(gib[2 * H + u] + r * nh);
+    float hp = hprev[i];
+    hout[i] = (1.f - z) * nn + z * hp;
+    if (R) { R[i] = r; Z[i] = z; N[i] = nn; NH[i] = nh; }
+  }
+}
+
+// dh (total grad wrt h') -> di [B,3H] (grad wrt W_ih x + b_ih), dhh [B,3H] (grad wrt W_hh h + b_hh),
+// dhc = dh * z (direct path to h_prev)
+__global__ void gru_gate_bwd_k(const float* dh, const float* R, const float* Z, const float* N, const float* NH,
+                               const float* hprev, float* di, float* dhh, float* dhc, int B, int H) {
+  long n = (long)B * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int u = (int)(i % H);
+    long b = i / H;
+    float g = dh[i], r = R[i], z = Z[i], nn = N[i], nh = NH[i], hp = hprev[i];
+    float dn = g * (1.f - z);
+    float dz = g * (hp - nn);
+    float dan = dn * (1.f - nn * nn);
+    float dar = dan * nh * r * (1.f - r);
+    float daz = dz * z * (1.f - z);
+    float* dib = di + b * 3 * H;
+    float* dhb = dhh + b * 3 * H;
+    dib[u] = dar; dib[H + u] = daz; dib[2 * H + u] = dan;
+    dhb[u] = dar; dhb[H + u] = daz; dhb[2 * H + u] = dan * r;
+    dhc[i] = g * z;
+  }
+}
+
+// devectorize_output + next step's vectorize_input for one step t
+__global__ void dec_devec_k(ZeggsDecDims d, ZeggsDecStats st, const float* y, int POL, const float* gaze, float* pose,
+                            float* rpos, float* rrot, float* gin_next, int GL, int t) {
+  const int b = blockIdx.x;
+  const float* yb = y + (long)b * POL;
+  float* pb = pose + ((long)b * d.T + t) * d.PO;
+  for (int c = threadIdx.x; c < d.PO; c += blockDim.x) {
+    float p = yb[c] * st.out_std[c] + st.out_mean[c];
+    pb[c] = p;
+    if (gin_next) gin_next[(long)b * GL + d.H + c] = (p - st.in_mean[c]) / st.in_std[c];
+  }
+  if (threadIdx.x == 0) {
+    float p[6];
+    for (int c = 0; c < 6; ++c) p[c] = yb[c] * st.out_std[c] + st.out_mean[c];
+    const float* rq = rrot + ((long)b * d.T + t - 1) * 4;
+    const float* rp = rpos + ((long)b * d.T + t - 1) * 3;
+    Q4 q = Q4{rq[0], rq[1], rq[2], rq[3]};
+    V3 pos = v3(rp[0], rp[1], rp[2]);
+    V3 npos = quat_mul_vec(q, d.dt * v3(p[0], p[1], p[2])) + pos;
+    V3 u = quat_mul_vec(q, d.dt * v3(p[3], p[4], p[5]));
+    Q4 nq = quat_mul(quat_exp(0.5f * u), q);
+    float* op = rpos + ((long)b * d.T + t) * 3; op[0] = npos.x; op[1] = npos.y; op[2] = npos.z;
+    float* oq = rrot + ((long)b * d.T + t) * 4; oq[0] = nq.w; oq[1] = nq.x; oq[2] = nq.y; oq[3] = nq.z;
+    if (gin_next) {
+      const float* gz = gaze + ((long)b * d.T + t + 1) * 3;
+      V3 gd = quat_mul_vec(quat_inv(nq), v3(gz[0], gz[1], gz[2]) - npos);
+      float gv[3] = {gd.x, gd.y, gd.z};
+      for (int k = 0; k < 3; ++k)
+        gin_next[(long)b * GL + d.H + d.PO + k] = (gv[k] - st.in_mean[d.PO + k]) / st.in_std[d.PO + k];
+    }
+  }
+}
+
+// backward of dec_devec_k for step t.
+//   dxn   [B, XD]  grad wrt x_{t+1} (pose part used), null at the last step
+//   carry [B, 8]   grad wrt (rpos_t[3], rrot_t[4]) coming from steps > t (updated to frame t-1's)
+//   dy    [B, POL] output: grad wrt the raw network output of step t
+__global__ void dec_devec_bwd_k(ZeggsDecDims d, ZeggsDecStats st, const float* dpose, const float* drpos,
+                                const float* drrot, const float* dxn, int XD, const float* gaze, const float* pose,
+                                const float* rpos, const float* rrot, float* carry, float* dy, int POL, int t) {
+  const int b = blockIdx.x;
+  const float* dpb = dpose + ((long)b * d.T + t) * d.PO;
+  const float* dxb = dxn ? dxn + (long)b * XD : nullptr;
+  float* dyb = dy + (long)b * POL;
+  for (int c = 6 + threadIdx.x; c < d.PO; c += blockDim.x) {
+    float g = dpb[c] + (dxb ? dxb[c] / st.in_std[c] : 0.f);
+    dyb[c] = g * st.out_std[c];
+  }
+  if (threadIdx.x == 0) {
+    float g6[6];
+    for (int c = 0; c < 6; ++c) g6[c] = dpb[c] + (dxb ? dxb[c] / st.in_std[c] : 0.f);
+    float* cr = carry + b * 8;
+    const float* a = drpos + ((long)b * d.T + t) * 3;
+    const float* e = drrot + ((long)b * d.T + t) * 4;
+    V3 g_rp = v3(cr[0] + a[0], cr[1] + a[1], cr[2] + a[2]);
+    Q4 g_rr = Q4{cr[3] + e[0], cr[4] + e[1], cr[5] + e[2], cr[6] + e[3]};
+    const float* rq = rrot + ((long)b * d.T + t) * 4;
+    const float* rp = rpos + ((long)b * d.T + t) * 3;
+    Q4 q_t = Q4{rq[0], rq[1], rq[2], rq[3]};
+    V3 p_t = v3(rp[0], rp[1], rp[2]);
+    if (dxb) {   // gaze direction of x_{t+1}
+      const float* gz = gaze + ((long)b * d.T + t + 1) * 3;
+      V3 dgd = v3(dxb[d.PO] / st.in_std[d.PO], dxb[d.PO + 1] / st.in_std[d.PO + 1],
+                  dxb[d.PO + 2] / st.in_std[d.PO + 2]);
+      Q4 dqi; V3 dv;
+      qmv_bwd(quat_inv(q_t), v3(gz[0], gz[1], gz[2]) - p_t, dgd, dqi, dv);
+      g_rr.w += dqi.w; g_rr.x -= dqi.x; g_rr.y -= dqi.y; g_rr.z -= dqi.z;
+      g_rp = g_rp - dv;
+    }
+    const float* pq = rrot + ((long)b * d.T + t - 1) * 4;
+    Q4 q_p = Q4{pq[0], pq[1], pq[2], pq[3]};
+    const float* pt = pose + ((long)b * d.T + t) * d.PO;
+    V3 vel = v3(pt[0], pt[1], pt[2]), vrt = v3(pt[3], pt[4], pt[5]);
+    // rpos_t = qmv(q_p, vel dt) + rpos_{t-1}
+    Q4 dq1; V3 dv1;
+    qmv_bwd(q_p, d.dt * vel, g_rp, dq1, dv1);
+    // rrot_t = qmul(E, q_p), E = qexp(u/2), u = qmv(q_p, vrt dt)
+    V3 u = quat_mul_vec(q_p, d.dt * vrt);
+    Q4 E = quat_exp(0.5f * u);
+    Q4 dE, dqy;
+    qmul_bwd(E, q_p, g_rr, dE, dqy);
+    V3 du = 0.5f * qexp_bwd(0.5f * u, dE);
+    Q4 dq2; V3 dv2;
+    qmv_bwd(q_p, d.dt * vrt, du, dq2, dv2);
+    g6[0] += d.dt * dv1.x; g6[1] += d.dt * dv1.y; g6[2] += d.dt * dv1.z;
+    g6[3] += d.dt * dv2.x; g6[4] += d.dt * dv2.y; g6[5] += d.dt * dv2.z;
+    cr[0] = g_rp.x; cr[1] = g_rp.y; cr[2] = g_rp.z;
+    cr[3] = dq1.w + dqy.w + dq2.w; cr[4] = dq1.x + dqy.x + dq2.x;
+    cr[5] = dq1.y + dqy.y + dq2.y; cr[6] = dq1.z + dqy.z + dq2.z;
+    for (int c = 0; c < 6; ++c) dyb[c] = g6[c] * st.out_std[c];
+  }
+}
+
+// d0[b][u] = dgin[b][u] * ELU'(hid[b][u]);  rows strided by GL
+__global__ void elu_bwd_rows_k(float* d0, const float* dgin, const float* gin, int B, int H, int GL) {
+  long n = (long)B * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int u = (int)(i % H);
+    long b = i / H;
+    d0[i] = dgin[b * GL + u] * d_elu_grad_from_out(gin[b * GL + u]);
+  }
+}
+
+// copy rows: dst[b][0:w] = src[b][off : off+w]
+__global__ void copy_cols_k(float* dst, long ldd, const float* src, long lds, int off, int w, int B) {
+  long n = (long)B * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % w);
+    long b = i / w;
+    dst[b * ldd + c] = src[b * lds + off + c];
+  }
+}
+
+// scatter time-major dX [T][B][XD] speech/style columns into batch-major outputs
+__global__ void dec_scatter_cond_grad_k(ZeggsDecDims d, const float* DX, int XD, float* dspeech, float* dstyle) {
+  const int XC = d.SP + d.ST;
+  long n = (long)d.T * d.B * XC;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % XC);
+    long r = i / XC;
+    int b = (int)(r % d.B);
+    int t = (int)(r / d.B);
+    float v = t == 0 ? 0.f : DX[((long)t * d.B + b) * XD + d.PI + c];
+    if (c < d.SP) dspeech[((long)b * d.T + t) * d.SP + c] = v;
+    else dstyle[((long)b * d.T + t) * d.ST + (c - d.SP)] = v;
+  }
+}
+__global__ void add_style0_grad_k(ZeggsDecDims d, const float* dcse_in, float* dstyle) {
+  long n = (long)d.B * d.ST;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % d.ST);
+    long b = i / d.ST;
+    dstyle[(b * d.T) * d.ST + c] += dcse_in[b * (d.PI + d.ST) + d.PI + c];
+  }
+}
+
+inline dim3 g1(long n) { long g = (n + 255) / 256; return dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))); }
+
+}  // namespace
+
+extern "C" size_t zeggs_decoder_workspace_bytes(const ZeggsDecDims* d, int training) {
+  Arena a(nullptr, 0);
+  carve_dec(*d, training, a);
+  return a.off + 256;
+}
+
+extern "C" int zeggs_decoder_fwd(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
+                                 const float* pose0, const float* rpos0, const float* rrot0, const float* gaze,
+                                 const float* speech, const float* style, float* pose, float* rpos, float* rrot,
+                                 int training, void* ws, size_t ws_bytes, void* stream) {
+  const ZeggsDecDims& d = *dp;
+  hipStream_t s = (hipStream_t)stream;
+  ZCHECK(d.PI == d.PO + 3, "decoder: pose_input_size must be pose_output_size + 3 (gaze)");
+  ZCHECK(d.B >= 1 && d.T >= 1, "decoder: empty batch or sequence");
+  Arena a(ws, ws_bytes);
+  DecWs w = carve_dec(d, training, a);
+  ZCHECK(a.ok(), "decoder: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  const int B = d.B, T = d.T, H = d.H, GL = w.GL, XD = w.XD, CI = d.PI + d.ST;
+  const long sG = (long)B * GL, sH = (long)B * H;
+  const int ring = training ? 0 : 1;
+  auto slot = [&](int t) { return ring ? (t & 1) : t; };
+  // frame 0 + CellStateEncoder
+  hipLaunchKernelGGL(dec_init_k, dim3(B), dim3(256), 0, s, d, *st, pose0, rpos0, rrot0, gaze, style, pose, rpos, rrot,
+                     w.cse_in, w.Gin + slot(1) * sG, GL);
+  ZLAUNCH_CHECK("dec_init");
+  ZTRY(gemm_nt(w.cse_in, CI, P->c0_w, CI, w.cse_a, H, P->c0_b, B, H, CI, ACT_ELU, 0.f, s));
+  ZTRY(gemm_nt(w.cse_a, H, P->c1_w, H, w.cse_b, H, P->c1_b, B, H, H, ACT_ELU, 0.f, s));
+  ZTRY(gemm_nt(w.cse_b, H, P->c2_w, H, w.H0 + slot(0) * sH, H, P->c2_b, B, H, H, ACT_NONE, 0.f, s));
+  ZTRY(gemm_nt(w.cse_b, H, P->c2_w + (long)H * H, H, w.H1 + slot(0) * sH, H, P->c2_b + H, B, H, H, ACT_NONE, 0.f, s));
+  if (training && T > 1) {
+    hipLaunchKernelGGL(dec_fill_cond_k, g1((long)(T - 1) * B * (d.SP + d.ST)), dim3(256), 0, s, d, speech, style, w.Gin,
+                       GL, 1, T - 1, sG, 0);
+    ZLAUNCH_CHECK("dec_fill_cond");
+  }
+  for (int t = 1; t < T; ++t) {
+    float* gin = w.Gin + slot(t) * sG;
+    float* gin_next = (t + 1 < T) ? w.Gin + slot(t + 1) * sG : nullptr;
+    const float *h0p = w.H0 + slot(t - 1) * sH, *h1p = w.H1 + slot(t - 1) * sH;
+    float *h0 = w.H0 + slot(t) * sH, *h1 = w.H1 + slot(t) * sH;
+    if (!training) {
+      hipLaunchKernelGGL(dec_fill_cond_k, g1((long)B * (d.SP + d.ST)), dim3(256), 0, s, d, speech, style, w.Gin, GL, t,
+                         1, sG, 1);
+      ZLAUNCH_CHECK("dec_fill_cond");
+    }
+    // hid = ELU(layer0(x))
+    ZTRY(gemm_nt(gin + H, GL, P->l0_w, XD, gin, GL, P->l0_b, B, H, XD, ACT_ELU, 0.f, s));
+    // GRU layer 0
+    ZTRY(gemm_nt(gin, GL, P->w_ih0, H + XD, w.gi, 3 * H, P->b_ih0, B, 3 * H, H + XD, ACT_NONE, 0.f, s));
+    ZTRY(gemm_nt(h0p, H, P->w_hh0, H, w.gh, 3 * H, P->b_hh0, B, 3 * H, H, ACT_NONE, 0.f, s));
+    const long o = (long)t * sH;
+    hipLaunchKernelGGL(gru_gate_fwd_k, g1(sH), dim3(256), 0, s, w.gi, w.gh, h0p, h0, training ? w.R0 + o : nullptr,
+                       training ? w.Z0 + o : nullptr, training ? w.N0 + o : nullptr, training ? w.NH0 + o : nullptr,
+                       B, H);
+    // GRU layer 1
+    ZTRY(gemm_nt(h0, H, P->w_ih1, H, w.gi, 3 * H, P->b_ih1, B, 3 * H, H, ACT_NONE, 0.f, s));
+    ZTRY(gemm_nt(h1p, H, P->w_hh1, H, w.gh, 3 * H, P->b_hh1, B, 3 * H, H, ACT_NONE, 0.f, s));
+    hipLaunchKernelGGL(gru_gate_fwd_k, g1(sH), dim3(256), 0, s, w.gi, w.gh, h1p, h1, training ? w.R1 + o : nullptr,
+                       training ? w.Z1 + o : nullptr, training ? w.N1 + o : nullptr, training ? w.NH1 + o : nullptr,
+                       B, H);
+    // output projection + pose integration
+    ZTRY(gemm_nt(h1, H, P->l2_w, H, w.Y, w.POL, P->l2_b, B, d.PO, H, ACT_NONE, 0.f, s));
+    hipLaunchKernelGGL(dec_devec_k, dim3(B), dim3(256), 0, s, d, *st, w.Y, w.POL, gaze, pose, rpos, rrot, gin_next, GL,
+                       t);
+    ZLAUNCH_CHECK("dec_step");
+  }
+  return 0;
+}
+
+extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
+                                 const float* gaze, const float* pose, const float* rpos, const float* rrot,
+                                 const float* dpose, const float* drpos, const float* drrot, const ZeggsDecGrads* G,
+                                 float* dspeech, float* dstyle, void* ws, size_t ws_bytes, void* stream) {
+  const ZeggsDecDims& d = *dp;
+  hipStream_t s = (hipStream_t)stream;
+  Arena a(ws, ws_bytes);
+  DecWs w = carve_dec(d, 1, a);
+  ZCHECK(a.ok(), "decoder bwd: workspace too small (was the forward run with training=1?)");
+  const int B = d.B, T = d.T, H = d.H, GL = w.GL, XD = w.XD, CI = d.PI + d.ST, POL = w.POL;
+  const long sG = (long)B * GL, sH = (long)B * H, s3 = 3 * sH;
+  ZTRY(k_fill(w.dH0c, sH, 0.f, s));
+  ZTRY(k_fill(w.dH1c, sH, 0.f, s));
+  ZTRY(k_fill(w.carry, (long)B * 8, 0.f, s));
+  ZTRY(k_fill(w.DX, (long)B * XD, 0.f, s));          // slot t = 0 unused but read by the scatter
+  for (int t = T - 1; t >= 1; --t) {
+    const float* gin = w.Gin + t * sG;
+    const long o = (long)t * sH;
+    float* dy = w.DY + (long)t * B * POL;
+    const float* dxn = (t + 1 < T) ? w.DX + (long)(t + 1) * B * XD : nullptr;
+    hipLaunchKernelGGL(dec_devec_bwd_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, dxn, XD, gaze, pose, rpos,
+                       rrot, w.carry, dy, POL, t);
+    ZLAUNCH_CHECK("dec_devec_bwd");
+    // dH1 total = dy W2 + carried
+    ZTRY(gemm_nn(dy, POL, P->l2_w, H, w.dH1c, H, B, d.PO, H, 1.f, s));
+    hipLaunchKernelGGL(gru_gate_bwd_k, g1(sH), dim3(256), 0, s, w.dH1c, w.R1 + o, w.Z1 + o, w.N1 + o, w.NH1 + o,
+                       w.H1 + o - sH, w.DI1 + t * s3, w.DH1 + t * s3, w.t0, B, H);
+    // t0 = dH1 * z (direct path); dH1c <- t0 + DH1 W_hh1 ; dH0 total = dH0c + DI1 W_ih1
+    ZTRY(k_copy(w.dH1c, w.t0, sH, s));
+    ZTRY(gemm_nn(w.DH1 + t * s3, 3 * H, P->w_hh1, H, w.dH1c, H, B, 3 * H, H, 1.f, s));
+    ZTRY(gemm_nn(w.DI1 + t * s3, 3 * H, P->w_ih1, H, w.dH0c, H, B, 3 * H, H, 1.f, s));
+    hipLaunchKernelGGL(gru_gate_bwd_k, g1(sH), dim3(256), 0, s, w.dH0c, w.R0 + o, w.Z0 + o, w.N0 + o, w.NH0 + o,
+                       w.H0 + o - sH, w.DI0 + t * s3, w.DH0 + t * s3, w.t0, B, H);
+    ZTRY(k_copy(w.dH0c, w.t0, sH, s));
+    ZTRY(gemm_nn(w.DH0 + t * s3, 3 * H, P->w_hh0, H, w.dH0c, H, B, 3 * H, H, 1.f, s));
+    // dGin = DI0 W_ih0 -> [dhid | dx]
+    ZTRY(gemm_nn(w.DI0 + t * s3, 3 * H, P->w_ih0, H + XD, w.dGin, GL, B, 3 * H, H + XD, 0.f, s));
+    hipLaunchKernelGGL(elu_bwd_rows_k, g1(sH), dim3(256), 0, s, w.D0 + o, w.dGin, gin, B, H, GL);
+    // dx_t = dGin[:, H:] + D0 W0
+    float* dx = w.DX + (long)t * B * XD;
+    hipLaunchKernelGGL(copy_cols_k, g1((long)B * XD), dim3(256), 0, s, dx, (long)XD, w.dGin, (long)GL, H, XD, B);
+    ZLAUNCH_CHECK("dec_bwd_step");
+    ZTRY(gemm_nn(w.D0 + o, H, P->l0_w, XD, dx, XD, B, H, XD, 1.f, s));
+  }
+  // ---- CellStateEncoder backward: dH0c / dH1c are the grads wrt its two output halves
+  if (T > 1) {
+    // weight grads of the recurrent part: contraction over the flattened (t,b) axis, t = 1..T-1
+    const int M = (T - 1) * B;
+    ZTRY(gemm_tn(w.DY + (long)B * POL, POL, w.H1 + sH, H, G->l2_w, H, M, d.PO, H, 0.f, s));
+    ZTRY(k_colsum(G->l2_b, w.DY + (long)B * POL, M, d.PO, POL, 0.f, s));
+    ZTRY(gemm_tn(w.DI1 + s3, 3 * H, w.H0 + sH, H, G->w_ih1, H, M, 3 * H, H, 0.f, s));
+    ZTRY(gemm_tn(w.DH1 + s3, 3 * H, w.H1, H, G->w_hh1, H, M, 3 * H, H, 0.f, s));
+    ZTRY(k_colsum(G->b_ih1, w.DI1 + s3, M, 3 * H, 3 * H, 0.f, s));
+    ZTRY(k_colsum(G->b_hh1, w.DH1 + s3, M, 3 * H, 3 * H, 0.f, s));
+    ZTRY(gemm_tn(w.DI0 + s3, 3 * H, w.Gin + sG, GL, G->w_ih0, H + XD, M, 3 * H, H + XD, 0.f, s));
+    ZTRY(gemm_tn(w.DH0 + s3, 3 * H, w.H0, H, G->w_hh0, H, M, 3 * H, H, 0.f, s));
+    ZTRY(k_colsum(G->b_ih0, w.DI0 + s3, M, 3 * H, 3 * H, 0.f, s));
+    ZTRY(k_colsum(G->b_hh0, w.DH0 + s3, M, 3 * H, 3 * H, 0.f, s));
+    ZTRY(gemm_tn(w.D0 + sH, H, w.Gin + sG + H, GL, G->l0_w, XD, M, H, XD, 0.f, s));
+    ZTRY(k_colsum(G->l0_b, w.D0 + sH, M, H, H, 0.f, s));
+  } else {
+    ZCHECK(false, "decoder bwd: T must be > 1");
+  }
+  {
+    // out = [H0_init | H1_init] = cse_b W2^T + b2
+    ZTRY(gemm_tn(w.dH0c, H, w.cse_b, H, G->c2_w, H, B, H, H, 0.f, s));
+    ZTRY(gemm_tn(w.dH1c, H, w.cse_b, H, G->c2_w + (long)H * H, H, B, H, H, 0.f, s));
+    ZTRY(k_colsum(G->c2_b, w.dH0c, B, H, H, 0.f, s));
+    ZTRY(k_colsum(G->c2_b + H, w.dH1c, B, H, H, 0.f, s));
+    float* db = w.t0;                       // [B,H] grad wrt cse_b
+    ZTRY(gemm_nn(w.dH0c, H, P->c2_w, H, db, H, B, H, H, 0.f, s));
+    ZTRY(gemm_nn(w.dH1c, H, P->c2_w + (long)H * H, H, db, H, B, H, H, 1.f, s));
+    ZTRY(k_act_bwd(db, db, w.cse_b, sH, ACT_ELU, 1.f, s));
+    ZTRY(gemm_tn(db, H, w.cse_a, H, G->c1_w, H, B, H, H, 0.f, s));
+    ZTRY(k_colsum(G->c1_b, db, B, H, H, 0.f, s));
+    float* da = w.t0 + sH;                  // [B,H] grad wrt cse_a
+    ZTRY(gemm_nn(db, H, P->c1_w, H, da, H, B, H, H, 0.f, s));
+    ZTRY(k_act_bwd(da, da, w.cse_a, sH, ACT_ELU, 1.f, s));
+    ZTRY(gemm_tn(da, H, w.cse_in, CI, G->c0_w, CI, B, H, CI, 0.f, s));
+    ZTRY(k_colsum(G->c0_b, da, B, H, H, 0.f, s));
+    ZTRY(gemm_nn(da, H, P->c0_w, CI, w.t1, CI, B, H, CI, 0.f, s));   // t1 = d cse_in [B, PI+ST]
+  }
+  hipLaunchKernelGGL(dec_scatter_cond_grad_k, g1((long)T * B * (d.SP + d.ST)), dim3(256), 0, s, d, w.DX, XD, dspeech,
+                     dstyle);
+  hipLaunchKernelGGL(add_style0_grad_k, g1((long)B * d.ST), dim3(256), 0, s, d, w.t1, dstyle);
+  ZLAUNCH_CHECK("dec_bwd_tail");
+  return 0;
+}

@@ -1,0 +1,27 @@
+// Host-side interface of the generic strided fp32 MFMA GEMM (gemm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;  // per output column n, may be null
+  int M, N, K;
+  long sam, sak, sbk, sbn, scm, scn;           // element strides; one of (sam,sak) and one of (sbk,sbn) must be 1
+  long bsA0, bsA1, bsB0, bsB1, bsC0, bsC1;     // batch z -> (z / nb1, z % nb1)
+  int nb1;
+  int kbatch;                                  // batch-reduce: K loop runs over kbatch segments
+  long kbsA, kbsB;
+  float alpha, beta;
+  int act;
+};
+
+GemmArgs gemm_args(const float* A, const float* B, float* C, int M, int N, int K);
+int launch_gemm(GemmArgs g, int nbatch, hipStream_t s);
+int gemm_nt(const float* x, long ldx, const float* W, long ldw, float* y, long ldy, const float* bias, int M,
+            int N, int K, int act, float beta, hipStream_t s);
+int gemm_nn(const float* dy, long lddy, const float* W, long ldw, float* dx, long lddx, int M, int N_contract,
+            int K_out, float beta, hipStream_t s);
+int gemm_tn(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M_contract, int N,
+            int K, float beta, hipStream_t s);

@@ -1,0 +1,235 @@
+// Generic batched fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   C(m,n) = act( alpha * sum_k A(m,k) B(k,n) + beta * C(m,n) + bias[n] )
+//
+// A, B, C are addressed through element strides, so one kernel family covers
+//   NT  (nn.Linear forward  y = x W^T)            A k-contig, B k-contig
+//   NN  (input gradients    dx = dy W)            A k-contig, B n-contig
+//   TN  (weight gradients   dW = dy^T x)          A m-contig, B n-contig
+// plus two-level batching (attention heads), a batch-reduce K loop (weight
+// gradients of batched convolutions) and overlapping-row A operands (a conv1d
+// over a padded [T+2p, C] buffer is a GEMM with lda = C and K = taps*C).
+// Tiles are staged global -> registers -> LDS (k-major, so MFMA operand reads are
+// conflict-free ds_read_b32 of 32 consecutive floats) and the next tile's global
+// loads are in flight while the current one feeds the MFMAs.
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+template <int E>
+__device__ __forceinline__ void load_contig(float (&r)[E], const float* p, int nvalid) {
+  // p is only 4-byte aligned in general
+  if (nvalid >= E) {
+    if constexpr (E == 8) {
+      f4u a = *(const f4u*)p, b = *(const f4u*)(p + 4);
+      r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+    } else if constexpr (E == 4) {
+      f4u a = *(const f4u*)p;
+      r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+    } else if constexpr (E == 2) {
+      f2u a = *(const f2u*)p;
+      r[0] = a.x; r[1] = a.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < E; ++i) r[i] = p[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = (i < nvalid) ? p[i] : 0.f;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MT = TM / 32, NTL = TN / 32;
+  constexpr int EA = BM * BK / NT, EB = BN * BK / NT;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  static_assert(EA >= 1 && EB >= 1 && (EA == 1 || EA == 2 || EA == 4 || EA == 8), "tile/threads");
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m_base = blockIdx.y * BM, n_base = blockIdx.x * BN;
+  const int z = blockIdx.z;
+  const long z0 = z / g.nb1, z1 = z % g.nb1;
+  const float* A = g.A + z0 * g.bsA0 + z1 * g.bsA1;
+  const float* B = g.B + z0 * g.bsB0 + z1 * g.bsB1;
+  float* C = g.C + z0 * g.bsC0 + z1 * g.bsC1;
+
+  // loader coordinates
+  int a_r, a_c, b_r, b_c;  // (row within tile along the non-contiguous dim, start along the contiguous dim)
+  if constexpr (AKC) { a_r = tid / (BK / EA); a_c = (tid % (BK / EA)) * EA; }   // a_r = m, a_c = k0
+  else               { a_r = tid / (BM / EA); a_c = (tid % (BM / EA)) * EA; }   // a_r = k, a_c = m0
+  if constexpr (BKC) { b_r = tid / (BK / EB); b_c = (tid % (BK / EB)) * EB; }   // b_r = n, b_c = k0
+  else               { b_r = tid / (BN / EB); b_c = (tid % (BN / EB)) * EB; }   // b_r = k, b_c = n0
+
+  const int nkt = (g.K + BK - 1) / BK;
+  const int ntiles = nkt * g.kbatch;
+  float ra[EA], rb[EB];
+
+  auto gload = [&](int tile) {
+    const int kb = tile / nkt, k_base = (tile % nkt) * BK;
+    const float* Ab = A + (long)kb * g.kbsA;
+    const float* Bb = B + (long)kb * g.kbsB;
+    if constexpr (AKC) {
+      int m = m_base + a_r, k = k_base + a_c;
+      int nv = (m < g.M) ? (g.K - k) : 0;
+      load_contig<EA>(ra, Ab + (long)m * g.sam + k, nv < 0 ? 0 : nv);
+    } else {
+      int k = k_base + a_r, m = m_base + a_c;
+      int nv = (k < g.K) ? (g.M - m) : 0;
+      load_contig<EA>(ra, Ab + (long)k * g.sak + m, nv < 0 ? 0 : nv);
+    }
+    if constexpr (BKC) {
+      int n = n_base + b_r, k = k_base + b_c;
+      int nv = (n < g.N) ? (g.K - k) : 0;
+      load_contig<EB>(rb, Bb + (long)n * g.sbn + k, nv < 0 ? 0 : nv);
+    } else {
+      int k = k_base + b_r, n = n_base + b_c;
+      int nv = (k < g.K) ? (g.N - n) : 0;
+      load_contig<EB>(rb, Bb + (long)k * g.sbk + n, nv < 0 ? 0 : nv);
+    }
+  };
+  auto sstore = [&]() {
+    if constexpr (AKC) {
+#pragma unroll
+      for (int i = 0; i < EA; ++i) As[(a_c + i) * LDA + a_r] = ra[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < EA; ++i) As[a_r * LDA + a_c + i] = ra[i];
+    }
+    if constexpr (BKC) {
+#pragma unroll
+      for (int i = 0; i < EB; ++i) Bs[(b_c + i) * LDB + b_r] = rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < EB; ++i) Bs[b_r * LDB + b_c + i] = rb[i];
+    }
+  };
+
+  f16v acc[MT][NTL];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  sstore();
+  __syncthreads();
+  const int kh = lane >> 5, l31 = lane & 31;
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) gload(t + 1);
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+      float a[MT], b[NTL];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = As[(2 * kp + kh) * LDA + wm * TM + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) b[j] = Bs[(2 * kp + kh) * LDB + wn * TN + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      sstore();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      const int n = n_base + wn * TN + j * 32 + l31;
+      if (n >= g.N) continue;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_base + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (m >= g.M) continue;
+        float* cp = C + (long)m * g.scm + (long)n * g.scn;
+        float v = g.alpha * acc[i][j][r] + bv;
+        if (g.beta != 0.f) v += g.beta * (*cp);
+        *cp = d_act(v, g.act);
+      }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const GemmArgs& g, int nbatch, hipStream_t s) {
+  dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), nbatch), block(WM * WN * 64);
+  const bool akc = (g.sak == 1), bkc = (g.sbk == 1) && (g.sbn != 1 || g.N == 1);
+  if (!akc && g.sam != 1) { zeggs_set_error("gemm: A has no unit stride (sam=%ld sak=%ld)", g.sam, g.sak); return -1; }
+  if (!bkc && g.sbn != 1) { zeggs_set_error("gemm: B has no unit stride (sbk=%ld sbn=%ld)", g.sbk, g.sbn); return -1; }
+  if (akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, g);
+  else if (akc && !bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, g);
+  else if (!akc && bkc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, g);
+  ZLAUNCH_CHECK("gemm");
+  return 0;
+}
+
+}  // namespace
+
+int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0 || nbatch <= 0) return 0;
+  if (g.nb1 <= 0) g.nb1 = 1;
+  if (g.kbatch <= 0) g.kbatch = 1;
+  if (g.M <= 32) return launch_cfg<32, 128, 1, 4>(g, nbatch, s);
+  const long big_tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nbatch;
+  if (g.M <= 64 || g.N <= 64 || big_tiles < 192) return launch_cfg<64, 64, 2, 2>(g, nbatch, s);
+  return launch_cfg<128, 128, 2, 2>(g, nbatch, s);
+}
+
+GemmArgs gemm_args(const float* A, const float* B, float* C, int M, int N, int K) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
+  g.nb1 = 1; g.kbatch = 1; g.alpha = 1.f; g.beta = 0.f; g.act = ACT_NONE;
+  return g;
+}
+
+// y[M,N] = act(x[M,K] W[N,K]^T + bias)       (nn.Linear forward)
+int gemm_nt(const float* x, long ldx, const float* W, long ldw, float* y, long ldy, const float* bias,
+            int M, int N, int K, int act, float beta, hipStream_t s) {
+  GemmArgs g = gemm_args(x, W, y, M, N, K);
+  g.sam = ldx; g.sak = 1; g.sbk = 1; g.sbn = ldw; g.scm = ldy; g.scn = 1;
+  g.bias = bias; g.act = act; g.beta = beta;
+  return launch_gemm(g, 1, s);
+}
+// dx[M,K] = beta*dx + dy[M,N] W[N,K]          (input gradient of nn.Linear)
+int gemm_nn(const float* dy, long lddy, const float* W, long ldw, float* dx, long lddx, int M, int N_contract,
+            int K_out, float beta, hipStream_t s) {
+  GemmArgs g = gemm_args(dy, W, dx, M, K_out, N_contract);
+  g.sam = lddy; g.sak = 1; g.sbk = ldw; g.sbn = 1; g.scm = lddx; g.scn = 1; g.beta = beta;
+  return launch_gemm(g, 1, s);
+}
+// dW[N,K] = beta*dW + dy[M,N]^T x[M,K]        (weight gradient of nn.Linear)
+int gemm_tn(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M_contract, int N,
+            int K, float beta, hipStream_t s) {
+  GemmArgs g = gemm_args(dy, x, dW, N, K, M_contract);
+  g.sam = 1; g.sak = lddy; g.sbk = ldx; g.sbn = 1; g.scm = lddw; g.scn = 1; g.beta = beta;
+  return launch_gemm(g, 1, s);
+}
+
+extern "C" int zeggs_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                          long sam, long sak, long sbk, long sbn, long scm, long scn, int nbatch, long bsA,
+                          long bsB, long bsC, float alpha, float beta, int act, void* stream) {
+  GemmArgs g = gemm_args(A, B, C, M, N, K);
+  g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.scm = scm; g.scn = scn;
+  g.bsA0 = bsA; g.bsB0 = bsB; g.bsC0 = bsC; g.nb1 = 1;
+  g.bias = bias; g.alpha = alpha; g.beta = beta; g.act = act;
+  return launch_gemm(g, nbatch, (hipStream_t)stream);
+}

@@ -1,0 +1,45 @@
+// Host-side launchers of the streaming (HBM-bound) kernels in kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// y = x (optional), fill
+int k_fill(float* p, long n, float v, hipStream_t s);
+int k_copy(float* dst, const float* src, long n, hipStream_t s);
+int k_add_inplace(float* dst, const float* src, long n, hipStream_t s);            // dst += src
+// dx = dy * act'(y) where y is the activation OUTPUT (times inv_keep if y went through dropout)
+int k_act_bwd(float* dx, const float* dy, const float* y, long n, int act, float y_scale, hipStream_t s);
+// x *= dropout_scale(seed, base+i, p)   (used for forward and for the backward mask)
+int k_dropout(float* x, long n, float p, uint64_t seed, hipStream_t s);
+// rows x cols views with a leading dimension (dropout on the interior of a padded buffer)
+int k_dropout_rows(float* x, int rows, int cols, long ld, long batch_rows, long batch_stride, float p,
+                   uint64_t seed, hipStream_t s);
+// LayerNorm over the last dim C of [R, C]; x may have an added residual; saves mean/rstd
+int k_layernorm_fwd(float* y, const float* x, const float* res, const float* gamma, const float* beta,
+                    float* mean, float* rstd, int R, int C, float eps, hipStream_t s);
+// dx (+)= LN backward; dgamma/dbeta accumulated with atomics (buffers must be zeroed by the caller)
+int k_layernorm_bwd(float* dx, const float* dy, const float* x, const float* res, const float* gamma,
+                    const float* mean, const float* rstd, float* dgamma, float* dbeta, int R, int C,
+                    hipStream_t s);
+// row softmax of [R, L]; optional dropout copy Pd = dropout(P)
+int k_softmax_fwd(float* P, float* Pd, const float* S, long R, int L, float p, uint64_t seed, hipStream_t s);
+// dS = P * (dP*mask - sum_j(dP_j*mask_j*P_j))
+int k_softmax_bwd(float* dS, const float* dPd, const float* P, long R, int L, float p, uint64_t seed,
+                  hipStream_t s);
+// out[c] (+)= sum_r x[r*ld + c]
+int k_colsum(float* out, const float* x, long R, int C, long ld, float beta, hipStream_t s);
+// [B, T, C] -> [B, pl + T + pr, C]; mode 0 zero, 1 replicate
+int k_pad_rows(float* dst, const float* src, int B, int T, int C, int pl, int pr, int mode, hipStream_t s);
+// fill only the pad rows of an already-populated padded buffer (mode 0 zero / 1 replicate)
+int k_pad_edges(float* buf, int B, int T, int C, int pl, int pr, int mode, hipStream_t s);
+// backward of replicate padding: dx[b,t] = dpad[b,t+pl] (+ folded edge rows at t=0 / t=T-1)
+int k_unpad_fold(float* dx, const float* dpad, int B, int T, int C, int pl, int pr, int mode, hipStream_t s);
+// conv weight [Co, Ci, Kw] -> fwd-packed [(j,ci), co] and bwd-packed [(j',co), ci] (flipped taps)
+int k_pack_conv_w(float* wf, float* wb, const float* w, int Co, int Ci, int Kw, hipStream_t s);
+// dW[co,ci,j] = dWf[(j,ci), co]
+int k_unpack_conv_dw(float* dw, const float* dwf, int Co, int Ci, int Kw, hipStream_t s);
+// h[b,l,c] += table[l,c]
+int k_add_rows_bcast(float* h, const float* table, int B, int L, int C, hipStream_t s);
+// pooled[b,c] = sum_l f[b,l,c] / L ; bwd: df[b,l,c] = dpooled[b,c] / L
+int k_meanpool_fwd(float* out, const float* f, int B, int L, int C, hipStream_t s);
+int k_meanpool_bwd(float* df, const float* dout, int B, int L, int C, hipStream_t s);

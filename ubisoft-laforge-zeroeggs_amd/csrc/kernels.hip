@@ -1,0 +1,375 @@
+// Streaming kernels shared by the encoders (HBM-bound: coalesced along the
+// feature axis, one wave per row for row reductions, grid-stride elsewhere).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+inline int grid1d(long n, int block = 256) {
+  long g = (n + block - 1) / block;
+  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+#define GS_LOOP(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+__global__ void fill_k(float* p, long n, float v) { GS_LOOP(i, n) p[i] = v; }
+__global__ void copy_k(float* d, const float* s, long n) { GS_LOOP(i, n) d[i] = s[i]; }
+__global__ void add_k(float* d, const float* s, long n) { GS_LOOP(i, n) d[i] += s[i]; }
+
+__global__ void act_bwd_k(float* dx, const float* dy, const float* y, long n, int act, float ys) {
+  GS_LOOP(i, n) {
+    float yv = y[i] * ys, g = dy[i];
+    if (act == ACT_ELU) g *= d_elu_grad_from_out(yv);
+    else if (act == ACT_RELU) g = yv > 0.f ? g : 0.f;
+    dx[i] = g;
+  }
+}
+
+__global__ void dropout_k(float* x, long n, float p, uint64_t seed) {
+  GS_LOOP(i, n) x[i] *= dropout_scale(seed, (uint64_t)i, p);
+}
+
+__global__ void dropout_rows_k(float* x, int rows, int cols, long ld, long batch_rows, long batch_stride,
+                               float p, uint64_t seed) {
+  long n = (long)rows * cols;
+  GS_LOOP(i, n) {
+    long r = i / cols;
+    int c = (int)(i - r * cols);
+    long b = r / batch_rows, rr = r - b * batch_rows;
+    x[b * batch_stride + rr * ld + c] *= dropout_scale(seed, (uint64_t)i, p);
+  }
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void layernorm_fwd_k(float* y, const float* x, const float* res,
+                                                        const float* gamma, const float* beta, float* mean,
+                                                        float* rstd, int R, int C, float eps) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* xr = x + (long)row * C;
+  const float* rr = res ? res + (long)row * C : nullptr;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c] + (rr ? rr[c] : 0.f);
+  float mu = wave_sum(s) / C;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    float d = xr[c] + (rr ? rr[c] : 0.f) - mu;
+    v += d * d;
+  }
+  float rs = 1.0f / sqrtf(wave_sum(v) / C + eps);   // biased variance, as torch
+  for (int c = lane; c < C; c += 64) {
+    float d = xr[c] + (rr ? rr[c] : 0.f) - mu;
+    y[(long)row * C + c] = d * rs * gamma[c] + beta[c];
+  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <int MAXJ>
+__global__ __launch_bounds__(256) void layernorm_bwd_k(float* dx, const float* dy, const float* x,
+                                                        const float* res, const float* gamma,
+                                                        const float* mean, const float* rstd, float* dgamma,
+                                                        float* dbeta, int R, int C, int rows_per_block) {
+  __shared__ float sg[4][64 * MAXJ], sb[4][64 * MAXJ];
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float pg[MAXJ], pb[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) pg[j] = pb[j] = 0.f;
+  int r0 = blockIdx.x * rows_per_block;
+  for (int row = r0 + wave; row < r0 + rows_per_block && row < R; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[MAXJ], g[MAXJ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      int c = lane + 64 * j;
+      xh[j] = 0.f; g[j] = 0.f;
+      if (c < C) {
+        float xv = x[(long)row * C + c] + (res ? res[(long)row * C + c] : 0.f);
+        float d = dy[(long)row * C + c];
+        xh[j] = (xv - mu) * rs;
+        g[j] = d * gamma[c];
+        pg[j] += d * xh[j];
+        pb[j] += d;
+        s1 += g[j];
+        s2 += g[j] * xh[j];
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      int c = lane + 64 * j;
+      if (c < C) dx[(long)row * C + c] = rs * (g[j] - s1 - xh[j] * s2);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) { sg[wave][lane + 64 * j] = pg[j]; sb[wave][lane + 64 * j] = pb[j]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+    atomicAdd(dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_fwd_k(float* P, float* Pd, const float* S, long R, int L, float p,
+                                                      uint64_t seed) {
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* s = S + row * L;
+  float m = -INFINITY;
+  for (int c = lane; c < L; c += 64) m = fmaxf(m, s[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float z = 0.f;
+  for (int c = lane; c < L; c += 64) z += expf(s[c] - m);
+  z = wave_sum(z);
+  for (int c = lane; c < L; c += 64) {
+    float v = expf(s[c] - m) / z;
+    P[row * L + c] = v;
+    if (Pd) Pd[row * L + c] = v * dropout_scale(seed, (uint64_t)(row * L + c), p);
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_k(float* dS, const float* dPd, const float* P, long R, int L,
+                                                      float p, uint64_t seed) {
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  float acc = 0.f;
+  for (int c = lane; c < L; c += 64) {
+    long i = row * L + c;
+    acc += dPd[i] * dropout_scale(seed, (uint64_t)i, p) * P[i];
+  }
+  acc = wave_sum(acc);
+  for (int c = lane; c < L; c += 64) {
+    long i = row * L + c;
+    dS[i] = P[i] * (dPd[i] * dropout_scale(seed, (uint64_t)i, p) - acc);
+  }
+}
+
+// column sums: block = 256 threads = 64 columns x 4 row-phases; grid.x over column groups, grid.y over row chunks
+__global__ __launch_bounds__(256) void colsum_k(float* out, const float* x, long R, int C, long ld,
+                                                 long rows_per_block) {
+  __shared__ float red[4][64];
+  int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  int c = blockIdx.x * 64 + cl;
+  long r0 = (long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block;
+  if (r1 > R) r1 = R;
+  float s = 0.f;
+  if (c < C)
+    for (long r = r0 + ph; r < r1; r += 4) s += x[r * ld + c];
+  red[ph][cl] = s;
+  __syncthreads();
+  if (ph == 0 && c < C) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+__global__ void scale_k(float* p, long n, float v) { GS_LOOP(i, n) p[i] *= v; }
+
+__global__ void pad_rows_k(float* dst, const float* src, int B, int T, int C, int pl, int pr, int mode) {
+  int TP = pl + T + pr;
+  long n = (long)B * TP * C;
+  GS_LOOP(i, n) {
+    int c = (int)(i % C);
+    long r = i / C;
+    int tp = (int)(r % TP);
+    long b = r / TP;
+    int t = tp - pl;
+    float v = 0.f;
+    if (t >= 0 && t < T) v = src[(b * T + t) * C + c];
+    else if (mode == 1) v = src[(b * T + (t < 0 ? 0 : T - 1)) * C + c];
+    dst[i] = v;
+  }
+}
+
+__global__ void pad_edges_k(float* buf, int B, int T, int C, int pl, int pr, int mode) {
+  int TP = pl + T + pr, NE = pl + pr;
+  long n = (long)B * NE * C;
+  GS_LOOP(i, n) {
+    int c = (int)(i % C);
+    long r = i / C;
+    int e = (int)(r % NE);
+    long b = r / NE;
+    int tp = e < pl ? e : T + e;     // e >= pl -> pl + T + (e - pl)
+    int src_t = e < pl ? pl : pl + T - 1;
+    float v = mode == 1 ? buf[(b * TP + src_t) * C + c] : 0.f;
+    buf[(b * TP + tp) * C + c] = v;
+  }
+}
+
+__global__ void unpad_fold_k(float* dx, const float* dpad, int B, int T, int C, int pl, int pr, int mode) {
+  int TP = pl + T + pr;
+  long n = (long)B * T * C;
+  GS_LOOP(i, n) {
+    int c = (int)(i % C);
+    long r = i / C;
+    int t = (int)(r % T);
+    long b = r / T;
+    const float* d = dpad + (b * TP) * C + c;
+    float v = d[(long)(t + pl) * C];
+    if (mode == 1) {
+      if (t == 0) for (int q = 0; q < pl; ++q) v += d[(long)q * C];
+      if (t == T - 1) for (int q = 0; q < pr; ++q) v += d[(long)(pl + T + q) * C];
+    }
+    dx[i] = v;
+  }
+}
+
+__global__ void pack_conv_w_k(float* wf, float* wb, const float* w, int Co, int Ci, int Kw) {
+  long n = (long)Co * Ci * Kw;
+  GS_LOOP(i, n) {
+    int j = (int)(i % Kw);
+    long r = i / Kw;
+    int ci = (int)(r % Ci), co = (int)(r / Ci);
+    float v = w[i];
+    wf[((long)j * Ci + ci) * Co + co] = v;
+    if (wb) wb[((long)(Kw - 1 - j) * Co + co) * Ci + ci] = v;
+  }
+}
+
+__global__ void unpack_conv_dw_k(float* dw, const float* dwf, int Co, int Ci, int Kw) {
+  long n = (long)Co * Ci * Kw;
+  GS_LOOP(i, n) {
+    int j = (int)(i % Kw);
+    long r = i / Kw;
+    int ci = (int)(r % Ci), co = (int)(r / Ci);
+    dw[i] = dwf[((long)j * Ci + ci) * Co + co];
+  }
+}
+
+__global__ void add_rows_bcast_k(float* h, const float* table, int B, int L, int C) {
+  long n = (long)B * L * C, lc = (long)L * C;
+  GS_LOOP(i, n) h[i] += table[i % lc];
+}
+
+__global__ void meanpool_fwd_k(float* out, const float* f, int B, int L, int C) {
+  // block per (b, 64-col group); 4 row phases
+  __shared__ float red[4][64];
+  int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  int b = blockIdx.y, c = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (c < C)
+    for (int l = ph; l < L; l += 4) s += f[((long)b * L + l) * C + c];
+  red[ph][cl] = s;
+  __syncthreads();
+  if (ph == 0 && c < C) out[(long)b * C + c] = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)L;
+}
+
+__global__ void meanpool_bwd_k(float* df, const float* dout, int B, int L, int C) {
+  long n = (long)B * L * C;
+  GS_LOOP(i, n) {
+    int c = (int)(i % C);
+    long b = i / ((long)L * C);
+    df[i] = dout[b * C + c] / (float)L;
+  }
+}
+
+}  // namespace
+
+#define L1D(kernel, n, s, ...)                                                        \
+  do {                                                                                \
+    if ((n) > 0) {                                                                    \
+      hipLaunchKernelGGL(kernel, dim3(grid1d(n)), dim3(256), 0, s, __VA_ARGS__);      \
+      ZLAUNCH_CHECK(#kernel);                                                         \
+    }                                                                                 \
+  } while (0)
+
+int k_fill(float* p, long n, float v, hipStream_t s) { L1D(fill_k, n, s, p, n, v); return 0; }
+int k_copy(float* d, const float* src, long n, hipStream_t s) { L1D(copy_k, n, s, d, src, n); return 0; }
+int k_add_inplace(float* d, const float* src, long n, hipStream_t s) { L1D(add_k, n, s, d, src, n); return 0; }
+int k_act_bwd(float* dx, const float* dy, const float* y, long n, int act, float ys, hipStream_t s) {
+  L1D(act_bwd_k, n, s, dx, dy, y, n, act, ys);
+  return 0;
+}
+int k_dropout(float* x, long n, float p, uint64_t seed, hipStream_t s) {
+  if (p <= 0.f) return 0;
+  L1D(dropout_k, n, s, x, n, p, seed);
+  return 0;
+}
+int k_dropout_rows(float* x, int rows, int cols, long ld, long batch_rows, long batch_stride, float p,
+                   uint64_t seed, hipStream_t s) {
+  if (p <= 0.f) return 0;
+  long n = (long)rows * cols;
+  L1D(dropout_rows_k, n, s, x, rows, cols, ld, batch_rows, batch_stride, p, seed);
+  return 0;
+}
+int k_layernorm_fwd(float* y, const float* x, const float* res, const float* gamma, const float* beta,
+                    float* mean, float* rstd, int R, int C, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(layernorm_fwd_k, dim3(cdiv(R, 4)), dim3(256), 0, s, y, x, res, gamma, beta, mean, rstd, R,
+                     C, eps);
+  ZLAUNCH_CHECK("layernorm_fwd");
+  return 0;
+}
+int k_layernorm_bwd(float* dx, const float* dy, const float* x, const float* res, const float* gamma,
+                    const float* mean, const float* rstd, float* dgamma, float* dbeta, int R, int C,
+                    hipStream_t s) {
+  const int rpb = 64;
+  ZCHECK(C <= 512, "layernorm_bwd: C=%d > 512 unsupported", C);
+  if (C <= 128)
+    hipLaunchKernelGGL((layernorm_bwd_k<2>), dim3(cdiv(R, rpb)), dim3(256), 0, s, dx, dy, x, res, gamma, mean,
+                       rstd, dgamma, dbeta, R, C, rpb);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_k<8>), dim3(cdiv(R, rpb)), dim3(256), 0, s, dx, dy, x, res, gamma, mean,
+                       rstd, dgamma, dbeta, R, C, rpb);
+  ZLAUNCH_CHECK("layernorm_bwd");
+  return 0;
+}
+int k_softmax_fwd(float* P, float* Pd, const float* S, long R, int L, float p, uint64_t seed, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_fwd_k, dim3(cdiv(R, 4)), dim3(256), 0, s, P, Pd, S, R, L, p, seed);
+  ZLAUNCH_CHECK("softmax_fwd");
+  return 0;
+}
+int k_softmax_bwd(float* dS, const float* dPd, const float* P, long R, int L, float p, uint64_t seed,
+                  hipStream_t s) {
+  hipLaunchKernelGGL(softmax_bwd_k, dim3(cdiv(R, 4)), dim3(256), 0, s, dS, dPd, P, R, L, p, seed);
+  ZLAUNCH_CHECK("softmax_bwd");
+  return 0;
+}
+int k_colsum(float* out, const float* x, long R, int C, long ld, float beta, hipStream_t s) {
+  if (beta == 0.f) { ZTRY(k_fill(out, C, 0.f, s)); }
+  else if (beta != 1.f) { L1D(scale_k, (long)C, s, out, (long)C, beta); }
+  long rpb = 256;
+  dim3 grid(cdiv(C, 64), cdiv(R, rpb));
+  hipLaunchKernelGGL(colsum_k, grid, dim3(256), 0, s, out, x, R, C, ld, rpb);
+  ZLAUNCH_CHECK("colsum");
+  return 0;
+}
+int k_pad_rows(float* dst, const float* src, int B, int T, int C, int pl, int pr, int mode, hipStream_t s) {
+  long n = (long)B * (pl + T + pr) * C;
+  L1D(pad_rows_k, n, s, dst, src, B, T, C, pl, pr, mode);
+  return 0;
+}
+int k_pad_edges(float* buf, int B, int T, int C, int pl, int pr, int mode, hipStream_t s) {
+  long n = (long)B * (pl + pr) * C;
+  L1D(pad_edges_k, n, s, buf, B, T, C, pl, pr, mode);
+  return 0;
+}
+int k_unpad_fold(float* dx, const float* dpad, int B, int T, int C, int pl, int pr, int mode, hipStream_t s) {
+  long n = (long)B * T * C;
+  L1D(unpad_fold_k, n, s, dx, dpad, B, T, C, pl, pr, mode);
+  return 0;
+}
+int k_pack_conv_w(float* wf, float* wb, const float* w, int Co, int Ci, int Kw, hipStream_t s) {
+  long n = (long)Co * Ci * Kw;
+  L1D(pack_conv_w_k, n, s, wf, wb, w, Co, Ci, Kw);
+  return 0;
+}
+int k_unpack_conv_dw(float* dw, const float* dwf, int Co, int Ci, int Kw, hipStream_t s) {
+  long n = (long)Co * Ci * Kw;
+  L1D(unpack_conv_dw_k, n, s, dw, dwf, Co, Ci, Kw);
+  return 0;
+}
+int k_add_rows_bcast(float* h, const float* table, int B, int L, int C, hipStream_t s) {
+  long n = (long)B * L * C;
+  L1D(add_rows_bcast_k, n, s, h, table, B, L, C);
+  return 0;
+}
+int k_meanpool_fwd(float* out, const float* f, int B, int L, int C, hipStream_t s) {
+  hipLaunchKernelGGL(meanpool_fwd_k, dim3(cdiv(C, 64), B), dim3(256), 0, s, out, f, B, L, C);
+  ZLAUNCH_CHECK("meanpool_fwd");
+  return 0;
+}
+int k_meanpool_bwd(float* df, const float* dout, int B, int L, int C, hipStream_t s) {
+  long n = (long)B * L * C;
+  L1D(meanpool_bwd_k, n, s, df, dout, B, L, C);
+  return 0;
+}

@@ -1,0 +1,488 @@
+// Training loss of the reference (ZEGGS/train.py:276-421) and its analytic backward.
+//
+// Per (batch, frame) the loss needs: 2-axis -> rotation matrices, the first joint
+// moved to world space by the root transform, a 75-joint forward-kinematics pass
+// with linear/angular velocities (ZEGGS/anim/txform.py:10-34), then 17 weighted
+// mean-|difference| terms (4 of them on finite differences along time) and the KL
+// term.  All per-frame quantities are kept as a structure-of-arrays feature table
+// F[e][frame] so that the 64 lanes of a wave (= 64 consecutive frames) always touch
+// consecutive addresses; the FK chain is walked sequentially per frame (thread per
+// frame), the reductions run one block per (feature row, 256 frames).
+#include "../../include/zeggs_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+struct Off {
+  int rpos, rmat, rvel, rvrt, lpos, ltxy, lvel, lvrt, cpos, cmat, cvel, cvrt, gaze, n;
+};
+__host__ __device__ inline Off offsets(int J) {
+  Off o;
+  o.rpos = 0; o.rmat = 3; o.rvel = 12; o.rvrt = 15; o.lpos = 18; o.ltxy = 18 + 3 * J; o.lvel = 18 + 9 * J;
+  o.lvrt = 18 + 12 * J; o.cpos = 18 + 15 * J; o.cmat = 18 + 18 * J; o.cvel = 18 + 27 * J; o.cvrt = 18 + 30 * J;
+  o.gaze = 18 + 33 * J; o.n = 21 + 33 * J;
+  return o;
+}
+
+struct LossWs {
+  float *FO, *FW, *LM, *G, *DQ;
+};
+LossWs carve_loss(const ZeggsLossDims& d, Arena& a) {
+  LossWs w;
+  const long NF = (long)d.B * d.T;
+  const Off o = offsets(d.J);
+  w.FO = a.f(NF * o.n); w.FW = a.f(NF * o.n); w.LM = a.f(NF * 9 * d.J); w.G = a.f(NF * o.n); w.DQ = a.f(NF * 4);
+  return w;
+}
+
+struct M3 { float m[9]; };   // row-major
+__device__ __forceinline__ V3 mv(const M3& a, V3 v) {
+  return v3(a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z,
+            a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z);
+}
+__device__ __forceinline__ V3 mtv(const M3& a, V3 v) {   // a^T v
+  return v3(a.m[0] * v.x + a.m[3] * v.y + a.m[6] * v.z, a.m[1] * v.x + a.m[4] * v.y + a.m[7] * v.z,
+            a.m[2] * v.x + a.m[5] * v.y + a.m[8] * v.z);
+}
+__device__ __forceinline__ M3 mm(const M3& a, const M3& b) {
+  M3 c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c.m[i * 3 + j] = a.m[i * 3] * b.m[j] + a.m[i * 3 + 1] * b.m[3 + j] + a.m[i * 3 + 2] * b.m[6 + j];
+  return c;
+}
+__device__ __forceinline__ M3 mtm(const M3& a, const M3& b) {   // a^T b
+  M3 c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c.m[i * 3 + j] = a.m[i] * b.m[j] + a.m[3 + i] * b.m[3 + j] + a.m[6 + i] * b.m[6 + j];
+  return c;
+}
+__device__ __forceinline__ M3 mmt(const M3& a, const M3& b) {   // a b^T
+  M3 c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c.m[i * 3 + j] = a.m[i * 3] * b.m[j * 3] + a.m[i * 3 + 1] * b.m[j * 3 + 1] + a.m[i * 3 + 2] * b.m[j * 3 + 2];
+  return c;
+}
+__device__ __forceinline__ void add_outer(M3& g, V3 a, V3 b) {   // g += a b^T
+  g.m[0] += a.x * b.x; g.m[1] += a.x * b.y; g.m[2] += a.x * b.z;
+  g.m[3] += a.y * b.x; g.m[4] += a.y * b.y; g.m[5] += a.y * b.z;
+  g.m[6] += a.z * b.x; g.m[7] += a.z * b.y; g.m[8] += a.z * b.z;
+}
+// reference anim/tquat.py:54-69
+__device__ __forceinline__ M3 quat_to_xform(Q4 q) {
+  float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+  float xx = q.x * x2, yy = q.y * y2, wx = q.w * x2;
+  float xy = q.x * y2, yz = q.y * z2, wy = q.w * y2;
+  float xz = q.x * z2, zz = q.z * z2, wz = q.w * z2;
+  M3 r;
+  r.m[0] = 1.0f - (yy + zz); r.m[1] = xy - wz; r.m[2] = xz + wy;
+  r.m[3] = xy + wz; r.m[4] = 1.0f - (xx + zz); r.m[5] = yz - wx;
+  r.m[6] = xz - wy; r.m[7] = yz + wx; r.m[8] = 1.0f - (xx + yy);
+  return r;
+}
+__device__ __forceinline__ Q4 quat_to_xform_bwd(Q4 q, const M3& g) {
+  const float* m = g.m;   // g00 g01 g02 g10 g11 g12 g20 g21 g22
+  Q4 d;
+  d.w = 2.f * (-q.z * m[1] + q.y * m[2] + q.z * m[3] - q.x * m[5] - q.y * m[6] + q.x * m[7]);
+  d.x = 2.f * (q.y * m[1] + q.z * m[2] + q.y * m[3] - 2.f * q.x * m[4] - q.w * m[5] + q.z * m[6] + q.w * m[7] - 2.f * q.x * m[8]);
+  d.y = 2.f * (-2.f * q.y * m[0] + q.x * m[1] + q.w * m[2] + q.x * m[3] + q.z * m[5] - q.w * m[6] + q.z * m[7] - 2.f * q.y * m[8]);
+  d.z = 2.f * (-2.f * q.z * m[0] - q.w * m[1] + q.x * m[2] + q.w * m[3] - 2.f * q.z * m[4] + q.y * m[5] + q.x * m[6] + q.y * m[7]);
+  return d;
+}
+__device__ __forceinline__ void qmv_bwd(Q4 q, V3 v, V3 g, Q4& dq, V3& dv) {
+  V3 qv = v3(q.x, q.y, q.z);
+  V3 t = 2.0f * cross(qv, v);
+  float dw = dot(g, t);
+  V3 dt = q.w * g + cross(g, qv);
+  V3 dqv = cross(t, g) + 2.0f * cross(v, dt);
+  dv = g + 2.0f * cross(dt, qv);
+  dq = Q4{dw, dqv.x, dqv.y, dqv.z};
+}
+__device__ __forceinline__ float vnorm(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+// grad of a/(|a|+e) wrt a, upstream g
+__device__ __forceinline__ V3 normalize_bwd(V3 a, V3 g, float e) {
+  float n = vnorm(a), ne = n + e;
+  float k = n > 0.f ? dot(a, g) / (n * ne * ne) : 0.f;
+  return (1.f / ne) * g - k * a;
+}
+
+struct FrameIO {
+  const float *pose, *rpos, *rrot;   // [B,T,*]
+};
+
+#define FE(F, e) (F)[(long)(e) * NF + f]
+
+// forward per frame; side 0 = prediction (also stores local matrices LM), side 1 = ground truth
+__global__ __launch_bounds__(64) void loss_frame_fwd_k(ZeggsLossDims d, const int* parents, FrameIO io0, FrameIO io1,
+                                                        const float* gaze, float* F0, float* F1, float* LM) {
+  const long NF = (long)d.B * d.T;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * NF) return;
+  const int side = gid >= NF;
+  const long f = side ? gid - NF : gid;
+  const FrameIO io = side ? io1 : io0;
+  float* F = side ? F1 : F0;
+  const int J = d.J, t = (int)(f % d.T);
+  const Off o = offsets(J);
+  const int PO = 6 + 15 * J;
+  const float* p = io.pose + f * PO;
+  const float* rq = io.rrot + f * 4;
+  const float* rqp = io.rrot + (t > 0 ? f - 1 : f) * 4;
+  Q4 q = Q4{rq[0], rq[1], rq[2], rq[3]}, qp = Q4{rqp[0], rqp[1], rqp[2], rqp[3]};
+  V3 rpos = v3(io.rpos[f * 3], io.rpos[f * 3 + 1], io.rpos[f * 3 + 2]);
+  V3 rvel = quat_mul_vec(qp, v3(p[0], p[1], p[2]));
+  V3 rvrt = quat_mul_vec(qp, v3(p[3], p[4], p[5]));
+  M3 R = quat_to_xform(q);
+  FE(F, o.rpos) = rpos.x; FE(F, o.rpos + 1) = rpos.y; FE(F, o.rpos + 2) = rpos.z;
+  for (int k = 0; k < 9; ++k) FE(F, o.rmat + k) = R.m[k];
+  FE(F, o.rvel) = rvel.x; FE(F, o.rvel + 1) = rvel.y; FE(F, o.rvel + 2) = rvel.z;
+  FE(F, o.rvrt) = rvrt.x; FE(F, o.rvrt + 1) = rvrt.y; FE(F, o.rvrt + 2) = rvrt.z;
+  {
+    const float* gz = gaze + f * 3;
+    V3 v = v3(gz[0], gz[1], gz[2]) - rpos;
+    float inv = 1.f / (vnorm(v) + 1e-8f);
+    V3 gd = quat_mul_vec(quat_inv(q), inv * v);
+    FE(F, o.gaze) = gd.x; FE(F, o.gaze + 1) = gd.y; FE(F, o.gaze + 2) = gd.z;
+  }
+  const float *lpos = p + 6, *ltxy = p + 6 + 3 * J, *lvel = p + 6 + 9 * J, *lvrt = p + 6 + 12 * J;
+  for (int i = 0; i < J; ++i) {
+    // orthogonalise (txform.py:23-34): columns x^, y^, z^
+    V3 x = v3(ltxy[6 * i], ltxy[6 * i + 1], ltxy[6 * i + 2]), yi = v3(ltxy[6 * i + 3], ltxy[6 * i + 4], ltxy[6 * i + 5]);
+    for (int k = 0; k < 6; ++k) FE(F, o.ltxy + 6 * i + k) = ltxy[6 * i + k];
+    V3 z = cross(x, yi), y = cross(z, x);
+    V3 xn = (1.f / (vnorm(x) + 1e-10f)) * x, yn = (1.f / (vnorm(y) + 1e-10f)) * y, zn = (1.f / (vnorm(z) + 1e-10f)) * z;
+    M3 L;
+    L.m[0] = xn.x; L.m[1] = yn.x; L.m[2] = zn.x;
+    L.m[3] = xn.y; L.m[4] = yn.y; L.m[5] = zn.y;
+    L.m[6] = xn.z; L.m[7] = yn.z; L.m[8] = zn.z;
+    if (side == 0)
+      for (int k = 0; k < 9; ++k) FE(LM, 9 * i + k) = L.m[k];
+    V3 lp = v3(lpos[3 * i], lpos[3 * i + 1], lpos[3 * i + 2]);
+    V3 lv = v3(lvel[3 * i], lvel[3 * i + 1], lvel[3 * i + 2]);
+    V3 lw = v3(lvrt[3 * i], lvrt[3 * i + 1], lvrt[3 * i + 2]);
+    M3 cm; V3 cp, cv, cw;
+    if (i == 0) {                               // train.py:296-303: first joint to world space
+      V3 rl = quat_mul_vec(q, lp);
+      cp = rl + rpos;
+      cm = mm(R, L);
+      cv = rvel + quat_mul_vec(q, lv) + cross(rvrt, rl);
+      cw = rvrt + quat_mul_vec(q, lw);
+      lp = cp; lv = cv; lw = cw;               // the "local" loss terms use the replaced joint 0 (train.py:305-308)
+    } else {
+      const int pa = parents[i];
+      M3 pm; V3 pp, pv, pw;
+      for (int k = 0; k < 9; ++k) pm.m[k] = FE(F, o.cmat + 9 * pa + k);
+      pp = v3(FE(F, o.cpos + 3 * pa), FE(F, o.cpos + 3 * pa + 1), FE(F, o.cpos + 3 * pa + 2));
+      pv = v3(FE(F, o.cvel + 3 * pa), FE(F, o.cvel + 3 * pa + 1), FE(F, o.cvel + 3 * pa + 2));
+      pw = v3(FE(F, o.cvrt + 3 * pa), FE(F, o.cvrt + 3 * pa + 1), FE(F, o.cvrt + 3 * pa + 2));
+      V3 rp = mv(pm, lp);
+      cp = pp + rp;
+      cm = mm(pm, L);
+      cw = pw + mv(pm, lw);
+      cv = pv + mv(pm, lv) + cross(pw, rp);
+    }
+    FE(F, o.lpos + 3 * i) = lp.x; FE(F, o.lpos + 3 * i + 1) = lp.y; FE(F, o.lpos + 3 * i + 2) = lp.z;
+    FE(F, o.lvel + 3 * i) = lv.x; FE(F, o.lvel + 3 * i + 1) = lv.y; FE(F, o.lvel + 3 * i + 2) = lv.z;
+    FE(F, o.lvrt + 3 * i) = lw.x; FE(F, o.lvrt + 3 * i + 1) = lw.y; FE(F, o.lvrt + 3 * i + 2) = lw.z;
+    FE(F, o.cpos + 3 * i) = cp.x; FE(F, o.cpos + 3 * i + 1) = cp.y; FE(F, o.cpos + 3 * i + 2) = cp.z;
+    FE(F, o.cvel + 3 * i) = cv.x; FE(F, o.cvel + 3 * i + 1) = cv.y; FE(F, o.cvel + 3 * i + 2) = cv.z;
+    FE(F, o.cvrt + 3 * i) = cw.x; FE(F, o.cvrt + 3 * i + 1) = cw.y; FE(F, o.cvrt + 3 * i + 2) = cw.z;
+    for (int k = 0; k < 9; ++k) FE(F, o.cmat + 9 * i + k) = cm.m[k];
+  }
+}
+
+// term of a feature row e: id/weight of the plain term and of the finite-difference term (id2 < 0: none)
+__device__ __forceinline__ void term_of(int e, int J, int& id, float& w, int& id2, float& w2, int& size) {
+  const Off o = offsets(J);
+  id2 = -1; w2 = 0.f;
+  if (e < o.rmat) { id = 0; w = 0.1f; size = 3; }
+  else if (e < o.rvel) { id = 1; w = 10.f; size = 9; }
+  else if (e < o.rvrt) { id = 2; w = 0.1f; size = 3; }
+  else if (e < o.lpos) { id = 3; w = 5.f; size = 3; }
+  else if (e < o.ltxy) { id = 4; w = 15.f; size = 3 * J; id2 = 12; w2 = 7.f; }
+  else if (e < o.lvel) { id = 5; w = 15.f; size = 6 * J; id2 = 13; w2 = 8.f; }
+  else if (e < o.lvrt) { id = 6; w = 10.f; size = 3 * J; }
+  else if (e < o.cpos) { id = 7; w = 7.f; size = 3 * J; }
+  else if (e < o.cmat) { id = 8; w = 0.1f; size = 3 * J; id2 = 14; w2 = 0.06f; }
+  else if (e < o.cvel) { id = 9; w = 3.f; size = 9 * J; id2 = 15; w2 = 1.25f; }
+  else if (e < o.cvrt) { id = 10; w = 0.06f; size = 3 * J; }
+  else if (e < o.gaze) { id = 11; w = 1.25f; size = 3 * J; }
+  else { id = 16; w = 10.f; size = 3; }
+}
+
+__device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+// one block = one feature row e x 256 consecutive frames; writes G = dLoss/dF_O and accumulates the terms
+__global__ __launch_bounds__(256) void loss_terms_k(ZeggsLossDims d, const float* FO, const float* FW, float* G,
+                                                     float* terms, float gscale) {
+  __shared__ float red[16];
+  const long NF = (long)d.B * d.T;
+  const int e = blockIdx.y;
+  const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int id, id2, size; float w, w2;
+  term_of(e, d.J, id, w, id2, w2, size);
+  float s1 = 0.f, s2 = 0.f, g = 0.f;
+  if (f < NF) {
+    const int t = (int)(f % d.T);
+    const float n1 = (float)d.B * d.T * size, n2 = (float)d.B * (d.T - 1) * size;
+    const float o0 = FE(FO, e), w0 = FE(FW, e);
+    const float v = w * (o0 - w0);
+    s1 = fabsf(v) / n1;
+    g = w * sgn(v) / n1;
+    if (id2 >= 0 && d.T > 1) {
+      if (t + 1 < d.T) {
+        float dd = w2 * ((FO[(long)e * NF + f + 1] - o0) / d.dt - (FW[(long)e * NF + f + 1] - w0) / d.dt);
+        s2 = fabsf(dd) / n2;
+        g -= w2 * sgn(dd) / (d.dt * n2);
+      }
+      if (t > 0) {
+        float dd = w2 * ((o0 - FO[(long)e * NF + f - 1]) / d.dt - (w0 - FW[(long)e * NF + f - 1]) / d.dt);
+        g += w2 * sgn(dd) / (d.dt * n2);
+      }
+    }
+    FE(G, e) = g * gscale / 18.0f;
+  }
+  s1 = block_sum(s1, red);
+  if (id2 >= 0) s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(terms + id, s1);
+    if (id2 >= 0) atomicAdd(terms + id2, s2);
+  }
+}
+
+// backward through FK / first-joint transform / orthogonalisation (prediction side), thread per frame.
+// Consumes G in place (its c* rows become running totals).  Writes dpose[6:], drpos, DQ (grad wrt rrot_f from
+// everything except the root-velocity rotation) and leaves total grads wrt rvel/rvrt in G's rvel/rvrt rows.
+__global__ __launch_bounds__(64) void loss_frame_bwd_k(ZeggsLossDims d, const int* parents, FrameIO io, const float* gaze,
+                                                        const float* F, const float* LM, float* G, float* dpose,
+                                                        float* drpos, float* DQ) {
+  const long NF = (long)d.B * d.T;
+  const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= NF) return;
+  const int J = d.J;
+  const Off o = offsets(J);
+  const int PO = 6 + 15 * J;
+  const float* p = io.pose + f * PO;
+  float* dp = dpose + f * PO;
+  const float* rq = io.rrot + f * 4;
+  Q4 q = Q4{rq[0], rq[1], rq[2], rq[3]};
+  V3 rpos = v3(io.rpos[f * 3], io.rpos[f * 3 + 1], io.rpos[f * 3 + 2]);
+  const float *lpos = p + 6, *ltxy = p + 6 + 3 * J, *lvel = p + 6 + 9 * J, *lvrt = p + 6 + 12 * J;
+  float *dlpos = dp + 6, *dltxy = dp + 6 + 3 * J, *dlvel = dp + 6 + 9 * J, *dlvrt = dp + 6 + 12 * J;
+  auto ld3 = [&](const float* A, int e) { return v3(A[(long)e * NF + f], A[(long)(e + 1) * NF + f], A[(long)(e + 2) * NF + f]); };
+  auto st3 = [&](float* A, int e, V3 v) { A[(long)e * NF + f] = v.x; A[(long)(e + 1) * NF + f] = v.y; A[(long)(e + 2) * NF + f] = v.z; };
+  auto ld9 = [&](const float* A, int e) { M3 m; for (int k = 0; k < 9; ++k) m.m[k] = A[(long)(e + k) * NF + f]; return m; };
+  auto st9 = [&](float* A, int e, const M3& m) { for (int k = 0; k < 9; ++k) A[(long)(e + k) * NF + f] = m.m[k]; };
+
+  // orthogonalisation backward for joint i given the grad of its local matrix; adds the direct ltxy-term grad
+  auto orth_bwd = [&](int i, const M3& gL) {
+    V3 x = v3(ltxy[6 * i], ltxy[6 * i + 1], ltxy[6 * i + 2]), yi = v3(ltxy[6 * i + 3], ltxy[6 * i + 4], ltxy[6 * i + 5]);
+    V3 z = cross(x, yi), y = cross(z, x);
+    V3 gxn = v3(gL.m[0], gL.m[3], gL.m[6]), gyn = v3(gL.m[1], gL.m[4], gL.m[7]), gzn = v3(gL.m[2], gL.m[5], gL.m[8]);
+    V3 gx = normalize_bwd(x, gxn, 1e-10f);
+    V3 gy = normalize_bwd(y, gyn, 1e-10f);
+    V3 gz = normalize_bwd(z, gzn, 1e-10f);
+    gz = gz + cross(x, gy);          // y = z x x
+    gx = gx + cross(gy, z);
+    gx = gx + cross(yi, gz);         // z = x x yi
+    V3 gyi = cross(gz, x);
+    dltxy[6 * i] = gx.x + FE(G, o.ltxy + 6 * i); dltxy[6 * i + 1] = gx.y + FE(G, o.ltxy + 6 * i + 1);
+    dltxy[6 * i + 2] = gx.z + FE(G, o.ltxy + 6 * i + 2);
+    dltxy[6 * i + 3] = gyi.x + FE(G, o.ltxy + 6 * i + 3); dltxy[6 * i + 4] = gyi.y + FE(G, o.ltxy + 6 * i + 4);
+    dltxy[6 * i + 5] = gyi.z + FE(G, o.ltxy + 6 * i + 5);
+  };
+
+  for (int i = J - 1; i >= 1; --i) {
+    const int pa = parents[i];
+    M3 pm = ld9(F, o.cmat + 9 * pa);
+    V3 pw = ld3(F, o.cvrt + 3 * pa);
+    V3 lp = v3(lpos[3 * i], lpos[3 * i + 1], lpos[3 * i + 2]);
+    V3 lv = v3(lvel[3 * i], lvel[3 * i + 1], lvel[3 * i + 2]);
+    V3 lw = v3(lvrt[3 * i], lvrt[3 * i + 1], lvrt[3 * i + 2]);
+    M3 L = ld9(LM, 9 * i);
+    V3 rp = mv(pm, lp);
+    V3 gcp = ld3(G, o.cpos + 3 * i), gcv = ld3(G, o.cvel + 3 * i), gcw = ld3(G, o.cvrt + 3 * i);
+    M3 gcm = ld9(G, o.cmat + 9 * i);
+    // parents' running totals
+    M3 gpm = ld9(G, o.cmat + 9 * pa);
+    V3 gpp = ld3(G, o.cpos + 3 * pa), gpv = ld3(G, o.cvel + 3 * pa), gpw = ld3(G, o.cvrt + 3 * pa);
+    // cvel_i = cvel_p + pm lv + pw x rp
+    gpv = gpv + gcv;
+    add_outer(gpm, gcv, lv);
+    V3 glv = mtv(pm, gcv);
+    gpw = gpw + cross(rp, gcv);
+    V3 grp = cross(gcv, pw);
+    // cvrt_i = cvrt_p + pm lw
+    gpw = gpw + gcw;
+    add_outer(gpm, gcw, lw);
+    V3 glw = mtv(pm, gcw);
+    // cmat_i = pm L
+    M3 t1 = mmt(gcm, L);
+    for (int k = 0; k < 9; ++k) gpm.m[k] += t1.m[k];
+    M3 gL = mtm(pm, gcm);
+    // cpos_i = cpos_p + rp
+    gpp = gpp + gcp;
+    grp = grp + gcp;
+    add_outer(gpm, grp, lp);
+    V3 glp = mtv(pm, grp);
+    st9(G, o.cmat + 9 * pa, gpm);
+    st3(G, o.cpos + 3 * pa, gpp); st3(G, o.cvel + 3 * pa, gpv); st3(G, o.cvrt + 3 * pa, gpw);
+    // local features (direct "local" loss terms + FK)
+    V3 a = glp + ld3(G, o.lpos + 3 * i);
+    dlpos[3 * i] = a.x; dlpos[3 * i + 1] = a.y; dlpos[3 * i + 2] = a.z;
+    a = glv + ld3(G, o.lvel + 3 * i);
+    dlvel[3 * i] = a.x; dlvel[3 * i + 1] = a.y; dlvel[3 * i + 2] = a.z;
+    a = glw + ld3(G, o.lvrt + 3 * i);
+    dlvrt[3 * i] = a.x; dlvrt[3 * i + 1] = a.y; dlvrt[3 * i + 2] = a.z;
+    orth_bwd(i, gL);
+  }
+  // ---- joint 0: world-space replacement (train.py:296-308)
+  {
+    V3 rvrt = ld3(F, o.rvrt);
+    M3 R = quat_to_xform(q);
+    M3 L = ld9(LM, 0);
+    V3 lp = v3(lpos[0], lpos[1], lpos[2]), lv = v3(lvel[0], lvel[1], lvel[2]), lw = v3(lvrt[0], lvrt[1], lvrt[2]);
+    V3 rl = quat_mul_vec(q, lp);
+    V3 gcp = ld3(G, o.cpos) + ld3(G, o.lpos);      // joint 0 appears in the c* and in the "local" terms
+    V3 gcv = ld3(G, o.cvel) + ld3(G, o.lvel);
+    V3 gcw = ld3(G, o.cvrt) + ld3(G, o.lvrt);
+    M3 gcm = ld9(G, o.cmat);
+    V3 g_rpos = ld3(G, o.rpos) + gcp;
+    V3 g_rvel = ld3(G, o.rvel) + gcv;
+    V3 g_rvrt = ld3(G, o.rvrt) + gcw + cross(rl, gcv);
+    V3 g_rl = gcp + cross(gcv, rvrt);
+    Q4 dq = Q4{0.f, 0.f, 0.f, 0.f}, dqt; V3 dv;
+    qmv_bwd(q, lp, g_rl, dqt, dv);
+    dq.w += dqt.w; dq.x += dqt.x; dq.y += dqt.y; dq.z += dqt.z;
+    dlpos[0] = dv.x; dlpos[1] = dv.y; dlpos[2] = dv.z;
+    qmv_bwd(q, lv, gcv, dqt, dv);
+    dq.w += dqt.w; dq.x += dqt.x; dq.y += dqt.y; dq.z += dqt.z;
+    dlvel[0] = dv.x; dlvel[1] = dv.y; dlvel[2] = dv.z;
+    qmv_bwd(q, lw, gcw, dqt, dv);
+    dq.w += dqt.w; dq.x += dqt.x; dq.y += dqt.y; dq.z += dqt.z;
+    dlvrt[0] = dv.x; dlvrt[1] = dv.y; dlvrt[2] = dv.z;
+    // lmat0w = R L
+    M3 gR = mmt(gcm, L);
+    M3 gL = mtm(R, gcm);
+    orth_bwd(0, gL);
+    M3 gRm = ld9(G, o.rmat);
+    for (int k = 0; k < 9; ++k) gR.m[k] += gRm.m[k];
+    dqt = quat_to_xform_bwd(q, gR);
+    dq.w += dqt.w; dq.x += dqt.x; dq.y += dqt.y; dq.z += dqt.z;
+    // gaze direction: gd = qmv(q^-1, n), n = v/(|v|+1e-8), v = gaze - rpos
+    const float* gz = gaze + f * 3;
+    V3 v = v3(gz[0], gz[1], gz[2]) - rpos;
+    float inv = 1.f / (vnorm(v) + 1e-8f);
+    V3 dn;
+    qmv_bwd(quat_inv(q), inv * v, ld3(G, o.gaze), dqt, dn);
+    dq.w += dqt.w; dq.x -= dqt.x; dq.y -= dqt.y; dq.z -= dqt.z;
+    g_rpos = g_rpos - normalize_bwd(v, dn, 1e-8f);
+    drpos[f * 3] = g_rpos.x; drpos[f * 3 + 1] = g_rpos.y; drpos[f * 3 + 2] = g_rpos.z;
+    DQ[f * 4] = dq.w; DQ[f * 4 + 1] = dq.x; DQ[f * 4 + 2] = dq.y; DQ[f * 4 + 3] = dq.z;
+    st3(G, o.rvel, g_rvel);
+    st3(G, o.rvrt, g_rvrt);
+  }
+}
+
+// root velocities are rotated by the PREVIOUS frame's root rotation (train.py:281-286): finish dpose[0:6], drrot
+__global__ void loss_rootvel_bwd_k(ZeggsLossDims d, FrameIO io, const float* G, const float* DQ, float* dpose,
+                                   float* drrot) {
+  const long NF = (long)d.B * d.T;
+  const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= NF) return;
+  const int t = (int)(f % d.T), J = d.J, PO = 6 + 15 * J;
+  const Off o = offsets(J);
+  auto ldq = [&](long fr) { const float* r = io.rrot + fr * 4; return Q4{r[0], r[1], r[2], r[3]}; };
+  auto ld3 = [&](int e, long fr) { return v3(G[(long)e * NF + fr], G[(long)(e + 1) * NF + fr], G[(long)(e + 2) * NF + fr]); };
+  Q4 acc = Q4{DQ[f * 4], DQ[f * 4 + 1], DQ[f * 4 + 2], DQ[f * 4 + 3]};
+  // own frame: value-gradient (and the quaternion gradient when the frame rotates itself, t == 0)
+  {
+    const float* p = io.pose + f * PO;
+    Q4 qp = ldq(t > 0 ? f - 1 : f);
+    Q4 dq1, dq2; V3 dv1, dv2;
+    qmv_bwd(qp, v3(p[0], p[1], p[2]), ld3(o.rvel, f), dq1, dv1);
+    qmv_bwd(qp, v3(p[3], p[4], p[5]), ld3(o.rvrt, f), dq2, dv2);
+    float* dp = dpose + f * PO;
+    dp[0] = dv1.x; dp[1] = dv1.y; dp[2] = dv1.z; dp[3] = dv2.x; dp[4] = dv2.y; dp[5] = dv2.z;
+    if (t == 0) { acc.w += dq1.w + dq2.w; acc.x += dq1.x + dq2.x; acc.y += dq1.y + dq2.y; acc.z += dq1.z + dq2.z; }
+  }
+  if (t + 1 < d.T) {   // the next frame's velocities are rotated by this frame's rotation
+    const float* p = io.pose + (f + 1) * PO;
+    Q4 q = ldq(f), dq1, dq2; V3 dv;
+    qmv_bwd(q, v3(p[0], p[1], p[2]), ld3(o.rvel, f + 1), dq1, dv);
+    qmv_bwd(q, v3(p[3], p[4], p[5]), ld3(o.rvrt, f + 1), dq2, dv);
+    acc.w += dq1.w + dq2.w; acc.x += dq1.x + dq2.x; acc.y += dq1.y + dq2.y; acc.z += dq1.z + dq2.z;
+  }
+  drrot[f * 4] = acc.w; drrot[f * 4 + 1] = acc.x; drrot[f * 4 + 2] = acc.y; drrot[f * 4 + 3] = acc.z;
+}
+
+// KL term (modules.py:778-779) + final sum/18 (train.py:402-421); one block
+__global__ __launch_bounds__(256) void loss_kl_final_k(const float* mu, const float* logvar, int n, int B, float klw,
+                                                        float* terms, float* dmu, float* dlogvar, float gscale) {
+  __shared__ float red[16];
+  float s = 0.f;
+  if (mu && klw > 0.f) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      float m = mu[i], lv = logvar[i], ev = expf(lv);
+      s += 1.f + lv - m * m - ev;
+      dmu[i] = klw * m / (float)n * gscale / 18.0f;
+      dlogvar[i] = klw * -0.5f * (1.f - ev) / (float)n * gscale / 18.0f;
+    }
+  } else if (dmu) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { dmu[i] = 0.f; dlogvar[i] = 0.f; }
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    float kl = (mu && klw > 0.f) ? klw * (-0.5f * s / (float)n) : 0.f;
+    terms[17] = kl;
+    float tot = 0.f;
+    for (int i = 0; i < 18; ++i) tot += terms[i];
+    terms[18] = tot / 18.0f;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t zeggs_loss_workspace_bytes(const ZeggsLossDims* d) {
+  Arena a(nullptr, 0);
+  carve_loss(*d, a);
+  return a.off + 256;
+}
+
+extern "C" int zeggs_loss_fwd_bwd(const ZeggsLossDims* dp, const int* parents, const float* o_pose, const float* o_rpos,
+                                  const float* o_rrot, const float* w_pose, const float* w_rpos, const float* w_rrot,
+                                  const float* gaze, const float* mu, const float* logvar, float kl_weight, float* terms,
+                                  float* dpose, float* drpos, float* drrot, float* dmu, float* dlogvar, float gscale,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  const ZeggsLossDims& d = *dp;
+  hipStream_t s = (hipStream_t)stream;
+  Arena a(ws, ws_bytes);
+  LossWs w = carve_loss(d, a);
+  ZCHECK(a.ok(), "loss: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  ZCHECK(d.J >= 1 && d.T >= 1 && d.B >= 1, "loss: bad dims");
+  const long NF = (long)d.B * d.T;
+  const Off o = offsets(d.J);
+  FrameIO ioO{o_pose, o_rpos, o_rrot}, ioW{w_pose, w_rpos, w_rrot};
+  ZTRY(k_fill(terms, 19, 0.f, s));
+  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(2 * NF, 64)), dim3(64), 0, s, d, parents, ioO, ioW, gaze, w.FO, w.FW, w.LM);
+  ZLAUNCH_CHECK("loss_frame_fwd");
+  hipLaunchKernelGGL(loss_terms_k, dim3(cdiv(NF, 256), o.n), dim3(256), 0, s, d, w.FO, w.FW, w.G, terms, gscale);
+  ZLAUNCH_CHECK("loss_terms");
+  hipLaunchKernelGGL(loss_kl_final_k, dim3(1), dim3(256), 0, s, mu, logvar, d.B * d.S, d.B, kl_weight, terms, dmu, dlogvar,
+                     gscale);
+  ZLAUNCH_CHECK("loss_kl_final");
+  if (dpose) {
+    hipLaunchKernelGGL(loss_frame_bwd_k, dim3(cdiv(NF, 64)), dim3(64), 0, s, d, parents, ioO, gaze, w.FO, w.LM, w.G, dpose,
+                       drpos, w.DQ);
+    ZLAUNCH_CHECK("loss_frame_bwd");
+    hipLaunchKernelGGL(loss_rootvel_bwd_k, dim3(cdiv(NF, 256)), dim3(256), 0, s, d, ioO, w.G, w.DQ, dpose, drrot);
+    ZLAUNCH_CHECK("loss_rootvel_bwd");
+  }
+  return 0;
+}

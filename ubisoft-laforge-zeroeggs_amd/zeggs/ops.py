@@ -1,1 +1,409 @@
-"""placeholder -- replaced by the ctypes/autograd bridge"""
+"""ctypes binding of libzeggs_hip.so (C ABI: include/zeggs_hip.h) + autograd glue.
+
+PyTorch is used here only as plumbing: device memory (tensors), the current HIP
+stream and autograd bookkeeping.  Every arithmetic op of the hot path is a call
+into the hand-written gfx950 library.  There is deliberately NO fallback: if the
+shared library is missing or a tensor is not on a GPU, these functions raise.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+_LIB = None
+_LIB_PATH = Path(__file__).resolve().parent / "libzeggs_hip.so"
+c_f = C.c_void_p  # device pointers are passed as raw addresses
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+# ----------------------------------------------------------------------------- structs (mirror zeggs_hip.h)
+class SpeechDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("F", C.c_int), ("H", C.c_int), ("O", C.c_int), ("KW", C.c_int),
+                ("dropout_p", C.c_float), ("seed", C.c_uint64)]
+
+
+class StyleDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int), ("E", C.c_int), ("NH", C.c_int),
+                ("dropout", C.c_int), ("seed", C.c_uint64)]
+
+
+class DecDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("PI", C.c_int), ("PO", C.c_int), ("SP", C.c_int), ("ST", C.c_int),
+                ("H", C.c_int), ("dt", C.c_float)]
+
+
+class LossDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("J", C.c_int), ("S", C.c_int), ("dt", C.c_float)]
+
+
+def _ptr_struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": [(f, C.c_void_p) for f in fields]})
+
+
+SPEECH_FIELDS = ("w0", "b0", "w1", "b1", "w2", "b2")
+STYLE_FIELDS = ("c0_w", "c0_b", "ln0_g", "ln0_b", "c4_w", "c4_b", "ln1_g", "ln1_b", "in_w", "in_b", "out_w", "out_b",
+                "lna_g", "lna_b", "ff0_w", "ff0_b", "ff2_w", "ff2_b", "lnf_g", "lnf_b")
+DEC_FIELDS = ("l0_w", "l0_b", "w_ih0", "w_hh0", "b_ih0", "b_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1", "l2_w", "l2_b",
+              "c0_w", "c0_b", "c1_w", "c1_b", "c2_w", "c2_b")
+SpeechPtrs = _ptr_struct("SpeechPtrs", SPEECH_FIELDS)
+StylePtrs = _ptr_struct("StylePtrs", STYLE_FIELDS)
+DecPtrs = _ptr_struct("DecPtrs", DEC_FIELDS)
+DecStats = _ptr_struct("DecStats", ("in_mean", "in_std", "out_mean", "out_std"))
+
+
+def lib():
+    """Load the HIP library (built by __graft_entry__.build() / csrc/build.sh)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not _LIB_PATH.exists():
+        raise HipLibraryMissing(
+            f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The ZeroEGGS MI355X engine has no CPU fallback.")
+    L = C.CDLL(str(_LIB_PATH))
+    L.zeggs_last_error.restype = C.c_char_p
+    for n in ("zeggs_speech_encoder_workspace_bytes", "zeggs_style_encoder_workspace_bytes",
+              "zeggs_decoder_workspace_bytes", "zeggs_loss_workspace_bytes"):
+        getattr(L, n).restype = C.c_size_t
+    _LIB = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what}: {lib().zeggs_last_error().decode()}")
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("zeggs.ops: tensor is not on a GPU (the HIP engine has no CPU path)")
+    if t.dtype not in (torch.float32, torch.int64, torch.int32, torch.uint8):
+        raise RuntimeError(f"zeggs.ops: unsupported dtype {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("zeggs.ops: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+_seed_rng = np.random.default_rng(0x5EED)
+
+
+def next_seed():
+    return int(_seed_rng.integers(1, 2 ** 62))
+
+
+def manual_seed(s):
+    """Seed of the dropout-mask stream (counter-based hash inside the kernels)."""
+    global _seed_rng
+    _seed_rng = np.random.default_rng(int(s))
+
+
+def _ptrs(cls, fields, tensors):
+    s = cls()
+    for f, t in zip(fields, tensors):
+        setattr(s, f, t.data_ptr() if t is not None else None)
+    return s
+
+
+# ----------------------------------------------------------------------------- raw GEMM (tests)
+def gemm(A, B, Cmat, M, N, K, sa, sb, sc, bias=None, nbatch=1, bs=(0, 0, 0), alpha=1.0, beta=0.0, act=0):
+    rc = lib().zeggs_gemm(_p(A), _p(B), _p(Cmat), _p(bias), M, N, K, C.c_long(sa[0]), C.c_long(sa[1]),
+                          C.c_long(sb[0]), C.c_long(sb[1]), C.c_long(sc[0]), C.c_long(sc[1]), nbatch,
+                          C.c_long(bs[0]), C.c_long(bs[1]), C.c_long(bs[2]), C.c_float(alpha), C.c_float(beta), act,
+                          _stream())
+    _check(rc, "zeggs_gemm")
+    return Cmat
+
+
+# ----------------------------------------------------------------------------- speech encoder
+class _SpeechFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, w2, b2, p, seed):
+        x = _f32c(x)
+        params = [_f32c(t) for t in (w0, b0, w1, b1, w2, b2)]
+        B, T, F = x.shape
+        d = SpeechDims(B, T, F, w0.shape[0], w2.shape[0], w1.shape[2], float(p), int(seed))
+        L = lib()
+        ws = _ws(L.zeggs_speech_encoder_workspace_bytes(C.byref(d)), x.device)
+        out = torch.empty(B, T, d.O, device=x.device, dtype=torch.float32)
+        P = _ptrs(SpeechPtrs, SPEECH_FIELDS, params)
+        _check(L.zeggs_speech_encoder_fwd(C.byref(d), C.byref(P), _p(x), _p(out), _p(ws), C.c_size_t(ws.numel()),
+                                          _stream()), "speech_encoder_fwd")
+        ctx.d, ctx.ws = d, ws
+        ctx.save_for_backward(x, out, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, *params = ctx.saved_tensors
+        L = lib()
+        grads = [torch.empty_like(t) for t in params]
+        P = _ptrs(SpeechPtrs, SPEECH_FIELDS, params)
+        G = _ptrs(SpeechPtrs, SPEECH_FIELDS, grads)
+        _check(L.zeggs_speech_encoder_bwd(C.byref(ctx.d), C.byref(P), _p(x), _p(out), _p(_f32c(dout)), C.byref(G),
+                                          _p(ctx.ws), C.c_size_t(ctx.ws.numel()), _stream()), "speech_encoder_bwd")
+        return (None, *grads, None, None)
+
+
+def speech_encoder(x, w0, b0, w1, b1, w2, b2, p=0.0):
+    return _SpeechFn.apply(x, w0, b0, w1, b1, w2, b2, p, next_seed() if p > 0 else 0)
+
+
+# ----------------------------------------------------------------------------- style encoder
+_POS_CACHE = {}
+
+
+def positional_table(length, dim, device):
+    """Sinusoidal table of the reference PositionalEncoding (modules.py:450-459), built on the host exactly as
+    the reference does (float32 torch ops) and cached on the device."""
+    key = (dim, str(device))
+    tab = _POS_CACHE.get(key)
+    if tab is None or tab.shape[0] < length:
+        n = max(length, 1024)
+        pos = torch.arange(0, n, dtype=torch.float).unsqueeze(1)
+        div = torch.exp(torch.arange(0, dim, 2).float() * (-np.log(10000.0) / dim))
+        t = torch.zeros(n, dim)
+        t[:, 0::2] = torch.sin(pos * div)
+        t[:, 1::2] = torch.cos(pos * div)
+        tab = t.to(device)
+        _POS_CACHE[key] = tab
+    return tab
+
+
+def style_param_list(enc):
+    """Parameters of a StyleEncoderAttn module in the C-ABI order (STYLE_FIELDS)."""
+    c, b = enc.convs, enc.blocks[0]
+    mha = b.attention.multi_head_attention
+    return [c[0].conv.weight, c[0].conv.bias, c[2].weight, c[2].bias, c[4].conv.weight, c[4].conv.bias,
+            c[6].weight, c[6].bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias,
+            b.attention.layer_norm.weight, b.attention.layer_norm.bias,
+            b.feed_forward.convs[0].conv.weight, b.feed_forward.convs[0].conv.bias,
+            b.feed_forward.convs[2].conv.weight, b.feed_forward.convs[2].conv.bias,
+            b.feed_forward.layer_norm.weight, b.feed_forward.layer_norm.bias]
+
+
+class _StyleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pos, dropout, seed, nheads, *params):
+        x = _f32c(x)
+        params = [_f32c(t) for t in params]
+        B, Lx, Cx = x.shape
+        H, E = params[0].shape[0], params[4].shape[0]
+        d = StyleDims(B, Lx, Cx, H, E, nheads, int(dropout), int(seed))
+        L = lib()
+        ws = _ws(L.zeggs_style_encoder_workspace_bytes(C.byref(d)), x.device)
+        out = torch.empty(B, E, device=x.device, dtype=torch.float32)
+        P = _ptrs(StylePtrs, STYLE_FIELDS, params)
+        _check(L.zeggs_style_encoder_fwd(C.byref(d), C.byref(P), _p(x), _p(pos), _p(out), _p(ws),
+                                         C.c_size_t(ws.numel()), _stream()), "style_encoder_fwd")
+        ctx.d, ctx.ws = d, ws
+        ctx.save_for_backward(*params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        params = list(ctx.saved_tensors)
+        L = lib()
+        grads = [torch.empty_like(t) for t in params]
+        P = _ptrs(StylePtrs, STYLE_FIELDS, params)
+        G = _ptrs(StylePtrs, STYLE_FIELDS, grads)
+        _check(L.zeggs_style_encoder_bwd(C.byref(ctx.d), C.byref(P), _p(_f32c(dout)), C.byref(G), _p(ctx.ws),
+                                         C.c_size_t(ctx.ws.numel()), _stream()), "style_encoder_bwd")
+        return (None, None, None, None, None, *grads)
+
+
+def style_encoder_attn(x, enc, training):
+    pos = positional_table(x.shape[1], enc.embed_dim, x.device)
+    return _StyleFn.apply(x, pos, 1 if training else 0, next_seed() if training else 0, 4, *style_param_list(enc))
+
+
+class _VaeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, eps, temperature, S):
+        enc, eps = _f32c(enc), _f32c(eps)
+        B = enc.shape[0]
+        z = torch.empty(B, S, device=enc.device, dtype=torch.float32)
+        _check(lib().zeggs_vae_reparam_fwd(_p(enc), _p(eps), _p(z), B, S, C.c_float(temperature), _stream()),
+               "vae_reparam_fwd")
+        ctx.save_for_backward(enc, eps)
+        ctx.t, ctx.S = temperature, S
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        enc, eps = ctx.saved_tensors
+        denc = torch.empty_like(enc)
+        _check(lib().zeggs_vae_reparam_bwd(_p(enc), _p(eps), _p(_f32c(dz)), None, None, _p(denc), enc.shape[0], ctx.S,
+                                           C.c_float(ctx.t), _stream()), "vae_reparam_bwd")
+        return denc, None, None, None
+
+
+def vae_reparam(enc, eps, temperature, S):
+    z = _VaeFn.apply(enc, eps, float(temperature), S)
+    return z, enc[:, :S], enc[:, S:]
+
+
+# ----------------------------------------------------------------------------- decoder
+def decoder_param_list(dec):
+    r, c = dec.recurrent_decoder, dec.cell_state_encoder
+    g = r.layer1
+    return [r.layer0.weight, r.layer0.bias, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
+            g.weight_ih_l1, g.weight_hh_l1, g.bias_ih_l1, g.bias_hh_l1, r.layer2.weight, r.layer2.bias,
+            c.layer0.weight, c.layer0.bias, c.layer1.weight, c.layer1.bias, c.layer2.weight, c.layer2.bias]
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt, H, *params):
+        pose0, rpos0, rrot0, gaze, speech, style = (_f32c(t) for t in (pose0, rpos0, rrot0, gaze, speech, style))
+        stats = [_f32c(t) for t in (in_mean, in_std, out_mean, out_std)]
+        params = [_f32c(t) for t in params]
+        B, T, SP = speech.shape
+        ST, PO = style.shape[2], pose0.shape[1]
+        training = any(ctx.needs_input_grad)
+        d = DecDims(B, T, PO + 3, PO, SP, ST, H, float(dt))
+        L = lib()
+        ws = _ws(L.zeggs_decoder_workspace_bytes(C.byref(d), int(training)), pose0.device)
+        dev = pose0.device
+        pose = torch.empty(B, T, PO, device=dev, dtype=torch.float32)
+        rpos = torch.empty(B, T, 3, device=dev, dtype=torch.float32)
+        rrot = torch.empty(B, T, 4, device=dev, dtype=torch.float32)
+        P = _ptrs(DecPtrs, DEC_FIELDS, params)
+        S = _ptrs(DecStats, ("in_mean", "in_std", "out_mean", "out_std"), stats)
+        _check(L.zeggs_decoder_fwd(C.byref(d), C.byref(P), C.byref(S), _p(pose0), _p(rpos0), _p(rrot0), _p(gaze),
+                                   _p(speech), _p(style), _p(pose), _p(rpos), _p(rrot), int(training), _p(ws),
+                                   C.c_size_t(ws.numel()), _stream()), "decoder_fwd")
+        if training:
+            ctx.d, ctx.ws = d, ws
+            ctx.save_for_backward(gaze, pose, rpos, rrot, *stats, *params)
+        return pose, rpos, rrot
+
+    @staticmethod
+    def backward(ctx, dpose, drpos, drrot):
+        gaze, pose, rpos, rrot, *rest = ctx.saved_tensors
+        stats, params = rest[:4], rest[4:]
+        d = ctx.d
+        L = lib()
+        dev = pose.device
+        z = lambda g, ref: torch.zeros_like(ref) if g is None else _f32c(g)  # noqa: E731
+        dpose, drpos, drrot = z(dpose, pose), z(drpos, rpos), z(drrot, rrot)
+        grads = [torch.empty_like(t) for t in params]
+        dspeech = torch.empty(d.B, d.T, d.SP, device=dev, dtype=torch.float32)
+        dstyle = torch.empty(d.B, d.T, d.ST, device=dev, dtype=torch.float32)
+        P = _ptrs(DecPtrs, DEC_FIELDS, params)
+        G = _ptrs(DecPtrs, DEC_FIELDS, grads)
+        S = _ptrs(DecStats, ("in_mean", "in_std", "out_mean", "out_std"), stats)
+        _check(L.zeggs_decoder_bwd(C.byref(d), C.byref(P), C.byref(S), _p(gaze), _p(pose), _p(rpos), _p(rrot),
+                                   _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
+                                   C.c_size_t(ctx.ws.numel()), _stream()), "decoder_bwd")
+        return (None, None, None, None, dspeech, dstyle, None, None, None, None, None, None, *grads)
+
+
+def decoder_core(dec, pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt):
+    """-> pose [B,T,PO] (de-normalised output vectors), rpos [B,T,3], rrot [B,T,4]"""
+    H = dec.dims[4]
+    return _DecoderFn.apply(pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt, H,
+                            *decoder_param_list(dec))
+
+
+def decoder_rollout(dec, Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos, Z_ltxy, Z_lvel, Z_lvrt, gaze,
+                    speech, style, in_mean, in_std, out_mean, out_std, dt):
+    """Reference-shaped Decoder.forward: 8 tensors [B,T,...] (views of the engine's pose rows)."""
+    B, J = Z_lpos.shape[0], Z_lpos.shape[1]
+    pose0 = torch.cat([Z_root_vel.reshape(B, -1), Z_root_vrt.reshape(B, -1), Z_lpos.reshape(B, -1),
+                       Z_ltxy.reshape(B, -1), Z_lvel.reshape(B, -1), Z_lvrt.reshape(B, -1)], dim=1)
+    pose, rpos, rrot = decoder_core(dec, pose0, Z_root_pos, Z_root_rot, gaze, speech, style, in_mean, in_std,
+                                    out_mean, out_std, dt)
+    T = pose.shape[1]
+    return (rpos, rrot, pose[..., 0:3], pose[..., 3:6], pose[..., 6:6 + 3 * J].reshape(B, T, J, 3),
+            pose[..., 6 + 3 * J:6 + 9 * J].reshape(B, T, J, 2, 3),
+            pose[..., 6 + 9 * J:6 + 12 * J].reshape(B, T, J, 3),
+            pose[..., 6 + 12 * J:6 + 15 * J].reshape(B, T, J, 3))
+
+
+# ----------------------------------------------------------------------------- loss
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, o_pose, o_rpos, o_rrot, mu, logvar, w_pose, w_rpos, w_rrot, gaze, parents, kl_weight, dt, gscale):
+        o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze = (
+            _f32c(t) for t in (o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze))
+        B, T, PO = o_pose.shape
+        J = (PO - 6) // 15
+        has_kl = mu is not None and kl_weight > 0
+        S = mu.shape[1] if mu is not None else 0
+        d = LossDims(B, T, J, S, float(dt))
+        L = lib()
+        dev = o_pose.device
+        ws = _ws(L.zeggs_loss_workspace_bytes(C.byref(d)), dev)
+        terms = torch.empty(19, device=dev, dtype=torch.float32)
+        dpose, drpos, drrot = torch.empty_like(o_pose), torch.empty_like(o_rpos), torch.empty_like(o_rrot)
+        dmu = torch.empty(B, S, device=dev) if mu is not None else None
+        dlv = torch.empty(B, S, device=dev) if mu is not None else None
+        _check(L.zeggs_loss_fwd_bwd(C.byref(d), _p(parents), _p(o_pose), _p(o_rpos), _p(o_rrot), _p(w_pose),
+                                    _p(w_rpos), _p(w_rrot), _p(gaze), _p(_f32c(mu)) if mu is not None else None,
+                                    _p(_f32c(logvar)) if mu is not None else None,
+                                    C.c_float(kl_weight if has_kl else 0.0), _p(terms), _p(dpose), _p(drpos),
+                                    _p(drrot), _p(dmu), _p(dlv), C.c_float(gscale), _p(ws), C.c_size_t(ws.numel()),
+                                    _stream()), "loss_fwd_bwd")
+        ctx.save_for_backward(dpose, drpos, drrot, dmu, dlv)
+        ctx.mark_non_differentiable(terms)
+        return terms[18].clone(), terms
+
+    @staticmethod
+    def backward(ctx, g, _gterms):
+        dpose, drpos, drrot, dmu, dlv = ctx.saved_tensors
+        dpose, drpos, drrot = dpose * g, drpos * g, drrot * g
+        if dmu is not None:
+            dmu, dlv = dmu * g, dlv * g
+        return (dpose, drpos, drrot, dmu, dlv, None, None, None, None, None, None, None, None)
+
+
+def training_loss(o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze, parents, dt, mu=None, logvar=None,
+                  kl_weight=0.0, gscale=1.0):
+    """-> (loss scalar tensor, terms[19]); terms[0:18] are the reference's weighted loss terms."""
+    return _LossFn.apply(o_pose, o_rpos, o_rrot, mu, logvar, w_pose, w_rpos, w_rrot, gaze, parents,
+                         float(kl_weight), float(dt), float(gscale))
+
+
+# ----------------------------------------------------------------------------- optimizer / data
+def radam_step(p, g, m, v, beta1, beta2, eps, step_scale, rectified):
+    _check(lib().zeggs_radam_step(_p(p), _p(g), _p(m), _p(v), C.c_long(p.numel()), C.c_float(beta1), C.c_float(beta2),
+                                  C.c_float(eps), C.c_float(step_scale), int(rectified), _stream()), "radam_step")
+
+
+def gather_windows(frames, starts, T):
+    """frames [N, W] device, starts int64 [B] device -> [B, T, W]"""
+    B, W = starts.shape[0], frames.shape[1]
+    out = torch.empty(B, T, W, device=frames.device, dtype=torch.float32)
+    _check(lib().zeggs_gather_windows(_p(frames), W, _p(starts), B, T, _p(out), _stream()), "gather_windows")
+    return out
+
+
+def gather_rows(frames, rows, out=None, out_ld=None):
+    """frames [N, W], rows int64 [...]-> [..., W] (or into a strided `out`)"""
+    W = frames.shape[1]
+    n = rows.numel()
+    if out is None:
+        out = torch.empty(*rows.shape, W, device=frames.device, dtype=torch.float32)
+        out_ld = W
+    _check(lib().zeggs_gather_rows(_p(frames), W, _p(rows.contiguous()), C.c_long(n), _p(out), int(out_ld), _stream()),
+           "gather_rows")
+    return out
