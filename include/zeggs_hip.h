@@ -165,6 +165,10 @@ int zeggs_gather_windows(const float* frames, int width, const int64_t* starts, 
 int zeggs_gather_rows(const float* frames, int width, const int64_t* rows, long nrows, float* out, int out_ld,
                       void* stream);
 
+/* in-place feature normalisation (x - mean) / std of ZEGGS/train.py:232-234,239 ; stdv == NULL -> scalar std */
+int zeggs_normalize_rows(float* x, long rows, int width, long ld, const float* mean, const float* stdv,
+                         float std_scalar, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

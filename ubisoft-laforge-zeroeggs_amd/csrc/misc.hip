@@ -79,6 +79,18 @@ __global__ void gather_rows_k(const float* frames, int width, const int64_t* row
   }
 }
 
+// x[r][c] = (x[r][c] - mean[c]) / std[c]   (std == null: scalar std)
+__global__ void normalize_rows_k(float* x, long rows, int width, long ld, const float* mean, const float* stdv,
+                                 float std_scalar) {
+  long n = rows * width;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % width);
+    long r = i / width;
+    float sd = stdv ? stdv[c] : std_scalar;
+    x[r * ld + c] = (x[r * ld + c] - mean[c]) / sd;
+  }
+}
+
 inline int g1(long n) { long g = (n + 255) / 256; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 
 }  // namespace
@@ -124,5 +136,15 @@ extern "C" int zeggs_gather_rows(const float* frames, int width, const int64_t* 
   hipLaunchKernelGGL(gather_rows_k, dim3(g1(n)), dim3(256), 0, (hipStream_t)stream, frames, width, rows, nrows, out,
                      out_ld);
   ZLAUNCH_CHECK("gather_rows");
+  return 0;
+}
+
+extern "C" int zeggs_normalize_rows(float* x, long rows, int width, long ld, const float* mean, const float* stdv,
+                                    float std_scalar, void* stream) {
+  long n = rows * width;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(normalize_rows_k, dim3(g1(n)), dim3(256), 0, (hipStream_t)stream, x, rows, width, ld, mean, stdv,
+                     std_scalar);
+  ZLAUNCH_CHECK("normalize_rows");
   return 0;
 }

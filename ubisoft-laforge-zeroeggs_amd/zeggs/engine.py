@@ -1,0 +1,149 @@
+"""Training engine: HBM-resident dataset, flat parameter buffers, one fused training step.
+
+This is the host-side runtime that `zeggs.train.train()` and `bench.py` drive.  Per iteration:
+  window/example index rule on the host (integers, reference dataset.py:79-96,176-204) ->
+  HIP gathers from the device-resident frame tables -> SpeechEncoder -> StyleEncoder (VAE) ->
+  Decoder rollout -> loss (fwd+bwd fused) -> BPTT -> [RCCL all-reduce of the flat gradient] ->
+  fused RAdam over the flat parameter buffer.
+Data parallelism: one process per GPU, every rank holds the full nets + dataset and takes its
+contiguous slice of the global batch; gradients are averaged with ONE all-reduce per iteration.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .modules import kl_div_weight
+from .optimizers import RAdam
+
+
+class DeviceDataset:
+    """The arrays of processed_data.npz resident in HBM (reference dataset.py:41-96 keeps them on the host)."""
+
+    def __init__(self, data, window, device):
+        f = lambda k: torch.as_tensor(np.asarray(data[k]), dtype=torch.float32)  # noqa: E731
+        n = len(data["Y_root_pos"])
+        self.n_frames = n
+        self.window = window
+        self.device = device
+        pose = torch.cat([f("Y_root_vel").reshape(n, -1), f("Y_root_vrt").reshape(n, -1), f("Y_lpos").reshape(n, -1),
+                          f("Y_ltxy").reshape(n, -1), f("Y_lvel").reshape(n, -1), f("Y_lvrt").reshape(n, -1)], dim=1)
+        self.pose = pose.to(device).contiguous()                 # [N, PO] reference output-vector layout
+        self.audio = f("X_audio_features").to(device).contiguous()
+        self.rpos = f("Y_root_pos").to(device).contiguous()
+        self.rrot = f("Y_root_rot").to(device).contiguous()
+        self.gaze = f("Y_gaze_pos").to(device).contiguous()
+        self.PO = self.pose.shape[1]
+        self.ranges_train = np.asarray(data["ranges_train"]).astype(np.int64)
+        self.ranges_train_labels = np.asarray(data["ranges_train_labels"]).astype(np.int64)
+        # window table (dataset.py:79-96): one window per start frame in [range_start, range_end - window)
+        counts = np.maximum(self.ranges_train[:, 1] - window - self.ranges_train[:, 0], 0)
+        self.win_sample = np.repeat(np.arange(len(counts)), counts).astype(np.int16)
+        self.win_start = np.concatenate([np.arange(a, a + c) for (a, _), c in zip(self.ranges_train, counts)]
+                                        or [np.zeros(0, np.int64)]).astype(np.int64)
+        t = lambda k, dt=torch.float32: torch.as_tensor(np.asarray(data[k]), dtype=dt).to(device)  # noqa: E731
+        self.audio_mean, self.audio_std = t("audio_input_mean"), float(np.asarray(data["audio_input_std"]))
+        self.in_mean, self.in_std = t("anim_input_mean").contiguous(), t("anim_input_std").contiguous()
+        self.out_mean, self.out_std = t("anim_output_mean").contiguous(), t("anim_output_std").contiguous()
+
+    def __len__(self):
+        return len(self.win_start)
+
+    def example_rows(self, idx, example_len):
+        """Source frame of every row of the style example (dataset.py:176-204), int64 [B, example_len]."""
+        W = self.window
+        r0 = self.win_start[idx]
+        rng = self.ranges_train[self.win_sample[idx]]
+        rs, re = rng[:, 0], rng[:, 1]
+        r_last = r0 + W - 1
+        ext = (example_len - W) // 2
+        ws = np.minimum(ext, r0 - rs)
+        we = np.minimum(ext, re - r_last)
+        start = np.maximum(r0 - (ws + ext - we), rs)
+        end = np.minimum(np.minimum(r_last + (we + ext - ws), re) + 1, self.n_frames)
+        cur = end - start
+        k = np.arange(example_len)[None, :]
+        rows = np.where(k < cur[:, None], start[:, None] + k, end[:, None] - example_len + k)
+        return rows.astype(np.int64)
+
+    def batch(self, idx, example_len):
+        """Gather one batch (normalised where the reference normalises before the nets)."""
+        dev = self.device
+        B, T = len(idx), self.window
+        starts = torch.as_tensor(self.win_start[idx]).to(dev, non_blocking=True)
+        out = dict(audio=ops.gather_windows(self.audio, starts, T), pose=ops.gather_windows(self.pose, starts, T),
+                   rpos=ops.gather_windows(self.rpos, starts, T), rrot=ops.gather_windows(self.rrot, starts, T),
+                   gaze=ops.gather_windows(self.gaze, starts, T))
+        ops.normalize_rows_(out["audio"], self.audio_mean, self.audio_std)
+        if example_len is not None:
+            rows = torch.as_tensor(self.example_rows(idx, example_len)).to(dev, non_blocking=True)
+            ex = torch.zeros(B, example_len, self.PO + 3, device=dev)      # gaze slot = 0 (dataset.py:194)
+            ops.gather_rows(self.pose, rows, out=ex, out_ld=self.PO + 3)
+            ops.normalize_rows_(ex, self.in_mean, self.in_std)
+            out["example"] = ex
+        return out
+
+
+def flatten_parameters(modules):
+    """Re-home all parameters of `modules` into ONE flat fp32 buffer (+ one flat grad buffer).
+    Parameter objects are kept (their .data / .grad become views), so state_dict() is unchanged."""
+    params = [p for m in modules for p in m.parameters()]
+    dev = params[0].device
+    total = sum(p.numel() for p in params)
+    flat_p = torch.empty(total, device=dev, dtype=torch.float32)
+    flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
+    off = 0
+    for p in params:
+        n = p.numel()
+        flat_p[off:off + n].copy_(p.data.reshape(-1))
+        p.data = flat_p[off:off + n].view(p.shape)
+        p.grad = flat_g[off:off + n].view(p.shape)
+        off += n
+    for m in modules:           # nn.GRU caches flattened weights; harmless on ROCm but keep it coherent
+        for sub in m.modules():
+            if isinstance(sub, torch.nn.GRU):
+                sub._flat_weights = [getattr(sub, n) for n in sub._flat_weights_names]
+    return params, flat_p, flat_g
+
+
+class TrainEngine:
+    def __init__(self, speech_encoder, decoder, style_encoder, dataset, parents, dt, lr=1e-4, eps=1e-5,
+                 style_encoding_type="example", world_size=1, rank=0, process_group=None):
+        self.se, self.de, self.st = speech_encoder, decoder, style_encoder
+        self.ds = dataset
+        self.dt = float(dt)
+        self.world, self.rank, self.pg = world_size, rank, process_group
+        self.style_type = style_encoding_type
+        dev = dataset.device
+        self.parents = torch.as_tensor(np.asarray(parents), dtype=torch.int32, device=dev)
+        mods = [speech_encoder, decoder] + ([style_encoder] if style_encoding_type == "example" else [])
+        self.params, self.flat_p, self.flat_g = flatten_parameters(mods)
+        self.opt = RAdam(self.params, lr=lr, eps=eps)
+        self.opt.attach_flat(self.flat_p, self.flat_g)
+        self.iteration = 0
+        self.last_terms = None
+
+    def step(self, idx, example_len, eps=None, labels=None):
+        """One training iteration on window indices `idx` (this rank's slice). Returns the loss tensor (device)."""
+        ds, T = self.ds, self.ds.window
+        b = ds.batch(idx, example_len if self.style_type == "example" else None)
+        self.flat_g.zero_()
+        speech = self.se(b["audio"])
+        mu = logvar = None
+        if self.style_type == "example":
+            z, mu, logvar = self.st(b["example"], 1.0, eps=eps)
+        else:
+            z = labels
+        style = z.unsqueeze(1).expand(-1, T, -1).contiguous()
+        pose, orp, orr = ops.decoder_core(self.de, b["pose"][:, 0].contiguous(), b["rpos"][:, 0].contiguous(),
+                                          b["rrot"][:, 0].contiguous(), b["gaze"], speech, style, ds.in_mean,
+                                          ds.in_std, ds.out_mean, ds.out_std, self.dt)
+        klw = kl_div_weight(self.iteration) if mu is not None else 0.0
+        loss, terms = ops.training_loss(pose, orp, orr, b["pose"], b["rpos"], b["rrot"], b["gaze"], self.parents,
+                                        self.dt, mu, logvar, kl_weight=klw, gscale=1.0 / self.world)
+        loss.backward()
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat_g, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        self.opt.step()
+        self.iteration += 1
+        self.last_terms = terms
+        return loss

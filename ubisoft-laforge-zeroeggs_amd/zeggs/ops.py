@@ -407,3 +407,14 @@ def gather_rows(frames, rows, out=None, out_ld=None):
     _check(lib().zeggs_gather_rows(_p(frames), W, _p(rows.contiguous()), C.c_long(n), _p(out), int(out_ld), _stream()),
            "gather_rows")
     return out
+
+
+def normalize_rows_(x, mean, std):
+    """in place (x - mean) / std over the last dim; std is a [W] tensor or a python float"""
+    W = x.shape[-1]
+    rows = x.numel() // W
+    vec = std if torch.is_tensor(std) and std.dim() > 0 else None
+    sc = 1.0 if vec is not None else float(std)
+    _check(lib().zeggs_normalize_rows(_p(x), C.c_long(rows), W, C.c_long(W), _p(mean), _p(vec) if vec is not None else None,
+                                      C.c_float(sc), _stream()), "normalize_rows")
+    return x
