@@ -28,6 +28,8 @@ extern "C" {
 
 int zeggs_version(void);
 const char* zeggs_last_error(void);
+/* runtime switches: "decoder_fast" 1 (default) = fragment-packed stage kernels, 0 = generic GEMM path */
+int zeggs_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------- generic GEMM (tests / tools)
  * C(m,n) = act(alpha * sum_k A(m,k) B(k,n) + beta * C(m,n) + bias[n]), element strides, batched. */

@@ -290,3 +290,69 @@ def test_gather_windows_and_rows():
     assert torch.equal(out, ref)                                          # indices bit-exact
     rows = torch.tensor([[3, 4, 4, 49], [0, 0, 1, 2]], device=DEV)
     assert torch.equal(ops.gather_rows(frames, rows), frames[rows])
+
+
+# ----------------------------------------------------------------------------- fast (packed) vs generic decoder path
+def _rollout_with_grads(de, B, T, seed, style_dim=64):
+    torch.manual_seed(seed)
+    stats = synth.make_stats()
+    s = {k: g(v) for k, v in helpers.stats_tensors().items()}
+    clips = [synth.make_clip(T, seed=300 + b, stats=stats) for b in range(B)]
+    tt = lambda k: g(torch.as_tensor(np.stack([c[k] for c in clips])))  # noqa: E731
+    pose0 = _pack_pose(tt("Y_root_vel"), tt("Y_root_vrt"), tt("Y_lpos"), tt("Y_ltxy"), tt("Y_lvel"), tt("Y_lvrt"))[:, 0]
+    speech = (torch.randn(B, T, 64, device=DEV) * 0.5).requires_grad_(True)
+    style = (torch.randn(B, T, style_dim, device=DEV) * 0.5).requires_grad_(True)
+    de.zero_grad()
+    pose, rp, rr = ops.decoder_core(de, pose0.contiguous(), tt("Y_root_pos")[:, 0].contiguous(),
+                                    tt("Y_root_rot")[:, 0].contiguous(), tt("Y_gaze_pos"), speech, style, s["in_mean"],
+                                    s["in_std"], s["out_mean"], s["out_std"], synth.DT)
+    wp, wr, wq = torch.randn_like(pose), torch.randn_like(rp), torch.randn_like(rr)
+    ((pose * wp).sum() + (rp * wr).sum() + (rr * wq).sum()).backward()
+    grads = {k: p.grad.clone() for k, p in de.named_parameters()}
+    return (pose.detach(), rp.detach(), rr.detach()), grads, speech.grad.clone(), style.grad.clone()
+
+
+@pytest.mark.parametrize("B,T", [(32, 12), (1, 9), (5, 7), (33, 5)])
+def test_decoder_fast_path_matches_generic_path(B, T):
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).train()
+    try:
+        ops.set_option("decoder_fast", 0)
+        out0, g0, ds0, dy0 = _rollout_with_grads(de, B, T, 11)
+        ops.set_option("decoder_fast", 1)
+        out1, g1, ds1, dy1 = _rollout_with_grads(de, B, T, 11)
+    finally:
+        ops.set_option("decoder_fast", 1)
+    for a, b in zip(out0, out1):
+        assert float((a - b).abs().max()) < 2e-5
+    assert relerr(ds1, ds0) < 1e-4 and relerr(dy1, dy0) < 1e-4
+    for k in g0:
+        assert relerr(g1[k], g0[k]) < 1e-4, k
+
+
+def test_decoder_inference_ring_long_rollout():
+    """no_grad path (2-slot ring buffers), B=1, 300 frames: fast == generic to fp32 rounding, and finite."""
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).eval()
+    B, T = 1, 300
+    stats = synth.make_stats()
+    s = {k: g(v) for k, v in helpers.stats_tensors().items()}
+    c = synth.make_clip(T, seed=5, stats=stats)
+    tt = lambda k: g(torch.as_tensor(c[k][None]))  # noqa: E731
+    pose0 = _pack_pose(tt("Y_root_vel"), tt("Y_root_vrt"), tt("Y_lpos"), tt("Y_ltxy"), tt("Y_lvel"), tt("Y_lvrt"))[:, 0]
+    torch.manual_seed(3)
+    speech, style = torch.randn(B, T, 64, device=DEV) * 0.5, torch.randn(B, T, 64, device=DEV) * 0.5
+    outs = []
+    try:
+        for fast in (0, 1):
+            ops.set_option("decoder_fast", fast)
+            with torch.no_grad():
+                outs.append(ops.decoder_core(de, pose0.contiguous(), tt("Y_root_pos")[:, 0].contiguous(),
+                                             tt("Y_root_rot")[:, 0].contiguous(), tt("Y_gaze_pos"), speech, style,
+                                             s["in_mean"], s["in_std"], s["out_mean"], s["out_std"], synth.DT))
+    finally:
+        ops.set_option("decoder_fast", 1)
+    J = 75
+    ltxy0, ltxy1 = outs[0][0][..., 6 + 3 * J:6 + 9 * J], outs[1][0][..., 6 + 3 * J:6 + 9 * J]
+    assert torch.isfinite(outs[1][0]).all()
+    assert float((ltxy0 - ltxy1).abs().max()) < 1e-4          # joint rotations (north_star tolerance)

@@ -1,0 +1,53 @@
+// Quaternion helpers of the decoder step (forward + analytic backward), shared by decoder.hip / decoder_fast.hip.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------ device helpers
+// reference anim/tquat.py:94-107: quat_from_helical(x) = quat_exp(x/2)
+static __device__ __forceinline__ Q4 quat_exp(V3 x) {
+  float h = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z);
+  if (h < 1e-5f) {
+    float n = sqrtf(1.f + h * h) + 1e-5f;
+    return Q4{1.f / n, x.x / n, x.y / n, x.z / n};
+  }
+  float s = sinf(h) / h;
+  return Q4{cosf(h), x.x * s, x.y * s, x.z * s};
+}
+
+// backward of out = quat_mul_vec(q, v) given upstream g
+static __device__ __forceinline__ void qmv_bwd(Q4 q, V3 v, V3 g, Q4& dq, V3& dv) {
+  V3 qv = v3(q.x, q.y, q.z);
+  V3 t = 2.0f * cross(qv, v);
+  float dw = dot(g, t);
+  V3 dt = q.w * g + cross(g, qv);
+  V3 dqv = cross(t, g) + 2.0f * cross(v, dt);
+  dv = g + 2.0f * cross(dt, qv);
+  dq = Q4{dw, dqv.x, dqv.y, dqv.z};
+}
+// backward of out = quat_mul(x, y)
+static __device__ __forceinline__ void qmul_bwd(Q4 x, Q4 y, Q4 g, Q4& dx, Q4& dy) {
+  dx.w = g.w * y.w + g.x * y.x + g.y * y.y + g.z * y.z;
+  dx.x = -g.w * y.x + g.x * y.w - g.y * y.z + g.z * y.y;
+  dx.y = -g.w * y.y + g.x * y.z + g.y * y.w - g.z * y.x;
+  dx.z = -g.w * y.z - g.x * y.y + g.y * y.x + g.z * y.w;
+  dy.w = g.w * x.w + g.x * x.x + g.y * x.y + g.z * x.z;
+  dy.x = -g.w * x.x + g.x * x.w + g.y * x.z - g.z * x.y;
+  dy.y = -g.w * x.y - g.x * x.z + g.y * x.w + g.z * x.x;
+  dy.z = -g.w * x.z + g.x * x.y - g.y * x.x + g.z * x.w;
+}
+// backward of out = quat_exp(x)
+static __device__ __forceinline__ V3 qexp_bwd(V3 x, Q4 g) {
+  float h = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z);
+  V3 gv = v3(g.x, g.y, g.z);
+  if (h < 1e-5f) {
+    float n = sqrtf(1.f + h * h), ne = n + 1e-5f;
+    float ug = g.w + dot(gv, x);
+    float k = ug / (n * ne * ne);
+    return (1.f / ne) * gv - k * x;
+  }
+  float sh = sinf(h), ch = cosf(h);
+  float s = sh / h, ds = (h * ch - sh) / (h * h);
+  float c = -g.w * s + dot(gv, x) * ds / h;
+  return s * gv + c * x;
+}
+

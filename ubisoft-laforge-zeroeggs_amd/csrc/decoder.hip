@@ -12,100 +12,17 @@
 #include "common.h"
 #include "gemm.h"
 #include "kernels.h"
+#include "dec_math.h"
+#include "decoder_ws.h"
+
+static int g_decoder_fast = 1;
+extern "C" int zeggs_set_option(const char* name, int value) {
+  if (strcmp(name, "decoder_fast") == 0) { g_decoder_fast = value; return 0; }
+  zeggs_set_error("unknown option %s", name);
+  return -1;
+}
 
 namespace {
-
-struct DecWs {
-  float *Gin, *H0, *H1, *R0, *Z0, *N0, *NH0, *R1, *Z1, *N1, *NH1, *Y;
-  float *cse_in, *cse_a, *cse_b;          // cell-state encoder activations
-  float *gi, *gh;                          // per-step gate pre-activations [B,3H]
-  // backward
-  float *DY, *DI0, *DH0, *DI1, *DH1, *D0, *DX;
-  float *dH0c, *dH1c, *dGin, *dXn, *carry, *t0, *t1;
-  int GL, XD, POL;
-};
-
-inline int round4(int x) { return (x + 3) / 4 * 4; }
-
-DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
-  DecWs w;
-  memset(&w, 0, sizeof(w));
-  const long B = d.B, T = d.T, H = d.H;
-  w.XD = d.PI + d.SP + d.ST;
-  w.GL = round4(d.H + w.XD);
-  w.POL = round4(d.PO);
-  const long TS = training ? T : 2;   // inference keeps a 2-slot ring for the step buffers
-  w.Gin = a.f(TS * B * w.GL);
-  w.H0 = a.f(TS * B * H); w.H1 = a.f(TS * B * H);
-  w.Y = a.f(B * (long)w.POL);
-  w.cse_in = a.f(B * (long)(d.PI + d.ST));
-  w.cse_a = a.f(B * H); w.cse_b = a.f(B * H);
-  w.gi = a.f(B * 3 * H); w.gh = a.f(B * 3 * H);
-  if (training) {
-    w.R0 = a.f(T * B * H); w.Z0 = a.f(T * B * H); w.N0 = a.f(T * B * H); w.NH0 = a.f(T * B * H);
-    w.R1 = a.f(T * B * H); w.Z1 = a.f(T * B * H); w.N1 = a.f(T * B * H); w.NH1 = a.f(T * B * H);
-    w.DY = a.f(T * B * (long)w.POL);
-    w.DI0 = a.f(T * B * 3 * H); w.DH0 = a.f(T * B * 3 * H);
-    w.DI1 = a.f(T * B * 3 * H); w.DH1 = a.f(T * B * 3 * H);
-    w.D0 = a.f(T * B * H);
-    w.DX = a.f(T * B * (long)w.XD);
-    w.dH0c = a.f(B * H); w.dH1c = a.f(B * H);
-    w.dGin = a.f(B * (long)w.GL);
-    w.dXn = a.f(B * (long)w.XD);
-    w.carry = a.f(B * 8);
-    w.t0 = a.f(B * 2 * H); w.t1 = a.f(B * (long)(d.PI + d.ST + 2 * H));
-  }
-  return w;
-}
-
-// ------------------------------------------------------------------ device helpers
-// reference anim/tquat.py:94-107: quat_from_helical(x) = quat_exp(x/2)
-__device__ __forceinline__ Q4 quat_exp(V3 x) {
-  float h = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z);
-  if (h < 1e-5f) {
-    float n = sqrtf(1.f + h * h) + 1e-5f;
-    return Q4{1.f / n, x.x / n, x.y / n, x.z / n};
-  }
-  float s = sinf(h) / h;
-  return Q4{cosf(h), x.x * s, x.y * s, x.z * s};
-}
-
-// backward of out = quat_mul_vec(q, v) given upstream g
-__device__ __forceinline__ void qmv_bwd(Q4 q, V3 v, V3 g, Q4& dq, V3& dv) {
-  V3 qv = v3(q.x, q.y, q.z);
-  V3 t = 2.0f * cross(qv, v);
-  float dw = dot(g, t);
-  V3 dt = q.w * g + cross(g, qv);
-  V3 dqv = cross(t, g) + 2.0f * cross(v, dt);
-  dv = g + 2.0f * cross(dt, qv);
-  dq = Q4{dw, dqv.x, dqv.y, dqv.z};
-}
-// backward of out = quat_mul(x, y)
-__device__ __forceinline__ void qmul_bwd(Q4 x, Q4 y, Q4 g, Q4& dx, Q4& dy) {
-  dx.w = g.w * y.w + g.x * y.x + g.y * y.y + g.z * y.z;
-  dx.x = -g.w * y.x + g.x * y.w - g.y * y.z + g.z * y.y;
-  dx.y = -g.w * y.y + g.x * y.z + g.y * y.w - g.z * y.x;
-  dx.z = -g.w * y.z - g.x * y.y + g.y * y.x + g.z * y.w;
-  dy.w = g.w * x.w + g.x * x.x + g.y * x.y + g.z * x.z;
-  dy.x = -g.w * x.x + g.x * x.w + g.y * x.z - g.z * x.y;
-  dy.y = -g.w * x.y - g.x * x.z + g.y * x.w + g.z * x.x;
-  dy.z = -g.w * x.z + g.x * x.y - g.y * x.x + g.z * x.w;
-}
-// backward of out = quat_exp(x)
-__device__ __forceinline__ V3 qexp_bwd(V3 x, Q4 g) {
-  float h = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z);
-  V3 gv = v3(g.x, g.y, g.z);
-  if (h < 1e-5f) {
-    float n = sqrtf(1.f + h * h), ne = n + 1e-5f;
-    float ug = g.w + dot(gv, x);
-    float k = ug / (n * ne * ne);
-    return (1.f / ne) * gv - k * x;
-  }
-  float sh = sinf(h), ch = cosf(h);
-  float s = sh / h, ds = (h * ch - sh) / (h * h);
-  float c = -g.w * s + dot(gv, x) * ds / h;
-  return s * gv + c * x;
-}
 
 // ------------------------------------------------------------------ kernels
 // init: frame-0 outputs, CellStateEncoder input (gaze of frame 0) and the pose part of x_1 (gaze of frame 1)
@@ -372,6 +289,17 @@ extern "C" int zeggs_decoder_fwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
                        GL, 1, T - 1, sG, 0);
     ZLAUNCH_CHECK("dec_fill_cond");
   }
+  const bool fast = g_decoder_fast && dec_fast_supported(d);
+  if (fast) {
+    if (!training && T > 1) {
+      hipLaunchKernelGGL(dec_fill_cond_k, g1((long)B * (d.SP + d.ST)), dim3(256), 0, s, d, speech, style, w.Gin, GL, 1,
+                         1, sG, 1);
+      ZLAUNCH_CHECK("dec_fill_cond");
+    }
+    ZTRY(dec_fast_pack_fwd(d, P, w, s));
+    ZTRY(dec_fast_fwd_steps(d, P, st, w, gaze, speech, style, pose, rpos, rrot, training, s));
+    return 0;
+  }
   for (int t = 1; t < T; ++t) {
     float* gin = w.Gin + slot(t) * sG;
     float* gin_next = (t + 1 < T) ? w.Gin + slot(t + 1) * sG : nullptr;
@@ -421,6 +349,10 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   ZTRY(k_fill(w.dH1c, sH, 0.f, s));
   ZTRY(k_fill(w.carry, (long)B * 8, 0.f, s));
   ZTRY(k_fill(w.DX, (long)B * XD, 0.f, s));          // slot t = 0 unused but read by the scatter
+  if (g_decoder_fast && dec_fast_supported(d)) {
+    ZTRY(dec_fast_pack_bwd(d, P, w, s));
+    ZTRY(dec_fast_bwd_steps(d, P, st, w, gaze, pose, rpos, rrot, dpose, drpos, drrot, s));
+  } else {
   for (int t = T - 1; t >= 1; --t) {
     const float* gin = w.Gin + t * sG;
     const long o = (long)t * sH;
@@ -449,6 +381,7 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
     hipLaunchKernelGGL(copy_cols_k, g1((long)B * XD), dim3(256), 0, s, dx, (long)XD, w.dGin, (long)GL, H, XD, B);
     ZLAUNCH_CHECK("dec_bwd_step");
     ZTRY(gemm_nn(w.D0 + o, H, P->l0_w, XD, dx, XD, B, H, XD, 1.f, s));
+  }
   }
   // ---- CellStateEncoder backward: dH0c / dH1c are the grads wrt its two output halves
   if (T > 1) {

@@ -1,0 +1,579 @@
+// Fast path of the decoder step: weight-streaming MFMA stage kernels over fragment-packed operands.
+//
+// One decoder step is a chain of four dependent matrix stages (layer0 -> GRU l0 -> GRU l1 -> layer2)
+// with M = batch <= 64 rows: at B = 32 every stage is bound by streaming its weights once
+// (75.7 MB per step).  Design for gfx950:
+//   * weights are re-packed once per optimizer step into MFMA *fragment order*: for every tile of
+//     16 "virtual output columns" and every block of 16 k-values, 64 lanes x float4 = one contiguous
+//     1 KiB block, so each wave-level load is a perfectly coalesced global_load_dwordx4 stream
+//     straight into VGPRs (no LDS round trip for a once-read operand);
+//   * activations are exchanged between stages in the matching B-operand fragment order (2 KiB per
+//     k-block at B = 32), written by the producing stage's epilogue next to the canonical row-major
+//     copy that the weight-gradient GEMMs need;
+//   * v_mfma_f32_16x16x4_f32: A = 16 weight rows, B = 16 batch columns; a float4 per lane feeds 4 MFMAs;
+//   * one workgroup (8 waves) owns one 16-column tile for the FULL contraction: the waves split K,
+//     reduce through LDS, and the epilogue (bias, ELU, GRU gate math, pose integration, next-step
+//     vectorisation, and their backward counterparts) runs in the same launch -> 4 launches per step,
+//     no cross-workgroup partial sums, no grid barrier;
+//   * GRU tiles interleave the r, z, n rows of 5 hidden units (15 of 16 columns) so the gate math
+//     needs no second pass; the input-side and hidden-side products use two accumulator sets.
+// Backward uses the transposed packs (16 output units x contraction over gate rows).
+#include "decoder_ws.h"
+#include "dec_math.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int WAVES = 8;
+enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX };
+
+struct Seg {
+  const float* w;   // packed weights  [tile][kb][64][4]
+  const float* x;   // packed activations [kb][NB][64][4]
+  int kb, acc;
+};
+struct Grp {
+  Seg seg[3];
+  int nseg, tiles, epi;
+  const float *p0, *p1, *p2, *p3, *p4;
+  float *o0, *o1, *o2, *o3, *o4, *o5;
+};
+struct StageArgs {
+  Grp g[2];
+  ZeggsDecDims d;
+  ZeggsDecStats st;
+  int NB, t, GL, XD, POL;
+  const float *gaze, *speech, *style;
+  float *pose, *rpos, *rrot;               // forward outputs
+  const float *cpose, *crpos, *crrot;      // backward: forward results
+  const float *dpose, *drpos, *drrot;      // backward: loss gradients
+  float* carry;                            // [B,8] root-state gradient carry
+};
+
+// column permutation of the dX stage: tile 0 holds root_vel/vrt (0..5) AND the gaze columns (PO..PO+2)
+__host__ __device__ inline int perm_dx(int q, int PO) {
+  if (q < 6) return q;
+  if (q < 9) return PO + (q - 6);
+  if (q < PO + 3) return q - 3;
+  return q;
+}
+
+__device__ __forceinline__ long xf_index(int b, int k, int NB) {
+  return ((((long)(k >> 4) * NB + (b >> 4)) * 64 + ((((k >> 2) & 3) << 4) | (b & 15))) << 2) | (k & 3);
+}
+
+template <int NB>
+__device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* __restrict__ xp, int lo, int hi,
+                                           f4 (&acc)[NB]) {
+  int kb = lo;
+  for (; kb + 4 <= hi; kb += 4) {
+    f4 wv[4], xv[4][NB];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      wv[u] = wp[(long)(kb + u) * 64];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) xv[u][nb] = xp[((long)(kb + u) * NB + nb) * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][c], xv[u][nb][c], acc[nb], 0, 0, 0);
+  }
+  for (; kb < hi; ++kb) {
+    f4 wv = wp[(long)kb * 64], xv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) xv[nb] = xp[((long)kb * NB + nb) * 64];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], xv[nb][c], acc[nb], 0, 0, 0);
+  }
+}
+
+// backward of the root integration of frame `f` (see dec_devec_bwd_k in decoder.hip for the derivation).
+// g6: in = dpose[f][0:6] + dx/sigma_i (when a next step exists); out = total grad wrt pose[f][0:6] (de-normalised).
+__device__ void root_bwd(const ZeggsDecDims& d, const ZeggsDecStats& st, int b, int f, bool has_next, const float* dgd_in,
+                         const float* gaze, const float* pose, const float* rpos, const float* rrot, const float* drpos,
+                         const float* drrot, float* carry, float (&g6)[6]) {
+  float* cr = carry + b * 8;
+  const float* a = drpos + ((long)b * d.T + f) * 3;
+  const float* e = drrot + ((long)b * d.T + f) * 4;
+  V3 g_rp = v3(cr[0] + a[0], cr[1] + a[1], cr[2] + a[2]);
+  Q4 g_rr = Q4{cr[3] + e[0], cr[4] + e[1], cr[5] + e[2], cr[6] + e[3]};
+  const float* rq = rrot + ((long)b * d.T + f) * 4;
+  const float* rp = rpos + ((long)b * d.T + f) * 3;
+  Q4 q_t = Q4{rq[0], rq[1], rq[2], rq[3]};
+  V3 p_t = v3(rp[0], rp[1], rp[2]);
+  if (has_next) {
+    const float* gz = gaze + ((long)b * d.T + f + 1) * 3;
+    V3 dgd = v3(dgd_in[0] / st.in_std[d.PO], dgd_in[1] / st.in_std[d.PO + 1], dgd_in[2] / st.in_std[d.PO + 2]);
+    Q4 dqi; V3 dv;
+    qmv_bwd(quat_inv(q_t), v3(gz[0], gz[1], gz[2]) - p_t, dgd, dqi, dv);
+    g_rr.w += dqi.w; g_rr.x -= dqi.x; g_rr.y -= dqi.y; g_rr.z -= dqi.z;
+    g_rp = g_rp - dv;
+  }
+  const float* pq = rrot + ((long)b * d.T + f - 1) * 4;
+  Q4 q_p = Q4{pq[0], pq[1], pq[2], pq[3]};
+  const float* pt = pose + ((long)b * d.T + f) * d.PO;
+  V3 vel = v3(pt[0], pt[1], pt[2]), vrt = v3(pt[3], pt[4], pt[5]);
+  Q4 dq1; V3 dv1;
+  qmv_bwd(q_p, d.dt * vel, g_rp, dq1, dv1);
+  V3 u = quat_mul_vec(q_p, d.dt * vrt);
+  Q4 E = quat_exp(0.5f * u);
+  Q4 dE, dqy;
+  qmul_bwd(E, q_p, g_rr, dE, dqy);
+  V3 du = 0.5f * qexp_bwd(0.5f * u, dE);
+  Q4 dq2; V3 dv2;
+  qmv_bwd(q_p, d.dt * vrt, du, dq2, dv2);
+  g6[0] += d.dt * dv1.x; g6[1] += d.dt * dv1.y; g6[2] += d.dt * dv1.z;
+  g6[3] += d.dt * dv2.x; g6[4] += d.dt * dv2.y; g6[5] += d.dt * dv2.z;
+  cr[0] = g_rp.x; cr[1] = g_rp.y; cr[2] = g_rp.z;
+  cr[3] = dq1.w + dqy.w + dq2.w; cr[4] = dq1.x + dqy.x + dq2.x;
+  cr[5] = dq1.y + dqy.y + dq2.y; cr[6] = dq1.z + dqy.z + dq2.z;
+}
+
+template <int NB>
+__global__ __launch_bounds__(512) void stage_k(StageArgs a) {
+  __shared__ f4 red[WAVES][2][NB][64];
+  __shared__ f4 fin[2][NB][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int gi = 0, tile = blockIdx.x;
+  if (tile >= a.g[0].tiles) { gi = 1; tile -= a.g[0].tiles; }
+  const Grp& G = a.g[gi];
+
+  f4 acc[2][NB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f4{0.f, 0.f, 0.f, 0.f};
+  int TB = 0;
+  for (int s = 0; s < G.nseg; ++s) TB += G.seg[s].kb;
+  const int b0 = wave * TB / WAVES, b1 = (wave + 1) * TB / WAVES;
+  int base = 0;
+  for (int s = 0; s < G.nseg; ++s) {
+    const int kbs = G.seg[s].kb;
+    const int lo = (b0 > base ? b0 : base) - base;
+    const int hi = (b1 < base + kbs ? b1 : base + kbs) - base;
+    if (lo < hi) {
+      const f4* wp = (const f4*)G.seg[s].w + ((long)tile * kbs) * 64 + lane;
+      const f4* xp = (const f4*)G.seg[s].x + lane;
+      if (G.seg[s].acc == 0) run_blocks<NB>(wp, xp, lo, hi, acc[0]);
+      else run_blocks<NB>(wp, xp, lo, hi, acc[1]);
+    }
+    base += kbs;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) red[wave][i][nb][lane] = acc[i][nb];
+  __syncthreads();
+  if (tid < 2 * NB * 64) {
+    const int i = tid / (NB * 64), r = tid % (NB * 64), nb = r / 64, l = r % 64;
+    f4 s = red[0][i][nb][l];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) s += red[w][i][nb][l];
+    fin[i][nb][l] = s;
+  }
+  __syncthreads();
+  const float* finf = (const float*)fin;
+  auto FV = [&](int i, int vcol, int b) -> float {
+    return finf[(((i * NB + (b >> 4)) * 64 + (((vcol >> 2) << 4) | (b & 15))) << 2) | (vcol & 3)];
+  };
+  const ZeggsDecDims& d = a.d;
+  const int B = d.B, H = d.H, BP = 16 * NB, t = a.t;
+
+  switch (G.epi) {
+    case EPI_ELU_HID: {   // hid = ELU(W0 x + b0) -> Gin[t][:, 0:H] and its fragment copy
+      for (int id = tid; id < 16 * BP; id += 512) {
+        const int v = id / BP, b = id % BP, col = tile * 16 + v;
+        if (b < B && col < H) {
+          const float val = d_elu(FV(0, v, b) + G.p0[col]);
+          G.o0[(long)b * a.GL + col] = val;
+          G.o1[xf_index(b, col, NB)] = val;
+        }
+      }
+    } break;
+    case EPI_GRU_FWD: {   // tile = 5 hidden units x (r, z, n); acc0 = input side, acc1 = hidden side
+      for (int id = tid; id < 5 * BP; id += 512) {
+        const int u = id / BP, b = id % BP, U = tile * 5 + u;
+        if (b < B && U < H) {
+          const float r = d_sigmoid(FV(0, u, b) + G.p0[U] + (FV(1, u, b) + G.p1[U]));
+          const float z = d_sigmoid(FV(0, 5 + u, b) + G.p0[H + U] + (FV(1, 5 + u, b) + G.p1[H + U]));
+          const float nh = FV(1, 10 + u, b) + G.p1[2 * H + U];
+          const float nn = tanhf(FV(0, 10 + u, b) + G.p0[2 * H + U] + r * nh);
+          const long i = (long)b * H + U;
+          const float hp = G.p2[i];
+          const float h = (1.f - z) * nn + z * hp;
+          G.o0[i] = h;
+          G.o1[xf_index(b, U, NB)] = h;
+          if (G.o2) { G.o2[i] = r; G.o3[i] = z; G.o4[i] = nn; G.o5[i] = nh; }
+        }
+      }
+    } break;
+    case EPI_OUT_FWD: {   // y = W2 h1 + b2 -> pose[t], root integration, x_{t+1}
+      const int PO = d.PO;
+      float* gnext = G.o0;
+      float* xnext = G.o1;
+      const bool next = (t + 1 < d.T);
+      for (int id = tid; id < 16 * BP; id += 512) {
+        const int v = id / BP, b = id % BP, col = tile * 16 + v;
+        if (b < B && col < PO) {
+          const float p = (FV(0, v, b) + G.p0[col]) * a.st.out_std[col] + a.st.out_mean[col];
+          a.pose[((long)b * d.T + t) * PO + col] = p;
+          if (next) {
+            const float e = (p - a.st.in_mean[col]) / a.st.in_std[col];
+            if (gnext) gnext[(long)b * a.GL + H + col] = e;
+            xnext[xf_index(b, col, NB)] = e;
+          }
+        }
+      }
+      if (next) {   // speech / style columns of x_{t+1}
+        const int XC = d.SP + d.ST;
+        for (int e = tile * 512 + tid; e < B * XC; e += G.tiles * 512) {
+          const int b = e / XC, c = e % XC;
+          const float val = c < d.SP ? a.speech[((long)b * d.T + t + 1) * d.SP + c]
+                                     : a.style[((long)b * d.T + t + 1) * d.ST + (c - d.SP)];
+          if (gnext) gnext[(long)b * a.GL + H + d.PI + c] = val;
+          xnext[xf_index(b, d.PI + c, NB)] = val;
+        }
+      }
+      if (tile == 0 && tid < B) {
+        const int b = tid;
+        float p[6];
+        for (int c = 0; c < 6; ++c) p[c] = (FV(0, c, b) + G.p0[c]) * a.st.out_std[c] + a.st.out_mean[c];
+        const float* rq = a.rrot + ((long)b * d.T + t - 1) * 4;
+        const float* rp = a.rpos + ((long)b * d.T + t - 1) * 3;
+        Q4 q = Q4{rq[0], rq[1], rq[2], rq[3]};
+        V3 pos = v3(rp[0], rp[1], rp[2]);
+        V3 npos = quat_mul_vec(q, d.dt * v3(p[0], p[1], p[2])) + pos;
+        V3 uu = quat_mul_vec(q, d.dt * v3(p[3], p[4], p[5]));
+        Q4 nq = quat_mul(quat_exp(0.5f * uu), q);
+        float* op = a.rpos + ((long)b * d.T + t) * 3; op[0] = npos.x; op[1] = npos.y; op[2] = npos.z;
+        float* oq = a.rrot + ((long)b * d.T + t) * 4; oq[0] = nq.w; oq[1] = nq.x; oq[2] = nq.y; oq[3] = nq.z;
+        if (next) {
+          const float* gz = a.gaze + ((long)b * d.T + t + 1) * 3;
+          V3 gd = quat_mul_vec(quat_inv(nq), v3(gz[0], gz[1], gz[2]) - npos);
+          const float gv[3] = {gd.x, gd.y, gd.z};
+          for (int k = 0; k < 3; ++k) {
+            const float e = (gv[k] - a.st.in_mean[PO + k]) / a.st.in_std[PO + k];
+            if (gnext) gnext[(long)b * a.GL + H + PO + k] = e;
+            xnext[xf_index(b, PO + k, NB)] = e;
+          }
+        }
+      }
+    } break;
+    case EPI_GRU_BWD: {   // dh = W^T delta + carry -> gate gradients of this layer
+      for (int id = tid; id < 16 * BP; id += 512) {
+        const int v = id / BP, b = id % BP, U = tile * 16 + v;
+        if (b < B && U < H) {
+          const long i = (long)b * H + U;
+          const float g = FV(0, v, b) + G.o0[i];
+          const float r = G.p0[i], z = G.p1[i], nn = G.p2[i], nh = G.p3[i], hp = G.p4[i];
+          const float dn = g * (1.f - z);
+          const float dz = g * (hp - nn);
+          const float dan = dn * (1.f - nn * nn);
+          const float dar = dan * nh * r * (1.f - r);
+          const float daz = dz * z * (1.f - z);
+          float* di = G.o1 + (long)b * 3 * H;
+          float* dh = G.o2 + (long)b * 3 * H;
+          di[U] = dar; di[H + U] = daz; di[2 * H + U] = dan;
+          dh[U] = dar; dh[H + U] = daz; dh[2 * H + U] = dan * r;
+          G.o3[xf_index(b, U, NB)] = dar; G.o3[xf_index(b, H + U, NB)] = daz; G.o3[xf_index(b, 2 * H + U, NB)] = dan;
+          G.o4[xf_index(b, U, NB)] = dar; G.o4[xf_index(b, H + U, NB)] = daz;
+          G.o4[xf_index(b, 2 * H + U, NB)] = dan * r;
+          G.o0[i] = g * z;
+        }
+      }
+    } break;
+    case EPI_ADD: {
+      for (int id = tid; id < 16 * BP; id += 512) {
+        const int v = id / BP, b = id % BP, col = tile * 16 + v;
+        if (b < B && col < H) G.o0[(long)b * H + col] += FV(0, v, b);
+      }
+    } break;
+    case EPI_DGIN: {      // dGin = W_ih0^T delta_i0 : [dhid -> ELU' -> D0 | dx part]
+      for (int id = tid; id < 16 * BP; id += 512) {
+        const int v = id / BP, b = id % BP, j = tile * 16 + v;
+        if (b < B && j < H + a.XD) {
+          const float g = FV(0, v, b);
+          if (j < H) {
+            const float d0 = g * d_elu_grad_from_out(G.p0[(long)b * a.GL + j]);
+            G.o0[(long)b * H + j] = d0;
+            G.o1[xf_index(b, j, NB)] = d0;
+          } else {
+            G.o2[(long)b * a.XD + (j - H)] = g;
+          }
+        }
+      }
+    } break;
+    case EPI_DX: {        // dx_t = dXa + W0^T D0 ; pose part -> dy_{t-1} (devectorize/vectorize backward)
+      const int PO = d.PO;
+      float* dy = G.o1;    // DY[t-1] canonical (null when t == 1)
+      for (int id = tid; id < 16 * BP; id += 512) {
+        const int v = id / BP, b = id % BP, q = tile * 16 + v;
+        if (b < B && q < a.XD) {
+          const int j = perm_dx(q, PO);
+          const float dx = FV(0, v, b) + G.p0[(long)b * a.XD + j];
+          G.o0[(long)b * a.XD + j] = dx;
+          if (dy && j >= 6 && j < PO) {
+            const float gy = (a.dpose[((long)b * d.T + t - 1) * PO + j] + dx / a.st.in_std[j]) * a.st.out_std[j];
+            dy[(long)b * a.POL + j] = gy;
+            G.o2[xf_index(b, j, NB)] = gy;
+          }
+        }
+      }
+      if (tile == 0 && dy && tid < B) {
+        const int b = tid;
+        float g6[6], dgd[3];
+        for (int c = 0; c < 6; ++c)
+          g6[c] = a.dpose[((long)b * d.T + t - 1) * PO + c] +
+                  (FV(0, c, b) + G.p0[(long)b * a.XD + c]) / a.st.in_std[c];
+        for (int k = 0; k < 3; ++k) dgd[k] = FV(0, 6 + k, b) + G.p0[(long)b * a.XD + PO + k];
+        root_bwd(d, a.st, b, t - 1, true, dgd, a.gaze, a.cpose, a.crpos, a.crrot, a.drpos, a.drrot, a.carry, g6);
+        for (int c = 0; c < 6; ++c) {
+          const float gy = g6[c] * a.st.out_std[c];
+          dy[(long)b * a.POL + c] = gy;
+          G.o2[xf_index(b, c, NB)] = gy;
+        }
+      }
+    } break;
+  }
+}
+
+// gradient wrt the raw output of the LAST step (no next step feeds on it)
+__global__ void dy_last_k(ZeggsDecDims d, ZeggsDecStats st, const float* dpose, const float* drpos, const float* drrot,
+                          const float* gaze, const float* pose, const float* rpos, const float* rrot, float* carry,
+                          float* dy, int POL, float* dyxf, int NB) {
+  const int b = blockIdx.x, t = d.T - 1;
+  const float* dpb = dpose + ((long)b * d.T + t) * d.PO;
+  for (int c = 6 + threadIdx.x; c < d.PO; c += blockDim.x) {
+    const float gy = dpb[c] * st.out_std[c];
+    dy[(long)b * POL + c] = gy;
+    dyxf[xf_index(b, c, NB)] = gy;
+  }
+  if (threadIdx.x == 0) {
+    float g6[6];
+    for (int c = 0; c < 6; ++c) g6[c] = dpb[c];
+    root_bwd(d, st, b, t, false, nullptr, gaze, pose, rpos, rrot, drpos, drrot, carry, g6);
+    for (int c = 0; c < 6; ++c) {
+      const float gy = g6[c] * st.out_std[c];
+      dy[(long)b * POL + c] = gy;
+      dyxf[xf_index(b, c, NB)] = gy;
+    }
+  }
+}
+
+// canonical [B, ld] (columns off .. off+K) -> activation fragments
+__global__ void to_xfrag_k(float* xf, const float* src, long ld, int off, int K, int B, int NB) {
+  long n = (long)B * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int k = (int)(i % K);
+    int b = (int)(i / K);
+    xf[xf_index(b, k, NB)] = src[(long)b * ld + off + k];
+  }
+}
+
+struct PackArgs {
+  float* dst;
+  const float* src;
+  int tiles, kb, mode, K, N, H, PO;
+  long ld;
+  int off;
+};
+// mode 0: rows (virtual col = source row)          V[vc][k] = src[vc*ld + off + k]
+// mode 1: GRU rows, tile = 5 units x (r,z,n)       V[g*5+u][k] = src[(g*H + tile*5+u)*ld + off + k]
+// mode 2: columns (transposed)                     V[vc][k] = src[k*ld + off + vc]
+// mode 3: columns with the dX permutation          V[q][k]  = src[k*ld + perm(q)]
+__global__ void pack_k(PackArgs p) {
+  const long n = (long)p.tiles * p.kb * 64;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    const long tk = idx >> 6;
+    const int kbi = (int)(tk % p.kb), tile = (int)(tk / p.kb);
+    const int i = lane & 15, k0 = 16 * kbi + 4 * (lane >> 4);
+    f4 v = f4{0.f, 0.f, 0.f, 0.f};
+    if (p.mode <= 1) {
+      long row = -1;
+      if (p.mode == 0) { if (tile * 16 + i < p.N) row = tile * 16 + i; }
+      else { const int g = i / 5, u = i % 5, U = tile * 5 + u; if (g < 3 && U < p.H) row = (long)g * p.H + U; }
+      if (row >= 0) {
+        const float* s = p.src + row * p.ld + p.off;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (k0 + c < p.K) v[c] = s[k0 + c];
+      }
+    } else {
+      const int q = tile * 16 + i;
+      if (q < p.N) {
+        const int col = p.mode == 3 ? perm_dx(q, p.PO) : p.off + q;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (k0 + c < p.K) v[c] = p.src[(long)(k0 + c) * p.ld + col];
+      }
+    }
+    ((f4*)p.dst)[idx] = v;
+  }
+}
+
+int pack(float* dst, const float* src, int tiles, int kb, int mode, int K, int N, int H, int PO, long ld, int off,
+         hipStream_t s) {
+  PackArgs p{dst, src, tiles, kb, mode, K, N, H, PO, ld, off};
+  long n = (long)tiles * kb * 64;
+  long g = (n + 255) / 256;
+  hipLaunchKernelGGL(pack_k, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, s, p);
+  ZLAUNCH_CHECK("pack");
+  return 0;
+}
+
+int launch_stage(const StageArgs& a, hipStream_t s) {
+  const int tiles = a.g[0].tiles + a.g[1].tiles;
+  switch (a.NB) {
+    case 1: hipLaunchKernelGGL(stage_k<1>, dim3(tiles), dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(stage_k<2>, dim3(tiles), dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(stage_k<3>, dim3(tiles), dim3(512), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(stage_k<4>, dim3(tiles), dim3(512), 0, s, a); break;
+    default: zeggs_set_error("decoder fast path: batch > 64"); return -1;
+  }
+  ZLAUNCH_CHECK("decoder_stage");
+  return 0;
+}
+
+inline Seg seg(const float* w, const float* x, int kb, int acc) { return Seg{w, x, kb, acc}; }
+
+StageArgs base_args(const ZeggsDecDims& d, const ZeggsDecStats* st, const DecWs& w) {
+  StageArgs a;
+  memset(&a, 0, sizeof(a));
+  a.d = d; a.st = *st; a.NB = w.NB; a.GL = w.GL; a.XD = w.XD; a.POL = w.POL;
+  return a;
+}
+
+}  // namespace
+
+int dec_fast_supported(const ZeggsDecDims& d) { return d.H % 16 == 0 && d.B <= 64 && d.PI == d.PO + 3 && d.PO >= 16; }
+
+int dec_fast_pack_fwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s) {
+  const int H = d.H, XD = w.XD;
+  ZTRY(pack(w.pw_l0, P->l0_w, w.nTH, w.KBX, 0, XD, H, H, d.PO, XD, 0, s));
+  ZTRY(pack(w.pw_ih0h, P->w_ih0, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H + XD, 0, s));
+  ZTRY(pack(w.pw_ih0x, P->w_ih0, w.nT5, w.KBX, 1, XD, 3 * H, H, d.PO, H + XD, H, s));
+  ZTRY(pack(w.pw_hh0, P->w_hh0, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s));
+  ZTRY(pack(w.pw_ih1, P->w_ih1, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s));
+  ZTRY(pack(w.pw_hh1, P->w_hh1, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s));
+  ZTRY(pack(w.pw_l2, P->l2_w, w.nTPO, w.KBH, 0, H, d.PO, H, d.PO, H, 0, s));
+  return 0;
+}
+
+int dec_fast_pack_bwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s) {
+  const int H = d.H, XD = w.XD;
+  ZTRY(pack(w.pb_l2, P->l2_w, w.nTH, w.KBPO, 2, d.PO, H, H, d.PO, H, 0, s));          // V[U][c] = W2[c][U]
+  ZTRY(pack(w.pb_ih1, P->w_ih1, w.nTH, w.KB3H, 2, 3 * H, H, H, d.PO, H, 0, s));        // V[U][k] = W_ih1[k][U]
+  ZTRY(pack(w.pb_hh1, P->w_hh1, w.nTH, w.KB3H, 2, 3 * H, H, H, d.PO, H, 0, s));
+  ZTRY(pack(w.pb_ih0, P->w_ih0, w.nTGI, w.KB3H, 2, 3 * H, H + XD, H, d.PO, H + XD, 0, s));
+  ZTRY(pack(w.pb_hh0, P->w_hh0, w.nTH, w.KB3H, 2, 3 * H, H, H, d.PO, H, 0, s));
+  ZTRY(pack(w.pb_l0, P->l0_w, w.nTX, w.KBH, 3, H, XD, H, d.PO, XD, 0, s));             // V[q][u] = W0[u][perm(q)]
+  return 0;
+}
+
+int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w,
+                       const float* gaze, const float* speech, const float* style, float* pose, float* rpos,
+                       float* rrot, int training, hipStream_t s) {
+  const int B = d.B, T = d.T, H = d.H, NB = w.NB;
+  const long sG = (long)B * w.GL, sH = (long)B * H;
+  const long XB = 256L * NB;
+  auto cs = [&](int t) { return training ? t : (t & 1); };
+  float* Xxf[2] = {w.Xxf, w.Xxf + w.KBX * XB};
+  float* H0xf[2] = {w.H0xf, w.H0xf + w.KBH * XB};
+  float* H1xf[2] = {w.H1xf, w.H1xf + w.KBH * XB};
+  ZTRY(k_fill(w.xf_base_fwd, (long)(w.xf_bytes_fwd / 4), 0.f, s));
+  if (T < 2) return 0;
+  // fragments of the initial state and of x_1 (written in canonical form by the init kernel / CSE GEMMs)
+  auto conv = [&](float* xf, const float* src, long ld, int off, int K) {
+    long n = (long)B * K, g = (n + 255) / 256;
+    hipLaunchKernelGGL(to_xfrag_k, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, s, xf, src, ld, off, K, B, NB);
+  };
+  conv(H0xf[0], w.H0 + cs(0) * sH, H, 0, H);
+  conv(H1xf[0], w.H1 + cs(0) * sH, H, 0, H);
+  conv(Xxf[1], w.Gin + cs(1) * sG, w.GL, H, w.XD);
+  ZLAUNCH_CHECK("to_xfrag");
+  for (int t = 1; t < T; ++t) {
+    const int c = t & 1, p = (t - 1) & 1;
+    const long o = (long)t * sH;
+    StageArgs a = base_args(d, st, w);
+    a.t = t; a.gaze = gaze; a.speech = speech; a.style = style; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
+    // S1: hid
+    a.g[0] = Grp{};
+    a.g[1] = Grp{};
+    a.g[0].seg[0] = seg(w.pw_l0, Xxf[c], w.KBX, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_ELU_HID;
+    a.g[0].p0 = P->l0_b; a.g[0].o0 = w.Gin + cs(t) * sG; a.g[0].o1 = w.HIDxf;
+    ZTRY(launch_stage(a, s));
+    // S2: GRU layer 0
+    a.g[0] = Grp{};
+    a.g[0].seg[0] = seg(w.pw_ih0h, w.HIDxf, w.KBH, 0); a.g[0].seg[1] = seg(w.pw_ih0x, Xxf[c], w.KBX, 0);
+    a.g[0].seg[2] = seg(w.pw_hh0, H0xf[p], w.KBH, 1); a.g[0].nseg = 3; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
+    a.g[0].p0 = P->b_ih0; a.g[0].p1 = P->b_hh0; a.g[0].p2 = w.H0 + cs(t - 1) * sH;
+    a.g[0].o0 = w.H0 + cs(t) * sH; a.g[0].o1 = H0xf[c];
+    if (training) { a.g[0].o2 = w.R0 + o; a.g[0].o3 = w.Z0 + o; a.g[0].o4 = w.N0 + o; a.g[0].o5 = w.NH0 + o; }
+    ZTRY(launch_stage(a, s));
+    // S3: GRU layer 1
+    a.g[0] = Grp{};
+    a.g[0].seg[0] = seg(w.pw_ih1, H0xf[c], w.KBH, 0); a.g[0].seg[1] = seg(w.pw_hh1, H1xf[p], w.KBH, 1);
+    a.g[0].nseg = 2; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
+    a.g[0].p0 = P->b_ih1; a.g[0].p1 = P->b_hh1; a.g[0].p2 = w.H1 + cs(t - 1) * sH;
+    a.g[0].o0 = w.H1 + cs(t) * sH; a.g[0].o1 = H1xf[c];
+    if (training) { a.g[0].o2 = w.R1 + o; a.g[0].o3 = w.Z1 + o; a.g[0].o4 = w.N1 + o; a.g[0].o5 = w.NH1 + o; }
+    ZTRY(launch_stage(a, s));
+    // S4: output projection + pose integration + x_{t+1}
+    a.g[0] = Grp{};
+    a.g[0].seg[0] = seg(w.pw_l2, H1xf[c], w.KBH, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTPO; a.g[0].epi = EPI_OUT_FWD;
+    a.g[0].p0 = P->l2_b; a.g[0].o0 = (t + 1 < T) ? w.Gin + cs(t + 1) * sG : nullptr; a.g[0].o1 = Xxf[(t + 1) & 1];
+    ZTRY(launch_stage(a, s));
+  }
+  return 0;
+}
+
+int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w,
+                       const float* gaze, const float* pose, const float* rpos, const float* rrot,
+                       const float* dpose, const float* drpos, const float* drrot, hipStream_t s) {
+  const int B = d.B, T = d.T, H = d.H, NB = w.NB;
+  const long sG = (long)B * w.GL, sH = (long)B * H, s3 = 3 * sH;
+  ZTRY(k_fill(w.xf_base_bwd, (long)(w.xf_bytes_bwd / 4), 0.f, s));
+  if (T < 2) return 0;
+  hipLaunchKernelGGL(dy_last_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, gaze, pose, rpos, rrot, w.carry,
+                     w.DY + (long)(T - 1) * B * w.POL, w.POL, w.DYxf, NB);
+  ZLAUNCH_CHECK("dy_last");
+  for (int t = T - 1; t >= 1; --t) {
+    const long o = (long)t * sH;
+    StageArgs a = base_args(d, st, w);
+    a.t = t; a.gaze = gaze; a.cpose = pose; a.crpos = rpos; a.crrot = rrot; a.dpose = dpose; a.drpos = drpos;
+    a.drrot = drrot; a.carry = w.carry;
+    // B1: dH1 = W2^T dy + carry -> layer-1 gate gradients
+    a.g[0] = Grp{}; a.g[1] = Grp{};
+    a.g[0].seg[0] = seg(w.pb_l2, w.DYxf, w.KBPO, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
+    a.g[0].p0 = w.R1 + o; a.g[0].p1 = w.Z1 + o; a.g[0].p2 = w.N1 + o; a.g[0].p3 = w.NH1 + o; a.g[0].p4 = w.H1 + o - sH;
+    a.g[0].o0 = w.dH1c; a.g[0].o1 = w.DI1 + t * s3; a.g[0].o2 = w.DH1 + t * s3; a.g[0].o3 = w.DI1xf; a.g[0].o4 = w.DH1xf;
+    ZTRY(launch_stage(a, s));
+    // B2: dH0 = W_ih1^T di1 + carry -> layer-0 gate gradients ; dH1 carry += W_hh1^T dh1
+    a.g[0] = Grp{};
+    a.g[0].seg[0] = seg(w.pb_ih1, w.DI1xf, w.KB3H, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
+    a.g[0].p0 = w.R0 + o; a.g[0].p1 = w.Z0 + o; a.g[0].p2 = w.N0 + o; a.g[0].p3 = w.NH0 + o; a.g[0].p4 = w.H0 + o - sH;
+    a.g[0].o0 = w.dH0c; a.g[0].o1 = w.DI0 + t * s3; a.g[0].o2 = w.DH0 + t * s3; a.g[0].o3 = w.DI0xf; a.g[0].o4 = w.DH0xf;
+    a.g[1].seg[0] = seg(w.pb_hh1, w.DH1xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
+    a.g[1].o0 = w.dH1c;
+    ZTRY(launch_stage(a, s));
+    // B3: dGin = W_ih0^T di0 -> [D0 | dx part] ; dH0 carry += W_hh0^T dh0
+    a.g[0] = Grp{}; a.g[1] = Grp{};
+    a.g[0].seg[0] = seg(w.pb_ih0, w.DI0xf, w.KB3H, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTGI; a.g[0].epi = EPI_DGIN;
+    a.g[0].p0 = w.Gin + t * sG; a.g[0].o0 = w.D0 + o; a.g[0].o1 = w.D0xf; a.g[0].o2 = w.dXa;
+    a.g[1].seg[0] = seg(w.pb_hh0, w.DH0xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
+    a.g[1].o0 = w.dH0c;
+    ZTRY(launch_stage(a, s));
+    // B4: dx_t = dx part + W0^T D0 -> dy_{t-1}
+    a.g[0] = Grp{}; a.g[1] = Grp{};
+    a.g[0].seg[0] = seg(w.pb_l0, w.D0xf, w.KBH, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTX; a.g[0].epi = EPI_DX;
+    a.g[0].p0 = w.dXa; a.g[0].o0 = w.DX + (long)t * B * w.XD;
+    a.g[0].o1 = t > 1 ? w.DY + (long)(t - 1) * B * w.POL : nullptr; a.g[0].o2 = w.DYxf;
+    ZTRY(launch_stage(a, s));
+  }
+  return 0;
+}

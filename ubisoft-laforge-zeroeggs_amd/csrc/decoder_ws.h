@@ -1,0 +1,103 @@
+// Workspace layout of the decoder (shared by decoder.hip and decoder_fast.hip).
+#pragma once
+#include <string.h>
+
+#include "../../include/zeggs_hip.h"
+#include "common.h"
+
+struct DecWs {
+  // canonical (row-major) activations, time-major [T][B][.] in training, 2-slot ring in inference
+  float *Gin, *H0, *H1, *R0, *Z0, *N0, *NH0, *R1, *Z1, *N1, *NH1, *Y;
+  float *cse_in, *cse_a, *cse_b;          // cell-state encoder activations
+  float *gi, *gh;                          // per-step gate pre-activations [B,3H]   (generic path)
+  // backward
+  float *DY, *DI0, *DH0, *DI1, *DH1, *D0, *DX;
+  float *dH0c, *dH1c, *dGin, *dXn, *carry, *t0, *t1;
+  int GL, XD, POL;
+  // ---- fast path: fragment-packed weights (see decoder_fast.hip) and activations
+  int NB, nT5, nTH, nTX, nTPO, nTGI, KBH, KBX, KBPO, KB3H;
+  float *pw_l0, *pw_ih0h, *pw_ih0x, *pw_hh0, *pw_ih1, *pw_hh1, *pw_l2;   // forward packs
+  float *pb_l2, *pb_ih1, *pb_hh1, *pb_ih0, *pb_hh0, *pb_l0;              // backward (transposed) packs
+  float *Xxf, *HIDxf, *H0xf, *H1xf;                                      // forward activation fragments (rings of 2)
+  float *DYxf, *DI1xf, *DH1xf, *DI0xf, *DH0xf, *D0xf, *dXa;               // backward fragments
+  size_t xf_bytes_fwd, xf_bytes_bwd;
+  float *xf_base_fwd, *xf_base_bwd;
+};
+
+inline int round4(int x) { return (x + 3) / 4 * 4; }
+
+inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
+  DecWs w;
+  memset(&w, 0, sizeof(w));
+  const long B = d.B, T = d.T, H = d.H;
+  w.XD = d.PI + d.SP + d.ST;
+  w.GL = round4(d.H + w.XD);
+  w.POL = round4(d.PO);
+  const long TS = training ? T : 2;   // inference keeps a 2-slot ring for the step buffers
+  w.Gin = a.f(TS * B * w.GL);
+  w.H0 = a.f(TS * B * H); w.H1 = a.f(TS * B * H);
+  w.Y = a.f(B * (long)w.POL);
+  w.cse_in = a.f(B * (long)(d.PI + d.ST));
+  w.cse_a = a.f(B * H); w.cse_b = a.f(B * H);
+  w.gi = a.f(B * 3 * H); w.gh = a.f(B * 3 * H);
+  if (training) {
+    w.R0 = a.f(T * B * H); w.Z0 = a.f(T * B * H); w.N0 = a.f(T * B * H); w.NH0 = a.f(T * B * H);
+    w.R1 = a.f(T * B * H); w.Z1 = a.f(T * B * H); w.N1 = a.f(T * B * H); w.NH1 = a.f(T * B * H);
+    w.DY = a.f(T * B * (long)w.POL);
+    w.DI0 = a.f(T * B * 3 * H); w.DH0 = a.f(T * B * 3 * H);
+    w.DI1 = a.f(T * B * 3 * H); w.DH1 = a.f(T * B * 3 * H);
+    w.D0 = a.f(T * B * H);
+    w.DX = a.f(T * B * (long)w.XD);
+    w.dH0c = a.f(B * H); w.dH1c = a.f(B * H);
+    w.dGin = a.f(B * (long)w.GL);
+    w.dXn = a.f(B * (long)w.XD);
+    w.carry = a.f(B * 8);
+    w.t0 = a.f(B * 2 * H); w.t1 = a.f(B * (long)(d.PI + d.ST + 2 * H));
+  }
+  // ---- fast path
+  w.NB = (d.B + 15) / 16;
+  w.nT5 = (d.H + 4) / 5; w.nTH = d.H / 16; w.nTX = (w.XD + 15) / 16; w.nTPO = (d.PO + 15) / 16;
+  w.nTGI = w.nTH + w.nTX;
+  w.KBH = d.H / 16; w.KBX = w.nTX; w.KBPO = w.nTPO; w.KB3H = 3 * d.H / 16;
+  const long BLK = 256;   // floats per (tile, k-block) weight fragment = 64 lanes x 4
+  w.pw_l0 = a.f((long)w.nTH * w.KBX * BLK);
+  w.pw_ih0h = a.f((long)w.nT5 * w.KBH * BLK);
+  w.pw_ih0x = a.f((long)w.nT5 * w.KBX * BLK);
+  w.pw_hh0 = a.f((long)w.nT5 * w.KBH * BLK);
+  w.pw_ih1 = a.f((long)w.nT5 * w.KBH * BLK);
+  w.pw_hh1 = a.f((long)w.nT5 * w.KBH * BLK);
+  w.pw_l2 = a.f((long)w.nTPO * w.KBH * BLK);
+  const long XB = 256L * w.NB;  // floats per k-block of an activation fragment
+  {
+    size_t o0 = a.off;
+    w.Xxf = a.f(2 * w.KBX * XB); w.HIDxf = a.f(w.KBH * XB); w.H0xf = a.f(2 * w.KBH * XB); w.H1xf = a.f(2 * w.KBH * XB);
+    w.xf_base_fwd = w.Xxf;
+    w.xf_bytes_fwd = a.off - align_up(o0, 256);
+  }
+  if (training) {
+    w.pb_l2 = a.f((long)w.nTH * w.KBPO * BLK);
+    w.pb_ih1 = a.f((long)w.nTH * w.KB3H * BLK);
+    w.pb_hh1 = a.f((long)w.nTH * w.KB3H * BLK);
+    w.pb_ih0 = a.f((long)w.nTGI * w.KB3H * BLK);
+    w.pb_hh0 = a.f((long)w.nTH * w.KB3H * BLK);
+    w.pb_l0 = a.f((long)w.nTX * w.KBH * BLK);
+    size_t o0 = a.off;
+    w.DYxf = a.f(w.KBPO * XB); w.DI1xf = a.f(w.KB3H * XB); w.DH1xf = a.f(w.KB3H * XB);
+    w.DI0xf = a.f(w.KB3H * XB); w.DH0xf = a.f(w.KB3H * XB); w.D0xf = a.f(w.KBH * XB);
+    w.xf_base_bwd = w.DYxf;
+    w.xf_bytes_bwd = a.off - align_up(o0, 256);
+    w.dXa = a.f(B * (long)w.XD);
+  }
+  return w;
+}
+
+// fast path entry points (decoder_fast.hip)
+int dec_fast_supported(const ZeggsDecDims& d);
+int dec_fast_pack_fwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s);
+int dec_fast_pack_bwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s);
+int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w,
+                       const float* gaze, const float* speech, const float* style, float* pose, float* rpos,
+                       float* rrot, int training, hipStream_t s);
+int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w,
+                       const float* gaze, const float* pose, const float* rpos, const float* rrot,
+                       const float* dpose, const float* drpos, const float* drrot, hipStream_t s);

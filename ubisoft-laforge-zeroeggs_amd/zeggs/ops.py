@@ -418,3 +418,8 @@ def normalize_rows_(x, mean, std):
     _check(lib().zeggs_normalize_rows(_p(x), C.c_long(rows), W, C.c_long(W), _p(mean), _p(vec) if vec is not None else None,
                                       C.c_float(sc), _stream()), "normalize_rows")
     return x
+
+
+def set_option(name, value):
+    """Runtime switches of the library (e.g. "decoder_fast": 1 packed stage kernels / 0 generic GEMM path)."""
+    _check(lib().zeggs_set_option(name.encode(), int(value)), "set_option")
