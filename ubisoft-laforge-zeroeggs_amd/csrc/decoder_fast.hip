@@ -24,7 +24,8 @@
 
 namespace {
 
-constexpr int WAVES = 8;
+constexpr int WAVES = 16;
+constexpr int NTHR = WAVES * 64;
 enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX };
 
 struct Seg {
@@ -65,32 +66,29 @@ __device__ __forceinline__ long xf_index(int b, int k, int NB) {
 template <int NB>
 __device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* __restrict__ xp, int lo, int hi,
                                            f4 (&acc)[NB]) {
-  int kb = lo;
-  for (; kb + 4 <= hi; kb += 4) {
-    f4 wv[4], xv[4][NB];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      wv[u] = wp[(long)(kb + u) * 64];
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) xv[u][nb] = xp[((long)(kb + u) * NB + nb) * 64];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][c], xv[u][nb][c], acc[nb], 0, 0, 0);
+  // register double buffering: the loads of group g+1 are in flight while group g feeds the matrix cores
+  constexpr int U = 2;
+  f4 w0[U], x0[U][NB], w1[U], x1[U][NB];
+#define ZLOAD(W, X, KB0)                                                            \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) if ((KB0) + u < hi) {                \
+    W[u] = wp[(long)((KB0) + u) * 64];                                              \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) X[u][nb] = xp[((long)((KB0) + u) * NB + nb) * 64]; \
   }
-  for (; kb < hi; ++kb) {
-    f4 wv = wp[(long)kb * 64], xv[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) xv[nb] = xp[((long)kb * NB + nb) * 64];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], xv[nb][c], acc[nb], 0, 0, 0);
+#define ZCOMP(W, X, KB0)                                                            \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) if ((KB0) + u < hi) {                \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                   \
+      _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                             \
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u][c], X[u][nb][c], acc[nb], 0, 0, 0); \
   }
+  ZLOAD(w0, x0, lo)
+  for (int kb = lo; kb < hi; kb += 2 * U) {
+    ZLOAD(w1, x1, kb + U)
+    ZCOMP(w0, x0, kb)
+    ZLOAD(w0, x0, kb + 2 * U)
+    ZCOMP(w1, x1, kb + U)
+  }
+#undef ZLOAD
+#undef ZCOMP
 }
 
 // backward of the root integration of frame `f` (see dec_devec_bwd_k in decoder.hip for the derivation).
@@ -136,7 +134,7 @@ __device__ void root_bwd(const ZeggsDecDims& d, const ZeggsDecStats& st, int b, 
 }
 
 template <int NB>
-__global__ __launch_bounds__(512) void stage_k(StageArgs a) {
+__global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
   __shared__ f4 red[WAVES][2][NB][64];
   __shared__ f4 fin[2][NB][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -187,7 +185,7 @@ __global__ __launch_bounds__(512) void stage_k(StageArgs a) {
 
   switch (G.epi) {
     case EPI_ELU_HID: {   // hid = ELU(W0 x + b0) -> Gin[t][:, 0:H] and its fragment copy
-      for (int id = tid; id < 16 * BP; id += 512) {
+      for (int id = tid; id < 16 * BP; id += NTHR) {
         const int v = id / BP, b = id % BP, col = tile * 16 + v;
         if (b < B && col < H) {
           const float val = d_elu(FV(0, v, b) + G.p0[col]);
@@ -197,7 +195,7 @@ __global__ __launch_bounds__(512) void stage_k(StageArgs a) {
       }
     } break;
     case EPI_GRU_FWD: {   // tile = 5 hidden units x (r, z, n); acc0 = input side, acc1 = hidden side
-      for (int id = tid; id < 5 * BP; id += 512) {
+      for (int id = tid; id < 5 * BP; id += NTHR) {
         const int u = id / BP, b = id % BP, U = tile * 5 + u;
         if (b < B && U < H) {
           const float r = d_sigmoid(FV(0, u, b) + G.p0[U] + (FV(1, u, b) + G.p1[U]));
@@ -218,7 +216,7 @@ __global__ __launch_bounds__(512) void stage_k(StageArgs a) {
       float* gnext = G.o0;
       float* xnext = G.o1;
       const bool next = (t + 1 < d.T);
-      for (int id = tid; id < 16 * BP; id += 512) {
+      for (int id = tid; id < 16 * BP; id += NTHR) {
         const int v = id / BP, b = id % BP, col = tile * 16 + v;
         if (b < B && col < PO) {
           const float p = (FV(0, v, b) + G.p0[col]) * a.st.out_std[col] + a.st.out_mean[col];
@@ -232,7 +230,7 @@ __global__ __launch_bounds__(512) void stage_k(StageArgs a) {
       }
       if (next) {   // speech / style columns of x_{t+1}
         const int XC = d.SP + d.ST;
-        for (int e = tile * 512 + tid; e < B * XC; e += G.tiles * 512) {
+        for (int e = tile * NTHR + tid; e < B * XC; e += G.tiles * NTHR) {
           const int b = e / XC, c = e % XC;
           const float val = c < d.SP ? a.speech[((long)b * d.T + t + 1) * d.SP + c]
                                      : a.style[((long)b * d.T + t + 1) * d.ST + (c - d.SP)];
@@ -266,7 +264,7 @@ __global__ __launch_bounds__(512) void stage_k(StageArgs a) {
       }
     } break;
     case EPI_GRU_BWD: {   // dh = W^T delta + carry -> gate gradients of this layer
-      for (int id = tid; id < 16 * BP; id += 512) {
+      for (int id = tid; id < 16 * BP; id += NTHR) {
         const int v = id / BP, b = id % BP, U = tile * 16 + v;
         if (b < B && U < H) {
           const long i = (long)b * H + U;
@@ -289,13 +287,13 @@ __global__ __launch_bounds__(512) void stage_k(StageArgs a) {
       }
     } break;
     case EPI_ADD: {
-      for (int id = tid; id < 16 * BP; id += 512) {
+      for (int id = tid; id < 16 * BP; id += NTHR) {
         const int v = id / BP, b = id % BP, col = tile * 16 + v;
         if (b < B && col < H) G.o0[(long)b * H + col] += FV(0, v, b);
       }
     } break;
     case EPI_DGIN: {      // dGin = W_ih0^T delta_i0 : [dhid -> ELU' -> D0 | dx part]
-      for (int id = tid; id < 16 * BP; id += 512) {
+      for (int id = tid; id < 16 * BP; id += NTHR) {
         const int v = id / BP, b = id % BP, j = tile * 16 + v;
         if (b < B && j < H + a.XD) {
           const float g = FV(0, v, b);
@@ -312,7 +310,7 @@ __global__ __launch_bounds__(512) void stage_k(StageArgs a) {
     case EPI_DX: {        // dx_t = dXa + W0^T D0 ; pose part -> dy_{t-1} (devectorize/vectorize backward)
       const int PO = d.PO;
       float* dy = G.o1;    // DY[t-1] canonical (null when t == 1)
-      for (int id = tid; id < 16 * BP; id += 512) {
+      for (int id = tid; id < 16 * BP; id += NTHR) {
         const int v = id / BP, b = id % BP, q = tile * 16 + v;
         if (b < B && q < a.XD) {
           const int j = perm_dx(q, PO);
@@ -429,10 +427,10 @@ int pack(float* dst, const float* src, int tiles, int kb, int mode, int K, int N
 int launch_stage(const StageArgs& a, hipStream_t s) {
   const int tiles = a.g[0].tiles + a.g[1].tiles;
   switch (a.NB) {
-    case 1: hipLaunchKernelGGL(stage_k<1>, dim3(tiles), dim3(512), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(stage_k<2>, dim3(tiles), dim3(512), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(stage_k<3>, dim3(tiles), dim3(512), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(stage_k<4>, dim3(tiles), dim3(512), 0, s, a); break;
+    case 1: hipLaunchKernelGGL(stage_k<1>, dim3(tiles), dim3(NTHR), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(stage_k<2>, dim3(tiles), dim3(NTHR), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(stage_k<3>, dim3(tiles), dim3(NTHR), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(stage_k<4>, dim3(tiles), dim3(NTHR), 0, s, a); break;
     default: zeggs_set_error("decoder fast path: batch > 64"); return -1;
   }
   ZLAUNCH_CHECK("decoder_stage");

@@ -13,6 +13,7 @@ struct GemmArgs {
   int nb1;
   int kbatch;                                  // batch-reduce: K loop runs over kbatch segments
   long kbsA, kbsB;
+  int splitk;                                  // set by launch_gemm (split-K with atomic accumulation)
   float alpha, beta;
   int act;
 };

@@ -14,6 +14,7 @@
 // loads are in flight while the current one feeds the MFMAs.
 #include "common.h"
 #include "gemm.h"
+#include "kernels.h"
 
 namespace {
 
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int m_base = blockIdx.y * BM, n_base = blockIdx.x * BN;
-  const int z = blockIdx.z;
+  const int zz = blockIdx.z;
+  const int z = zz / g.splitk, ks = zz % g.splitk;
   const long z0 = z / g.nb1, z1 = z % g.nb1;
   const float* A = g.A + z0 * g.bsA0 + z1 * g.bsA1;
   const float* B = g.B + z0 * g.bsB0 + z1 * g.bsB1;
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   else               { b_r = tid / (BN / EB); b_c = (tid % (BN / EB)) * EB; }   // b_r = k, b_c = n0
 
   const int nkt = (g.K + BK - 1) / BK;
-  const int ntiles = nkt * g.kbatch;
+  const int ntiles_all = nkt * g.kbatch;
+  const int t_begin = (int)((long)ntiles_all * ks / g.splitk), ntiles = (int)((long)ntiles_all * (ks + 1) / g.splitk);
   float ra[EA], rb[EB];
 
   auto gload = [&](int tile) {
@@ -121,11 +124,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gload(0);
-  sstore();
-  __syncthreads();
   const int kh = lane >> 5, l31 = lane & 31;
-  for (int t = 0; t < ntiles; ++t) {
+  if (t_begin < ntiles) {
+    gload(t_begin);
+    sstore();
+  }
+  __syncthreads();
+  for (int t = t_begin; t < ntiles; ++t) {
     if (t + 1 < ntiles) gload(t + 1);
 #pragma unroll
     for (int kp = 0; kp < BK / 2; ++kp) {
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
         const int m = m_base + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (m >= g.M) continue;
         float* cp = C + (long)m * g.scm + (long)n * g.scn;
+        if (g.splitk > 1) { atomicAdd(cp, g.alpha * acc[i][j][r]); continue; }
         float v = g.alpha * acc[i][j][r] + bv;
         if (g.beta != 0.f) v += g.beta * (*cp);
         *cp = d_act(v, g.act);
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmArgs& g, int nbatch, hipStream_t s) {
-  dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), nbatch), block(WM * WN * 64);
+  dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), nbatch * g.splitk), block(WM * WN * 64);
   const bool akc = (g.sak == 1), bkc = (g.sbk == 1) && (g.sbn != 1 || g.N == 1);
   if (!akc && g.sam != 1) { zeggs_set_error("gemm: A has no unit stride (sam=%ld sak=%ld)", g.sam, g.sak); return -1; }
   if (!bkc && g.sbn != 1) { zeggs_set_error("gemm: B has no unit stride (sbk=%ld sbn=%ld)", g.sbk, g.sbn); return -1; }
@@ -187,17 +193,32 @@ int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || nbatch <= 0) return 0;
   if (g.nb1 <= 0) g.nb1 = 1;
   if (g.kbatch <= 0) g.kbatch = 1;
+  g.splitk = 1;
   if (g.M <= 32) return launch_cfg<32, 128, 1, 4>(g, nbatch, s);
-  const long big_tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nbatch;
-  if (g.M <= 64 || g.N <= 64 || big_tiles < 192) return launch_cfg<64, 64, 2, 2>(g, nbatch, s);
-  return launch_cfg<128, 128, 2, 2>(g, nbatch, s);
+  const bool big = g.M > 64 && g.N > 64;
+  const long tiles = big ? (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nbatch : (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nbatch;
+  const long ktiles = (long)cdiv(g.K, 16) * g.kbatch;
+  // few output tiles but a long contraction (weight gradients): split K over workgroups, combine with fp32 atomics
+  const bool can_split = nbatch == 1 && g.beta == 0.f && g.bias == nullptr && g.act == ACT_NONE && g.scn == 1 &&
+                         g.scm == g.N && ktiles >= 64;
+  if (tiles < 160 && can_split) {
+    long sk = (256 + tiles - 1) / tiles;
+    if (sk > ktiles / 16) sk = ktiles / 16;
+    if (sk > 32) sk = 32;
+    if (sk > 1) {
+      g.splitk = (int)sk;
+      ZTRY(k_fill(g.C, (long)g.M * g.N, 0.f, s));
+    }
+  }
+  if (big && (tiles * g.splitk >= 128 || g.splitk > 1)) return launch_cfg<128, 128, 2, 2>(g, nbatch, s);
+  return launch_cfg<64, 64, 2, 2>(g, nbatch, s);
 }
 
 GemmArgs gemm_args(const float* A, const float* B, float* C, int M, int N, int K) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
-  g.nb1 = 1; g.kbatch = 1; g.alpha = 1.f; g.beta = 0.f; g.act = ACT_NONE;
+  g.nb1 = 1; g.kbatch = 1; g.splitk = 1; g.alpha = 1.f; g.beta = 0.f; g.act = ACT_NONE;
   return g;
 }
 

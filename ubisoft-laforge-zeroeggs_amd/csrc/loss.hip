@@ -218,41 +218,43 @@ __device__ __forceinline__ void term_of(int e, int J, int& id, float& w, int& id
 
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
-// one block = one feature row e x 256 consecutive frames; writes G = dLoss/dF_O and accumulates the terms
+// one block = one feature row e, looping over all frames (coalesced along the frame axis);
+// writes G = dLoss/dF_O and accumulates the row's share of its (one or two) loss terms
 __global__ __launch_bounds__(256) void loss_terms_k(ZeggsLossDims d, const float* FO, const float* FW, float* G,
                                                      float* terms, float gscale) {
   __shared__ float red[16];
   const long NF = (long)d.B * d.T;
-  const int e = blockIdx.y;
-  const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.x;
   int id, id2, size; float w, w2;
   term_of(e, d.J, id, w, id2, w2, size);
-  float s1 = 0.f, s2 = 0.f, g = 0.f;
-  if (f < NF) {
+  const float n1 = (float)d.B * d.T * size, n2 = (float)d.B * (d.T - 1) * size;
+  const float* fo = FO + (long)e * NF;
+  const float* fw = FW + (long)e * NF;
+  float s1 = 0.f, s2 = 0.f;
+  for (long f = threadIdx.x; f < NF; f += blockDim.x) {
     const int t = (int)(f % d.T);
-    const float n1 = (float)d.B * d.T * size, n2 = (float)d.B * (d.T - 1) * size;
-    const float o0 = FE(FO, e), w0 = FE(FW, e);
+    const float o0 = fo[f], w0 = fw[f];
     const float v = w * (o0 - w0);
-    s1 = fabsf(v) / n1;
-    g = w * sgn(v) / n1;
+    s1 += fabsf(v);
+    float g = w * sgn(v) / n1;
     if (id2 >= 0 && d.T > 1) {
       if (t + 1 < d.T) {
-        float dd = w2 * ((FO[(long)e * NF + f + 1] - o0) / d.dt - (FW[(long)e * NF + f + 1] - w0) / d.dt);
-        s2 = fabsf(dd) / n2;
+        float dd = w2 * ((fo[f + 1] - o0) / d.dt - (fw[f + 1] - w0) / d.dt);
+        s2 += fabsf(dd);
         g -= w2 * sgn(dd) / (d.dt * n2);
       }
       if (t > 0) {
-        float dd = w2 * ((o0 - FO[(long)e * NF + f - 1]) / d.dt - (w0 - FW[(long)e * NF + f - 1]) / d.dt);
+        float dd = w2 * ((o0 - fo[f - 1]) / d.dt - (w0 - fw[f - 1]) / d.dt);
         g += w2 * sgn(dd) / (d.dt * n2);
       }
     }
-    FE(G, e) = g * gscale / 18.0f;
+    G[(long)e * NF + f] = g * gscale / 18.0f;
   }
   s1 = block_sum(s1, red);
   if (id2 >= 0) s2 = block_sum(s2, red);
   if (threadIdx.x == 0) {
-    atomicAdd(terms + id, s1);
-    if (id2 >= 0) atomicAdd(terms + id2, s2);
+    atomicAdd(terms + id, s1 / n1);
+    if (id2 >= 0 && d.T > 1) atomicAdd(terms + id2, s2 / n2);
   }
 }
 
@@ -472,7 +474,7 @@ extern "C" int zeggs_loss_fwd_bwd(const ZeggsLossDims* dp, const int* parents, c
   ZTRY(k_fill(terms, 19, 0.f, s));
   hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(2 * NF, 64)), dim3(64), 0, s, d, parents, ioO, ioW, gaze, w.FO, w.FW, w.LM);
   ZLAUNCH_CHECK("loss_frame_fwd");
-  hipLaunchKernelGGL(loss_terms_k, dim3(cdiv(NF, 256), o.n), dim3(256), 0, s, d, w.FO, w.FW, w.G, terms, gscale);
+  hipLaunchKernelGGL(loss_terms_k, dim3(o.n), dim3(256), 0, s, d, w.FO, w.FW, w.G, terms, gscale);
   ZLAUNCH_CHECK("loss_terms");
   hipLaunchKernelGGL(loss_kl_final_k, dim3(1), dim3(256), 0, s, mu, logvar, d.B * d.S, d.B, kl_weight, terms, dmu, dlogvar,
                      gscale);
