@@ -22,8 +22,11 @@
 #include "dec_math.h"
 #include "kernels.h"
 
+int g_stage_variant = 0;
+
 namespace {
 
+enum { V_NOX = 1, V_NOW = 2, V_NOEPI = 4, V_NOMFMA = 8, V_ROT = 16 };
 constexpr int WAVES = 16;
 constexpr int NTHR = WAVES * 64;
 enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX };
@@ -49,6 +52,7 @@ struct StageArgs {
   const float *cpose, *crpos, *crrot;      // backward: forward results
   const float *dpose, *drpos, *drrot;      // backward: loss gradients
   float* carry;                            // [B,8] root-state gradient carry
+  int variant;                             // ablation switches (tools/stage_bench.py); 0 in production
 };
 
 // column permutation of the dX stage: tile 0 holds root_vel/vrt (0..5) AND the gaze columns (PO..PO+2)
@@ -65,28 +69,40 @@ __device__ __forceinline__ long xf_index(int b, int k, int NB) {
 
 template <int NB>
 __device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* __restrict__ xp, int lo, int hi,
-                                           f4 (&acc)[NB]) {
-  // register double buffering: the loads of group g+1 are in flight while group g feeds the matrix cores
+                                           f4 (&acc)[NB], int variant, int rot) {
+  // register double buffering: the loads of group g+1 are in flight while group g feeds the matrix cores.
+  // The block sequence of a wave is rotated by a tile-dependent offset so that the workgroups, which all
+  // read the SAME activation fragments, do not hit the same L2 lines at the same moment.
   constexpr int U = 2;
+  const int n = hi - lo;
+  const int r0 = (variant & V_ROT) ? rot % n : 0;
   f4 w0[U], x0[U][NB], w1[U], x1[U][NB];
-#define ZLOAD(W, X, KB0)                                                            \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) if ((KB0) + u < hi) {                \
-    W[u] = wp[(long)((KB0) + u) * 64];                                              \
-    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) X[u][nb] = xp[((long)((KB0) + u) * NB + nb) * 64]; \
+  const f4 one = f4{1.f, 1.f, 1.f, 1.f};
+#define ZIDX(I) (lo + (((I) + r0) >= n ? (I) + r0 - n : (I) + r0))
+#define ZLOAD(W, X, I0)                                                             \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) if ((I0) + u < n) {                  \
+    const long kb_ = ZIDX((I0) + u);                                                \
+    W[u] = (variant & V_NOW) ? one : wp[kb_ * 64];                                   \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) X[u][nb] = (variant & V_NOX) ? one : xp[(kb_ * NB + nb) * 64]; \
   }
-#define ZCOMP(W, X, KB0)                                                            \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) if ((KB0) + u < hi) {                \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                   \
-      _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                             \
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u][c], X[u][nb][c], acc[nb], 0, 0, 0); \
+#define ZCOMP(W, X, I0)                                                             \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) if ((I0) + u < n) {                  \
+    if (variant & V_NOMFMA) {                                                       \
+      _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[nb] += W[u] + X[u][nb];  \
+    } else {                                                                        \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c)                                 \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                           \
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u][c], X[u][nb][c], acc[nb], 0, 0, 0); \
+    }                                                                               \
   }
-  ZLOAD(w0, x0, lo)
-  for (int kb = lo; kb < hi; kb += 2 * U) {
-    ZLOAD(w1, x1, kb + U)
-    ZCOMP(w0, x0, kb)
-    ZLOAD(w0, x0, kb + 2 * U)
-    ZCOMP(w1, x1, kb + U)
+  ZLOAD(w0, x0, 0)
+  for (int i = 0; i < n; i += 2 * U) {
+    ZLOAD(w1, x1, i + U)
+    ZCOMP(w0, x0, i)
+    ZLOAD(w0, x0, i + 2 * U)
+    ZCOMP(w1, x1, i + U)
   }
+#undef ZIDX
 #undef ZLOAD
 #undef ZCOMP
 }
@@ -158,8 +174,8 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
     if (lo < hi) {
       const f4* wp = (const f4*)G.seg[s].w + ((long)tile * kbs) * 64 + lane;
       const f4* xp = (const f4*)G.seg[s].x + lane;
-      if (G.seg[s].acc == 0) run_blocks<NB>(wp, xp, lo, hi, acc[0]);
-      else run_blocks<NB>(wp, xp, lo, hi, acc[1]);
+      if (G.seg[s].acc == 0) run_blocks<NB>(wp, xp, lo, hi, acc[0], a.variant, tile * 5 + wave);
+      else run_blocks<NB>(wp, xp, lo, hi, acc[1], a.variant, tile * 5 + wave);
     }
     base += kbs;
   }
@@ -183,6 +199,10 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
   const ZeggsDecDims& d = a.d;
   const int B = d.B, H = d.H, BP = 16 * NB, t = a.t;
 
+  if (a.variant & V_NOEPI) {
+    if (tid == 0 && finf[0] == 123.456f) a.carry[0] = 1.f;
+    return;
+  }
   switch (G.epi) {
     case EPI_ELU_HID: {   // hid = ELU(W0 x + b0) -> Gin[t][:, 0:H] and its fragment copy
       for (int id = tid; id < 16 * BP; id += NTHR) {
@@ -442,7 +462,7 @@ inline Seg seg(const float* w, const float* x, int kb, int acc) { return Seg{w, 
 StageArgs base_args(const ZeggsDecDims& d, const ZeggsDecStats* st, const DecWs& w) {
   StageArgs a;
   memset(&a, 0, sizeof(a));
-  a.d = d; a.st = *st; a.NB = w.NB; a.GL = w.GL; a.XD = w.XD; a.POL = w.POL;
+  a.d = d; a.st = *st; a.NB = w.NB; a.GL = w.GL; a.XD = w.XD; a.POL = w.POL; a.variant = g_stage_variant;
   return a;
 }
 
