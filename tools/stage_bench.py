@@ -34,8 +34,7 @@ def run(train):
             ops.decoder_core(*args)
 
 
-NAMES = {0: "baseline", 16: "rotate", 1: "no-x-loads", 2: "no-w-loads", 3: "no-loads", 4: "no-epilogue", 8: "no-mfma",
-         5: "no-x,no-epi", 12: "no-mfma,no-epi", 15: "nothing", 17: "rot+nox", 20: "rot+noepi"}
+NAMES = {0: "baseline", 4: "no-epilogue"}
 for v, name in NAMES.items():
     ops.set_option("stage_variant", v)
     for train in (False, True):

@@ -69,40 +69,45 @@ __device__ __forceinline__ long xf_index(int b, int k, int NB) {
 
 template <int NB>
 __device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* __restrict__ xp, int lo, int hi,
-                                           f4 (&acc)[NB], int variant, int rot) {
-  // register double buffering: the loads of group g+1 are in flight while group g feeds the matrix cores.
-  // The block sequence of a wave is rotated by a tile-dependent offset so that the workgroups, which all
-  // read the SAME activation fragments, do not hit the same L2 lines at the same moment.
+                                           f4 (&acc)[NB]) {
+  // Software pipeline with two register buffers: the loads of group g+1 are in flight while group g feeds the
+  // matrix cores.  The steady-state loop is branch-free (the look-ahead index is clamped, a redundant reload of
+  // the last group is cheaper than a branch that would force s_waitcnt vmcnt(0)).
   constexpr int U = 2;
-  const int n = hi - lo;
-  const int r0 = (variant & V_ROT) ? rot % n : 0;
+  const int n = hi - lo, ng = n / U;
   f4 w0[U], x0[U][NB], w1[U], x1[U][NB];
-  const f4 one = f4{1.f, 1.f, 1.f, 1.f};
-#define ZIDX(I) (lo + (((I) + r0) >= n ? (I) + r0 - n : (I) + r0))
-#define ZLOAD(W, X, I0)                                                             \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) if ((I0) + u < n) {                  \
-    const long kb_ = ZIDX((I0) + u);                                                \
-    W[u] = (variant & V_NOW) ? one : wp[kb_ * 64];                                   \
-    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) X[u][nb] = (variant & V_NOX) ? one : xp[(kb_ * NB + nb) * 64]; \
+#define ZLOAD(W, X, G)                                                                         \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
+    const long kb_ = lo + (long)(G) * U + u;                                                   \
+    W[u] = wp[kb_ * 64];                                                                       \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) X[u][nb] = xp[(kb_ * NB + nb) * 64];      \
   }
-#define ZCOMP(W, X, I0)                                                             \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) if ((I0) + u < n) {                  \
-    if (variant & V_NOMFMA) {                                                       \
-      _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[nb] += W[u] + X[u][nb];  \
-    } else {                                                                        \
-      _Pragma("unroll") for (int c = 0; c < 4; ++c)                                 \
-        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                           \
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u][c], X[u][nb][c], acc[nb], 0, 0, 0); \
-    }                                                                               \
+#define ZCOMP(W, X)                                                                            \
+  _Pragma("unroll") for (int u = 0; u < U; ++u)                                                \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                              \
+      _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                        \
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u][c], X[u][nb][c], acc[nb], 0, 0, 0);
+  if (ng > 0) {
+    ZLOAD(w0, x0, 0)
+    int g = 0;
+    for (; g + 1 < ng; g += 2) {
+      ZLOAD(w1, x1, g + 1)
+      ZCOMP(w0, x0)
+      const int gn = (g + 2 < ng) ? g + 2 : ng - 1;
+      ZLOAD(w0, x0, gn)
+      ZCOMP(w1, x1)
+    }
+    if (ng & 1) { ZCOMP(w0, x0) }
   }
-  ZLOAD(w0, x0, 0)
-  for (int i = 0; i < n; i += 2 * U) {
-    ZLOAD(w1, x1, i + U)
-    ZCOMP(w0, x0, i)
-    ZLOAD(w0, x0, i + 2 * U)
-    ZCOMP(w1, x1, i + U)
+  for (int kb = lo + ng * U; kb < hi; ++kb) {
+    f4 wv = wp[(long)kb * 64], xv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) xv[nb] = xp[((long)kb * NB + nb) * 64];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], xv[nb][c], acc[nb], 0, 0, 0);
   }
-#undef ZIDX
 #undef ZLOAD
 #undef ZCOMP
 }
@@ -149,15 +154,87 @@ __device__ void root_bwd(const ZeggsDecDims& d, const ZeggsDecStats& st, int b, 
   cr[5] = dq1.y + dqy.y + dq2.y; cr[6] = dq1.z + dqy.z + dq2.z;
 }
 
-template <int NB>
+template <int NB, int FAM>   // FAM 0: forward epilogues, 1: backward epilogues (keeps register pressure apart)
 __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
   __shared__ f4 red[WAVES][2][NB][64];
   __shared__ f4 fin[2][NB][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int gi = 0, tile = blockIdx.x;
   if (tile >= a.g[0].tiles) { gi = 1; tile -= a.g[0].tiles; }
   const Grp& G = a.g[gi];
+  const ZeggsDecDims& d = a.d;
+  const int B = d.B, H = d.H, BP = 16 * NB, t = a.t, PO = d.PO;
 
+  // ---- epilogue operands are fetched FIRST so that their latency hides under the weight stream.
+  // Every epilogue item (virtual column ev, batch row eb) belongs to exactly one thread (16*BP <= NTHR).
+  const int ev = tid / BP, eb = tid % BP;
+  bool eact = false;
+  float pre[7];
+  float rt[10];
+  const bool root = (tile == 0 && gi == 0 && tid < B);
+  switch (G.epi) {
+    case EPI_ELU_HID: if constexpr (FAM == 0) {
+      const int col = tile * 16 + ev;
+      eact = tid < 16 * BP && eb < B && col < H;
+      if (eact) pre[0] = G.p0[col];
+    } break;
+    case EPI_GRU_FWD: if constexpr (FAM == 0) {
+      const int U = tile * 5 + ev;
+      eact = tid < 5 * BP && eb < B && U < H;
+      if (eact) {
+        pre[0] = G.p0[U]; pre[1] = G.p1[U]; pre[2] = G.p0[H + U]; pre[3] = G.p1[H + U];
+        pre[4] = G.p0[2 * H + U]; pre[5] = G.p1[2 * H + U]; pre[6] = G.p2[(long)eb * H + U];
+      }
+    } break;
+    case EPI_OUT_FWD: if constexpr (FAM == 0) {
+      const int col = tile * 16 + ev;
+      eact = tid < 16 * BP && eb < B && col < PO;
+      if (eact) {
+        pre[0] = G.p0[col]; pre[1] = a.st.out_std[col]; pre[2] = a.st.out_mean[col];
+        pre[3] = a.st.in_mean[col]; pre[4] = a.st.in_std[col];
+      }
+      if (root) {
+        const float* rq = a.rrot + ((long)tid * d.T + t - 1) * 4;
+        const float* rp = a.rpos + ((long)tid * d.T + t - 1) * 3;
+        rt[0] = rq[0]; rt[1] = rq[1]; rt[2] = rq[2]; rt[3] = rq[3]; rt[4] = rp[0]; rt[5] = rp[1]; rt[6] = rp[2];
+        if (t + 1 < d.T) {
+          const float* gz = a.gaze + ((long)tid * d.T + t + 1) * 3;
+          rt[7] = gz[0]; rt[8] = gz[1]; rt[9] = gz[2];
+        }
+      }
+    } break;
+    case EPI_GRU_BWD: if constexpr (FAM == 1) {
+      const int U = tile * 16 + ev;
+      eact = tid < 16 * BP && eb < B && U < H;
+      if (eact) {
+        const long i = (long)eb * H + U;
+        pre[0] = G.o0[i]; pre[1] = G.p0[i]; pre[2] = G.p1[i]; pre[3] = G.p2[i]; pre[4] = G.p3[i]; pre[5] = G.p4[i];
+      }
+    } break;
+    case EPI_ADD: if constexpr (FAM == 1) {
+      const int col = tile * 16 + ev;
+      eact = tid < 16 * BP && eb < B && col < H;
+      if (eact) pre[0] = G.o0[(long)eb * H + col];
+    } break;
+    case EPI_DGIN: if constexpr (FAM == 1) {
+      const int j = tile * 16 + ev;
+      eact = tid < 16 * BP && eb < B && j < H + a.XD;
+      if (eact && j < H) pre[0] = G.p0[(long)eb * a.GL + j];
+    } break;
+    case EPI_DX: if constexpr (FAM == 1) {
+      const int q = tile * 16 + ev;
+      eact = tid < 16 * BP && eb < B && q < a.XD;
+      if (eact) {
+        const int j = perm_dx(q, PO);
+        pre[0] = G.p0[(long)eb * a.XD + j];
+        if (G.o1 && j < PO) {
+          pre[1] = a.dpose[((long)eb * d.T + t - 1) * PO + j]; pre[2] = a.st.in_std[j]; pre[3] = a.st.out_std[j];
+        }
+      }
+    } break;
+  }
+
+  // ---- weight stream: the waves split the concatenated k-block list of the segments
   f4 acc[2][NB];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -174,8 +251,8 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
     if (lo < hi) {
       const f4* wp = (const f4*)G.seg[s].w + ((long)tile * kbs) * 64 + lane;
       const f4* xp = (const f4*)G.seg[s].x + lane;
-      if (G.seg[s].acc == 0) run_blocks<NB>(wp, xp, lo, hi, acc[0], a.variant, tile * 5 + wave);
-      else run_blocks<NB>(wp, xp, lo, hi, acc[1], a.variant, tile * 5 + wave);
+      if (G.seg[s].acc == 0) run_blocks<NB>(wp, xp, lo, hi, acc[0]);
+      else run_blocks<NB>(wp, xp, lo, hi, acc[1]);
     }
     base += kbs;
   }
@@ -196,56 +273,46 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
   auto FV = [&](int i, int vcol, int b) -> float {
     return finf[(((i * NB + (b >> 4)) * 64 + (((vcol >> 2) << 4) | (b & 15))) << 2) | (vcol & 3)];
   };
-  const ZeggsDecDims& d = a.d;
-  const int B = d.B, H = d.H, BP = 16 * NB, t = a.t;
-
   if (a.variant & V_NOEPI) {
     if (tid == 0 && finf[0] == 123.456f) a.carry[0] = 1.f;
     return;
   }
+
   switch (G.epi) {
-    case EPI_ELU_HID: {   // hid = ELU(W0 x + b0) -> Gin[t][:, 0:H] and its fragment copy
-      for (int id = tid; id < 16 * BP; id += NTHR) {
-        const int v = id / BP, b = id % BP, col = tile * 16 + v;
-        if (b < B && col < H) {
-          const float val = d_elu(FV(0, v, b) + G.p0[col]);
-          G.o0[(long)b * a.GL + col] = val;
-          G.o1[xf_index(b, col, NB)] = val;
-        }
+    case EPI_ELU_HID: if constexpr (FAM == 0) {   // hid = ELU(W0 x + b0) -> Gin[t][:, 0:H] and its fragment copy
+      if (eact) {
+        const int col = tile * 16 + ev;
+        const float val = d_elu(FV(0, ev, eb) + pre[0]);
+        G.o0[(long)eb * a.GL + col] = val;
+        G.o1[xf_index(eb, col, NB)] = val;
       }
     } break;
-    case EPI_GRU_FWD: {   // tile = 5 hidden units x (r, z, n); acc0 = input side, acc1 = hidden side
-      for (int id = tid; id < 5 * BP; id += NTHR) {
-        const int u = id / BP, b = id % BP, U = tile * 5 + u;
-        if (b < B && U < H) {
-          const float r = d_sigmoid(FV(0, u, b) + G.p0[U] + (FV(1, u, b) + G.p1[U]));
-          const float z = d_sigmoid(FV(0, 5 + u, b) + G.p0[H + U] + (FV(1, 5 + u, b) + G.p1[H + U]));
-          const float nh = FV(1, 10 + u, b) + G.p1[2 * H + U];
-          const float nn = tanhf(FV(0, 10 + u, b) + G.p0[2 * H + U] + r * nh);
-          const long i = (long)b * H + U;
-          const float hp = G.p2[i];
-          const float h = (1.f - z) * nn + z * hp;
-          G.o0[i] = h;
-          G.o1[xf_index(b, U, NB)] = h;
-          if (G.o2) { G.o2[i] = r; G.o3[i] = z; G.o4[i] = nn; G.o5[i] = nh; }
-        }
+    case EPI_GRU_FWD: if constexpr (FAM == 0) {   // tile = 5 hidden units x (r, z, n); acc0 = input side, acc1 = hidden side
+      if (eact) {
+        const int u = ev, b = eb, U = tile * 5 + u;
+        const float r = d_sigmoid(FV(0, u, b) + pre[0] + (FV(1, u, b) + pre[1]));
+        const float z = d_sigmoid(FV(0, 5 + u, b) + pre[2] + (FV(1, 5 + u, b) + pre[3]));
+        const float nh = FV(1, 10 + u, b) + pre[5];
+        const float nn = tanhf(FV(0, 10 + u, b) + pre[4] + r * nh);
+        const long i = (long)b * H + U;
+        const float h = (1.f - z) * nn + z * pre[6];
+        G.o0[i] = h;
+        G.o1[xf_index(b, U, NB)] = h;
+        if (G.o2) { G.o2[i] = r; G.o3[i] = z; G.o4[i] = nn; G.o5[i] = nh; }
       }
     } break;
-    case EPI_OUT_FWD: {   // y = W2 h1 + b2 -> pose[t], root integration, x_{t+1}
-      const int PO = d.PO;
+    case EPI_OUT_FWD: if constexpr (FAM == 0) {   // y = W2 h1 + b2 -> pose[t], root integration, x_{t+1}
       float* gnext = G.o0;
       float* xnext = G.o1;
       const bool next = (t + 1 < d.T);
-      for (int id = tid; id < 16 * BP; id += NTHR) {
-        const int v = id / BP, b = id % BP, col = tile * 16 + v;
-        if (b < B && col < PO) {
-          const float p = (FV(0, v, b) + G.p0[col]) * a.st.out_std[col] + a.st.out_mean[col];
-          a.pose[((long)b * d.T + t) * PO + col] = p;
-          if (next) {
-            const float e = (p - a.st.in_mean[col]) / a.st.in_std[col];
-            if (gnext) gnext[(long)b * a.GL + H + col] = e;
-            xnext[xf_index(b, col, NB)] = e;
-          }
+      if (eact) {
+        const int col = tile * 16 + ev, b = eb;
+        const float p = (FV(0, ev, b) + pre[0]) * pre[1] + pre[2];
+        a.pose[((long)b * d.T + t) * PO + col] = p;
+        if (next) {
+          const float e = (p - pre[3]) / pre[4];
+          if (gnext) gnext[(long)b * a.GL + H + col] = e;
+          xnext[xf_index(b, col, NB)] = e;
         }
       }
       if (next) {   // speech / style columns of x_{t+1}
@@ -258,22 +325,19 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
           xnext[xf_index(b, d.PI + c, NB)] = val;
         }
       }
-      if (tile == 0 && tid < B) {
+      if (root) {
         const int b = tid;
         float p[6];
         for (int c = 0; c < 6; ++c) p[c] = (FV(0, c, b) + G.p0[c]) * a.st.out_std[c] + a.st.out_mean[c];
-        const float* rq = a.rrot + ((long)b * d.T + t - 1) * 4;
-        const float* rp = a.rpos + ((long)b * d.T + t - 1) * 3;
-        Q4 q = Q4{rq[0], rq[1], rq[2], rq[3]};
-        V3 pos = v3(rp[0], rp[1], rp[2]);
+        Q4 q = Q4{rt[0], rt[1], rt[2], rt[3]};
+        V3 pos = v3(rt[4], rt[5], rt[6]);
         V3 npos = quat_mul_vec(q, d.dt * v3(p[0], p[1], p[2])) + pos;
         V3 uu = quat_mul_vec(q, d.dt * v3(p[3], p[4], p[5]));
         Q4 nq = quat_mul(quat_exp(0.5f * uu), q);
         float* op = a.rpos + ((long)b * d.T + t) * 3; op[0] = npos.x; op[1] = npos.y; op[2] = npos.z;
         float* oq = a.rrot + ((long)b * d.T + t) * 4; oq[0] = nq.w; oq[1] = nq.x; oq[2] = nq.y; oq[3] = nq.z;
         if (next) {
-          const float* gz = a.gaze + ((long)b * d.T + t + 1) * 3;
-          V3 gd = quat_mul_vec(quat_inv(nq), v3(gz[0], gz[1], gz[2]) - npos);
+          V3 gd = quat_mul_vec(quat_inv(nq), v3(rt[7], rt[8], rt[9]) - npos);
           const float gv[3] = {gd.x, gd.y, gd.z};
           for (int k = 0; k < 3; ++k) {
             const float e = (gv[k] - a.st.in_mean[PO + k]) / a.st.in_std[PO + k];
@@ -283,67 +347,56 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
         }
       }
     } break;
-    case EPI_GRU_BWD: {   // dh = W^T delta + carry -> gate gradients of this layer
-      for (int id = tid; id < 16 * BP; id += NTHR) {
-        const int v = id / BP, b = id % BP, U = tile * 16 + v;
-        if (b < B && U < H) {
-          const long i = (long)b * H + U;
-          const float g = FV(0, v, b) + G.o0[i];
-          const float r = G.p0[i], z = G.p1[i], nn = G.p2[i], nh = G.p3[i], hp = G.p4[i];
-          const float dn = g * (1.f - z);
-          const float dz = g * (hp - nn);
-          const float dan = dn * (1.f - nn * nn);
-          const float dar = dan * nh * r * (1.f - r);
-          const float daz = dz * z * (1.f - z);
-          float* di = G.o1 + (long)b * 3 * H;
-          float* dh = G.o2 + (long)b * 3 * H;
-          di[U] = dar; di[H + U] = daz; di[2 * H + U] = dan;
-          dh[U] = dar; dh[H + U] = daz; dh[2 * H + U] = dan * r;
-          G.o3[xf_index(b, U, NB)] = dar; G.o3[xf_index(b, H + U, NB)] = daz; G.o3[xf_index(b, 2 * H + U, NB)] = dan;
-          G.o4[xf_index(b, U, NB)] = dar; G.o4[xf_index(b, H + U, NB)] = daz;
-          G.o4[xf_index(b, 2 * H + U, NB)] = dan * r;
-          G.o0[i] = g * z;
+    case EPI_GRU_BWD: if constexpr (FAM == 1) {   // dh = W^T delta + carry -> gate gradients of this layer
+      if (eact) {
+        const int b = eb, U = tile * 16 + ev;
+        const long i = (long)b * H + U;
+        const float g = FV(0, ev, b) + pre[0];
+        const float r = pre[1], z = pre[2], nn = pre[3], nh = pre[4], hp = pre[5];
+        const float dn = g * (1.f - z);
+        const float dz = g * (hp - nn);
+        const float dan = dn * (1.f - nn * nn);
+        const float dar = dan * nh * r * (1.f - r);
+        const float daz = dz * z * (1.f - z);
+        float* di = G.o1 + (long)b * 3 * H;
+        float* dh = G.o2 + (long)b * 3 * H;
+        di[U] = dar; di[H + U] = daz; di[2 * H + U] = dan;
+        dh[U] = dar; dh[H + U] = daz; dh[2 * H + U] = dan * r;
+        G.o3[xf_index(b, U, NB)] = dar; G.o3[xf_index(b, H + U, NB)] = daz; G.o3[xf_index(b, 2 * H + U, NB)] = dan;
+        G.o4[xf_index(b, U, NB)] = dar; G.o4[xf_index(b, H + U, NB)] = daz;
+        G.o4[xf_index(b, 2 * H + U, NB)] = dan * r;
+        G.o0[i] = g * z;
+      }
+    } break;
+    case EPI_ADD: if constexpr (FAM == 1) {
+      if (eact) G.o0[(long)eb * H + tile * 16 + ev] = pre[0] + FV(0, ev, eb);
+    } break;
+    case EPI_DGIN: if constexpr (FAM == 1) {      // dGin = W_ih0^T delta_i0 : [dhid -> ELU' -> D0 | dx part]
+      if (eact) {
+        const int b = eb, j = tile * 16 + ev;
+        const float g = FV(0, ev, b);
+        if (j < H) {
+          const float d0 = g * d_elu_grad_from_out(pre[0]);
+          G.o0[(long)b * H + j] = d0;
+          G.o1[xf_index(b, j, NB)] = d0;
+        } else {
+          G.o2[(long)b * a.XD + (j - H)] = g;
         }
       }
     } break;
-    case EPI_ADD: {
-      for (int id = tid; id < 16 * BP; id += NTHR) {
-        const int v = id / BP, b = id % BP, col = tile * 16 + v;
-        if (b < B && col < H) G.o0[(long)b * H + col] += FV(0, v, b);
-      }
-    } break;
-    case EPI_DGIN: {      // dGin = W_ih0^T delta_i0 : [dhid -> ELU' -> D0 | dx part]
-      for (int id = tid; id < 16 * BP; id += NTHR) {
-        const int v = id / BP, b = id % BP, j = tile * 16 + v;
-        if (b < B && j < H + a.XD) {
-          const float g = FV(0, v, b);
-          if (j < H) {
-            const float d0 = g * d_elu_grad_from_out(G.p0[(long)b * a.GL + j]);
-            G.o0[(long)b * H + j] = d0;
-            G.o1[xf_index(b, j, NB)] = d0;
-          } else {
-            G.o2[(long)b * a.XD + (j - H)] = g;
-          }
-        }
-      }
-    } break;
-    case EPI_DX: {        // dx_t = dXa + W0^T D0 ; pose part -> dy_{t-1} (devectorize/vectorize backward)
-      const int PO = d.PO;
+    case EPI_DX: if constexpr (FAM == 1) {        // dx_t = dXa + W0^T D0 ; pose part -> dy_{t-1} (devectorize/vectorize backward)
       float* dy = G.o1;    // DY[t-1] canonical (null when t == 1)
-      for (int id = tid; id < 16 * BP; id += NTHR) {
-        const int v = id / BP, b = id % BP, q = tile * 16 + v;
-        if (b < B && q < a.XD) {
-          const int j = perm_dx(q, PO);
-          const float dx = FV(0, v, b) + G.p0[(long)b * a.XD + j];
-          G.o0[(long)b * a.XD + j] = dx;
-          if (dy && j >= 6 && j < PO) {
-            const float gy = (a.dpose[((long)b * d.T + t - 1) * PO + j] + dx / a.st.in_std[j]) * a.st.out_std[j];
-            dy[(long)b * a.POL + j] = gy;
-            G.o2[xf_index(b, j, NB)] = gy;
-          }
+      if (eact) {
+        const int b = eb, j = perm_dx(tile * 16 + ev, PO);
+        const float dx = FV(0, ev, b) + pre[0];
+        G.o0[(long)b * a.XD + j] = dx;
+        if (dy && j >= 6 && j < PO) {
+          const float gy = (pre[1] + dx / pre[2]) * pre[3];
+          dy[(long)b * a.POL + j] = gy;
+          G.o2[xf_index(b, j, NB)] = gy;
         }
       }
-      if (tile == 0 && dy && tid < B) {
+      if (root && dy) {
         const int b = tid;
         float g6[6], dgd[3];
         for (int c = 0; c < 6; ++c)
@@ -444,17 +497,21 @@ int pack(float* dst, const float* src, int tiles, int kb, int mode, int K, int N
   return 0;
 }
 
-int launch_stage(const StageArgs& a, hipStream_t s) {
+template <int FAM>
+int launch_stage_f(const StageArgs& a, hipStream_t s) {
   const int tiles = a.g[0].tiles + a.g[1].tiles;
   switch (a.NB) {
-    case 1: hipLaunchKernelGGL(stage_k<1>, dim3(tiles), dim3(NTHR), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(stage_k<2>, dim3(tiles), dim3(NTHR), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(stage_k<3>, dim3(tiles), dim3(NTHR), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(stage_k<4>, dim3(tiles), dim3(NTHR), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((stage_k<1, FAM>), dim3(tiles), dim3(NTHR), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((stage_k<2, FAM>), dim3(tiles), dim3(NTHR), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((stage_k<3, FAM>), dim3(tiles), dim3(NTHR), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((stage_k<4, FAM>), dim3(tiles), dim3(NTHR), 0, s, a); break;
     default: zeggs_set_error("decoder fast path: batch > 64"); return -1;
   }
   ZLAUNCH_CHECK("decoder_stage");
   return 0;
+}
+int launch_stage(const StageArgs& a, hipStream_t s) {
+  return a.g[0].epi >= EPI_GRU_BWD ? launch_stage_f<1>(a, s) : launch_stage_f<0>(a, s);
 }
 
 inline Seg seg(const float* w, const float* x, int kb, int acc) { return Seg{w, x, kb, acc}; }
