@@ -67,9 +67,9 @@ __device__ __forceinline__ long xf_index(int b, int k, int NB) {
   return ((((long)(k >> 4) * NB + (b >> 4)) * 64 + ((((k >> 2) & 3) << 4) | (b & 15))) << 2) | (k & 3);
 }
 
-template <int NB>
+template <int NB>   // NB here = batch blocks handled by this workgroup; LNB = batch blocks in the fragment layout
 __device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* __restrict__ xp, int lo, int hi,
-                                           f4 (&acc)[NB]) {
+                                           f4 (&acc)[NB], int LNB) {
   // Software pipeline with two register buffers: the loads of group g+1 are in flight while group g feeds the
   // matrix cores.  The steady-state loop is branch-free (the look-ahead index is clamped, a redundant reload of
   // the last group is cheaper than a branch that would force s_waitcnt vmcnt(0)).
@@ -80,7 +80,7 @@ __device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* 
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
     const long kb_ = lo + (long)(G) * U + u;                                                   \
     W[u] = wp[kb_ * 64];                                                                       \
-    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) X[u][nb] = xp[(kb_ * NB + nb) * 64];      \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) X[u][nb] = xp[(kb_ * LNB + nb) * 64];      \
   }
 #define ZCOMP(W, X)                                                                            \
   _Pragma("unroll") for (int u = 0; u < U; ++u)                                                \
@@ -102,7 +102,7 @@ __device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* 
   for (int kb = lo + ng * U; kb < hi; ++kb) {
     f4 wv = wp[(long)kb * 64], xv[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) xv[nb] = xp[((long)kb * NB + nb) * 64];
+    for (int nb = 0; nb < NB; ++nb) xv[nb] = xp[((long)kb * LNB + nb) * 64];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -158,20 +158,31 @@ template <int NB, int FAM>   // FAM 0: forward epilogues, 1: backward epilogues 
 __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
   __shared__ f4 red[WAVES][2][NB][64];
   __shared__ f4 fin[2][NB][64];
+  // NB (template) = batch blocks of 16 rows handled by THIS workgroup; a.NB = batch blocks of the fragment layout.
+  // With nsplit = a.NB / NB > 1 a tile is shared by nsplit workgroups (one per batch part): more workgroups for
+  // the stages with few tiles; the parts of a tile are 8 ids apart so they land on the same XCD / L2.
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int gi = 0, tile = blockIdx.x;
-  if (tile >= a.g[0].tiles) { gi = 1; tile -= a.g[0].tiles; }
+  const int LNB = a.NB, nsplit = LNB / NB;
+  int gi = 0, wg = blockIdx.x;
+  if (wg >= a.g[0].tiles * nsplit) { gi = 1; wg -= a.g[0].tiles * nsplit; }
   const Grp& G = a.g[gi];
+  int tile = wg, part = 0;
+  if (nsplit == 2) {
+    const int full = (G.tiles / 8) * 16;            // ids in complete 16-blocks: [8 tiles part 0 | same 8 tiles part 1]
+    if (wg < full) { tile = (wg / 16) * 8 + (wg & 7); part = (wg >> 3) & 1; }
+    else { const int r = wg - full; tile = (G.tiles / 8) * 8 + (r >> 1); part = r & 1; }
+  }
+  const int nb0 = part * NB;
   const ZeggsDecDims& d = a.d;
   const int B = d.B, H = d.H, BP = 16 * NB, t = a.t, PO = d.PO;
 
   // ---- epilogue operands are fetched FIRST so that their latency hides under the weight stream.
   // Every epilogue item (virtual column ev, batch row eb) belongs to exactly one thread (16*BP <= NTHR).
-  const int ev = tid / BP, eb = tid % BP;
+  const int ev = tid / BP, ebl = tid % BP, eb = 16 * nb0 + ebl;   // ebl: batch row within this workgroup's part
   bool eact = false;
   float pre[7];
   float rt[10];
-  const bool root = (tile == 0 && gi == 0 && tid < B);
+  const bool root = (tile == 0 && gi == 0 && tid < BP && eb < B);   // then ev == 0 and eb is this thread's batch row
   switch (G.epi) {
     case EPI_ELU_HID: if constexpr (FAM == 0) {
       const int col = tile * 16 + ev;
@@ -194,11 +205,11 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
         pre[3] = a.st.in_mean[col]; pre[4] = a.st.in_std[col];
       }
       if (root) {
-        const float* rq = a.rrot + ((long)tid * d.T + t - 1) * 4;
-        const float* rp = a.rpos + ((long)tid * d.T + t - 1) * 3;
+        const float* rq = a.rrot + ((long)eb * d.T + t - 1) * 4;
+        const float* rp = a.rpos + ((long)eb * d.T + t - 1) * 3;
         rt[0] = rq[0]; rt[1] = rq[1]; rt[2] = rq[2]; rt[3] = rq[3]; rt[4] = rp[0]; rt[5] = rp[1]; rt[6] = rp[2];
         if (t + 1 < d.T) {
-          const float* gz = a.gaze + ((long)tid * d.T + t + 1) * 3;
+          const float* gz = a.gaze + ((long)eb * d.T + t + 1) * 3;
           rt[7] = gz[0]; rt[8] = gz[1]; rt[9] = gz[2];
         }
       }
@@ -244,15 +255,15 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
   for (int s = 0; s < G.nseg; ++s) TB += G.seg[s].kb;
   const int b0 = wave * TB / WAVES, b1 = (wave + 1) * TB / WAVES;
   int base = 0;
-  for (int s = 0; s < G.nseg; ++s) {
+  for (int s = 0; s < ((a.variant & V_NOW) ? 0 : G.nseg); ++s) {
     const int kbs = G.seg[s].kb;
     const int lo = (b0 > base ? b0 : base) - base;
     const int hi = (b1 < base + kbs ? b1 : base + kbs) - base;
     if (lo < hi) {
       const f4* wp = (const f4*)G.seg[s].w + ((long)tile * kbs) * 64 + lane;
-      const f4* xp = (const f4*)G.seg[s].x + lane;
-      if (G.seg[s].acc == 0) run_blocks<NB>(wp, xp, lo, hi, acc[0]);
-      else run_blocks<NB>(wp, xp, lo, hi, acc[1]);
+      const f4* xp = (const f4*)G.seg[s].x + nb0 * 64 + lane;
+      if (G.seg[s].acc == 0) run_blocks<NB>(wp, xp, lo, hi, acc[0], LNB);
+      else run_blocks<NB>(wp, xp, lo, hi, acc[1], LNB);
     }
     base += kbs;
   }
@@ -270,7 +281,8 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
   }
   __syncthreads();
   const float* finf = (const float*)fin;
-  auto FV = [&](int i, int vcol, int b) -> float {
+  auto FV = [&](int i, int vcol, int bg) -> float {   // bg = global batch row (must belong to this part)
+    const int b = bg - 16 * nb0;
     return finf[(((i * NB + (b >> 4)) * 64 + (((vcol >> 2) << 4) | (b & 15))) << 2) | (vcol & 3)];
   };
   if (a.variant & V_NOEPI) {
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
         const int col = tile * 16 + ev;
         const float val = d_elu(FV(0, ev, eb) + pre[0]);
         G.o0[(long)eb * a.GL + col] = val;
-        G.o1[xf_index(eb, col, NB)] = val;
+        G.o1[xf_index(eb, col, LNB)] = val;
       }
     } break;
     case EPI_GRU_FWD: if constexpr (FAM == 0) {   // tile = 5 hidden units x (r, z, n); acc0 = input side, acc1 = hidden side
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
         const long i = (long)b * H + U;
         const float h = (1.f - z) * nn + z * pre[6];
         G.o0[i] = h;
-        G.o1[xf_index(b, U, NB)] = h;
+        G.o1[xf_index(b, U, LNB)] = h;
         if (G.o2) { G.o2[i] = r; G.o3[i] = z; G.o4[i] = nn; G.o5[i] = nh; }
       }
     } break;
@@ -312,21 +324,21 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
         if (next) {
           const float e = (p - pre[3]) / pre[4];
           if (gnext) gnext[(long)b * a.GL + H + col] = e;
-          xnext[xf_index(b, col, NB)] = e;
+          xnext[xf_index(b, col, LNB)] = e;
         }
       }
       if (next) {   // speech / style columns of x_{t+1}
         const int XC = d.SP + d.ST;
-        for (int e = tile * NTHR + tid; e < B * XC; e += G.tiles * NTHR) {
+        for (int e = wg * NTHR + tid; e < B * XC; e += G.tiles * nsplit * NTHR) {
           const int b = e / XC, c = e % XC;
           const float val = c < d.SP ? a.speech[((long)b * d.T + t + 1) * d.SP + c]
                                      : a.style[((long)b * d.T + t + 1) * d.ST + (c - d.SP)];
           if (gnext) gnext[(long)b * a.GL + H + d.PI + c] = val;
-          xnext[xf_index(b, d.PI + c, NB)] = val;
+          xnext[xf_index(b, d.PI + c, LNB)] = val;
         }
       }
       if (root) {
-        const int b = tid;
+        const int b = eb;
         float p[6];
         for (int c = 0; c < 6; ++c) p[c] = (FV(0, c, b) + G.p0[c]) * a.st.out_std[c] + a.st.out_mean[c];
         Q4 q = Q4{rt[0], rt[1], rt[2], rt[3]};
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
           for (int k = 0; k < 3; ++k) {
             const float e = (gv[k] - a.st.in_mean[PO + k]) / a.st.in_std[PO + k];
             if (gnext) gnext[(long)b * a.GL + H + PO + k] = e;
-            xnext[xf_index(b, PO + k, NB)] = e;
+            xnext[xf_index(b, PO + k, LNB)] = e;
           }
         }
       }
@@ -362,9 +374,9 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
         float* dh = G.o2 + (long)b * 3 * H;
         di[U] = dar; di[H + U] = daz; di[2 * H + U] = dan;
         dh[U] = dar; dh[H + U] = daz; dh[2 * H + U] = dan * r;
-        G.o3[xf_index(b, U, NB)] = dar; G.o3[xf_index(b, H + U, NB)] = daz; G.o3[xf_index(b, 2 * H + U, NB)] = dan;
-        G.o4[xf_index(b, U, NB)] = dar; G.o4[xf_index(b, H + U, NB)] = daz;
-        G.o4[xf_index(b, 2 * H + U, NB)] = dan * r;
+        G.o3[xf_index(b, U, LNB)] = dar; G.o3[xf_index(b, H + U, LNB)] = daz; G.o3[xf_index(b, 2 * H + U, LNB)] = dan;
+        G.o4[xf_index(b, U, LNB)] = dar; G.o4[xf_index(b, H + U, LNB)] = daz;
+        G.o4[xf_index(b, 2 * H + U, LNB)] = dan * r;
         G.o0[i] = g * z;
       }
     } break;
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
         if (j < H) {
           const float d0 = g * d_elu_grad_from_out(pre[0]);
           G.o0[(long)b * H + j] = d0;
-          G.o1[xf_index(b, j, NB)] = d0;
+          G.o1[xf_index(b, j, LNB)] = d0;
         } else {
           G.o2[(long)b * a.XD + (j - H)] = g;
         }
@@ -393,11 +405,11 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
         if (dy && j >= 6 && j < PO) {
           const float gy = (pre[1] + dx / pre[2]) * pre[3];
           dy[(long)b * a.POL + j] = gy;
-          G.o2[xf_index(b, j, NB)] = gy;
+          G.o2[xf_index(b, j, LNB)] = gy;
         }
       }
       if (root && dy) {
-        const int b = tid;
+        const int b = eb;
         float g6[6], dgd[3];
         for (int c = 0; c < 6; ++c)
           g6[c] = a.dpose[((long)b * d.T + t - 1) * PO + c] +
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
         for (int c = 0; c < 6; ++c) {
           const float gy = g6[c] * a.st.out_std[c];
           dy[(long)b * a.POL + c] = gy;
-          G.o2[xf_index(b, c, NB)] = gy;
+          G.o2[xf_index(b, c, LNB)] = gy;
         }
       }
     } break;
@@ -499,12 +511,16 @@ int pack(float* dst, const float* src, int tiles, int kb, int mode, int K, int N
 
 template <int FAM>
 int launch_stage_f(const StageArgs& a, hipStream_t s) {
-  const int tiles = a.g[0].tiles + a.g[1].tiles;
-  switch (a.NB) {
-    case 1: hipLaunchKernelGGL((stage_k<1, FAM>), dim3(tiles), dim3(NTHR), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((stage_k<2, FAM>), dim3(tiles), dim3(NTHR), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((stage_k<3, FAM>), dim3(tiles), dim3(NTHR), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((stage_k<4, FAM>), dim3(tiles), dim3(NTHR), 0, s, a); break;
+  // stages with few tiles are split over the batch (two workgroups per tile) to occupy more CUs
+  const bool few = a.g[0].tiles < 160 && a.g[1].tiles < 160;
+  const int nsplit = (few && a.NB % 2 == 0 && !(g_stage_variant & 32)) ? 2 : 1;
+  const int nbw = a.NB / nsplit;
+  const int wgs = (a.g[0].tiles + a.g[1].tiles) * nsplit;
+  switch (nbw) {
+    case 1: hipLaunchKernelGGL((stage_k<1, FAM>), dim3(wgs), dim3(NTHR), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((stage_k<2, FAM>), dim3(wgs), dim3(NTHR), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((stage_k<3, FAM>), dim3(wgs), dim3(NTHR), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((stage_k<4, FAM>), dim3(wgs), dim3(NTHR), 0, s, a); break;
     default: zeggs_set_error("decoder fast path: batch > 64"); return -1;
   }
   ZLAUNCH_CHECK("decoder_stage");
