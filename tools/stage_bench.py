@@ -48,7 +48,7 @@ def timed(args, train, reps=3):
 
 
 A64, A192 = make(64), make(192)
-NAMES = {0: "baseline(split)", 32: "no-batch-split"}
+NAMES = {0: "split<160", 64: "split-always"}
 for v, name in NAMES.items():
     ops.set_option("stage_variant", v)
     for train in (False, True):

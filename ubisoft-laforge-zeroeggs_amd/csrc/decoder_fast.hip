@@ -512,7 +512,7 @@ int pack(float* dst, const float* src, int tiles, int kb, int mode, int K, int N
 template <int FAM>
 int launch_stage_f(const StageArgs& a, hipStream_t s) {
   // stages with few tiles are split over the batch (two workgroups per tile) to occupy more CUs
-  const bool few = a.g[0].tiles < 160 && a.g[1].tiles < 160;
+  const bool few = (a.g[0].tiles < 160 && a.g[1].tiles < 160) || (g_stage_variant & 64);
   const int nsplit = (few && a.NB % 2 == 0 && !(g_stage_variant & 32)) ? 2 : 1;
   const int nbw = a.NB / nsplit;
   const int wgs = (a.g[0].tiles + a.g[1].tiles) * nsplit;
