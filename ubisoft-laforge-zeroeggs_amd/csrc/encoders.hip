@@ -114,15 +114,13 @@ extern "C" int zeggs_speech_encoder_bwd(const ZeggsSpeechDims* dp, const ZeggsSp
   }
   // mask (same seed/idx as forward), then ELU' using the post-dropout saved output
   ZTRY(k_dropout_rows(dh1, (int)BT, d.O, d.O, T, (long)TPP * d.O, d.dropout_p, d.seed + 2, s));
-  for (int b = 0; b < B; ++b)
-    ZTRY(k_act_bwd(dh1 + (long)b * TPP * d.O, dh1 + (long)b * TPP * d.O, w.h1 + (long)b * T * d.O, (long)T * d.O,
-                   ACT_ELU, keep, s));
+  {
+    RowView v = rv(dh1, T, (long)TPP * d.O);
+    ZTRY(k_act_bwd_v(v, v, rv(w.h1), BT, d.O, ACT_ELU, keep, s));
+  }
   ZTRY(k_pad_edges(w.dh1pp, B, T, d.O, pad, pad, 0, s));
   // bias / weight grads of the conv
-  {
-    ZTRY(k_fill(G->b1, d.O, 0.f, s));
-    for (int b = 0; b < B; ++b) ZTRY(k_colsum(G->b1, dh1 + (long)b * TPP * d.O, T, d.O, d.O, 1.f, s));
-  }
+  ZTRY(k_colsum_v(G->b1, rv(dh1, T, (long)TPP * d.O), BT, d.O, 0.f, s));
   ZTRY(conv_dw_gemm(w.h0p, (long)TP * d.H, d.H, dh1, d.O, (long)TPP * d.O, w.dwf1, d.KW * d.H, d.O, B, T, s));
   ZTRY(k_unpack_conv_dw(G->w1, w.dwf1, d.O, d.H, d.KW, s));
   // input grad w.r.t. the padded conv input: correlation of zero-padded dh1 with flipped taps
@@ -131,9 +129,7 @@ extern "C" int zeggs_speech_encoder_bwd(const ZeggsSpeechDims* dp, const ZeggsSp
   ZTRY(k_unpad_fold(w.dh0, w.dh0p, B, T, d.H, half, half, 1, s));
   // through dropout0 and ELU0 (saved h0p interior is post-dropout)
   ZTRY(k_dropout(w.dh0, BT * d.H, d.dropout_p, d.seed + 1, s));
-  for (int b = 0; b < B; ++b)
-    ZTRY(k_act_bwd(w.dh0 + (long)b * T * d.H, w.dh0 + (long)b * T * d.H, w.h0p + ((long)b * TP + half) * d.H,
-                   (long)T * d.H, ACT_ELU, keep, s));
+  ZTRY(k_act_bwd_v(rv(w.dh0), rv(w.dh0), rv(w.h0p + (long)half * d.H, T, (long)TP * d.H), BT, d.H, ACT_ELU, keep, s));
   ZTRY(gemm_tn(w.dh0, d.H, x, d.F, G->w0, d.F, (int)BT, d.H, d.F, 0.f, s));
   ZTRY(k_colsum(G->b0, w.dh0, BT, d.H, d.H, 0.f, s));
   return 0;
@@ -207,13 +203,8 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
   ZTRY(k_pack_conv_w(w.wf0, nullptr, P->c0_w, H, C, 3, s));
   ZTRY(conv_gemm(w.xp, (long)LP * C, C, w.wf0, 3 * C, H, w.c1, H, (long)L * H, P->c0_b, B, L, ACT_RELU, s));
   // LN1 -> interior of padded a1p, dropout, zero edges
-  {
-    // layernorm writes contiguous rows; write to t0 then scatter?  Interior rows of a padded buffer are
-    // contiguous per batch, so run LN per batch directly into the interior.
-    for (int b = 0; b < B; ++b)
-      ZTRY(k_layernorm_fwd(w.a1p + ((long)b * LP + 1) * H, w.c1 + (long)b * L * H, nullptr, P->ln0_g, P->ln0_b,
-                           w.m1 + (long)b * L, w.r1 + (long)b * L, L, H, eps, s));
-  }
+  ZTRY(k_layernorm_fwd_v(rv(w.a1p + H, L, (long)LP * H), rv(w.c1), rv(nullptr), P->ln0_g, P->ln0_b, w.m1, w.r1,
+                          (int)BL, H, eps, s));
   ZTRY(k_dropout_rows(w.a1p + H, (int)BL, H, H, L, (long)LP * H, p2, d.seed + 1, s));
   ZTRY(k_pad_edges(w.a1p, B, L, H, 1, 1, 0, s));
   ZTRY(k_pack_conv_w(w.wf4, w.wb4, P->c4_w, E, H, 3, s));
@@ -242,9 +233,8 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
   ZTRY(gemm_nt(w.O, E, P->out_w, E, w.ao, E, P->out_b, (int)BL, E, E, ACT_NONE, 0.f, s));
   ZTRY(k_dropout(w.ao, BL * E, p1, d.seed + 4, s));
   // a = LN(ao + h) -> interior of padded ap
-  for (int b = 0; b < B; ++b)
-    ZTRY(k_layernorm_fwd(w.ap + ((long)b * LP + 1) * E, w.ao + (long)b * L * E, w.h + (long)b * L * E, P->lna_g,
-                         P->lna_b, w.ma + (long)b * L, w.ra + (long)b * L, L, E, eps, s));
+  ZTRY(k_layernorm_fwd_v(rv(w.ap + E, L, (long)LP * E), rv(w.ao), rv(w.h), P->lna_g, P->lna_b, w.ma, w.ra, (int)BL, E,
+                          eps, s));
   ZTRY(k_pad_edges(w.ap, B, L, E, 1, 1, 0, s));
   // position-wise conv feed-forward
   ZTRY(k_pack_conv_w(w.wff0, w.wfb0, P->ff0_w, E, E, 3, s));
@@ -253,9 +243,8 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
   ZTRY(k_pad_edges(w.f1p, B, L, E, 1, 1, 0, s));
   ZTRY(conv_gemm(w.f1p, (long)LP * E, E, w.wff2, 3 * E, E, w.f2, E, (long)L * E, P->ff2_b, B, L, ACT_NONE, s));
   ZTRY(k_dropout(w.f2, BL * E, p1, d.seed + 5, s));
-  for (int b = 0; b < B; ++b)
-    ZTRY(k_layernorm_fwd(w.f + (long)b * L * E, w.f2 + (long)b * L * E, w.ap + ((long)b * LP + 1) * E, P->lnf_g,
-                         P->lnf_b, w.mf + (long)b * L, w.rf + (long)b * L, L, E, eps, s));
+  ZTRY(k_layernorm_fwd_v(rv(w.f), rv(w.f2), rv(w.ap + E, L, (long)LP * E), P->lnf_g, P->lnf_b, w.mf, w.rf, (int)BL, E,
+                          eps, s));
   ZTRY(k_meanpool_fwd(out, w.f, B, L, E, s));
   return 0;
 }
@@ -274,10 +263,8 @@ extern "C" int zeggs_style_encoder_bwd(const ZeggsStyleDims* dp, const ZeggsStyl
   // ---- mean pool, final LN (f = LN(f2 + a))
   ZTRY(k_meanpool_bwd(t1, dout, B, L, E, s));                                   // t1 = df [BL,E]
   ZTRY(k_fill(G->lnf_g, E, 0.f, s)); ZTRY(k_fill(G->lnf_b, E, 0.f, s));
-  for (int b = 0; b < B; ++b)
-    ZTRY(k_layernorm_bwd(t2 + (long)b * L * E, t1 + (long)b * L * E, w.f2 + (long)b * L * E,
-                         w.ap + ((long)b * LP + 1) * E, P->lnf_g, w.mf + (long)b * L, w.rf + (long)b * L, G->lnf_g,
-                         G->lnf_b, L, E, s));                                    // t2 = d(f2 + a) [BL,E]
+  ZTRY(k_layernorm_bwd_v(rv(t2), rv(t1), rv(w.f2), rv(w.ap + E, L, (long)LP * E), P->lnf_g, w.mf, w.rf, G->lnf_g,
+                          G->lnf_b, (int)BL, E, s));                              // t2 = d(f2 + a) [BL,E]
   // residual branch: da_res = t2 (kept in t2); conv branch: df2 = t2 * mask
   ZTRY(k_copy(t1, t2, BL * E, s));
   ZTRY(k_dropout(t1, BL * E, p1, d.seed + 5, s));                               // t1 = df2
@@ -287,9 +274,7 @@ extern "C" int zeggs_style_encoder_bwd(const ZeggsStyleDims* dp, const ZeggsStyl
   // d f1 = conv_bwd(df2): zero-pad df2 by 1 and correlate with flipped taps
   ZTRY(k_pad_rows(t0, t1, B, L, E, 1, 1, 0, s));                                // t0 = df2 padded [B,LP,E]
   ZTRY(conv_gemm(t0, (long)LP * E, E, w.wfb2, 3 * E, E, t1, E, (long)L * E, nullptr, B, L, ACT_NONE, s));
-  for (int b = 0; b < B; ++b)                                                     // ReLU' with saved f1 (interior of f1p)
-    ZTRY(k_act_bwd(t1 + (long)b * L * E, t1 + (long)b * L * E, w.f1p + ((long)b * LP + 1) * E, (long)L * E,
-                   ACT_RELU, 1.f, s));
+  ZTRY(k_act_bwd_v(rv(t1), rv(t1), rv(w.f1p + E, L, (long)LP * E), BL, E, ACT_RELU, 1.f, s));  // ReLU' (saved f1)
   ZTRY(k_colsum(G->ff0_b, t1, BL, E, E, 0.f, s));
   ZTRY(conv_dw_gemm(w.ap, (long)LP * E, E, t1, E, (long)L * E, w.dwf, 3 * E, E, B, L, s));
   ZTRY(k_unpack_conv_dw(G->ff0_w, w.dwf, E, E, 3, s));

@@ -51,8 +51,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   constexpr int EA = BM * BK / NT, EB = BN * BK / NT;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   static_assert(EA >= 1 && EB >= 1 && (EA == 1 || EA == 2 || EA == 4 || EA == 8), "tile/threads");
-  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  __shared__ __attribute__((aligned(16))) float As2[2][BK * LDA];   // double-buffered: one barrier per k-tile
+  __shared__ __attribute__((aligned(16))) float Bs2[2][BK * LDB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -99,7 +99,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
       load_contig<EB>(rb, Bb + (long)k * g.sbk + n, nv < 0 ? 0 : nv);
     }
   };
-  auto sstore = [&]() {
+  auto sstore = [&](int buf) {
+    float* As = As2[buf];
+    float* Bs = Bs2[buf];
     if constexpr (AKC) {
 #pragma unroll
       for (int i = 0; i < EA; ++i) As[(a_c + i) * LDA + a_r] = ra[i];
@@ -127,10 +129,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   const int kh = lane >> 5, l31 = lane & 31;
   if (t_begin < ntiles) {
     gload(t_begin);
-    sstore();
+    sstore(0);
   }
   __syncthreads();
   for (int t = t_begin; t < ntiles; ++t) {
+    const int cur = (t - t_begin) & 1;
+    const float* As = As2[cur];
+    const float* Bs = Bs2[cur];
     if (t + 1 < ntiles) gload(t + 1);
 #pragma unroll
     for (int kp = 0; kp < BK / 2; ++kp) {
@@ -145,11 +150,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < NTL; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    if (t + 1 < ntiles) sstore(cur ^ 1);
     __syncthreads();
-    if (t + 1 < ntiles) {
-      sstore();
-      __syncthreads();
-    }
   }
 
   // epilogue: D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

@@ -3,6 +3,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// strided-batch view of a [R, C] row set: row r lives at p + (r / rpb) * bstride + (r % rpb) * C (rpb == 0: contiguous)
+struct RowView {
+  float* p;
+  long rpb, bstride;
+};
+inline RowView rv(const float* p) { return RowView{(float*)p, 0, 0}; }
+inline RowView rv(const float* p, long rpb, long bstride) { return RowView{(float*)p, rpb, bstride}; }
+int k_layernorm_fwd_v(RowView y, RowView x, RowView res, const float* gamma, const float* beta, float* mean,
+                      float* rstd, int R, int C, float eps, hipStream_t s);
+int k_layernorm_bwd_v(RowView dx, RowView dy, RowView x, RowView res, const float* gamma, const float* mean,
+                      const float* rstd, float* dgamma, float* dbeta, int R, int C, hipStream_t s);
+int k_act_bwd_v(RowView dx, RowView dy, RowView y, long R, int C, int act, float y_scale, hipStream_t s);
+int k_colsum_v(float* out, RowView x, long R, int C, float beta, hipStream_t s);
+
 // y = x (optional), fill
 int k_fill(float* p, long n, float v, hipStream_t s);
 int k_copy(float* dst, const float* src, long n, hipStream_t s);

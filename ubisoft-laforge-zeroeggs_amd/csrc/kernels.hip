@@ -11,6 +11,12 @@ inline int grid1d(long n, int block = 256) {
 }
 #define GS_LOOP(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
+__device__ __forceinline__ float* rv_row(const RowView& v, long r, int C) {
+  if (v.rpb == 0) return v.p + r * C;
+  const long b = r / v.rpb;
+  return v.p + b * v.bstride + (r - b * v.rpb) * C;
+}
+
 __global__ void fill_k(float* p, long n, float v) { GS_LOOP(i, n) p[i] = v; }
 __global__ void copy_k(float* d, const float* s, long n) { GS_LOOP(i, n) d[i] = s[i]; }
 __global__ void add_k(float* d, const float* s, long n) { GS_LOOP(i, n) d[i] += s[i]; }
@@ -21,6 +27,18 @@ __global__ void act_bwd_k(float* dx, const float* dy, const float* y, long n, in
     if (act == ACT_ELU) g *= d_elu_grad_from_out(yv);
     else if (act == ACT_RELU) g = yv > 0.f ? g : 0.f;
     dx[i] = g;
+  }
+}
+
+__global__ void act_bwd_v_k(RowView dx, RowView dy, RowView y, long R, int C, int act, float ys) {
+  long n = R * C;
+  GS_LOOP(i, n) {
+    long r = i / C;
+    int c = (int)(i - r * C);
+    float yv = rv_row(y, r, C)[c] * ys, g = rv_row(dy, r, C)[c];
+    if (act == ACT_ELU) g *= d_elu_grad_from_out(yv);
+    else if (act == ACT_RELU) g = yv > 0.f ? g : 0.f;
+    rv_row(dx, r, C)[c] = g;
   }
 }
 
@@ -40,13 +58,14 @@ __global__ void dropout_rows_k(float* x, int rows, int cols, long ld, long batch
 }
 
 // one wave per row
-__global__ __launch_bounds__(256) void layernorm_fwd_k(float* y, const float* x, const float* res,
-                                                        const float* gamma, const float* beta, float* mean,
-                                                        float* rstd, int R, int C, float eps) {
+__global__ __launch_bounds__(256) void layernorm_fwd_k(RowView y, RowView x, RowView res, const float* gamma,
+                                                        const float* beta, float* mean, float* rstd, int R, int C,
+                                                        float eps) {
   int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
-  const float* xr = x + (long)row * C;
-  const float* rr = res ? res + (long)row * C : nullptr;
+  const float* xr = rv_row(x, row, C);
+  const float* rr = res.p ? rv_row(res, row, C) : nullptr;
+  float* yr = rv_row(y, row, C);
   float s = 0.f;
   for (int c = lane; c < C; c += 64) s += xr[c] + (rr ? rr[c] : 0.f);
   float mu = wave_sum(s) / C;
@@ -58,16 +77,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_k(float* y, const float* x,
   float rs = 1.0f / sqrtf(wave_sum(v) / C + eps);   // biased variance, as torch
   for (int c = lane; c < C; c += 64) {
     float d = xr[c] + (rr ? rr[c] : 0.f) - mu;
-    y[(long)row * C + c] = d * rs * gamma[c] + beta[c];
+    yr[c] = d * rs * gamma[c] + beta[c];
   }
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
 template <int MAXJ>
-__global__ __launch_bounds__(256) void layernorm_bwd_k(float* dx, const float* dy, const float* x,
-                                                        const float* res, const float* gamma,
-                                                        const float* mean, const float* rstd, float* dgamma,
-                                                        float* dbeta, int R, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void layernorm_bwd_k(RowView dxv, RowView dyv, RowView xv, RowView resv,
+                                                        const float* gamma, const float* mean, const float* rstd,
+                                                        float* dgamma, float* dbeta, int R, int C,
+                                                        int rows_per_block) {
   __shared__ float sg[4][64 * MAXJ], sb[4][64 * MAXJ];
   int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float pg[MAXJ], pb[MAXJ];
@@ -76,6 +95,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(float* dx, const float* d
   int r0 = blockIdx.x * rows_per_block;
   for (int row = r0 + wave; row < r0 + rows_per_block && row < R; row += 4) {
     const float mu = mean[row], rs = rstd[row];
+    const float* x = rv_row(xv, row, C);
+    const float* res = resv.p ? rv_row(resv, row, C) : nullptr;
+    const float* dy = rv_row(dyv, row, C);
+    float* dx = rv_row(dxv, row, C);
     float xh[MAXJ], g[MAXJ];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -83,9 +106,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(float* dx, const float* d
       int c = lane + 64 * j;
       xh[j] = 0.f; g[j] = 0.f;
       if (c < C) {
-        float xv = x[(long)row * C + c] + (res ? res[(long)row * C + c] : 0.f);
-        float d = dy[(long)row * C + c];
-        xh[j] = (xv - mu) * rs;
+        float xval = x[c] + (res ? res[c] : 0.f);
+        float d = dy[c];
+        xh[j] = (xval - mu) * rs;
         g[j] = d * gamma[c];
         pg[j] += d * xh[j];
         pb[j] += d;
@@ -98,7 +121,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(float* dx, const float* d
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
       int c = lane + 64 * j;
-      if (c < C) dx[(long)row * C + c] = rs * (g[j] - s1 - xh[j] * s2);
+      if (c < C) dx[c] = rs * (g[j] - s1 - xh[j] * s2);
     }
   }
 #pragma unroll
@@ -158,6 +181,20 @@ __global__ __launch_bounds__(256) void colsum_k(float* out, const float* x, long
   float s = 0.f;
   if (c < C)
     for (long r = r0 + ph; r < r1; r += 4) s += x[r * ld + c];
+  red[ph][cl] = s;
+  __syncthreads();
+  if (ph == 0 && c < C) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+__global__ __launch_bounds__(256) void colsum_v_k(float* out, RowView x, long R, int C, long rows_per_block) {
+  __shared__ float red[4][64];
+  int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  int c = blockIdx.x * 64 + cl;
+  long r0 = (long)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block;
+  if (r1 > R) r1 = R;
+  float s = 0.f;
+  if (c < C)
+    for (long r = r0 + ph; r < r1; r += 4) s += rv_row(x, r, C)[c];
   red[ph][cl] = s;
   __syncthreads();
   if (ph == 0 && c < C) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
@@ -292,25 +329,45 @@ int k_dropout_rows(float* x, int rows, int cols, long ld, long batch_rows, long 
   L1D(dropout_rows_k, n, s, x, rows, cols, ld, batch_rows, batch_stride, p, seed);
   return 0;
 }
+int k_layernorm_fwd_v(RowView y, RowView x, RowView res, const float* gamma, const float* beta, float* mean,
+                      float* rstd, int R, int C, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(layernorm_fwd_k, dim3(cdiv(R, 4)), dim3(256), 0, s, y, x, res, gamma, beta, mean, rstd, R, C, eps);
+  ZLAUNCH_CHECK("layernorm_fwd");
+  return 0;
+}
 int k_layernorm_fwd(float* y, const float* x, const float* res, const float* gamma, const float* beta,
                     float* mean, float* rstd, int R, int C, float eps, hipStream_t s) {
-  hipLaunchKernelGGL(layernorm_fwd_k, dim3(cdiv(R, 4)), dim3(256), 0, s, y, x, res, gamma, beta, mean, rstd, R,
-                     C, eps);
-  ZLAUNCH_CHECK("layernorm_fwd");
+  return k_layernorm_fwd_v(rv(y), rv(x), rv(res), gamma, beta, mean, rstd, R, C, eps, s);
+}
+int k_layernorm_bwd_v(RowView dx, RowView dy, RowView x, RowView res, const float* gamma, const float* mean,
+                      const float* rstd, float* dgamma, float* dbeta, int R, int C, hipStream_t s) {
+  const int rpb = 64;
+  ZCHECK(C <= 512, "layernorm_bwd: C=%d > 512 unsupported", C);
+  if (C <= 128)
+    hipLaunchKernelGGL((layernorm_bwd_k<2>), dim3(cdiv(R, rpb)), dim3(256), 0, s, dx, dy, x, res, gamma, mean, rstd,
+                       dgamma, dbeta, R, C, rpb);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_k<8>), dim3(cdiv(R, rpb)), dim3(256), 0, s, dx, dy, x, res, gamma, mean, rstd,
+                       dgamma, dbeta, R, C, rpb);
+  ZLAUNCH_CHECK("layernorm_bwd");
   return 0;
 }
 int k_layernorm_bwd(float* dx, const float* dy, const float* x, const float* res, const float* gamma,
                     const float* mean, const float* rstd, float* dgamma, float* dbeta, int R, int C,
                     hipStream_t s) {
-  const int rpb = 64;
-  ZCHECK(C <= 512, "layernorm_bwd: C=%d > 512 unsupported", C);
-  if (C <= 128)
-    hipLaunchKernelGGL((layernorm_bwd_k<2>), dim3(cdiv(R, rpb)), dim3(256), 0, s, dx, dy, x, res, gamma, mean,
-                       rstd, dgamma, dbeta, R, C, rpb);
-  else
-    hipLaunchKernelGGL((layernorm_bwd_k<8>), dim3(cdiv(R, rpb)), dim3(256), 0, s, dx, dy, x, res, gamma, mean,
-                       rstd, dgamma, dbeta, R, C, rpb);
-  ZLAUNCH_CHECK("layernorm_bwd");
+  return k_layernorm_bwd_v(rv(dx), rv(dy), rv(x), rv(res), gamma, mean, rstd, dgamma, dbeta, R, C, s);
+}
+int k_act_bwd_v(RowView dx, RowView dy, RowView y, long R, int C, int act, float ys, hipStream_t s) {
+  long n = R * C;
+  L1D(act_bwd_v_k, n, s, dx, dy, y, R, C, act, ys);
+  return 0;
+}
+int k_colsum_v(float* out, RowView x, long R, int C, float beta, hipStream_t s) {
+  if (beta == 0.f) { ZTRY(k_fill(out, C, 0.f, s)); }
+  long rpb = 256;
+  dim3 grid(cdiv(C, 64), cdiv(R, rpb));
+  hipLaunchKernelGGL(colsum_v_k, grid, dim3(256), 0, s, out, x, R, C, rpb);
+  ZLAUNCH_CHECK("colsum_v");
   return 0;
 }
 int k_softmax_fwd(float* P, float* Pd, const float* S, long R, int L, float p, uint64_t seed, hipStream_t s) {
