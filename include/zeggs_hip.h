@@ -167,6 +167,21 @@ int zeggs_gather_windows(const float* frames, int width, const int64_t* starts, 
 int zeggs_gather_rows(const float* frames, int width, const int64_t* rows, long nrows, float* out, int out_ld,
                       void* stream);
 
+/* ---------------------------------------------------------------- audio front-end
+ * replaces preprocess_audio, ZEGGS/data_pipeline.py:33-84 (mel + energy at the animation rate), i.e.
+ * extract_mel_spectrogram_for_tts / extract_spectrogram / linear_to_mel / amplitude_to_db of
+ * ZEGGS/audio/spectrograms.py:8-269 in float64, for the shipped conf (centered, real amplitude, Slaney
+ * mel, range-normalised, no pre-emphasis).  Loudness normalisation (pyloudnorm) is applied by the caller.
+ * wav float32 [n] (device) -> out float32 [n_frames, n_mels+1]; filterbank float64 [n_mels, n_fft/2+1]. */
+typedef struct {
+  int n_fft, hop, n_mels, fs;
+  float fps, min_clip;
+} ZeggsMelDims;
+long zeggs_mel_stft_frames(const ZeggsMelDims*, long n_samples); /* integer rule of spectrograms.py:242-245 */
+size_t zeggs_mel_workspace_bytes(const ZeggsMelDims*, long n_samples);
+int zeggs_mel_features(const ZeggsMelDims*, const float* wav, long n_samples, const double* filterbank,
+                       int n_frames, float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* in-place feature normalisation (x - mean) / std of ZEGGS/train.py:232-234,239 ; stdv == NULL -> scalar std */
 int zeggs_normalize_rows(float* x, long rows, int width, long ld, const float* mean, const float* stdv,
                          float std_scalar, void* stream);

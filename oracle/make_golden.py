@@ -246,12 +246,54 @@ def gold_radam(ref):
     print("radam.npz")
 
 
+def gold_generate(ref):
+    """Reference generate_gesture() end to end (CPU): 2 s synthetic wav, synthetic 75-joint exemplar BVH written by
+    the reference's bvh.save, random-init nets (seed 1234) pickled as whole modules.  temperature = 1e8 makes the
+    VAE sample deterministic (z = mu + eps * 1e-8 * std).  Also pins the host plumbing (BVH parse, exemplar features)."""
+    import scipy.io.wavfile as wavfile
+    tmp = Path(tempfile.mkdtemp(prefix="zeggs_gold_gen_"))
+    net, data, res = tmp / "net", tmp / "data", tmp / "res"
+    net.mkdir(), data.mkdir()
+    se, de, st = build_ref_nets(ref)
+    torch.save(se, net / "speech_encoder.pt"), torch.save(de, net / "decoder.pt"), torch.save(st, net / "style_encoder.pt")
+    np.savez(data / "stats.npz", **synth.make_stats())
+    json.dump(synth.data_definition(), open(data / "data_definition.json", "w"))
+    conf = json.load(open("/root/reference/data/processed_v1/data_pipeline_conf.json"))
+    conf["audio_conf"]["normalize_loudness"] = False
+    json.dump(conf, open(data / "data_pipeline_conf.json", "w"))
+    wav = synth.synth_wav(32000, seed=9)
+    wavfile.write(tmp / "a.wav", 16000, wav)
+    clip = synth.make_bvh_clip(40, seed=4)
+    ref.bvh.save(str(tmp / "ex.bvh"), clip)
+    orig_load = torch.load
+    torch.load = ref.torch_load
+    try:
+        enc = ref.generate.generate_gesture(tmp / "a.wav", [(tmp / "ex.bvh", None)], net, data, res,
+                                            style_encoding_type="example", blend_type="add", blend_ratio=[1.0],
+                                            file_name="out", first_pose=tmp / "ex.bvh", temperature=1e8, seed=1234,
+                                            use_gpu=False, use_script=False)
+    finally:
+        torch.load = orig_load
+    out = ref.bvh.load(str(res / "out.bvh"))
+    loaded = ref.bvh.load(str(tmp / "ex.bvh"))
+    feats = ref.data_pipeline.preprocess_animation(ref.bvh.load(str(tmp / "ex.bvh")))
+    names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "lrot", "ltxy", "lvel", "lvrt", "cpos", "crot",
+             "ctxy", "cvel", "cvrt", "gaze_pos", "gaze_dir")
+    g = dict(wav=wav, exemplar_bvh=np.frombuffer(open(tmp / "ex.bvh", "rb").read(), dtype=np.uint8),
+             out_rotations=out["rotations"], out_positions=out["positions"], out_frametime=out["frametime"],
+             encoding=enc.numpy(), ex_rotations=loaded["rotations"], ex_positions=loaded["positions"],
+             ex_parents=loaded["parents"], ex_offsets=loaded["offsets"])
+    g.update({"feat_" + n: np.asarray(f) for n, f in zip(names, feats)})
+    np.savez_compressed(GOLD / "generate.npz", **g)
+    print("generate.npz frames", out["rotations"].shape)
+
+
 def main():
     assert ref_shims.available(), "/root/reference is required to (re)generate golden vectors"
     GOLD.mkdir(parents=True, exist_ok=True)
     ref = ref_shims.load()
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["nets", "train", "mel", "dataset", "radam"]
+    which = sys.argv[1:] or ["nets", "train", "mel", "dataset", "radam", "generate"]
     if "nets" in which:
         gold_nets(ref)
     if "mel" in which:
@@ -260,6 +302,8 @@ def main():
         gold_dataset(ref)
     if "radam" in which:
         gold_radam(ref)
+    if "generate" in which:
+        gold_generate(ref)
     if "train" in which:
         gold_train_iter(ref)
 

@@ -33,3 +33,22 @@ def test_flatten_parameters_keeps_state_dict_and_views():
     assert all(float(p.abs().sum()) == 0 for p in params)          # parameters are views of the flat buffer
     flat_g.fill_(2.0)
     assert all(float(p.grad.min()) == 2.0 for p in params)
+
+
+def test_mel_filterbank_matches_oracle():
+    from oracle import mel as omel
+    from zeggs import audio
+    np.testing.assert_allclose(audio.mel_filterbank(800, 16000, 80, 20.0, 7600.0), omel.mel_filterbank(), atol=1e-15)
+    assert (audio.mel_filterbank(800, 16000, 80, 20.0, 7600.0) > 0).sum() == 742
+    assert audio.n_anim_frames(16123) == omel.n_anim_frames(16123)
+
+
+def test_bs1770_loudness_analytic_case():
+    """BS.1770: a 997 Hz full-scale sine measures -3.01 LKFS; normalising to -20 LUFS applies the matching gain."""
+    from zeggs import audio
+    fs = 48000
+    t = np.arange(fs * 5) / fs
+    x = np.sin(2 * np.pi * 997.0 * t)
+    assert abs(audio.integrated_loudness(x, fs) - (-3.01)) < 0.05
+    y = audio.normalize_loudness(x, fs, -20.0)
+    assert abs(audio.integrated_loudness(y, fs) - (-20.0)) < 1e-6

@@ -1,0 +1,50 @@
+"""CPU tests of the host-side plumbing of generate_gesture() against fixtures recorded from the reference:
+BVH parsing of a file written by the reference's bvh.save, exemplar feature extraction, BVH writing round trip."""
+import numpy as np
+
+from zeggs import anim, generate, synth
+
+
+def _exemplar(golden_dir, tmp_path):
+    g = np.load(golden_dir / "generate.npz")
+    p = tmp_path / "ex.bvh"
+    p.write_bytes(g["exemplar_bvh"].tobytes())
+    return g, p
+
+
+def test_bvh_load_matches_reference(golden_dir, tmp_path):
+    g, p = _exemplar(golden_dir, tmp_path)
+    clip = anim.bvh_load(p)
+    np.testing.assert_array_equal(clip["parents"], g["ex_parents"])          # integer skeleton table: bit-exact
+    np.testing.assert_allclose(clip["rotations"], g["ex_rotations"], atol=0)
+    np.testing.assert_allclose(clip["positions"], g["ex_positions"], atol=0)
+    np.testing.assert_allclose(clip["offsets"], g["ex_offsets"], atol=0)
+    assert clip["order"] == "zyx" and abs(clip["frametime"] - 1 / 60) < 1e-6 and clip["names"] == synth.BONE_NAMES
+
+
+def test_preprocess_animation_matches_reference(golden_dir, tmp_path):
+    g, p = _exemplar(golden_dir, tmp_path)
+    feats = anim.preprocess_animation(anim.bvh_load(p))
+    names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "lrot", "ltxy", "lvel", "lvrt", "cpos", "crot",
+             "ctxy", "cvel", "cvrt", "gaze_pos", "gaze_dir")
+    for n, f in zip(names, feats):
+        np.testing.assert_allclose(np.asarray(f), g["feat_" + n], atol=2e-4, rtol=1e-4, err_msg=n)   # reference: float32 path
+
+
+def test_bvh_save_load_round_trip(tmp_path):
+    clip = synth.make_bvh_clip(7, seed=1)
+    anim.bvh_save(tmp_path / "a.bvh", clip)
+    back = anim.bvh_load(tmp_path / "a.bvh")
+    np.testing.assert_allclose(back["rotations"], clip["rotations"], atol=1e-5)
+    np.testing.assert_allclose(back["positions"][:, 0], clip["positions"][:, 0], atol=1e-5)
+    np.testing.assert_array_equal(back["parents"], clip["parents"])
+
+
+def test_quaternion_matrix_round_trip_and_split():
+    rng = np.random.default_rng(0)
+    q = anim.q_normalize(rng.standard_normal((50, 4)))
+    ex, ey = np.array([1.0, 0, 0]), np.array([0, 1.0, 0])
+    xy = np.stack([anim.q_mul_vec(q, ex), anim.q_mul_vec(q, ey)], axis=-2)
+    q2 = anim.q_from_xform(anim.xform_from_xy(xy))
+    assert np.abs(np.abs(np.sum(q * q2, axis=-1)) - 1.0).max() < 1e-9
+    assert generate.split_by_ratio(601, [0.3, 0.7]) == [[0, 180], [180, 601]]

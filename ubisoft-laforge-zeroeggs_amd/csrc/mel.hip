@@ -1,0 +1,151 @@
+// Audio front-end on the GPU: wav -> [n_frames, n_mels + 1] features (log-mel + energy at the animation rate).
+//
+// Reference (all float64 NumPy): ZEGGS/audio/spectrograms.py:216-269 (symmetric Hann, reflect padding,
+// per-frame rfft, |.|/n_fft), :161-183 + :386-443 (Slaney mel filterbank), :57-131 (clip, dB, map to
+// [0,1]); ZEGGS/data_pipeline.py:62-80 (10**(x/20) -> ln, linear resampling to the animation rate,
+// energy = ||exp(mel)||_2 resampled with extrapolation).
+//
+// The reference's spectrogram is float64, so this kernel computes in float64 as well (MI355X runs f64
+// FMAs at full vector rate): one workgroup per STFT frame, the windowed frame and an n_fft-entry
+// cos/sin table are staged in LDS, each thread evaluates a direct DFT for its bins (index k*n mod n_fft
+// walks the table, no trigonometry in the loop), then the 80 x 401 filterbank (742 non-zeros, given
+// as a dense matrix resident in L2) and the log/normalise chain run on the same workgroup.
+#include <math.h>
+
+#include "../../include/zeggs_hip.h"
+#include "common.h"
+
+namespace {
+
+struct MelWs {
+  double* logmel;   // [M, n_mels]
+  double* energy;   // [M]
+};
+MelWs carve_mel(const ZeggsMelDims& d, long M, Arena& a) {
+  MelWs w;
+  w.logmel = (double*)a.raw(sizeof(double) * M * d.n_mels);
+  w.energy = (double*)a.raw(sizeof(double) * M);
+  return w;
+}
+
+// spectrograms.py:233-246 (integer rule)
+inline long stft_frames(long n, int n_fft, int hop) {
+  long np = (n > n_fft ? n : n_fft) + 2 * (long)(n_fft / 2);
+  return (np % hop == 0) ? (np - n_fft) / hop : 1 + (np - n_fft) / hop;
+}
+
+__global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* wav, long n, const double* fb,
+                                                   double* logmel, double* energy, long M) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int NF = d.n_fft, NBIN = NF / 2 + 1;
+  double* xw = sm;              // [NF] windowed samples
+  double* ct = xw + NF;         // [NF] cos(2 pi j / NF)
+  double* st = ct + NF;         // [NF] sin
+  double* amp = st + NF;        // [NBIN]
+  double* melv = amp + NBIN;    // [n_mels]
+  const long fr = blockIdx.x;
+  const long neff = n > NF ? n : NF;   // zero-extended to n_fft when shorter (spectrograms.py:233-234)
+  for (int j = threadIdx.x; j < NF; j += blockDim.x) {
+    const long p = fr * d.hop + j - NF / 2;          // index into the (zero-extended) signal before reflect padding
+    long src = p < 0 ? -p : (p >= neff ? 2 * (neff - 1) - p : p);
+    const double x = (src >= 0 && src < n) ? (double)wav[src] : 0.0;
+    const double win = 0.5 - 0.5 * cos(2.0 * M_PI * (double)j / (double)(NF - 1));   // scipy hann(sym=True)
+    xw[j] = x * win;
+    const double ang = 2.0 * M_PI * (double)j / (double)NF;
+    ct[j] = cos(ang);
+    st[j] = sin(ang);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < NBIN; k += blockDim.x) {
+    double re = 0.0, im = 0.0;
+    int idx = 0;
+    for (int j = 0; j < NF; ++j) {
+      const double x = xw[j];
+      re = fma(x, ct[idx], re);
+      im = fma(-x, st[idx], im);
+      idx += k;
+      if (idx >= NF) idx -= NF;
+    }
+    amp[k] = sqrt(re * re + im * im) / (double)NF;     // real_amplitude (spectrograms.py:266-267)
+  }
+  __syncthreads();
+  const double amin = (double)d.min_clip / (double)NF;  // spectrograms.py:88-90
+  const double rng = -20.0 * log10(amin);
+  for (int m = threadIdx.x; m < d.n_mels; m += blockDim.x) {
+    const double* f = fb + (long)m * NBIN;
+    double s = 0.0;
+    for (int k = 0; k < NBIN; ++k) s = fma(f[k], amp[k], s);
+    s = fabs(s);
+    if (s < amin) s = amin;
+    const double v = (20.0 * log10(s) + rng) / rng;    // spectrograms.py:121-129
+    const double y = log(pow(10.0, v / 20.0));          // data_pipeline.py:62-63
+    melv[m] = y;
+    logmel[fr * d.n_mels + m] = y;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {                               // energy = || exp(mel) ||_2 (data_pipeline.py:28-30,75)
+    double e = 0.0;
+    for (int m = 0; m < d.n_mels; ++m) { const double z = exp(melv[m]); e += z * z; }
+    energy[fr] = sqrt(e);
+  }
+}
+
+// linear resampling at t_k = ((fs/hop)/fps) k : mel -> NaN outside the hull (griddata), energy extrapolates
+__global__ void mel_resample_k(ZeggsMelDims d, const double* logmel, const double* energy, long M, int n_frames,
+                               float* out) {
+  const int W = d.n_mels + 1;
+  const long n = (long)n_frames * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % W);
+    const long k = i / W;
+    const double t = (((double)d.fs / (double)d.hop) / (double)d.fps) * (double)k;
+    long hi = (long)ceil(t);            // searchsorted(side=left) over the integer grid
+    if (hi < 1) hi = 1;
+    if (hi > M - 1) hi = M - 1;
+    const long lo = hi - 1;
+    if (M < 2) { out[i] = nanf(""); continue; }
+    if (c < d.n_mels) {
+      if (t < 0.0 || t > (double)(M - 1)) { out[i] = nanf(""); continue; }
+      const double ylo = logmel[lo * d.n_mels + c], yhi = logmel[hi * d.n_mels + c];
+      out[i] = (float)((yhi - ylo) * (t - (double)lo) + ylo);
+    } else {
+      const double ylo = energy[lo], yhi = energy[hi];
+      out[i] = (float)((yhi - ylo) * (t - (double)lo) + ylo);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" long zeggs_mel_stft_frames(const ZeggsMelDims* d, long n_samples) {
+  return stft_frames(n_samples, d->n_fft, d->hop);
+}
+
+extern "C" size_t zeggs_mel_workspace_bytes(const ZeggsMelDims* d, long n_samples) {
+  Arena a(nullptr, 0);
+  carve_mel(*d, stft_frames(n_samples, d->n_fft, d->hop), a);
+  return a.off + 256;
+}
+
+extern "C" int zeggs_mel_features(const ZeggsMelDims* dp, const float* wav, long n_samples, const double* filterbank,
+                                  int n_frames, float* out, void* ws, size_t ws_bytes, void* stream) {
+  const ZeggsMelDims& d = *dp;
+  hipStream_t s = (hipStream_t)stream;
+  ZCHECK(d.n_fft >= 2 && d.n_fft % 2 == 0 && d.hop > 0 && d.n_mels > 0, "mel: bad dims");
+  ZCHECK(n_samples > 0 && n_frames >= 0, "mel: empty input");
+  const long M = stft_frames(n_samples, d.n_fft, d.hop);
+  Arena a(ws, ws_bytes);
+  MelWs w = carve_mel(d, M, a);
+  ZCHECK(a.ok(), "mel: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  const size_t lds = sizeof(double) * (3 * (size_t)d.n_fft + d.n_fft / 2 + 1 + d.n_mels);
+  hipLaunchKernelGGL(mel_stft_k, dim3((unsigned)M), dim3(256), lds, s, d, wav, n_samples, filterbank, w.logmel, w.energy,
+                     M);
+  ZLAUNCH_CHECK("mel_stft");
+  if (n_frames > 0) {
+    long n = (long)n_frames * (d.n_mels + 1), g = (n + 255) / 256;
+    hipLaunchKernelGGL(mel_resample_k, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, d, w.logmel, w.energy, M,
+                       n_frames, out);
+    ZLAUNCH_CHECK("mel_resample");
+  }
+  return 0;
+}

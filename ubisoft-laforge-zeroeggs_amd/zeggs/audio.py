@@ -1,0 +1,163 @@
+"""Audio front-end: wav -> [n_frames, 81] features, computed by the HIP mel kernel.
+
+Mirrors the call surface the reference uses on this path: `preprocess_audio(audio, anim_fs, anim_length,
+params, feature_type)` of ZEGGS/data_pipeline.py:33 (params = the `audio_conf` block of
+data_pipeline_conf.json) and the frame-count rules.  Host side keeps only table construction (mel
+filterbank) and the optional BS.1770 loudness gain.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class MelDims(C.Structure):
+    _fields_ = [("n_fft", C.c_int), ("hop", C.c_int), ("n_mels", C.c_int), ("fs", C.c_int), ("fps", C.c_float),
+                ("min_clip", C.c_float)]
+
+
+def n_anim_frames(n_samples, fs=16000, fps=60.0):
+    """reference generate.py:170 (banker's rounding of Python round)"""
+    return int(round(fps * (n_samples / fs)))
+
+
+def _slaney_hz_to_mel(f):
+    f = np.atleast_1d(np.asarray(f, dtype=np.float64))
+    lin = f / (200.0 / 3)
+    log_part = 15.0 + np.log(np.maximum(f, 1e-300) / 1000.0) / (np.log(6.4) / 27.0)
+    return np.where(f >= 1000.0, log_part, lin)
+
+
+def _slaney_mel_to_hz(m):
+    m = np.atleast_1d(np.asarray(m, dtype=np.float64))
+    return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), (200.0 / 3) * m)
+
+
+def mel_filterbank(n_fft, fs, n_mels, fmin, fmax, normalize=True):
+    """Triangular Slaney filterbank [n_mels, n_fft//2+1] float64 (reference spectrograms.py:386-443)."""
+    nbins = n_fft // 2 + 1
+    bin_hz = np.linspace(0.0, fs / 2.0, nbins)
+    edges = _slaney_mel_to_hz(np.linspace(_slaney_hz_to_mel(fmin)[0], _slaney_hz_to_mel(fmax)[0], n_mels + 2))
+    width = np.diff(edges)
+    dist = edges[:, None] - bin_hz[None, :]
+    rising = -dist[:-2] / width[:-1, None]
+    falling = dist[2:] / width[1:, None]
+    fb = np.clip(np.minimum(rising, falling), 0.0, None)
+    if normalize:
+        fb = fb * (2.0 / (edges[2:] - edges[:-2]))[:, None]
+    return np.ascontiguousarray(fb)
+
+
+_FB_CACHE = {}
+
+
+def mel_features(wav, n_frames, n_fft=800, hop=200, n_mels=80, fs=16000, fps=60.0, fmin=20.0, fmax=7600.0,
+                 min_clip=1e-5, normalize_mel_bins=True, device="cuda"):
+    """wav: float array/tensor [n] -> torch float32 [n_frames, n_mels + 1] on `device` (HIP kernel)."""
+    dev = torch.device(device)
+    key = (n_fft, fs, n_mels, fmin, fmax, normalize_mel_bins, str(dev))
+    if key not in _FB_CACHE:
+        _FB_CACHE[key] = torch.as_tensor(mel_filterbank(n_fft, fs, n_mels, fmin, fmax, normalize_mel_bins)).to(dev)
+    fb = _FB_CACHE[key]
+    w = torch.as_tensor(np.asarray(wav, dtype=np.float32) if not torch.is_tensor(wav) else wav,
+                        dtype=torch.float32).to(dev).contiguous()
+    d = MelDims(n_fft, hop, n_mels, fs, float(fps), float(min_clip))
+    L = ops.lib()
+    L.zeggs_mel_workspace_bytes.restype = C.c_size_t
+    ws = torch.empty(int(L.zeggs_mel_workspace_bytes(C.byref(d), C.c_long(w.numel()))), dtype=torch.uint8, device=dev)
+    out = torch.empty(n_frames, n_mels + 1, device=dev, dtype=torch.float32)
+    rc = L.zeggs_mel_features(C.byref(d), C.c_void_p(w.data_ptr()), C.c_long(w.numel()), C.c_void_p(fb.data_ptr()),
+                              int(n_frames), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                              C.c_size_t(ws.numel()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise RuntimeError("zeggs_mel_features: " + L.zeggs_last_error().decode())
+    return out
+
+
+def stft_frame_count(n_samples, n_fft=800, hop=200):
+    d = MelDims(n_fft, hop, 80, 16000, 60.0, 1e-5)
+    L = ops.lib()
+    L.zeggs_mel_stft_frames.restype = C.c_long
+    return int(L.zeggs_mel_stft_frames(C.byref(d), C.c_long(n_samples)))
+
+
+# ----------------------------------------------------------------------------- BS.1770 loudness (host, O(n))
+def integrated_loudness(x, rate):
+    """ITU-R BS.1770-4 integrated loudness (mono/multi-channel), K-weighting + 400 ms / 75 % overlap gating.
+    Written from the recommendation (the reference calls pyloudnorm==0.1.0, not installed here): parity with the
+    reference for this stage is UNPINNED -- see DESIGN.md."""
+    from scipy import signal
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x[:, None]
+
+    def biquad(kind, G, Q, fc):
+        A = 10 ** (G / 40.0)
+        w0 = 2.0 * np.pi * fc / rate
+        alpha = np.sin(w0) / (2.0 * Q)
+        if kind == "high_shelf":
+            b0 = A * ((A + 1) + (A - 1) * np.cos(w0) + 2 * np.sqrt(A) * alpha)
+            b1 = -2 * A * ((A - 1) + (A + 1) * np.cos(w0))
+            b2 = A * ((A + 1) + (A - 1) * np.cos(w0) - 2 * np.sqrt(A) * alpha)
+            a0 = (A + 1) - (A - 1) * np.cos(w0) + 2 * np.sqrt(A) * alpha
+            a1 = 2 * ((A - 1) - (A + 1) * np.cos(w0))
+            a2 = (A + 1) - (A - 1) * np.cos(w0) - 2 * np.sqrt(A) * alpha
+        else:  # high pass
+            b0, b1, b2 = (1 + np.cos(w0)) / 2, -(1 + np.cos(w0)), (1 + np.cos(w0)) / 2
+            a0, a1, a2 = 1 + alpha, -2 * np.cos(w0), 1 - alpha
+        return np.array([b0, b1, b2]) / a0, np.array([a0, a1, a2]) / a0
+
+    y = x
+    for kind, G, Q, fc in (("high_shelf", 4.0, 1 / np.sqrt(2), 1500.0), ("high_pass", 0.0, 0.5, 38.0)):
+        b, a = biquad(kind, G, Q, fc)
+        y = signal.lfilter(b, a, y, axis=0)
+    T_g, overlap = 0.4, 0.75
+    step = 1.0 - overlap
+    T = x.shape[0] / rate
+    nblocks = int(np.round((T - T_g) / (T_g * step)) + 1)
+    gains = [1.0, 1.0, 1.0, 1.41, 1.41][:x.shape[1]]
+    z = np.zeros((x.shape[1], max(nblocks, 0)))
+    for j in range(nblocks):
+        lo, hi = int(T_g * (j * step) * rate), int(T_g * (j * step + 1) * rate)
+        z[:, j] = np.sum(np.square(y[lo:hi]), axis=0) / (T_g * rate)
+    with np.errstate(divide="ignore"):
+        l_blocks = -0.691 + 10.0 * np.log10(np.sum(np.array(gains)[:, None] * z, axis=0))
+    keep = l_blocks >= -70.0
+    if not np.any(keep):
+        return -np.inf
+    z_avg = np.mean(z[:, keep], axis=1)
+    gamma_r = -0.691 + 10.0 * np.log10(np.sum(gains * z_avg)) - 10.0
+    keep = (l_blocks > gamma_r) & (l_blocks > -70.0)
+    z_avg = np.nan_to_num(np.mean(z[:, keep], axis=1)) if np.any(keep) else np.zeros(x.shape[1])
+    with np.errstate(divide="ignore"):
+        return float(-0.691 + 10.0 * np.log10(np.sum(gains * z_avg)))
+
+
+def normalize_loudness(x, rate, target=-20.0):
+    lufs = integrated_loudness(x, rate)
+    return np.asarray(x) * (10.0 ** ((target - lufs) / 20.0))
+
+
+def preprocess_audio(audio_data, anim_fs, anim_length, params, feature_type, device="cuda"):
+    """Drop-in for reference data_pipeline.preprocess_audio (same arguments, returns float32 ndarray
+    [anim_length, 81]); `params` may be a dict or an attribute-style config."""
+    g = (lambda k: params[k]) if isinstance(params, dict) else (lambda k: getattr(params, k))
+    if g("normalize_loudness"):
+        audio_data = normalize_loudness(audio_data, g("sampling_rate"), -20.0)
+    if g("pre_emphasis") or not (g("centered") and g("real_amplitude") and g("normalize_range")):
+        raise NotImplementedError("only the shipped audio_conf (centered, real_amplitude, normalize_range, "
+                                  "no pre-emphasis) has a HIP path")
+    if g("resample_method") != "linear":
+        raise NotImplementedError("resample_method must be 'linear' (the shipped conf)")
+    feat = mel_features(audio_data, anim_length, n_fft=g("filter_length"), hop=g("hop_length"),
+                        n_mels=g("n_mel_channels"), fs=g("sampling_rate"), fps=float(anim_fs), fmin=g("mel_fmin"),
+                        fmax=g("mel_fmax"), min_clip=g("min_clipping"), normalize_mel_bins=g("normalize_mel_bins"),
+                        device=device)
+    cols = []
+    if "mel_spec" in feature_type:
+        cols.append(feat[:, :-1])
+    if "energy" in feature_type:
+        cols.append(feat[:, -1:])
+    return torch.cat(cols, dim=1).cpu().numpy()

@@ -1,0 +1,156 @@
+"""generate_gesture(): the reference's inference entry point on the HIP engine.
+
+Same signature, file layout and return value as ZEGGS/generate.py:22-411.  Host side: file I/O, exemplar feature
+extraction, style blending.  Device side (HIP kernels): mel front-end, speech encoder, style encoder + VAE,
+autoregressive decoder rollout (no-grad ring-buffer path).  `use_script` is accepted and ignored (TorchScript cannot
+wrap the C-ABI calls; every shipped config sets it to false).
+"""
+import json
+import pathlib
+from pathlib import Path
+from shutil import copyfile
+
+import numpy as np
+import torch
+from scipy.io import wavfile
+
+from . import anim, audio, compat
+
+
+def split_by_ratio(length, ratio):
+    """integer frame splits of the "stitch" blend (reference helpers.py:26-37: truncation, last end = length)"""
+    assert sum(ratio) == 1.0
+    out, prev = [], 0
+    for r in ratio:
+        s, e = int(prev), int(prev + r * length)
+        out.append([s, e])
+        prev = e
+    out[-1][-1] = length
+    return out
+
+
+def read_wav_mono16k(path):
+    """16 kHz WAV -> float32 in [-1, 1) (the reference rescales int PCM the same way; other formats would need SoX)"""
+    fs, x = wavfile.read(str(path))
+    if fs != 16000:
+        raise ValueError(f"{path}: expected a 16 kHz wav (got {fs} Hz); resample offline")
+    if x.ndim > 1:
+        x = x.mean(axis=1)
+    if np.issubdtype(x.dtype, np.integer):
+        x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
+    return fs, x.astype(np.float32)
+
+
+def _example_features(p):
+    """feature rows [F, 1134] of an exemplar clip (gaze slot zero), as in generate.py:229-248"""
+    root_pos, root_rot, root_vel, root_vrt, lpos, lrot, ltxy, lvel, lvrt = p[:9]
+    n = len(root_vel)
+    return np.concatenate([root_vel.reshape(n, -1), root_vrt.reshape(n, -1), lpos.reshape(n, -1), ltxy.reshape(n, -1),
+                           lvel.reshape(n, -1), lvrt.reshape(n, -1), np.zeros((n, 3))], axis=1).astype(np.float32)
+
+
+def generate_gesture(audio_file, styles, network_path, data_path, results_path, style_encoding_type="example",
+                     blend_type="add", blend_ratio=[0.5, 0.5], file_name=None, first_pose=None, temperature=1.0,
+                     seed=1234, use_gpu=True, use_script=False):
+    network_path, data_path = Path(network_path), Path(data_path)
+    if results_path is not None:
+        results_path = Path(results_path)
+        results_path.mkdir(exist_ok=True)
+    assert (audio_file is None) == (results_path is None)
+    if not (use_gpu and torch.cuda.is_available()):
+        raise RuntimeError("the ZeroEGGS MI355X engine has no CPU path (use_gpu=False / no GPU visible)")
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    device = torch.device("cuda")
+
+    with open(data_path / "data_pipeline_conf.json") as f:
+        pipe_conf = json.load(f)
+    with open(data_path / "data_definition.json") as f:
+        details = json.load(f)
+    nlabels, label_names, bone_names = len(details["label_names"]), details["label_names"], details["bone_names"]
+    parents, dt = np.asarray(details["parents"]), details["dt"]
+    stat = np.load(data_path / "stats.npz")
+    tt = lambda k: torch.as_tensor(np.asarray(stat[k]), dtype=torch.float32, device=device)  # noqa: E731
+    audio_mean, audio_std = tt("audio_input_mean"), tt("audio_input_std")
+    in_mean, in_std, out_mean, out_std = (tt("anim_input_mean"), tt("anim_input_std"), tt("anim_output_mean"),
+                                          tt("anim_output_std"))
+    speech_net = compat.load_module(network_path / "speech_encoder.pt", device).to(device).eval()
+    decoder = compat.load_module(network_path / "decoder.pt", device).to(device).eval()
+    style_net = None
+    if style_encoding_type == "example":
+        style_net = compat.load_module(network_path / "style_encoder.pt", device).to(device).eval()
+
+    with torch.no_grad():
+        if audio_file is not None:
+            _, wav = read_wav_mono16k(audio_file)
+            n_frames = audio.n_anim_frames(len(wav))
+            feats = torch.as_tensor(audio.preprocess_audio(wav, 60, n_frames, pipe_conf["audio_conf"],
+                                                           pipe_conf["audio_feature_type"]), device=device)
+            speech = speech_net(((feats[None] - audio_mean) / audio_std).contiguous())
+
+        encodings, feat = [], None
+        anim_name = "style"
+        for style in styles:
+            if style_encoding_type == "example":
+                if isinstance(style[0], (pathlib.PurePath, str)):
+                    anim_name = Path(style[0]).stem
+                    clip = anim.bvh_load(style[0])
+                    if style[1] is not None:
+                        clip["rotations"] = clip["rotations"][style[1][0]:style[1][1]]
+                        clip["positions"] = clip["positions"][style[1][0]:style[1][1]]
+                    assert int(np.ceil(1 / clip["frametime"])) == 60
+                    feat = anim.preprocess_animation(clip)
+                    ex = (torch.as_tensor(_example_features(feat), device=device) - in_mean) / in_std
+                    z, _, _ = style_net(ex[None].contiguous(), temperature)
+                    encodings.append(z)
+                elif isinstance(style[0], np.ndarray):
+                    anim_name = style[1]
+                    encodings.append(torch.as_tensor(style[0], dtype=torch.float32, device=device)[None])
+            elif style_encoding_type == "label":
+                onehot = torch.zeros((1, nlabels), device=device)
+                onehot[0, label_names.index(style)] = 1.0
+                encodings.append(onehot)
+                anim_name = style
+                assert first_pose is not None
+            else:
+                raise ValueError("Unknown style encoding type")
+
+        if blend_type == "stitch" and len(encodings) > 1:
+            if audio_file is None:
+                final = encodings
+            else:
+                assert len(styles) == len(blend_ratio)
+                se = split_by_ratio(n_frames, blend_ratio)
+                final = torch.cat([z.unsqueeze(1).repeat(1, e - s, 1) for z, (s, e) in zip(encodings, se)], dim=1)
+        elif blend_type == "add" and len(encodings) > 1:
+            assert len(encodings) == len(blend_ratio)
+            final = torch.matmul(torch.stack(encodings, dim=1).transpose(2, 1),
+                                 torch.tensor(blend_ratio, device=device, dtype=torch.float32))
+        else:
+            final = encodings[0]
+
+        if audio_file is not None:
+            if first_pose is not None:
+                clip = anim.bvh_load(first_pose) if isinstance(first_pose, (pathlib.PurePath, str)) else dict(first_pose)
+                feat = anim.preprocess_animation(clip)
+            g = lambda a: torch.as_tensor(np.asarray(a[0:1]), dtype=torch.float32, device=device)  # noqa: E731
+            root_pos, root_rot, root_vel, root_vrt, lpos, lrot, ltxy, lvel, lvrt = feat[:9]
+            gaze_pos = feat[14]
+            if final.dim() == 2:
+                final = final.unsqueeze(1).repeat(1, speech.shape[1], 1)
+            gaze = g(gaze_pos).repeat(speech.shape[1], 1)[None]
+            out = decoder(g(root_pos), g(root_rot), g(root_vel), g(root_vrt), g(lpos), g(ltxy), g(lvel), g(lvrt),
+                          gaze.contiguous(), speech, final.contiguous(), None, in_mean, in_std, out_mean, out_std, dt)
+            V_root_pos, V_root_rot, _, _, V_lpos, V_ltxy = out[0], out[1], out[2], out[3], out[4], out[5]
+            V_lrot = anim.q_from_xform(anim.xform_from_xy(V_ltxy[0].cpu().numpy().astype(np.float64)))
+            if file_name is None:
+                file_name = f"audio_{Path(audio_file).stem}_label_{anim_name}"
+            try:
+                anim.write_bvh(str(results_path / (file_name + ".bvh")), V_root_pos[0].cpu().numpy(),
+                               V_root_rot[0].cpu().numpy(), V_lpos[0].cpu().numpy(), V_lrot, parents=parents,
+                               names=bone_names, order="zyx", dt=dt, start_position=np.array([0, 0, 0]),
+                               start_rotation=np.array([1, 0, 0, 0]))
+                copyfile(audio_file, str(results_path / (file_name + ".wav")))
+            except (PermissionError, OSError) as e:
+                print(e)
+    return final

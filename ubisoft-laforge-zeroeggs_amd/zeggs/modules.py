@@ -162,7 +162,6 @@ class Decoder(nn.Module):
             hidden_size, num_rnn_layers)
         self.cell_state_encoder = CellStateEncoder(pose_input_size + style_encoding_size,
                                                    hidden_size, num_rnn_layers)
-        self.dims = (pose_input_size, pose_output_size, speech_encoding_size, style_encoding_size, hidden_size)
 
     def forward(self, Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos, Z_ltxy, Z_lvel, Z_lvrt,
                 Z_gaze_pos, speech_encoding, style_encoding, parents, anim_input_mean, anim_input_std,
@@ -171,6 +170,30 @@ class Decoder(nn.Module):
                                    Z_lvel, Z_lvrt, Z_gaze_pos, speech_encoding, style_encoding,
                                    anim_input_mean, anim_input_std, anim_output_mean, anim_output_std,
                                    float(dt))
+
+
+# names under which the reference pickles its sub-modules (`torch.save(module)` stores the class path
+# `modules.<Class>`); zeggs.compat maps that module name here so reference checkpoints load into this engine
+RecurrentDecoderNormal = _RecurrentDecoderNormal
+FFTBlock = _FFTBlock
+MultiHeadAttention = _MultiHeadAttention
+PositionWiseConvFF = _PositionWiseConvFF
+
+
+class PositionalEncoding(nn.Module):
+    """Placeholder for un-pickling reference checkpoints (their 20000x128 table attribute is ignored: the engine
+    builds the same sinusoidal table on demand, see ops.positional_table)."""
+
+    def __init__(self, embed_dim=128, max_len=20000, timestep=10000.0):
+        super().__init__()
+        self.embed_dim = embed_dim
+
+
+class LinearNorm(nn.Module):
+    def __init__(self, in_dim, out_dim, bias=True, w_init_gain="linear"):
+        super().__init__()
+        self.linear_layer = nn.Linear(in_dim, out_dim, bias=bias)
+        nn.init.xavier_uniform_(self.linear_layer.weight, gain=nn.init.calculate_gain(w_init_gain))
 
 
 # ----------------------------------------------------------------------------

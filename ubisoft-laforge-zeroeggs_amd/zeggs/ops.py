@@ -231,7 +231,7 @@ class _StyleFn(torch.autograd.Function):
 
 
 def style_encoder_attn(x, enc, training):
-    pos = positional_table(x.shape[1], enc.embed_dim, x.device)
+    pos = positional_table(x.shape[1], enc.convs[6].normalized_shape[0], x.device)
     return _StyleFn.apply(x, pos, 1 if training else 0, next_seed() if training else 0, 4, *style_param_list(enc))
 
 
@@ -319,7 +319,7 @@ class _DecoderFn(torch.autograd.Function):
 
 def decoder_core(dec, pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt):
     """-> pose [B,T,PO] (de-normalised output vectors), rpos [B,T,3], rrot [B,T,4]"""
-    H = dec.dims[4]
+    H = dec.recurrent_decoder.layer2.in_features
     return _DecoderFn.apply(pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt, H,
                             *decoder_param_list(dec))
 

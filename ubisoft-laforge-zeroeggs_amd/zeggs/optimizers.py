@@ -44,16 +44,21 @@ class RAdam(Optimizer):
         self._flat = None      # (p, g, m, v) flat buffers when attached
         self._step = 0
 
-    def attach_flat(self, flat_p, flat_g):
-        """Run the step as ONE kernel over flat buffers (all params must be views of flat_p in order)."""
+    def attach_flat(self, flat_p, flat_g, keep_state=False):
+        """Run the step as ONE kernel over flat buffers (all params must be views of flat_p in order).
+        keep_state=True copies already-loaded per-tensor moments (resume) into the flat moment buffers."""
         self._flat = (flat_p, flat_g, torch.zeros_like(flat_p), torch.zeros_like(flat_p))
         off = 0
         for group in self.param_groups:
             for p in group["params"]:
                 st = self.state[p]
                 n = p.numel()
-                st["exp_avg"] = self._flat[2][off:off + n].view_as(p)
-                st["exp_avg_sq"] = self._flat[3][off:off + n].view_as(p)
+                m_view, v_view = self._flat[2][off:off + n].view_as(p), self._flat[3][off:off + n].view_as(p)
+                if keep_state and "exp_avg" in st:
+                    m_view.copy_(st["exp_avg"])
+                    v_view.copy_(st["exp_avg_sq"])
+                    self._step = max(self._step, int(st.get("step", 0)))
+                st["exp_avg"], st["exp_avg_sq"] = m_view, v_view
                 st.setdefault("step", 0)
                 off += n
         assert off == flat_p.numel()

@@ -162,3 +162,16 @@ def synth_wav(n_samples, seed=0, fs=16000):
     env = 0.55 + 0.45 * np.sin(2 * np.pi * 4.0 * np.arange(n_samples) / fs)
     x = x / np.max(np.abs(x)) * env * 0.6
     return (x * 32767).astype(np.int16)
+
+
+def make_bvh_clip(nframes, seed=0):
+    """A synthetic 75-joint, 60-fps BVH animation dict (zyx Euler degrees) for exemplar / first-pose inputs."""
+    rng = np.random.default_rng(seed)
+    offsets = rng.normal(0, 6.0, (NJ, 3)).astype(np.float32)
+    offsets[:, 1] = np.abs(offsets[:, 1])
+    offsets[0] = [0.0, 90.0, 0.0]
+    rot = (_smooth(rng, nframes, NJ * 3, 12.0).reshape(nframes, NJ, 3)).astype(np.float32)
+    pos = np.repeat(offsets[None], nframes, axis=0)
+    pos[:, 0] += (_smooth(rng, nframes, 3, 3.0) * np.array([1.0, 0.1, 1.0])).astype(np.float32)
+    return dict(rotations=rot, positions=pos, offsets=offsets, parents=np.asarray(PARENTS, np.int32),
+                names=list(BONE_NAMES), order="zyx", frametime=1.0 / 60.0)

@@ -1,0 +1,110 @@
+"""train(): the reference's training entry point on the HIP engine.
+
+Same signature and on-disk artefacts as ZEGGS/train.py:29-36 (options dictionaries = configs_v*.json blocks):
+reads processed_data.npz + data_definition.json, writes models_dir/{speech_encoder,decoder,style_encoder,
+checkpoints}.pt (+ models_dir/<iteration>/) every `generate_samples_step` iterations INCLUDING iteration 0, steps
+the exponential LR decay every 1000 iterations, stops after niterations*1000 iterations (checked per epoch, like the
+reference).  Differences (documented in DESIGN.md): the dataset lives in HBM and batches are gathered by a HIP
+kernel; data parallelism over torch.distributed (RCCL) when WORLD_SIZE > 1; TensorBoard / sample-BVH rendering are
+optional host extras (skipped when tensorboard is not installed).
+"""
+import datetime
+import json
+import os
+import random
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import engine, modules, ops
+
+
+def train(models_dir, logs_dir, path_processed_data, path_data_definition, train_options, network_options):
+    models_dir, logs_dir = Path(models_dir), Path(logs_dir)
+    np.random.seed(train_options["seed"])
+    torch.manual_seed(train_options["seed"])
+    ops.manual_seed(train_options["seed"])
+    if not (train_options["use_gpu"] and torch.cuda.is_available()):
+        raise RuntimeError("the ZeroEGGS MI355X engine has no CPU path (use_gpu=false / no GPU visible)")
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    window, batchsize = train_options["window"], train_options["batchsize"]
+    se_opt, st_opt, de_opt = (network_options["speech_encoder"], network_options["style_encoder"],
+                              network_options["decoder"])
+    with open(path_data_definition) as f:
+        details = json.load(f)
+    nlabels, parents, dt = len(details["label_names"]), details["parents"], details["dt"]
+    ds = engine.DeviceDataset(np.load(path_processed_data), window, device)
+    style_type = train_options["style_encoding_type"]
+    style_size = nlabels if style_type == "label" else st_opt["style_encoding_size"]
+    paths = {k: models_dir / f"{k}.pt" for k in ("speech_encoder", "decoder", "style_encoder", "checkpoints")}
+    resume = train_options["resume"] and all(paths[k].exists() for k in ("speech_encoder", "decoder", "checkpoints"))
+    from . import compat
+    if resume:
+        se = compat.load_module(paths["speech_encoder"], device).to(device)
+        de = compat.load_module(paths["decoder"], device).to(device)
+        st = compat.load_module(paths["style_encoder"], device).to(device) if style_type == "example" else None
+    else:      # construction order of the reference (train.py:118-139): same seed -> same initial weights
+        se = modules.SpeechEncoder(ds.audio.shape[1], se_opt["nhidden"], se_opt["speech_encoding_size"]).to(device)
+        de = modules.Decoder(ds.PO + 3, ds.PO, se_opt["speech_encoding_size"], style_size, de_opt["nhidden"], 2).to(device)
+        st = None
+        if style_type == "example":
+            st = modules.StyleEncoder(ds.PO + 3, st_opt["nhidden"], style_size, type=st_opt["type"],
+                                      use_vae=st_opt["use_vae"]).to(device)
+    eng = engine.TrainEngine(se, de, st, ds, parents, dt, lr=train_options["learning_rate"], eps=train_options["eps"],
+                             style_encoding_type=style_type, world_size=world, rank=rank)
+    iteration = epoch = 0
+    if resume:
+        ck = torch.load(paths["checkpoints"], map_location=device, weights_only=False)
+        iteration, epoch = ck["iteration"], ck["epoch"]
+        eng.opt.load_state_dict(ck["optimizer_state_dict"])
+        eng.opt.attach_flat(eng.flat_p, eng.flat_g, keep_state=True)
+        eng.iteration = iteration
+    (logs_dir / "samples").mkdir(parents=True, exist_ok=True)
+    example_len = st_opt["example_length"]
+    gb = batchsize * world
+    labels_onehot = None
+    if style_type == "label":
+        labels_onehot = torch.eye(nlabels, device=device)[torch.as_tensor(ds.ranges_train_labels, device=device)]
+    perm_rng = np.random.default_rng(train_options["seed"])           # identical on every rank
+    while iteration < 1000 * train_options["niterations"]:
+        start = datetime.datetime.now()
+        perm = perm_rng.permutation(len(ds))
+        nb = len(ds) // gb                                            # drop_last
+        for bi in range(nb):
+            se.train(), de.train()
+            if st is not None:
+                st.train()
+            idx = perm[bi * gb + rank * batchsize: bi * gb + (rank + 1) * batchsize]
+            lab = labels_onehot[torch.as_tensor(ds.win_sample[idx].astype(np.int64), device=device)] \
+                if labels_onehot is not None else None
+            loss = eng.step(idx, example_len, labels=lab)
+            # the example length of the NEXT iteration (train.py:228); seeded here so that all ranks agree
+            example_len = 2 * random.Random(train_options["seed"] * 1000003 + iteration).randint(
+                st_opt["example_length"] // 2, st_opt["example_length"])
+            if (iteration + 1) % 1000 == 0:
+                for g in eng.opt.param_groups:
+                    g["lr"] *= train_options["learning_rate_decay"]
+            if rank == 0 and iteration % 50 == 0:
+                sys.stdout.write(f"\r| epoch {epoch} | it {iteration} | batch {bi}/{nb} | loss {float(loss):.4f} "
+                                 f"| {datetime.datetime.now() - start} |")
+            if rank == 0 and iteration % train_options["generate_samples_step"] == 0:
+                for d in (models_dir, models_dir / str(iteration)):
+                    d.mkdir(parents=True, exist_ok=True)
+                    torch.save(se, d / "speech_encoder.pt")
+                    torch.save(de, d / "decoder.pt")
+                    if st is not None:
+                        torch.save(st, d / "style_encoder.pt")
+                    torch.save({"iteration": iteration, "epoch": epoch, "loss": loss.detach(),
+                                "optimizer_state_dict": eng.opt.state_dict()}, d / "checkpoints.pt")
+            iteration += 1
+        epoch += 1
+    if rank == 0:
+        print("\nDone!")
+    return eng
