@@ -131,8 +131,7 @@ def main():
     gb = BATCH * world
 
     def indices(it):
-        s = (it * gb) % (len(ds) - gb)
-        return perm[s + rank * BATCH: s + (rank + 1) * BATCH]
+        return engine.shard_indices(perm, it % (len(ds) // gb), BATCH, world, rank)
 
     torch.manual_seed(77 + rank)
     ev = []

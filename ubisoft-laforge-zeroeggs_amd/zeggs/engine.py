@@ -83,6 +83,24 @@ class DeviceDataset:
         return out
 
 
+def shard_indices(perm, batch_index, per_rank_batch, world_size, rank):
+    """Window indices of `rank` for global batch `batch_index`: the global batch is the next world*per_rank entries of
+    the (identical on every rank) permutation, split contiguously by rank -- drop_last semantics."""
+    gb = per_rank_batch * world_size
+    s = batch_index * gb
+    return perm[s + rank * per_rank_batch: s + (rank + 1) * per_rank_batch]
+
+
+def allreduce_mean_(flat_grad, world_size, group=None, prescaled=True):
+    """ONE collective per iteration over the flat gradient buffer (RCCL on GPUs, gloo in the CPU tests).  With
+    prescaled=True every rank already multiplied its gradients by 1/world (the loss kernel's gscale)."""
+    if world_size > 1:
+        torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=group)
+        if not prescaled:
+            flat_grad.mul_(1.0 / world_size)
+    return flat_grad
+
+
 def flatten_parameters(modules):
     """Re-home all parameters of `modules` into ONE flat fp32 buffer (+ one flat grad buffer).
     Parameter objects are kept (their .data / .grad become views), so state_dict() is unchanged."""
@@ -141,8 +159,7 @@ class TrainEngine:
         loss, terms = ops.training_loss(pose, orp, orr, b["pose"], b["rpos"], b["rrot"], b["gaze"], self.parents,
                                         self.dt, mu, logvar, kl_weight=klw, gscale=1.0 / self.world)
         loss.backward()
-        if self.world > 1:
-            torch.distributed.all_reduce(self.flat_g, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        allreduce_mean_(self.flat_g, self.world, self.pg, prescaled=True)
         self.opt.step()
         self.iteration += 1
         self.last_terms = terms

@@ -81,7 +81,7 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
             se.train(), de.train()
             if st is not None:
                 st.train()
-            idx = perm[bi * gb + rank * batchsize: bi * gb + (rank + 1) * batchsize]
+            idx = engine.shard_indices(perm, bi, batchsize, world, rank)
             lab = labels_onehot[torch.as_tensor(ds.win_sample[idx].astype(np.int64), device=device)] \
                 if labels_onehot is not None else None
             loss = eng.step(idx, example_len, labels=lab)
