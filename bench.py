@@ -134,7 +134,6 @@ def main():
         return engine.shard_indices(perm, it % (len(ds) // gb), BATCH, world, rank)
 
     torch.manual_seed(77 + rank)
-    ev = []
 
     def sync():
         if world > 1:
@@ -144,23 +143,7 @@ def main():
     for it in range(a.warmup):
         eng.step(indices(it), EXAMPLE_LEN)
     sync()
-    # decoder-step probe on the same stream with HIP events (forward rollout of the timed workload's shape)
-    probe = None
-    if rank == 0:
-        b = ds.batch(indices(0), None)
-        with torch.no_grad():
-            speech = torch.randn(BATCH, WINDOW, SP, device=dev)
-            style = torch.randn(BATCH, WINDOW, ST, device=dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            args = (de, b["pose"][:, 0].contiguous(), b["rpos"][:, 0].contiguous(), b["rrot"][:, 0].contiguous(),
-                    b["gaze"], speech, style, ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, synth.DT)
-            ops.decoder_core(*args)
-            e0.record()
-            for _ in range(3):
-                ops.decoder_core(*args)
-            e1.record()
-            torch.cuda.synchronize()
-            probe = e0.elapsed_time(e1) / 3.0 / (WINDOW - 1) * 1e-3       # seconds per decoder step
+    eng.decoder_fwd_events = []          # HIP events (torch's current stream = the stream the kernels run on)
     sync()
     t0 = time.perf_counter()
     for it in range(a.warmup, a.warmup + a.steps):
@@ -183,11 +166,19 @@ def main():
                        "global_batch": gb, "window": WINDOW, "parallelism": f"dp{world}"},
             "final_loss": round(loss, 4),
         }
+        ev = eng.decoder_fwd_events[:a.steps]
+        probe = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e-3 / (WINDOW - 1)   # s per decoder step
         ach = step_bytes(BATCH) / probe / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "decoder step (forward, all GEMV/GEMM stages of one frame)",
+        pmc_file = ROOT / "profiles" / "r01_decoder_step_pmc.json"
+        traffic = json.load(open(pmc_file))["traffic_bytes_per_step"] if pmc_file.exists() else None
+        out["roofline"] = {"bound": "hbm", "kernel": "decoder forward step = 4 launches of stage_k (layer0, GRU l0, "
+                                                     "GRU l1, layer2+pose integration), per-step figures",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                           "us_per_step": round(probe * 1e6, 2), "algorithmic_bytes_per_step": step_bytes(BATCH)}
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "us_per_step": round(probe * 1e6, 2), "algorithmic_bytes_per_step": step_bytes(BATCH),
+                           "note": "HIP events around the 255-step forward rollout inside the timed iterations; "
+                                   "traffic = FETCH_SIZE(x2)+WRITE_SIZE from profiles/r01_decoder_step_pmc.json; at "
+                                   "B=32 the step is also at the fp32 MFMA ridge (1.24 GFLOP/step)"}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(data)
         else:

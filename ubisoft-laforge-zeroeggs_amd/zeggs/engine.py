@@ -139,6 +139,7 @@ class TrainEngine:
         self.opt.attach_flat(self.flat_p, self.flat_g)
         self.iteration = 0
         self.last_terms = None
+        self.decoder_fwd_events = None      # bench.py: list of (start, end) HIP events around the forward rollout
 
     def step(self, idx, example_len, eps=None, labels=None):
         """One training iteration on window indices `idx` (this rank's slice). Returns the loss tensor (device)."""
@@ -152,9 +153,16 @@ class TrainEngine:
         else:
             z = labels
         style = z.unsqueeze(1).expand(-1, T, -1).contiguous()
+        if self.decoder_fwd_events is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         pose, orp, orr = ops.decoder_core(self.de, b["pose"][:, 0].contiguous(), b["rpos"][:, 0].contiguous(),
                                           b["rrot"][:, 0].contiguous(), b["gaze"], speech, style, ds.in_mean,
                                           ds.in_std, ds.out_mean, ds.out_std, self.dt)
+        if self.decoder_fwd_events is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.decoder_fwd_events.append((e0, e1))
         klw = kl_div_weight(self.iteration) if mu is not None else 0.0
         loss, terms = ops.training_loss(pose, orp, orr, b["pose"], b["rpos"], b["rrot"], b["gaze"], self.parents,
                                         self.dt, mu, logvar, kl_weight=klw, gscale=1.0 / self.world)
