@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Decode throughput (config 5 regime): B=1 autoregressive rollout, no_grad ring-buffer path."""
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "ubisoft-laforge-zeroeggs_amd")]
+from zeggs import modules, ops, synth  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 3001
+de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, 64, 64, 1024, 2).to(dev).eval()
+s = {k: torch.as_tensor(v, dtype=torch.float32, device=dev) for k, v in synth.make_stats().items() if k.startswith("anim")}
+args = (de, torch.randn(B, synth.POSE_OUT, device=dev), torch.zeros(B, 3, device=dev),
+        torch.tensor([[1.0, 0, 0, 0]], device=dev).repeat(B, 1), torch.randn(B, T, 3, device=dev),
+        torch.randn(B, T, 64, device=dev) * 0.3, torch.randn(B, T, 64, device=dev) * 0.3, s["anim_input_mean"],
+        s["anim_input_std"], s["anim_output_mean"], s["anim_output_std"], synth.DT)
+with torch.no_grad():
+    ops.decoder_core(*args)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ops.decoder_core(*args)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print(f"B={B} T={T}: {dt * 1e6 / (T - 1):.2f} us/step, {B * (T - 1) / dt:.0f} frames/s, "
+      f"{75698604 / (dt / (T - 1)) / 1e9:.0f} GB/s weight stream")
