@@ -27,9 +27,8 @@ int g_stage_variant = 0;
 namespace {
 
 enum { V_NOX = 1, V_NOW = 2, V_NOEPI = 4, V_NOMFMA = 8, V_ROT = 16 };
-constexpr int WAVES = 16;
-constexpr int NTHR = WAVES * 64;
-enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX };
+
+enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_STORE_ACC, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX };
 
 struct Seg {
   const float* w;   // packed weights  [tile][kb][64][4]
@@ -154,8 +153,10 @@ __device__ void root_bwd(const ZeggsDecDims& d, const ZeggsDecStats& st, int b, 
   cr[5] = dq1.y + dqy.y + dq2.y; cr[6] = dq1.z + dqy.z + dq2.z;
 }
 
-template <int NB, int FAM>   // FAM 0: forward epilogues, 1: backward epilogues (keeps register pressure apart)
-__global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
+template <int NB, int FAM, int WAVES>   // FAM 0: forward epilogues, 1: backward (keeps register pressure apart)
+__global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
+  constexpr int NTHR = WAVES * 64;
+  static_assert(16 * 16 * NB <= NTHR, "one epilogue item per thread");
   __shared__ f4 red[WAVES][2][NB][64];
   __shared__ f4 fin[2][NB][64];
   // NB (template) = batch blocks of 16 rows handled by THIS workgroup; a.NB = batch blocks of the fragment layout.
@@ -245,6 +246,13 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
     } break;
   }
 
+  // hidden-side pre-activations computed by an earlier launch (accumulator-fragment layout)
+  f4 pre4 = f4{0.f, 0.f, 0.f, 0.f};
+  if (G.epi == EPI_GRU_FWD && G.p3 && tid >= NB * 64 && tid < 2 * NB * 64) {
+    const int r = tid - NB * 64;
+    pre4 = ((const f4*)G.p3)[((long)tile * LNB + nb0 + r / 64) * 64 + (r % 64)];
+  }
+
   // ---- weight stream: the waves split the concatenated k-block list of the segments
   f4 acc[2][NB];
 #pragma unroll
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
     f4 s = red[0][i][nb][l];
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) s += red[w][i][nb][l];
-    fin[i][nb][l] = s;
+    fin[i][nb][l] = s + pre4;
   }
   __syncthreads();
   const float* finf = (const float*)fin;
@@ -357,6 +365,12 @@ __global__ __launch_bounds__(NTHR) void stage_k(StageArgs a) {
             xnext[xf_index(b, PO + k, LNB)] = e;
           }
         }
+      }
+    } break;
+    case EPI_STORE_ACC: if constexpr (FAM == 0) {   // side product W_hh h for the NEXT GRU launch: keep the raw accumulators
+      if (tid < NB * 64) {
+        const int nb = tid / 64, l = tid % 64;
+        ((f4*)G.o0)[((long)tile * LNB + nb0 + nb) * 64 + l] = fin[0][nb][l];
       }
     } break;
     case EPI_GRU_BWD: if constexpr (FAM == 1) {   // dh = W^T delta + carry -> gate gradients of this layer
@@ -516,18 +530,25 @@ int launch_stage_f(const StageArgs& a, hipStream_t s) {
   const int nsplit = (few && a.NB % 2 == 0 && !(g_stage_variant & 32)) ? 2 : 1;
   const int nbw = a.NB / nsplit;
   const int wgs = (a.g[0].tiles + a.g[1].tiles) * nsplit;
+  const bool w8 = !(g_stage_variant & 128);   // 8 waves (2 workgroups per CU) for <= 32 batch rows per workgroup
   switch (nbw) {
-    case 1: hipLaunchKernelGGL((stage_k<1, FAM>), dim3(wgs), dim3(NTHR), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((stage_k<2, FAM>), dim3(wgs), dim3(NTHR), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((stage_k<3, FAM>), dim3(wgs), dim3(NTHR), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((stage_k<4, FAM>), dim3(wgs), dim3(NTHR), 0, s, a); break;
+    case 1:
+      if (w8) hipLaunchKernelGGL((stage_k<1, FAM, 8>), dim3(wgs), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((stage_k<1, FAM, 16>), dim3(wgs), dim3(1024), 0, s, a);
+      break;
+    case 2:
+      if (w8) hipLaunchKernelGGL((stage_k<2, FAM, 8>), dim3(wgs), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((stage_k<2, FAM, 16>), dim3(wgs), dim3(1024), 0, s, a);
+      break;
+    case 3: hipLaunchKernelGGL((stage_k<3, FAM, 16>), dim3(wgs), dim3(1024), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((stage_k<4, FAM, 16>), dim3(wgs), dim3(1024), 0, s, a); break;
     default: zeggs_set_error("decoder fast path: batch > 64"); return -1;
   }
   ZLAUNCH_CHECK("decoder_stage");
   return 0;
 }
 int launch_stage(const StageArgs& a, hipStream_t s) {
-  return a.g[0].epi >= EPI_GRU_BWD ? launch_stage_f<1>(a, s) : launch_stage_f<0>(a, s);
+  return a.g[0].epi >= EPI_GRU_BWD ? launch_stage_f<1>(a, s) : launch_stage_f<0>(a, s);   // enum order: fwd < bwd
 }
 
 inline Seg seg(const float* w, const float* x, int kb, int acc) { return Seg{w, x, kb, acc}; }
@@ -587,37 +608,58 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   conv(H1xf[0], w.H1 + cs(0) * sH, H, 0, H);
   conv(Xxf[1], w.Gin + cs(1) * sG, w.GL, H, w.XD);
   ZLAUNCH_CHECK("to_xfrag");
+  const bool reb = (g_stage_variant & 256) != 0;   // hidden-side products in the S1/S4 launches (measured: no gain)
+  if (reb) {
+    StageArgs a = base_args(d, st, w);
+    a.t = 0;
+    a.g[0] = Grp{}; a.g[1] = Grp{};
+    a.g[0].seg[0] = seg(w.pw_hh0, H0xf[0], w.KBH, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_STORE_ACC;
+    a.g[0].o0 = w.GH0;
+    a.g[1].seg[0] = seg(w.pw_hh1, H1xf[0], w.KBH, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nT5; a.g[1].epi = EPI_STORE_ACC;
+    a.g[1].o0 = w.GH1;
+    ZTRY(launch_stage(a, s));
+  }
   for (int t = 1; t < T; ++t) {
     const int c = t & 1, p = (t - 1) & 1;
     const long o = (long)t * sH;
     StageArgs a = base_args(d, st, w);
     a.t = t; a.gaze = gaze; a.speech = speech; a.style = style; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
-    // S1: hid
-    a.g[0] = Grp{};
-    a.g[1] = Grp{};
+    // S1: hid = ELU(W0 x + b0)    [+ side: GH0 = W_hh0 h0[t-1] for S2 of this step, except t == 1 (done above)]
+    a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pw_l0, Xxf[c], w.KBX, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_ELU_HID;
     a.g[0].p0 = P->l0_b; a.g[0].o0 = w.Gin + cs(t) * sG; a.g[0].o1 = w.HIDxf;
+    if (reb && t > 1) {
+      a.g[1].seg[0] = seg(w.pw_hh0, H0xf[p], w.KBH, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nT5; a.g[1].epi = EPI_STORE_ACC;
+      a.g[1].o0 = w.GH0;
+    }
     ZTRY(launch_stage(a, s));
-    // S2: GRU layer 0
-    a.g[0] = Grp{};
+    // S2: GRU layer 0 (input side only; hidden side comes from GH0)
+    a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pw_ih0h, w.HIDxf, w.KBH, 0); a.g[0].seg[1] = seg(w.pw_ih0x, Xxf[c], w.KBX, 0);
-    a.g[0].seg[2] = seg(w.pw_hh0, H0xf[p], w.KBH, 1); a.g[0].nseg = 3; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
+    a.g[0].nseg = 2; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
     a.g[0].p0 = P->b_ih0; a.g[0].p1 = P->b_hh0; a.g[0].p2 = w.H0 + cs(t - 1) * sH;
+    if (reb) a.g[0].p3 = w.GH0;
+    else { a.g[0].seg[2] = seg(w.pw_hh0, H0xf[p], w.KBH, 1); a.g[0].nseg = 3; }
     a.g[0].o0 = w.H0 + cs(t) * sH; a.g[0].o1 = H0xf[c];
     if (training) { a.g[0].o2 = w.R0 + o; a.g[0].o3 = w.Z0 + o; a.g[0].o4 = w.N0 + o; a.g[0].o5 = w.NH0 + o; }
     ZTRY(launch_stage(a, s));
-    // S3: GRU layer 1
+    // S3: GRU layer 1 (hidden side from GH1)
     a.g[0] = Grp{};
-    a.g[0].seg[0] = seg(w.pw_ih1, H0xf[c], w.KBH, 0); a.g[0].seg[1] = seg(w.pw_hh1, H1xf[p], w.KBH, 1);
-    a.g[0].nseg = 2; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
+    a.g[0].seg[0] = seg(w.pw_ih1, H0xf[c], w.KBH, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
     a.g[0].p0 = P->b_ih1; a.g[0].p1 = P->b_hh1; a.g[0].p2 = w.H1 + cs(t - 1) * sH;
+    if (reb) a.g[0].p3 = w.GH1;
+    else { a.g[0].seg[1] = seg(w.pw_hh1, H1xf[p], w.KBH, 1); a.g[0].nseg = 2; }
     a.g[0].o0 = w.H1 + cs(t) * sH; a.g[0].o1 = H1xf[c];
     if (training) { a.g[0].o2 = w.R1 + o; a.g[0].o3 = w.Z1 + o; a.g[0].o4 = w.N1 + o; a.g[0].o5 = w.NH1 + o; }
     ZTRY(launch_stage(a, s));
-    // S4: output projection + pose integration + x_{t+1}
-    a.g[0] = Grp{};
+    // S4: output projection + pose integration + x_{t+1}   [+ side: GH1 = W_hh1 h1[t] for S3 of the next step]
+    a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pw_l2, H1xf[c], w.KBH, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTPO; a.g[0].epi = EPI_OUT_FWD;
     a.g[0].p0 = P->l2_b; a.g[0].o0 = (t + 1 < T) ? w.Gin + cs(t + 1) * sG : nullptr; a.g[0].o1 = Xxf[(t + 1) & 1];
+    if (reb && t + 1 < T) {
+      a.g[1].seg[0] = seg(w.pw_hh1, H1xf[c], w.KBH, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nT5; a.g[1].epi = EPI_STORE_ACC;
+      a.g[1].o0 = w.GH1;
+    }
     ZTRY(launch_stage(a, s));
   }
   return 0;
@@ -652,15 +694,22 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     a.g[1].seg[0] = seg(w.pb_hh1, w.DH1xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
     a.g[1].o0 = w.dH1c;
     ZTRY(launch_stage(a, s));
-    // B3: dGin = W_ih0^T di0 -> [D0 | dx part] ; dH0 carry += W_hh0^T dh0
+    // B3: dGin = W_ih0^T di0 -> [D0 | dx part]
     a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pb_ih0, w.DI0xf, w.KB3H, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTGI; a.g[0].epi = EPI_DGIN;
     a.g[0].p0 = w.Gin + t * sG; a.g[0].o0 = w.D0 + o; a.g[0].o1 = w.D0xf; a.g[0].o2 = w.dXa;
-    a.g[1].seg[0] = seg(w.pb_hh0, w.DH0xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
-    a.g[1].o0 = w.dH0c;
+    const bool side_in_b4 = (g_stage_variant & 512) != 0;
+    if (!side_in_b4) {
+      a.g[1].seg[0] = seg(w.pb_hh0, w.DH0xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
+      a.g[1].o0 = w.dH0c;
+    }
     ZTRY(launch_stage(a, s));
-    // B4: dx_t = dx part + W0^T D0 -> dy_{t-1}
+    // B4: dx_t = dx part + W0^T D0 -> dy_{t-1}   [+ side: dH0 carry += W_hh0^T dh0, needed by the next step's B2]
     a.g[0] = Grp{}; a.g[1] = Grp{};
+    if (side_in_b4) {
+      a.g[1].seg[0] = seg(w.pb_hh0, w.DH0xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
+      a.g[1].o0 = w.dH0c;
+    }
     a.g[0].seg[0] = seg(w.pb_l0, w.D0xf, w.KBH, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTX; a.g[0].epi = EPI_DX;
     a.g[0].p0 = w.dXa; a.g[0].o0 = w.DX + (long)t * B * w.XD;
     a.g[0].o1 = t > 1 ? w.DY + (long)(t - 1) * B * w.POL : nullptr; a.g[0].o2 = w.DYxf;

@@ -19,6 +19,7 @@ struct DecWs {
   float *pw_l0, *pw_ih0h, *pw_ih0x, *pw_hh0, *pw_ih1, *pw_hh1, *pw_l2;   // forward packs
   float *pb_l2, *pb_ih1, *pb_hh1, *pb_ih0, *pb_hh0, *pb_l0;              // backward (transposed) packs
   float *Xxf, *HIDxf, *H0xf, *H1xf;                                      // forward activation fragments (rings of 2)
+  float *GH0, *GH1;                                                      // hidden-side GRU pre-activations W_hh h (accumulator fragments)
   float *DYxf, *DI1xf, *DH1xf, *DI0xf, *DH0xf, *D0xf, *dXa;               // backward fragments
   size_t xf_bytes_fwd, xf_bytes_bwd;
   float *xf_base_fwd, *xf_base_bwd;
@@ -71,6 +72,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
   {
     size_t o0 = a.off;
     w.Xxf = a.f(2 * w.KBX * XB); w.HIDxf = a.f(w.KBH * XB); w.H0xf = a.f(2 * w.KBH * XB); w.H1xf = a.f(2 * w.KBH * XB);
+    w.GH0 = a.f((long)w.nT5 * XB); w.GH1 = a.f((long)w.nT5 * XB);
     w.xf_base_fwd = w.Xxf;
     w.xf_bytes_fwd = a.off - align_up(o0, 256);
   }

@@ -203,8 +203,8 @@ int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   // few output tiles but a long contraction (weight gradients): split K over workgroups, combine with fp32 atomics
   const bool can_split = nbatch == 1 && g.beta == 0.f && g.bias == nullptr && g.act == ACT_NONE && g.scn == 1 &&
                          g.scm == g.N && ktiles >= 64;
-  if (tiles < 160 && can_split) {
-    long sk = (256 + tiles - 1) / tiles;
+  if (tiles < 640 && can_split) {        // aim at ~3 workgroups per CU (one wave per SIMD each)
+    long sk = (768 + tiles - 1) / tiles;
     if (sk > ktiles / 16) sk = ktiles / 16;
     if (sk > 32) sk = 32;
     if (sk > 1) {
