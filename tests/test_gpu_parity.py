@@ -430,3 +430,31 @@ def test_train_api_runs_and_checkpoints(tmp_path):
     assert "recurrent_decoder.layer1.weight_hh_l1" in de.state_dict()
     ck = torch.load(tmp_path / "models" / "checkpoints.pt", weights_only=False)
     assert set(ck) == {"iteration", "epoch", "loss", "optimizer_state_dict"}
+
+
+@pytest.mark.parametrize("B", [1, 3, 4])
+def test_decoder_gemv_decode_path_matches_mfma_path(B):
+    """B <= 4 no_grad rollouts use the GEMV stage kernels; option bit 1024 forces the MFMA path for comparison."""
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).eval()
+    T = 40
+    stats = synth.make_stats()
+    s = {k: g(v) for k, v in helpers.stats_tensors().items()}
+    clips = [synth.make_clip(T, seed=500 + b, stats=stats) for b in range(B)]
+    tt = lambda k: g(torch.as_tensor(np.stack([c[k] for c in clips])))  # noqa: E731
+    pose0 = _pack_pose(tt("Y_root_vel"), tt("Y_root_vrt"), tt("Y_lpos"), tt("Y_ltxy"), tt("Y_lvel"), tt("Y_lvrt"))[:, 0]
+    torch.manual_seed(9)
+    speech, style = torch.randn(B, T, 64, device=DEV) * 0.5, torch.randn(B, T, 64, device=DEV) * 0.5
+    outs = []
+    try:
+        for v in (1024, 0):
+            ops.set_option("stage_variant", v)
+            with torch.no_grad():
+                outs.append(ops.decoder_core(de, pose0.contiguous(), tt("Y_root_pos")[:, 0].contiguous(),
+                                             tt("Y_root_rot")[:, 0].contiguous(), tt("Y_gaze_pos"), speech, style,
+                                             s["in_mean"], s["in_std"], s["out_mean"], s["out_std"], synth.DT))
+    finally:
+        ops.set_option("stage_variant", 0)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) < 5e-5

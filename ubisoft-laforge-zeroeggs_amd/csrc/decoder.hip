@@ -278,6 +278,7 @@ extern "C" int zeggs_decoder_fwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   const long sG = (long)B * GL, sH = (long)B * H;
   const int ring = training ? 0 : 1;
   auto slot = [&](int t) { return ring ? (t & 1) : t; };
+  if (!training) ZTRY(k_fill(w.Gin, 2 * sG, 0.f, s));   // ring slots: pad columns must be finite (GEMV decode path)
   // frame 0 + CellStateEncoder
   hipLaunchKernelGGL(dec_init_k, dim3(B), dim3(256), 0, s, d, *st, pose0, rpos0, rrot0, gaze, style, pose, rpos, rrot,
                      w.cse_in, w.Gin + slot(1) * sG, GL);

@@ -34,6 +34,8 @@ struct Seg {
   const float* w;   // packed weights  [tile][kb][64][4]
   const float* x;   // packed activations [kb][NB][64][4]
   int kb, acc;
+  const float* xc;  // GEMV mode (batch <= 4, inference): the same activations in canonical row-major form
+  int ldx;
 };
 struct Grp {
   Seg seg[3];
@@ -52,6 +54,7 @@ struct StageArgs {
   const float *dpose, *drpos, *drrot;      // backward: loss gradients
   float* carry;                            // [B,8] root-state gradient carry
   int variant;                             // ablation switches (tools/stage_bench.py); 0 in production
+  int gemv;                                // 1: tiny-batch decode, VALU dot products over canonical activations
 };
 
 // column permutation of the dX stage: tile 0 holds root_vel/vrt (0..5) AND the gaze columns (PO..PO+2)
@@ -153,7 +156,7 @@ __device__ void root_bwd(const ZeggsDecDims& d, const ZeggsDecStats& st, int b, 
   cr[5] = dq1.y + dqy.y + dq2.y; cr[6] = dq1.z + dqy.z + dq2.z;
 }
 
-template <int NB, int FAM, int WAVES>   // FAM 0: forward epilogues, 1: backward (keeps register pressure apart)
+template <int NB, int FAM, int WAVES, int BV = 0>   // FAM 0: forward epilogues, 1: backward; BV > 0: GEMV mode for BV rows
 __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
   constexpr int NTHR = WAVES * 64;
   static_assert(16 * 16 * NB <= NTHR, "one epilogue item per thread");
@@ -253,41 +256,105 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
     pre4 = ((const f4*)G.p3)[((long)tile * LNB + nb0 + r / 64) * 64 + (r % 64)];
   }
 
-  // ---- weight stream: the waves split the concatenated k-block list of the segments
-  f4 acc[2][NB];
+  if constexpr (BV > 0) {
+    // ---- GEMV mode: batch <= 4 (autoregressive decode).  No MFMA padding to 16 batch rows: each lane owns
+    // (column i, k-quarter) of the weight fragment and multiplies it with the matching float4 of every batch row
+    // read straight from the canonical activations (16 lanes share an address: one L1 broadcast).
+    float av[2][BV];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f4{0.f, 0.f, 0.f, 0.f};
-  int TB = 0;
-  for (int s = 0; s < G.nseg; ++s) TB += G.seg[s].kb;
-  const int b0 = wave * TB / WAVES, b1 = (wave + 1) * TB / WAVES;
-  int base = 0;
-  for (int s = 0; s < ((a.variant & V_NOW) ? 0 : G.nseg); ++s) {
-    const int kbs = G.seg[s].kb;
-    const int lo = (b0 > base ? b0 : base) - base;
-    const int hi = (b1 < base + kbs ? b1 : base + kbs) - base;
-    if (lo < hi) {
-      const f4* wp = (const f4*)G.seg[s].w + ((long)tile * kbs) * 64 + lane;
-      const f4* xp = (const f4*)G.seg[s].x + nb0 * 64 + lane;
-      if (G.seg[s].acc == 0) run_blocks<NB>(wp, xp, lo, hi, acc[0], LNB);
-      else run_blocks<NB>(wp, xp, lo, hi, acc[1], LNB);
+      for (int b = 0; b < BV; ++b) av[i][b] = 0.f;
+    int TB = 0;
+    for (int s = 0; s < G.nseg; ++s) TB += G.seg[s].kb;
+    const int b0 = wave * TB / WAVES, b1 = (wave + 1) * TB / WAVES;
+    int base = 0;
+    for (int s = 0; s < G.nseg; ++s) {
+      const int kbs = G.seg[s].kb;
+      const int lo = (b0 > base ? b0 : base) - base;
+      const int hi = (b1 < base + kbs ? b1 : base + kbs) - base;
+      if (lo < hi) {
+        const f4* wp = (const f4*)G.seg[s].w + ((long)tile * kbs) * 64 + lane;
+        const float* xc = G.seg[s].xc + 4 * (lane >> 4);
+        const int ldx = G.seg[s].ldx;
+        float part[BV];
+#pragma unroll
+        for (int b = 0; b < BV; ++b) part[b] = 0.f;
+#pragma unroll 4
+        for (int kb = lo; kb < hi; ++kb) {
+          const f4 wv = wp[(long)kb * 64];
+#pragma unroll
+          for (int b = 0; b < BV; ++b) {
+            const f4 xv = *(const f4*)(xc + (long)b * ldx + 16 * kb);
+            part[b] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, part[b]))));
+          }
+        }
+        if (G.seg[s].acc == 0) {
+#pragma unroll
+          for (int b = 0; b < BV; ++b) av[0][b] += part[b];
+        } else {
+#pragma unroll
+          for (int b = 0; b < BV; ++b) av[1][b] += part[b];
+        }
+      }
+      base += kbs;
     }
-    base += kbs;
-  }
+    float* redf = (float*)red;   // [wave][2][BV][16]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) red[wave][i][nb][lane] = acc[i][nb];
-  __syncthreads();
-  if (tid < 2 * NB * 64) {
-    const int i = tid / (NB * 64), r = tid % (NB * 64), nb = r / 64, l = r % 64;
-    f4 s = red[0][i][nb][l];
+      for (int b = 0; b < BV; ++b) {
+        float v = av[i][b];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16) redf[((wave * 2 + i) * BV + b) * 16 + lane] = v;
+      }
+    __syncthreads();
+    if (tid < 2 * BV * 16) {
+      const int i = tid / (BV * 16), r = tid % (BV * 16), b = r / 16, col = r % 16;
+      float sum = 0.f;
 #pragma unroll
-    for (int w = 1; w < WAVES; ++w) s += red[w][i][nb][l];
-    fin[i][nb][l] = s + pre4;
-  }
-  __syncthreads();
+      for (int w = 0; w < WAVES; ++w) sum += redf[((w * 2 + i) * BV + b) * 16 + col];
+      ((float*)fin)[(((i * NB) * 64 + (((col >> 2) << 4) | b)) << 2) | (col & 3)] = sum;
+    }
+    __syncthreads();
+  } else {
+  // ---- weight stream: the waves split the concatenated k-block list of the segments
+    f4 acc[2][NB];
+  #pragma unroll
+    for (int i = 0; i < 2; ++i)
+  #pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f4{0.f, 0.f, 0.f, 0.f};
+    int TB = 0;
+    for (int s = 0; s < G.nseg; ++s) TB += G.seg[s].kb;
+    const int b0 = wave * TB / WAVES, b1 = (wave + 1) * TB / WAVES;
+    int base = 0;
+    for (int s = 0; s < ((a.variant & V_NOW) ? 0 : G.nseg); ++s) {
+      const int kbs = G.seg[s].kb;
+      const int lo = (b0 > base ? b0 : base) - base;
+      const int hi = (b1 < base + kbs ? b1 : base + kbs) - base;
+      if (lo < hi) {
+        const f4* wp = (const f4*)G.seg[s].w + ((long)tile * kbs) * 64 + lane;
+        const f4* xp = (const f4*)G.seg[s].x + nb0 * 64 + lane;
+        if (G.seg[s].acc == 0) run_blocks<NB>(wp, xp, lo, hi, acc[0], LNB);
+        else run_blocks<NB>(wp, xp, lo, hi, acc[1], LNB);
+      }
+      base += kbs;
+    }
+  #pragma unroll
+    for (int i = 0; i < 2; ++i)
+  #pragma unroll
+      for (int nb = 0; nb < NB; ++nb) red[wave][i][nb][lane] = acc[i][nb];
+    __syncthreads();
+    if (tid < 2 * NB * 64) {
+      const int i = tid / (NB * 64), r = tid % (NB * 64), nb = r / 64, l = r % 64;
+      f4 s = red[0][i][nb][l];
+  #pragma unroll
+      for (int w = 1; w < WAVES; ++w) s += red[w][i][nb][l];
+      fin[i][nb][l] = s + pre4;
+    }
+    __syncthreads();
+}
   const float* finf = (const float*)fin;
   auto FV = [&](int i, int vcol, int bg) -> float {   // bg = global batch row (must belong to this part)
     const int b = bg - 16 * nb0;
@@ -304,7 +371,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         const int col = tile * 16 + ev;
         const float val = d_elu(FV(0, ev, eb) + pre[0]);
         G.o0[(long)eb * a.GL + col] = val;
-        G.o1[xf_index(eb, col, LNB)] = val;
+        if (G.o1) G.o1[xf_index(eb, col, LNB)] = val;
       }
     } break;
     case EPI_GRU_FWD: if constexpr (FAM == 0) {   // tile = 5 hidden units x (r, z, n); acc0 = input side, acc1 = hidden side
@@ -317,7 +384,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         const long i = (long)b * H + U;
         const float h = (1.f - z) * nn + z * pre[6];
         G.o0[i] = h;
-        G.o1[xf_index(b, U, LNB)] = h;
+        if (G.o1) G.o1[xf_index(b, U, LNB)] = h;
         if (G.o2) { G.o2[i] = r; G.o3[i] = z; G.o4[i] = nn; G.o5[i] = nh; }
       }
     } break;
@@ -332,7 +399,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         if (next) {
           const float e = (p - pre[3]) / pre[4];
           if (gnext) gnext[(long)b * a.GL + H + col] = e;
-          xnext[xf_index(b, col, LNB)] = e;
+          if (xnext) xnext[xf_index(b, col, LNB)] = e;
         }
       }
       if (next) {   // speech / style columns of x_{t+1}
@@ -342,7 +409,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
           const float val = c < d.SP ? a.speech[((long)b * d.T + t + 1) * d.SP + c]
                                      : a.style[((long)b * d.T + t + 1) * d.ST + (c - d.SP)];
           if (gnext) gnext[(long)b * a.GL + H + d.PI + c] = val;
-          xnext[xf_index(b, d.PI + c, LNB)] = val;
+          if (xnext) xnext[xf_index(b, d.PI + c, LNB)] = val;
         }
       }
       if (root) {
@@ -362,7 +429,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
           for (int k = 0; k < 3; ++k) {
             const float e = (gv[k] - a.st.in_mean[PO + k]) / a.st.in_std[PO + k];
             if (gnext) gnext[(long)b * a.GL + H + PO + k] = e;
-            xnext[xf_index(b, PO + k, LNB)] = e;
+            if (xnext) xnext[xf_index(b, PO + k, LNB)] = e;
           }
         }
       }
@@ -523,6 +590,19 @@ int pack(float* dst, const float* src, int tiles, int kb, int mode, int K, int N
   return 0;
 }
 
+int launch_stage_gemv(const StageArgs& a, hipStream_t s) {
+  const int wgs = a.g[0].tiles + a.g[1].tiles;
+  switch (a.d.B) {
+    case 1: hipLaunchKernelGGL((stage_k<1, 0, 8, 1>), dim3(wgs), dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((stage_k<1, 0, 8, 2>), dim3(wgs), dim3(512), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((stage_k<1, 0, 8, 3>), dim3(wgs), dim3(512), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((stage_k<1, 0, 8, 4>), dim3(wgs), dim3(512), 0, s, a); break;
+    default: zeggs_set_error("gemv mode needs batch <= 4"); return -1;
+  }
+  ZLAUNCH_CHECK("decoder_stage_gemv");
+  return 0;
+}
+
 template <int FAM>
 int launch_stage_f(const StageArgs& a, hipStream_t s) {
   // stages with few tiles are split over the batch (two workgroups per tile) to occupy more CUs
@@ -548,10 +628,13 @@ int launch_stage_f(const StageArgs& a, hipStream_t s) {
   return 0;
 }
 int launch_stage(const StageArgs& a, hipStream_t s) {
+  if (a.gemv) return launch_stage_gemv(a, s);
   return a.g[0].epi >= EPI_GRU_BWD ? launch_stage_f<1>(a, s) : launch_stage_f<0>(a, s);   // enum order: fwd < bwd
 }
 
-inline Seg seg(const float* w, const float* x, int kb, int acc) { return Seg{w, x, kb, acc}; }
+inline Seg seg(const float* w, const float* x, int kb, int acc, const float* xc = nullptr, int ldx = 0) {
+  return Seg{w, x, kb, acc, xc, ldx};
+}
 
 StageArgs base_args(const ZeggsDecDims& d, const ZeggsDecStats* st, const DecWs& w) {
   StageArgs a;
@@ -619,43 +702,55 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     a.g[1].o0 = w.GH1;
     ZTRY(launch_stage(a, s));
   }
+  // tiny-batch decode (B <= 4, no_grad): GEMV stage kernels over the canonical activations (decoder.hip zero-fills
+  // the Gin ring first: the pad columns of x are read against zero weights and must be finite)
+  const bool gemv = !training && B <= 4 && !(g_stage_variant & 1024);
   for (int t = 1; t < T; ++t) {
     const int c = t & 1, p = (t - 1) & 1;
     const long o = (long)t * sH;
     StageArgs a = base_args(d, st, w);
     a.t = t; a.gaze = gaze; a.speech = speech; a.style = style; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
-    // S1: hid = ELU(W0 x + b0)    [+ side: GH0 = W_hh0 h0[t-1] for S2 of this step, except t == 1 (done above)]
+    a.gemv = gemv;
+    const float* gin_c = w.Gin + cs(t) * sG;
+    const float *h0p = w.H0 + cs(t - 1) * sH, *h1p = w.H1 + cs(t - 1) * sH;
+    float *h0c = w.H0 + cs(t) * sH, *h1c = w.H1 + cs(t) * sH;
+    // S1: hid = ELU(W0 x + b0)    [+ optional side: GH0 = W_hh0 h0[t-1]]
     a.g[0] = Grp{}; a.g[1] = Grp{};
-    a.g[0].seg[0] = seg(w.pw_l0, Xxf[c], w.KBX, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_ELU_HID;
-    a.g[0].p0 = P->l0_b; a.g[0].o0 = w.Gin + cs(t) * sG; a.g[0].o1 = w.HIDxf;
+    a.g[0].seg[0] = seg(w.pw_l0, Xxf[c], w.KBX, 0, gin_c + H, w.GL); a.g[0].nseg = 1; a.g[0].tiles = w.nTH;
+    a.g[0].epi = EPI_ELU_HID;
+    a.g[0].p0 = P->l0_b; a.g[0].o0 = w.Gin + cs(t) * sG; a.g[0].o1 = gemv ? nullptr : w.HIDxf;
     if (reb && t > 1) {
       a.g[1].seg[0] = seg(w.pw_hh0, H0xf[p], w.KBH, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nT5; a.g[1].epi = EPI_STORE_ACC;
       a.g[1].o0 = w.GH0;
     }
     ZTRY(launch_stage(a, s));
-    // S2: GRU layer 0 (input side only; hidden side comes from GH0)
+    // S2: GRU layer 0
     a.g[0] = Grp{}; a.g[1] = Grp{};
-    a.g[0].seg[0] = seg(w.pw_ih0h, w.HIDxf, w.KBH, 0); a.g[0].seg[1] = seg(w.pw_ih0x, Xxf[c], w.KBX, 0);
+    a.g[0].seg[0] = seg(w.pw_ih0h, w.HIDxf, w.KBH, 0, gin_c, w.GL);
+    a.g[0].seg[1] = seg(w.pw_ih0x, Xxf[c], w.KBX, 0, gin_c + H, w.GL);
     a.g[0].nseg = 2; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
-    a.g[0].p0 = P->b_ih0; a.g[0].p1 = P->b_hh0; a.g[0].p2 = w.H0 + cs(t - 1) * sH;
+    a.g[0].p0 = P->b_ih0; a.g[0].p1 = P->b_hh0; a.g[0].p2 = h0p;
     if (reb) a.g[0].p3 = w.GH0;
-    else { a.g[0].seg[2] = seg(w.pw_hh0, H0xf[p], w.KBH, 1); a.g[0].nseg = 3; }
-    a.g[0].o0 = w.H0 + cs(t) * sH; a.g[0].o1 = H0xf[c];
+    else { a.g[0].seg[2] = seg(w.pw_hh0, H0xf[p], w.KBH, 1, h0p, H); a.g[0].nseg = 3; }
+    a.g[0].o0 = h0c; a.g[0].o1 = gemv ? nullptr : H0xf[c];
     if (training) { a.g[0].o2 = w.R0 + o; a.g[0].o3 = w.Z0 + o; a.g[0].o4 = w.N0 + o; a.g[0].o5 = w.NH0 + o; }
     ZTRY(launch_stage(a, s));
-    // S3: GRU layer 1 (hidden side from GH1)
+    // S3: GRU layer 1
     a.g[0] = Grp{};
-    a.g[0].seg[0] = seg(w.pw_ih1, H0xf[c], w.KBH, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
-    a.g[0].p0 = P->b_ih1; a.g[0].p1 = P->b_hh1; a.g[0].p2 = w.H1 + cs(t - 1) * sH;
+    a.g[0].seg[0] = seg(w.pw_ih1, H0xf[c], w.KBH, 0, h0c, H); a.g[0].nseg = 1; a.g[0].tiles = w.nT5;
+    a.g[0].epi = EPI_GRU_FWD;
+    a.g[0].p0 = P->b_ih1; a.g[0].p1 = P->b_hh1; a.g[0].p2 = h1p;
     if (reb) a.g[0].p3 = w.GH1;
-    else { a.g[0].seg[1] = seg(w.pw_hh1, H1xf[p], w.KBH, 1); a.g[0].nseg = 2; }
-    a.g[0].o0 = w.H1 + cs(t) * sH; a.g[0].o1 = H1xf[c];
+    else { a.g[0].seg[1] = seg(w.pw_hh1, H1xf[p], w.KBH, 1, h1p, H); a.g[0].nseg = 2; }
+    a.g[0].o0 = h1c; a.g[0].o1 = gemv ? nullptr : H1xf[c];
     if (training) { a.g[0].o2 = w.R1 + o; a.g[0].o3 = w.Z1 + o; a.g[0].o4 = w.N1 + o; a.g[0].o5 = w.NH1 + o; }
     ZTRY(launch_stage(a, s));
-    // S4: output projection + pose integration + x_{t+1}   [+ side: GH1 = W_hh1 h1[t] for S3 of the next step]
+    // S4: output projection + pose integration + x_{t+1}   [+ optional side: GH1 = W_hh1 h1[t]]
     a.g[0] = Grp{}; a.g[1] = Grp{};
-    a.g[0].seg[0] = seg(w.pw_l2, H1xf[c], w.KBH, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTPO; a.g[0].epi = EPI_OUT_FWD;
-    a.g[0].p0 = P->l2_b; a.g[0].o0 = (t + 1 < T) ? w.Gin + cs(t + 1) * sG : nullptr; a.g[0].o1 = Xxf[(t + 1) & 1];
+    a.g[0].seg[0] = seg(w.pw_l2, H1xf[c], w.KBH, 0, h1c, H); a.g[0].nseg = 1; a.g[0].tiles = w.nTPO;
+    a.g[0].epi = EPI_OUT_FWD;
+    a.g[0].p0 = P->l2_b; a.g[0].o0 = (t + 1 < T) ? w.Gin + cs(t + 1) * sG : nullptr;
+    a.g[0].o1 = gemv ? nullptr : Xxf[(t + 1) & 1];
     if (reb && t + 1 < T) {
       a.g[1].seg[0] = seg(w.pw_hh1, H1xf[c], w.KBH, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nT5; a.g[1].epi = EPI_STORE_ACC;
       a.g[1].o0 = w.GH1;
