@@ -458,3 +458,52 @@ def test_decoder_gemv_decode_path_matches_mfma_path(B):
     for a, b in zip(outs[0], outs[1]):
         assert torch.isfinite(b).all()
         assert float((a - b).abs().max()) < 5e-5
+
+
+# ----------------------------------------------------------------------------- edge cases
+def _oracle_vs_hip_rollout(B, T, style_dim, tol=1e-4):
+    torch.manual_seed(1234)
+    from zeggs import modules
+    de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, 64, style_dim, 1024, 2)
+    stats = synth.make_stats()
+    s = helpers.stats_tensors()
+    clips = [synth.make_clip(max(T, 4), seed=700 + b, stats=stats) for b in range(B)]
+    tt = lambda k: torch.as_tensor(np.stack([c[k][:T] for c in clips]))  # noqa: E731
+    torch.manual_seed(4)
+    speech, style = torch.randn(B, T, 64) * 0.5, torch.randn(B, T, style_dim) * 0.5
+    fp = [tt(k)[:, 0] for k in ("Y_root_pos", "Y_root_rot", "Y_root_vel", "Y_root_vrt", "Y_lpos", "Y_ltxy", "Y_lvel",
+                                "Y_lvrt")]
+    with torch.no_grad():
+        ref = onets.decoder_rollout(helpers.sd(de), *fp, tt("Y_gaze_pos"), speech, style, s["in_mean"], s["in_std"],
+                                    s["out_mean"], s["out_std"], synth.DT)
+        de = de.to(DEV).eval()
+        out = de(*[g(t) for t in fp], g(tt("Y_gaze_pos")), g(speech), g(style), None, g(s["in_mean"]), g(s["in_std"]),
+                 g(s["out_mean"]), g(s["out_std"]), synth.DT)
+    for n, o, r in zip(NAMES, out, ref):
+        assert o.shape == r.shape, n
+        assert float((o.cpu() - r).abs().max()) < tol, n
+
+
+def test_decoder_label_conditioning_dims():
+    """configs_v2: style = one-hot over 19 labels (decoder input width 1217, W_ih0 [3072, 2241])."""
+    _oracle_vs_hip_rollout(B=3, T=5, style_dim=19)
+
+
+def test_decoder_shortest_sequences():
+    _oracle_vs_hip_rollout(B=2, T=2, style_dim=64)       # one generated frame
+    _oracle_vs_hip_rollout(B=2, T=1, style_dim=64)       # nothing to generate: outputs = the given first pose
+
+
+def test_decoder_batch_above_fast_path_limit_uses_generic_path():
+    _oracle_vs_hip_rollout(B=65, T=3, style_dim=64)
+
+
+def test_loss_is_zero_and_finite_when_prediction_equals_target():
+    stats = synth.make_stats()
+    c = synth.make_clip(6, seed=1, stats=stats)
+    tt = lambda k: g(torch.as_tensor(c[k][None]))  # noqa: E731
+    pose = _pack_pose(tt("Y_root_vel"), tt("Y_root_vrt"), tt("Y_lpos"), tt("Y_ltxy"), tt("Y_lvel"), tt("Y_lvrt"))
+    parents = torch.as_tensor(synth.PARENTS, dtype=torch.int32, device=DEV)
+    loss, terms = ops.training_loss(pose.clone().requires_grad_(True), tt("Y_root_pos"), tt("Y_root_rot"), pose,
+                                    tt("Y_root_pos"), tt("Y_root_rot"), tt("Y_gaze_pos"), parents, synth.DT)
+    assert float(loss) == 0.0 and float(terms[:18].abs().max()) == 0.0

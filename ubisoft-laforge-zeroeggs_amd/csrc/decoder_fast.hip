@@ -786,8 +786,11 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     a.g[0].seg[0] = seg(w.pb_ih1, w.DI1xf, w.KB3H, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
     a.g[0].p0 = w.R0 + o; a.g[0].p1 = w.Z0 + o; a.g[0].p2 = w.N0 + o; a.g[0].p3 = w.NH0 + o; a.g[0].p4 = w.H0 + o - sH;
     a.g[0].o0 = w.dH0c; a.g[0].o1 = w.DI0 + t * s3; a.g[0].o2 = w.DH0 + t * s3; a.g[0].o3 = w.DI0xf; a.g[0].o4 = w.DH0xf;
-    a.g[1].seg[0] = seg(w.pb_hh1, w.DH1xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
-    a.g[1].o0 = w.dH1c;
+    const bool hh1_in_b4 = (g_stage_variant & 2048) != 0;
+    if (!hh1_in_b4) {
+      a.g[1].seg[0] = seg(w.pb_hh1, w.DH1xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
+      a.g[1].o0 = w.dH1c;
+    }
     ZTRY(launch_stage(a, s));
     // B3: dGin = W_ih0^T di0 -> [D0 | dx part]
     a.g[0] = Grp{}; a.g[1] = Grp{};
@@ -804,6 +807,10 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     if (side_in_b4) {
       a.g[1].seg[0] = seg(w.pb_hh0, w.DH0xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
       a.g[1].o0 = w.dH0c;
+    }
+    if (hh1_in_b4) {
+      a.g[1].seg[0] = seg(w.pb_hh1, w.DH1xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
+      a.g[1].o0 = w.dH1c;
     }
     a.g[0].seg[0] = seg(w.pb_l0, w.D0xf, w.KBH, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTX; a.g[0].epi = EPI_DX;
     a.g[0].p0 = w.dXa; a.g[0].o0 = w.DX + (long)t * B * w.XD;
