@@ -280,8 +280,21 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         float part[BV];
 #pragma unroll
         for (int b = 0; b < BV; ++b) part[b] = 0.f;
-#pragma unroll 4
-        for (int kb = lo; kb < hi; ++kb) {
+        // 8 weight blocks (8 KiB per wave) in flight per round trip
+        int kb = lo;
+        for (; kb + 8 <= hi; kb += 8) {
+          f4 wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) wv[u] = wp[(long)(kb + u) * 64];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int b = 0; b < BV; ++b) {
+              const f4 xv = *(const f4*)(xc + (long)b * ldx + 16 * (kb + u));
+              part[b] = fmaf(wv[u].x, xv.x, fmaf(wv[u].y, xv.y, fmaf(wv[u].z, xv.z, fmaf(wv[u].w, xv.w, part[b]))));
+            }
+        }
+        for (; kb < hi; ++kb) {
           const f4 wv = wp[(long)kb * 64];
 #pragma unroll
           for (int b = 0; b < BV; ++b) {

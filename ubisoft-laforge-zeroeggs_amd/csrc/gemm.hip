@@ -16,6 +16,8 @@
 #include "gemm.h"
 #include "kernels.h"
 
+int g_gemm_wg_target = 3072;   // split-K aims at this many workgroups (6 per CU; measured sweep in tools/gemm_bench.py)
+
 namespace {
 
 constexpr int BK = 16;
@@ -40,6 +42,23 @@ __device__ __forceinline__ void load_contig(float (&r)[E], const float* p, int n
   } else {
 #pragma unroll
     for (int i = 0; i < E; ++i) r[i] = (i < nvalid) ? p[i] : 0.f;
+  }
+}
+
+template <int E>
+__device__ __forceinline__ void load_full(float (&r)[E], const float* p) {
+  if constexpr (E == 8) {
+    f4u a = *(const f4u*)p, b = *(const f4u*)(p + 4);
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+  } else if constexpr (E == 4) {
+    f4u a = *(const f4u*)p;
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+  } else if constexpr (E == 2) {
+    f2u a = *(const f2u*)p;
+    r[0] = a.x; r[1] = a.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = p[i];
   }
 }
 
@@ -76,10 +95,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   const int t_begin = (int)((long)ntiles_all * ks / g.splitk), ntiles = (int)((long)ntiles_all * (ks + 1) / g.splitk);
   float ra[EA], rb[EB];
 
+  // interior blocks take a branch-free path (unguarded vector loads); edge blocks / the K tail use guarded loads
+  const bool interior = (m_base + BM <= g.M) && (n_base + BN <= g.N);
   auto gload = [&](int tile) {
     const int kb = tile / nkt, k_base = (tile % nkt) * BK;
     const float* Ab = A + (long)kb * g.kbsA;
     const float* Bb = B + (long)kb * g.kbsB;
+    if (interior && k_base + BK <= g.K) {
+      if constexpr (AKC) load_full<EA>(ra, Ab + (long)(m_base + a_r) * g.sam + (k_base + a_c));
+      else load_full<EA>(ra, Ab + (long)(k_base + a_r) * g.sak + (m_base + a_c));
+      if constexpr (BKC) load_full<EB>(rb, Bb + (long)(n_base + b_r) * g.sbn + (k_base + b_c));
+      else load_full<EB>(rb, Bb + (long)(k_base + b_r) * g.sbk + (n_base + b_c));
+      return;
+    }
     if constexpr (AKC) {
       int m = m_base + a_r, k = k_base + a_c;
       int nv = (m < g.M) ? (g.K - k) : 0;
@@ -203,8 +231,8 @@ int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   // few output tiles but a long contraction (weight gradients): split K over workgroups, combine with fp32 atomics
   const bool can_split = nbatch == 1 && g.beta == 0.f && g.bias == nullptr && g.act == ACT_NONE && g.scn == 1 &&
                          g.scm == g.N && ktiles >= 64;
-  if (tiles < 640 && can_split) {        // aim at ~3 workgroups per CU (one wave per SIMD each)
-    long sk = (768 + tiles - 1) / tiles;
+  if (tiles < g_gemm_wg_target * 5 / 6 && can_split) {        // aim at ~3 workgroups per CU (one wave per SIMD each)
+    long sk = (g_gemm_wg_target + tiles - 1) / tiles;
     if (sk > ktiles / 16) sk = ktiles / 16;
     if (sk > 32) sk = 32;
     if (sk > 1) {
