@@ -1,18 +1,21 @@
 #!/bin/bash
-# Build libzeggs_hip.so for gfx950 (cross-compiles without a GPU). Output lands in ../zeggs/ (in-tree).
+# Build the MI355X engine library: every .hip translation unit -> zeggs/libzeggs_hip.so (gfx950 only).
 set -e
 cd "$(dirname "$0")"
-OUT=../zeggs/libzeggs_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result ${ZEGGS_HIPCC_FLAGS}"
-mkdir -p build
+# experiments: ZEGGS_DEFS="-DZEGGS_U=4" ZEGGS_OUT=../zeggs/libzeggs_alt.so bash build.sh ; load with ZEGGS_LIB=<path>
+OUT=${ZEGGS_OUT:-../zeggs/libzeggs_hip.so}
+BD=${ZEGGS_BUILD_DIR:-build}
+mkdir -p $BD
 pids=()
-for f in gemm kernels encoders decoder decoder_fast loss misc mel; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm.h -nt build/$f.o ] \
-     || [ kernels.h -nt build/$f.o ] || [ decoder_ws.h -nt build/$f.o ] || [ dec_math.h -nt build/$f.o ] || [ ../../include/zeggs_hip.h -nt build/$f.o ]; then
-    hipcc $FLAGS -c $f.hip -o build/$f.o &
+SRC="gemm kernels encoders decoder decoder_fast loss misc mel"
+for f in $SRC; do
+  if [ ! -f $BD/$f.o ] || [ $f.hip -nt $BD/$f.o ] || [ common.h -nt $BD/$f.o ] || [ decoder_ws.h -nt $BD/$f.o ] || [ dec_math.h -nt $BD/$f.o ] || [ ../../include/zeggs_hip.h -nt $BD/$f.o ] || [ kernels.h -nt $BD/$f.o ] || [ gemm.h -nt $BD/$f.o ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $ZEGGS_DEFS -c $f.hip -o $BD/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
+OBJ=""
+for f in $SRC; do OBJ="$OBJ $BD/$f.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ
 echo "built $OUT"

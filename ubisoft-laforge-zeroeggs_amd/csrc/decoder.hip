@@ -16,12 +16,14 @@
 #include "decoder_ws.h"
 
 static int g_decoder_fast = 1;
+static int g_bwd_chunks = 1;   // BPTT sweep chunks whose weight-gradient GEMMs overlap the rest of the sweep (1: serial)
 extern int g_stage_variant;
 extern int g_gemm_wg_target;
 extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "decoder_fast") == 0) { g_decoder_fast = value; return 0; }
   if (strcmp(name, "stage_variant") == 0) { g_stage_variant = value; return 0; }
   if (strcmp(name, "gemm_wg_target") == 0) { g_gemm_wg_target = value; return 0; }
+  if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
   zeggs_set_error("unknown option %s", name);
   return -1;
 }
@@ -255,6 +257,47 @@ __global__ void add_style0_grad_k(ZeggsDecDims d, const float* dcse_in, float* d
   }
 }
 
+// weight gradients of the recurrent part for the steps t_lo..t_hi: contraction over the flattened (t, b) rows
+int dec_recurrent_wgrads(const ZeggsDecDims& d, const DecWs& w, const ZeggsDecGrads* G, int t_lo, int t_hi, float beta,
+                         hipStream_t s) {
+  const int B = d.B, H = d.H, GL = w.GL, XD = w.XD, POL = w.POL;
+  const long sG = (long)B * GL, sH = (long)B * H, s3 = 3 * sH, sY = (long)B * POL;
+  const int M = (t_hi - t_lo + 1) * B;
+  const long o = t_lo;
+  ZTRY(gemm_tn(w.DY + o * sY, POL, w.H1 + o * sH, H, G->l2_w, H, M, d.PO, H, beta, s));
+  ZTRY(k_colsum(G->l2_b, w.DY + o * sY, M, d.PO, POL, beta, s));
+  ZTRY(gemm_tn(w.DI1 + o * s3, 3 * H, w.H0 + o * sH, H, G->w_ih1, H, M, 3 * H, H, beta, s));
+  ZTRY(gemm_tn(w.DH1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, M, 3 * H, H, beta, s));
+  ZTRY(k_colsum(G->b_ih1, w.DI1 + o * s3, M, 3 * H, 3 * H, beta, s));
+  ZTRY(k_colsum(G->b_hh1, w.DH1 + o * s3, M, 3 * H, 3 * H, beta, s));
+  ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.Gin + o * sG, GL, G->w_ih0, H + XD, M, 3 * H, H + XD, beta, s));
+  ZTRY(gemm_tn(w.DH0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 3 * H, H, beta, s));
+  ZTRY(k_colsum(G->b_ih0, w.DI0 + o * s3, M, 3 * H, 3 * H, beta, s));
+  ZTRY(k_colsum(G->b_hh0, w.DH0 + o * s3, M, 3 * H, 3 * H, beta, s));
+  ZTRY(gemm_tn(w.D0 + o * sH, H, w.Gin + o * sG + H, GL, G->l0_w, XD, M, H, XD, beta, s));
+  ZTRY(k_colsum(G->l0_b, w.D0 + o * sH, M, H, H, beta, s));
+  return 0;
+}
+
+// Side stream (lowest priority) + events for the overlapped weight-gradient GEMMs, one set per device.
+struct SideStream { hipStream_t s; hipEvent_t chunk, done; };
+int side_stream(SideStream** out) {
+  static SideStream pool[16];
+  static bool ready[16] = {};
+  int dev = 0;
+  ZCHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "decoder bwd: unsupported device index");
+  if (!ready[dev]) {
+    int lo = 0, hi = 0;
+    ZCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess, "hipDeviceGetStreamPriorityRange failed");
+    ZCHECK(hipStreamCreateWithPriority(&pool[dev].s, hipStreamNonBlocking, lo) == hipSuccess, "side stream creation failed");
+    ZCHECK(hipEventCreateWithFlags(&pool[dev].chunk, hipEventDisableTiming) == hipSuccess, "event creation failed");
+    ZCHECK(hipEventCreateWithFlags(&pool[dev].done, hipEventDisableTiming) == hipSuccess, "event creation failed");
+    ready[dev] = true;
+  }
+  *out = &pool[dev];
+  return 0;
+}
+
 inline dim3 g1(long n) { long g = (n + 255) / 256; return dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))); }
 
 }  // namespace
@@ -354,9 +397,28 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   ZTRY(k_fill(w.dH1c, sH, 0.f, s));
   ZTRY(k_fill(w.carry, (long)B * 8, 0.f, s));
   ZTRY(k_fill(w.DX, (long)B * XD, 0.f, s));          // slot t = 0 unused but read by the scatter
+  ZCHECK(T > 1, "decoder bwd: T must be > 1");
+  bool wgrads_done = false;
+  SideStream* ss = nullptr;
   if (g_decoder_fast && dec_fast_supported(d)) {
     ZTRY(dec_fast_pack_bwd(d, P, w, s));
-    ZTRY(dec_fast_bwd_steps(d, P, st, w, gaze, pose, rpos, rrot, dpose, drpos, drrot, s));
+    // The sweep is a chain of small dependent launches that leaves most of the chip idle; the weight-gradient
+    // GEMMs of the steps already swept run beside it on a low-priority stream, chunk by chunk.
+    const int nch = g_bwd_chunks < T - 1 ? g_bwd_chunks : T - 1;
+    if (nch > 1) ZTRY(side_stream(&ss));
+    for (int c = 0; c < nch; ++c) {
+      const int t_hi = T - 1 - (int)((long)(T - 1) * c / nch), t_lo = T - (int)((long)(T - 1) * (c + 1) / nch);
+      ZTRY(dec_fast_bwd_steps(d, P, st, w, gaze, pose, rpos, rrot, dpose, drpos, drrot, t_hi, t_lo, s));
+      if (nch > 1) {
+        ZCHECK(hipEventRecord(ss->chunk, s) == hipSuccess, "hipEventRecord failed");
+        ZCHECK(hipStreamWaitEvent(ss->s, ss->chunk, 0) == hipSuccess, "hipStreamWaitEvent failed");
+        ZTRY(dec_recurrent_wgrads(d, w, G, t_lo, t_hi, c == 0 ? 0.f : 1.f, ss->s));
+      }
+    }
+    if (nch > 1) {
+      ZCHECK(hipEventRecord(ss->done, ss->s) == hipSuccess, "hipEventRecord failed");
+      wgrads_done = true;
+    }
   } else {
   for (int t = T - 1; t >= 1; --t) {
     const float* gin = w.Gin + t * sG;
@@ -389,24 +451,7 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   }
   }
   // ---- CellStateEncoder backward: dH0c / dH1c are the grads wrt its two output halves
-  if (T > 1) {
-    // weight grads of the recurrent part: contraction over the flattened (t,b) axis, t = 1..T-1
-    const int M = (T - 1) * B;
-    ZTRY(gemm_tn(w.DY + (long)B * POL, POL, w.H1 + sH, H, G->l2_w, H, M, d.PO, H, 0.f, s));
-    ZTRY(k_colsum(G->l2_b, w.DY + (long)B * POL, M, d.PO, POL, 0.f, s));
-    ZTRY(gemm_tn(w.DI1 + s3, 3 * H, w.H0 + sH, H, G->w_ih1, H, M, 3 * H, H, 0.f, s));
-    ZTRY(gemm_tn(w.DH1 + s3, 3 * H, w.H1, H, G->w_hh1, H, M, 3 * H, H, 0.f, s));
-    ZTRY(k_colsum(G->b_ih1, w.DI1 + s3, M, 3 * H, 3 * H, 0.f, s));
-    ZTRY(k_colsum(G->b_hh1, w.DH1 + s3, M, 3 * H, 3 * H, 0.f, s));
-    ZTRY(gemm_tn(w.DI0 + s3, 3 * H, w.Gin + sG, GL, G->w_ih0, H + XD, M, 3 * H, H + XD, 0.f, s));
-    ZTRY(gemm_tn(w.DH0 + s3, 3 * H, w.H0, H, G->w_hh0, H, M, 3 * H, H, 0.f, s));
-    ZTRY(k_colsum(G->b_ih0, w.DI0 + s3, M, 3 * H, 3 * H, 0.f, s));
-    ZTRY(k_colsum(G->b_hh0, w.DH0 + s3, M, 3 * H, 3 * H, 0.f, s));
-    ZTRY(gemm_tn(w.D0 + sH, H, w.Gin + sG + H, GL, G->l0_w, XD, M, H, XD, 0.f, s));
-    ZTRY(k_colsum(G->l0_b, w.D0 + sH, M, H, H, 0.f, s));
-  } else {
-    ZCHECK(false, "decoder bwd: T must be > 1");
-  }
+  if (!wgrads_done) ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, s));
   {
     // out = [H0_init | H1_init] = cse_b W2^T + b2
     ZTRY(gemm_tn(w.dH0c, H, w.cse_b, H, G->c2_w, H, B, H, H, 0.f, s));
@@ -430,5 +475,6 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
                      dstyle);
   hipLaunchKernelGGL(add_style0_grad_k, g1((long)B * d.ST), dim3(256), 0, s, d, w.t1, dstyle);
   ZLAUNCH_CHECK("dec_bwd_tail");
+  if (wgrads_done) ZCHECK(hipStreamWaitEvent(s, ss->done, 0) == hipSuccess, "hipStreamWaitEvent failed");   // join
   return 0;
 }

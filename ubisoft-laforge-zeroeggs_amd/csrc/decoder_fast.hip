@@ -20,6 +20,7 @@
 // Backward uses the transposed packs (16 output units x contraction over gate rows).
 #include "decoder_ws.h"
 #include "dec_math.h"
+#include "gemm.h"
 #include "kernels.h"
 
 int g_stage_variant = 0;
@@ -28,7 +29,7 @@ namespace {
 
 enum { V_NOX = 1, V_NOW = 2, V_NOEPI = 4, V_NOMFMA = 8, V_ROT = 16 };
 
-enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_STORE_ACC, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX };
+enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_HID_MERGED, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX };
 
 struct Seg {
   const float* w;   // packed weights  [tile][kb][64][4]
@@ -36,6 +37,7 @@ struct Seg {
   int kb, acc;
   const float* xc;  // GEMV mode (batch <= 4, inference): the same activations in canonical row-major form
   int ldx;
+  int fixed;        // 1: every workgroup streams weight tile 0 of this pack (the root columns of layer2)
 };
 struct Grp {
   Seg seg[3];
@@ -55,6 +57,8 @@ struct StageArgs {
   float* carry;                            // [B,8] root-state gradient carry
   int variant;                             // ablation switches (tools/stage_bench.py); 0 in production
   int gemv;                                // 1: tiny-batch decode, VALU dot products over canonical activations
+  // speech/style columns of x_{t+1}, staged by the GRU layer-1 launch (all null: nothing to stage)
+  float *cf_gin, *cf_x, *cf_cond;
 };
 
 // column permutation of the dX stage: tile 0 holds root_vel/vrt (0..5) AND the gaze columns (PO..PO+2)
@@ -75,7 +79,10 @@ __device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* 
   // Software pipeline with two register buffers: the loads of group g+1 are in flight while group g feeds the
   // matrix cores.  The steady-state loop is branch-free (the look-ahead index is clamped, a redundant reload of
   // the last group is cheaper than a branch that would force s_waitcnt vmcnt(0)).
-  constexpr int U = 2;
+#ifndef ZEGGS_U
+#define ZEGGS_U 2
+#endif
+  constexpr int U = ZEGGS_U;
   const int n = hi - lo, ng = n / U;
   f4 w0[U], x0[U][NB], w1[U], x1[U][NB];
 #define ZLOAD(W, X, G)                                                                         \
@@ -156,6 +163,24 @@ __device__ void root_bwd(const ZeggsDecDims& d, const ZeggsDecStats& st, int b, 
   cr[5] = dq1.y + dqy.y + dq2.y; cr[6] = dq1.z + dqy.z + dq2.z;
 }
 
+// root integration of frame t from the de-normalised root velocities p6 (reference: devectorize_output,
+// ZEGGS/modules.py:139-176) and, when a next step exists, the normalised gaze direction of x_{t+1}.
+// rt = [rrot_{t-1}(4) | rpos_{t-1}(3) | gaze_{t+1}(3)]
+__device__ __forceinline__ void root_step(const ZeggsDecDims& d, const ZeggsDecStats& st, const float (&rt)[10],
+                                          const float (&p)[6], bool next, V3& npos, Q4& nq, float (&genc)[3]) {
+  const Q4 q = Q4{rt[0], rt[1], rt[2], rt[3]};
+  const V3 pos = v3(rt[4], rt[5], rt[6]);
+  npos = quat_mul_vec(q, d.dt * v3(p[0], p[1], p[2])) + pos;
+  const V3 uu = quat_mul_vec(q, d.dt * v3(p[3], p[4], p[5]));
+  nq = quat_mul(quat_exp(0.5f * uu), q);
+  if (next) {
+    const V3 gd = quat_mul_vec(quat_inv(nq), v3(rt[7], rt[8], rt[9]) - npos);
+    genc[0] = (gd.x - st.in_mean[d.PO]) / st.in_std[d.PO];
+    genc[1] = (gd.y - st.in_mean[d.PO + 1]) / st.in_std[d.PO + 1];
+    genc[2] = (gd.z - st.in_mean[d.PO + 2]) / st.in_std[d.PO + 2];
+  }
+}
+
 template <int NB, int FAM, int WAVES, int BV = 0>   // FAM 0: forward epilogues, 1: backward; BV > 0: GEMV mode for BV rows
 __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
   constexpr int NTHR = WAVES * 64;
@@ -218,6 +243,21 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         }
       }
     } break;
+    case EPI_HID_MERGED: if constexpr (FAM == 0) {
+      const int col = tile * 16 + ev;
+      eact = tid < 16 * BP && eb < B && col < H;
+      if (eact) {
+        const float* wgz = G.p1 + (long)col * a.XD + PO;     // gaze columns of layer0
+        pre[0] = G.p0[col]; pre[1] = wgz[0]; pre[2] = wgz[1]; pre[3] = wgz[2];
+      }
+      if (tid < BP && eb < B) {
+        const float* rq = a.rrot + ((long)eb * d.T + t - 1) * 4;
+        const float* rp = a.rpos + ((long)eb * d.T + t - 1) * 3;
+        const float* gz = a.gaze + ((long)eb * d.T + t + 1) * 3;
+        rt[0] = rq[0]; rt[1] = rq[1]; rt[2] = rq[2]; rt[3] = rq[3]; rt[4] = rp[0]; rt[5] = rp[1]; rt[6] = rp[2];
+        rt[7] = gz[0]; rt[8] = gz[1]; rt[9] = gz[2];
+      }
+    } break;
     case EPI_GRU_BWD: if constexpr (FAM == 1) {
       const int U = tile * 16 + ev;
       eact = tid < 16 * BP && eb < B && U < H;
@@ -249,13 +289,6 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
     } break;
   }
 
-  // hidden-side pre-activations computed by an earlier launch (accumulator-fragment layout)
-  f4 pre4 = f4{0.f, 0.f, 0.f, 0.f};
-  if (G.epi == EPI_GRU_FWD && G.p3 && tid >= NB * 64 && tid < 2 * NB * 64) {
-    const int r = tid - NB * 64;
-    pre4 = ((const f4*)G.p3)[((long)tile * LNB + nb0 + r / 64) * 64 + (r % 64)];
-  }
-
   if constexpr (BV > 0) {
     // ---- GEMV mode: batch <= 4 (autoregressive decode).  No MFMA padding to 16 batch rows: each lane owns
     // (column i, k-quarter) of the weight fragment and multiplies it with the matching float4 of every batch row
@@ -274,7 +307,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       const int lo = (b0 > base ? b0 : base) - base;
       const int hi = (b1 < base + kbs ? b1 : base + kbs) - base;
       if (lo < hi) {
-        const f4* wp = (const f4*)G.seg[s].w + ((long)tile * kbs) * 64 + lane;
+        const f4* wp = (const f4*)G.seg[s].w + ((long)(G.seg[s].fixed ? 0 : tile) * kbs) * 64 + lane;
         const float* xc = G.seg[s].xc + 4 * (lane >> 4);
         const int ldx = G.seg[s].ldx;
         float part[BV];
@@ -347,7 +380,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       const int lo = (b0 > base ? b0 : base) - base;
       const int hi = (b1 < base + kbs ? b1 : base + kbs) - base;
       if (lo < hi) {
-        const f4* wp = (const f4*)G.seg[s].w + ((long)tile * kbs) * 64 + lane;
+        const f4* wp = (const f4*)G.seg[s].w + ((long)(G.seg[s].fixed ? 0 : tile) * kbs) * 64 + lane;
         const f4* xp = (const f4*)G.seg[s].x + nb0 * 64 + lane;
         if (G.seg[s].acc == 0) run_blocks<NB>(wp, xp, lo, hi, acc[0], LNB);
         else run_blocks<NB>(wp, xp, lo, hi, acc[1], LNB);
@@ -364,7 +397,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       f4 s = red[0][i][nb][l];
   #pragma unroll
       for (int w = 1; w < WAVES; ++w) s += red[w][i][nb][l];
-      fin[i][nb][l] = s + pre4;
+      fin[i][nb][l] = s;
     }
     __syncthreads();
 }
@@ -400,6 +433,17 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         if (G.o1) G.o1[xf_index(b, U, LNB)] = h;
         if (G.o2) { G.o2[i] = r; G.o3[i] = z; G.o4[i] = nn; G.o5[i] = nh; }
       }
+      if (a.cf_gin || a.cf_x || a.cf_cond) {   // speech / style columns of x_{t+1} (inputs: independent of this step)
+        const int XC = d.SP + d.ST;
+        for (int e = blockIdx.x * NTHR + tid; e < B * XC; e += gridDim.x * NTHR) {
+          const int b = e / XC, c = e % XC;
+          const float val = c < d.SP ? a.speech[((long)b * d.T + t + 1) * d.SP + c]
+                                     : a.style[((long)b * d.T + t + 1) * d.ST + (c - d.SP)];
+          if (a.cf_gin) a.cf_gin[(long)b * a.GL + H + d.PI + c] = val;
+          if (a.cf_x) a.cf_x[xf_index(b, d.PI + c, LNB)] = val;
+          if (a.cf_cond) a.cf_cond[xf_index(b, c, LNB)] = val;
+        }
+      }
     } break;
     case EPI_OUT_FWD: if constexpr (FAM == 0) {   // y = W2 h1 + b2 -> pose[t], root integration, x_{t+1}
       float* gnext = G.o0;
@@ -415,42 +459,38 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
           if (xnext) xnext[xf_index(b, col, LNB)] = e;
         }
       }
-      if (next) {   // speech / style columns of x_{t+1}
-        const int XC = d.SP + d.ST;
-        for (int e = wg * NTHR + tid; e < B * XC; e += G.tiles * nsplit * NTHR) {
-          const int b = e / XC, c = e % XC;
-          const float val = c < d.SP ? a.speech[((long)b * d.T + t + 1) * d.SP + c]
-                                     : a.style[((long)b * d.T + t + 1) * d.ST + (c - d.SP)];
-          if (gnext) gnext[(long)b * a.GL + H + d.PI + c] = val;
-          if (xnext) xnext[xf_index(b, d.PI + c, LNB)] = val;
-        }
-      }
       if (root) {
         const int b = eb;
-        float p[6];
+        float p[6], genc[3];
         for (int c = 0; c < 6; ++c) p[c] = (FV(0, c, b) + G.p0[c]) * a.st.out_std[c] + a.st.out_mean[c];
-        Q4 q = Q4{rt[0], rt[1], rt[2], rt[3]};
-        V3 pos = v3(rt[4], rt[5], rt[6]);
-        V3 npos = quat_mul_vec(q, d.dt * v3(p[0], p[1], p[2])) + pos;
-        V3 uu = quat_mul_vec(q, d.dt * v3(p[3], p[4], p[5]));
-        Q4 nq = quat_mul(quat_exp(0.5f * uu), q);
+        V3 npos; Q4 nq;
+        root_step(d, a.st, rt, p, next, npos, nq, genc);
         float* op = a.rpos + ((long)b * d.T + t) * 3; op[0] = npos.x; op[1] = npos.y; op[2] = npos.z;
         float* oq = a.rrot + ((long)b * d.T + t) * 4; oq[0] = nq.w; oq[1] = nq.x; oq[2] = nq.y; oq[3] = nq.z;
         if (next) {
-          V3 gd = quat_mul_vec(quat_inv(nq), v3(rt[7], rt[8], rt[9]) - npos);
-          const float gv[3] = {gd.x, gd.y, gd.z};
           for (int k = 0; k < 3; ++k) {
-            const float e = (gv[k] - a.st.in_mean[PO + k]) / a.st.in_std[PO + k];
-            if (gnext) gnext[(long)b * a.GL + H + PO + k] = e;
-            if (xnext) xnext[xf_index(b, PO + k, LNB)] = e;
+            if (gnext) gnext[(long)b * a.GL + H + PO + k] = genc[k];
+            if (xnext) xnext[xf_index(b, PO + k, LNB)] = genc[k];
           }
         }
       }
     } break;
-    case EPI_STORE_ACC: if constexpr (FAM == 0) {   // side product W_hh h for the NEXT GRU launch: keep the raw accumulators
-      if (tid < NB * 64) {
-        const int nb = tid / 64, l = tid % 64;
-        ((f4*)G.o0)[((long)tile * LNB + nb0 + nb) * 64 + l] = fin[0][nb][l];
+    case EPI_HID_MERGED: if constexpr (FAM == 0) {   // hid_{t+1} = ELU(M h1 + Wc cond + cvec + W0[:, gaze] genc)
+      float* gsh = (float*)red;                       // [BP][3] normalised gaze direction of x_{t+1}
+      if (tid < BP && eb < B) {
+        float p[6], genc[3];
+        for (int c = 0; c < 6; ++c) p[c] = (FV(1, c, eb) + G.p2[c]) * a.st.out_std[c] + a.st.out_mean[c];
+        V3 npos; Q4 nq;
+        root_step(d, a.st, rt, p, true, npos, nq, genc);
+        gsh[ebl * 3] = genc[0]; gsh[ebl * 3 + 1] = genc[1]; gsh[ebl * 3 + 2] = genc[2];
+      }
+      __syncthreads();
+      if (eact) {
+        const int col = tile * 16 + ev;
+        const float pa = FV(0, ev, eb) + pre[0] + pre[1] * gsh[ebl * 3] + pre[2] * gsh[ebl * 3 + 1] + pre[3] * gsh[ebl * 3 + 2];
+        const float val = d_elu(pa);
+        G.o0[(long)eb * a.GL + col] = val;
+        if (G.o1) G.o1[xf_index(eb, col, LNB)] = val;
       }
     } break;
     case EPI_GRU_BWD: if constexpr (FAM == 1) {   // dh = W^T delta + carry -> gate gradients of this layer
@@ -645,8 +685,20 @@ int launch_stage(const StageArgs& a, hipStream_t s) {
   return a.g[0].epi >= EPI_GRU_BWD ? launch_stage_f<1>(a, s) : launch_stage_f<0>(a, s);   // enum order: fwd < bwd
 }
 
-inline Seg seg(const float* w, const float* x, int kb, int acc, const float* xc = nullptr, int ldx = 0) {
-  return Seg{w, x, kb, acc, xc, ldx};
+inline Seg seg(const float* w, const float* x, int kb, int acc, const float* xc = nullptr, int ldx = 0, int fixed = 0) {
+  return Seg{w, x, kb, acc, xc, ldx, fixed};
+}
+
+// W0s = W0[:, :PO] diag(sigma_o / sigma_i) (zero padded to POL columns); v = (b2 sigma_o + mu_o - mu_i) / sigma_i
+__global__ void merge_prep_k(float* W0s, float* vvec, const float* W0, const float* b2, ZeggsDecStats st, int H, int PO,
+                             int POL, int XD) {
+  const long n = (long)H * POL;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % POL);
+    const long r = i / POL;
+    W0s[i] = c < PO ? W0[r * XD + c] * (st.out_std[c] / st.in_std[c]) : 0.f;
+    if (r == 0) vvec[c] = c < PO ? (b2[c] * st.out_std[c] + st.out_mean[c] - st.in_mean[c]) / st.in_std[c] : 0.f;
+  }
 }
 
 StageArgs base_args(const ZeggsDecDims& d, const ZeggsDecStats* st, const DecWs& w) {
@@ -669,6 +721,23 @@ int dec_fast_pack_fwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, 
   ZTRY(pack(w.pw_ih1, P->w_ih1, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s));
   ZTRY(pack(w.pw_hh1, P->w_hh1, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s));
   ZTRY(pack(w.pw_l2, P->l2_w, w.nTPO, w.KBH, 0, H, d.PO, H, d.PO, H, 0, s));
+  return 0;
+}
+
+// operands of the merged stage (layer2 of step t folded into layer0 of step t+1): between the two layers the
+// reference only de-normalises / re-normalises the pose columns (ZEGGS/modules.py:60-76), which is affine, so
+//   W0 x_{t+1} + b0 = M h1_t + Wc cond_{t+1} + W0[:, gaze] g_{t+1} + cvec
+// with M = W0[:, :PO] diag(sigma_o/sigma_i) W2.  Only the 3 gaze columns depend on the (non-linear) root integration.
+int dec_fast_pack_merged(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s) {
+  const int H = d.H, XD = w.XD;
+  const long n = (long)H * w.POL;
+  hipLaunchKernelGGL(merge_prep_k, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, w.W0s,
+                     w.vvec, P->l0_w, P->l2_b, *st, H, d.PO, w.POL, XD);
+  ZLAUNCH_CHECK("merge_prep");
+  ZTRY(gemm_nn(w.W0s, w.POL, P->l2_w, H, w.Mc, H, H, d.PO, H, 0.f, s));
+  ZTRY(gemm_nt(w.vvec, w.POL, P->l0_w, XD, w.cvec, H, P->l0_b, 1, H, d.PO, ACT_NONE, 0.f, s));
+  ZTRY(pack(w.pw_m, w.Mc, w.nTH, w.KBH, 0, H, H, H, d.PO, H, 0, s));
+  ZTRY(pack(w.pw_c, P->l0_w, w.nTH, w.KBC, 0, d.SP + d.ST, H, H, d.PO, XD, d.PI, s));
   return 0;
 }
 
@@ -704,69 +773,70 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   conv(H1xf[0], w.H1 + cs(0) * sH, H, 0, H);
   conv(Xxf[1], w.Gin + cs(1) * sG, w.GL, H, w.XD);
   ZLAUNCH_CHECK("to_xfrag");
-  const bool reb = (g_stage_variant & 256) != 0;   // hidden-side products in the S1/S4 launches (measured: no gain)
-  if (reb) {
-    StageArgs a = base_args(d, st, w);
-    a.t = 0;
-    a.g[0] = Grp{}; a.g[1] = Grp{};
-    a.g[0].seg[0] = seg(w.pw_hh0, H0xf[0], w.KBH, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_STORE_ACC;
-    a.g[0].o0 = w.GH0;
-    a.g[1].seg[0] = seg(w.pw_hh1, H1xf[0], w.KBH, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nT5; a.g[1].epi = EPI_STORE_ACC;
-    a.g[1].o0 = w.GH1;
-    ZTRY(launch_stage(a, s));
-  }
   // tiny-batch decode (B <= 4, no_grad): GEMV stage kernels over the canonical activations (decoder.hip zero-fills
   // the Gin ring first: the pad columns of x are read against zero weights and must be finite)
   const bool gemv = !training && B <= 4 && !(g_stage_variant & 1024);
+  // 3 launches per step: layer2 of step t and layer0 of step t+1 run in ONE launch (variant 4096: 4 launches)
+  const bool merged = !(g_stage_variant & 4096);
+  if (merged && T > 2) ZTRY(dec_fast_pack_merged(d, P, st, w, s));
   for (int t = 1; t < T; ++t) {
     const int c = t & 1, p = (t - 1) & 1;
     const long o = (long)t * sH;
+    const bool next = t + 1 < T;
     StageArgs a = base_args(d, st, w);
     a.t = t; a.gaze = gaze; a.speech = speech; a.style = style; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
     a.gemv = gemv;
     const float* gin_c = w.Gin + cs(t) * sG;
+    float* gin_n = w.Gin + cs(t + 1) * sG;
     const float *h0p = w.H0 + cs(t - 1) * sH, *h1p = w.H1 + cs(t - 1) * sH;
     float *h0c = w.H0 + cs(t) * sH, *h1c = w.H1 + cs(t) * sH;
-    // S1: hid = ELU(W0 x + b0)    [+ optional side: GH0 = W_hh0 h0[t-1]]
-    a.g[0] = Grp{}; a.g[1] = Grp{};
-    a.g[0].seg[0] = seg(w.pw_l0, Xxf[c], w.KBX, 0, gin_c + H, w.GL); a.g[0].nseg = 1; a.g[0].tiles = w.nTH;
-    a.g[0].epi = EPI_ELU_HID;
-    a.g[0].p0 = P->l0_b; a.g[0].o0 = w.Gin + cs(t) * sG; a.g[0].o1 = gemv ? nullptr : w.HIDxf;
-    if (reb && t > 1) {
-      a.g[1].seg[0] = seg(w.pw_hh0, H0xf[p], w.KBH, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nT5; a.g[1].epi = EPI_STORE_ACC;
-      a.g[1].o0 = w.GH0;
+    if (t == 1 || !merged) {
+      // S1: hid = ELU(W0 x + b0)
+      a.g[0] = Grp{}; a.g[1] = Grp{};
+      a.g[0].seg[0] = seg(w.pw_l0, Xxf[c], w.KBX, 0, gin_c + H, w.GL); a.g[0].nseg = 1; a.g[0].tiles = w.nTH;
+      a.g[0].epi = EPI_ELU_HID;
+      a.g[0].p0 = P->l0_b; a.g[0].o0 = w.Gin + cs(t) * sG; a.g[0].o1 = gemv ? nullptr : w.HIDxf;
+      ZTRY(launch_stage(a, s));
     }
-    ZTRY(launch_stage(a, s));
     // S2: GRU layer 0
     a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pw_ih0h, w.HIDxf, w.KBH, 0, gin_c, w.GL);
     a.g[0].seg[1] = seg(w.pw_ih0x, Xxf[c], w.KBX, 0, gin_c + H, w.GL);
-    a.g[0].nseg = 2; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
+    a.g[0].seg[2] = seg(w.pw_hh0, H0xf[p], w.KBH, 1, h0p, H);
+    a.g[0].nseg = 3; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
     a.g[0].p0 = P->b_ih0; a.g[0].p1 = P->b_hh0; a.g[0].p2 = h0p;
-    if (reb) a.g[0].p3 = w.GH0;
-    else { a.g[0].seg[2] = seg(w.pw_hh0, H0xf[p], w.KBH, 1, h0p, H); a.g[0].nseg = 3; }
     a.g[0].o0 = h0c; a.g[0].o1 = gemv ? nullptr : H0xf[c];
     if (training) { a.g[0].o2 = w.R0 + o; a.g[0].o3 = w.Z0 + o; a.g[0].o4 = w.N0 + o; a.g[0].o5 = w.NH0 + o; }
     ZTRY(launch_stage(a, s));
-    // S3: GRU layer 1
+    // S3: GRU layer 1 (+ stages the speech/style columns of x_{t+1}: ring slots last read one step ago)
     a.g[0] = Grp{};
-    a.g[0].seg[0] = seg(w.pw_ih1, H0xf[c], w.KBH, 0, h0c, H); a.g[0].nseg = 1; a.g[0].tiles = w.nT5;
-    a.g[0].epi = EPI_GRU_FWD;
+    a.g[0].seg[0] = seg(w.pw_ih1, H0xf[c], w.KBH, 0, h0c, H);
+    a.g[0].seg[1] = seg(w.pw_hh1, H1xf[p], w.KBH, 1, h1p, H);
+    a.g[0].nseg = 2; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
     a.g[0].p0 = P->b_ih1; a.g[0].p1 = P->b_hh1; a.g[0].p2 = h1p;
-    if (reb) a.g[0].p3 = w.GH1;
-    else { a.g[0].seg[1] = seg(w.pw_hh1, H1xf[p], w.KBH, 1, h1p, H); a.g[0].nseg = 2; }
     a.g[0].o0 = h1c; a.g[0].o1 = gemv ? nullptr : H1xf[c];
     if (training) { a.g[0].o2 = w.R1 + o; a.g[0].o3 = w.Z1 + o; a.g[0].o4 = w.N1 + o; a.g[0].o5 = w.NH1 + o; }
+    if (next) {
+      a.cf_gin = training ? nullptr : gin_n;            // training: filled for every t by dec_fill_cond_k
+      a.cf_x = gemv ? nullptr : Xxf[(t + 1) & 1];
+      a.cf_cond = (gemv || !merged) ? nullptr : w.CONDxf;
+    }
     ZTRY(launch_stage(a, s));
-    // S4: output projection + pose integration + x_{t+1}   [+ optional side: GH1 = W_hh1 h1[t]]
+    a.cf_gin = a.cf_x = a.cf_cond = nullptr;
+    // S4: y = W2 h1 + b2 -> pose[t], root integration, pose/gaze columns of x_{t+1}
+    //     [merged: + hid_{t+1} = ELU(M h1 + Wc cond_{t+1} + W0[:, gaze] g_{t+1} + cvec) in the same launch]
     a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pw_l2, H1xf[c], w.KBH, 0, h1c, H); a.g[0].nseg = 1; a.g[0].tiles = w.nTPO;
     a.g[0].epi = EPI_OUT_FWD;
-    a.g[0].p0 = P->l2_b; a.g[0].o0 = (t + 1 < T) ? w.Gin + cs(t + 1) * sG : nullptr;
+    a.g[0].p0 = P->l2_b; a.g[0].o0 = next ? gin_n : nullptr;
     a.g[0].o1 = gemv ? nullptr : Xxf[(t + 1) & 1];
-    if (reb && t + 1 < T) {
-      a.g[1].seg[0] = seg(w.pw_hh1, H1xf[c], w.KBH, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nT5; a.g[1].epi = EPI_STORE_ACC;
-      a.g[1].o0 = w.GH1;
+    if (merged && next) {
+      a.g[1].seg[0] = seg(w.pw_m, H1xf[c], w.KBH, 0, h1c, H);
+      a.g[1].seg[1] = seg(w.pw_c, w.CONDxf, w.KBC, 0, gin_n + H + d.PI, w.GL);
+      a.g[1].seg[2] = seg(w.pw_l2, H1xf[c], w.KBH, 1, h1c, H, 1);
+      a.g[1].nseg = 3; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_HID_MERGED;
+      a.g[1].p0 = w.cvec; a.g[1].p1 = P->l0_w; a.g[1].p2 = P->l2_b;
+      a.g[1].o0 = gin_n; a.g[1].o1 = gemv ? nullptr : w.HIDxf;
     }
     ZTRY(launch_stage(a, s));
   }
@@ -775,15 +845,17 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
 
 int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w,
                        const float* gaze, const float* pose, const float* rpos, const float* rrot,
-                       const float* dpose, const float* drpos, const float* drrot, hipStream_t s) {
+                       const float* dpose, const float* drpos, const float* drrot, int t_hi, int t_lo, hipStream_t s) {
   const int B = d.B, T = d.T, H = d.H, NB = w.NB;
   const long sG = (long)B * w.GL, sH = (long)B * H, s3 = 3 * sH;
-  ZTRY(k_fill(w.xf_base_bwd, (long)(w.xf_bytes_bwd / 4), 0.f, s));
   if (T < 2) return 0;
-  hipLaunchKernelGGL(dy_last_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, gaze, pose, rpos, rrot, w.carry,
-                     w.DY + (long)(T - 1) * B * w.POL, w.POL, w.DYxf, NB);
-  ZLAUNCH_CHECK("dy_last");
-  for (int t = T - 1; t >= 1; --t) {
+  if (t_hi == T - 1) {   // first chunk of the sweep
+    ZTRY(k_fill(w.xf_base_bwd, (long)(w.xf_bytes_bwd / 4), 0.f, s));
+    hipLaunchKernelGGL(dy_last_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, gaze, pose, rpos, rrot, w.carry,
+                       w.DY + (long)(T - 1) * B * w.POL, w.POL, w.DYxf, NB);
+    ZLAUNCH_CHECK("dy_last");
+  }
+  for (int t = t_hi; t >= t_lo; --t) {
     const long o = (long)t * sH;
     StageArgs a = base_args(d, st, w);
     a.t = t; a.gaze = gaze; a.cpose = pose; a.crpos = rpos; a.crrot = rrot; a.dpose = dpose; a.drpos = drpos;

@@ -19,7 +19,9 @@ struct DecWs {
   float *pw_l0, *pw_ih0h, *pw_ih0x, *pw_hh0, *pw_ih1, *pw_hh1, *pw_l2;   // forward packs
   float *pb_l2, *pb_ih1, *pb_hh1, *pb_ih0, *pb_hh0, *pb_l0;              // backward (transposed) packs
   float *Xxf, *HIDxf, *H0xf, *H1xf;                                      // forward activation fragments (rings of 2)
-  float *GH0, *GH1;                                                      // hidden-side GRU pre-activations W_hh h (accumulator fragments)
+  // merged layer2 -> layer0 stage: M = W0[:, :PO] diag(sigma_o / sigma_i) W2, Wc = W0[:, PI:], cvec = b0 + W0[:, :PO] v
+  int KBC;
+  float *W0s, *Mc, *vvec, *cvec, *pw_m, *pw_c, *CONDxf;
   float *DYxf, *DI1xf, *DH1xf, *DI0xf, *DH0xf, *D0xf, *dXa;               // backward fragments
   size_t xf_bytes_fwd, xf_bytes_bwd;
   float *xf_base_fwd, *xf_base_bwd;
@@ -68,11 +70,15 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
   w.pw_ih1 = a.f((long)w.nT5 * w.KBH * BLK);
   w.pw_hh1 = a.f((long)w.nT5 * w.KBH * BLK);
   w.pw_l2 = a.f((long)w.nTPO * w.KBH * BLK);
+  w.KBC = (d.SP + d.ST + 15) / 16;
+  w.pw_m = a.f((long)w.nTH * w.KBH * BLK);
+  w.pw_c = a.f((long)w.nTH * w.KBC * BLK);
+  w.W0s = a.f(H * (long)w.POL); w.Mc = a.f(H * H); w.vvec = a.f(w.POL); w.cvec = a.f(H);
   const long XB = 256L * w.NB;  // floats per k-block of an activation fragment
   {
     size_t o0 = a.off;
     w.Xxf = a.f(2 * w.KBX * XB); w.HIDxf = a.f(w.KBH * XB); w.H0xf = a.f(2 * w.KBH * XB); w.H1xf = a.f(2 * w.KBH * XB);
-    w.GH0 = a.f((long)w.nT5 * XB); w.GH1 = a.f((long)w.nT5 * XB);
+    w.CONDxf = a.f(w.KBC * XB);
     w.xf_base_fwd = w.Xxf;
     w.xf_bytes_fwd = a.off - align_up(o0, 256);
   }
@@ -102,4 +108,4 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
                        float* rrot, int training, hipStream_t s);
 int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w,
                        const float* gaze, const float* pose, const float* rpos, const float* rrot,
-                       const float* dpose, const float* drpos, const float* drrot, hipStream_t s);
+                       const float* dpose, const float* drpos, const float* drrot, int t_hi, int t_lo, hipStream_t s);

@@ -229,15 +229,15 @@ int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   const long tiles = big ? (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nbatch : (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nbatch;
   const long ktiles = (long)cdiv(g.K, 16) * g.kbatch;
   // few output tiles but a long contraction (weight gradients): split K over workgroups, combine with fp32 atomics
-  const bool can_split = nbatch == 1 && g.beta == 0.f && g.bias == nullptr && g.act == ACT_NONE && g.scn == 1 &&
-                         g.scm == g.N && ktiles >= 64;
+  const bool can_split = nbatch == 1 && (g.beta == 0.f || g.beta == 1.f) && g.bias == nullptr && g.act == ACT_NONE &&
+                         g.scn == 1 && g.scm == g.N && ktiles >= 64;
   if (tiles < g_gemm_wg_target * 5 / 6 && can_split) {        // aim at ~3 workgroups per CU (one wave per SIMD each)
     long sk = (g_gemm_wg_target + tiles - 1) / tiles;
     if (sk > ktiles / 16) sk = ktiles / 16;
     if (sk > 32) sk = 32;
     if (sk > 1) {
       g.splitk = (int)sk;
-      ZTRY(k_fill(g.C, (long)g.M * g.N, 0.f, s));
+      if (g.beta == 0.f) ZTRY(k_fill(g.C, (long)g.M * g.N, 0.f, s));   // beta == 1: the atomics accumulate onto C
     }
   }
   if (big && (tiles * g.splitk >= 128 || g.splitk > 1)) return launch_cfg<128, 128, 2, 2>(g, nbatch, s);

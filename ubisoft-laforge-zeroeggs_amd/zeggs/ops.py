@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 _LIB = None
-_LIB_PATH = Path(__file__).resolve().parent / "libzeggs_hip.so"
+_LIB_PATH = Path(os.environ.get("ZEGGS_LIB") or Path(__file__).resolve().parent / "libzeggs_hip.so")   # ZEGGS_LIB: A/B builds
 c_f = C.c_void_p  # device pointers are passed as raw addresses
 
 
@@ -71,6 +71,11 @@ def lib():
               "zeggs_decoder_workspace_bytes", "zeggs_loss_workspace_bytes"):
         getattr(L, n).restype = C.c_size_t
     _LIB = L
+    # tuning switches for experiments, e.g. ZEGGS_OPTIONS="bwd_chunks=4,stage_variant=0" (see zeggs_set_option)
+    for kv in filter(None, os.environ.get("ZEGGS_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        if L.zeggs_set_option(k.strip().encode(), int(v)) != 0:
+            raise RuntimeError(f"ZEGGS_OPTIONS: {L.zeggs_last_error().decode()}")
     return L
 
 
