@@ -186,6 +186,39 @@ int zeggs_mel_features(const ZeggsMelDims*, const float* wav, long n_samples, co
 int zeggs_normalize_rows(float* x, long rows, int width, long ld, const float* mean, const float* stdv,
                          float std_scalar, void* stream);
 
+/* ---------------------------------------------------------------- animation pre-/post-processing (float64)
+ * zeggs_anim_features replaces preprocess_animation, ZEGGS/data_pipeline.py:90-228 (with quat.py from_euler /
+ * unroll / fk / between / to_helical / fk_vel): BVH channels of one clip -> the feature arrays consumed by
+ * generate_gesture (ZEGGS/generate.py:229-248, 339-362) and by the dataset builder.
+ *   euler_deg [N,J,3] channel order "zyx" (degrees), positions [N,J,3], parents int32 [J] (device, -1 = root);
+ *   hips / spine2 / head = joint indices of "Hips" / "Spine2" / "Head"; N >= 4.
+ * Outputs (device, caller-owned): float64 except the two-axis encodings ltxy / ctxy (float32, as the reference). */
+typedef struct {
+  int N, J, hips, spine2, head;
+  double dt;
+} ZeggsAnimDims;
+typedef struct {
+  double *root_pos, *root_rot, *root_vel, *root_vrt; /* [N,3] [N,4] [N,3] [N,3] */
+  double *lpos, *lrot, *lvel, *lvrt;                 /* [N,J,3] [N,J,4] [N,J,3] [N,J,3] */
+  float* ltxy;                                       /* [N,J,2,3] */
+  double *cpos, *crot, *cvel, *cvrt;                 /* character space (root-relative FK) */
+  float* ctxy;
+  double *gaze_pos, *gaze_dir;                       /* [N,3] */
+} ZeggsAnimOut;
+size_t zeggs_anim_features_workspace_bytes(const ZeggsAnimDims*);
+int zeggs_anim_features(const ZeggsAnimDims*, const int* parents, const double* euler_deg, const double* positions,
+                        const ZeggsAnimOut* out, void* ws, size_t ws_bytes, void* stream);
+
+/* decoder output -> BVH channels: replaces quat.from_xform(xform_orthogonalize_from_xy(V_ltxy)) of
+ * ZEGGS/generate.py:389 and write_bvh, ZEGGS/utils.py:47-87 (root re-basing, root folded into joint 0,
+ * quat.to_euler order "zyx" in degrees).  Inputs float32 [T,3] [T,4] [T,J,3] [T,J,2,3]; outputs float64 [T,J,3]. */
+typedef struct {
+  int T, J, rebase;            /* rebase != 0: start_position / start_rotation given */
+  double start_pos[3], start_rot[4];
+} ZeggsBvhDims;
+int zeggs_pose_to_bvh(const ZeggsBvhDims*, const float* root_pos, const float* root_rot, const float* lpos,
+                      const float* ltxy, double* positions, double* euler_deg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

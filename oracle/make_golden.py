@@ -267,6 +267,18 @@ def gold_generate(ref):
     ref.bvh.save(str(tmp / "ex.bvh"), clip)
     orig_load = torch.load
     torch.load = ref.torch_load
+    cap = {}                                   # decoder outputs as they enter the BVH conversion (generate.py:389-405)
+    orig_ortho, orig_write = ref.generate.xform_orthogonalize_from_xy, ref.generate.write_bvh
+
+    def ortho(xy):
+        cap["dec_ltxy"] = xy.detach().cpu().numpy()[0]
+        return orig_ortho(xy)
+
+    def write(fn, rp, rr, lp, lr, **kw):
+        cap.update(dec_root_pos=np.array(rp), dec_root_rot=np.array(rr), dec_lpos=np.array(lp), dec_lrot=np.array(lr))
+        return orig_write(fn, rp, rr, lp, lr, **kw)
+
+    ref.generate.xform_orthogonalize_from_xy, ref.generate.write_bvh = ortho, write
     try:
         enc = ref.generate.generate_gesture(tmp / "a.wav", [(tmp / "ex.bvh", None)], net, data, res,
                                             style_encoding_type="example", blend_type="add", blend_ratio=[1.0],
@@ -274,6 +286,7 @@ def gold_generate(ref):
                                             use_gpu=False, use_script=False)
     finally:
         torch.load = orig_load
+        ref.generate.xform_orthogonalize_from_xy, ref.generate.write_bvh = orig_ortho, orig_write
     out = ref.bvh.load(str(res / "out.bvh"))
     loaded = ref.bvh.load(str(tmp / "ex.bvh"))
     feats = ref.data_pipeline.preprocess_animation(ref.bvh.load(str(tmp / "ex.bvh")))
@@ -284,6 +297,7 @@ def gold_generate(ref):
              encoding=enc.numpy(), ex_rotations=loaded["rotations"], ex_positions=loaded["positions"],
              ex_parents=loaded["parents"], ex_offsets=loaded["offsets"])
     g.update({"feat_" + n: np.asarray(f) for n, f in zip(names, feats)})
+    g.update(cap)
     np.savez_compressed(GOLD / "generate.npz", **g)
     print("generate.npz frames", out["rotations"].shape)
 

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import helpers
+from oracle import anim as oanim
 from oracle import loss as oloss
 from oracle import nets as onets
 from oracle import radam as oradam
@@ -401,8 +402,8 @@ def test_generate_gesture_vs_reference(golden_dir, tmp_path):
     assert out["rotations"].shape == gd["out_rotations"].shape             # integer frame count: bit-exact
     assert (res / "out.wav").exists()
     # Euler angles in degrees as written with 6 decimals; compare as rotations to avoid +-180 wrap artefacts
-    qa = anim.q_from_euler(np.radians(out["rotations"].astype(np.float64)))
-    qb = anim.q_from_euler(np.radians(gd["out_rotations"].astype(np.float64)))
+    qa = oanim.q_from_euler(np.radians(out["rotations"].astype(np.float64)))
+    qb = oanim.q_from_euler(np.radians(gd["out_rotations"].astype(np.float64)))
     ang = 2 * np.degrees(np.arccos(np.clip(np.abs(np.sum(qa * qb, axis=-1)), 0, 1)))
     assert ang.max() < 2e-2, ang.max()                                      # < 0.02 degrees on every joint / frame
     np.testing.assert_allclose(out["positions"][:, 0], gd["out_positions"][:, 0], atol=2e-3)
@@ -507,3 +508,68 @@ def test_loss_is_zero_and_finite_when_prediction_equals_target():
     loss, terms = ops.training_loss(pose.clone().requires_grad_(True), tt("Y_root_pos"), tt("Y_root_rot"), pose,
                                     tt("Y_root_pos"), tt("Y_root_rot"), tt("Y_gaze_pos"), parents, synth.DT)
     assert float(loss) == 0.0 and float(terms[:18].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- animation kernels (csrc/anim.hip)
+FEAT_NAMES = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "lrot", "ltxy", "lvel", "lvrt", "cpos", "crot",
+              "ctxy", "cvel", "cvrt", "gaze_pos", "gaze_dir")
+
+
+def test_anim_features_vs_oracle_and_reference(golden_dir, tmp_path):
+    """exemplar BVH -> preprocess_animation on the device: float64 agreement with the NumPy oracle (1e-9) and with
+    the reference's own output (its float32 steps bound that comparison: 2e-4)"""
+    from zeggs import anim
+    gd = np.load(golden_dir / "generate.npz")
+    (tmp_path / "ex.bvh").write_bytes(gd["exemplar_bvh"].tobytes())
+    clip = anim.bvh_load(tmp_path / "ex.bvh")
+    dev = anim.preprocess_animation(clip, DEV)
+    ora = oanim.preprocess_animation(clip)
+    for n, a, b in zip(FEAT_NAMES, dev, ora):
+        tol = 1e-6 if a.dtype == torch.float32 else 1e-9
+        np.testing.assert_allclose(a.cpu().numpy(), np.asarray(b), atol=tol, rtol=tol, err_msg=n)
+        np.testing.assert_allclose(a.cpu().numpy(), gd["feat_" + n], atol=2e-4, rtol=1e-4, err_msg=n)
+
+
+@pytest.mark.parametrize("nframes", [4, 5, 257, 1000])
+def test_anim_features_sizes_and_median(nframes):
+    """odd / even frame counts exercise both np.median branches of the gaze target; long clips the sign unrolling
+    (rotations sweep through +-180 degrees so consecutive raw quaternions flip sign)"""
+    from zeggs import anim
+    clip = synth.make_bvh_clip(nframes, seed=nframes)
+    rng = np.random.default_rng(nframes)
+    clip["rotations"] = clip["rotations"].astype(np.float64)
+    clip["rotations"][:, 3:9, 0] += np.linspace(0, 900, nframes)[:, None] + rng.standard_normal((nframes, 6))
+    clip["rotations"] = (clip["rotations"] + 180.0) % 360.0 - 180.0        # wrapped channels, as BVH files store them
+    raw = oanim.q_from_euler(np.radians(clip["rotations"]))
+    assert nframes < 100 or (np.sum(raw[1:] * raw[:-1], axis=-1) < 0).any()   # the unrolling has work to do
+    dev = anim.preprocess_animation(clip, DEV)
+    ora = oanim.preprocess_animation(clip)
+    for n, a, b in zip(FEAT_NAMES, dev, ora):
+        tol = 2e-6 if a.dtype == torch.float32 else 1e-8
+        np.testing.assert_allclose(a.cpu().numpy(), np.asarray(b), atol=tol, rtol=tol, err_msg=f"{n} N={nframes}")
+
+
+def test_anim_features_rejects_short_clips():
+    from zeggs import anim
+    with pytest.raises(RuntimeError, match="at least 4 frames"):
+        anim.preprocess_animation(synth.make_bvh_clip(3, seed=0), DEV)
+
+
+def test_pose_to_bvh_vs_oracle_and_reference(golden_dir):
+    """decoder outputs captured inside the reference's generate_gesture -> BVH channels on the device"""
+    from zeggs import anim
+    gd = np.load(golden_dir / "generate.npz")
+    t = lambda k: torch.as_tensor(gd[k], device=DEV)  # noqa: E731
+    for start in (None, (np.array([0, 0, 0]), np.array([1, 0, 0, 0])), (np.array([1.0, 2, 3]), np.array([0.6, 0, 0.8, 0]))):
+        kw = {} if start is None else dict(start_position=start[0], start_rotation=start[1])
+        pos, eul = anim.bvh_channels(t("dec_root_pos"), t("dec_root_rot"), t("dec_lpos"), t("dec_ltxy"), **kw)
+        opos, oeul = oanim.bvh_channels(gd["dec_root_pos"], gd["dec_root_rot"], gd["dec_lpos"], gd["dec_ltxy"], **kw)
+        np.testing.assert_allclose(pos.cpu().numpy(), opos, atol=1e-9)
+        qa, qb = oanim.q_from_euler(np.radians(eul.cpu().numpy())), oanim.q_from_euler(np.radians(oeul))
+        assert np.abs(np.abs(np.sum(qa * qb, axis=-1)) - 1.0).max() < 1e-12
+    pos, eul = anim.bvh_channels(t("dec_root_pos"), t("dec_root_rot"), t("dec_lpos"), t("dec_ltxy"),
+                                 start_position=np.array([0, 0, 0]), start_rotation=np.array([1, 0, 0, 0]))
+    np.testing.assert_allclose(pos.cpu().numpy()[:, 0], gd["out_positions"][:, 0], atol=2e-5)     # out.bvh: 6 decimals
+    qa = oanim.q_from_euler(np.radians(eul.cpu().numpy()))
+    qb = oanim.q_from_euler(np.radians(gd["out_rotations"].astype(np.float64)))
+    assert np.abs(np.abs(np.sum(qa * qb, axis=-1)) - 1.0).max() < 1e-9

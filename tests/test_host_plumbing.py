@@ -1,7 +1,9 @@
 """CPU tests of the host-side plumbing of generate_gesture() against fixtures recorded from the reference:
-BVH parsing of a file written by the reference's bvh.save, exemplar feature extraction, BVH writing round trip."""
+BVH parsing of a file written by the reference's bvh.save, BVH writing round trip; and of the NumPy oracle of the
+animation kernels (exemplar feature extraction, decoder output -> BVH channels) against the same fixtures."""
 import numpy as np
 
+from oracle import anim as oanim
 from zeggs import anim, generate, synth
 
 
@@ -24,7 +26,7 @@ def test_bvh_load_matches_reference(golden_dir, tmp_path):
 
 def test_preprocess_animation_matches_reference(golden_dir, tmp_path):
     g, p = _exemplar(golden_dir, tmp_path)
-    feats = anim.preprocess_animation(anim.bvh_load(p))
+    feats = oanim.preprocess_animation(anim.bvh_load(p))
     names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "lrot", "ltxy", "lvel", "lvrt", "cpos", "crot",
              "ctxy", "cvel", "cvrt", "gaze_pos", "gaze_dir")
     for n, f in zip(names, feats):
@@ -42,9 +44,24 @@ def test_bvh_save_load_round_trip(tmp_path):
 
 def test_quaternion_matrix_round_trip_and_split():
     rng = np.random.default_rng(0)
-    q = anim.q_normalize(rng.standard_normal((50, 4)))
+    q = oanim.q_normalize(rng.standard_normal((50, 4)))
     ex, ey = np.array([1.0, 0, 0]), np.array([0, 1.0, 0])
-    xy = np.stack([anim.q_mul_vec(q, ex), anim.q_mul_vec(q, ey)], axis=-2)
-    q2 = anim.q_from_xform(anim.xform_from_xy(xy))
+    xy = np.stack([oanim.q_mul_vec(q, ex), oanim.q_mul_vec(q, ey)], axis=-2)
+    q2 = oanim.q_from_xform(oanim.xform_from_xy(xy))
     assert np.abs(np.abs(np.sum(q * q2, axis=-1)) - 1.0).max() < 1e-9
     assert generate.split_by_ratio(601, [0.3, 0.7]) == [[0, 180], [180, 601]]
+
+
+def test_bvh_channels_oracle_matches_reference(golden_dir):
+    """decoder outputs captured inside the reference's generate_gesture -> the channels it wrote to out.bvh
+    (text with 6 decimals: compared as rotations, 1e-5)"""
+    g = np.load(golden_dir / "generate.npz")
+    pos, eul = oanim.bvh_channels(g["dec_root_pos"], g["dec_root_rot"], g["dec_lpos"], g["dec_ltxy"],
+                                  start_position=np.array([0, 0, 0]), start_rotation=np.array([1, 0, 0, 0]))
+    np.testing.assert_allclose(pos[:, 0], g["out_positions"][:, 0], atol=2e-5)
+    qa = oanim.q_from_euler(np.radians(eul))
+    qb = oanim.q_from_euler(np.radians(g["out_rotations"].astype(np.float64)))
+    assert np.abs(np.abs(np.sum(qa * qb, axis=-1)) - 1.0).max() < 1e-9
+    # the quaternions the reference derived from the two-axis encodings (generate.py:389), float32
+    q = oanim.q_from_xform(oanim.xform_from_xy(g["dec_ltxy"].astype(np.float64)))
+    assert np.abs(np.abs(np.sum(q * g["dec_lrot"], axis=-1)) - 1.0).max() < 1e-5

@@ -1,129 +1,21 @@
-"""Host-side animation plumbing (NumPy): quaternions, BVH text I/O, exemplar feature extraction.
+"""Animation plumbing around the decoder: BVH text I/O on the host, feature extraction and BVH-channel
+conversion on the device (csrc/anim.hip, float64).
 
-This is the part of the pipeline that the north_star leaves on the host ("host code stays Python for
-tensor plumbing and BVH I/O"): it runs once per clip, not per frame.  Semantics follow the reference so that
-`generate_gesture()` consumes and produces the same files:
-  ZEGGS/anim/quat.py (quaternion conventions, w first), ZEGGS/anim/bvh.py (BVH reader/writer),
-  ZEGGS/data_pipeline.py:90-228 (preprocess_animation), ZEGGS/utils.py:47-87 (write_bvh).
+Semantics follow the reference so that `generate_gesture()` consumes and produces the same files:
+  ZEGGS/anim/bvh.py (BVH reader/writer), ZEGGS/data_pipeline.py:90-228 (preprocess_animation),
+  ZEGGS/generate.py:389 + ZEGGS/utils.py:47-87 (two-axis rotations -> quaternions -> euler channels, write_bvh).
+The NumPy restatement of the device kernels lives in oracle/anim.py (test infrastructure).
 """
+import ctypes as C
 import re
 
 import numpy as np
+import torch
 
-_AXES = {"x": np.array([1.0, 0.0, 0.0]), "y": np.array([0.0, 1.0, 0.0]), "z": np.array([0.0, 0.0, 1.0])}
+from . import ops
+
 _CHAN = {"Xrotation": "x", "Yrotation": "y", "Zrotation": "z"}
 _CHAN_INV = {v: k for k, v in _CHAN.items()}
-
-
-# ----------------------------------------------------------------------------- quaternions (w, x, y, z)
-def q_mul(a, b):
-    aw, av = a[..., :1], a[..., 1:]
-    bw, bv = b[..., :1], b[..., 1:]
-    return np.concatenate([aw * bw - np.sum(av * bv, axis=-1, keepdims=True),
-                           aw * bv + bw * av + np.cross(av, bv)], axis=-1)
-
-
-def q_inv(q):
-    return q * np.array([1.0, -1.0, -1.0, -1.0], dtype=q.dtype)
-
-
-def q_mul_vec(q, v):
-    t = 2.0 * np.cross(q[..., 1:], v)
-    return v + q[..., :1] * t + np.cross(q[..., 1:], t)
-
-
-def q_abs(q):
-    return np.where(q[..., :1] > 0.0, q, -q)
-
-
-def q_normalize(q, eps=0.0):
-    return q / (np.linalg.norm(q, axis=-1, keepdims=True) + eps)
-
-
-def q_log(q, eps=1e-5):
-    n = np.linalg.norm(q[..., 1:], axis=-1, keepdims=True)
-    scale = np.where(n < eps, 1.0, np.arctan2(n, q[..., :1]) / np.where(n < eps, 1.0, n))
-    return scale * q[..., 1:]
-
-
-def q_to_helical(q, eps=1e-5):
-    return 2.0 * q_log(q, eps)
-
-
-def q_between(a, b):
-    """rotation taking direction a to direction b (un-normalised), reference quat.between"""
-    w = np.sqrt(np.sum(a * a, axis=-1) * np.sum(b * b, axis=-1)) + np.sum(a * b, axis=-1)
-    return np.concatenate([w[..., None], np.cross(a, b)], axis=-1)
-
-
-def q_from_angle_axis(angle, axis):
-    h = 0.5 * angle[..., None]
-    return np.concatenate([np.cos(h), np.sin(h) * axis], axis=-1)
-
-
-def q_from_euler(e, order="zyx"):
-    """e in radians, intrinsic order as in the reference (quat.from_euler): q0 * (q1 * q2)"""
-    qs = [q_from_angle_axis(e[..., i], _AXES[order[i]]) for i in range(3)]
-    return q_mul(qs[0], q_mul(qs[1], qs[2]))
-
-
-def q_to_euler(q, order="zyx"):
-    if order != "zyx":
-        raise NotImplementedError("only the 'zyx' channel order of the ZeroEGGS rigs is supported")
-    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
-    return np.stack([np.arctan2(2.0 * (w * z + x * y), 1.0 - 2.0 * (y * y + z * z)),
-                     np.arcsin(np.clip(2.0 * (w * y - z * x), -1.0, 1.0)),
-                     np.arctan2(2.0 * (w * x + y * z), 1.0 - 2.0 * (x * x + y * y))], axis=-1)
-
-
-def q_unroll(q):
-    """make consecutive frames sign-continuous"""
-    out = q.copy()
-    for i in range(1, len(out)):
-        flip = np.sum(out[i] * out[i - 1], axis=-1) < 0.0
-        out[i][flip] = -out[i][flip]
-    return out
-
-
-def q_from_xform(m, eps=1e-10):
-    """rotation matrices [..., 3, 3] -> quaternions (branch choice as reference quat.from_xform)"""
-    m00, m11, m22 = m[..., 0, 0], m[..., 1, 1], m[..., 2, 2]
-    tr = m00 + m11 + m22
-    sw = 0.5 / np.sqrt(np.maximum(tr + 1.0, eps))
-    sx = 2.0 * np.sqrt(np.maximum(1.0 + m00 - m11 - m22, eps))
-    sy = 2.0 * np.sqrt(np.maximum(1.0 + m11 - m00 - m22, eps))
-    sz = 2.0 * np.sqrt(np.maximum(1.0 + m22 - m00 - m11, eps))
-    a, b, c = m[..., 2, 1] - m[..., 1, 2], m[..., 0, 2] - m[..., 2, 0], m[..., 1, 0] - m[..., 0, 1]
-    p, q, r = m[..., 0, 1] + m[..., 1, 0], m[..., 0, 2] + m[..., 2, 0], m[..., 1, 2] + m[..., 2, 1]
-    cand = [np.stack([0.25 / sw, sw * a, sw * b, sw * c], axis=-1),
-            np.stack([a / sx, 0.25 * sx, p / sx, q / sx], axis=-1),
-            np.stack([b / sy, p / sy, 0.25 * sy, r / sy], axis=-1),
-            np.stack([c / sz, q / sz, r / sz, 0.25 * sz], axis=-1)]
-    x_big = (m00 > m11) & (m00 > m22)
-    y_big = ~x_big & (m11 > m22)
-    case = np.where(tr > 0, 0, np.where(x_big, 1, np.where(y_big, 2, 3)))[..., None]
-    return np.select([case == 0, case == 1, case == 2, case == 3], cand)
-
-
-def q_fk(lrot, lpos, parents):
-    grot, gpos = [lrot[..., 0, :]], [lpos[..., 0, :]]
-    for i in range(1, len(parents)):
-        p = parents[i]
-        gpos.append(q_mul_vec(grot[p], lpos[..., i, :]) + gpos[p])
-        grot.append(q_mul(grot[p], lrot[..., i, :]))
-    return np.stack(grot, axis=-2), np.stack(gpos, axis=-2)
-
-
-def q_fk_vel(lrot, lpos, lvrt, lvel, parents):
-    gr, gp, gt, gv = [lrot[..., 0, :]], [lpos[..., 0, :]], [lvrt[..., 0, :]], [lvel[..., 0, :]]
-    for i in range(1, len(parents)):
-        p = parents[i]
-        rp = q_mul_vec(gr[p], lpos[..., i, :])
-        gp.append(rp + gp[p])
-        gr.append(q_mul(gr[p], lrot[..., i, :]))
-        gt.append(gt[p] + q_mul_vec(gr[p], lvrt[..., i, :]))
-        gv.append(gv[p] + q_mul_vec(gr[p], lvel[..., i, :]) + np.cross(gt[p], rp))
-    return np.stack(gr, axis=-2), np.stack(gp, axis=-2), np.stack(gt, axis=-2), np.stack(gv, axis=-2)
 
 
 # ----------------------------------------------------------------------------- BVH
@@ -221,82 +113,90 @@ def bvh_save(filename, data):
         fh.write("\n".join(out) + "\n")
 
 
-# ----------------------------------------------------------------------------- features of an exemplar clip
-def _finite_diff_first(x):
-    """frame 0 by linear extrapolation of the next differences (data_pipeline.py:150-156)"""
-    x[0] = x[1] - (x[3] - x[2])
-    return x
+# ----------------------------------------------------------------------------- device kernels (csrc/anim.hip)
+class AnimDims(C.Structure):       # mirrors ZeggsAnimDims
+    _fields_ = [("N", C.c_int), ("J", C.c_int), ("hips", C.c_int), ("spine2", C.c_int), ("head", C.c_int),
+                ("dt", C.c_double)]
 
 
-def preprocess_animation(anim):
-    """BVH dict -> the 16 feature arrays of reference data_pipeline.preprocess_animation (same order)."""
-    names, parents, dt = anim["names"], anim["parents"], anim["frametime"]
-    n = len(anim["rotations"])
-    lrot = q_unroll(q_from_euler(np.radians(anim["rotations"].astype(np.float64)), anim["order"]))
-    lpos = anim["positions"].astype(np.float64).copy()
-    grot, gpos = q_fk(lrot, lpos, parents)
-    fwd = np.array([[0.0, 0.0, 1.0]])
-    root_pos = gpos[:, names.index("Spine2")] * np.array([1.0, 0.0, 1.0])
-    root_fwd = q_mul_vec(grot[:, names.index("Hips")], fwd)
-    root_fwd[:, 1] = 0.0
-    root_fwd /= np.linalg.norm(root_fwd, axis=-1, keepdims=True)
-    root_rot = q_normalize(q_between(np.repeat(fwd, n, axis=0), root_fwd))
-    look = q_mul_vec(grot[:, names.index("Head")], fwd[0])
-    look[:, 1] = 0.0
-    look /= np.linalg.norm(look, axis=-1, keepdims=True)
-    gaze_pos = np.repeat(np.median(root_pos + 100.0 * look, axis=0)[None], n, axis=0)
-    inv_root = q_inv(root_rot)
-    gaze_dir = q_mul_vec(inv_root, gaze_pos - root_pos)
-    lrot[:, 0] = q_mul(inv_root, lrot[:, 0])
-    lpos[:, 0] = q_mul_vec(inv_root, lpos[:, 0] - root_pos)
-
-    lvel = np.zeros_like(lpos)
-    lvel[1:] = (lpos[1:] - lpos[:-1]) / dt
-    _finite_diff_first(lvel)
-    lvrt = np.zeros_like(lpos)
-    lvrt[1:] = q_to_helical(q_abs(q_mul(lrot[1:], q_inv(lrot[:-1])))) / dt
-    _finite_diff_first(lvrt)
-    root_vrt = np.zeros_like(root_pos)
-    root_vrt[1:] = q_to_helical(q_abs(q_mul(root_rot[1:], q_inv(root_rot[:-1])))) / dt
-    _finite_diff_first(root_vrt)
-    root_vrt[1:] = q_mul_vec(inv_root[:-1], root_vrt[1:])
-    root_vrt[0] = q_mul_vec(inv_root[0], root_vrt[0])
-    root_vel = np.zeros_like(root_pos)
-    root_vel[1:] = (root_pos[1:] - root_pos[:-1]) / dt
-    _finite_diff_first(root_vel)
-    root_vel[1:] = q_mul_vec(inv_root[:-1], root_vel[1:])
-    root_vel[0] = q_mul_vec(inv_root[0], root_vel[0])
-
-    crot, cpos, cvrt, cvel = q_fk_vel(lrot, lpos, lvrt, lvel, parents)
-    ex, ey = np.array([1.0, 0.0, 0.0]), np.array([0.0, 1.0, 0.0])
-    ltxy = np.stack([q_mul_vec(lrot, ex), q_mul_vec(lrot, ey)], axis=-2).astype(np.float32)
-    ctxy = np.stack([q_mul_vec(crot, ex), q_mul_vec(crot, ey)], axis=-2).astype(np.float32)
-    return (root_pos, root_rot, root_vel, root_vrt, lpos, lrot, ltxy, lvel, lvrt, cpos, crot, ctxy, cvel, cvrt,
-            gaze_pos, gaze_dir)
+ANIM_OUT = (("root_pos", 3, torch.float64), ("root_rot", 4, torch.float64), ("root_vel", 3, torch.float64),
+            ("root_vrt", 3, torch.float64), ("lpos", -3, torch.float64), ("lrot", -4, torch.float64),
+            ("lvel", -3, torch.float64), ("lvrt", -3, torch.float64), ("ltxy", -6, torch.float32),
+            ("cpos", -3, torch.float64), ("crot", -4, torch.float64), ("cvel", -3, torch.float64),
+            ("cvrt", -3, torch.float64), ("ctxy", -6, torch.float32), ("gaze_pos", 3, torch.float64),
+            ("gaze_dir", 3, torch.float64))
+AnimOut = type("AnimOut", (C.Structure,), {"_fields_": [(n, C.c_void_p) for n, _, _ in ANIM_OUT]})   # ZeggsAnimOut
 
 
-def xform_from_xy(xy, eps=1e-10):
-    """two-axis rows [..., 2, 3] -> rotation matrices (columns = axes), reference txform.py:23-34 in NumPy"""
-    x = xy[..., 0, :]
-    z = np.cross(x, xy[..., 1, :])
-    y = np.cross(z, x)
-    rows = np.stack([v / (np.linalg.norm(v, axis=-1, keepdims=True) + eps) for v in (x, y, z)], axis=-2)
-    return np.swapaxes(rows, -1, -2)
+class BvhDims(C.Structure):        # mirrors ZeggsBvhDims
+    _fields_ = [("T", C.c_int), ("J", C.c_int), ("rebase", C.c_int), ("start_pos", C.c_double * 3),
+                ("start_rot", C.c_double * 4)]
 
 
-def write_bvh(filename, root_pos, root_rot, lpos, lrot, parents, names, order, dt, start_position=None,
-              start_rotation=None):
-    """reference utils.write_bvh: optionally re-base the root trajectory, fold the root into joint 0, save."""
-    root_pos, root_rot = np.asarray(root_pos, np.float64), np.asarray(root_rot, np.float64)
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def preprocess_animation(anim, device=None):
+    """BVH dict -> the 16 feature arrays of reference data_pipeline.preprocess_animation, same order:
+    (root_pos, root_rot, root_vel, root_vrt, lpos, lrot, ltxy, lvel, lvrt, cpos, crot, ctxy, cvel, cvrt, gaze_pos,
+    gaze_dir) as DEVICE tensors (float64; ltxy / ctxy float32)."""
+    device = torch.device(device or "cuda")
+    if anim["order"] != "zyx":
+        raise NotImplementedError("only the 'zyx' channel order of the ZeroEGGS rigs is supported")
+    names = list(anim["names"])
+    rot = torch.as_tensor(np.ascontiguousarray(anim["rotations"], dtype=np.float64), device=device)
+    pos = torch.as_tensor(np.ascontiguousarray(anim["positions"], dtype=np.float64), device=device)
+    parents = torch.as_tensor(np.ascontiguousarray(anim["parents"], dtype=np.int32), device=device)
+    N, J = rot.shape[0], rot.shape[1]
+    d = AnimDims(N, J, names.index("Hips"), names.index("Spine2"), names.index("Head"), float(anim["frametime"]))
+    L = ops.lib()
+    L.zeggs_anim_features_workspace_bytes.restype = C.c_size_t
+    ws = torch.empty(int(L.zeggs_anim_features_workspace_bytes(C.byref(d))), dtype=torch.uint8, device=device)
+    out, ptr = {}, AnimOut()
+    for n, w, dt in ANIM_OUT:
+        shape = (N, w) if w > 0 else ((N, J, 2, 3) if w == -6 else (N, J, -w))
+        out[n] = torch.empty(shape, dtype=dt, device=device)
+        setattr(ptr, n, out[n].data_ptr())
+    rc = L.zeggs_anim_features(C.byref(d), C.c_void_p(parents.data_ptr()), C.c_void_p(rot.data_ptr()),
+                               C.c_void_p(pos.data_ptr()), C.byref(ptr), C.c_void_p(ws.data_ptr()),
+                               C.c_size_t(ws.numel()), _stream())
+    if rc != 0:
+        raise RuntimeError("zeggs_anim_features: " + L.zeggs_last_error().decode())
+    order = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "lrot", "ltxy", "lvel", "lvrt", "cpos", "crot",
+             "ctxy", "cvel", "cvrt", "gaze_pos", "gaze_dir")
+    return tuple(out[k] for k in order)
+
+
+def bvh_channels(root_pos, root_rot, lpos, ltxy, start_position=None, start_rotation=None):
+    """decoder output (device float32: [T,3], [T,4], [T,J,3], [T,J,2,3]) -> (positions, euler degrees) float64
+    device tensors [T,J,3], channel order zyx, root folded into joint 0 (reference generate.py:389, utils.py:47-87)."""
+    T, J = lpos.shape[0], lpos.shape[1]
+    d = BvhDims(T, J, 0)
     if start_position is not None and start_rotation is not None:
-        p0, r0 = root_pos[0:1].copy(), root_rot[0:1].copy()
-        root_pos = q_mul_vec(q_inv(r0), root_pos - p0)
-        root_rot = q_mul(q_inv(r0), root_rot)
-        sr = np.asarray(start_rotation, np.float64)[None]
-        root_pos = q_mul_vec(sr, root_pos) + np.asarray(start_position, np.float64)[None]
-        root_rot = q_mul(sr, root_rot)
-    lpos, lrot = np.array(lpos, np.float64), np.array(lrot, np.float64)
-    lpos[:, 0] = q_mul_vec(root_rot, lpos[:, 0]) + root_pos
-    lrot[:, 0] = q_mul(root_rot, lrot[:, 0])
-    bvh_save(filename, dict(order=order, offsets=lpos[0], names=names, frametime=dt, parents=parents, positions=lpos,
-                            rotations=np.degrees(q_to_euler(lrot, order=order))))
+        d.rebase = 1
+        d.start_pos[:] = [float(v) for v in start_position]
+        d.start_rot[:] = [float(v) for v in start_rotation]
+    f = lambda t: t.detach().to(torch.float32).contiguous()  # noqa: E731
+    root_pos, root_rot, lpos, ltxy = f(root_pos), f(root_rot), f(lpos), f(ltxy)
+    positions = torch.empty(T, J, 3, dtype=torch.float64, device=lpos.device)
+    euler = torch.empty(T, J, 3, dtype=torch.float64, device=lpos.device)
+    L = ops.lib()
+    rc = L.zeggs_pose_to_bvh(C.byref(d), C.c_void_p(root_pos.data_ptr()), C.c_void_p(root_rot.data_ptr()),
+                             C.c_void_p(lpos.data_ptr()), C.c_void_p(ltxy.data_ptr()),
+                             C.c_void_p(positions.data_ptr()), C.c_void_p(euler.data_ptr()), _stream())
+    if rc != 0:
+        raise RuntimeError("zeggs_pose_to_bvh: " + L.zeggs_last_error().decode())
+    return positions, euler
+
+
+def write_bvh(filename, root_pos, root_rot, lpos, ltxy, parents, names, order, dt, start_position=None,
+              start_rotation=None):
+    """reference utils.write_bvh, fed with the decoder's two-axis rotations (the quaternion / euler conversion of
+    generate.py:389 happens on the device)."""
+    if order != "zyx":
+        raise NotImplementedError("only the 'zyx' channel order of the ZeroEGGS rigs is supported")
+    positions, euler = bvh_channels(root_pos, root_rot, lpos, ltxy, start_position, start_rotation)
+    positions = positions.cpu().numpy()
+    bvh_save(filename, dict(order=order, offsets=positions[0], names=names, frametime=dt, parents=parents,
+                            positions=positions, rotations=euler.cpu().numpy()))

@@ -1,7 +1,7 @@
 """generate_gesture(): the reference's inference entry point on the HIP engine.
 
-Same signature, file layout and return value as ZEGGS/generate.py:22-411.  Host side: file I/O, exemplar feature
-extraction, style blending.  Device side (HIP kernels): mel front-end, speech encoder, style encoder + VAE,
+Same signature, file layout and return value as ZEGGS/generate.py:22-411.  Host side: file I/O, style blending.
+Device side (HIP kernels): exemplar feature extraction, BVH channel conversion, mel front-end, speech encoder, style encoder + VAE,
 autoregressive decoder rollout (no-grad ring-buffer path).  `use_script` is accepted and ignored (TorchScript cannot
 wrap the C-ABI calls; every shipped config sets it to false).
 """
@@ -42,11 +42,12 @@ def read_wav_mono16k(path):
 
 
 def _example_features(p):
-    """feature rows [F, 1134] of an exemplar clip (gaze slot zero), as in generate.py:229-248"""
+    """feature rows [F, 1134] of an exemplar clip (gaze slot zero), as in generate.py:229-248 (device tensors)"""
     root_pos, root_rot, root_vel, root_vrt, lpos, lrot, ltxy, lvel, lvrt = p[:9]
     n = len(root_vel)
-    return np.concatenate([root_vel.reshape(n, -1), root_vrt.reshape(n, -1), lpos.reshape(n, -1), ltxy.reshape(n, -1),
-                           lvel.reshape(n, -1), lvrt.reshape(n, -1), np.zeros((n, 3))], axis=1).astype(np.float32)
+    cols = [root_vel, root_vrt, lpos, ltxy, lvel, lvrt]
+    return torch.cat([c.reshape(n, -1).to(torch.float32) for c in cols] +
+                     [torch.zeros(n, 3, dtype=torch.float32, device=root_vel.device)], dim=1)
 
 
 def generate_gesture(audio_file, styles, network_path, data_path, results_path, style_encoding_type="example",
@@ -99,8 +100,8 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
                         clip["rotations"] = clip["rotations"][style[1][0]:style[1][1]]
                         clip["positions"] = clip["positions"][style[1][0]:style[1][1]]
                     assert int(np.ceil(1 / clip["frametime"])) == 60
-                    feat = anim.preprocess_animation(clip)
-                    ex = (torch.as_tensor(_example_features(feat), device=device) - in_mean) / in_std
+                    feat = anim.preprocess_animation(clip, device)
+                    ex = (_example_features(feat) - in_mean) / in_std
                     z, _, _ = style_net(ex[None].contiguous(), temperature)
                     encodings.append(z)
                 elif isinstance(style[0], np.ndarray):
@@ -132,8 +133,8 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
         if audio_file is not None:
             if first_pose is not None:
                 clip = anim.bvh_load(first_pose) if isinstance(first_pose, (pathlib.PurePath, str)) else dict(first_pose)
-                feat = anim.preprocess_animation(clip)
-            g = lambda a: torch.as_tensor(np.asarray(a[0:1]), dtype=torch.float32, device=device)  # noqa: E731
+                feat = anim.preprocess_animation(clip, device)
+            g = lambda a: a[0:1].to(torch.float32).contiguous()  # noqa: E731
             root_pos, root_rot, root_vel, root_vrt, lpos, lrot, ltxy, lvel, lvrt = feat[:9]
             gaze_pos = feat[14]
             if final.dim() == 2:
@@ -142,12 +143,11 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
             out = decoder(g(root_pos), g(root_rot), g(root_vel), g(root_vrt), g(lpos), g(ltxy), g(lvel), g(lvrt),
                           gaze.contiguous(), speech, final.contiguous(), None, in_mean, in_std, out_mean, out_std, dt)
             V_root_pos, V_root_rot, _, _, V_lpos, V_ltxy = out[0], out[1], out[2], out[3], out[4], out[5]
-            V_lrot = anim.q_from_xform(anim.xform_from_xy(V_ltxy[0].cpu().numpy().astype(np.float64)))
             if file_name is None:
                 file_name = f"audio_{Path(audio_file).stem}_label_{anim_name}"
             try:
-                anim.write_bvh(str(results_path / (file_name + ".bvh")), V_root_pos[0].cpu().numpy(),
-                               V_root_rot[0].cpu().numpy(), V_lpos[0].cpu().numpy(), V_lrot, parents=parents,
+                anim.write_bvh(str(results_path / (file_name + ".bvh")), V_root_pos[0], V_root_rot[0], V_lpos[0],
+                               V_ltxy[0], parents=parents,
                                names=bone_names, order="zyx", dt=dt, start_position=np.array([0, 0, 0]),
                                start_rotation=np.array([1, 0, 0, 0]))
                 copyfile(audio_file, str(results_path / (file_name + ".wav")))
