@@ -171,8 +171,8 @@ def main():
         ach = step_bytes(BATCH) / probe / 1e9
         pmc_file = ROOT / "profiles" / "r01_decoder_step_pmc.json"
         traffic = json.load(open(pmc_file))["traffic_bytes_per_step"] if pmc_file.exists() else None
-        out["roofline"] = {"bound": "hbm", "kernel": "decoder forward step = 4 launches of stage_k (layer0, GRU l0, "
-                                                     "GRU l1, layer2+pose integration), per-step figures",
+        out["roofline"] = {"bound": "hbm", "kernel": "decoder forward step = 3 launches of stage_k (GRU l0, GRU l1, "
+                                                     "layer2+pose integration+next layer0), per-step figures",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "us_per_step": round(probe * 1e6, 2), "algorithmic_bytes_per_step": step_bytes(BATCH),
