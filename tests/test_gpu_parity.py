@@ -433,9 +433,9 @@ def test_train_api_runs_and_checkpoints(tmp_path):
     assert set(ck) == {"iteration", "epoch", "loss", "optimizer_state_dict"}
 
 
-@pytest.mark.parametrize("B", [1, 3, 4])
+@pytest.mark.parametrize("B", [1, 2])
 def test_decoder_gemv_decode_path_matches_mfma_path(B):
-    """B <= 4 no_grad rollouts use the GEMV stage kernels; option bit 1024 forces the MFMA path for comparison."""
+    """B <= 2 no_grad rollouts use the GEMV stage kernels; option bit 1024 forces the MFMA path for comparison."""
     _, de, _ = helpers.build_nets()
     de = de.to(DEV).eval()
     T = 40

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
   }
 
   if constexpr (BV > 0) {
-    // ---- GEMV mode: batch <= 4 (autoregressive decode).  No MFMA padding to 16 batch rows: each lane owns
+    // ---- GEMV mode: batch <= 2 (autoregressive decode).  No MFMA padding to 16 batch rows: each lane owns
     // (column i, k-quarter) of the weight fragment and multiplies it with the matching float4 of every batch row
     // read straight from the canonical activations (16 lanes share an address: one L1 broadcast).
     float av[2][BV];
@@ -648,9 +648,7 @@ int launch_stage_gemv(const StageArgs& a, hipStream_t s) {
   switch (a.d.B) {
     case 1: hipLaunchKernelGGL((stage_k<1, 0, 8, 1>), dim3(wgs), dim3(512), 0, s, a); break;
     case 2: hipLaunchKernelGGL((stage_k<1, 0, 8, 2>), dim3(wgs), dim3(512), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((stage_k<1, 0, 8, 3>), dim3(wgs), dim3(512), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((stage_k<1, 0, 8, 4>), dim3(wgs), dim3(512), 0, s, a); break;
-    default: zeggs_set_error("gemv mode needs batch <= 4"); return -1;
+    default: zeggs_set_error("gemv mode needs batch <= 2"); return -1;
   }
   ZLAUNCH_CHECK("decoder_stage_gemv");
   return 0;
@@ -773,9 +771,10 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   conv(H1xf[0], w.H1 + cs(0) * sH, H, 0, H);
   conv(Xxf[1], w.Gin + cs(1) * sG, w.GL, H, w.XD);
   ZLAUNCH_CHECK("to_xfrag");
-  // tiny-batch decode (B <= 4, no_grad): GEMV stage kernels over the canonical activations (decoder.hip zero-fills
-  // the Gin ring first: the pad columns of x are read against zero weights and must be finite)
-  const bool gemv = !training && B <= 4 && !(g_stage_variant & 1024);
+  // tiny-batch decode (B <= 2, no_grad; measured: B >= 3 is faster on the MFMA path): GEMV stage kernels over the
+  // canonical activations (decoder.hip zero-fills the Gin ring first: the pad columns of x are read against zero
+  // weights and must be finite)
+  const bool gemv = !training && B <= 2 && !(g_stage_variant & 1024);
   // 3 launches per step: layer2 of step t and layer0 of step t+1 run in ONE launch (variant 4096: 4 launches)
   const bool merged = !(g_stage_variant & 4096);
   if (merged && T > 2) ZTRY(dec_fast_pack_merged(d, P, st, w, s));

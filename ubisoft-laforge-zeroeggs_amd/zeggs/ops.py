@@ -277,13 +277,15 @@ def decoder_param_list(dec):
 
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt, H, *params):
+    def forward(ctx, pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt, H, grad_mode,
+                *params):
         pose0, rpos0, rrot0, gaze, speech, style = (_f32c(t) for t in (pose0, rpos0, rrot0, gaze, speech, style))
         stats = [_f32c(t) for t in (in_mean, in_std, out_mean, out_std)]
         params = [_f32c(t) for t in params]
         B, T, SP = speech.shape
         ST, PO = style.shape[2], pose0.shape[1]
-        training = any(ctx.needs_input_grad)
+        # needs_input_grad ignores torch.no_grad(): the caller's grad mode selects the BPTT workspace / ring path
+        training = bool(grad_mode) and any(ctx.needs_input_grad)
         d = DecDims(B, T, PO + 3, PO, SP, ST, H, float(dt))
         L = lib()
         ws = _ws(L.zeggs_decoder_workspace_bytes(C.byref(d), int(training)), pose0.device)
@@ -319,14 +321,14 @@ class _DecoderFn(torch.autograd.Function):
         _check(L.zeggs_decoder_bwd(C.byref(d), C.byref(P), C.byref(S), _p(gaze), _p(pose), _p(rpos), _p(rrot),
                                    _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
                                    C.c_size_t(ctx.ws.numel()), _stream()), "decoder_bwd")
-        return (None, None, None, None, dspeech, dstyle, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, dspeech, dstyle, None, None, None, None, None, None, None, *grads)
 
 
 def decoder_core(dec, pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt):
     """-> pose [B,T,PO] (de-normalised output vectors), rpos [B,T,3], rrot [B,T,4]"""
     H = dec.recurrent_decoder.layer2.in_features
     return _DecoderFn.apply(pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt, H,
-                            *decoder_param_list(dec))
+                            torch.is_grad_enabled(), *decoder_param_list(dec))
 
 
 def decoder_rollout(dec, Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos, Z_ltxy, Z_lvel, Z_lvrt, gaze,
