@@ -89,6 +89,26 @@ int zeggs_style_encoder_fwd(const ZeggsStyleDims*, const ZeggsStyleParams*, cons
                             float* out, void* ws, size_t ws_bytes, void* stream);
 int zeggs_style_encoder_bwd(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* dout,
                             const ZeggsStyleGrads*, void* ws, size_t ws_bytes, void* stream);
+/* style_encoder.type "gru": replaces StyleEncoderGRU.forward, ZEGGS/modules.py:307-343 (conv3+ReLU x2, one
+ * bidirectional GRU layer, projection of the last time step) and its backward.  x [B,L,C] -> out [B,O]. */
+typedef struct {
+  int B, L, C, H, O;
+} ZeggsStyleGruDims;
+typedef struct {
+  const float *c0_w, *c0_b;                   /* encoder.convs.0.conv [H,C,3] */
+  const float *c2_w, *c2_b;                   /* encoder.convs.2.conv [H,H,3] */
+  const float *w_ih, *w_hh, *b_ih, *b_hh;     /* encoder.rnn_layer *_l0          [3H,H] (gates r,z,n) */
+  const float *w_ih_r, *w_hh_r, *b_ih_r, *b_hh_r; /* encoder.rnn_layer *_l0_reverse */
+  const float *p_w, *p_b;                     /* encoder.projection_layer.linear_layer [O,2H] */
+} ZeggsStyleGruParams;
+typedef struct {
+  float *c0_w, *c0_b, *c2_w, *c2_b, *w_ih, *w_hh, *b_ih, *b_hh, *w_ih_r, *w_hh_r, *b_ih_r, *b_hh_r, *p_w, *p_b;
+} ZeggsStyleGruGrads;
+size_t zeggs_style_encoder_gru_workspace_bytes(const ZeggsStyleGruDims*);
+int zeggs_style_encoder_gru_fwd(const ZeggsStyleGruDims*, const ZeggsStyleGruParams*, const float* x, float* out,
+                                void* ws, size_t ws_bytes, void* stream);
+int zeggs_style_encoder_gru_bwd(const ZeggsStyleGruDims*, const ZeggsStyleGruParams*, const float* dout,
+                                const ZeggsStyleGruGrads*, void* ws, size_t ws_bytes, void* stream);
 /* VAE re-parameterisation, StyleEncoder.forward ZEGGS/modules.py:291-302:
  * enc [B,2S] -> z = mu + eps*exp(.5 logvar)/temperature ; bwd gives denc from dz, dmu, dlogvar */
 int zeggs_vae_reparam_fwd(const float* enc, const float* eps, float* z, int B, int S, float temperature,
@@ -104,17 +124,23 @@ int zeggs_vae_reparam_bwd(const float* enc, const float* eps, const float* dz, c
 typedef struct {
   int B, T, PI, PO, SP, ST, H;
   float dt;
+  int film; /* 0: RecurrentDecoderNormal (rnn_cond "normal"); 1: RecurrentDecoderFiLM, ZEGGS/modules.py:188-227 */
 } ZeggsDecDims;
+/* rnn_cond "film": the style leaves the step input (x = [pose, speech], XS = PI+SP) and modulates the two hidden
+ * layers instead: hid = ELU(layer0 x) * (1 + gamma[:H]) + beta[:H]; h2 = ELU(layer2 h1) * (1 + gamma[H:]) + beta[H:];
+ * y = layer3 h2, with gamma = gammas_predictor(style), beta = betas_predictor(style). */
 typedef struct {
-  const float *l0_w, *l0_b;                     /* recurrent_decoder.layer0 [H, PI+SP+ST] */
-  const float *w_ih0, *w_hh0, *b_ih0, *b_hh0;   /* layer1 GRU l0: [3H, H+PI+SP+ST], [3H,H] (gates r,z,n) */
+  const float *l0_w, *l0_b;                     /* recurrent_decoder.layer0 [H, PI+SP+ST]          (film: [H, PI+SP]) */
+  const float *w_ih0, *w_hh0, *b_ih0, *b_hh0;   /* layer1 GRU l0: [3H, H+PI+SP+ST], [3H,H] (gates r,z,n)  (film: [3H, H+PI+SP]) */
   const float *w_ih1, *w_hh1, *b_ih1, *b_hh1;   /* layer1 GRU l1: [3H,H],[3H,H] */
-  const float *l2_w, *l2_b;                     /* layer2 [PO,H] */
+  const float *l2_w, *l2_b;                     /* layer2 [PO,H]                                   (film: [H,H]) */
   const float *c0_w, *c0_b, *c1_w, *c1_b, *c2_w, *c2_b; /* cell_state_encoder [H,PI+ST],[H,H],[2H,H] */
+  const float *l3_w, *l3_b;                     /* film only: layer3 [PO,H] */
+  const float *g_w, *g_b, *be_w, *be_b;         /* film only: gammas_predictor / betas_predictor [2H,ST],[2H] */
 } ZeggsDecParams;
 typedef struct {
   float *l0_w, *l0_b, *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1, *l2_w, *l2_b, *c0_w,
-      *c0_b, *c1_w, *c1_b, *c2_w, *c2_b;
+      *c0_b, *c1_w, *c1_b, *c2_w, *c2_b, *l3_w, *l3_b, *g_w, *g_b, *be_w, *be_b;
 } ZeggsDecGrads;
 typedef struct {
   const float *in_mean, *in_std;   /* [PI] */

@@ -103,6 +103,53 @@ def gold_nets(ref):
     print("nets.npz", {k: v.shape for k, v in out.items() if k.startswith("O_")})
 
 
+def gold_variants(ref):
+    """Option-surface variants of the nets on a tiny case (full-size layers): rnn_cond="film" decoder rollout and
+    style_encoder type="gru" (+VAE), reference forward outputs; weights seeded 4321 in this construction order."""
+    torch.manual_seed(4321)
+    de = ref.modules.Decoder(pose_input_size=synth.POSE_IN, pose_output_size=synth.POSE_OUT, speech_encoding_size=64,
+                             style_encoding_size=64, hidden_size=1024, num_rnn_layers=2, rnn_cond="film")
+    st = ref.modules.StyleEncoder(synth.POSE_IN, 512, 64, type="gru", use_vae=True)
+    de.eval(), st.eval()
+    stats = synth.make_stats()
+    B, T, L = 2, 5, 9
+    clips = [synth.make_clip(T + L, seed=70 + b, stats=stats) for b in range(B)]
+    W = {k: torch.as_tensor(np.stack([c[k][:T] for c in clips])) for k in clips[0]}
+    in_mean, in_std = torch.as_tensor(stats["anim_input_mean"]), torch.as_tensor(stats["anim_input_std"])
+    out_mean, out_std = torch.as_tensor(stats["anim_output_mean"]), torch.as_tensor(stats["anim_output_std"])
+    ex = []
+    for c in clips:
+        ex.append(np.concatenate([c["Y_root_vel"][T:T + L], c["Y_root_vrt"][T:T + L],
+                                  c["Y_lpos"][T:T + L].reshape(L, -1), c["Y_ltxy"][T:T + L].reshape(L, -1),
+                                  c["Y_lvel"][T:T + L].reshape(L, -1), c["Y_lvrt"][T:T + L].reshape(L, -1),
+                                  np.zeros((L, 3), np.float32)], axis=1))
+    example = torch.as_tensor(np.stack(ex))
+    rng = np.random.default_rng(8)
+    eps = torch.as_tensor(rng.standard_normal((B, 64)).astype(np.float32))
+    speech = torch.as_tensor(rng.standard_normal((B, T, 64)).astype(np.float32) * 0.5)
+    style = torch.as_tensor(rng.standard_normal((B, T, 64)).astype(np.float32) * 0.5)
+    with torch.no_grad():
+        orig = torch.randn_like
+        torch.randn_like = lambda x, *a, **k: eps.to(x.dtype)
+        try:
+            z, mu, logvar = st((example - in_mean) / in_std, 1.0)
+        finally:
+            torch.randn_like = orig
+        O = de(W["Y_root_pos"][:, 0], W["Y_root_rot"][:, 0], W["Y_root_vel"][:, 0], W["Y_root_vrt"][:, 0],
+               W["Y_lpos"][:, 0], W["Y_ltxy"][:, 0], W["Y_lvel"][:, 0], W["Y_lvrt"][:, 0], W["Y_gaze_pos"], speech,
+               style, torch.LongTensor(synth.PARENTS), in_mean, in_std, out_mean, out_std, synth.DT)
+    out = {"in_" + k: v.numpy() for k, v in W.items()}
+    out.update(in_example=example.numpy(), in_eps=eps.numpy(), in_speech=speech.numpy(), in_style=style.numpy(),
+               gru_z=z.numpy(), gru_mu=mu.numpy(), gru_logvar=logvar.numpy())
+    names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
+    out.update({"O_" + n: o.numpy() for n, o in zip(names, O)})
+    for tag, net in (("decoder", de), ("style", st)):
+        for k, v in net.state_dict().items():
+            out[f"fp_{tag}.{k}"] = fingerprint(v)
+    np.savez_compressed(GOLD / "variants.npz", **out)
+    print("variants.npz", out["O_lpos"].shape, out["gru_z"].shape)
+
+
 def gold_train_iter(ref):
     """Two full reference train() iterations, B=2, window=8 (dropout patched to
     identity, VAE eps injected) -> batches, losses, gradient / weight samples."""
@@ -307,7 +354,9 @@ def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     ref = ref_shims.load()
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["nets", "train", "mel", "dataset", "radam", "generate"]
+    which = sys.argv[1:] or ["nets", "train", "mel", "dataset", "radam", "generate", "variants"]
+    if "variants" in which:
+        gold_variants(ref)
     if "nets" in which:
         gold_nets(ref)
     if "mel" in which:

@@ -161,10 +161,28 @@ def style_encoder_attn(w, x, prefix="encoder."):
     return f.sum(dim=1) / L                                      # modules.py:416
 
 
+def style_encoder_gru(w, x, prefix="encoder."):
+    """StyleEncoderGRU.forward (modules.py:307-343): two conv(3)+ReLU, one bidirectional GRU layer, projection of
+    the LAST time step (forward direction: final state; reverse direction: its first step, which saw x[-1] only)."""
+    p = prefix
+    h = torch.relu(_conv3(x, w[p + "convs.0.conv.weight"], w[p + "convs.0.conv.bias"]))
+    h = torch.relu(_conv3(h, w[p + "convs.2.conv.weight"], w[p + "convs.2.conv.bias"]))
+    B, L, Hh = h.shape
+    hf = torch.zeros(B, Hh, dtype=h.dtype)
+    for t in range(L):
+        hf = gru_cell(h[:, t], hf, w[p + "rnn_layer.weight_ih_l0"], w[p + "rnn_layer.weight_hh_l0"],
+                      w[p + "rnn_layer.bias_ih_l0"], w[p + "rnn_layer.bias_hh_l0"])
+    hb = gru_cell(h[:, L - 1], torch.zeros(B, Hh, dtype=h.dtype), w[p + "rnn_layer.weight_ih_l0_reverse"],
+                  w[p + "rnn_layer.weight_hh_l0_reverse"], w[p + "rnn_layer.bias_ih_l0_reverse"],
+                  w[p + "rnn_layer.bias_hh_l0_reverse"])
+    return F.linear(torch.cat([hf, hb], dim=-1), w[p + "projection_layer.linear_layer.weight"],
+                    w[p + "projection_layer.linear_layer.bias"])
+
+
 def style_encoder(w, x, eps, temperature=1.0, S=64):
     """StyleEncoder.forward with use_vae (modules.py:289-302); `eps` is the
     injected N(0,1) sample that the reference draws with randn_like."""
-    out = style_encoder_attn(w, x)
+    out = style_encoder_gru(w, x) if "encoder.rnn_layer.weight_ih_l0" in w else style_encoder_attn(w, x)   # type
     mu, logvar = out[:, :S], out[:, S:]
     std = torch.exp(0.5 * logvar) / temperature
     return mu + eps * std, mu, logvar
@@ -232,6 +250,25 @@ def recurrent_step(w, pose, speech, style, state, prefix="recurrent_decoder."):
     return out, torch.stack([h0, h1], dim=0)
 
 
+def recurrent_step_film(w, pose, speech, style, state, prefix="recurrent_decoder."):
+    """RecurrentDecoderFiLM.forward (modules.py:213-227): gamma/beta from the style modulate both hidden layers."""
+    p = prefix
+    H = state.shape[-1]
+    gam = F.linear(style, w[p + "gammas_predictor.linear_layer.weight"], w[p + "gammas_predictor.linear_layer.bias"]) + 1
+    bet = F.linear(style, w[p + "betas_predictor.linear_layer.weight"], w[p + "betas_predictor.linear_layer.bias"])
+    x = torch.cat([pose, speech], dim=-1)
+    hid = F.elu(F.linear(x, w[p + "layer0.weight"], w[p + "layer0.bias"]))
+    hid = hid * gam[:, :H] + bet[:, :H]
+    h0 = gru_cell(torch.cat([hid, x], dim=-1), state[0], w[p + "layer1.weight_ih_l0"], w[p + "layer1.weight_hh_l0"],
+                  w[p + "layer1.bias_ih_l0"], w[p + "layer1.bias_hh_l0"])
+    h1 = gru_cell(h0, state[1], w[p + "layer1.weight_ih_l1"], w[p + "layer1.weight_hh_l1"],
+                  w[p + "layer1.bias_ih_l1"], w[p + "layer1.bias_hh_l1"])
+    h2 = F.elu(F.linear(h1, w[p + "layer2.weight"], w[p + "layer2.bias"]))
+    h2 = h2 * gam[:, H:] + bet[:, H:]
+    out = F.linear(h2, w[p + "layer3.weight"], w[p + "layer3.bias"])
+    return out, torch.stack([h0, h1], dim=0)
+
+
 def decoder_rollout(w, Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos, Z_ltxy, Z_lvel, Z_lvrt,
                     gaze_pos, speech, style, in_mean, in_std, out_mean, out_std, dt,
                     return_raw=False):
@@ -246,7 +283,8 @@ def decoder_rollout(w, Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos, Z
     raws = []
     for i in range(1, T):
         pose = vectorize_input(*cur, gaze_pos[:, i], in_mean, in_std)
-        pred, state = recurrent_step(w, pose, speech[:, i], style[:, i], state)
+        step = recurrent_step_film if "recurrent_decoder.layer3.weight" in w else recurrent_step   # rnn_cond
+        pred, state = step(w, pose, speech[:, i], style[:, i], state)
         raws.append(pred)
         cur = devectorize_output(pred, cur[0], cur[1], J, dt, out_mean, out_std)
         for o, c in zip(outs, cur):

@@ -573,3 +573,88 @@ def test_pose_to_bvh_vs_oracle_and_reference(golden_dir):
     qa = oanim.q_from_euler(np.radians(eul.cpu().numpy()))
     qb = oanim.q_from_euler(np.radians(gd["out_rotations"].astype(np.float64)))
     assert np.abs(np.abs(np.sum(qa * qb, axis=-1)) - 1.0).max() < 1e-9
+
+
+# ----------------------------------------------------------------------------- option-surface variants
+def _variant_nets():
+    """rnn_cond="film" decoder and type="gru" style encoder, seed 4321 in the golden's construction order"""
+    from zeggs import modules
+    torch.manual_seed(4321)
+    de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, 64, 64, 1024, 2, rnn_cond="film")
+    st = modules.StyleEncoder(synth.POSE_IN, 512, 64, type="gru", use_vae=True)
+    return de, st
+
+
+def test_film_decoder_forward_backward(golden_dir):
+    """RecurrentDecoderFiLM: forward vs the reference's rollout (variants.npz), inference ring path vs the same,
+    BPTT gradients vs the float64 oracle"""
+    gd = np.load(golden_dir / "variants.npz")
+    de, _ = _variant_nets()
+    for k, v in de.state_dict().items():
+        np.testing.assert_allclose(helpers.fingerprint(v), gd[f"fp_decoder.{k}"], rtol=1e-12, atol=0, err_msg=k)
+    s = helpers.stats_tensors()
+    t = lambda k: torch.as_tensor(gd[k])  # noqa: E731
+    fp = [t("in_" + k)[:, 0] for k in ("Y_root_pos", "Y_root_rot", "Y_root_vel", "Y_root_vrt", "Y_lpos", "Y_ltxy",
+                                       "Y_lvel", "Y_lvrt")]
+    gaze, speech, style = t("in_Y_gaze_pos"), t("in_speech"), t("in_style")
+    de_g = de.to(DEV).train()
+    stat = [g(s[k]) for k in ("in_mean", "in_std", "out_mean", "out_std")]
+    with torch.no_grad():      # ring path
+        out = de_g(*[g(x) for x in fp], g(gaze), g(speech), g(style), None, *stat, synth.DT)
+    for n, o in zip(NAMES, out):
+        assert float((o.cpu() - t("O_" + n)).abs().max()) < 1e-4, n
+    B, T = speech.shape[:2]
+    torch.manual_seed(3)
+    wts = [torch.randn(B, T, *o.shape[1:]) for o in fp]
+    s64 = {k: v.double() for k, v in s.items()}
+    w64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in de_g.state_dict().items()}
+    sp64, sy64 = speech.double().requires_grad_(True), style.double().requires_grad_(True)
+    O = onets.decoder_rollout(w64, *[x.double() for x in fp], gaze.double(), sp64, sy64, s64["in_mean"], s64["in_std"],
+                              s64["out_mean"], s64["out_std"], synth.DT)
+    sum((o * w.double()).sum() for o, w in zip(O, wts)).backward()
+    spg, syg = g(speech).requires_grad_(True), g(style).requires_grad_(True)
+    out = de_g(*[g(x) for x in fp], g(gaze), spg, syg, None, *stat, synth.DT)
+    for n, o, r in zip(NAMES, out, O):
+        assert float((o.detach().cpu().double() - r.detach()).abs().max()) < 1e-4, n
+        assert float((o.detach().cpu() - t("O_" + n)).abs().max()) < 1e-4, n      # training-mode path vs reference
+    sum((o * g(w)).sum() for o, w in zip(out, wts)).backward()
+    assert relerr(spg.grad, sp64.grad) < 3e-4
+    assert relerr(syg.grad, sy64.grad) < 3e-4
+    for k, p in de_g.named_parameters():
+        assert relerr(p.grad, w64[k].grad) < 3e-4, k
+
+
+def test_gru_style_encoder_forward_backward(golden_dir):
+    """StyleEncoderGRU (+VAE): forward vs the reference, gradients vs the float64 oracle"""
+    gd = np.load(golden_dir / "variants.npz")
+    _, st = _variant_nets()
+    for k, v in st.state_dict().items():
+        np.testing.assert_allclose(helpers.fingerprint(v), gd[f"fp_style.{k}"], rtol=1e-12, atol=0, err_msg=k)
+    s = helpers.stats_tensors()
+    ex = (torch.as_tensor(gd["in_example"]) - s["in_mean"]) / s["in_std"]
+    eps = torch.as_tensor(gd["in_eps"])
+    st_g = st.to(DEV).train()
+    exg = g(ex).requires_grad_(True)
+    z, mu, lv = st_g(exg, 1.0, eps=g(eps))
+    for a, k in ((z, "gru_z"), (mu, "gru_mu"), (lv, "gru_logvar")):
+        assert float((a.detach().cpu() - torch.as_tensor(gd[k])).abs().max()) < 2e-5, k
+    w64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in st_g.state_dict().items()}
+    z64, mu64, lv64 = onets.style_encoder(w64, ex.double(), eps.double(), 1.0)
+    torch.manual_seed(5)
+    wz, wm, wl = torch.randn_like(z64), torch.randn_like(z64), torch.randn_like(z64)
+    ((z64 * wz).sum() + (mu64 * wm).sum() + (lv64 * wl).sum()).backward()
+    ((z * g(wz.float())).sum() + (mu * g(wm.float())).sum() + (lv * g(wl.float())).sum()).backward()
+    for k, p in st_g.named_parameters():
+        assert relerr(p.grad, w64[k].grad) < 3e-4, k
+
+
+@pytest.mark.parametrize("L", [1, 2, 37])
+def test_gru_style_encoder_sequence_lengths(L):
+    """exemplars of 1 / 2 / odd lengths (the reverse direction always contributes exactly one step)"""
+    _, st = _variant_nets()
+    st_g = st.to(DEV).eval()
+    torch.manual_seed(L)
+    ex, eps = torch.randn(3, L, synth.POSE_IN), torch.randn(3, 64)
+    z, mu, lv = st_g(g(ex), 1.0, eps=g(eps))
+    z0, mu0, lv0 = onets.style_encoder(helpers.sd(st_g.cpu()), ex, eps, 1.0)
+    assert float((z.cpu() - z0).abs().max()) < 5e-5 and float((lv.cpu() - lv0).abs().max()) < 5e-5

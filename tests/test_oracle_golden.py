@@ -137,3 +137,28 @@ def test_oracle_dataset_indices_vs_reference(golden_dir):
         np.testing.assert_array_equal(rows, q[3:3 + nrows])
     assert ods.split_by_ratio(10, [0.5, 0.25, 0.25]) == [tuple(x) for x in g["split_10_3"]]
     assert ods.split_by_ratio(601, [0.3, 0.7]) == [tuple(x) for x in g["split_601"]]
+
+
+def test_oracle_variants_vs_reference(golden_dir):
+    """rnn_cond="film" decoder rollout and type="gru" style encoder of the oracle vs the reference (variants.npz)"""
+    from zeggs import modules
+    g = np.load(golden_dir / "variants.npz")
+    torch.manual_seed(4321)
+    de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, 64, 64, 1024, 2, rnn_cond="film")
+    st = modules.StyleEncoder(synth.POSE_IN, 512, 64, type="gru", use_vae=True)
+    for tag, net in (("decoder", de), ("style", st)):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(helpers.fingerprint(v), g[f"fp_{tag}.{k}"], rtol=1e-12, atol=0, err_msg=k)
+    s = helpers.stats_tensors()
+    t = lambda k: torch.as_tensor(g[k])  # noqa: E731
+    z, mu, logvar = onets.style_encoder(helpers.sd(st), (t("in_example") - s["in_mean"]) / s["in_std"], t("in_eps"), 1.0)
+    for a, k in ((z, "gru_z"), (mu, "gru_mu"), (logvar, "gru_logvar")):
+        np.testing.assert_allclose(a.numpy(), g[k], atol=5e-6, err_msg=k)
+    O = onets.decoder_rollout(
+        helpers.sd(de), t("in_Y_root_pos")[:, 0], t("in_Y_root_rot")[:, 0], t("in_Y_root_vel")[:, 0],
+        t("in_Y_root_vrt")[:, 0], t("in_Y_lpos")[:, 0], t("in_Y_ltxy")[:, 0], t("in_Y_lvel")[:, 0],
+        t("in_Y_lvrt")[:, 0], t("in_Y_gaze_pos"), t("in_speech"), t("in_style"),
+        s["in_mean"], s["in_std"], s["out_mean"], s["out_std"], synth.DT)
+    names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
+    for n, o in zip(names, O):
+        np.testing.assert_allclose(o.numpy(), g["O_" + n], atol=1e-5, rtol=1e-5, err_msg=n)

@@ -67,7 +67,7 @@ __global__ void dec_init_k(ZeggsDecDims d, ZeggsDecStats st, const float* pose0,
 // speech / style columns of x_t for one step (or all steps when nt > 1): Gin[t][b][H+PI ...]
 __global__ void dec_fill_cond_k(ZeggsDecDims d, const float* speech, const float* style, float* gin, int GL, int t0,
                                 int nt, long slot_stride, int ring) {
-  const int XC = d.SP + d.ST;
+  const int XC = d.SP + (d.film ? 0 : d.ST);
   long n = (long)nt * d.B * XC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % XC);
@@ -236,7 +236,7 @@ __global__ void copy_cols_k(float* dst, long ldd, const float* src, long lds, in
 
 // scatter time-major dX [T][B][XD] speech/style columns into batch-major outputs
 __global__ void dec_scatter_cond_grad_k(ZeggsDecDims d, const float* DX, int XD, float* dspeech, float* dstyle) {
-  const int XC = d.SP + d.ST;
+  const int XC = d.SP + (d.film ? 0 : d.ST);
   long n = (long)d.T * d.B * XC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % XC);
@@ -246,6 +246,48 @@ __global__ void dec_scatter_cond_grad_k(ZeggsDecDims d, const float* DX, int XD,
     float v = t == 0 ? 0.f : DX[((long)t * d.B + b) * XD + d.PI + c];
     if (c < d.SP) dspeech[((long)b * d.T + t) * d.SP + c] = v;
     else dstyle[((long)b * d.T + t) * d.ST + (c - d.SP)] = v;
+  }
+}
+// ---- FiLM (reference modules.py:213-225): out = a * (1 + gamma) + beta; all operands row-strided views
+__global__ void film_fwd_k(float* out, long ldo, const float* a, const float* gam, const float* bet, long ldg, int B,
+                           int H) {
+  long n = (long)B * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int u = (int)(i % H);
+    long b = i / H;
+    out[b * ldo + u] = a[i] * (1.f + gam[b * ldg + u]) + bet[b * ldg + u];
+  }
+}
+// g = grad wrt the modulated value -> dpre = g (1+gamma) ELU'(a) (a = ELU output), dgamma = g a, dbeta = g
+__global__ void film_bwd_k(const float* g, long ldgr, const float* a, const float* gam, long ldg, float* dpre,
+                           float* dgam, float* dbet, int B, int H) {
+  long n = (long)B * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int u = (int)(i % H);
+    long b = i / H;
+    const float gv = g[b * ldgr + u], av = a[i];
+    dpre[i] = gv * (1.f + gam[b * ldg + u]) * d_elu_grad_from_out(av);
+    dgam[b * ldg + u] = gv * av;
+    dbet[b * ldg + u] = gv;
+  }
+}
+// batch-major style [B,T,ST] <-> time-major [T,B,ST]
+__global__ void style_time_major_k(ZeggsDecDims d, const float* style, float* stm) {
+  long n = (long)d.T * d.B * d.ST;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % d.ST);
+    long r = i / d.ST;
+    int b = (int)(r % d.B), t = (int)(r / d.B);
+    stm[i] = style[((long)b * d.T + t) * d.ST + c];
+  }
+}
+__global__ void style_grad_from_time_major_k(ZeggsDecDims d, const float* dstm, float* dstyle) {
+  long n = (long)d.T * d.B * d.ST;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % d.ST);
+    long r = i / d.ST;
+    int b = (int)(r % d.B), t = (int)(r / d.B);
+    dstyle[((long)b * d.T + t) * d.ST + c] = t == 0 ? 0.f : dstm[i];
   }
 }
 __global__ void add_style0_grad_k(ZeggsDecDims d, const float* dcse_in, float* dstyle) {
@@ -264,8 +306,20 @@ int dec_recurrent_wgrads(const ZeggsDecDims& d, const DecWs& w, const ZeggsDecGr
   const long sG = (long)B * GL, sH = (long)B * H, s3 = 3 * sH, sY = (long)B * POL;
   const int M = (t_hi - t_lo + 1) * B;
   const long o = t_lo;
-  ZTRY(gemm_tn(w.DY + o * sY, POL, w.H1 + o * sH, H, G->l2_w, H, M, d.PO, H, beta, s));
-  ZTRY(k_colsum(G->l2_b, w.DY + o * sY, M, d.PO, POL, beta, s));
+  if (d.film) {
+    const long sg = (long)B * 2 * H, sS = (long)B * d.ST;
+    ZTRY(gemm_tn(w.DY + o * sY, POL, w.F2 + o * sH, H, G->l3_w, H, M, d.PO, H, beta, s));
+    ZTRY(k_colsum(G->l3_b, w.DY + o * sY, M, d.PO, POL, beta, s));
+    ZTRY(gemm_tn(w.D2 + o * sH, H, w.H1 + o * sH, H, G->l2_w, H, M, H, H, beta, s));
+    ZTRY(k_colsum(G->l2_b, w.D2 + o * sH, M, H, H, beta, s));
+    ZTRY(gemm_tn(w.DGAM + o * sg, 2 * H, w.STm + o * sS, d.ST, G->g_w, d.ST, M, 2 * H, d.ST, beta, s));
+    ZTRY(k_colsum(G->g_b, w.DGAM + o * sg, M, 2 * H, 2 * H, beta, s));
+    ZTRY(gemm_tn(w.DBET + o * sg, 2 * H, w.STm + o * sS, d.ST, G->be_w, d.ST, M, 2 * H, d.ST, beta, s));
+    ZTRY(k_colsum(G->be_b, w.DBET + o * sg, M, 2 * H, 2 * H, beta, s));
+  } else {
+    ZTRY(gemm_tn(w.DY + o * sY, POL, w.H1 + o * sH, H, G->l2_w, H, M, d.PO, H, beta, s));
+    ZTRY(k_colsum(G->l2_b, w.DY + o * sY, M, d.PO, POL, beta, s));
+  }
   ZTRY(gemm_tn(w.DI1 + o * s3, 3 * H, w.H0 + o * sH, H, G->w_ih1, H, M, 3 * H, H, beta, s));
   ZTRY(gemm_tn(w.DH1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, M, 3 * H, H, beta, s));
   ZTRY(k_colsum(G->b_ih1, w.DI1 + o * s3, M, 3 * H, 3 * H, beta, s));
@@ -336,6 +390,13 @@ extern "C" int zeggs_decoder_fwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
     hipLaunchKernelGGL(dec_fill_cond_k, g1((long)(T - 1) * B * (d.SP + d.ST)), dim3(256), 0, s, d, speech, style, w.Gin,
                        GL, 1, T - 1, sG, 0);
     ZLAUNCH_CHECK("dec_fill_cond");
+    if (d.film) {   // modulation vectors of every step in two GEMMs over the time-major style
+      ZCHECK(P->l3_w && P->l3_b && P->g_w && P->g_b && P->be_w && P->be_b, "decoder: film parameters missing");
+      hipLaunchKernelGGL(style_time_major_k, g1((long)T * B * d.ST), dim3(256), 0, s, d, style, w.STm);
+      ZLAUNCH_CHECK("style_time_major");
+      ZTRY(gemm_nt(w.STm, d.ST, P->g_w, d.ST, w.GAM, 2 * H, P->g_b, T * B, 2 * H, d.ST, ACT_NONE, 0.f, s));
+      ZTRY(gemm_nt(w.STm, d.ST, P->be_w, d.ST, w.BET, 2 * H, P->be_b, T * B, 2 * H, d.ST, ACT_NONE, 0.f, s));
+    }
   }
   const bool fast = g_decoder_fast && dec_fast_supported(d);
   if (fast) {
@@ -358,8 +419,24 @@ extern "C" int zeggs_decoder_fwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
                          1, sG, 1);
       ZLAUNCH_CHECK("dec_fill_cond");
     }
-    // hid = ELU(layer0(x))
-    ZTRY(gemm_nt(gin + H, GL, P->l0_w, XD, gin, GL, P->l0_b, B, H, XD, ACT_ELU, 0.f, s));
+    // hid = ELU(layer0(x))   [film: modulated by the style]
+    const float *gam = nullptr, *bet = nullptr;
+    if (d.film) {
+      if (!training) {   // ring path: this step's modulation vectors from style[:, t]
+        ZCHECK(P->l3_w && P->l3_b && P->g_w && P->g_b && P->be_w && P->be_b, "decoder: film parameters missing");
+        ZTRY(gemm_nt(style + (long)t * d.ST, (long)T * d.ST, P->g_w, d.ST, w.GAM, 2 * H, P->g_b, B, 2 * H, d.ST, ACT_NONE,
+                     0.f, s));
+        ZTRY(gemm_nt(style + (long)t * d.ST, (long)T * d.ST, P->be_w, d.ST, w.BET, 2 * H, P->be_b, B, 2 * H, d.ST, ACT_NONE,
+                     0.f, s));
+      }
+      gam = w.GAM + (training ? (long)t * B * 2 * H : 0);
+      bet = w.BET + (training ? (long)t * B * 2 * H : 0);
+      float* a0 = w.A0 + slot(t) * sH;
+      ZTRY(gemm_nt(gin + H, GL, P->l0_w, XD, a0, H, P->l0_b, B, H, XD, ACT_ELU, 0.f, s));
+      hipLaunchKernelGGL(film_fwd_k, g1(sH), dim3(256), 0, s, gin, (long)GL, a0, gam, bet, (long)2 * H, B, H);
+    } else {
+      ZTRY(gemm_nt(gin + H, GL, P->l0_w, XD, gin, GL, P->l0_b, B, H, XD, ACT_ELU, 0.f, s));
+    }
     // GRU layer 0
     ZTRY(gemm_nt(gin, GL, P->w_ih0, H + XD, w.gi, 3 * H, P->b_ih0, B, 3 * H, H + XD, ACT_NONE, 0.f, s));
     ZTRY(gemm_nt(h0p, H, P->w_hh0, H, w.gh, 3 * H, P->b_hh0, B, 3 * H, H, ACT_NONE, 0.f, s));
@@ -374,7 +451,14 @@ extern "C" int zeggs_decoder_fwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
                        training ? w.Z1 + o : nullptr, training ? w.N1 + o : nullptr, training ? w.NH1 + o : nullptr,
                        B, H);
     // output projection + pose integration
-    ZTRY(gemm_nt(h1, H, P->l2_w, H, w.Y, w.POL, P->l2_b, B, d.PO, H, ACT_NONE, 0.f, s));
+    if (d.film) {
+      float *a2 = w.A2 + slot(t) * sH, *f2 = w.F2 + slot(t) * sH;
+      ZTRY(gemm_nt(h1, H, P->l2_w, H, a2, H, P->l2_b, B, H, H, ACT_ELU, 0.f, s));
+      hipLaunchKernelGGL(film_fwd_k, g1(sH), dim3(256), 0, s, f2, (long)H, a2, gam + H, bet + H, (long)2 * H, B, H);
+      ZTRY(gemm_nt(f2, H, P->l3_w, H, w.Y, w.POL, P->l3_b, B, d.PO, H, ACT_NONE, 0.f, s));
+    } else {
+      ZTRY(gemm_nt(h1, H, P->l2_w, H, w.Y, w.POL, P->l2_b, B, d.PO, H, ACT_NONE, 0.f, s));
+    }
     hipLaunchKernelGGL(dec_devec_k, dim3(B), dim3(256), 0, s, d, *st, w.Y, w.POL, gaze, pose, rpos, rrot, gin_next, GL,
                        t);
     ZLAUNCH_CHECK("dec_step");
@@ -428,8 +512,16 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
     hipLaunchKernelGGL(dec_devec_bwd_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, dxn, XD, gaze, pose, rpos,
                        rrot, w.carry, dy, POL, t);
     ZLAUNCH_CHECK("dec_devec_bwd");
-    // dH1 total = dy W2 + carried
-    ZTRY(gemm_nn(dy, POL, P->l2_w, H, w.dH1c, H, B, d.PO, H, 1.f, s));
+    // dH1 total = dy W2 + carried   [film: through layer3, the modulation and layer2]
+    if (d.film) {
+      const long og = (long)t * B * 2 * H;
+      ZTRY(gemm_nn(dy, POL, P->l3_w, H, w.dF2, H, B, d.PO, H, 0.f, s));
+      hipLaunchKernelGGL(film_bwd_k, g1(sH), dim3(256), 0, s, w.dF2, (long)H, w.A2 + o, w.GAM + og + H, (long)2 * H,
+                         w.D2 + o, w.DGAM + og + H, w.DBET + og + H, B, H);
+      ZTRY(gemm_nn(w.D2 + o, H, P->l2_w, H, w.dH1c, H, B, H, H, 1.f, s));
+    } else {
+      ZTRY(gemm_nn(dy, POL, P->l2_w, H, w.dH1c, H, B, d.PO, H, 1.f, s));
+    }
     hipLaunchKernelGGL(gru_gate_bwd_k, g1(sH), dim3(256), 0, s, w.dH1c, w.R1 + o, w.Z1 + o, w.N1 + o, w.NH1 + o,
                        w.H1 + o - sH, w.DI1 + t * s3, w.DH1 + t * s3, w.t0, B, H);
     // t0 = dH1 * z (direct path); dH1c <- t0 + DH1 W_hh1 ; dH0 total = dH0c + DI1 W_ih1
@@ -442,7 +534,13 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
     ZTRY(gemm_nn(w.DH0 + t * s3, 3 * H, P->w_hh0, H, w.dH0c, H, B, 3 * H, H, 1.f, s));
     // dGin = DI0 W_ih0 -> [dhid | dx]
     ZTRY(gemm_nn(w.DI0 + t * s3, 3 * H, P->w_ih0, H + XD, w.dGin, GL, B, 3 * H, H + XD, 0.f, s));
-    hipLaunchKernelGGL(elu_bwd_rows_k, g1(sH), dim3(256), 0, s, w.D0 + o, w.dGin, gin, B, H, GL);
+    if (d.film) {
+      const long og = (long)t * B * 2 * H;
+      hipLaunchKernelGGL(film_bwd_k, g1(sH), dim3(256), 0, s, w.dGin, (long)GL, w.A0 + o, w.GAM + og, (long)2 * H,
+                         w.D0 + o, w.DGAM + og, w.DBET + og, B, H);
+    } else {
+      hipLaunchKernelGGL(elu_bwd_rows_k, g1(sH), dim3(256), 0, s, w.D0 + o, w.dGin, gin, B, H, GL);
+    }
     // dx_t = dGin[:, H:] + D0 W0
     float* dx = w.DX + (long)t * B * XD;
     hipLaunchKernelGGL(copy_cols_k, g1((long)B * XD), dim3(256), 0, s, dx, (long)XD, w.dGin, (long)GL, H, XD, B);
@@ -473,6 +571,12 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   }
   hipLaunchKernelGGL(dec_scatter_cond_grad_k, g1((long)T * B * (d.SP + d.ST)), dim3(256), 0, s, d, w.DX, XD, dspeech,
                      dstyle);
+  if (d.film) {   // the style reaches the steps through the two predictors only
+    const long M1 = (long)(T - 1) * B, sg = (long)B * 2 * H, sS = (long)B * d.ST;
+    ZTRY(gemm_nn(w.DGAM + sg, 2 * H, P->g_w, d.ST, w.dSTm + sS, d.ST, (int)M1, 2 * H, d.ST, 0.f, s));
+    ZTRY(gemm_nn(w.DBET + sg, 2 * H, P->be_w, d.ST, w.dSTm + sS, d.ST, (int)M1, 2 * H, d.ST, 1.f, s));
+    hipLaunchKernelGGL(style_grad_from_time_major_k, g1((long)T * B * d.ST), dim3(256), 0, s, d, w.dSTm, dstyle);
+  }
   hipLaunchKernelGGL(add_style0_grad_k, g1((long)B * d.ST), dim3(256), 0, s, d, w.t1, dstyle);
   ZLAUNCH_CHECK("dec_bwd_tail");
   if (wgrads_done) ZCHECK(hipStreamWaitEvent(s, ss->done, 0) == hipSuccess, "hipStreamWaitEvent failed");   // join

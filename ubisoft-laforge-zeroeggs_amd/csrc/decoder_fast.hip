@@ -708,7 +708,7 @@ StageArgs base_args(const ZeggsDecDims& d, const ZeggsDecStats* st, const DecWs&
 
 }  // namespace
 
-int dec_fast_supported(const ZeggsDecDims& d) { return d.H % 16 == 0 && d.B <= 64 && d.PI == d.PO + 3 && d.PO >= 16; }
+int dec_fast_supported(const ZeggsDecDims& d) { return !d.film && d.H % 16 == 0 && d.B <= 64 && d.PI == d.PO + 3 && d.PO >= 16; }
 
 int dec_fast_pack_fwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s) {
   const int H = d.H, XD = w.XD;

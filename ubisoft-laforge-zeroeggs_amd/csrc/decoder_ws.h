@@ -14,6 +14,8 @@ struct DecWs {
   float *DY, *DI0, *DH0, *DI1, *DH1, *D0, *DX;
   float *dH0c, *dH1c, *dGin, *dXn, *carry, *t0, *t1;
   int GL, XD, POL;
+  // FiLM variant (d.film): pre-modulation activations, modulation vectors and their gradients, time-major
+  float *A0, *A2, *F2, *GAM, *BET, *DGAM, *DBET, *D2, *dF2, *STm, *dSTm;
   // ---- fast path: fragment-packed weights (see decoder_fast.hip) and activations
   int NB, nT5, nTH, nTX, nTPO, nTGI, KBH, KBX, KBPO, KB3H;
   float *pw_l0, *pw_ih0h, *pw_ih0x, *pw_hh0, *pw_ih1, *pw_hh1, *pw_l2;   // forward packs
@@ -33,7 +35,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
   DecWs w;
   memset(&w, 0, sizeof(w));
   const long B = d.B, T = d.T, H = d.H;
-  w.XD = d.PI + d.SP + d.ST;
+  w.XD = d.PI + d.SP + (d.film ? 0 : d.ST);   // film: the style is not part of the step input
   w.GL = round4(d.H + w.XD);
   w.POL = round4(d.PO);
   const long TS = training ? T : 2;   // inference keeps a 2-slot ring for the step buffers
@@ -56,6 +58,15 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
     w.dXn = a.f(B * (long)w.XD);
     w.carry = a.f(B * 8);
     w.t0 = a.f(B * 2 * H); w.t1 = a.f(B * (long)(d.PI + d.ST + 2 * H));
+  }
+  if (d.film) {
+    w.A0 = a.f(TS * B * H); w.A2 = a.f(TS * B * H); w.F2 = a.f(TS * B * H);
+    w.GAM = a.f(TS * B * 2 * H); w.BET = a.f(TS * B * 2 * H);
+    if (training) {
+      w.DGAM = a.f(T * B * 2 * H); w.DBET = a.f(T * B * 2 * H); w.D2 = a.f(T * B * H); w.dF2 = a.f(B * H);
+      w.STm = a.f(T * B * (long)d.ST); w.dSTm = a.f(T * B * (long)d.ST);
+    }
+    return w;   // the fragment-packed fast path covers rnn_cond "normal" only
   }
   // ---- fast path
   w.NB = (d.B + 15) / 16;

@@ -33,6 +33,22 @@ class _RecurrentDecoderNormal(nn.Module):
         self.layer2 = nn.Linear(hidden_size, output_size)
 
 
+class _RecurrentDecoderFiLM(nn.Module):
+    """Parameters of reference RecurrentDecoderFiLM (modules.py:188-211): the style modulates the two hidden layers
+    (feature-wise affine, gamma/beta predicted from the style) instead of entering the step input."""
+
+    def __init__(self, pose_input_size, speech_size, style_size, output_size, hidden_size, num_rnn_layers):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.gammas_predictor = LinearNorm(style_size, hidden_size * 2, w_init_gain="linear")
+        self.betas_predictor = LinearNorm(style_size, hidden_size * 2, w_init_gain="linear")
+        self.layer0 = nn.Linear(pose_input_size + speech_size, hidden_size)
+        self.layer1 = nn.GRU(pose_input_size + speech_size + hidden_size, hidden_size, num_rnn_layers,
+                             batch_first=True, dropout=0.0)
+        self.layer2 = nn.Linear(hidden_size, hidden_size)
+        self.layer3 = nn.Linear(hidden_size, output_size)
+
+
 class CellStateEncoder(nn.Module):
     """Parameters of reference CellStateEncoder (modules.py:230-236)."""
 
@@ -99,6 +115,21 @@ class StyleEncoderAttn(nn.Module):
         self.blocks = nn.ModuleList([_FFTBlock(style_embedding_size)])
 
 
+class StyleEncoderGRU(nn.Module):
+    """Parameters of reference StyleEncoderGRU (modules.py:307-337)."""
+
+    def __init__(self, input_size, hidden_size, style_embedding_size):
+        super().__init__()
+        self.convs = nn.Sequential(
+            ConvNorm1D(input_size, hidden_size, kernel_size=3, stride=1, padding=1, dilation=1, w_init_gain="relu"),
+            nn.ReLU(),
+            ConvNorm1D(hidden_size, hidden_size, kernel_size=3, stride=1, padding=1, dilation=1, w_init_gain="relu"),
+            nn.ReLU(),
+        )
+        self.rnn_layer = nn.GRU(hidden_size, hidden_size, 1, batch_first=True, bidirectional=True)
+        self.projection_layer = LinearNorm(hidden_size * 2, style_embedding_size, w_init_gain="linear")
+
+
 # ----------------------------------------------------------------------------
 # public modules
 # ----------------------------------------------------------------------------
@@ -130,14 +161,18 @@ class StyleEncoder(nn.Module):
         self.use_vae = use_vae
         self.style_embedding_size = style_embedding_size
         output_size = 2 * style_embedding_size if use_vae else style_embedding_size
-        if type == "attn":
+        if type == "gru":
+            self.encoder = StyleEncoderGRU(input_size, hidden_size, output_size)
+        elif type == "attn":
             self.encoder = StyleEncoderAttn(input_size, hidden_size, output_size)
         else:
-            raise NotImplementedError(
-                f"style encoder type {type!r}: only 'attn' (the shipped default) has a HIP path yet")
+            raise ValueError(f"unknown style encoder type {type!r}")
 
     def forward(self, input, temprature: float = 1.0, eps=None):
-        out = ops.style_encoder_attn(input, self.encoder, self.training)
+        if isinstance(self.encoder, StyleEncoderGRU):
+            out = ops.style_encoder_gru(input, self.encoder)
+        else:
+            out = ops.style_encoder_attn(input, self.encoder, self.training)
         if not self.use_vae:
             return out, None, None
         S = self.style_embedding_size
@@ -152,14 +187,16 @@ class Decoder(nn.Module):
     def __init__(self, pose_input_size, pose_output_size, speech_encoding_size, style_encoding_size,
                  hidden_size, num_rnn_layers, rnn_cond="normal"):
         super().__init__()
-        if rnn_cond != "normal":
-            raise NotImplementedError("rnn_cond='film' is unreachable from the reference train() "
-                                      "(train.py:124-131) and has no HIP path yet")
         if num_rnn_layers != 2:
             raise NotImplementedError("the reference hard-codes 2 GRU layers (train.py:130)")
-        self.recurrent_decoder = _RecurrentDecoderNormal(
-            pose_input_size, speech_encoding_size, style_encoding_size, pose_output_size,
-            hidden_size, num_rnn_layers)
+        if rnn_cond == "normal":
+            cls = _RecurrentDecoderNormal
+        elif rnn_cond == "film":          # generic per-step GEMM path (the fragment-packed fast path is "normal" only)
+            cls = _RecurrentDecoderFiLM
+        else:
+            raise ValueError(f"unknown rnn_cond {rnn_cond!r}")
+        self.recurrent_decoder = cls(pose_input_size, speech_encoding_size, style_encoding_size, pose_output_size,
+                                     hidden_size, num_rnn_layers)
         self.cell_state_encoder = CellStateEncoder(pose_input_size + style_encoding_size,
                                                    hidden_size, num_rnn_layers)
 
@@ -175,6 +212,7 @@ class Decoder(nn.Module):
 # names under which the reference pickles its sub-modules (`torch.save(module)` stores the class path
 # `modules.<Class>`); zeggs.compat maps that module name here so reference checkpoints load into this engine
 RecurrentDecoderNormal = _RecurrentDecoderNormal
+RecurrentDecoderFiLM = _RecurrentDecoderFiLM
 FFTBlock = _FFTBlock
 MultiHeadAttention = _MultiHeadAttention
 PositionWiseConvFF = _PositionWiseConvFF

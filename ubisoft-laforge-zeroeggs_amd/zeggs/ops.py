@@ -34,7 +34,7 @@ class StyleDims(C.Structure):
 
 class DecDims(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("PI", C.c_int), ("PO", C.c_int), ("SP", C.c_int), ("ST", C.c_int),
-                ("H", C.c_int), ("dt", C.c_float)]
+                ("H", C.c_int), ("dt", C.c_float), ("film", C.c_int)]
 
 
 class LossDims(C.Structure):
@@ -49,7 +49,8 @@ SPEECH_FIELDS = ("w0", "b0", "w1", "b1", "w2", "b2")
 STYLE_FIELDS = ("c0_w", "c0_b", "ln0_g", "ln0_b", "c4_w", "c4_b", "ln1_g", "ln1_b", "in_w", "in_b", "out_w", "out_b",
                 "lna_g", "lna_b", "ff0_w", "ff0_b", "ff2_w", "ff2_b", "lnf_g", "lnf_b")
 DEC_FIELDS = ("l0_w", "l0_b", "w_ih0", "w_hh0", "b_ih0", "b_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1", "l2_w", "l2_b",
-              "c0_w", "c0_b", "c1_w", "c1_b", "c2_w", "c2_b")
+              "c0_w", "c0_b", "c1_w", "c1_b", "c2_w", "c2_b",
+              "l3_w", "l3_b", "g_w", "g_b", "be_w", "be_b")          # last six: rnn_cond "film" only (else NULL)
 SpeechPtrs = _ptr_struct("SpeechPtrs", SPEECH_FIELDS)
 StylePtrs = _ptr_struct("StylePtrs", STYLE_FIELDS)
 DecPtrs = _ptr_struct("DecPtrs", DEC_FIELDS)
@@ -235,6 +236,53 @@ class _StyleFn(torch.autograd.Function):
         return (None, None, None, None, None, *grads)
 
 
+STYLE_GRU_FIELDS = ("c0_w", "c0_b", "c2_w", "c2_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_ih_r", "w_hh_r", "b_ih_r",
+                    "b_hh_r", "p_w", "p_b")
+StyleGruPtrs = _ptr_struct("StyleGruPtrs", STYLE_GRU_FIELDS)
+
+
+class StyleGruDims(C.Structure):       # mirrors ZeggsStyleGruDims
+    _fields_ = [("B", C.c_int), ("L", C.c_int), ("C", C.c_int), ("H", C.c_int), ("O", C.c_int)]
+
+
+class _StyleGruFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, *params):
+        x = _f32c(x)
+        params = [_f32c(t) for t in params]
+        B, Lx, Cx = x.shape
+        d = StyleGruDims(B, Lx, Cx, params[0].shape[0], params[12].shape[0])
+        L = lib()
+        L.zeggs_style_encoder_gru_workspace_bytes.restype = C.c_size_t
+        ws = _ws(L.zeggs_style_encoder_gru_workspace_bytes(C.byref(d)), x.device)
+        out = torch.empty(B, d.O, device=x.device, dtype=torch.float32)
+        P = _ptrs(StyleGruPtrs, STYLE_GRU_FIELDS, params)
+        _check(L.zeggs_style_encoder_gru_fwd(C.byref(d), C.byref(P), _p(x), _p(out), _p(ws), C.c_size_t(ws.numel()),
+                                             _stream()), "style_encoder_gru_fwd")
+        ctx.d, ctx.ws = d, ws
+        ctx.save_for_backward(*params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        params = list(ctx.saved_tensors)
+        grads = [torch.empty_like(t) for t in params]
+        P = _ptrs(StyleGruPtrs, STYLE_GRU_FIELDS, params)
+        G = _ptrs(StyleGruPtrs, STYLE_GRU_FIELDS, grads)
+        _check(lib().zeggs_style_encoder_gru_bwd(C.byref(ctx.d), C.byref(P), _p(_f32c(dout)), C.byref(G), _p(ctx.ws),
+                                                 C.c_size_t(ctx.ws.numel()), _stream()), "style_encoder_gru_bwd")
+        return (None, *grads)
+
+
+def style_encoder_gru(x, enc):
+    """StyleEncoderGRU.forward (reference modules.py:339-343) on the HIP engine"""
+    g, pl = enc.rnn_layer, enc.projection_layer.linear_layer
+    return _StyleGruFn.apply(x, enc.convs[0].conv.weight, enc.convs[0].conv.bias, enc.convs[2].conv.weight,
+                             enc.convs[2].conv.bias, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
+                             g.weight_ih_l0_reverse, g.weight_hh_l0_reverse, g.bias_ih_l0_reverse, g.bias_hh_l0_reverse,
+                             pl.weight, pl.bias)
+
+
 def style_encoder_attn(x, enc, training):
     pos = positional_table(x.shape[1], enc.convs[6].normalized_shape[0], x.device)
     return _StyleFn.apply(x, pos, 1 if training else 0, next_seed() if training else 0, 4, *style_param_list(enc))
@@ -270,9 +318,14 @@ def vae_reparam(enc, eps, temperature, S):
 def decoder_param_list(dec):
     r, c = dec.recurrent_decoder, dec.cell_state_encoder
     g = r.layer1
-    return [r.layer0.weight, r.layer0.bias, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
-            g.weight_ih_l1, g.weight_hh_l1, g.bias_ih_l1, g.bias_hh_l1, r.layer2.weight, r.layer2.bias,
-            c.layer0.weight, c.layer0.bias, c.layer1.weight, c.layer1.bias, c.layer2.weight, c.layer2.bias]
+    ps = [r.layer0.weight, r.layer0.bias, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
+          g.weight_ih_l1, g.weight_hh_l1, g.bias_ih_l1, g.bias_hh_l1, r.layer2.weight, r.layer2.bias,
+          c.layer0.weight, c.layer0.bias, c.layer1.weight, c.layer1.bias, c.layer2.weight, c.layer2.bias]
+    if hasattr(r, "gammas_predictor"):      # RecurrentDecoderFiLM
+        ps += [r.layer3.weight, r.layer3.bias, r.gammas_predictor.linear_layer.weight,
+               r.gammas_predictor.linear_layer.bias, r.betas_predictor.linear_layer.weight,
+               r.betas_predictor.linear_layer.bias]
+    return ps
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -286,7 +339,7 @@ class _DecoderFn(torch.autograd.Function):
         ST, PO = style.shape[2], pose0.shape[1]
         # needs_input_grad ignores torch.no_grad(): the caller's grad mode selects the BPTT workspace / ring path
         training = bool(grad_mode) and any(ctx.needs_input_grad)
-        d = DecDims(B, T, PO + 3, PO, SP, ST, H, float(dt))
+        d = DecDims(B, T, PO + 3, PO, SP, ST, H, float(dt), 1 if len(params) == len(DEC_FIELDS) else 0)
         L = lib()
         ws = _ws(L.zeggs_decoder_workspace_bytes(C.byref(d), int(training)), pose0.device)
         dev = pose0.device
@@ -326,7 +379,7 @@ class _DecoderFn(torch.autograd.Function):
 
 def decoder_core(dec, pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt):
     """-> pose [B,T,PO] (de-normalised output vectors), rpos [B,T,3], rrot [B,T,4]"""
-    H = dec.recurrent_decoder.layer2.in_features
+    H = dec.recurrent_decoder.layer1.hidden_size
     return _DecoderFn.apply(pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt, H,
                             torch.is_grad_enabled(), *decoder_param_list(dec))
 
