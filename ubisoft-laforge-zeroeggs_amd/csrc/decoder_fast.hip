@@ -73,6 +73,19 @@ __device__ __forceinline__ long xf_index(int b, int k, int NB) {
   return ((((long)(k >> 4) * NB + (b >> 4)) * 64 + ((((k >> 2) & 3) << 4) | (b & 15))) << 2) | (k & 3);
 }
 
+// limiter experiments (tools/stage_bench.py with an alternative build): -DZEGGS_NOX re-reads ONE activation block
+// (no activation traffic), -DZEGGS_NOMFMA replaces the matrix op by one VALU add (results are garbage, timing only)
+#ifdef ZEGGS_NOX
+#define ZXSEL(kb) ((kb) & 0)
+#else
+#define ZXSEL(kb) (kb)
+#endif
+#ifdef ZEGGS_NOMFMA
+#define ZMAC(A, w, x) A[0] += (w) + (x)
+#else
+#define ZMAC(A, w, x) A = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x, A, 0, 0, 0)
+#endif
+
 template <int NB>   // NB here = batch blocks handled by this workgroup; LNB = batch blocks in the fragment layout
 __device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* __restrict__ xp, int lo, int hi,
                                            f4 (&acc)[NB], int LNB) {
@@ -89,13 +102,13 @@ __device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* 
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                                              \
     const long kb_ = lo + (long)(G) * U + u;                                                   \
     W[u] = wp[kb_ * 64];                                                                       \
-    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) X[u][nb] = xp[(kb_ * LNB + nb) * 64];      \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) X[u][nb] = xp[(ZXSEL(kb_) * LNB + nb) * 64];      \
   }
 #define ZCOMP(W, X)                                                                            \
   _Pragma("unroll") for (int u = 0; u < U; ++u)                                                \
     _Pragma("unroll") for (int c = 0; c < 4; ++c)                                              \
       _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                        \
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u][c], X[u][nb][c], acc[nb], 0, 0, 0);
+        ZMAC(acc[nb], W[u][c], X[u][nb][c]);
   if (ng > 0) {
     ZLOAD(w0, x0, 0)
     int g = 0;
