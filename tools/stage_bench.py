@@ -48,7 +48,7 @@ def timed(args, train, reps=3):
 
 
 A64, A192 = make(64), make(192)
-NAMES = {0: "default", 4096: "4 launches/step"}
+NAMES = {0: "default", 4096 + 8192: "4+4 launches/step"}
 for v, name in NAMES.items():
     ops.set_option("stage_variant", v)
     for train in (False, True):

@@ -479,13 +479,13 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   const long sG = (long)B * GL, sH = (long)B * H, s3 = 3 * sH;
   ZTRY(k_fill(w.dH0c, sH, 0.f, s));
   ZTRY(k_fill(w.dH1c, sH, 0.f, s));
-  ZTRY(k_fill(w.carry, (long)B * 8, 0.f, s));
+  ZTRY(k_fill(w.carry, (long)2 * B * 8, 0.f, s));
   ZTRY(k_fill(w.DX, (long)B * XD, 0.f, s));          // slot t = 0 unused but read by the scatter
   ZCHECK(T > 1, "decoder bwd: T must be > 1");
   bool wgrads_done = false;
   SideStream* ss = nullptr;
   if (g_decoder_fast && dec_fast_supported(d)) {
-    ZTRY(dec_fast_pack_bwd(d, P, w, s));
+    ZTRY(dec_fast_pack_bwd(d, P, st, w, s));
     // The sweep is a chain of small dependent launches that leaves most of the chip idle; the weight-gradient
     // GEMMs of the steps already swept run beside it on a low-priority stream, chunk by chunk.
     const int nch = g_bwd_chunks < T - 1 ? g_bwd_chunks : T - 1;

@@ -29,7 +29,7 @@ namespace {
 
 enum { V_NOX = 1, V_NOW = 2, V_NOEPI = 4, V_NOMFMA = 8, V_ROT = 16 };
 
-enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_HID_MERGED, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX };
+enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_HID_MERGED, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX, EPI_GRU_BWD_M };
 
 struct Seg {
   const float* w;   // packed weights  [tile][kb][64][4]
@@ -54,7 +54,10 @@ struct StageArgs {
   float *pose, *rpos, *rrot;               // forward outputs
   const float *cpose, *crpos, *crrot;      // backward: forward results
   const float *dpose, *drpos, *drrot;      // backward: loss gradients
-  float* carry;                            // [B,8] root-state gradient carry
+  float* carry;                            // [B,8] root-state gradient carry (read)
+  float* carry_out;                        // [B,8] carry written by this launch (double-buffered: other workgroups read `carry`)
+  const float *aux0, *aux1;                // merged backward stage: dXa [B,XD], layer2 weight [PO,H]
+  float* rxf;                              // DGIN epilogue: fragment of r = sigma_o dpose[t-1] + (sigma_o/sigma_i) dXa (pose columns >= 6)
   int variant;                             // ablation switches (tools/stage_bench.py); 0 in production
   int gemv;                                // 1: tiny-batch decode, VALU dot products over canonical activations
   // speech/style columns of x_{t+1}, staged by the GRU layer-1 launch (all null: nothing to stage)
@@ -138,8 +141,8 @@ __device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* 
 // g6: in = dpose[f][0:6] + dx/sigma_i (when a next step exists); out = total grad wrt pose[f][0:6] (de-normalised).
 __device__ void root_bwd(const ZeggsDecDims& d, const ZeggsDecStats& st, int b, int f, bool has_next, const float* dgd_in,
                          const float* gaze, const float* pose, const float* rpos, const float* rrot, const float* drpos,
-                         const float* drrot, float* carry, float (&g6)[6]) {
-  float* cr = carry + b * 8;
+                         const float* drrot, const float* carry, float* carry_out, float (&g6)[6]) {
+  const float* cr = carry + b * 8;
   const float* a = drpos + ((long)b * d.T + f) * 3;
   const float* e = drrot + ((long)b * d.T + f) * 4;
   V3 g_rp = v3(cr[0] + a[0], cr[1] + a[1], cr[2] + a[2]);
@@ -171,9 +174,12 @@ __device__ void root_bwd(const ZeggsDecDims& d, const ZeggsDecStats& st, int b, 
   qmv_bwd(q_p, d.dt * vrt, du, dq2, dv2);
   g6[0] += d.dt * dv1.x; g6[1] += d.dt * dv1.y; g6[2] += d.dt * dv1.z;
   g6[3] += d.dt * dv2.x; g6[4] += d.dt * dv2.y; g6[5] += d.dt * dv2.z;
-  cr[0] = g_rp.x; cr[1] = g_rp.y; cr[2] = g_rp.z;
-  cr[3] = dq1.w + dqy.w + dq2.w; cr[4] = dq1.x + dqy.x + dq2.x;
-  cr[5] = dq1.y + dqy.y + dq2.y; cr[6] = dq1.z + dqy.z + dq2.z;
+  if (carry_out) {
+    float* co = carry_out + b * 8;
+    co[0] = g_rp.x; co[1] = g_rp.y; co[2] = g_rp.z;
+    co[3] = dq1.w + dqy.w + dq2.w; co[4] = dq1.x + dqy.x + dq2.x;
+    co[5] = dq1.y + dqy.y + dq2.y; co[6] = dq1.z + dqy.z + dq2.z;
+  }
 }
 
 // root integration of frame t from the de-normalised root velocities p6 (reference: devectorize_output,
@@ -277,6 +283,16 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       if (eact) {
         const long i = (long)eb * H + U;
         pre[0] = G.o0[i]; pre[1] = G.p0[i]; pre[2] = G.p1[i]; pre[3] = G.p2[i]; pre[4] = G.p3[i]; pre[5] = G.p4[i];
+      }
+    } break;
+    case EPI_GRU_BWD_M: if constexpr (FAM == 1) {
+      const int U = tile * 16 + ev;
+      eact = tid < 16 * BP && eb < B && U < H;
+      if (eact) {
+        const long i = (long)eb * H + U;
+        pre[0] = G.o0[i]; pre[1] = G.p0[i]; pre[2] = G.p1[i]; pre[3] = G.p2[i]; pre[4] = G.p3[i]; pre[5] = G.p4[i];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) rt[c] = a.aux1[(long)c * H + U];     // layer2 rows of the 6 root columns
       }
     } break;
     case EPI_ADD: if constexpr (FAM == 1) {
@@ -527,6 +543,42 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         G.o0[i] = g * z;
       }
     } break;
+    case EPI_GRU_BWD_M: if constexpr (FAM == 1) {   // layer-1 gate gradients of step t-1 in the launch that produces dy_{t-1}:
+      // dH1 = M'^T D0 + W2^T r (acc 0) + W2[0:6]^T dy6 + carry, with dy6 from the root-integration backward
+      // evaluated here from the root columns of W0^T D0 (acc 1); the DX group of this launch owns the carry update.
+      float* dsh = (float*)red;                      // [BP][6]
+      if (tid < BP && eb < B) {
+        const int b = eb;
+        float g6[6], dgd[3];
+        for (int c = 0; c < 6; ++c)
+          g6[c] = a.dpose[((long)b * d.T + t - 1) * PO + c] + (FV(1, c, b) + a.aux0[(long)b * a.XD + c]) / a.st.in_std[c];
+        for (int k = 0; k < 3; ++k) dgd[k] = FV(1, 6 + k, b) + a.aux0[(long)b * a.XD + PO + k];
+        root_bwd(d, a.st, b, t - 1, true, dgd, a.gaze, a.cpose, a.crpos, a.crrot, a.drpos, a.drrot, a.carry, nullptr, g6);
+        for (int c = 0; c < 6; ++c) dsh[ebl * 6 + c] = g6[c] * a.st.out_std[c];
+      }
+      __syncthreads();
+      if (eact) {
+        const int b = eb, U = tile * 16 + ev;
+        const long i = (long)b * H + U;
+        float g = FV(0, ev, b) + pre[0];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) g = fmaf(rt[c], dsh[ebl * 6 + c], g);
+        const float r = pre[1], z = pre[2], nn = pre[3], nh = pre[4], hp = pre[5];
+        const float dn = g * (1.f - z);
+        const float dz = g * (hp - nn);
+        const float dan = dn * (1.f - nn * nn);
+        const float dar = dan * nh * r * (1.f - r);
+        const float daz = dz * z * (1.f - z);
+        float* di = G.o1 + (long)b * 3 * H;
+        float* dh = G.o2 + (long)b * 3 * H;
+        di[U] = dar; di[H + U] = daz; di[2 * H + U] = dan;
+        dh[U] = dar; dh[H + U] = daz; dh[2 * H + U] = dan * r;
+        G.o3[xf_index(b, U, LNB)] = dar; G.o3[xf_index(b, H + U, LNB)] = daz; G.o3[xf_index(b, 2 * H + U, LNB)] = dan;
+        G.o4[xf_index(b, U, LNB)] = dar; G.o4[xf_index(b, H + U, LNB)] = daz;
+        G.o4[xf_index(b, 2 * H + U, LNB)] = dan * r;
+        G.o0[i] = g * z;
+      }
+    } break;
     case EPI_ADD: if constexpr (FAM == 1) {
       if (eact) G.o0[(long)eb * H + tile * 16 + ev] = pre[0] + FV(0, ev, eb);
     } break;
@@ -539,7 +591,10 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
           G.o0[(long)b * H + j] = d0;
           G.o1[xf_index(b, j, LNB)] = d0;
         } else {
-          G.o2[(long)b * a.XD + (j - H)] = g;
+          const int c = j - H;
+          G.o2[(long)b * a.XD + c] = g;
+          if (a.rxf && c >= 6 && c < PO)     // operand of the merged W2^T product of the next launch
+            a.rxf[xf_index(b, c, LNB)] = a.st.out_std[c] * (a.dpose[((long)b * d.T + t - 1) * PO + c] + g / a.st.in_std[c]);
         }
       }
     } break;
@@ -562,7 +617,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
           g6[c] = a.dpose[((long)b * d.T + t - 1) * PO + c] +
                   (FV(0, c, b) + G.p0[(long)b * a.XD + c]) / a.st.in_std[c];
         for (int k = 0; k < 3; ++k) dgd[k] = FV(0, 6 + k, b) + G.p0[(long)b * a.XD + PO + k];
-        root_bwd(d, a.st, b, t - 1, true, dgd, a.gaze, a.cpose, a.crpos, a.crrot, a.drpos, a.drrot, a.carry, g6);
+        root_bwd(d, a.st, b, t - 1, true, dgd, a.gaze, a.cpose, a.crpos, a.crrot, a.drpos, a.drrot, a.carry, a.carry_out, g6);
         for (int c = 0; c < 6; ++c) {
           const float gy = g6[c] * a.st.out_std[c];
           dy[(long)b * a.POL + c] = gy;
@@ -587,7 +642,7 @@ __global__ void dy_last_k(ZeggsDecDims d, ZeggsDecStats st, const float* dpose, 
   if (threadIdx.x == 0) {
     float g6[6];
     for (int c = 0; c < 6; ++c) g6[c] = dpb[c];
-    root_bwd(d, st, b, t, false, nullptr, gaze, pose, rpos, rrot, drpos, drrot, carry, g6);
+    root_bwd(d, st, b, t, false, nullptr, gaze, pose, rpos, rrot, drpos, drrot, carry, carry, g6);
     for (int c = 0; c < 6; ++c) {
       const float gy = g6[c] * st.out_std[c];
       dy[(long)b * POL + c] = gy;
@@ -702,13 +757,13 @@ inline Seg seg(const float* w, const float* x, int kb, int acc, const float* xc 
 
 // W0s = W0[:, :PO] diag(sigma_o / sigma_i) (zero padded to POL columns); v = (b2 sigma_o + mu_o - mu_i) / sigma_i
 __global__ void merge_prep_k(float* W0s, float* vvec, const float* W0, const float* b2, ZeggsDecStats st, int H, int PO,
-                             int POL, int XD) {
+                             int POL, int XD, int skip /* zero the first `skip` columns (backward: root columns) */) {
   const long n = (long)H * POL;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % POL);
     const long r = i / POL;
-    W0s[i] = c < PO ? W0[r * XD + c] * (st.out_std[c] / st.in_std[c]) : 0.f;
-    if (r == 0) vvec[c] = c < PO ? (b2[c] * st.out_std[c] + st.out_mean[c] - st.in_mean[c]) / st.in_std[c] : 0.f;
+    W0s[i] = (c < PO && c >= skip) ? W0[r * XD + c] * (st.out_std[c] / st.in_std[c]) : 0.f;
+    if (r == 0 && vvec) vvec[c] = c < PO ? (b2[c] * st.out_std[c] + st.out_mean[c] - st.in_mean[c]) / st.in_std[c] : 0.f;
   }
 }
 
@@ -743,7 +798,7 @@ int dec_fast_pack_merged(const ZeggsDecDims& d, const ZeggsDecParams* P, const Z
   const int H = d.H, XD = w.XD;
   const long n = (long)H * w.POL;
   hipLaunchKernelGGL(merge_prep_k, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, w.W0s,
-                     w.vvec, P->l0_w, P->l2_b, *st, H, d.PO, w.POL, XD);
+                     w.vvec, P->l0_w, P->l2_b, *st, H, d.PO, w.POL, XD, 0);
   ZLAUNCH_CHECK("merge_prep");
   ZTRY(gemm_nn(w.W0s, w.POL, P->l2_w, H, w.Mc, H, H, d.PO, H, 0.f, s));
   ZTRY(gemm_nt(w.vvec, w.POL, P->l0_w, XD, w.cvec, H, P->l0_b, 1, H, d.PO, ACT_NONE, 0.f, s));
@@ -752,8 +807,19 @@ int dec_fast_pack_merged(const ZeggsDecDims& d, const ZeggsDecParams* P, const Z
   return 0;
 }
 
-int dec_fast_pack_bwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s) {
+int dec_fast_pack_bwd(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s) {
   const int H = d.H, XD = w.XD;
+  if (!(g_stage_variant & 8192) && d.T > 2) {
+    // merged stage (dx of step t + layer-1 gates of step t-1): M' = W0[:, 6:PO] diag(sigma_o/sigma_i) W2[6:PO, :],
+    // packed transposed (V[U][k] = M'[k][U]); the six root columns take the non-linear root-integration path.
+    // W0s / Mc are the forward pass's scratch, free again by now.
+    const long n = (long)H * w.POL;
+    hipLaunchKernelGGL(merge_prep_k, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, w.W0s,
+                       (float*)nullptr, P->l0_w, P->l2_b, *st, H, d.PO, w.POL, XD, 6);
+    ZLAUNCH_CHECK("merge_prep");
+    ZTRY(gemm_nn(w.W0s, w.POL, P->l2_w, H, w.Mc, H, H, d.PO, H, 0.f, s));
+    ZTRY(pack(w.pb_mt, w.Mc, w.nTH, w.KBH, 2, H, H, H, d.PO, H, 0, s));
+  }
   ZTRY(pack(w.pb_l2, P->l2_w, w.nTH, w.KBPO, 2, d.PO, H, H, d.PO, H, 0, s));          // V[U][c] = W2[c][U]
   ZTRY(pack(w.pb_ih1, P->w_ih1, w.nTH, w.KB3H, 2, 3 * H, H, H, d.PO, H, 0, s));        // V[U][k] = W_ih1[k][U]
   ZTRY(pack(w.pb_hh1, P->w_hh1, w.nTH, w.KB3H, 2, 3 * H, H, H, d.PO, H, 0, s));
@@ -863,55 +929,65 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   if (T < 2) return 0;
   if (t_hi == T - 1) {   // first chunk of the sweep
     ZTRY(k_fill(w.xf_base_bwd, (long)(w.xf_bytes_bwd / 4), 0.f, s));
-    hipLaunchKernelGGL(dy_last_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, gaze, pose, rpos, rrot, w.carry,
-                       w.DY + (long)(T - 1) * B * w.POL, w.POL, w.DYxf, NB);
+    const bool merged0 = !(g_stage_variant & 8192) && T > 2;   // carry slot read by the first dx stage (see below)
+    hipLaunchKernelGGL(dy_last_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, gaze, pose, rpos, rrot,
+                       w.carry + (merged0 ? (long)((T - 1) & 1) * B * 8 : 0), w.DY + (long)(T - 1) * B * w.POL, w.POL,
+                       w.DYxf, NB);
     ZLAUNCH_CHECK("dy_last");
   }
+  // 3 launches per step: the dx stage of step t also evaluates the layer-1 gate gradients of step t-1 (variant 8192:
+  // separate launches).  The root-state carry is double-buffered: slot (t & 1) is read, slot ((t - 1) & 1) written.
+  const bool merged = !(g_stage_variant & 8192) && T > 2;
   for (int t = t_hi; t >= t_lo; --t) {
     const long o = (long)t * sH;
     StageArgs a = base_args(d, st, w);
     a.t = t; a.gaze = gaze; a.cpose = pose; a.crpos = rpos; a.crrot = rrot; a.dpose = dpose; a.drpos = drpos;
-    a.drrot = drrot; a.carry = w.carry;
-    // B1: dH1 = W2^T dy + carry -> layer-1 gate gradients
-    a.g[0] = Grp{}; a.g[1] = Grp{};
-    a.g[0].seg[0] = seg(w.pb_l2, w.DYxf, w.KBPO, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
-    a.g[0].p0 = w.R1 + o; a.g[0].p1 = w.Z1 + o; a.g[0].p2 = w.N1 + o; a.g[0].p3 = w.NH1 + o; a.g[0].p4 = w.H1 + o - sH;
-    a.g[0].o0 = w.dH1c; a.g[0].o1 = w.DI1 + t * s3; a.g[0].o2 = w.DH1 + t * s3; a.g[0].o3 = w.DI1xf; a.g[0].o4 = w.DH1xf;
-    ZTRY(launch_stage(a, s));
+    a.drrot = drrot;
+    float* c_in = w.carry + (merged ? (long)(t & 1) * B * 8 : 0);
+    float* c_out = w.carry + (merged ? (long)((t - 1) & 1) * B * 8 : 0);
+    a.carry = c_in; a.carry_out = c_out;
+    if (t == T - 1 || !merged) {
+      // B1: dH1 = W2^T dy + carry -> layer-1 gate gradients
+      a.g[0] = Grp{}; a.g[1] = Grp{};
+      a.g[0].seg[0] = seg(w.pb_l2, w.DYxf, w.KBPO, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
+      a.g[0].p0 = w.R1 + o; a.g[0].p1 = w.Z1 + o; a.g[0].p2 = w.N1 + o; a.g[0].p3 = w.NH1 + o; a.g[0].p4 = w.H1 + o - sH;
+      a.g[0].o0 = w.dH1c; a.g[0].o1 = w.DI1 + t * s3; a.g[0].o2 = w.DH1 + t * s3; a.g[0].o3 = w.DI1xf; a.g[0].o4 = w.DH1xf;
+      ZTRY(launch_stage(a, s));
+    }
     // B2: dH0 = W_ih1^T di1 + carry -> layer-0 gate gradients ; dH1 carry += W_hh1^T dh1
-    a.g[0] = Grp{};
+    a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pb_ih1, w.DI1xf, w.KB3H, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
     a.g[0].p0 = w.R0 + o; a.g[0].p1 = w.Z0 + o; a.g[0].p2 = w.N0 + o; a.g[0].p3 = w.NH0 + o; a.g[0].p4 = w.H0 + o - sH;
     a.g[0].o0 = w.dH0c; a.g[0].o1 = w.DI0 + t * s3; a.g[0].o2 = w.DH0 + t * s3; a.g[0].o3 = w.DI0xf; a.g[0].o4 = w.DH0xf;
-    const bool hh1_in_b4 = (g_stage_variant & 2048) != 0;
-    if (!hh1_in_b4) {
-      a.g[1].seg[0] = seg(w.pb_hh1, w.DH1xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
-      a.g[1].o0 = w.dH1c;
-    }
+    a.g[1].seg[0] = seg(w.pb_hh1, w.DH1xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
+    a.g[1].o0 = w.dH1c;
     ZTRY(launch_stage(a, s));
-    // B3: dGin = W_ih0^T di0 -> [D0 | dx part]
+    // B3: dGin = W_ih0^T di0 -> [D0 | dx part (+ the r operand of the merged stage)] ; dH0 carry += W_hh0^T dh0
     a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pb_ih0, w.DI0xf, w.KB3H, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTGI; a.g[0].epi = EPI_DGIN;
     a.g[0].p0 = w.Gin + t * sG; a.g[0].o0 = w.D0 + o; a.g[0].o1 = w.D0xf; a.g[0].o2 = w.dXa;
-    const bool side_in_b4 = (g_stage_variant & 512) != 0;
-    if (!side_in_b4) {
-      a.g[1].seg[0] = seg(w.pb_hh0, w.DH0xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
-      a.g[1].o0 = w.dH0c;
-    }
+    a.g[1].seg[0] = seg(w.pb_hh0, w.DH0xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
+    a.g[1].o0 = w.dH0c;
+    a.rxf = (merged && t > 1) ? w.Rxf : nullptr;
     ZTRY(launch_stage(a, s));
-    // B4: dx_t = dx part + W0^T D0 -> dy_{t-1}   [+ side: dH0 carry += W_hh0^T dh0, needed by the next step's B2]
+    a.rxf = nullptr;
+    // B4: dx_t = dx part + W0^T D0 -> dy_{t-1}, root-integration backward
+    //     [merged, t > 1: + layer-1 gate gradients of step t-1 from dH1 = M'^T D0 + W2^T r + W2[0:6]^T dy6 + carry]
     a.g[0] = Grp{}; a.g[1] = Grp{};
-    if (side_in_b4) {
-      a.g[1].seg[0] = seg(w.pb_hh0, w.DH0xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
-      a.g[1].o0 = w.dH0c;
-    }
-    if (hh1_in_b4) {
-      a.g[1].seg[0] = seg(w.pb_hh1, w.DH1xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
-      a.g[1].o0 = w.dH1c;
-    }
     a.g[0].seg[0] = seg(w.pb_l0, w.D0xf, w.KBH, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTX; a.g[0].epi = EPI_DX;
     a.g[0].p0 = w.dXa; a.g[0].o0 = w.DX + (long)t * B * w.XD;
     a.g[0].o1 = t > 1 ? w.DY + (long)(t - 1) * B * w.POL : nullptr; a.g[0].o2 = w.DYxf;
+    if (merged && t > 1) {
+      const long o1 = o - sH;
+      a.g[1].seg[0] = seg(w.pb_mt, w.D0xf, w.KBH, 0);
+      a.g[1].seg[1] = seg(w.pb_l2, w.Rxf, w.KBPO, 0);
+      a.g[1].seg[2] = seg(w.pb_l0, w.D0xf, w.KBH, 1, nullptr, 0, 1);
+      a.g[1].nseg = 3; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_GRU_BWD_M;
+      a.g[1].p0 = w.R1 + o1; a.g[1].p1 = w.Z1 + o1; a.g[1].p2 = w.N1 + o1; a.g[1].p3 = w.NH1 + o1; a.g[1].p4 = w.H1 + o1 - sH;
+      a.g[1].o0 = w.dH1c; a.g[1].o1 = w.DI1 + (t - 1) * s3; a.g[1].o2 = w.DH1 + (t - 1) * s3; a.g[1].o3 = w.DI1xf;
+      a.g[1].o4 = w.DH1xf;
+      a.aux0 = w.dXa; a.aux1 = P->l2_w;
+    }
     ZTRY(launch_stage(a, s));
   }
   return 0;

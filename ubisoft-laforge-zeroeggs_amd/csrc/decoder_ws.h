@@ -19,12 +19,12 @@ struct DecWs {
   // ---- fast path: fragment-packed weights (see decoder_fast.hip) and activations
   int NB, nT5, nTH, nTX, nTPO, nTGI, KBH, KBX, KBPO, KB3H;
   float *pw_l0, *pw_ih0h, *pw_ih0x, *pw_hh0, *pw_ih1, *pw_hh1, *pw_l2;   // forward packs
-  float *pb_l2, *pb_ih1, *pb_hh1, *pb_ih0, *pb_hh0, *pb_l0;              // backward (transposed) packs
+  float *pb_l2, *pb_ih1, *pb_hh1, *pb_ih0, *pb_hh0, *pb_l0, *pb_mt;      // backward (transposed) packs
   float *Xxf, *HIDxf, *H0xf, *H1xf;                                      // forward activation fragments (rings of 2)
   // merged layer2 -> layer0 stage: M = W0[:, :PO] diag(sigma_o / sigma_i) W2, Wc = W0[:, PI:], cvec = b0 + W0[:, :PO] v
   int KBC;
   float *W0s, *Mc, *vvec, *cvec, *pw_m, *pw_c, *CONDxf;
-  float *DYxf, *DI1xf, *DH1xf, *DI0xf, *DH0xf, *D0xf, *dXa;               // backward fragments
+  float *DYxf, *DI1xf, *DH1xf, *DI0xf, *DH0xf, *D0xf, *Rxf, *dXa;         // backward fragments
   size_t xf_bytes_fwd, xf_bytes_bwd;
   float *xf_base_fwd, *xf_base_bwd;
 };
@@ -56,7 +56,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
     w.dH0c = a.f(B * H); w.dH1c = a.f(B * H);
     w.dGin = a.f(B * (long)w.GL);
     w.dXn = a.f(B * (long)w.XD);
-    w.carry = a.f(B * 8);
+    w.carry = a.f(2 * B * 8);   // double-buffered (merged backward stage: one group writes, the other reads)
     w.t0 = a.f(B * 2 * H); w.t1 = a.f(B * (long)(d.PI + d.ST + 2 * H));
   }
   if (d.film) {
@@ -100,9 +100,10 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
     w.pb_ih0 = a.f((long)w.nTGI * w.KB3H * BLK);
     w.pb_hh0 = a.f((long)w.nTH * w.KB3H * BLK);
     w.pb_l0 = a.f((long)w.nTX * w.KBH * BLK);
+    w.pb_mt = a.f((long)w.nTH * w.KBH * BLK);
     size_t o0 = a.off;
     w.DYxf = a.f(w.KBPO * XB); w.DI1xf = a.f(w.KB3H * XB); w.DH1xf = a.f(w.KB3H * XB);
-    w.DI0xf = a.f(w.KB3H * XB); w.DH0xf = a.f(w.KB3H * XB); w.D0xf = a.f(w.KBH * XB);
+    w.DI0xf = a.f(w.KB3H * XB); w.DH0xf = a.f(w.KB3H * XB); w.D0xf = a.f(w.KBH * XB); w.Rxf = a.f(w.KBPO * XB);
     w.xf_base_bwd = w.DYxf;
     w.xf_bytes_bwd = a.off - align_up(o0, 256);
     w.dXa = a.f(B * (long)w.XD);
@@ -113,7 +114,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
 // fast path entry points (decoder_fast.hip)
 int dec_fast_supported(const ZeggsDecDims& d);
 int dec_fast_pack_fwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s);
-int dec_fast_pack_bwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s);
+int dec_fast_pack_bwd(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s);
 int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w,
                        const float* gaze, const float* speech, const float* style, float* pose, float* rpos,
                        float* rrot, int training, hipStream_t s);
