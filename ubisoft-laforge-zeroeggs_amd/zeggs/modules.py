@@ -100,8 +100,8 @@ class _FFTBlock(nn.Module):
 
 class StyleEncoderAttn(nn.Module):
     """Parameters of reference StyleEncoderAttn (modules.py:353-389).  The
-    sinusoidal table (reference PositionalEncoding, :450-459) is evaluated
-    inside the HIP kernel, so no 20000x128 attribute is kept."""
+    sinusoidal table (reference PositionalEncoding, :450-459) is built on demand
+    for the exemplar length (ops.positional_table), so no 20000x128 attribute is kept."""
 
     def __init__(self, input_size, hidden_size, style_embedding_size):
         super().__init__()
