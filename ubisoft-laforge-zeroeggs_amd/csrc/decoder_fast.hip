@@ -27,7 +27,10 @@ int g_stage_variant = 0;
 
 namespace {
 
-enum { V_NOX = 1, V_NOW = 2, V_NOEPI = 4, V_NOMFMA = 8, V_ROT = 16 };
+// zeggs_set_option("stage_variant", bits) -- measurement switches, all off in production:
+//   2 no main loop / 4 no epilogue (ablation: results are garbage), 32 never / 64 always split stages over the batch,
+//   128 16-wave workgroups, 1024 MFMA path for B <= 2 (no GEMV kernels), 4096 / 8192 unmerged forward / backward stages
+enum { V_NOW = 2, V_NOEPI = 4 };
 
 enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_HID_MERGED, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX, EPI_GRU_BWD_M };
 
