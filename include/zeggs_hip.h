@@ -153,6 +153,14 @@ int zeggs_decoder_fwd(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDec
                       const float* rpos0, const float* rrot0, const float* gaze, const float* speech,
                       const float* style, float* pose, float* rpos, float* rrot, int training, void* ws,
                       size_t ws_bytes, void* stream);
+/* Chunked (streaming) decode, inference only: the same rollout resumed from a given state.  Frame 0 of the chunk is
+ * the last frame already produced (pose0 / rpos0 / rrot0 = its outputs; index 0 of gaze / speech / style belongs to
+ * it), h_in [2,B,H] = GRU state after that frame (NULL: first chunk -> CellStateEncoder as in zeggs_decoder_fwd),
+ * h_out [2,B,H] (may be NULL) = state after the chunk's last frame.  Workspace: zeggs_decoder_workspace_bytes(d, 0). */
+int zeggs_decoder_fwd_state(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDecStats*, const float* pose0,
+                            const float* rpos0, const float* rrot0, const float* gaze, const float* speech,
+                            const float* style, float* pose, float* rpos, float* rrot, const float* h_in,
+                            float* h_out, void* ws, size_t ws_bytes, void* stream);
 /* dpose [B,T,PO], drpos [B,T,3], drrot [B,T,4] (frame 0 ignored) -> parameter grads, dspeech [B,T,SP],
  * dstyle [B,T,ST] */
 int zeggs_decoder_bwd(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDecStats*, const float* gaze,
@@ -207,6 +215,13 @@ long zeggs_mel_stft_frames(const ZeggsMelDims*, long n_samples); /* integer rule
 size_t zeggs_mel_workspace_bytes(const ZeggsMelDims*, long n_samples);
 int zeggs_mel_features(const ZeggsMelDims*, const float* wav, long n_samples, const double* filterbank,
                        int n_frames, float* out, void* ws, size_t ws_bytes, void* stream);
+/* streaming form: rows [k0, k1) of the same feature table from the samples received so far.  final == 0: the signal
+ * continues, k1 must be <= zeggs_mel_frames_ready(d, n_samples) (no frame may need samples not yet received);
+ * final != 0: n_samples is the whole signal -> identical to rows k0..k1-1 of zeggs_mel_features. */
+long zeggs_mel_frames_ready(const ZeggsMelDims*, long n_samples);
+size_t zeggs_mel_range_workspace_bytes(const ZeggsMelDims*, long k0, long k1);
+int zeggs_mel_features_range(const ZeggsMelDims*, const float* wav, long n_samples, int final, const double* filterbank,
+                             long k0, long k1, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* in-place feature normalisation (x - mean) / std of ZEGGS/train.py:232-234,239 ; stdv == NULL -> scalar std */
 int zeggs_normalize_rows(float* x, long rows, int width, long ld, const float* mean, const float* stdv,

@@ -658,3 +658,47 @@ def test_gru_style_encoder_sequence_lengths(L):
     z, mu, lv = st_g(g(ex), 1.0, eps=g(eps))
     z0, mu0, lv0 = onets.style_encoder(helpers.sd(st_g.cpu()), ex, eps, 1.0)
     assert float((z.cpu() - z0).abs().max()) < 5e-5 and float((lv.cpu() - lv0).abs().max()) < 5e-5
+
+
+# ----------------------------------------------------------------------------- streaming inference
+@pytest.mark.parametrize("seed,nsamp", [(0, 48000), (1, 40123)])
+def test_streaming_matches_offline_generation(seed, nsamp):
+    """any chunking of the audio yields the frames of the offline path (mel -> speech encoder -> decoder): integer
+    frame count bit-exact, values to fp32 re-association (chunk boundaries re-enter through the unmerged layer0)"""
+    from zeggs import anim, audio, stream
+    se, de, _ = helpers.build_nets()
+    se, de = se.to(DEV).eval(), de.to(DEV).eval()
+    stats = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32, device=DEV) for k, v in synth.make_stats().items()}
+    conf = dict(pre_emphasis=False, pre_emph_coeff=0.97, centered=True, real_amplitude=True, normalize_mel_bins=True,
+                normalize_range=True, min_clipping=1e-5, sampling_rate=16000, mel_fmin=20, mel_fmax=7600,
+                n_mel_channels=80, filter_length=800, hop_length=200, resample_method="linear", normalize_loudness=False)
+    wav = synth.synth_wav(nsamp, seed=seed).astype(np.float32) / 32768.0
+    first = anim.preprocess_animation(synth.make_bvh_clip(8, seed=3), DEV)
+    torch.manual_seed(seed)
+    style = torch.randn(1, 64, device=DEV) * 0.5
+    # offline
+    n_frames = audio.n_anim_frames(len(wav))
+    feats = torch.as_tensor(audio.preprocess_audio(wav, 60, n_frames, conf, ["mel_spec", "energy"]), device=DEV)
+    with torch.no_grad():
+        sp = se(((feats[None] - stats["audio_input_mean"]) / stats["audio_input_std"]).contiguous())
+        f32 = lambda a: a[0:1].to(torch.float32).contiguous()  # noqa: E731
+        rp, rr, rv, rw, lp, _, lt, lv, lw = first[:9]
+        pose0 = torch.cat([f32(x).reshape(1, -1) for x in (rv, rw, lp, lt, lv, lw)], dim=1)
+        gaze = f32(first[14]).repeat(n_frames, 1)[None].contiguous()
+        ref = ops.decoder_core(de, pose0, f32(rp), f32(rr), gaze, sp, style.repeat(n_frames, 1)[None].contiguous(),
+                               stats["anim_input_mean"], stats["anim_input_std"], stats["anim_output_mean"],
+                               stats["anim_output_std"], synth.DT)
+    # streamed with irregular chunks (some shorter than one STFT hop, some several seconds)
+    gs = stream.GestureStream(se, de, first, style, stats, conf, synth.DT)
+    rng = np.random.default_rng(seed)
+    outs, pos = [], 0
+    while pos < len(wav):
+        n = int(rng.choice([37, 160, 1600, 5000, 16000]))
+        outs.append(gs.push(wav[pos:pos + n]))
+        pos += n
+    outs.append(gs.finish())
+    cat = lambda k: torch.cat([o[k] for o in outs if o], dim=0)  # noqa: E731
+    assert cat("pose").shape[0] == n_frames == ref[0].shape[1]
+    assert sum(1 for o in outs if o) >= 3                                   # frames really left incrementally
+    for k, r in zip(("pose", "rpos", "rrot"), ref):
+        assert float((cat(k) - r[0]).abs().max()) < 5e-5, k

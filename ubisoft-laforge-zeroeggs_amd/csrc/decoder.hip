@@ -362,10 +362,34 @@ extern "C" size_t zeggs_decoder_workspace_bytes(const ZeggsDecDims* d, int train
   return a.off + 256;
 }
 
+static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
+                            const float* pose0, const float* rpos0, const float* rrot0, const float* gaze,
+                            const float* speech, const float* style, float* pose, float* rpos, float* rrot,
+                            int training, const float* h_in, float* h_out, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int zeggs_decoder_fwd(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
                                  const float* pose0, const float* rpos0, const float* rrot0, const float* gaze,
                                  const float* speech, const float* style, float* pose, float* rpos, float* rrot,
                                  int training, void* ws, size_t ws_bytes, void* stream) {
+  return decoder_fwd_impl(dp, P, st, pose0, rpos0, rrot0, gaze, speech, style, pose, rpos, rrot, training, nullptr,
+                          nullptr, ws, ws_bytes, stream);
+}
+
+// Chunked (streaming) decode: frame 0 of the chunk is the last frame already produced (its pose / root state come in as
+// pose0 / rpos0 / rrot0), h_in [2,B,H] is the GRU state after that frame (NULL: first chunk, CellStateEncoder), h_out
+// receives the state after the chunk's last frame.  Inference only (2-slot rings).
+extern "C" int zeggs_decoder_fwd_state(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
+                                       const float* pose0, const float* rpos0, const float* rrot0, const float* gaze,
+                                       const float* speech, const float* style, float* pose, float* rpos, float* rrot,
+                                       const float* h_in, float* h_out, void* ws, size_t ws_bytes, void* stream) {
+  return decoder_fwd_impl(dp, P, st, pose0, rpos0, rrot0, gaze, speech, style, pose, rpos, rrot, 0, h_in, h_out, ws,
+                          ws_bytes, stream);
+}
+
+static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
+                            const float* pose0, const float* rpos0, const float* rrot0, const float* gaze,
+                            const float* speech, const float* style, float* pose, float* rpos, float* rrot,
+                            int training, const float* h_in, float* h_out, void* ws, size_t ws_bytes, void* stream) {
   const ZeggsDecDims& d = *dp;
   hipStream_t s = (hipStream_t)stream;
   ZCHECK(d.PI == d.PO + 3, "decoder: pose_input_size must be pose_output_size + 3 (gaze)");
@@ -382,10 +406,22 @@ extern "C" int zeggs_decoder_fwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   hipLaunchKernelGGL(dec_init_k, dim3(B), dim3(256), 0, s, d, *st, pose0, rpos0, rrot0, gaze, style, pose, rpos, rrot,
                      w.cse_in, w.Gin + slot(1) * sG, GL);
   ZLAUNCH_CHECK("dec_init");
-  ZTRY(gemm_nt(w.cse_in, CI, P->c0_w, CI, w.cse_a, H, P->c0_b, B, H, CI, ACT_ELU, 0.f, s));
-  ZTRY(gemm_nt(w.cse_a, H, P->c1_w, H, w.cse_b, H, P->c1_b, B, H, H, ACT_ELU, 0.f, s));
-  ZTRY(gemm_nt(w.cse_b, H, P->c2_w, H, w.H0 + slot(0) * sH, H, P->c2_b, B, H, H, ACT_NONE, 0.f, s));
-  ZTRY(gemm_nt(w.cse_b, H, P->c2_w + (long)H * H, H, w.H1 + slot(0) * sH, H, P->c2_b + H, B, H, H, ACT_NONE, 0.f, s));
+  if (h_in) {   // resumed rollout: the recurrent state is given
+    ZTRY(k_copy(w.H0 + slot(0) * sH, h_in, sH, s));
+    ZTRY(k_copy(w.H1 + slot(0) * sH, h_in + sH, sH, s));
+  } else {
+    ZTRY(gemm_nt(w.cse_in, CI, P->c0_w, CI, w.cse_a, H, P->c0_b, B, H, CI, ACT_ELU, 0.f, s));
+    ZTRY(gemm_nt(w.cse_a, H, P->c1_w, H, w.cse_b, H, P->c1_b, B, H, H, ACT_ELU, 0.f, s));
+    ZTRY(gemm_nt(w.cse_b, H, P->c2_w, H, w.H0 + slot(0) * sH, H, P->c2_b, B, H, H, ACT_NONE, 0.f, s));
+    ZTRY(gemm_nt(w.cse_b, H, P->c2_w + (long)H * H, H, w.H1 + slot(0) * sH, H, P->c2_b + H, B, H, H, ACT_NONE, 0.f, s));
+  }
+  auto save_state = [&]() -> int {
+    if (h_out) {
+      ZTRY(k_copy(h_out, w.H0 + slot(T - 1) * sH, sH, s));
+      ZTRY(k_copy(h_out + sH, w.H1 + slot(T - 1) * sH, sH, s));
+    }
+    return 0;
+  };
   if (training && T > 1) {
     hipLaunchKernelGGL(dec_fill_cond_k, g1((long)(T - 1) * B * (d.SP + d.ST)), dim3(256), 0, s, d, speech, style, w.Gin,
                        GL, 1, T - 1, sG, 0);
@@ -407,7 +443,7 @@ extern "C" int zeggs_decoder_fwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
     }
     ZTRY(dec_fast_pack_fwd(d, P, w, s));
     ZTRY(dec_fast_fwd_steps(d, P, st, w, gaze, speech, style, pose, rpos, rrot, training, s));
-    return 0;
+    return save_state();
   }
   for (int t = 1; t < T; ++t) {
     float* gin = w.Gin + slot(t) * sG;
@@ -463,7 +499,7 @@ extern "C" int zeggs_decoder_fwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
                        t);
     ZLAUNCH_CHECK("dec_step");
   }
-  return 0;
+  return save_state();
 }
 
 extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,

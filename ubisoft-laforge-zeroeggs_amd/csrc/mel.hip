@@ -34,8 +34,10 @@ inline long stft_frames(long n, int n_fft, int hop) {
   return (np % hop == 0) ? (np - n_fft) / hop : 1 + (np - n_fft) / hop;
 }
 
-__global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* wav, long n, const double* fb,
-                                                   double* logmel, double* energy, long M) {
+// STFT frames m0 .. m0 + gridDim.x - 1.  n = signal length for the reflect rule, n_avail = samples present in `wav`
+// (streaming: n is unknown yet and passed as a huge value; the caller only asks for frames that end before n_avail)
+__global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* wav, long n, long n_avail, const double* fb,
+                                                   double* logmel, double* energy, long m0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int NF = d.n_fft, NBIN = NF / 2 + 1;
   double* xw = sm;              // [NF] windowed samples
@@ -43,12 +45,12 @@ __global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* w
   double* st = ct + NF;         // [NF] sin
   double* amp = st + NF;        // [NBIN]
   double* melv = amp + NBIN;    // [n_mels]
-  const long fr = blockIdx.x;
+  const long fr = m0 + blockIdx.x, slot = blockIdx.x;
   const long neff = n > NF ? n : NF;   // zero-extended to n_fft when shorter (spectrograms.py:233-234)
   for (int j = threadIdx.x; j < NF; j += blockDim.x) {
     const long p = fr * d.hop + j - NF / 2;          // index into the (zero-extended) signal before reflect padding
     long src = p < 0 ? -p : (p >= neff ? 2 * (neff - 1) - p : p);
-    const double x = (src >= 0 && src < n) ? (double)wav[src] : 0.0;
+    const double x = (src >= 0 && src < n && src < n_avail) ? (double)wav[src] : 0.0;
     const double win = 0.5 - 0.5 * cos(2.0 * M_PI * (double)j / (double)(NF - 1));   // scipy hann(sym=True)
     xw[j] = x * win;
     const double ang = 2.0 * M_PI * (double)j / (double)NF;
@@ -80,24 +82,27 @@ __global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* w
     const double v = (20.0 * log10(s) + rng) / rng;    // spectrograms.py:121-129
     const double y = log(pow(10.0, v / 20.0));          // data_pipeline.py:62-63
     melv[m] = y;
-    logmel[fr * d.n_mels + m] = y;
+    logmel[slot * d.n_mels + m] = y;
   }
   __syncthreads();
   if (threadIdx.x == 0) {                               // energy = || exp(mel) ||_2 (data_pipeline.py:28-30,75)
     double e = 0.0;
     for (int m = 0; m < d.n_mels; ++m) { const double z = exp(melv[m]); e += z * z; }
-    energy[fr] = sqrt(e);
+    energy[slot] = sqrt(e);
   }
 }
 
 // linear resampling at t_k = ((fs/hop)/fps) k : mel -> NaN outside the hull (griddata), energy extrapolates
-__global__ void mel_resample_k(ZeggsMelDims d, const double* logmel, const double* energy, long M, int n_frames,
-                               float* out) {
+// animation frames k0 .. k0 + n_frames - 1; logmel / energy hold the STFT frames m0 .. (indices relative to m0)
+__global__ void mel_resample_k(ZeggsMelDims d, const double* logmel, const double* energy, long M, long m0, long k0,
+                               int n_frames, float* out) {
   const int W = d.n_mels + 1;
   const long n = (long)n_frames * W;
+  logmel -= m0 * d.n_mels;
+  energy -= m0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % W);
-    const long k = i / W;
+    const long k = k0 + i / W;
     const double t = (((double)d.fs / (double)d.hop) / (double)d.fps) * (double)k;
     long hi = (long)ceil(t);            // searchsorted(side=left) over the integer grid
     if (hi < 1) hi = 1;
@@ -138,14 +143,63 @@ extern "C" int zeggs_mel_features(const ZeggsMelDims* dp, const float* wav, long
   MelWs w = carve_mel(d, M, a);
   ZCHECK(a.ok(), "mel: workspace too small (%zu < %zu)", ws_bytes, a.off);
   const size_t lds = sizeof(double) * (3 * (size_t)d.n_fft + d.n_fft / 2 + 1 + d.n_mels);
-  hipLaunchKernelGGL(mel_stft_k, dim3((unsigned)M), dim3(256), lds, s, d, wav, n_samples, filterbank, w.logmel, w.energy,
-                     M);
+  hipLaunchKernelGGL(mel_stft_k, dim3((unsigned)M), dim3(256), lds, s, d, wav, n_samples, n_samples, filterbank, w.logmel,
+                     w.energy, 0L);
   ZLAUNCH_CHECK("mel_stft");
   if (n_frames > 0) {
     long n = (long)n_frames * (d.n_mels + 1), g = (n + 255) / 256;
     hipLaunchKernelGGL(mel_resample_k, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, d, w.logmel, w.energy, M,
-                       n_frames, out);
+                       0L, 0L, n_frames, out);
     ZLAUNCH_CHECK("mel_resample");
   }
+  return 0;
+}
+
+// Streaming form: features of the animation frames [k0, k1) from the samples received so far.
+//   final == 0: the signal continues; every STFT frame the range needs must end inside the n_samples present
+//               (zeggs_mel_frames_ready tells how far that is) -- no right-edge reflection, no end clamps;
+//   final != 0: n_samples is the whole signal: identical to rows k0..k1-1 of zeggs_mel_features.
+extern "C" long zeggs_mel_frames_ready(const ZeggsMelDims* d, long n_samples) {
+  // STFT frame m is complete when 200 m + 400 <= n; animation frame k interpolates STFT frames ceil(t)-1, ceil(t)
+  const long mmax = (n_samples - d->n_fft / 2) / d->hop;           // last complete STFT frame (may be < 1)
+  if (mmax < 1) return 0;
+  const double r = ((double)d->fs / (double)d->hop) / (double)d->fps;
+  long k = (long)floor((double)mmax / r);                           // largest k with t_k <= mmax
+  while (k >= 0 && ceil(r * (double)k) > (double)mmax) --k;
+  return k + 1;                                                     // frames 0 .. k are computable
+}
+extern "C" size_t zeggs_mel_range_workspace_bytes(const ZeggsMelDims* d, long k0, long k1) {
+  const double r = ((double)d->fs / (double)d->hop) / (double)d->fps;
+  const long mspan = (long)ceil(r * (double)(k1 - 1)) - (long)floor(r * (double)k0) + 4;
+  Arena a(nullptr, 0);
+  carve_mel(*d, mspan, a);
+  return a.off + 256;
+}
+extern "C" int zeggs_mel_features_range(const ZeggsMelDims* dp, const float* wav, long n_samples, int final,
+                                        const double* filterbank, long k0, long k1, float* out, void* ws, size_t ws_bytes,
+                                        void* stream) {
+  const ZeggsMelDims& d = *dp;
+  hipStream_t s = (hipStream_t)stream;
+  ZCHECK(d.n_fft >= 2 && d.n_fft % 2 == 0 && d.hop > 0 && d.n_mels > 0, "mel: bad dims");
+  ZCHECK(n_samples > 0 && k0 >= 0 && k1 > k0, "mel range: empty input");
+  if (!final) ZCHECK(k1 <= zeggs_mel_frames_ready(dp, n_samples), "mel range: frames %ld..%ld need samples not received yet", k0, k1);
+  const long M = final ? stft_frames(n_samples, d.n_fft, d.hop) : (1L << 40);
+  const double r = ((double)d.fs / (double)d.hop) / (double)d.fps;
+  long m0 = (long)ceil(r * (double)k0) - 1, m1 = (long)ceil(r * (double)(k1 - 1)) + 1;   // [m0, m1)
+  if (m0 < 0) m0 = 0;
+  if (m1 < 2) m1 = 2;
+  if (m1 > M) m1 = M;
+  if (m0 > m1 - 2) m0 = m1 - 2 > 0 ? m1 - 2 : 0;
+  Arena a(ws, ws_bytes);
+  MelWs w = carve_mel(d, m1 - m0, a);
+  ZCHECK(a.ok(), "mel range: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  const size_t lds = sizeof(double) * (3 * (size_t)d.n_fft + d.n_fft / 2 + 1 + d.n_mels);
+  hipLaunchKernelGGL(mel_stft_k, dim3((unsigned)(m1 - m0)), dim3(256), lds, s, d, wav, final ? n_samples : (1L << 50),
+                     n_samples, filterbank, w.logmel, w.energy, m0);
+  ZLAUNCH_CHECK("mel_stft");
+  const long n = (k1 - k0) * (d.n_mels + 1), g = (n + 255) / 256;
+  hipLaunchKernelGGL(mel_resample_k, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, d, w.logmel, w.energy, M, m0, k0,
+                     (int)(k1 - k0), out);
+  ZLAUNCH_CHECK("mel_resample");
   return 0;
 }
