@@ -398,6 +398,16 @@ def test_generate_gesture_vs_reference(golden_dir, tmp_path):
                                     style_encoding_type="example", blend_type="add", blend_ratio=[1.0],
                                     file_name="out", first_pose=tmp_path / "ex.bvh", temperature=1e8, seed=1234)
     assert float((enc.cpu() - torch.as_tensor(gd["encoding"])).abs().max()) < 1e-4
+    # the pickle-free checkpoint twin (safetensors + arch.json) generates the same file
+    from zeggs import compat
+    compat.save_state(tmp_path / "net_st", se, de, st)
+    enc2 = generate.generate_gesture(tmp_path / "a.wav", [(tmp_path / "ex.bvh", None)], tmp_path / "net_st", data, res,
+                                     style_encoding_type="example", blend_type="add", blend_ratio=[1.0],
+                                     file_name="out_st", first_pose=tmp_path / "ex.bvh", temperature=1e8, seed=1234)
+    assert float((enc2 - enc).abs().max()) < 1e-5          # (split-K atomics: not bit-reproducible run to run)
+    o1, o2 = anim.bvh_load(res / "out.bvh"), anim.bvh_load(res / "out_st.bvh")
+    np.testing.assert_allclose(o2["rotations"], o1["rotations"], atol=2e-2)
+    np.testing.assert_allclose(o2["positions"], o1["positions"], atol=2e-3)
     out = anim.bvh_load(res / "out.bvh")
     assert out["rotations"].shape == gd["out_rotations"].shape             # integer frame count: bit-exact
     assert (res / "out.wav").exists()

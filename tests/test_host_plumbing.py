@@ -65,3 +65,23 @@ def test_bvh_channels_oracle_matches_reference(golden_dir):
     # the quaternions the reference derived from the two-axis encodings (generate.py:389), float32
     q = oanim.q_from_xform(oanim.xform_from_xy(g["dec_ltxy"].astype(np.float64)))
     assert np.abs(np.abs(np.sum(q * g["dec_lrot"], axis=-1)) - 1.0).max() < 1e-5
+
+
+def test_state_dict_checkpoint_round_trip(tmp_path):
+    """pickle-free checkpoints (safetensors + arch.json) rebuild every variant with identical weights"""
+    import torch
+    from zeggs import compat, modules
+    torch.manual_seed(3)
+    for rnn_cond, typ in (("normal", "attn"), ("film", "gru")):
+        se = modules.SpeechEncoder(81, 64, 64)
+        de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, 64, 64, 128, 2, rnn_cond=rnn_cond)
+        st = modules.StyleEncoder(synth.POSE_IN, 96, 64, type=typ, use_vae=True)
+        compat.save_state(tmp_path / rnn_cond, se, de, st, meta={"iteration": 7})
+        se2, de2, st2, meta = compat.load_state(tmp_path / rnn_cond)
+        assert meta["iteration"] == 7
+        for a, b in ((se, se2), (de, de2), (st, st2)):
+            sa, sb = a.state_dict(), b.state_dict()
+            assert sa.keys() == sb.keys()
+            assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    se2, de2, st2, _ = (lambda d: (compat.save_state(d, se, de, None), compat.load_state(d))[1])(tmp_path / "label")
+    assert st2 is None

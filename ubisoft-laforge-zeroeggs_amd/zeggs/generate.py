@@ -75,11 +75,17 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
     audio_mean, audio_std = tt("audio_input_mean"), tt("audio_input_std")
     in_mean, in_std, out_mean, out_std = (tt("anim_input_mean"), tt("anim_input_std"), tt("anim_output_mean"),
                                           tt("anim_output_std"))
-    speech_net = compat.load_module(network_path / "speech_encoder.pt", device).to(device).eval()
-    decoder = compat.load_module(network_path / "decoder.pt", device).to(device).eval()
-    style_net = None
-    if style_encoding_type == "example":
-        style_net = compat.load_module(network_path / "style_encoder.pt", device).to(device).eval()
+    if (network_path / "decoder.pt").exists():      # the reference's whole-module pickles
+        speech_net = compat.load_module(network_path / "speech_encoder.pt", device).to(device).eval()
+        decoder = compat.load_module(network_path / "decoder.pt", device).to(device).eval()
+        style_net = None
+        if style_encoding_type == "example":
+            style_net = compat.load_module(network_path / "style_encoder.pt", device).to(device).eval()
+    else:                                           # pickle-free twin written by zeggs.train (safetensors + arch.json)
+        speech_net, decoder, style_net, _ = compat.load_state(network_path, device)
+        speech_net, decoder = speech_net.eval(), decoder.eval()
+        style_net = style_net.eval() if style_net is not None else None
+        assert style_net is not None or style_encoding_type != "example", "checkpoint has no style encoder"
 
     with torch.no_grad():
         if audio_file is not None:

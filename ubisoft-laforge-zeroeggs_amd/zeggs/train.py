@@ -103,6 +103,7 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
                         torch.save(st, d / "style_encoder.pt")
                     torch.save({"iteration": iteration, "epoch": epoch, "loss": loss.detach(),
                                 "optimizer_state_dict": eng.opt.state_dict()}, d / "checkpoints.pt")
+                    compat.save_state(d, se, de, st, meta={"iteration": iteration, "epoch": epoch})   # pickle-free twin
             iteration += 1
         epoch += 1
     if rank == 0:
