@@ -104,6 +104,27 @@ def cpu_baseline(data, iters=2):
                       f"oracle, {dt_:.2f} s/iteration"}
 
 
+def decode_rate(de, dev, T=1801):
+    """second half of BASELINE.json's metric: autoregressive decode frames/s (config 5 regime: B=1, no_grad ring
+    path, speech/style already encoded; 30 s of 60-fps frames), measured after the timed training steps."""
+    st = {k: torch.as_tensor(v, dtype=torch.float32, device=dev) for k, v in synth.make_stats().items() if k.startswith("anim")}
+    g = torch.Generator(device="cpu").manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    args = (de.eval(), r(1, synth.POSE_OUT), torch.zeros(1, 3, device=dev), torch.tensor([[1.0, 0, 0, 0]], device=dev),
+            r(1, T, 3) * 10, r(1, T, SP) * 0.3, r(1, T, ST) * 0.3, st["anim_input_mean"], st["anim_input_std"],
+            st["anim_output_mean"], st["anim_output_std"], synth.DT)
+    with torch.no_grad():
+        ops.decoder_core(*args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ops.decoder_core(*args)
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+    de.train()
+    return {"value": round((T - 1) / dt_, 1), "unit": "frames/s", "us_per_frame": round(dt_ * 1e6 / (T - 1), 2),
+            "config": f"B=1 autoregressive rollout of {T - 1} frames, no_grad ring path (GEMV stage kernels)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +200,8 @@ def main():
                            "note": "HIP events around the 255-step forward rollout inside the timed iterations; "
                                    "traffic = FETCH_SIZE(x2)+WRITE_SIZE from profiles/r01_decoder_step_pmc.json; at "
                                    "B=32 the step is also at the fp32 MFMA ridge (1.24 GFLOP/step)"}
+        if world == 1:
+            out["decode"] = decode_rate(de, dev)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(data)
         else:
