@@ -203,6 +203,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// skinny-M helpers: zero / finish a strided [M, N] row block (split-K accumulates with atomics, bias + activation follow)
+__global__ void rows_fill_k(float* C, int M, int N, long ld) {
+  long n = (long)M * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    C[(i / N) * ld + (i % N)] = 0.f;
+}
+__global__ void rows_bias_act_k(float* C, const float* bias, int M, int N, long ld, int act) {
+  long n = (long)M * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float* c = C + (i / N) * ld + (i % N);
+    *c = d_act(*c + (bias ? bias[i % N] : 0.f), act);
+  }
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmArgs& g, int nbatch, hipStream_t s) {
   dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), nbatch * g.splitk), block(WM * WN * 64);
@@ -224,7 +238,37 @@ int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   if (g.nb1 <= 0) g.nb1 = 1;
   if (g.kbatch <= 0) g.kbatch = 1;
   g.splitk = 1;
-  if (g.M <= 32) return launch_cfg<32, 128, 1, 4>(g, nbatch, s);
+  if (g.M <= 32) {
+    // batch-sized products (M = B rows against a whole weight matrix: CellStateEncoder, the per-step GEMMs of the
+    // generic decoder path): N / 128 workgroups would leave most of the chip idle -> split K over workgroups
+    // (fp32 atomics onto a zeroed / existing C), bias + activation in a second tiny pass
+    const long tiles = (long)cdiv(g.N, 128) * nbatch;
+    const long ktiles = (long)cdiv(g.K, 16) * g.kbatch;
+    const bool plain_beta = g.beta == 0.f || (g.beta == 1.f && g.bias == nullptr && g.act == ACT_NONE);
+    if (nbatch == 1 && g.scn == 1 && plain_beta && ktiles >= 16 && tiles < 128) {
+      long sk = (256 + tiles - 1) / tiles;
+      if (sk > ktiles / 4) sk = ktiles / 4;
+      if (sk > 64) sk = 64;
+      if (sk > 1) {
+        const float* bias = g.bias;
+        const int act = g.act;
+        const long n = (long)g.M * g.N, blocks = (n + 255) / 256;
+        if (g.beta == 0.f) {
+          hipLaunchKernelGGL(rows_fill_k, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, s, g.C, g.M, g.N, g.scm);
+          ZLAUNCH_CHECK("gemm_rows_fill");
+        }
+        g.bias = nullptr; g.act = ACT_NONE; g.splitk = (int)sk;
+        ZTRY((launch_cfg<32, 128, 1, 4>(g, nbatch, s)));
+        if (bias || act != ACT_NONE) {
+          hipLaunchKernelGGL(rows_bias_act_k, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, s, g.C, bias, g.M,
+                             g.N, g.scm, act);
+          ZLAUNCH_CHECK("gemm_rows_bias_act");
+        }
+        return 0;
+      }
+    }
+    return launch_cfg<32, 128, 1, 4>(g, nbatch, s);
+  }
   const bool big = g.M > 64 && g.N > 64;
   const long tiles = big ? (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nbatch : (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nbatch;
   const long ktiles = (long)cdiv(g.K, 16) * g.kbatch;
