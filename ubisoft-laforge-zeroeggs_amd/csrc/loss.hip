@@ -27,12 +27,15 @@ __host__ __device__ inline Off offsets(int J) {
 
 struct LossWs {
   float *FO, *FW, *LM, *G, *DQ;
+  float *PT0, *PT1, *DPT;   // pose rows of both sides / their gradient, transposed to [PO][frames]
 };
 LossWs carve_loss(const ZeggsLossDims& d, Arena& a) {
   LossWs w;
   const long NF = (long)d.B * d.T;
   const Off o = offsets(d.J);
   w.FO = a.f(NF * o.n); w.FW = a.f(NF * o.n); w.LM = a.f(NF * 9 * d.J); w.G = a.f(NF * o.n); w.DQ = a.f(NF * 4);
+  const long PO = 6 + 15 * d.J;
+  w.PT0 = a.f(NF * PO); w.PT1 = a.f(NF * PO); w.DPT = a.f(NF * PO);
   return w;
 }
 
@@ -115,12 +118,37 @@ __device__ __forceinline__ V3 normalize_bwd(V3 a, V3 g, float e) {
 struct FrameIO {
   const float *pose, *rpos, *rrot;   // [B,T,*]
 };
+// The frame kernels run one thread per frame: the [frame][PO] pose rows are first transposed to [PO][frame] so that
+// the 64 lanes of a wave read / write consecutive addresses (a lane-per-row access touches 64 cache lines per
+// instruction).  Col / ColW keep the row-style indexing p[k] over the transposed table.
+struct Col {
+  const float* base; long NF, f;
+  __device__ __forceinline__ float operator[](int k) const { return base[(long)k * NF + f]; }
+  __device__ __forceinline__ Col operator+(int k) const { return Col{base + (long)k * NF, NF, f}; }
+};
+struct ColW {
+  float* base; long NF, f;
+  __device__ __forceinline__ float& operator[](int k) const { return base[(long)k * NF + f]; }
+  __device__ __forceinline__ ColW operator+(int k) const { return ColW{base + (long)k * NF, NF, f}; }
+};
+// dst[c][r] = src[r][c] for an [R][C] row-major source (64x64 tiles through LDS, both sides coalesced)
+__global__ __launch_bounds__(256) void transpose_k(float* dst, const float* src, long R, int C) {
+  __shared__ float tile[64][65];
+  const long r0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4)
+    if (r0 + i < R && c0 + tx < C) tile[i][tx] = src[(r0 + i) * C + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4)
+    if (c0 + i < C && r0 + tx < R) dst[(long)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
 
 #define FE(F, e) (F)[(long)(e) * NF + f]
 
 // forward per frame; side 0 = prediction (also stores local matrices LM), side 1 = ground truth
 __global__ __launch_bounds__(64) void loss_frame_fwd_k(ZeggsLossDims d, const int* parents, FrameIO io0, FrameIO io1,
-                                                        const float* gaze, float* F0, float* F1, float* LM) {
+                                                        const float* PT0, const float* PT1, const float* gaze, float* F0,
+                                                        float* F1, float* LM) {
   const long NF = (long)d.B * d.T;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= 2 * NF) return;
@@ -131,7 +159,7 @@ __global__ __launch_bounds__(64) void loss_frame_fwd_k(ZeggsLossDims d, const in
   const int J = d.J, t = (int)(f % d.T);
   const Off o = offsets(J);
   const int PO = 6 + 15 * J;
-  const float* p = io.pose + f * PO;
+  const Col p{side ? PT1 : PT0, NF, f};
   const float* rq = io.rrot + f * 4;
   const float* rqp = io.rrot + (t > 0 ? f - 1 : f) * 4;
   Q4 q = Q4{rq[0], rq[1], rq[2], rq[3]}, qp = Q4{rqp[0], rqp[1], rqp[2], rqp[3]};
@@ -150,7 +178,7 @@ __global__ __launch_bounds__(64) void loss_frame_fwd_k(ZeggsLossDims d, const in
     V3 gd = quat_mul_vec(quat_inv(q), inv * v);
     FE(F, o.gaze) = gd.x; FE(F, o.gaze + 1) = gd.y; FE(F, o.gaze + 2) = gd.z;
   }
-  const float *lpos = p + 6, *ltxy = p + 6 + 3 * J, *lvel = p + 6 + 9 * J, *lvrt = p + 6 + 12 * J;
+  const Col lpos = p + 6, ltxy = p + (6 + 3 * J), lvel = p + (6 + 9 * J), lvrt = p + (6 + 12 * J);
   for (int i = 0; i < J; ++i) {
     // orthogonalise (txform.py:23-34): columns x^, y^, z^
     V3 x = v3(ltxy[6 * i], ltxy[6 * i + 1], ltxy[6 * i + 2]), yi = v3(ltxy[6 * i + 3], ltxy[6 * i + 4], ltxy[6 * i + 5]);
@@ -262,21 +290,21 @@ __global__ __launch_bounds__(256) void loss_terms_k(ZeggsLossDims d, const float
 // Consumes G in place (its c* rows become running totals).  Writes dpose[6:], drpos, DQ (grad wrt rrot_f from
 // everything except the root-velocity rotation) and leaves total grads wrt rvel/rvrt in G's rvel/rvrt rows.
 __global__ __launch_bounds__(64) void loss_frame_bwd_k(ZeggsLossDims d, const int* parents, FrameIO io, const float* gaze,
-                                                        const float* F, const float* LM, float* G, float* dpose,
-                                                        float* drpos, float* DQ) {
+                                                        const float* PT, const float* F, const float* LM, float* G,
+                                                        float* DPT, float* drpos, float* DQ) {
   const long NF = (long)d.B * d.T;
   const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= NF) return;
   const int J = d.J;
   const Off o = offsets(J);
   const int PO = 6 + 15 * J;
-  const float* p = io.pose + f * PO;
-  float* dp = dpose + f * PO;
+  const Col p{PT, NF, f};
+  const ColW dp{DPT, NF, f};
   const float* rq = io.rrot + f * 4;
   Q4 q = Q4{rq[0], rq[1], rq[2], rq[3]};
   V3 rpos = v3(io.rpos[f * 3], io.rpos[f * 3 + 1], io.rpos[f * 3 + 2]);
-  const float *lpos = p + 6, *ltxy = p + 6 + 3 * J, *lvel = p + 6 + 9 * J, *lvrt = p + 6 + 12 * J;
-  float *dlpos = dp + 6, *dltxy = dp + 6 + 3 * J, *dlvel = dp + 6 + 9 * J, *dlvrt = dp + 6 + 12 * J;
+  const Col lpos = p + 6, ltxy = p + (6 + 3 * J), lvel = p + (6 + 9 * J), lvrt = p + (6 + 12 * J);
+  const ColW dlpos = dp + 6, dltxy = dp + (6 + 3 * J), dlvel = dp + (6 + 9 * J), dlvrt = dp + (6 + 12 * J);
   auto ld3 = [&](const float* A, int e) { return v3(A[(long)e * NF + f], A[(long)(e + 1) * NF + f], A[(long)(e + 2) * NF + f]); };
   auto st3 = [&](float* A, int e, V3 v) { A[(long)e * NF + f] = v.x; A[(long)(e + 1) * NF + f] = v.y; A[(long)(e + 2) * NF + f] = v.z; };
   auto ld9 = [&](const float* A, int e) { M3 m; for (int k = 0; k < 9; ++k) m.m[k] = A[(long)(e + k) * NF + f]; return m; };
@@ -472,7 +500,12 @@ extern "C" int zeggs_loss_fwd_bwd(const ZeggsLossDims* dp, const int* parents, c
   const Off o = offsets(d.J);
   FrameIO ioO{o_pose, o_rpos, o_rrot}, ioW{w_pose, w_rpos, w_rrot};
   ZTRY(k_fill(terms, 19, 0.f, s));
-  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(2 * NF, 64)), dim3(64), 0, s, d, parents, ioO, ioW, gaze, w.FO, w.FW, w.LM);
+  const int PO = 6 + 15 * d.J;
+  const dim3 tg((unsigned)cdiv(NF, 64), (unsigned)cdiv(PO, 64));
+  hipLaunchKernelGGL(transpose_k, tg, dim3(256), 0, s, w.PT0, o_pose, NF, PO);
+  hipLaunchKernelGGL(transpose_k, tg, dim3(256), 0, s, w.PT1, w_pose, NF, PO);
+  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(2 * NF, 64)), dim3(64), 0, s, d, parents, ioO, ioW, w.PT0, w.PT1, gaze, w.FO,
+                     w.FW, w.LM);
   ZLAUNCH_CHECK("loss_frame_fwd");
   hipLaunchKernelGGL(loss_terms_k, dim3(o.n), dim3(256), 0, s, d, w.FO, w.FW, w.G, terms, gscale);
   ZLAUNCH_CHECK("loss_terms");
@@ -480,9 +513,13 @@ extern "C" int zeggs_loss_fwd_bwd(const ZeggsLossDims* dp, const int* parents, c
                      gscale);
   ZLAUNCH_CHECK("loss_kl_final");
   if (dpose) {
-    hipLaunchKernelGGL(loss_frame_bwd_k, dim3(cdiv(NF, 64)), dim3(64), 0, s, d, parents, ioO, gaze, w.FO, w.LM, w.G, dpose,
-                       drpos, w.DQ);
+    hipLaunchKernelGGL(loss_frame_bwd_k, dim3(cdiv(NF, 64)), dim3(64), 0, s, d, parents, ioO, gaze, w.PT0, w.FO, w.LM, w.G,
+                       w.DPT, drpos, w.DQ);
     ZLAUNCH_CHECK("loss_frame_bwd");
+    // back to [frame][PO] (columns 0..5 hold nothing yet: the root-velocity kernel below writes them)
+    hipLaunchKernelGGL(transpose_k, dim3((unsigned)cdiv(PO, 64), (unsigned)cdiv(NF, 64)), dim3(256), 0, s, dpose, w.DPT,
+                       (long)PO, (int)NF);
+    ZLAUNCH_CHECK("loss_transpose");
     hipLaunchKernelGGL(loss_rootvel_bwd_k, dim3(cdiv(NF, 256)), dim3(256), 0, s, d, ioO, w.G, w.DQ, dpose, drrot);
     ZLAUNCH_CHECK("loss_rootvel_bwd");
   }
