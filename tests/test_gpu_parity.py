@@ -313,7 +313,7 @@ def _rollout_with_grads(de, B, T, seed, style_dim=64):
     return (pose.detach(), rp.detach(), rr.detach()), grads, speech.grad.clone(), style.grad.clone()
 
 
-@pytest.mark.parametrize("B,T", [(32, 12), (1, 9), (5, 7), (33, 5)])
+@pytest.mark.parametrize("B,T", [(32, 12), (1, 9), (5, 7), (33, 5), (32, 2), (16, 3), (17, 4), (64, 6)])
 def test_decoder_fast_path_matches_generic_path(B, T):
     _, de, _ = helpers.build_nets()
     de = de.to(DEV).train()
