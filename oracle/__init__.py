@@ -14,8 +14,9 @@ Rules (see DESIGN.md "Oracle"):
     build container: oracle/make_golden.py imports /root/reference through
     the shims in oracle/ref_shims.py and writes tests/golden/*.npz; the
     `-m "not gpu"` tests check this restatement against those fixtures.
-  * Parity status: PINNED for nets / loss / RAdam / mel / dataset index rules
-    (golden vectors from the reference itself).  UNPINNED for the BS.1770
+  * Parity status: PINNED for nets (incl. the rnn_cond="film" / type="gru"
+    variants) / loss / RAdam / mel / dataset index rules / animation pre- and
+    post-processing (golden vectors from the reference itself).  UNPINNED for the BS.1770
     loudness stage (pyloudnorm==0.1.0 is a third-party dependency absent from
     this image; golden vectors use normalize_loudness=false).
 """

@@ -1,8 +1,10 @@
 // Fast path of the decoder step: weight-streaming MFMA stage kernels over fragment-packed operands.
 //
-// One decoder step is a chain of four dependent matrix stages (layer0 -> GRU l0 -> GRU l1 -> layer2)
+// One decoder step is a chain of dependent matrix stages (layer0 -> GRU l0 -> GRU l1 -> layer2)
 // with M = batch <= 64 rows: at B = 32 every stage is bound by streaming its weights once
-// (75.7 MB per step).  Design for gfx950:
+// (75.7 MB per step).  layer2 of step t and layer0 of step t+1 are folded into one
+// launch (dec_fast_pack_merged), and so are their backward counterparts: 3 launches per step in each
+// direction.  Design for gfx950:
 //   * weights are re-packed once per optimizer step into MFMA *fragment order*: for every tile of
 //     16 "virtual output columns" and every block of 16 k-values, 64 lanes x float4 = one contiguous
 //     1 KiB block, so each wave-level load is a perfectly coalesced global_load_dwordx4 stream
@@ -13,8 +15,8 @@
 //   * v_mfma_f32_16x16x4_f32: A = 16 weight rows, B = 16 batch columns; a float4 per lane feeds 4 MFMAs;
 //   * one workgroup (8 waves) owns one 16-column tile for the FULL contraction: the waves split K,
 //     reduce through LDS, and the epilogue (bias, ELU, GRU gate math, pose integration, next-step
-//     vectorisation, and their backward counterparts) runs in the same launch -> 4 launches per step,
-//     no cross-workgroup partial sums, no grid barrier;
+//     vectorisation, and their backward counterparts) runs in the same launch: no cross-workgroup
+//     partial sums, no grid barrier (tools/barrier_probe.hip: 6.4 us vs 2.6 us for a kernel boundary);
 //   * GRU tiles interleave the r, z, n rows of 5 hidden units (15 of 16 columns) so the gate math
 //     needs no second pass; the input-side and hidden-side products use two accumulator sets.
 // Backward uses the transposed packs (16 output units x contraction over gate rows).
