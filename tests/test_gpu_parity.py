@@ -712,3 +712,46 @@ def test_streaming_matches_offline_generation(seed, nsamp):
     assert sum(1 for o in outs if o) >= 3                                   # frames really left incrementally
     for k, r in zip(("pose", "rpos", "rrot"), ref):
         assert float((cat(k) - r[0]).abs().max()) < 5e-5, k
+
+
+# ----------------------------------------------------------------------------- BASELINE.json full size
+def test_full_size_rollout_fast_equals_generic_and_is_linear_in_loss_weights():
+    """configs[1] shape (B=32, T=256): the fragment-packed stage kernels (merged stages, batch split) and the generic
+    per-step GEMM path are two independent implementations of the same recurrence -> outputs and all gradients agree;
+    and BPTT is linear in the upstream gradient (2x the loss weights -> 2x every gradient)."""
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).train()
+    B, T = 32, 256
+    try:
+        ops.set_option("decoder_fast", 0)
+        out0, g0, ds0, dy0 = _rollout_with_grads(de, B, T, 21)
+        ops.set_option("decoder_fast", 1)
+        out1, g1, ds1, dy1 = _rollout_with_grads(de, B, T, 21)
+    finally:
+        ops.set_option("decoder_fast", 1)
+    for a, b in zip(out0, out1):
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) < 5e-4        # 255 chained steps of fp32 re-association
+    assert relerr(ds1, ds0) < 2e-3 and relerr(dy1, dy0) < 2e-3
+    for k in g0:
+        assert relerr(g1[k], g0[k]) < 2e-3, k
+    # linearity of the backward sweep in the upstream gradient
+    torch.manual_seed(21)
+    stats = synth.make_stats()
+    s = {k: g(v) for k, v in helpers.stats_tensors().items()}
+    clips = [synth.make_clip(T, seed=300 + b, stats=stats) for b in range(B)]
+    tt = lambda k: g(torch.as_tensor(np.stack([c[k] for c in clips])))  # noqa: E731
+    pose0 = _pack_pose(tt("Y_root_vel"), tt("Y_root_vrt"), tt("Y_lpos"), tt("Y_ltxy"), tt("Y_lvel"), tt("Y_lvrt"))[:, 0]
+    speech = (torch.randn(B, T, 64, device=DEV) * 0.5).requires_grad_(True)
+    style = torch.randn(B, T, 64, device=DEV) * 0.5
+    grads = []
+    for scale in (1.0, 2.0):
+        de.zero_grad()
+        speech.grad = None
+        pose, rp, rr = ops.decoder_core(de, pose0.contiguous(), tt("Y_root_pos")[:, 0].contiguous(),
+                                        tt("Y_root_rot")[:, 0].contiguous(), tt("Y_gaze_pos"), speech, style, s["in_mean"],
+                                        s["in_std"], s["out_mean"], s["out_std"], synth.DT)
+        torch.manual_seed(5)
+        wp = torch.randn_like(pose)
+        (scale * (pose * wp).sum()).backward()
+        grads.append((speech.grad.clone(), de.recurrent_decoder.layer1.weight_hh_l0.grad.clone()))
+    assert relerr(grads[1][0], 2.0 * grads[0][0]) < 1e-4 and relerr(grads[1][1], 2.0 * grads[0][1]) < 1e-4
