@@ -145,15 +145,49 @@ __global__ __launch_bounds__(256) void transpose_k(float* dst, const float* src,
 
 #define FE(F, e) (F)[(long)(e) * NF + f]
 
-// forward per frame; side 0 = prediction (also stores local matrices LM), side 1 = ground truth
-__global__ __launch_bounds__(64) void loss_frame_fwd_k(ZeggsLossDims d, const int* parents, FrameIO io0, FrameIO io1,
+// Joints grouped by depth in the skeleton tree: the joints of one level are independent of each other, so the waves
+// of a workgroup walk the tree level by level (critical path = tree depth, ~13 for the 75-joint rig, instead of J).
+// Built in LDS by every workgroup (J is small): lvl_start[l] .. lvl_start[l+1] index lvl_joint[].
+constexpr int MAXJ = 256;
+struct Levels { int start[MAXJ + 1]; int joint[MAXJ]; int depth[MAXJ]; int nlevels; };
+__device__ void build_levels(Levels& L, const int* parents, int J) {
+  for (int j = threadIdx.x; j <= J; j += blockDim.x) L.start[j] = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < J; j += blockDim.x) {
+    int dpt = 0;
+    for (int p = parents[j]; p >= 0; p = parents[p]) ++dpt;
+    L.depth[j] = dpt;
+    atomicAdd(&L.start[dpt + 1], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int nl = 0;
+    for (int l = 0; l < J; ++l) { if (L.start[l + 1] > 0) nl = l + 1; L.start[l + 1] += L.start[l]; }
+    L.nlevels = nl;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < J; j += blockDim.x) {   // index order within a level (deterministic)
+    const int dj = L.depth[j];
+    int pos = L.start[dj];
+    for (int q = 0; q < j; ++q) pos += (L.depth[q] == dj);
+    L.joint[pos] = j;
+  }
+  __syncthreads();
+}
+
+// forward per frame; side 0 = prediction (also stores local matrices LM), side 1 = ground truth.
+// One workgroup = 64 consecutive frames (lanes) x 8 waves sharing the joints of each tree level.
+__global__ __launch_bounds__(512) void loss_frame_fwd_k(ZeggsLossDims d, const int* parents, FrameIO io0, FrameIO io1,
                                                         const float* PT0, const float* PT1, const float* gaze, float* F0,
                                                         float* F1, float* LM) {
+  __shared__ Levels lv;
   const long NF = (long)d.B * d.T;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= 2 * NF) return;
-  const int side = gid >= NF;
-  const long f = side ? gid - NF : gid;
+  build_levels(lv, parents, d.J);
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const long gid = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+  const bool live = gid < 2 * NF;                 // dead lanes keep walking (barriers), on a clamped frame, storing nothing
+  const int side = live ? gid >= NF : 0;
+  const long f = live ? (side ? gid - NF : gid) : 0;
   const FrameIO io = side ? io1 : io0;
   float* F = side ? F1 : F0;
   const int J = d.J, t = (int)(f % d.T);
@@ -167,22 +201,24 @@ __global__ __launch_bounds__(64) void loss_frame_fwd_k(ZeggsLossDims d, const in
   V3 rvel = quat_mul_vec(qp, v3(p[0], p[1], p[2]));
   V3 rvrt = quat_mul_vec(qp, v3(p[3], p[4], p[5]));
   M3 R = quat_to_xform(q);
-  FE(F, o.rpos) = rpos.x; FE(F, o.rpos + 1) = rpos.y; FE(F, o.rpos + 2) = rpos.z;
-  for (int k = 0; k < 9; ++k) FE(F, o.rmat + k) = R.m[k];
-  FE(F, o.rvel) = rvel.x; FE(F, o.rvel + 1) = rvel.y; FE(F, o.rvel + 2) = rvel.z;
-  FE(F, o.rvrt) = rvrt.x; FE(F, o.rvrt + 1) = rvrt.y; FE(F, o.rvrt + 2) = rvrt.z;
+  if (live && wave == 0) FE(F, o.rpos) = rpos.x; if (live && wave == 0) FE(F, o.rpos + 1) = rpos.y; if (live && wave == 0) FE(F, o.rpos + 2) = rpos.z;
+  for (int k = 0; k < 9; ++k) if (live && wave == 0) FE(F, o.rmat + k) = R.m[k];
+  if (live && wave == 0) FE(F, o.rvel) = rvel.x; if (live && wave == 0) FE(F, o.rvel + 1) = rvel.y; if (live && wave == 0) FE(F, o.rvel + 2) = rvel.z;
+  if (live && wave == 0) FE(F, o.rvrt) = rvrt.x; if (live && wave == 0) FE(F, o.rvrt + 1) = rvrt.y; if (live && wave == 0) FE(F, o.rvrt + 2) = rvrt.z;
   {
     const float* gz = gaze + f * 3;
     V3 v = v3(gz[0], gz[1], gz[2]) - rpos;
     float inv = 1.f / (vnorm(v) + 1e-8f);
     V3 gd = quat_mul_vec(quat_inv(q), inv * v);
-    FE(F, o.gaze) = gd.x; FE(F, o.gaze + 1) = gd.y; FE(F, o.gaze + 2) = gd.z;
+    if (live && wave == 0) FE(F, o.gaze) = gd.x; if (live && wave == 0) FE(F, o.gaze + 1) = gd.y; if (live && wave == 0) FE(F, o.gaze + 2) = gd.z;
   }
   const Col lpos = p + 6, ltxy = p + (6 + 3 * J), lvel = p + (6 + 9 * J), lvrt = p + (6 + 12 * J);
-  for (int i = 0; i < J; ++i) {
+  for (int l = 0; l < lv.nlevels; ++l) {
+   for (int kk = lv.start[l] + wave; kk < lv.start[l + 1]; kk += nwaves) {
+    const int i = lv.joint[kk];
     // orthogonalise (txform.py:23-34): columns x^, y^, z^
     V3 x = v3(ltxy[6 * i], ltxy[6 * i + 1], ltxy[6 * i + 2]), yi = v3(ltxy[6 * i + 3], ltxy[6 * i + 4], ltxy[6 * i + 5]);
-    for (int k = 0; k < 6; ++k) FE(F, o.ltxy + 6 * i + k) = ltxy[6 * i + k];
+    for (int k = 0; k < 6; ++k) if (live) FE(F, o.ltxy + 6 * i + k) = ltxy[6 * i + k];
     V3 z = cross(x, yi), y = cross(z, x);
     V3 xn = (1.f / (vnorm(x) + 1e-10f)) * x, yn = (1.f / (vnorm(y) + 1e-10f)) * y, zn = (1.f / (vnorm(z) + 1e-10f)) * z;
     M3 L;
@@ -190,7 +226,7 @@ __global__ __launch_bounds__(64) void loss_frame_fwd_k(ZeggsLossDims d, const in
     L.m[3] = xn.y; L.m[4] = yn.y; L.m[5] = zn.y;
     L.m[6] = xn.z; L.m[7] = yn.z; L.m[8] = zn.z;
     if (side == 0)
-      for (int k = 0; k < 9; ++k) FE(LM, 9 * i + k) = L.m[k];
+      for (int k = 0; k < 9; ++k) if (live) FE(LM, 9 * i + k) = L.m[k];
     V3 lp = v3(lpos[3 * i], lpos[3 * i + 1], lpos[3 * i + 2]);
     V3 lv = v3(lvel[3 * i], lvel[3 * i + 1], lvel[3 * i + 2]);
     V3 lw = v3(lvrt[3 * i], lvrt[3 * i + 1], lvrt[3 * i + 2]);
@@ -215,13 +251,15 @@ __global__ __launch_bounds__(64) void loss_frame_fwd_k(ZeggsLossDims d, const in
       cw = pw + mv(pm, lw);
       cv = pv + mv(pm, lv) + cross(pw, rp);
     }
-    FE(F, o.lpos + 3 * i) = lp.x; FE(F, o.lpos + 3 * i + 1) = lp.y; FE(F, o.lpos + 3 * i + 2) = lp.z;
-    FE(F, o.lvel + 3 * i) = lv.x; FE(F, o.lvel + 3 * i + 1) = lv.y; FE(F, o.lvel + 3 * i + 2) = lv.z;
-    FE(F, o.lvrt + 3 * i) = lw.x; FE(F, o.lvrt + 3 * i + 1) = lw.y; FE(F, o.lvrt + 3 * i + 2) = lw.z;
-    FE(F, o.cpos + 3 * i) = cp.x; FE(F, o.cpos + 3 * i + 1) = cp.y; FE(F, o.cpos + 3 * i + 2) = cp.z;
-    FE(F, o.cvel + 3 * i) = cv.x; FE(F, o.cvel + 3 * i + 1) = cv.y; FE(F, o.cvel + 3 * i + 2) = cv.z;
-    FE(F, o.cvrt + 3 * i) = cw.x; FE(F, o.cvrt + 3 * i + 1) = cw.y; FE(F, o.cvrt + 3 * i + 2) = cw.z;
-    for (int k = 0; k < 9; ++k) FE(F, o.cmat + 9 * i + k) = cm.m[k];
+    if (live) FE(F, o.lpos + 3 * i) = lp.x; if (live) FE(F, o.lpos + 3 * i + 1) = lp.y; if (live) FE(F, o.lpos + 3 * i + 2) = lp.z;
+    if (live) FE(F, o.lvel + 3 * i) = lv.x; if (live) FE(F, o.lvel + 3 * i + 1) = lv.y; if (live) FE(F, o.lvel + 3 * i + 2) = lv.z;
+    if (live) FE(F, o.lvrt + 3 * i) = lw.x; if (live) FE(F, o.lvrt + 3 * i + 1) = lw.y; if (live) FE(F, o.lvrt + 3 * i + 2) = lw.z;
+    if (live) FE(F, o.cpos + 3 * i) = cp.x; if (live) FE(F, o.cpos + 3 * i + 1) = cp.y; if (live) FE(F, o.cpos + 3 * i + 2) = cp.z;
+    if (live) FE(F, o.cvel + 3 * i) = cv.x; if (live) FE(F, o.cvel + 3 * i + 1) = cv.y; if (live) FE(F, o.cvel + 3 * i + 2) = cv.z;
+    if (live) FE(F, o.cvrt + 3 * i) = cw.x; if (live) FE(F, o.cvrt + 3 * i + 1) = cw.y; if (live) FE(F, o.cvrt + 3 * i + 2) = cw.z;
+    for (int k = 0; k < 9; ++k) if (live) FE(F, o.cmat + 9 * i + k) = cm.m[k];
+   }
+   __syncthreads();   // the next level reads these joints' transforms (same CU: L1 is coherent within the workgroup)
   }
 }
 
@@ -287,17 +325,46 @@ __global__ __launch_bounds__(256) void loss_terms_k(ZeggsLossDims d, const float
 }
 
 // backward through FK / first-joint transform / orthogonalisation (prediction side), thread per frame.
-// Consumes G in place (its c* rows become running totals).  Writes dpose[6:], drpos, DQ (grad wrt rrot_f from
-// everything except the root-velocity rotation) and leaves total grads wrt rvel/rvrt in G's rvel/rvrt rows.
-__global__ __launch_bounds__(64) void loss_frame_bwd_k(ZeggsLossDims d, const int* parents, FrameIO io, const float* gaze,
-                                                        const float* PT, const float* F, const float* LM, float* G,
-                                                        float* DPT, float* drpos, float* DQ) {
+// Consumes G in place.  Level-parallel like the forward kernel, deepest level first; a joint never writes another
+// joint's rows: it GATHERS the totals of its character-space gradients (its own rows + its children's messages, in
+// descending child order = the summation order of a sequential sweep) and leaves its message to its parent in its own
+// c* rows (cpos / cvel rows already are the message; cmat / cvrt rows are overwritten).  Writes dpose[6:] (transposed
+// table DPT), drpos, DQ (grad wrt rrot_f from everything except the root-velocity rotation) and leaves the total grads
+// wrt rvel / rvrt in G's rvel / rvrt rows.
+struct Children { int start[MAXJ + 1]; int idx[MAXJ]; };
+__device__ void build_children(Children& Cn, const int* parents, int J) {
+  for (int j = threadIdx.x; j <= J; j += blockDim.x) Cn.start[j] = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < J; j += blockDim.x)
+    if (parents[j] >= 0) atomicAdd(&Cn.start[parents[j] + 1], 1);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int j = 0; j < J; ++j) Cn.start[j + 1] += Cn.start[j];
+  __syncthreads();
+  for (int j = threadIdx.x; j < J; j += blockDim.x) {   // children of a parent in DESCENDING index order
+    const int pa = parents[j];
+    if (pa < 0) continue;
+    int pos = Cn.start[pa];
+    for (int q = J - 1; q > j; --q) pos += (parents[q] == pa);
+    Cn.idx[pos] = j;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void loss_frame_bwd_k(ZeggsLossDims d, const int* parents, FrameIO io, const float* gaze,
+                                                         const float* PT, const float* F, const float* LM, float* G,
+                                                         float* DPT, float* drpos, float* DQ) {
+  __shared__ Levels lv;
+  __shared__ Children ch;
   const long NF = (long)d.B * d.T;
-  const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= NF) return;
+  build_levels(lv, parents, d.J);
+  build_children(ch, parents, d.J);
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const long gid = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+  const bool live = gid < NF;
+  const long f = live ? gid : 0;
   const int J = d.J;
   const Off o = offsets(J);
-  const int PO = 6 + 15 * J;
   const Col p{PT, NF, f};
   const ColW dp{DPT, NF, f};
   const float* rq = io.rrot + f * 4;
@@ -306,9 +373,10 @@ __global__ __launch_bounds__(64) void loss_frame_bwd_k(ZeggsLossDims d, const in
   const Col lpos = p + 6, ltxy = p + (6 + 3 * J), lvel = p + (6 + 9 * J), lvrt = p + (6 + 12 * J);
   const ColW dlpos = dp + 6, dltxy = dp + (6 + 3 * J), dlvel = dp + (6 + 9 * J), dlvrt = dp + (6 + 12 * J);
   auto ld3 = [&](const float* A, int e) { return v3(A[(long)e * NF + f], A[(long)(e + 1) * NF + f], A[(long)(e + 2) * NF + f]); };
-  auto st3 = [&](float* A, int e, V3 v) { A[(long)e * NF + f] = v.x; A[(long)(e + 1) * NF + f] = v.y; A[(long)(e + 2) * NF + f] = v.z; };
+  auto st3 = [&](float* A, int e, V3 v) { if (live) { A[(long)e * NF + f] = v.x; A[(long)(e + 1) * NF + f] = v.y; A[(long)(e + 2) * NF + f] = v.z; } };
   auto ld9 = [&](const float* A, int e) { M3 m; for (int k = 0; k < 9; ++k) m.m[k] = A[(long)(e + k) * NF + f]; return m; };
-  auto st9 = [&](float* A, int e, const M3& m) { for (int k = 0; k < 9; ++k) A[(long)(e + k) * NF + f] = m.m[k]; };
+  auto st9 = [&](float* A, int e, const M3& m) { if (live) for (int k = 0; k < 9; ++k) A[(long)(e + k) * NF + f] = m.m[k]; };
+  auto put3 = [&](const ColW& c, int e, V3 v) { if (live) { c[e] = v.x; c[e + 1] = v.y; c[e + 2] = v.z; } };
 
   // orthogonalisation backward for joint i given the grad of its local matrix; adds the direct ltxy-term grad
   auto orth_bwd = [&](int i, const M3& gL) {
@@ -322,67 +390,78 @@ __global__ __launch_bounds__(64) void loss_frame_bwd_k(ZeggsLossDims d, const in
     gx = gx + cross(gy, z);
     gx = gx + cross(yi, gz);         // z = x x yi
     V3 gyi = cross(gz, x);
-    dltxy[6 * i] = gx.x + FE(G, o.ltxy + 6 * i); dltxy[6 * i + 1] = gx.y + FE(G, o.ltxy + 6 * i + 1);
-    dltxy[6 * i + 2] = gx.z + FE(G, o.ltxy + 6 * i + 2);
-    dltxy[6 * i + 3] = gyi.x + FE(G, o.ltxy + 6 * i + 3); dltxy[6 * i + 4] = gyi.y + FE(G, o.ltxy + 6 * i + 4);
-    dltxy[6 * i + 5] = gyi.z + FE(G, o.ltxy + 6 * i + 5);
+    put3(dltxy, 6 * i, gx + ld3(G, o.ltxy + 6 * i));
+    put3(dltxy, 6 * i + 3, gyi + ld3(G, o.ltxy + 6 * i + 3));
+  };
+  // totals of joint i's character-space gradients: own rows + children's messages
+  auto gather = [&](int i, V3& gcp, V3& gcv, V3& gcw, M3& gcm) {
+    gcp = ld3(G, o.cpos + 3 * i); gcv = ld3(G, o.cvel + 3 * i); gcw = ld3(G, o.cvrt + 3 * i); gcm = ld9(G, o.cmat + 9 * i);
+    for (int c = ch.start[i]; c < ch.start[i + 1]; ++c) {
+      const int j = ch.idx[c];
+      gcp = gcp + ld3(G, o.cpos + 3 * j); gcv = gcv + ld3(G, o.cvel + 3 * j); gcw = gcw + ld3(G, o.cvrt + 3 * j);
+      const M3 m = ld9(G, o.cmat + 9 * j);
+      for (int k = 0; k < 9; ++k) gcm.m[k] += m.m[k];
+    }
   };
 
-  for (int i = J - 1; i >= 1; --i) {
-    const int pa = parents[i];
-    M3 pm = ld9(F, o.cmat + 9 * pa);
-    V3 pw = ld3(F, o.cvrt + 3 * pa);
-    V3 lp = v3(lpos[3 * i], lpos[3 * i + 1], lpos[3 * i + 2]);
-    V3 lv = v3(lvel[3 * i], lvel[3 * i + 1], lvel[3 * i + 2]);
-    V3 lw = v3(lvrt[3 * i], lvrt[3 * i + 1], lvrt[3 * i + 2]);
-    M3 L = ld9(LM, 9 * i);
-    V3 rp = mv(pm, lp);
-    V3 gcp = ld3(G, o.cpos + 3 * i), gcv = ld3(G, o.cvel + 3 * i), gcw = ld3(G, o.cvrt + 3 * i);
-    M3 gcm = ld9(G, o.cmat + 9 * i);
-    // parents' running totals
-    M3 gpm = ld9(G, o.cmat + 9 * pa);
-    V3 gpp = ld3(G, o.cpos + 3 * pa), gpv = ld3(G, o.cvel + 3 * pa), gpw = ld3(G, o.cvrt + 3 * pa);
-    // cvel_i = cvel_p + pm lv + pw x rp
-    gpv = gpv + gcv;
-    add_outer(gpm, gcv, lv);
-    V3 glv = mtv(pm, gcv);
-    gpw = gpw + cross(rp, gcv);
-    V3 grp = cross(gcv, pw);
-    // cvrt_i = cvrt_p + pm lw
-    gpw = gpw + gcw;
-    add_outer(gpm, gcw, lw);
-    V3 glw = mtv(pm, gcw);
-    // cmat_i = pm L
-    M3 t1 = mmt(gcm, L);
-    for (int k = 0; k < 9; ++k) gpm.m[k] += t1.m[k];
-    M3 gL = mtm(pm, gcm);
-    // cpos_i = cpos_p + rp
-    gpp = gpp + gcp;
-    grp = grp + gcp;
-    add_outer(gpm, grp, lp);
-    V3 glp = mtv(pm, grp);
-    st9(G, o.cmat + 9 * pa, gpm);
-    st3(G, o.cpos + 3 * pa, gpp); st3(G, o.cvel + 3 * pa, gpv); st3(G, o.cvrt + 3 * pa, gpw);
-    // local features (direct "local" loss terms + FK)
-    V3 a = glp + ld3(G, o.lpos + 3 * i);
-    dlpos[3 * i] = a.x; dlpos[3 * i + 1] = a.y; dlpos[3 * i + 2] = a.z;
-    a = glv + ld3(G, o.lvel + 3 * i);
-    dlvel[3 * i] = a.x; dlvel[3 * i + 1] = a.y; dlvel[3 * i + 2] = a.z;
-    a = glw + ld3(G, o.lvrt + 3 * i);
-    dlvrt[3 * i] = a.x; dlvrt[3 * i + 1] = a.y; dlvrt[3 * i + 2] = a.z;
-    orth_bwd(i, gL);
+  for (int l = lv.nlevels - 1; l >= 1; --l) {
+    for (int kk = lv.start[l] + wave; kk < lv.start[l + 1]; kk += nwaves) {
+      const int i = lv.joint[kk];
+      const int pa = parents[i];
+      M3 pm = ld9(F, o.cmat + 9 * pa);
+      V3 pw = ld3(F, o.cvrt + 3 * pa);
+      V3 lp = v3(lpos[3 * i], lpos[3 * i + 1], lpos[3 * i + 2]);
+      V3 lv_ = v3(lvel[3 * i], lvel[3 * i + 1], lvel[3 * i + 2]);
+      V3 lw = v3(lvrt[3 * i], lvrt[3 * i + 1], lvrt[3 * i + 2]);
+      M3 L = ld9(LM, 9 * i);
+      V3 rp = mv(pm, lp);
+      V3 gcp, gcv, gcw;
+      M3 gcm;
+      gather(i, gcp, gcv, gcw, gcm);
+      // message to the parent: (dm, gcp, gcv, dw)
+      M3 dm;
+      for (int k = 0; k < 9; ++k) dm.m[k] = 0.f;
+      // cvel_i = cvel_p + pm lv + pw x rp
+      add_outer(dm, gcv, lv_);
+      V3 glv = mtv(pm, gcv);
+      V3 dw = cross(rp, gcv);
+      V3 grp = cross(gcv, pw);
+      // cvrt_i = cvrt_p + pm lw
+      dw = dw + gcw;
+      add_outer(dm, gcw, lw);
+      V3 glw = mtv(pm, gcw);
+      // cmat_i = pm L
+      M3 t1 = mmt(gcm, L);
+      for (int k = 0; k < 9; ++k) dm.m[k] += t1.m[k];
+      M3 gL = mtm(pm, gcm);
+      // cpos_i = cpos_p + rp
+      grp = grp + gcp;
+      add_outer(dm, grp, lp);
+      V3 glp = mtv(pm, grp);
+      st9(G, o.cmat + 9 * i, dm);
+      st3(G, o.cpos + 3 * i, gcp); st3(G, o.cvel + 3 * i, gcv); st3(G, o.cvrt + 3 * i, dw);
+      // local features (direct "local" loss terms + FK)
+      put3(dlpos, 3 * i, glp + ld3(G, o.lpos + 3 * i));
+      put3(dlvel, 3 * i, glv + ld3(G, o.lvel + 3 * i));
+      put3(dlvrt, 3 * i, glw + ld3(G, o.lvrt + 3 * i));
+      orth_bwd(i, gL);
+    }
+    __syncthreads();
   }
+  if (wave != 0) return;
   // ---- joint 0: world-space replacement (train.py:296-308)
   {
     V3 rvrt = ld3(F, o.rvrt);
     M3 R = quat_to_xform(q);
     M3 L = ld9(LM, 0);
-    V3 lp = v3(lpos[0], lpos[1], lpos[2]), lv = v3(lvel[0], lvel[1], lvel[2]), lw = v3(lvrt[0], lvrt[1], lvrt[2]);
+    V3 lp = v3(lpos[0], lpos[1], lpos[2]), lv_ = v3(lvel[0], lvel[1], lvel[2]), lw = v3(lvrt[0], lvrt[1], lvrt[2]);
     V3 rl = quat_mul_vec(q, lp);
-    V3 gcp = ld3(G, o.cpos) + ld3(G, o.lpos);      // joint 0 appears in the c* and in the "local" terms
-    V3 gcv = ld3(G, o.cvel) + ld3(G, o.lvel);
-    V3 gcw = ld3(G, o.cvrt) + ld3(G, o.lvrt);
-    M3 gcm = ld9(G, o.cmat);
+    V3 gcp, gcv, gcw;
+    M3 gcm;
+    gather(0, gcp, gcv, gcw, gcm);
+    gcp = gcp + ld3(G, o.lpos);      // joint 0 appears in the c* and in the "local" terms
+    gcv = gcv + ld3(G, o.lvel);
+    gcw = gcw + ld3(G, o.lvrt);
     V3 g_rpos = ld3(G, o.rpos) + gcp;
     V3 g_rvel = ld3(G, o.rvel) + gcv;
     V3 g_rvrt = ld3(G, o.rvrt) + gcw + cross(rl, gcv);
@@ -390,13 +469,13 @@ __global__ __launch_bounds__(64) void loss_frame_bwd_k(ZeggsLossDims d, const in
     Q4 dq = Q4{0.f, 0.f, 0.f, 0.f}, dqt; V3 dv;
     qmv_bwd(q, lp, g_rl, dqt, dv);
     dq.w += dqt.w; dq.x += dqt.x; dq.y += dqt.y; dq.z += dqt.z;
-    dlpos[0] = dv.x; dlpos[1] = dv.y; dlpos[2] = dv.z;
-    qmv_bwd(q, lv, gcv, dqt, dv);
+    put3(dlpos, 0, dv);
+    qmv_bwd(q, lv_, gcv, dqt, dv);
     dq.w += dqt.w; dq.x += dqt.x; dq.y += dqt.y; dq.z += dqt.z;
-    dlvel[0] = dv.x; dlvel[1] = dv.y; dlvel[2] = dv.z;
+    put3(dlvel, 0, dv);
     qmv_bwd(q, lw, gcw, dqt, dv);
     dq.w += dqt.w; dq.x += dqt.x; dq.y += dqt.y; dq.z += dqt.z;
-    dlvrt[0] = dv.x; dlvrt[1] = dv.y; dlvrt[2] = dv.z;
+    put3(dlvrt, 0, dv);
     // lmat0w = R L
     M3 gR = mmt(gcm, L);
     M3 gL = mtm(R, gcm);
@@ -413,8 +492,10 @@ __global__ __launch_bounds__(64) void loss_frame_bwd_k(ZeggsLossDims d, const in
     qmv_bwd(quat_inv(q), inv * v, ld3(G, o.gaze), dqt, dn);
     dq.w += dqt.w; dq.x -= dqt.x; dq.y -= dqt.y; dq.z -= dqt.z;
     g_rpos = g_rpos - normalize_bwd(v, dn, 1e-8f);
-    drpos[f * 3] = g_rpos.x; drpos[f * 3 + 1] = g_rpos.y; drpos[f * 3 + 2] = g_rpos.z;
-    DQ[f * 4] = dq.w; DQ[f * 4 + 1] = dq.x; DQ[f * 4 + 2] = dq.y; DQ[f * 4 + 3] = dq.z;
+    if (live) {
+      drpos[f * 3] = g_rpos.x; drpos[f * 3 + 1] = g_rpos.y; drpos[f * 3 + 2] = g_rpos.z;
+      DQ[f * 4] = dq.w; DQ[f * 4 + 1] = dq.x; DQ[f * 4 + 2] = dq.y; DQ[f * 4 + 3] = dq.z;
+    }
     st3(G, o.rvel, g_rvel);
     st3(G, o.rvrt, g_rvrt);
   }
@@ -504,7 +585,8 @@ extern "C" int zeggs_loss_fwd_bwd(const ZeggsLossDims* dp, const int* parents, c
   const dim3 tg((unsigned)cdiv(NF, 64), (unsigned)cdiv(PO, 64));
   hipLaunchKernelGGL(transpose_k, tg, dim3(256), 0, s, w.PT0, o_pose, NF, PO);
   hipLaunchKernelGGL(transpose_k, tg, dim3(256), 0, s, w.PT1, w_pose, NF, PO);
-  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(2 * NF, 64)), dim3(64), 0, s, d, parents, ioO, ioW, w.PT0, w.PT1, gaze, w.FO,
+  ZCHECK(d.J <= MAXJ, "loss: more than %d joints", MAXJ);
+  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(2 * NF, 64)), dim3(512), 0, s, d, parents, ioO, ioW, w.PT0, w.PT1, gaze, w.FO,
                      w.FW, w.LM);
   ZLAUNCH_CHECK("loss_frame_fwd");
   hipLaunchKernelGGL(loss_terms_k, dim3(o.n), dim3(256), 0, s, d, w.FO, w.FW, w.G, terms, gscale);
@@ -513,7 +595,7 @@ extern "C" int zeggs_loss_fwd_bwd(const ZeggsLossDims* dp, const int* parents, c
                      gscale);
   ZLAUNCH_CHECK("loss_kl_final");
   if (dpose) {
-    hipLaunchKernelGGL(loss_frame_bwd_k, dim3(cdiv(NF, 64)), dim3(64), 0, s, d, parents, ioO, gaze, w.PT0, w.FO, w.LM, w.G,
+    hipLaunchKernelGGL(loss_frame_bwd_k, dim3(cdiv(NF, 64)), dim3(512), 0, s, d, parents, ioO, gaze, w.PT0, w.FO, w.LM, w.G,
                        w.DPT, drpos, w.DQ);
     ZLAUNCH_CHECK("loss_frame_bwd");
     // back to [frame][PO] (columns 0..5 hold nothing yet: the root-velocity kernel below writes them)
