@@ -60,3 +60,26 @@ def test_state_dict_keys_match_reference_layout():
         assert k in skeys
     assert sum(p.numel() for p in de.parameters()) == 23301227
     assert sum(p.numel() for p in st.parameters()) == 2105472
+
+
+def test_streaming_frame_accounting_is_consistent_host_only():
+    """zeggs_mel_frames_ready (host integer rule of the streaming front-end): monotone in the sample count, never
+    promises a frame whose STFT support reaches past the received samples, and reaches the offline frame count's
+    neighbourhood as the signal grows (the tail is flushed by the final call)."""
+    import ctypes as C
+    import math
+    from zeggs import audio, ops
+    L = ops.lib()
+    L.zeggs_mel_frames_ready.restype = C.c_long
+    d = audio.MelDims(800, 200, 80, 16000, 60.0, 1e-5)
+    prev = 0
+    for n in list(range(0, 3000, 37)) + [16000, 16001, 48000, 480000]:
+        k = int(L.zeggs_mel_frames_ready(C.byref(d), C.c_long(n)))
+        assert k >= prev or n < 3000 and k >= 0
+        prev = max(prev, k)
+        for kk in (k - 1,):
+            if kk >= 0:
+                hi = max(math.ceil((80.0 / 60.0) * kk), 1)          # last STFT frame that animation frame kk interpolates
+                assert 200 * hi + 400 <= n, (n, kk, hi)              # its window ends inside the received samples
+        assert k <= audio.n_anim_frames(n) + 1
+    assert int(L.zeggs_mel_frames_ready(C.byref(d), C.c_long(480000))) >= audio.n_anim_frames(480000) - 3
