@@ -755,3 +755,42 @@ def test_full_size_rollout_fast_equals_generic_and_is_linear_in_loss_weights():
         (scale * (pose * wp).sum()).backward()
         grads.append((speech.grad.clone(), de.recurrent_decoder.layer1.weight_hh_l0.grad.clone()))
     assert relerr(grads[1][0], 2.0 * grads[0][0]) < 1e-4 and relerr(grads[1][1], 2.0 * grads[0][1]) < 1e-4
+
+
+def test_decoder_rollout_is_graph_capturable():
+    """the C ABI neither allocates nor synchronises: a whole no_grad rollout (hundreds of stage launches) can be captured
+    into a HIP graph and replayed on new inputs (BASELINE.json configs[4]: graph-captured decode step)"""
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).eval()
+    B, T = 1, 48
+    s = {k: g(v) for k, v in helpers.stats_tensors().items()}
+    stats = synth.make_stats()
+    clip = synth.make_clip(T, seed=811, stats=stats)
+    tt = lambda k: g(torch.as_tensor(clip[k][None]))  # noqa: E731
+    pose0 = _pack_pose(tt("Y_root_vel"), tt("Y_root_vrt"), tt("Y_lpos"), tt("Y_ltxy"), tt("Y_lvel"), tt("Y_lvrt"))[:, 0].contiguous()
+    rp0, rr0, gaze = tt("Y_root_pos")[:, 0].contiguous(), tt("Y_root_rot")[:, 0].contiguous(), tt("Y_gaze_pos")
+    torch.manual_seed(12)
+    speech, style = torch.randn(B, T, 64, device=DEV) * 0.5, torch.randn(B, T, 64, device=DEV) * 0.5
+    run = lambda: ops.decoder_core(de, pose0, rp0, rr0, gaze, speech, style, s["in_mean"], s["in_std"], s["out_mean"],  # noqa: E731
+                                   s["out_std"], synth.DT)
+    with torch.no_grad():
+        ref1 = [t.clone() for t in run()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()                                      # warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = run()
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(out, ref1):
+            assert float((a - b).abs().max()) < 1e-6
+        speech.copy_(torch.randn(B, T, 64, device=DEV) * 0.5)      # new input in the captured buffers
+        graph.replay()
+        torch.cuda.synchronize()
+        ref2 = run()
+        for a, b in zip(out, ref2):
+            assert float((a - b).abs().max()) < 1e-6
+        assert float((ref2[0] - ref1[0]).abs().max()) > 1e-3       # the replay really consumed the new speech
