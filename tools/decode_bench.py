@@ -29,3 +29,22 @@ with torch.no_grad():
     dt = time.perf_counter() - t0
 print(f"B={B} T={T}: {dt * 1e6 / (T - 1):.2f} us/step, {B * (T - 1) / dt:.0f} frames/s, "
       f"{75698604 / (dt / (T - 1)) / 1e9:.0f} GB/s weight stream")
+
+# the same rollout replayed from a HIP graph (host launch cost out of the picture)
+if len(sys.argv) > 3 and sys.argv[3] == "graph":
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.decoder_core(*args)
+        torch.cuda.current_stream().wait_stream(side)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            ops.decoder_core(*args)
+        gr.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gr.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(f"graph replay: {dt * 1e6 / (T - 1):.2f} us/step, {B * (T - 1) / dt:.0f} frames/s")
