@@ -300,8 +300,10 @@ __global__ void add_style0_grad_k(ZeggsDecDims d, const float* dcse_in, float* d
 }
 
 // weight gradients of the recurrent part for the steps t_lo..t_hi: contraction over the flattened (t, b) rows
+// compact != 0 (fast path): DH0 / DH1 hold only the n rows of the hidden-side gate gradients, [T][B][H]; their r, z rows
+// are the r, z rows of DI0 / DI1.
 int dec_recurrent_wgrads(const ZeggsDecDims& d, const DecWs& w, const ZeggsDecGrads* G, int t_lo, int t_hi, float beta,
-                         hipStream_t s) {
+                         int compact, hipStream_t s) {
   const int B = d.B, H = d.H, GL = w.GL, XD = w.XD, POL = w.POL;
   const long sG = (long)B * GL, sH = (long)B * H, s3 = 3 * sH, sY = (long)B * POL;
   const int M = (t_hi - t_lo + 1) * B;
@@ -321,13 +323,27 @@ int dec_recurrent_wgrads(const ZeggsDecDims& d, const DecWs& w, const ZeggsDecGr
     ZTRY(k_colsum(G->l2_b, w.DY + o * sY, M, d.PO, POL, beta, s));
   }
   ZTRY(gemm_tn(w.DI1 + o * s3, 3 * H, w.H0 + o * sH, H, G->w_ih1, H, M, 3 * H, H, beta, s));
-  ZTRY(gemm_tn(w.DH1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, M, 3 * H, H, beta, s));
   ZTRY(k_colsum(G->b_ih1, w.DI1 + o * s3, M, 3 * H, 3 * H, beta, s));
-  ZTRY(k_colsum(G->b_hh1, w.DH1 + o * s3, M, 3 * H, 3 * H, beta, s));
+  if (compact) {
+    ZTRY(gemm_tn(w.DI1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, M, 2 * H, H, beta, s));
+    ZTRY(gemm_tn(w.DH1 + o * sH, H, w.H1 + (o - 1) * sH, H, G->w_hh1 + 2L * H * H, H, M, H, H, beta, s));
+    ZTRY(k_colsum(G->b_hh1, w.DI1 + o * s3, M, 2 * H, 3 * H, beta, s));
+    ZTRY(k_colsum(G->b_hh1 + 2 * H, w.DH1 + o * sH, M, H, H, beta, s));
+  } else {
+    ZTRY(gemm_tn(w.DH1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, M, 3 * H, H, beta, s));
+    ZTRY(k_colsum(G->b_hh1, w.DH1 + o * s3, M, 3 * H, 3 * H, beta, s));
+  }
   ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.Gin + o * sG, GL, G->w_ih0, H + XD, M, 3 * H, H + XD, beta, s));
-  ZTRY(gemm_tn(w.DH0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 3 * H, H, beta, s));
   ZTRY(k_colsum(G->b_ih0, w.DI0 + o * s3, M, 3 * H, 3 * H, beta, s));
-  ZTRY(k_colsum(G->b_hh0, w.DH0 + o * s3, M, 3 * H, 3 * H, beta, s));
+  if (compact) {
+    ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 2 * H, H, beta, s));
+    ZTRY(gemm_tn(w.DH0 + o * sH, H, w.H0 + (o - 1) * sH, H, G->w_hh0 + 2L * H * H, H, M, H, H, beta, s));
+    ZTRY(k_colsum(G->b_hh0, w.DI0 + o * s3, M, 2 * H, 3 * H, beta, s));
+    ZTRY(k_colsum(G->b_hh0 + 2 * H, w.DH0 + o * sH, M, H, H, beta, s));
+  } else {
+    ZTRY(gemm_tn(w.DH0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 3 * H, H, beta, s));
+    ZTRY(k_colsum(G->b_hh0, w.DH0 + o * s3, M, 3 * H, 3 * H, beta, s));
+  }
   ZTRY(gemm_tn(w.D0 + o * sH, H, w.Gin + o * sG + H, GL, G->l0_w, XD, M, H, XD, beta, s));
   ZTRY(k_colsum(G->l0_b, w.D0 + o * sH, M, H, H, beta, s));
   return 0;
@@ -520,7 +536,8 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   ZCHECK(T > 1, "decoder bwd: T must be > 1");
   bool wgrads_done = false;
   SideStream* ss = nullptr;
-  if (g_decoder_fast && dec_fast_supported(d)) {
+  const bool fast_path = g_decoder_fast && dec_fast_supported(d);
+  if (fast_path) {
     ZTRY(dec_fast_pack_bwd(d, P, st, w, s));
     // The sweep is a chain of small dependent launches that leaves most of the chip idle; the weight-gradient
     // GEMMs of the steps already swept run beside it on a low-priority stream, chunk by chunk.
@@ -532,7 +549,7 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
       if (nch > 1) {
         ZCHECK(hipEventRecord(ss->chunk, s) == hipSuccess, "hipEventRecord failed");
         ZCHECK(hipStreamWaitEvent(ss->s, ss->chunk, 0) == hipSuccess, "hipStreamWaitEvent failed");
-        ZTRY(dec_recurrent_wgrads(d, w, G, t_lo, t_hi, c == 0 ? 0.f : 1.f, ss->s));
+        ZTRY(dec_recurrent_wgrads(d, w, G, t_lo, t_hi, c == 0 ? 0.f : 1.f, 1, ss->s));
       }
     }
     if (nch > 1) {
@@ -585,7 +602,7 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   }
   }
   // ---- CellStateEncoder backward: dH0c / dH1c are the grads wrt its two output halves
-  if (!wgrads_done) ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, s));
+  if (!wgrads_done) ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, s));
   {
     // out = [H0_init | H1_init] = cse_b W2^T + b2
     ZTRY(gemm_tn(w.dH0c, H, w.cse_b, H, G->c2_w, H, B, H, H, 0.f, s));

@@ -44,6 +44,7 @@ struct Seg {
   const float* xc;  // GEMV mode (batch <= 4, inference): the same activations in canonical row-major form
   int ldx;
   int fixed;        // 1: every workgroup streams weight tile 0 of this pack (the root columns of layer2)
+  int tkb;          // k-blocks per tile in the pack when this segment is a k-sub-range of it (0: = kb; w is pre-offset)
 };
 struct Grp {
   Seg seg[3];
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       const int lo = (b0 > base ? b0 : base) - base;
       const int hi = (b1 < base + kbs ? b1 : base + kbs) - base;
       if (lo < hi) {
-        const f4* wp = (const f4*)G.seg[s].w + ((long)(G.seg[s].fixed ? 0 : tile) * kbs) * 64 + lane;
+        const f4* wp = (const f4*)G.seg[s].w + ((long)(G.seg[s].fixed ? 0 : tile) * (G.seg[s].tkb ? G.seg[s].tkb : kbs)) * 64 + lane;
         const float* xc = G.seg[s].xc + 4 * (lane >> 4);
         const int ldx = G.seg[s].ldx;
         float part[BV];
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       const int lo = (b0 > base ? b0 : base) - base;
       const int hi = (b1 < base + kbs ? b1 : base + kbs) - base;
       if (lo < hi) {
-        const f4* wp = (const f4*)G.seg[s].w + ((long)(G.seg[s].fixed ? 0 : tile) * kbs) * 64 + lane;
+        const f4* wp = (const f4*)G.seg[s].w + ((long)(G.seg[s].fixed ? 0 : tile) * (G.seg[s].tkb ? G.seg[s].tkb : kbs)) * 64 + lane;
         const f4* xp = (const f4*)G.seg[s].x + nb0 * 64 + lane;
         if (G.seg[s].acc == 0) run_blocks<NB>(wp, xp, lo, hi, acc[0], LNB);
         else run_blocks<NB>(wp, xp, lo, hi, acc[1], LNB);
@@ -540,12 +541,10 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         const float dar = dan * nh * r * (1.f - r);
         const float daz = dz * z * (1.f - z);
         float* di = G.o1 + (long)b * 3 * H;
-        float* dh = G.o2 + (long)b * 3 * H;
         di[U] = dar; di[H + U] = daz; di[2 * H + U] = dan;
-        dh[U] = dar; dh[H + U] = daz; dh[2 * H + U] = dan * r;
+        G.o2[i] = dan * r;                 // hidden-side gradient: only its n rows differ from di (r, z rows are shared)
         G.o3[xf_index(b, U, LNB)] = dar; G.o3[xf_index(b, H + U, LNB)] = daz; G.o3[xf_index(b, 2 * H + U, LNB)] = dan;
-        G.o4[xf_index(b, U, LNB)] = dar; G.o4[xf_index(b, H + U, LNB)] = daz;
-        G.o4[xf_index(b, 2 * H + U, LNB)] = dan * r;
+        G.o4[xf_index(b, U, LNB)] = dan * r;
         G.o0[i] = g * z;
       }
     } break;
@@ -576,12 +575,10 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         const float dar = dan * nh * r * (1.f - r);
         const float daz = dz * z * (1.f - z);
         float* di = G.o1 + (long)b * 3 * H;
-        float* dh = G.o2 + (long)b * 3 * H;
         di[U] = dar; di[H + U] = daz; di[2 * H + U] = dan;
-        dh[U] = dar; dh[H + U] = daz; dh[2 * H + U] = dan * r;
+        G.o2[i] = dan * r;                 // hidden-side gradient: only its n rows differ from di (r, z rows are shared)
         G.o3[xf_index(b, U, LNB)] = dar; G.o3[xf_index(b, H + U, LNB)] = daz; G.o3[xf_index(b, 2 * H + U, LNB)] = dan;
-        G.o4[xf_index(b, U, LNB)] = dar; G.o4[xf_index(b, H + U, LNB)] = daz;
-        G.o4[xf_index(b, 2 * H + U, LNB)] = dan * r;
+        G.o4[xf_index(b, U, LNB)] = dan * r;
         G.o0[i] = g * z;
       }
     } break;
@@ -762,7 +759,11 @@ int launch_stage(const StageArgs& a, hipStream_t s) {
 }
 
 inline Seg seg(const float* w, const float* x, int kb, int acc, const float* xc = nullptr, int ldx = 0, int fixed = 0) {
-  return Seg{w, x, kb, acc, xc, ldx, fixed};
+  return Seg{w, x, kb, acc, xc, ldx, fixed, 0};
+}
+// k-blocks [kb0, kb0 + kb) of a pack with `tkb` blocks per tile
+inline Seg subseg(const float* w, const float* x, int kb0, int kb, int tkb, int acc) {
+  return Seg{w + (long)kb0 * 256, x, kb, acc, nullptr, 0, 0, tkb};
 }
 
 // W0s = W0[:, :PO] diag(sigma_o / sigma_i) (zero padded to POL columns); v = (b2 sigma_o + mu_o - mu_i) / sigma_i
@@ -961,22 +962,27 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
       a.g[0] = Grp{}; a.g[1] = Grp{};
       a.g[0].seg[0] = seg(w.pb_l2, w.DYxf, w.KBPO, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
       a.g[0].p0 = w.R1 + o; a.g[0].p1 = w.Z1 + o; a.g[0].p2 = w.N1 + o; a.g[0].p3 = w.NH1 + o; a.g[0].p4 = w.H1 + o - sH;
-      a.g[0].o0 = w.dH1c; a.g[0].o1 = w.DI1 + t * s3; a.g[0].o2 = w.DH1 + t * s3; a.g[0].o3 = w.DI1xf; a.g[0].o4 = w.DH1xf;
+      a.g[0].o0 = w.dH1c; a.g[0].o1 = w.DI1 + t * s3; a.g[0].o2 = w.DH1 + o; a.g[0].o3 = w.DI1xf; a.g[0].o4 = w.DH1xf;
       ZTRY(launch_stage(a, s));
     }
     // B2: dH0 = W_ih1^T di1 + carry -> layer-0 gate gradients ; dH1 carry += W_hh1^T dh1
     a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pb_ih1, w.DI1xf, w.KB3H, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
     a.g[0].p0 = w.R0 + o; a.g[0].p1 = w.Z0 + o; a.g[0].p2 = w.N0 + o; a.g[0].p3 = w.NH0 + o; a.g[0].p4 = w.H0 + o - sH;
-    a.g[0].o0 = w.dH0c; a.g[0].o1 = w.DI0 + t * s3; a.g[0].o2 = w.DH0 + t * s3; a.g[0].o3 = w.DI0xf; a.g[0].o4 = w.DH0xf;
-    a.g[1].seg[0] = seg(w.pb_hh1, w.DH1xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
+    a.g[0].o0 = w.dH0c; a.g[0].o1 = w.DI0 + t * s3; a.g[0].o2 = w.DH0 + o; a.g[0].o3 = w.DI0xf; a.g[0].o4 = w.DH0xf;
+    // W_hh^T dh: the r, z rows of dh are those of di (first 2H k-values of the DI fragments), the n rows come compact
+    a.g[1].seg[0] = subseg(w.pb_hh1, w.DI1xf, 0, 2 * w.KBH, w.KB3H, 0);
+    a.g[1].seg[1] = subseg(w.pb_hh1, w.DH1xf, 2 * w.KBH, w.KBH, w.KB3H, 0);
+    a.g[1].nseg = 2; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
     a.g[1].o0 = w.dH1c;
     ZTRY(launch_stage(a, s));
     // B3: dGin = W_ih0^T di0 -> [D0 | dx part (+ the r operand of the merged stage)] ; dH0 carry += W_hh0^T dh0
     a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pb_ih0, w.DI0xf, w.KB3H, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTGI; a.g[0].epi = EPI_DGIN;
     a.g[0].p0 = w.Gin + t * sG; a.g[0].o0 = w.D0 + o; a.g[0].o1 = w.D0xf; a.g[0].o2 = w.dXa;
-    a.g[1].seg[0] = seg(w.pb_hh0, w.DH0xf, w.KB3H, 0); a.g[1].nseg = 1; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
+    a.g[1].seg[0] = subseg(w.pb_hh0, w.DI0xf, 0, 2 * w.KBH, w.KB3H, 0);
+    a.g[1].seg[1] = subseg(w.pb_hh0, w.DH0xf, 2 * w.KBH, w.KBH, w.KB3H, 0);
+    a.g[1].nseg = 2; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
     a.g[1].o0 = w.dH0c;
     a.rxf = (merged && t > 1) ? w.Rxf : nullptr;
     ZTRY(launch_stage(a, s));
@@ -994,7 +1000,7 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
       a.g[1].seg[2] = seg(w.pb_l0, w.D0xf, w.KBH, 1, nullptr, 0, 1);
       a.g[1].nseg = 3; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_GRU_BWD_M;
       a.g[1].p0 = w.R1 + o1; a.g[1].p1 = w.Z1 + o1; a.g[1].p2 = w.N1 + o1; a.g[1].p3 = w.NH1 + o1; a.g[1].p4 = w.H1 + o1 - sH;
-      a.g[1].o0 = w.dH1c; a.g[1].o1 = w.DI1 + (t - 1) * s3; a.g[1].o2 = w.DH1 + (t - 1) * s3; a.g[1].o3 = w.DI1xf;
+      a.g[1].o0 = w.dH1c; a.g[1].o1 = w.DI1 + (t - 1) * s3; a.g[1].o2 = w.DH1 + o1; a.g[1].o3 = w.DI1xf;
       a.g[1].o4 = w.DH1xf;
       a.aux0 = w.dXa; a.aux1 = P->l2_w;
     }
