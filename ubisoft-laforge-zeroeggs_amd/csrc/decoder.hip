@@ -81,8 +81,7 @@ __global__ void dec_fill_cond_k(ZeggsDecDims d, const float* speech, const float
 }
 
 // GRU cell gate math (nn.GRU, gate order r,z,n)
-__global__ void gru_gate_fwd_k(const float* gi, const float* gh, const float* hprev, float* hout, float* R,
-                               float* Z, float* N, float* NH, int B, int H) {
+__global__ void gru_gate_fwd_k(const float* gi, const float* gh, const float* hprev, float* hout, f4* GT, int B, int H) {
   long n = (long)B * H;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     int u = (int)(i % H);
@@ -95,19 +94,20 @@ __global__ void gru_gate_fwd_k(const float* gi, const float* gh, const float* hp
     float nn = tanhf(gib[2 * H + u] + r * nh);
     float hp = hprev[i];
     hout[i] = (1.f - z) * nn + z * hp;
-    if (R) { R[i] = r; Z[i] = z; N[i] = nn; NH[i] = nh; }
+    if (GT) GT[i] = f4{r, z, nn, nh};
   }
 }
 
 // dh (total grad wrt h') -> di [B,3H] (grad wrt W_ih x + b_ih), dhh [B,3H] (grad wrt W_hh h + b_hh),
 // dhc = dh * z (direct path to h_prev)
-__global__ void gru_gate_bwd_k(const float* dh, const float* R, const float* Z, const float* N, const float* NH,
-                               const float* hprev, float* di, float* dhh, float* dhc, int B, int H) {
+__global__ void gru_gate_bwd_k(const float* dh, const f4* GT, const float* hprev, float* di, float* dhh, float* dhc, int B,
+                               int H) {
   long n = (long)B * H;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     int u = (int)(i % H);
     long b = i / H;
-    float g = dh[i], r = R[i], z = Z[i], nn = N[i], nh = NH[i], hp = hprev[i];
+    const f4 gt = GT[i];
+    float g = dh[i], r = gt.x, z = gt.y, nn = gt.z, nh = gt.w, hp = hprev[i];
     float dn = g * (1.f - z);
     float dz = g * (hp - nn);
     float dan = dn * (1.f - nn * nn);
@@ -493,15 +493,13 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
     ZTRY(gemm_nt(gin, GL, P->w_ih0, H + XD, w.gi, 3 * H, P->b_ih0, B, 3 * H, H + XD, ACT_NONE, 0.f, s));
     ZTRY(gemm_nt(h0p, H, P->w_hh0, H, w.gh, 3 * H, P->b_hh0, B, 3 * H, H, ACT_NONE, 0.f, s));
     const long o = (long)t * sH;
-    hipLaunchKernelGGL(gru_gate_fwd_k, g1(sH), dim3(256), 0, s, w.gi, w.gh, h0p, h0, training ? w.R0 + o : nullptr,
-                       training ? w.Z0 + o : nullptr, training ? w.N0 + o : nullptr, training ? w.NH0 + o : nullptr,
-                       B, H);
+    hipLaunchKernelGGL(gru_gate_fwd_k, g1(sH), dim3(256), 0, s, w.gi, w.gh, h0p, h0,
+                       training ? (f4*)w.GT0 + o : (f4*)nullptr, B, H);
     // GRU layer 1
     ZTRY(gemm_nt(h0, H, P->w_ih1, H, w.gi, 3 * H, P->b_ih1, B, 3 * H, H, ACT_NONE, 0.f, s));
     ZTRY(gemm_nt(h1p, H, P->w_hh1, H, w.gh, 3 * H, P->b_hh1, B, 3 * H, H, ACT_NONE, 0.f, s));
-    hipLaunchKernelGGL(gru_gate_fwd_k, g1(sH), dim3(256), 0, s, w.gi, w.gh, h1p, h1, training ? w.R1 + o : nullptr,
-                       training ? w.Z1 + o : nullptr, training ? w.N1 + o : nullptr, training ? w.NH1 + o : nullptr,
-                       B, H);
+    hipLaunchKernelGGL(gru_gate_fwd_k, g1(sH), dim3(256), 0, s, w.gi, w.gh, h1p, h1,
+                       training ? (f4*)w.GT1 + o : (f4*)nullptr, B, H);
     // output projection + pose integration
     if (d.film) {
       float *a2 = w.A2 + slot(t) * sH, *f2 = w.F2 + slot(t) * sH;
@@ -575,13 +573,13 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
     } else {
       ZTRY(gemm_nn(dy, POL, P->l2_w, H, w.dH1c, H, B, d.PO, H, 1.f, s));
     }
-    hipLaunchKernelGGL(gru_gate_bwd_k, g1(sH), dim3(256), 0, s, w.dH1c, w.R1 + o, w.Z1 + o, w.N1 + o, w.NH1 + o,
+    hipLaunchKernelGGL(gru_gate_bwd_k, g1(sH), dim3(256), 0, s, w.dH1c, (const f4*)w.GT1 + o,
                        w.H1 + o - sH, w.DI1 + t * s3, w.DH1 + t * s3, w.t0, B, H);
     // t0 = dH1 * z (direct path); dH1c <- t0 + DH1 W_hh1 ; dH0 total = dH0c + DI1 W_ih1
     ZTRY(k_copy(w.dH1c, w.t0, sH, s));
     ZTRY(gemm_nn(w.DH1 + t * s3, 3 * H, P->w_hh1, H, w.dH1c, H, B, 3 * H, H, 1.f, s));
     ZTRY(gemm_nn(w.DI1 + t * s3, 3 * H, P->w_ih1, H, w.dH0c, H, B, 3 * H, H, 1.f, s));
-    hipLaunchKernelGGL(gru_gate_bwd_k, g1(sH), dim3(256), 0, s, w.dH0c, w.R0 + o, w.Z0 + o, w.N0 + o, w.NH0 + o,
+    hipLaunchKernelGGL(gru_gate_bwd_k, g1(sH), dim3(256), 0, s, w.dH0c, (const f4*)w.GT0 + o,
                        w.H0 + o - sH, w.DI0 + t * s3, w.DH0 + t * s3, w.t0, B, H);
     ZTRY(k_copy(w.dH0c, w.t0, sH, s));
     ZTRY(gemm_nn(w.DH0 + t * s3, 3 * H, P->w_hh0, H, w.dH0c, H, B, 3 * H, H, 1.f, s));

@@ -289,7 +289,8 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       eact = tid < 16 * BP && eb < B && U < H;
       if (eact) {
         const long i = (long)eb * H + U;
-        pre[0] = G.o0[i]; pre[1] = G.p0[i]; pre[2] = G.p1[i]; pre[3] = G.p2[i]; pre[4] = G.p3[i]; pre[5] = G.p4[i];
+        const f4 gt = ((const f4*)G.p0)[i];            // saved gates (r, z, n, nh)
+        pre[0] = G.o0[i]; pre[1] = gt.x; pre[2] = gt.y; pre[3] = gt.z; pre[4] = gt.w; pre[5] = G.p4[i];
       }
     } break;
     case EPI_GRU_BWD_M: if constexpr (FAM == 1) {
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       eact = tid < 16 * BP && eb < B && U < H;
       if (eact) {
         const long i = (long)eb * H + U;
-        pre[0] = G.o0[i]; pre[1] = G.p0[i]; pre[2] = G.p1[i]; pre[3] = G.p2[i]; pre[4] = G.p3[i]; pre[5] = G.p4[i];
+        const f4 gt = ((const f4*)G.p0)[i];            // saved gates (r, z, n, nh)
+        pre[0] = G.o0[i]; pre[1] = gt.x; pre[2] = gt.y; pre[3] = gt.z; pre[4] = gt.w; pre[5] = G.p4[i];
 #pragma unroll
         for (int c = 0; c < 6; ++c) rt[c] = a.aux1[(long)c * H + U];     // layer2 rows of the 6 root columns
       }
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         const float h = (1.f - z) * nn + z * pre[6];
         G.o0[i] = h;
         if (G.o1) G.o1[xf_index(b, U, LNB)] = h;
-        if (G.o2) { G.o2[i] = r; G.o3[i] = z; G.o4[i] = nn; G.o5[i] = nh; }
+        if (G.o2) ((f4*)G.o2)[i] = f4{r, z, nn, nh};   // saved gates, one 16-byte store
       }
       if (a.cf_gin || a.cf_x || a.cf_cond) {   // speech / style columns of x_{t+1} (inputs: independent of this step)
         const int XC = d.SP + d.ST;
@@ -895,7 +897,7 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     a.g[0].nseg = 3; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
     a.g[0].p0 = P->b_ih0; a.g[0].p1 = P->b_hh0; a.g[0].p2 = h0p;
     a.g[0].o0 = h0c; a.g[0].o1 = gemv ? nullptr : H0xf[c];
-    if (training) { a.g[0].o2 = w.R0 + o; a.g[0].o3 = w.Z0 + o; a.g[0].o4 = w.N0 + o; a.g[0].o5 = w.NH0 + o; }
+    if (training) a.g[0].o2 = w.GT0 + 4 * o;
     ZTRY(launch_stage(a, s));
     // S3: GRU layer 1 (+ stages the speech/style columns of x_{t+1}: ring slots last read one step ago)
     a.g[0] = Grp{};
@@ -904,7 +906,7 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     a.g[0].nseg = 2; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
     a.g[0].p0 = P->b_ih1; a.g[0].p1 = P->b_hh1; a.g[0].p2 = h1p;
     a.g[0].o0 = h1c; a.g[0].o1 = gemv ? nullptr : H1xf[c];
-    if (training) { a.g[0].o2 = w.R1 + o; a.g[0].o3 = w.Z1 + o; a.g[0].o4 = w.N1 + o; a.g[0].o5 = w.NH1 + o; }
+    if (training) a.g[0].o2 = w.GT1 + 4 * o;
     if (next) {
       a.cf_gin = training ? nullptr : gin_n;            // training: filled for every t by dec_fill_cond_k
       a.cf_x = gemv ? nullptr : Xxf[(t + 1) & 1];
@@ -961,14 +963,14 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
       // B1: dH1 = W2^T dy + carry -> layer-1 gate gradients
       a.g[0] = Grp{}; a.g[1] = Grp{};
       a.g[0].seg[0] = seg(w.pb_l2, w.DYxf, w.KBPO, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
-      a.g[0].p0 = w.R1 + o; a.g[0].p1 = w.Z1 + o; a.g[0].p2 = w.N1 + o; a.g[0].p3 = w.NH1 + o; a.g[0].p4 = w.H1 + o - sH;
+      a.g[0].p0 = w.GT1 + 4 * o; a.g[0].p4 = w.H1 + o - sH;
       a.g[0].o0 = w.dH1c; a.g[0].o1 = w.DI1 + t * s3; a.g[0].o2 = w.DH1 + o; a.g[0].o3 = w.DI1xf; a.g[0].o4 = w.DH1xf;
       ZTRY(launch_stage(a, s));
     }
     // B2: dH0 = W_ih1^T di1 + carry -> layer-0 gate gradients ; dH1 carry += W_hh1^T dh1
     a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pb_ih1, w.DI1xf, w.KB3H, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
-    a.g[0].p0 = w.R0 + o; a.g[0].p1 = w.Z0 + o; a.g[0].p2 = w.N0 + o; a.g[0].p3 = w.NH0 + o; a.g[0].p4 = w.H0 + o - sH;
+    a.g[0].p0 = w.GT0 + 4 * o; a.g[0].p4 = w.H0 + o - sH;
     a.g[0].o0 = w.dH0c; a.g[0].o1 = w.DI0 + t * s3; a.g[0].o2 = w.DH0 + o; a.g[0].o3 = w.DI0xf; a.g[0].o4 = w.DH0xf;
     // W_hh^T dh: the r, z rows of dh are those of di (first 2H k-values of the DI fragments), the n rows come compact
     a.g[1].seg[0] = subseg(w.pb_hh1, w.DI1xf, 0, 2 * w.KBH, w.KB3H, 0);
@@ -999,7 +1001,7 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
       a.g[1].seg[1] = seg(w.pb_l2, w.Rxf, w.KBPO, 0);
       a.g[1].seg[2] = seg(w.pb_l0, w.D0xf, w.KBH, 1, nullptr, 0, 1);
       a.g[1].nseg = 3; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_GRU_BWD_M;
-      a.g[1].p0 = w.R1 + o1; a.g[1].p1 = w.Z1 + o1; a.g[1].p2 = w.N1 + o1; a.g[1].p3 = w.NH1 + o1; a.g[1].p4 = w.H1 + o1 - sH;
+      a.g[1].p0 = w.GT1 + 4 * o1; a.g[1].p4 = w.H1 + o1 - sH;
       a.g[1].o0 = w.dH1c; a.g[1].o1 = w.DI1 + (t - 1) * s3; a.g[1].o2 = w.DH1 + o1; a.g[1].o3 = w.DI1xf;
       a.g[1].o4 = w.DH1xf;
       a.aux0 = w.dXa; a.aux1 = P->l2_w;

@@ -7,7 +7,7 @@
 
 struct DecWs {
   // canonical (row-major) activations, time-major [T][B][.] in training, 2-slot ring in inference
-  float *Gin, *H0, *H1, *R0, *Z0, *N0, *NH0, *R1, *Z1, *N1, *NH1, *Y;
+  float *Gin, *H0, *H1, *GT0, *GT1, *Y;   // GT*: saved gates of both GRU layers, [T][B][H] x float4 (r, z, n, W_hn h + b_hn)
   float *cse_in, *cse_a, *cse_b;          // cell-state encoder activations
   float *gi, *gh;                          // per-step gate pre-activations [B,3H]   (generic path)
   // backward
@@ -46,8 +46,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
   w.cse_a = a.f(B * H); w.cse_b = a.f(B * H);
   w.gi = a.f(B * 3 * H); w.gh = a.f(B * 3 * H);
   if (training) {
-    w.R0 = a.f(T * B * H); w.Z0 = a.f(T * B * H); w.N0 = a.f(T * B * H); w.NH0 = a.f(T * B * H);
-    w.R1 = a.f(T * B * H); w.Z1 = a.f(T * B * H); w.N1 = a.f(T * B * H); w.NH1 = a.f(T * B * H);
+    w.GT0 = a.f(T * B * H * 4); w.GT1 = a.f(T * B * H * 4);
     w.DY = a.f(T * B * (long)w.POL);
     w.DI0 = a.f(T * B * 3 * H); w.DH0 = a.f(T * B * 3 * H);
     w.DI1 = a.f(T * B * 3 * H); w.DH1 = a.f(T * B * 3 * H);
