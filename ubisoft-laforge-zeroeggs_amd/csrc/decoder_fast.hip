@@ -608,7 +608,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       if (eact) {
         const int b = eb, j = perm_dx(tile * 16 + ev, PO);
         const float dx = FV(0, ev, b) + pre[0];
-        G.o0[(long)b * a.XD + j] = dx;
+        if (j >= d.PI) G.o0[(long)b * a.XD + j] = dx;   // only the speech / style columns of dx_t are consumed later
         if (dy && j >= 6 && j < PO) {
           const float gy = (pre[1] + dx / pre[2]) * pre[3];
           dy[(long)b * a.POL + j] = gy;
