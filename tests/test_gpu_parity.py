@@ -794,3 +794,32 @@ def test_decoder_rollout_is_graph_capturable():
         for a, b in zip(out, ref2):
             assert float((a - b).abs().max()) < 1e-6
         assert float((ref2[0] - ref1[0]).abs().max()) > 1e-3       # the replay really consumed the new speech
+
+
+# ----------------------------------------------------------------------------- loud failures
+def test_c_abi_rejects_bad_arguments_loudly():
+    """error behaviour of the boundary: -1 + zeggs_last_error(), never a silent fallback"""
+    import ctypes as C
+    L = ops.lib()
+    dev_buf = torch.zeros(1 << 16, device=DEV)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # decoder: pose_input_size must be pose_output_size + 3, batch / sequence must be non-empty, workspace must fit
+    P, S = ops.DecPtrs(), ops.DecStats()
+    for dims, msg in ((ops.DecDims(2, 4, 100, 90, 8, 8, 64, 0.016, 0), "pose_input_size"),
+                      (ops.DecDims(0, 4, 93, 90, 8, 8, 64, 0.016, 0), "empty"),
+                      (ops.DecDims(2, 4, 93, 90, 8, 8, 64, 0.016, 0), "workspace too small")):
+        rc = L.zeggs_decoder_fwd(C.byref(dims), C.byref(P), C.byref(S), p(dev_buf), p(dev_buf), p(dev_buf), p(dev_buf),
+                                 p(dev_buf), p(dev_buf), p(dev_buf), p(dev_buf), p(dev_buf), 0, p(dev_buf), C.c_size_t(16),
+                                 stream)
+        assert rc == -1 and msg in L.zeggs_last_error().decode(), (msg, L.zeggs_last_error())
+    # unknown option, bad mel dims, streaming range ahead of the received samples
+    assert L.zeggs_set_option(b"no_such_option", 1) == -1 and b"unknown option" in L.zeggs_last_error()
+    from zeggs import audio
+    d = audio.MelDims(800, 200, 80, 16000, 60.0, 1e-5)
+    rc = L.zeggs_mel_features_range(C.byref(d), p(dev_buf), C.c_long(3000), 0, p(dev_buf), C.c_long(0), C.c_long(50),
+                                    p(dev_buf), p(dev_buf), C.c_size_t(1 << 18), stream)
+    assert rc == -1 and b"not received yet" in L.zeggs_last_error()
+    # product path without a GPU tensor
+    with pytest.raises(RuntimeError, match="not on a GPU"):
+        ops.normalize_rows_(torch.zeros(4, 4), torch.zeros(4), torch.ones(4))
