@@ -102,15 +102,12 @@ def bvh_save(filename, data):
 
     emit(0, 0)
     out += ["MOTION", "Frames: %i" % len(rots), "Frame Time: %f" % data.get("frametime", 1.0 / 60.0)]
-    for f in range(len(rots)):
-        vals = []
-        for j in seq:
-            if j == 0:
-                vals += list(poss[f, 0])
-            vals += list(rots[f, j])
-        out.append(" ".join("%f" % v for v in vals) + " ")
+    # motion block: one row per frame = root position + the rotations in hierarchy order (formatted in C by savetxt)
+    table = np.concatenate([np.asarray(poss[:, 0], np.float64).reshape(len(rots), 3)] +
+                           [np.asarray(rots[:, j], np.float64).reshape(len(rots), 3) for j in seq], axis=1)
     with open(filename, "w") as fh:
         fh.write("\n".join(out) + "\n")
+        np.savetxt(fh, table, fmt="%f", delimiter=" ", newline=" \n")
 
 
 # ----------------------------------------------------------------------------- device kernels (csrc/anim.hip)
