@@ -54,7 +54,8 @@ def bvh_load(filename):
             break
     nframes = int(re.match(r"\s*Frames:\s+(\d+)", next(lines)).group(1))
     frametime = float(re.match(r"\s*Frame Time:\s+([\d\.eE\-]+)", next(lines)).group(1))
-    data = np.array([[float(v) for v in ln.split()] for ln in lines if ln.strip()], dtype=np.float64)[:nframes]
+    rows = [ln for ln in lines if ln.strip()][:nframes]
+    data = np.loadtxt(rows, dtype=np.float64, ndmin=2) if rows else np.zeros((0, 0))     # C parser
     J = len(names)
     offsets = np.asarray(offsets, dtype=np.float32)
     positions = np.repeat(offsets[None], len(data), axis=0)
