@@ -34,7 +34,8 @@ def bench(name, M, N, K, layout):
     print(f"{name:28s} {layout} M={M} N={N} K={K}: {dt * 1e6:8.1f} us  {2.0 * M * N * K / dt / 1e12:6.1f} TFLOP/s", flush=True)
 
 
-for tgt in (1024, 2048, 3072, 4096, 6144):
+import os
+for tgt in [int(v) for v in os.environ.get("ZEGGS_GEMM_BENCH_TARGETS", "1536,2048,3072").split(",")]:
     ops.set_option("gemm_wg_target", tgt)
     print("wg target", tgt)
     bench("dW_hh (decoder)", 3072, 1024, 8160, "TN")
