@@ -14,6 +14,33 @@ static __device__ __forceinline__ Q4 quat_exp(V3 x) {
   return Q4{cosf(h), x.x * s, x.y * s, x.z * s};
 }
 
+// quat_exp and its backward for the SAME argument share the norm and its sine / cosine (the root-integration backward
+// evaluates both on one thread: half the transcendental work of calling quat_exp + qexp_bwd)
+struct QExpCtx { float h, sh, ch; };
+static __device__ __forceinline__ Q4 quat_exp_ctx(V3 x, QExpCtx& c) {
+  c.h = sqrtf(x.x * x.x + x.y * x.y + x.z * x.z);
+  if (c.h < 1e-5f) {
+    c.sh = 0.f; c.ch = 1.f;
+    float n = sqrtf(1.f + c.h * c.h) + 1e-5f;
+    return Q4{1.f / n, x.x / n, x.y / n, x.z / n};
+  }
+  c.sh = sinf(c.h); c.ch = cosf(c.h);
+  const float s = c.sh / c.h;
+  return Q4{c.ch, x.x * s, x.y * s, x.z * s};
+}
+static __device__ __forceinline__ V3 qexp_bwd_ctx(V3 x, Q4 g, const QExpCtx& c) {
+  V3 gv = v3(g.x, g.y, g.z);
+  if (c.h < 1e-5f) {
+    float n = sqrtf(1.f + c.h * c.h), ne = n + 1e-5f;
+    float ug = g.w + dot(gv, x);
+    float k = ug / (n * ne * ne);
+    return (1.f / ne) * gv - k * x;
+  }
+  const float s = c.sh / c.h, ds = (c.h * c.ch - c.sh) / (c.h * c.h);
+  const float cc = -g.w * s + dot(gv, x) * ds / c.h;
+  return s * gv + cc * x;
+}
+
 // backward of out = quat_mul_vec(q, v) given upstream g
 static __device__ __forceinline__ void qmv_bwd(Q4 q, V3 v, V3 g, Q4& dq, V3& dv) {
   V3 qv = v3(q.x, q.y, q.z);

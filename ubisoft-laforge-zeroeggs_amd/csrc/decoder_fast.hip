@@ -173,10 +173,11 @@ __device__ void root_bwd(const ZeggsDecDims& d, const ZeggsDecStats& st, int b, 
   Q4 dq1; V3 dv1;
   qmv_bwd(q_p, d.dt * vel, g_rp, dq1, dv1);
   V3 u = quat_mul_vec(q_p, d.dt * vrt);
-  Q4 E = quat_exp(0.5f * u);
+  QExpCtx ec;
+  Q4 E = quat_exp_ctx(0.5f * u, ec);
   Q4 dE, dqy;
   qmul_bwd(E, q_p, g_rr, dE, dqy);
-  V3 du = 0.5f * qexp_bwd(0.5f * u, dE);
+  V3 du = 0.5f * qexp_bwd_ctx(0.5f * u, dE, ec);
   Q4 dq2; V3 dv2;
   qmv_bwd(q_p, d.dt * vrt, du, dq2, dv2);
   g6[0] += d.dt * dv1.x; g6[1] += d.dt * dv1.y; g6[2] += d.dt * dv1.z;
