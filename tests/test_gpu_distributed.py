@@ -1,0 +1,71 @@
+"""Data-parallel path of the REAL engine on the GPU: two ranks (both on cuda:0 of the test box, gloo collectives over
+CUDA tensors) each run TrainEngine.step on their shard of a global batch; the updated weights must equal those of a
+single process stepping on the whole global batch (gradients pre-scaled by 1/world in the loss kernel, ONE all-reduce
+of the flat buffer, identical fused RAdam step).  bench.py / train() use the same code with the nccl (= RCCL) backend."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _step(world, rank, per_rank):
+    """one optimizer step of the engine on this rank's shard; returns the flat parameter vector after the step"""
+    import helpers
+    from zeggs import engine, synth
+    dev = torch.device("cuda:0")
+    se, de, st = helpers.build_nets()
+    se, de, st = se.to(dev).eval(), de.to(dev).eval(), st.to(dev).eval()        # eval: no dropout masks to agree on
+    T, L = 6, 8
+    data = synth.make_processed(2, 0, T + 10, seed=8)
+    ds = engine.DeviceDataset(data, T, dev)
+    eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, world_size=world, rank=rank)
+    perm = np.random.default_rng(5).permutation(len(ds))
+    gb = per_rank * world
+    eps_all = torch.randn(gb, 64, generator=torch.Generator().manual_seed(3)).to(dev)
+    idx = engine.shard_indices(perm, 0, per_rank, world, rank)
+    loss = eng.step(idx, L, eps=eps_all[rank * per_rank:(rank + 1) * per_rank].contiguous())
+    torch.cuda.synchronize()
+    return eng.flat_p.detach().cpu().clone(), float(loss)
+
+
+def _worker(rank, world, port, out):
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "ubisoft-laforge-zeroeggs_amd"), str(root / "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p, loss = _step(world, rank, per_rank=2)
+    out[rank] = (p.numpy(), loss)
+    dist.destroy_process_group()
+
+
+def test_two_rank_engine_step_equals_single_process_global_batch():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    p0, p1 = torch.as_tensor(out[0][0]), torch.as_tensor(out[1][0])
+    assert torch.equal(p0, p1)                                    # every rank ends with identical weights
+    ref, ref_loss = _step(1, 0, per_rank=4)                       # the whole global batch in one process
+    assert abs(0.5 * (out[0][1] + out[1][1]) - ref_loss) < 1e-4 * abs(ref_loss)
+    # the step moves every weight by ~lr; compare the UPDATE, not the weights
+    import helpers
+    init = torch.cat([p.detach().flatten() for m in helpers.build_nets() for p in m.parameters()])
+    d_par, d_ref = p0 - init, ref - init
+    assert float(d_ref.abs().max()) > 0
+    assert float((d_par - d_ref).abs().max()) <= 2e-3 * float(d_ref.abs().max())
