@@ -823,3 +823,33 @@ def test_c_abi_rejects_bad_arguments_loudly():
     # product path without a GPU tensor
     with pytest.raises(RuntimeError, match="not on a GPU"):
         ops.normalize_rows_(torch.zeros(4, 4), torch.zeros(4), torch.ones(4))
+
+
+def test_streaming_with_film_decoder_matches_offline():
+    """the chunked decode entry point resumes the generic per-step path (rnn_cond="film") as well"""
+    from zeggs import anim, audio, modules, stream
+    se, _, _ = helpers.build_nets()
+    torch.manual_seed(4321)
+    de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, 64, 64, 1024, 2, rnn_cond="film")
+    se, de = se.to(DEV).eval(), de.to(DEV).eval()
+    stats = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32, device=DEV) for k, v in synth.make_stats().items()}
+    conf = dict(pre_emphasis=False, pre_emph_coeff=0.97, centered=True, real_amplitude=True, normalize_mel_bins=True,
+                normalize_range=True, min_clipping=1e-5, sampling_rate=16000, mel_fmin=20, mel_fmax=7600,
+                n_mel_channels=80, filter_length=800, hop_length=200, resample_method="linear", normalize_loudness=False)
+    wav = synth.synth_wav(20000, seed=2).astype(np.float32) / 32768.0
+    first = anim.preprocess_animation(synth.make_bvh_clip(8, seed=3), DEV)
+    style = torch.randn(1, 64, device=DEV) * 0.5
+    n_frames = audio.n_anim_frames(len(wav))
+    feats = torch.as_tensor(audio.preprocess_audio(wav, 60, n_frames, conf, ["mel_spec", "energy"]), device=DEV)
+    with torch.no_grad():
+        sp = se(((feats[None] - stats["audio_input_mean"]) / stats["audio_input_std"]).contiguous())
+        f32 = lambda a: a[0:1].to(torch.float32).contiguous()  # noqa: E731
+        rp, rr, rv, rw, lp, _, lt, lv, lw = first[:9]
+        pose0 = torch.cat([f32(x).reshape(1, -1) for x in (rv, rw, lp, lt, lv, lw)], dim=1)
+        ref = ops.decoder_core(de, pose0, f32(rp), f32(rr), f32(first[14]).repeat(n_frames, 1)[None].contiguous(), sp,
+                               style.repeat(n_frames, 1)[None].contiguous(), stats["anim_input_mean"],
+                               stats["anim_input_std"], stats["anim_output_mean"], stats["anim_output_std"], synth.DT)
+    gs = stream.GestureStream(se, de, first, style, stats, conf, synth.DT)
+    outs = [gs.push(wav[:7000]), gs.push(wav[7000:15000]), gs.push(wav[15000:]), gs.finish()]
+    pose = torch.cat([o["pose"] for o in outs if o], dim=0)
+    assert pose.shape[0] == n_frames and float((pose - ref[0][0]).abs().max()) < 5e-5
