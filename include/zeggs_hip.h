@@ -111,8 +111,8 @@ int zeggs_style_encoder_gru_bwd(const ZeggsStyleGruDims*, const ZeggsStyleGruPar
                                 const ZeggsStyleGruGrads*, void* ws, size_t ws_bytes, void* stream);
 /* VAE re-parameterisation, StyleEncoder.forward ZEGGS/modules.py:291-302:
  * enc [B,2S] -> z = mu + eps*exp(.5 logvar)/temperature ; bwd gives denc from dz, dmu, dlogvar */
-int zeggs_vae_reparam_fwd(const float* enc, const float* eps, float* z, int B, int S, float temperature,
-                          void* stream);
+int zeggs_vae_reparam_fwd(const float* enc, const float* eps, float* z, float* mu_out /* [B,S] or NULL */,
+                          float* logvar_out /* [B,S] or NULL */, int B, int S, float temperature, void* stream);
 int zeggs_vae_reparam_bwd(const float* enc, const float* eps, const float* dz, const float* dmu,
                           const float* dlogvar, float* denc, int B, int S, float temperature, void* stream);
 
@@ -226,6 +226,22 @@ int zeggs_mel_features_range(const ZeggsMelDims*, const float* wav, long n_sampl
 /* in-place feature normalisation (x - mean) / std of ZEGGS/train.py:232-234,239 ; stdv == NULL -> scalar std */
 int zeggs_normalize_rows(float* x, long rows, int width, long ld, const float* mean, const float* stdv,
                          float std_scalar, void* stream);
+
+/* ---------------------------------------------------------------- plumbing kernels of the training step
+ * Elementwise work that the reference leaves to ATen inside train() (ZEGGS/train.py:215-432): zeroing the gradient
+ * buffer (optimizer.zero_grad, :428), scaling by the upstream scalar of loss.backward() (:423), the VAE noise
+ * eps = randn_like(std) (ZEGGS/modules.py:772-775; counter-hash stream, not torch's Philox), and
+ * style_encoding.unsqueeze(1).repeat_interleave(T, 1) with its adjoint (ZEGGS/train.py:256). */
+int zeggs_fill(float* dst, long n, float value, void* stream);
+int zeggs_scale_copy(float* dst, const float* src, long n, const float* dev_scale /* device scalar or NULL */,
+                     float alpha, void* stream);
+int zeggs_randn(float* out, long n, uint64_t seed, void* stream);
+/* x[i] *= mask(seed, i) / (1 - p): the counter-hash dropout mask every encoder kernel applies (F.dropout /
+ * nn.Dropout of ZEGGS/modules.py:258-272, 361-388); element i depends on (seed, i) only, so forward and backward
+ * regenerate the same mask without storing it */
+int zeggs_dropout(float* x, long n, float p, uint64_t seed, void* stream);
+int zeggs_broadcast_time(float* out /* [B,T,S] */, const float* z /* [B,S] */, int B, int T, int S, void* stream);
+int zeggs_sum_time(float* dz /* [B,S] */, const float* dout /* [B,T,S] */, int B, int T, int S, void* stream);
 
 /* ---------------------------------------------------------------- animation pre-/post-processing (float64)
  * zeggs_anim_features replaces preprocess_animation, ZEGGS/data_pipeline.py:90-228 (with quat.py from_euler /

@@ -36,3 +36,55 @@ def stats_tensors(dtype=torch.float32, device="cpu"):
     t = lambda k: torch.as_tensor(np.asarray(s[k]), dtype=dtype, device=device)  # noqa: E731
     return dict(a_mean=t("audio_input_mean"), a_std=t("audio_input_std"), in_mean=t("anim_input_mean"),
                 in_std=t("anim_input_std"), out_mean=t("anim_output_mean"), out_std=t("anim_output_std"))
+
+
+# ----------------------------------------------------------------------------- full-shape fixtures (oracle/make_golden_full.py)
+GOLDEN = __import__("pathlib").Path(__file__).resolve().parent / "golden"
+STAT_KEYS = ("audio_input_mean", "audio_input_std", "anim_input_mean", "anim_input_std", "anim_output_mean",
+             "anim_output_std")
+
+
+def real_stats(v="v1"):
+    """The reference's own normalisation statistics (data/processed_v*/stats.npz), stored as a fixture."""
+    s = np.load(GOLDEN / f"real_stats_{v}.npz")
+    return {k: np.asarray(s[k]) for k in STAT_KEYS}
+
+
+def real_stats_tensors(v="v1", dtype=torch.float32, device="cpu"):
+    s = real_stats(v)
+    t = lambda k: torch.as_tensor(np.asarray(s[k]), dtype=dtype, device=device)  # noqa: E731
+    return dict(a_mean=t("audio_input_mean"), a_std=t("audio_input_std"), in_mean=t("anim_input_mean"),
+                in_std=t("anim_input_std"), out_mean=t("anim_output_mean"), out_std=t("anim_output_std"))
+
+
+def checksum(a):
+    a = np.asarray(a, np.float64).ravel()
+    return np.array([a.sum(), np.abs(a).sum()])
+
+
+def full_decoder_inputs(st, B, T, seed):
+    """The seeded decoder inputs of oracle/make_golden_full.py:decoder_inputs (same generator, same seeds)."""
+    clips = [synth.make_clip_stats(T, seed=seed + b, stats=st) for b in range(B)]
+    W = {k: torch.as_tensor(np.stack([c[k] for c in clips])) for k in clips[0]}
+    rng = np.random.default_rng(seed + 7)
+    speech = torch.as_tensor(rng.standard_normal((B, T, 64)).astype(np.float32) * 0.5)
+    style = torch.as_tensor(np.repeat(rng.standard_normal((B, 1, 64)).astype(np.float32) * 0.5, T, axis=1))
+    return W, speech, style
+
+
+def assert_inputs_match(gd, W, speech, style):
+    got = np.stack([checksum(W[k]) for k in sorted(W)] + [checksum(speech), checksum(style)])
+    np.testing.assert_allclose(got, gd["in_check"], rtol=1e-9, err_msg="synthetic input generator drifted")
+
+
+def pack_pose(vel, vrt, lpos, ltxy, lvel, lvrt):
+    B, T = vel.shape[:2]
+    return torch.cat([vel.reshape(B, T, -1), vrt.reshape(B, T, -1), lpos.reshape(B, T, -1), ltxy.reshape(B, T, -1),
+                      lvel.reshape(B, T, -1), lvrt.reshape(B, T, -1)], dim=-1)
+
+
+def full_dataset(gd, v):
+    """The synthetic processed_data (dict) that oracle/make_golden_full.py:record_train_iteration trained on."""
+    st = real_stats(v)
+    return synth.make_processed(int(gd["n_train"]), 1, int(gd["nframes"]), int(gd["data_seed"]), int(gd["nlabels"]), st,
+                                synth.make_clip_stats)

@@ -1,0 +1,279 @@
+"""GPU parity at the BENCHMARKED shapes: the HIP engine (through the C ABI) against vectors recorded from the
+unmodified reference with its REAL normalisation statistics (oracle/make_golden_full.py; anim_input_std in
+[0.28, 47.7], 364 exact zeros in anim_output_std) -- decoder forward B=32 x 256 (the NB=2 / batch-split stage
+kernels bench.py times), one complete train() iteration at B=32 x 256 with example length 384 (batch fetch,
+encoders, BPTT, fused RAdam), the v2 / label iteration at B=64, an 1800-frame B=1 free-running decode against
+the reference in fp64, the 10 s mel front-end and the style encoder at example length 512.
+Tolerances (north_star): forward outputs / ltxy 1e-4 absolute; gradients 5e-4 of the tensor's max |grad| (both
+sides fp32 over 255 BPTT steps); integers bit-exact; root position drift is reported per frame."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import nets as onets
+from zeggs import engine, ops, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NAMES = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
+
+
+def g(t):
+    return t.to(DEV)
+
+
+def relerr(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / max(1e-12, float(ref.abs().max())))
+
+
+def _hip_rollout(de, W, speech, style, s, grad=False):
+    fp = [g(W[k][:, 0].contiguous()) for k in ("Y_root_pos", "Y_root_rot", "Y_root_vel", "Y_root_vrt", "Y_lpos",
+                                               "Y_ltxy", "Y_lvel", "Y_lvrt")]
+    ctx = torch.enable_grad() if grad else torch.no_grad()
+    with ctx:
+        return de(*fp, g(W["Y_gaze_pos"]), g(speech), g(style), None, s["in_mean"], s["in_std"], s["out_mean"],
+                  s["out_std"], synth.DT)
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_decoder_b32_t256_real_stats_vs_reference(golden_dir, training):
+    """configs_v1.json:28-33 shape.  training=True runs the BPTT-workspace forward (what bench.py times),
+    training=False the no_grad ring path."""
+    gd = np.load(golden_dir / "full_dec32.npz")
+    _, de, _ = helpers.build_nets()
+    B, T = int(gd["B"]), int(gd["T"])
+    W, speech, style = helpers.full_decoder_inputs(helpers.real_stats("v1"), B, T, int(gd["seed"]))
+    helpers.assert_inputs_match(gd, W, speech, style)
+    s = helpers.real_stats_tensors("v1", device=DEV)
+    de = de.to(DEV)
+    de.train() if training else de.eval()
+    if training:
+        speech = speech.clone().requires_grad_(True)
+    O = [o.detach().cpu() for o in _hip_rollout(de, W, speech, style, s, grad=training)]
+    pose = helpers.pack_pose(*O[2:]).numpy()
+    err = np.abs(pose[:, gd["frames"]] - gd["pose_frames"])
+    assert err.max() < 1e-4, f"pose channels: {err.max():.3e} at channel {int(err.max(axis=(0, 1)).argmax())}"
+    e_ltxy = np.abs(O[5].numpy().reshape(B, T, -1)[::8, ::4] - gd["ltxy_rows"]).max()
+    e_rot = np.abs(O[1].numpy() - gd["root_rot"]).max()
+    e_pos = np.abs(O[0].numpy() - gd["root_pos"]).max(axis=(0, 2))            # per frame
+    print(f"\nB=32 T=256 real stats: pose {err.max():.2e} ltxy {e_ltxy:.2e} root_rot {e_rot:.2e} "
+          f"root_pos {e_pos.max():.2e} ({(e_pos / np.maximum(np.arange(T), 1)).max():.2e} per frame)")
+    assert e_ltxy < 1e-4 and e_rot < 1e-4
+    assert e_pos.max() < 1e-3 and (e_pos / np.maximum(np.arange(T), 1)).max() < 2e-5
+
+
+def test_free_running_decode_1800_frames_vs_fp64_reference(golden_dir):
+    """SURVEY 8(c) noise-floor case: B=1, 1800 free-running frames (the GEMV decode kernels), HIP fp32 against the
+    reference run in fp64; the reference's own fp32 deviation from fp64 is stored next to it."""
+    gd = np.load(golden_dir / "full_rollout.npz")
+    _, de, _ = helpers.build_nets()
+    T = int(gd["T"])
+    W, speech, style = helpers.full_decoder_inputs(helpers.real_stats("v1"), 1, T, int(gd["seed"]))
+    helpers.assert_inputs_match(gd, W, speech, style)
+    s = helpers.real_stats_tensors("v1", device=DEV)
+    O = [o.detach().cpu().double() for o in _hip_rollout(de.to(DEV).eval(), W, speech, style, s)]
+    pose = helpers.pack_pose(*O[2:]).numpy()[0]
+    J = synth.NJ
+    sl = dict(root_vel=slice(0, 3), root_vrt=slice(3, 6), lpos=slice(6, 6 + 3 * J), ltxy=slice(6 + 3 * J, 6 + 9 * J),
+              lvel=slice(6 + 9 * J, 6 + 12 * J), lvrt=slice(6 + 12 * J, 6 + 15 * J))
+    e = {k: float(np.abs(pose[::10, v] - gd["pose_every10"][:, v]).max()) for k, v in sl.items()}
+    e_rot = float(np.abs(O[1].numpy()[0] - gd["root_rot"]).max())
+    e_pos = np.abs(O[0].numpy()[0] - gd["root_pos"]).max(axis=1)
+    floor = dict(zip(NAMES, gd["ref_fp32_floor"]))
+    print(f"\n1800-frame decode vs fp64 reference: {e} root_rot {e_rot:.2e} root_pos {e_pos.max():.2e} "
+          f"({e_pos.max() / T:.2e} per frame); reference fp32 floor: root_pos {floor['root_pos']:.2e} "
+          f"root_rot {floor['root_rot']:.2e} ltxy {floor['ltxy']:.2e}")
+    assert e["ltxy"] < 1e-4 and e["lpos"] < 1e-4 and e["lvel"] < 1e-4 and e["lvrt"] < 1e-4
+    assert e["root_vel"] < 1e-4 and e["root_vrt"] < 1e-4 and e_rot < 1e-4
+    # the root position integrates 1799 steps: bounded by a small multiple of the reference's own fp32 drift
+    assert e_pos.max() < max(1e-3, 4 * floor["root_pos"]) and e_pos.max() / T < 1e-6
+
+
+def _engine_iteration(gd, v):
+    """One TrainEngine.step on the recorded window indices -> (engine, loss)."""
+    data = helpers.full_dataset(gd, v)
+    B, T, Lx = int(gd["B"]), int(gd["window"]), int(gd["example_length"])
+    label = "eps" not in gd.files
+    nl = int(gd["nlabels"])
+    se, de, st = helpers.build_nets(style_size=nl if label else 64)
+    se, de, st = se.to(DEV).eval(), de.to(DEV).train(), st.to(DEV).eval()     # dropout was patched to identity
+    ds = engine.DeviceDataset(data, T, DEV)
+    eng = engine.TrainEngine(se, de, None if label else st, ds, synth.PARENTS, synth.DT, lr=1e-4, eps=1e-5,
+                             style_encoding_type="label" if label else "example")
+    idx = gd["idx"]
+    # E8: the engine's batch reproduces the reference DataLoader's batch (checksums of all 11 batch tensors)
+    b = ds.batch(idx, None if label else Lx)
+    chk = gd["batch_check"]
+    np.testing.assert_allclose(helpers.checksum(b["rpos"].cpu().numpy()), chk[1], rtol=1e-6)
+    np.testing.assert_allclose(helpers.checksum(b["gaze"].cpu().numpy()), chk[9], rtol=1e-6)
+    pose_ref = sum(chk[j] for j in (3, 4, 5, 6, 7, 8))                        # vel, vrt, lpos, ltxy, lvel, lvrt
+    np.testing.assert_allclose(helpers.checksum(b["pose"].cpu().numpy())[1], pose_ref[1], rtol=1e-6)
+    labels = None
+    if label:
+        lab = np.asarray(data["ranges_train_labels"])[ds.win_sample[idx].astype(np.int64)]
+        labels = g(torch.as_tensor(np.eye(nl, dtype=np.float32)[lab]))
+        np.testing.assert_allclose(helpers.checksum(labels.cpu().numpy()), chk[10], rtol=1e-9)
+    eps = None if label else g(torch.as_tensor(gd["eps"]))
+    w_before = [p.detach().clone() for p in eng.params]
+    loss = eng.step(idx, Lx, eps=eps, labels=labels)
+    return eng, loss, w_before
+
+
+def _check_engine_iteration(gd, v):
+    from oracle import radam as oradam
+    eng, loss, w_before = _engine_iteration(gd, v)
+    np.testing.assert_allclose(float(loss), gd["loss"][0], rtol=2e-5)
+    np.testing.assert_allclose(eng.last_terms[:18].cpu().numpy(), gd["terms"][0], rtol=2e-4, atol=1e-6)
+    off, worst = 0, 0.0
+    for i, p in enumerate(eng.params):
+        idx = helpers.sample_idx(p.numel())
+        it = torch.as_tensor(idx, device=DEV)
+        got = p.grad.flatten()[it].cpu().numpy()
+        ref = gd["grad_samples"][off:off + len(idx)]
+        scale = max(1e-7, float(np.abs(ref).max()))
+        e = float(np.abs(got - ref).max()) / scale
+        worst = max(worst, e)
+        assert e < 5e-4, f"param {i}: gradient off by {e:.2e} of max|g|"
+        fp = helpers.fingerprint(p.grad)
+        np.testing.assert_allclose(fp[1], gd["grad_fp"][i][1], rtol=2e-3, err_msg=f"param {i} |g| sum")
+        # fused RAdam over the flat buffer: weights after the step vs the reference's
+        np.testing.assert_allclose(p.detach().flatten()[it].cpu().numpy(), gd["weight_samples"][off:off + len(idx)],
+                                   atol=3e-7, err_msg=f"param {i} after RAdam")
+        pn, gn = w_before[i].flatten()[it].cpu().numpy().copy(), got.copy()
+        m, vv = np.zeros_like(pn), np.zeros_like(pn)
+        oradam.radam_step(pn, gn, m, vv, 1, 1e-4, 1e-5)
+        np.testing.assert_allclose(p.detach().flatten()[it].cpu().numpy(), pn, atol=2e-7)
+        off += len(idx)
+    assert off == len(gd["grad_samples"])
+    print(f"\nfull iteration vs reference: loss {float(loss):.6f} / {gd['loss'][0]:.6f}, worst gradient sample "
+          f"{worst:.2e} of max|g|")
+
+
+def test_train_iteration_b32_t256_ex384_vs_reference(golden_dir):
+    """ONE complete iteration of the reference train() at the headline shape (ZEGGS/train.py:232-432,
+    configs_v1.json:28-33) against TrainEngine.step: loss, 18 terms, gradients of all 44 tensors, weights after RAdam."""
+    _check_engine_iteration(np.load(golden_dir / "full_train32.npz"), "v1")
+
+
+def test_train_iteration_v2_label_b64_vs_reference(golden_dir):
+    """configs_v2 (label conditioning, no style encoder), B=64: the MFMA-bound NB=4 stage kernels."""
+    _check_engine_iteration(np.load(golden_dir / "full_trainv2.npz"), "v2")
+
+
+def test_style_encoder_len512_real_stats(golden_dir):
+    gd = np.load(golden_dir / "full_style512.npz")
+    _, _, st = helpers.build_nets()
+    s = helpers.real_stats_tensors("v1")
+    stats = helpers.real_stats("v1")
+    B, L = int(gd["B"]), int(gd["L"])
+    clips = [synth.make_clip_stats(L, seed=int(gd["seed"]) + b, stats=stats) for b in range(B)]
+    ex = torch.as_tensor(np.stack([np.concatenate(
+        [c["Y_root_vel"], c["Y_root_vrt"], c["Y_lpos"].reshape(L, -1), c["Y_ltxy"].reshape(L, -1),
+         c["Y_lvel"].reshape(L, -1), c["Y_lvrt"].reshape(L, -1), np.zeros((L, 3), np.float32)], axis=1) for c in clips]))
+    exn = (ex - s["in_mean"]) / s["in_std"]
+    st_g = st.to(DEV).eval()
+    z, mu, lv = st_g(g(exn), 1.0, eps=g(torch.as_tensor(gd["eps"])))
+    for got, key in ((z, "z"), (mu, "mu"), (lv, "logvar")):
+        assert float((got.cpu() - torch.as_tensor(gd[key])).abs().max()) < 1e-4, key          # vs the reference
+    # gradients at L=512 vs the fp64 oracle (attention / softmax / LayerNorm over the long axis)
+    Bg = 2
+    x = exn[:Bg]
+    eps = torch.as_tensor(gd["eps"][:Bg])
+    torch.manual_seed(12)
+    wz, wm, wl = torch.randn(Bg, 64), torch.randn(Bg, 64), torch.randn(Bg, 64)
+    w64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in st_g.state_dict().items()}
+    z64, mu64, lv64 = onets.style_encoder(w64, x.double(), eps.double(), 1.0)
+    (z64 * wz.double() + mu64 * wm.double() + lv64 * wl.double()).sum().backward()
+    st_g.zero_grad()
+    zg, mug, lvg = st_g(g(x), 1.0, eps=g(eps))
+    (zg * g(wz) + mug * g(wm) + lvg * g(wl)).sum().backward()
+    for k, p in st_g.named_parameters():
+        assert relerr(p.grad, w64[k].grad) < 3e-4, k
+
+
+def test_style_encoder_embedding_wider_than_hidden():
+    """2*style_size > nhidden (E > H): the backward scratch is sized for the wider of the two."""
+    from zeggs import modules
+    torch.manual_seed(3)
+    st = modules.StyleEncoder(40, 16, 32, type="attn", use_vae=True)       # H=16, E=64
+    B, L = 2, 9
+    x, eps = torch.randn(B, L, 40), torch.randn(B, 32)
+    w64 = {k: v.detach().double().requires_grad_(True) for k, v in st.state_dict().items()}
+    z64, mu64, lv64 = onets.style_encoder(w64, x.double(), eps.double(), 1.0)
+    (z64.sum() + (mu64 * mu64).sum() + lv64.sum()).backward()
+    st_g = st.to(DEV).eval()
+    zg, mug, lvg = st_g(g(x), 1.0, eps=g(eps))
+    assert relerr(zg, z64) < 2e-5
+    (zg.sum() + (mug * mug).sum() + lvg.sum()).backward()
+    for k, p in st_g.named_parameters():
+        assert relerr(p.grad, w64[k].grad) < 3e-4, k
+
+
+def test_mel_10s_vs_reference(golden_dir):
+    from zeggs import audio
+    gd = np.load(golden_dir / "full_mel10.npz")
+    wav = synth.synth_wav(int(gd["n_samples"]), seed=0).astype(np.float32) / 32768.0
+    assert audio.n_anim_frames(len(wav)) == int(gd["nframes"]) == 600          # integer, bit-exact
+    assert audio.stft_frame_count(len(wav)) == 800
+    feat = audio.mel_features(wav, int(gd["nframes"])).cpu().numpy()
+    assert feat.shape == gd["feat"].shape
+    np.testing.assert_allclose(feat, gd["feat"], atol=2e-6)
+
+
+# ----------------------------------------------------------------------------- hygiene
+def test_dropout_hash_keep_rate_and_scaling():
+    """The counter-hash masks drop a fraction p of the elements and scale the kept ones by 1/(1-p)."""
+    import ctypes as C
+    n = 1 << 20
+    for p in (0.1, 0.2, 0.5):
+        t = torch.ones(n, device=DEV)
+        L = ops.lib()
+        assert L.zeggs_dropout(C.c_void_p(t.data_ptr()), C.c_long(n), C.c_float(p), C.c_uint64(1234 + int(100 * p)),
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        kept = t != 0
+        rate = float(kept.float().mean())
+        assert abs(rate - (1 - p)) < 4 * np.sqrt(p * (1 - p) / n) + 1e-4, (p, rate)
+        np.testing.assert_allclose(t[kept].cpu().numpy(), 1.0 / (1.0 - p), rtol=1e-6)
+        assert abs(float(t.mean()) - 1.0) < 5e-3          # unbiased
+
+
+def test_randn_stream_moments_and_reproducibility():
+    a = ops.randn((1 << 20,), DEV, seed=77)
+    b = ops.randn((1 << 20,), DEV, seed=77)
+    c = ops.randn((1 << 20,), DEV, seed=78)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1.0) < 5e-3
+    assert abs(float((a ** 4).mean()) - 3.0) < 0.05 and torch.isfinite(a).all()
+
+
+def test_lr_decay_at_iteration_1000_and_resume_restores_moments(tmp_path):
+    """ExponentialLR(0.995) stepped when (iteration + 1) % 1000 == 0 (ZEGGS/train.py:162-164,431-432); resume
+    restores iteration, RAdam moments and the decayed learning rate (train.py:166-172)."""
+    from zeggs import train as train_mod
+    npz, jsn = synth.write_dataset(tmp_path / "data", n_train=1, n_valid=1, nframes=14, seed=3)
+    net_opt = {"decoder": {"nhidden": 1024, "num_rnn_layers": 2, "rnn_cond": "normal"},
+               "speech_encoder": {"nhidden": 64, "speech_encoding_size": 64},
+               "style_encoder": {"nhidden": 512, "style_encoding_size": 64, "example_length": 8, "type": "attn",
+                                 "use_vae": True}}
+    opt = dict(niterations=1.001, batchsize=2, window=4, change_pace=True, learning_rate=1e-4,
+               learning_rate_decay=0.995, eps=1e-5, resume=False, use_gpu=True, thread_count=1, seed=1234,
+               use_tensorboard=False, style_encoding_type="example", generate_samples_step=1000, use_script=False)
+    (tmp_path / "models").mkdir(), (tmp_path / "logs").mkdir()
+    train_mod.train(tmp_path / "models", tmp_path / "logs", npz, jsn, opt, net_opt)
+    eng = train_mod.last_engine
+    assert eng.iteration >= 1001
+    np.testing.assert_allclose(eng.opt.param_groups[0]["lr"], 1e-4 * 0.995, rtol=1e-12)   # decayed once, after it 999
+    ck = torch.load(tmp_path / "models" / "checkpoints.pt", weights_only=False)
+    assert ck["iteration"] == 1000
+    # the checkpoint of iteration 1000 carries the decayed lr and the moments
+    assert abs(ck["optimizer_state_dict"]["param_groups"][0]["lr"] - 1e-4 * 0.995) < 1e-15
+    m_saved = ck["optimizer_state_dict"]["state"][0]["exp_avg"].clone()
+    opt2 = dict(opt, resume=True, niterations=1.002)
+    train_mod.train(tmp_path / "models", tmp_path / "logs", npz, jsn, opt2, net_opt)
+    eng2 = train_mod.last_engine
+    assert eng2.iteration > 1000 and abs(eng2.opt.param_groups[0]["lr"] - 1e-4 * 0.995) < 1e-15
+    st0 = eng2.opt.state[eng2.params[0]]
+    assert st0["step"] > 1000 and float((st0["exp_avg"] - g(m_saved)).abs().max()) < 1.0   # moments continued, not reset
+    assert float(st0["exp_avg"].abs().max()) > 0

@@ -423,6 +423,7 @@ def test_train_api_runs_and_checkpoints(tmp_path):
     """train() with the reference's option dictionaries on a tiny synthetic dataset: runs, loss finite, writes
     the reference's checkpoint layout (incl. iteration 0), and the checkpoints load back into generate-able nets."""
     from zeggs import compat
+    from zeggs import train as train_mod
     from zeggs.train import train
     npz, jsn = synth.write_dataset(tmp_path / "data", n_train=2, n_valid=1, nframes=40, seed=3)
     net_opt = {"decoder": {"nhidden": 1024, "num_rnn_layers": 2, "rnn_cond": "normal"},
@@ -433,8 +434,11 @@ def test_train_api_runs_and_checkpoints(tmp_path):
                      learning_rate_decay=0.995, eps=1e-5, resume=False, use_gpu=True, thread_count=1, seed=1234,
                      use_tensorboard=False, style_encoding_type="example", generate_samples_step=3, use_script=False)
     (tmp_path / "models").mkdir(), (tmp_path / "logs").mkdir()
-    eng = train(tmp_path / "models", tmp_path / "logs", npz, jsn, train_opt, net_opt)
+    assert train(tmp_path / "models", tmp_path / "logs", npz, jsn, train_opt, net_opt) is None     # like the reference
+    eng = train_mod.last_engine
     assert eng.iteration >= 4 and torch.isfinite(eng.last_terms).all()
+    # every parameter is saved in its own storage (not the engine's whole flat buffer per file)
+    assert (tmp_path / "models" / "speech_encoder.pt").stat().st_size < 2 * 4 * sum(p.numel() for p in eng.se.parameters()) + 65536
     for f in ("speech_encoder.pt", "decoder.pt", "style_encoder.pt", "checkpoints.pt"):
         assert (tmp_path / "models" / f).exists() and (tmp_path / "models" / "0" / f).exists()
     de = compat.load_module(tmp_path / "models" / "decoder.pt", DEV)

@@ -171,9 +171,15 @@ StyleWs carve_style(const ZeggsStyleDims& d, Arena& a) {
   w.f = a.f(BL * E);
   w.S = a.f(B * NH * L * L);
   long big = BL * (long)(H > 3 * E ? H : 3 * E);
-  w.t0 = a.f(B * LP * (long)H); w.t1 = a.f(big); w.t2 = a.f(big); w.t3 = a.f(B * LP * (long)H);
+  // t0 / t3 hold padded rows of width H AND of width E (k_pad_rows(..., E)); dwf holds the packed weight gradient of
+  // every conv in turn (3*C*H, 3*H*E, 3*E*E): size them for the widest user, whatever the option dictionary says
+  const long HE = H > E ? H : E;
+  long dw = (long)C * H;
+  if ((long)H * E > dw) dw = (long)H * E;
+  if ((long)E * E > dw) dw = (long)E * E;
+  w.t0 = a.f(B * LP * HE); w.t1 = a.f(big); w.t2 = a.f(big); w.t3 = a.f(B * LP * HE);
   w.dqkv = a.f(BL * 3 * E);
-  w.dwf = a.f(3L * C * H);
+  w.dwf = a.f(3L * dw);
   return w;
 }
 

@@ -3,6 +3,7 @@
 
 #include "../../include/zeggs_hip.h"
 #include "common.h"
+#include "kernels.h"
 
 static thread_local char g_err[512] = "";
 
@@ -41,12 +42,15 @@ __global__ __launch_bounds__(256) void radam_k(float* p, const float* g, float* 
   }
 }
 
-__global__ void vae_fwd_k(const float* enc, const float* eps, float* z, int B, int S, float temp) {
+__global__ void vae_fwd_k(const float* enc, const float* eps, float* z, float* mu_out, float* lv_out, int B, int S,
+                          float temp) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * S) return;
   int b = i / S, c = i % S;
   float mu = enc[b * 2 * S + c], lv = enc[b * 2 * S + S + c];
   z[i] = mu + eps[i] * (expf(0.5f * lv) / temp);
+  if (mu_out) mu_out[i] = mu;
+  if (lv_out) lv_out[i] = lv;
 }
 __global__ void vae_bwd_k(const float* enc, const float* eps, const float* dz, const float* dmu, const float* dlv,
                           float* denc, int B, int S, float temp) {
@@ -91,6 +95,48 @@ __global__ void normalize_rows_k(float* x, long rows, int width, long ld, const 
   }
 }
 
+// dst = alpha * (*dev_scale, when given) * src   (gradient scaling by the upstream scalar of loss.backward(), copies)
+__global__ void scale_copy_k(float* dst, const float* src, long n, const float* dev_scale, float alpha) {
+  const float a = dev_scale ? alpha * dev_scale[0] : alpha;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = a * src[i];
+}
+__global__ void fill_k2(float* dst, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = v;
+}
+// standard normal samples from the counter hash (two 24-bit uniforms -> Box-Muller); element i depends on (seed, i) only
+__global__ void randn_k(float* out, long n, uint64_t seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float u1 = ((float)(hash_u32(seed, 2 * (uint64_t)i) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(hash_u32(seed, 2 * (uint64_t)i + 1) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    out[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+  }
+}
+// out[b][t][:] = z[b][:]  (style encoding repeated over the window, ZEGGS/train.py:256) and its adjoint
+__global__ void bcast_time_k(float* out, const float* z, int B, int T, int S) {
+  long n = (long)B * T * S;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % S);
+    long b = i / ((long)T * S);
+    out[i] = z[b * S + c];
+  }
+}
+__global__ void sum_time_k(float* dz, const float* dout, int B, int T, int S) {
+  // one workgroup per batch row; thread (c, part) sums a strided share of the T rows, LDS combine
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, parts = blockDim.x / S;
+  const int c = threadIdx.x % S, part = threadIdx.x / S;
+  float acc = 0.f;
+  if (part < parts)
+    for (int t = part; t < T; t += parts) acc += dout[((long)b * T + t) * S + c];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < S) {
+    float s = 0.f;
+    for (int q = 0; q < parts; ++q) s += sm[q * S + threadIdx.x];
+    dz[(long)b * S + threadIdx.x] = s;
+  }
+}
+
 inline int g1(long n) { long g = (n + 255) / 256; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 
 }  // namespace
@@ -106,10 +152,10 @@ extern "C" int zeggs_radam_step(float* p, const float* g, float* m, float* v, lo
   return 0;
 }
 
-extern "C" int zeggs_vae_reparam_fwd(const float* enc, const float* eps, float* z, int B, int S, float temperature,
-                                     void* stream) {
-  hipLaunchKernelGGL(vae_fwd_k, dim3(cdiv((long)B * S, 256)), dim3(256), 0, (hipStream_t)stream, enc, eps, z, B, S,
-                     temperature);
+extern "C" int zeggs_vae_reparam_fwd(const float* enc, const float* eps, float* z, float* mu_out, float* logvar_out,
+                                     int B, int S, float temperature, void* stream) {
+  hipLaunchKernelGGL(vae_fwd_k, dim3(cdiv((long)B * S, 256)), dim3(256), 0, (hipStream_t)stream, enc, eps, z, mu_out,
+                     logvar_out, B, S, temperature);
   ZLAUNCH_CHECK("vae_fwd");
   return 0;
 }
@@ -147,4 +193,46 @@ extern "C" int zeggs_normalize_rows(float* x, long rows, int width, long ld, con
                      std_scalar);
   ZLAUNCH_CHECK("normalize_rows");
   return 0;
+}
+
+extern "C" int zeggs_fill(float* dst, long n, float value, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(fill_k2, dim3(g1(n)), dim3(256), 0, (hipStream_t)stream, dst, n, value);
+  ZLAUNCH_CHECK("fill");
+  return 0;
+}
+extern "C" int zeggs_scale_copy(float* dst, const float* src, long n, const float* dev_scale, float alpha, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scale_copy_k, dim3(g1(n)), dim3(256), 0, (hipStream_t)stream, dst, src, n, dev_scale, alpha);
+  ZLAUNCH_CHECK("scale_copy");
+  return 0;
+}
+extern "C" int zeggs_randn(float* out, long n, uint64_t seed, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(randn_k, dim3(g1(n)), dim3(256), 0, (hipStream_t)stream, out, n, seed);
+  ZLAUNCH_CHECK("randn");
+  return 0;
+}
+extern "C" int zeggs_broadcast_time(float* out, const float* z, int B, int T, int S, void* stream) {
+  long n = (long)B * T * S;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(bcast_time_k, dim3(g1(n)), dim3(256), 0, (hipStream_t)stream, out, z, B, T, S);
+  ZLAUNCH_CHECK("broadcast_time");
+  return 0;
+}
+extern "C" int zeggs_sum_time(float* dz, const float* dout, int B, int T, int S, void* stream) {
+  ZCHECK(S >= 1 && S <= 1024, "sum_time: 1 <= S <= 1024");
+  if (B <= 0) return 0;
+  int parts = 1024 / S;
+  if (parts > T) parts = T > 0 ? T : 1;
+  const int threads = parts * S;
+  hipLaunchKernelGGL(sum_time_k, dim3(B), dim3(threads), threads * sizeof(float), (hipStream_t)stream, dz, dout, B, T, S);
+  ZLAUNCH_CHECK("sum_time");
+  return 0;
+}
+
+extern "C" int zeggs_dropout(float* x, long n, float p, uint64_t seed, void* stream) {
+  ZCHECK(p >= 0.f && p < 1.f, "dropout: 0 <= p < 1");
+  if (n <= 0) return 0;
+  return k_dropout(x, n, p, seed, (hipStream_t)stream);
 }

@@ -72,11 +72,14 @@ class DeviceDataset:
         starts = torch.as_tensor(self.win_start[idx]).to(dev, non_blocking=True)
         out = dict(audio=ops.gather_windows(self.audio, starts, T), pose=ops.gather_windows(self.pose, starts, T),
                    rpos=ops.gather_windows(self.rpos, starts, T), rrot=ops.gather_windows(self.rrot, starts, T),
-                   gaze=ops.gather_windows(self.gaze, starts, T))
+                   gaze=ops.gather_windows(self.gaze, starts, T),
+                   # first frame of every window (the decoder's initial pose), gathered directly: no strided copies
+                   pose0=ops.gather_rows(self.pose, starts), rpos0=ops.gather_rows(self.rpos, starts),
+                   rrot0=ops.gather_rows(self.rrot, starts))
         ops.normalize_rows_(out["audio"], self.audio_mean, self.audio_std)
         if example_len is not None:
             rows = torch.as_tensor(self.example_rows(idx, example_len)).to(dev, non_blocking=True)
-            ex = torch.zeros(B, example_len, self.PO + 3, device=dev)      # gaze slot = 0 (dataset.py:194)
+            ex = ops.fill_(torch.empty(B, example_len, self.PO + 3, device=dev))      # gaze slot = 0 (dataset.py:194)
             ops.gather_rows(self.pose, rows, out=ex, out_ld=self.PO + 3)
             ops.normalize_rows_(ex, self.in_mean, self.in_std)
             out["example"] = ex
@@ -140,33 +143,47 @@ class TrainEngine:
         self.iteration = 0
         self.last_terms = None
         self.decoder_fwd_events = None      # bench.py: list of (start, end) HIP events around the forward rollout
+        self.decoder_bwd_events = None      # bench.py: same around loss.backward() (BPTT + encoder backward)
+        self._one = torch.ones((), device=dev, dtype=torch.float32)     # upstream gradient of loss.backward()
 
     def step(self, idx, example_len, eps=None, labels=None):
         """One training iteration on window indices `idx` (this rank's slice). Returns the loss tensor (device)."""
         ds, T = self.ds, self.ds.window
         b = ds.batch(idx, example_len if self.style_type == "example" else None)
-        self.flat_g.zero_()
-        speech = self.se(b["audio"])
-        mu = logvar = None
-        if self.style_type == "example":
-            z, mu, logvar = self.st(b["example"], 1.0, eps=eps)
-        else:
-            z = labels
-        style = z.unsqueeze(1).expand(-1, T, -1).contiguous()
-        if self.decoder_fwd_events is not None:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-        pose, orp, orr = ops.decoder_core(self.de, b["pose"][:, 0].contiguous(), b["rpos"][:, 0].contiguous(),
-                                          b["rrot"][:, 0].contiguous(), b["gaze"], speech, style, ds.in_mean,
-                                          ds.in_std, ds.out_mean, ds.out_std, self.dt)
-        if self.decoder_fwd_events is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            self.decoder_fwd_events.append((e0, e1))
-        klw = kl_div_weight(self.iteration) if mu is not None else 0.0
-        loss, terms = ops.training_loss(pose, orp, orr, b["pose"], b["rpos"], b["rrot"], b["gaze"], self.parents,
-                                        self.dt, mu, logvar, kl_weight=klw, gscale=1.0 / self.world)
-        loss.backward()
+        ops.fill_(self.flat_g)
+        ops.direct_param_grads(True)        # *_bwd kernels write straight into the flat gradient buffer
+        try:
+            speech = self.se(b["audio"])
+            mu = logvar = None
+            if self.style_type == "example":
+                z, mu, logvar = self.st(b["example"], 1.0, eps=eps)
+            else:
+                z = labels
+            style = ops.broadcast_time(z, T)
+            ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+            if self.decoder_fwd_events is not None:
+                e0 = ev()
+                e0.record()
+            pose, orp, orr = ops.decoder_core(self.de, b["pose0"], b["rpos0"], b["rrot0"], b["gaze"], speech, style,
+                                              ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, self.dt)
+            if self.decoder_fwd_events is not None:
+                e1 = ev()
+                e1.record()
+                self.decoder_fwd_events.append((e0, e1))
+            klw = kl_div_weight(self.iteration) if mu is not None else 0.0
+            loss, terms = ops.training_loss(pose, orp, orr, b["pose"], b["rpos"], b["rrot"], b["gaze"], self.parents,
+                                            self.dt, mu, logvar, kl_weight=klw, gscale=1.0 / self.world,
+                                            unit_grad=True)
+            if self.decoder_bwd_events is not None:
+                e2 = ev()
+                e2.record()
+            loss.backward(self._one)
+            if self.decoder_bwd_events is not None:
+                e3 = ev()
+                e3.record()
+                self.decoder_bwd_events.append((e2, e3))
+        finally:
+            ops.direct_param_grads(False)
         allreduce_mean_(self.flat_g, self.world, self.pg, prescaled=True)
         self.opt.step()
         self.iteration += 1

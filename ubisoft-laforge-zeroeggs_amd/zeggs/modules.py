@@ -154,7 +154,7 @@ class SpeechEncoder(nn.Module):
 class StyleEncoder(nn.Module):
     """Style encoder + VAE re-parameterisation (reference modules.py:278-304).
     As in the reference, eval mode still samples eps; `eps` may be injected for
-    testing (otherwise drawn with torch.randn on the input's device)."""
+    testing (otherwise drawn from the library's counter-hash normal stream)."""
 
     def __init__(self, input_size, hidden_size, style_embedding_size, type="attn", use_vae=False):
         super().__init__()
@@ -177,7 +177,7 @@ class StyleEncoder(nn.Module):
             return out, None, None
         S = self.style_embedding_size
         if eps is None:
-            eps = torch.randn(out.shape[0], S, device=out.device, dtype=out.dtype)
+            eps = ops.randn((out.shape[0], S), out.device)      # library counter-hash stream (ops.manual_seed)
         return ops.vae_reparam(out, eps, float(temprature), S)
 
 

@@ -122,6 +122,78 @@ def manual_seed(s):
     _seed_rng = np.random.default_rng(int(s))
 
 
+_DIRECT_GRADS = False
+
+
+def direct_param_grads(on):
+    """Training-engine mode: the *_bwd entry points write parameter gradients STRAIGHT into the parameters'
+    existing `.grad` tensors (views of the engine's flat gradient buffer) and the autograd Functions return None
+    for them, so no AccumulateGrad add runs.  Semantics are OVERWRITE (every parameter is used by exactly one
+    op per iteration), not accumulate -- only engine.TrainEngine turns this on."""
+    global _DIRECT_GRADS
+    _DIRECT_GRADS = bool(on)
+
+
+def _grad_targets(orig_params, params):
+    """-> (tensors the backward kernel writes, values returned to autograd)"""
+    outs, rets = [], []
+    for o, t in zip(orig_params, params):
+        g = getattr(o, "grad", None) if _DIRECT_GRADS else None
+        if g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.shape == t.shape:
+            outs.append(g)
+            rets.append(None)
+        else:
+            e = torch.empty_like(t)
+            outs.append(e)
+            rets.append(e)
+    return outs, rets
+
+
+def fill_(t, value=0.0):
+    _check(lib().zeggs_fill(_p(t), C.c_long(t.numel()), C.c_float(value), _stream()), "fill")
+    return t
+
+
+def scale_copy(src, dev_scale=None, alpha=1.0, out=None):
+    """out = alpha * dev_scale[0] * src (dev_scale: 1-element device tensor or None)"""
+    src = src if src.is_contiguous() else src.contiguous()
+    out = torch.empty_like(src) if out is None else out
+    _check(lib().zeggs_scale_copy(_p(out), _p(src), C.c_long(src.numel()), _p(dev_scale) if dev_scale is not None else None,
+                                  C.c_float(alpha), _stream()), "scale_copy")
+    return out
+
+
+def randn(shape, device, seed=None):
+    """Standard normal samples from the library's counter-hash stream (seeded by ops.manual_seed)."""
+    out = torch.empty(*shape, device=device, dtype=torch.float32)
+    _check(lib().zeggs_randn(_p(out), C.c_long(out.numel()), C.c_uint64(next_seed() if seed is None else int(seed)),
+                             _stream()), "randn")
+    return out
+
+
+class _BroadcastTimeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, T):
+        z = _f32c(z)
+        B, S = z.shape
+        out = torch.empty(B, T, S, device=z.device, dtype=torch.float32)
+        _check(lib().zeggs_broadcast_time(_p(out), _p(z), B, T, S, _stream()), "broadcast_time")
+        ctx.dims = (B, T, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, S = ctx.dims
+        dz = torch.empty(B, S, device=dout.device, dtype=torch.float32)
+        _check(lib().zeggs_sum_time(_p(dz), _p(_f32c(dout)), B, T, S, _stream()), "sum_time")
+        return dz, None
+
+
+def broadcast_time(z, T):
+    """z [B,S] -> [B,T,S] contiguous (style_encoding.unsqueeze(1).repeat_interleave(T, 1), ZEGGS/train.py:256)"""
+    return _BroadcastTimeFn.apply(z, int(T))
+
+
 def _ptrs(cls, fields, tensors):
     s = cls()
     for f, t in zip(fields, tensors):
@@ -144,6 +216,7 @@ class _SpeechFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w0, b0, w1, b1, w2, b2, p, seed):
         x = _f32c(x)
+        ctx.orig = (w0, b0, w1, b1, w2, b2)
         params = [_f32c(t) for t in (w0, b0, w1, b1, w2, b2)]
         B, T, F = x.shape
         d = SpeechDims(B, T, F, w0.shape[0], w2.shape[0], w1.shape[2], float(p), int(seed))
@@ -161,12 +234,12 @@ class _SpeechFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, out, *params = ctx.saved_tensors
         L = lib()
-        grads = [torch.empty_like(t) for t in params]
+        grads, rets = _grad_targets(ctx.orig, params)
         P = _ptrs(SpeechPtrs, SPEECH_FIELDS, params)
         G = _ptrs(SpeechPtrs, SPEECH_FIELDS, grads)
         _check(L.zeggs_speech_encoder_bwd(C.byref(ctx.d), C.byref(P), _p(x), _p(out), _p(_f32c(dout)), C.byref(G),
                                           _p(ctx.ws), C.c_size_t(ctx.ws.numel()), _stream()), "speech_encoder_bwd")
-        return (None, *grads, None, None)
+        return (None, *rets, None, None)
 
 
 def speech_encoder(x, w0, b0, w1, b1, w2, b2, p=0.0):
@@ -210,6 +283,7 @@ class _StyleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos, dropout, seed, nheads, *params):
         x = _f32c(x)
+        ctx.orig = params
         params = [_f32c(t) for t in params]
         B, Lx, Cx = x.shape
         H, E = params[0].shape[0], params[4].shape[0]
@@ -228,12 +302,12 @@ class _StyleFn(torch.autograd.Function):
     def backward(ctx, dout):
         params = list(ctx.saved_tensors)
         L = lib()
-        grads = [torch.empty_like(t) for t in params]
+        grads, rets = _grad_targets(ctx.orig, params)
         P = _ptrs(StylePtrs, STYLE_FIELDS, params)
         G = _ptrs(StylePtrs, STYLE_FIELDS, grads)
         _check(L.zeggs_style_encoder_bwd(C.byref(ctx.d), C.byref(P), _p(_f32c(dout)), C.byref(G), _p(ctx.ws),
                                          C.c_size_t(ctx.ws.numel()), _stream()), "style_encoder_bwd")
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, *rets)
 
 
 STYLE_GRU_FIELDS = ("c0_w", "c0_b", "c2_w", "c2_b", "w_ih", "w_hh", "b_ih", "b_hh", "w_ih_r", "w_hh_r", "b_ih_r",
@@ -249,6 +323,7 @@ class _StyleGruFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, *params):
         x = _f32c(x)
+        ctx.orig = params
         params = [_f32c(t) for t in params]
         B, Lx, Cx = x.shape
         d = StyleGruDims(B, Lx, Cx, params[0].shape[0], params[12].shape[0])
@@ -266,12 +341,12 @@ class _StyleGruFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         params = list(ctx.saved_tensors)
-        grads = [torch.empty_like(t) for t in params]
+        grads, rets = _grad_targets(ctx.orig, params)
         P = _ptrs(StyleGruPtrs, STYLE_GRU_FIELDS, params)
         G = _ptrs(StyleGruPtrs, STYLE_GRU_FIELDS, grads)
         _check(lib().zeggs_style_encoder_gru_bwd(C.byref(ctx.d), C.byref(P), _p(_f32c(dout)), C.byref(G), _p(ctx.ws),
                                                  C.c_size_t(ctx.ws.numel()), _stream()), "style_encoder_gru_bwd")
-        return (None, *grads)
+        return (None, *rets)
 
 
 def style_encoder_gru(x, enc):
@@ -293,25 +368,26 @@ class _VaeFn(torch.autograd.Function):
     def forward(ctx, enc, eps, temperature, S):
         enc, eps = _f32c(enc), _f32c(eps)
         B = enc.shape[0]
-        z = torch.empty(B, S, device=enc.device, dtype=torch.float32)
-        _check(lib().zeggs_vae_reparam_fwd(_p(enc), _p(eps), _p(z), B, S, C.c_float(temperature), _stream()),
-               "vae_reparam_fwd")
+        z, mu, lv = (torch.empty(B, S, device=enc.device, dtype=torch.float32) for _ in range(3))
+        _check(lib().zeggs_vae_reparam_fwd(_p(enc), _p(eps), _p(z), _p(mu), _p(lv), B, S, C.c_float(temperature),
+                                           _stream()), "vae_reparam_fwd")
         ctx.save_for_backward(enc, eps)
         ctx.t, ctx.S = temperature, S
-        return z
+        return z, mu, lv
 
     @staticmethod
-    def backward(ctx, dz):
+    def backward(ctx, dz, dmu, dlv):
         enc, eps = ctx.saved_tensors
         denc = torch.empty_like(enc)
-        _check(lib().zeggs_vae_reparam_bwd(_p(enc), _p(eps), _p(_f32c(dz)), None, None, _p(denc), enc.shape[0], ctx.S,
+        c = lambda g: _p(_f32c(g)) if g is not None else None  # noqa: E731
+        _check(lib().zeggs_vae_reparam_bwd(_p(enc), _p(eps), c(dz), c(dmu), c(dlv), _p(denc), enc.shape[0], ctx.S,
                                            C.c_float(ctx.t), _stream()), "vae_reparam_bwd")
         return denc, None, None, None
 
 
 def vae_reparam(enc, eps, temperature, S):
-    z = _VaeFn.apply(enc, eps, float(temperature), S)
-    return z, enc[:, :S], enc[:, S:]
+    """-> z, mu, logvar (contiguous [B,S] each; mu / logvar are the two halves of enc)"""
+    return _VaeFn.apply(enc, eps, float(temperature), S)
 
 
 # ----------------------------------------------------------------------------- decoder
@@ -334,6 +410,7 @@ class _DecoderFn(torch.autograd.Function):
                 *params):
         pose0, rpos0, rrot0, gaze, speech, style = (_f32c(t) for t in (pose0, rpos0, rrot0, gaze, speech, style))
         stats = [_f32c(t) for t in (in_mean, in_std, out_mean, out_std)]
+        ctx.orig = params
         params = [_f32c(t) for t in params]
         B, T, SP = speech.shape
         ST, PO = style.shape[2], pose0.shape[1]
@@ -363,9 +440,9 @@ class _DecoderFn(torch.autograd.Function):
         d = ctx.d
         L = lib()
         dev = pose.device
-        z = lambda g, ref: torch.zeros_like(ref) if g is None else _f32c(g)  # noqa: E731
+        z = lambda g, ref: fill_(torch.empty_like(ref)) if g is None else _f32c(g)  # noqa: E731
         dpose, drpos, drrot = z(dpose, pose), z(drpos, rpos), z(drrot, rrot)
-        grads = [torch.empty_like(t) for t in params]
+        grads, rets = _grad_targets(ctx.orig, params)
         dspeech = torch.empty(d.B, d.T, d.SP, device=dev, dtype=torch.float32)
         dstyle = torch.empty(d.B, d.T, d.ST, device=dev, dtype=torch.float32)
         P = _ptrs(DecPtrs, DEC_FIELDS, params)
@@ -374,7 +451,7 @@ class _DecoderFn(torch.autograd.Function):
         _check(L.zeggs_decoder_bwd(C.byref(d), C.byref(P), C.byref(S), _p(gaze), _p(pose), _p(rpos), _p(rrot),
                                    _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
                                    C.c_size_t(ctx.ws.numel()), _stream()), "decoder_bwd")
-        return (None, None, None, None, dspeech, dstyle, None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, dspeech, dstyle, None, None, None, None, None, None, None, *rets)
 
 
 def decoder_core(dec, pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt):
@@ -402,7 +479,8 @@ def decoder_rollout(dec, Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos,
 # ----------------------------------------------------------------------------- loss
 class _LossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, o_pose, o_rpos, o_rrot, mu, logvar, w_pose, w_rpos, w_rrot, gaze, parents, kl_weight, dt, gscale):
+    def forward(ctx, o_pose, o_rpos, o_rrot, mu, logvar, w_pose, w_rpos, w_rrot, gaze, parents, kl_weight, dt, gscale,
+                unit_grad):
         o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze = (
             _f32c(t) for t in (o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze))
         B, T, PO = o_pose.shape
@@ -424,23 +502,30 @@ class _LossFn(torch.autograd.Function):
                                     _p(drrot), _p(dmu), _p(dlv), C.c_float(gscale), _p(ws), C.c_size_t(ws.numel()),
                                     _stream()), "loss_fwd_bwd")
         ctx.save_for_backward(dpose, drpos, drrot, dmu, dlv)
+        ctx.unit_grad = bool(unit_grad)
         ctx.mark_non_differentiable(terms)
-        return terms[18].clone(), terms
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        scale_copy(terms[18:19], out=loss)
+        return loss, terms
 
     @staticmethod
     def backward(ctx, g, _gterms):
         dpose, drpos, drrot, dmu, dlv = ctx.saved_tensors
-        dpose, drpos, drrot = dpose * g, drpos * g, drrot * g
-        if dmu is not None:
-            dmu, dlv = dmu * g, dlv * g
-        return (dpose, drpos, drrot, dmu, dlv, None, None, None, None, None, None, None, None)
+        if not ctx.unit_grad:        # general case: scale by the upstream scalar (device side, no host sync)
+            g = _f32c(g).reshape(1)
+            dpose, drpos, drrot = scale_copy(dpose, g), scale_copy(drpos, g), scale_copy(drrot, g)
+            if dmu is not None:
+                dmu, dlv = scale_copy(dmu, g), scale_copy(dlv, g)
+        return (dpose, drpos, drrot, dmu, dlv, None, None, None, None, None, None, None, None, None)
 
 
 def training_loss(o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze, parents, dt, mu=None, logvar=None,
-                  kl_weight=0.0, gscale=1.0):
-    """-> (loss scalar tensor, terms[19]); terms[0:18] are the reference's weighted loss terms."""
+                  kl_weight=0.0, gscale=1.0, unit_grad=False):
+    """-> (loss scalar tensor, terms[19]); terms[0:18] are the reference's weighted loss terms.
+    unit_grad=True: the caller promises to call backward() on the returned loss itself (upstream gradient 1), so
+    the gradients computed in the fused forward+backward kernel are handed on without a scaling pass."""
     return _LossFn.apply(o_pose, o_rpos, o_rrot, mu, logvar, w_pose, w_rpos, w_rrot, gaze, parents,
-                         float(kl_weight), float(dt), float(gscale))
+                         float(kl_weight), float(dt), float(gscale), bool(unit_grad))
 
 
 # ----------------------------------------------------------------------------- optimizer / data

@@ -119,10 +119,37 @@ def make_clip(nframes, seed=0, stats=None):
                 Y_lvel=lvel.astype(f), Y_lvrt=lvrt.astype(f), Y_gaze_pos=gaze.astype(f))
 
 
-def make_processed(n_train, n_valid, nframes, seed=0, nlabels=19, stats=None):
+def make_clip_stats(nframes, seed, stats, amp=0.8):
+    """A clip drawn AROUND GIVEN normalisation statistics (e.g. the reference's real data/processed_v*/stats.npz):
+    every pose channel is mean + std * smooth noise, so that normalised inputs are O(1) whatever the dynamic
+    range of the statistics is, and channels with anim_output_std == 0 are exactly constant -- as in the real
+    dataset.  Root trajectory / gaze / audio as in make_clip."""
+    rng = np.random.default_rng(seed)
+    n = nframes
+    om = np.asarray(stats["anim_output_mean"], np.float64)
+    osd = np.asarray(stats["anim_output_std"], np.float64)
+    pose = om[None] + osd[None] * _smooth(rng, n, POSE_OUT, amp)
+    yaw = _smooth(rng, n, 1, 0.4)[:, 0]
+    root_rot = np.stack([np.cos(yaw / 2), np.zeros(n), np.sin(yaw / 2), np.zeros(n)], axis=1)
+    root_pos = np.cumsum(_smooth(rng, n, 3, 0.5) * np.array([1.0, 0.0, 1.0]) * DT * 30, axis=0)
+    gaze = np.tile(np.array([[10.0, 150.0, 100.0]]), (n, 1)) + rng.normal(0, 1.0, (1, 3)) + _smooth(rng, n, 3, 2.0)
+    am = np.asarray(stats["audio_input_mean"], np.float64)
+    audio = am[None] + rng.standard_normal((n, N_AUDIO)) * np.concatenate([np.full(80, 0.02), [1.0]])[None]
+    f = np.float32
+    o = [0, 3, 6, 6 + 3 * NJ, 6 + 9 * NJ, 6 + 12 * NJ, POSE_OUT]
+    return dict(X_audio_features=audio.astype(f), Y_root_pos=root_pos.astype(f), Y_root_rot=root_rot.astype(f),
+                Y_root_vel=pose[:, o[0]:o[1]].astype(f), Y_root_vrt=pose[:, o[1]:o[2]].astype(f),
+                Y_lpos=pose[:, o[2]:o[3]].reshape(n, NJ, 3).astype(f),
+                Y_ltxy=pose[:, o[3]:o[4]].reshape(n, NJ, 2, 3).astype(f),
+                Y_lvel=pose[:, o[4]:o[5]].reshape(n, NJ, 3).astype(f),
+                Y_lvrt=pose[:, o[5]:o[6]].reshape(n, NJ, 3).astype(f), Y_gaze_pos=gaze.astype(f))
+
+
+def make_processed(n_train, n_valid, nframes, seed=0, nlabels=19, stats=None, clip_fn=None):
     """Concatenate clips into the processed_data.npz layout (dict of arrays)."""
     stats = stats or make_stats()
-    clips = [make_clip(nframes, seed=seed * 1000 + i, stats=stats) for i in range(n_train + n_valid)]
+    clip_fn = clip_fn or (lambda n, seed, stats: make_clip(n, seed=seed, stats=stats))
+    clips = [clip_fn(nframes, seed=seed * 1000 + i, stats=stats) for i in range(n_train + n_valid)]
     data = {k: np.concatenate([c[k] for c in clips], axis=0) for k in clips[0]}
     bounds = np.arange(n_train + n_valid + 1) * nframes
     rng = np.random.default_rng(seed + 99)
@@ -138,12 +165,12 @@ def data_definition(nlabels=19):
     return dict(dt=DT, label_names=LABEL_NAMES[:nlabels], parents=PARENTS, bone_names=BONE_NAMES)
 
 
-def write_dataset(directory, n_train=2, n_valid=1, nframes=600, seed=0, nlabels=19):
+def write_dataset(directory, n_train=2, n_valid=1, nframes=600, seed=0, nlabels=19, stats=None, clip_fn=None):
     """Write processed_data.npz + data_definition.json + stats.npz into `directory`."""
     d = Path(directory)
     d.mkdir(parents=True, exist_ok=True)
-    stats = make_stats()
-    data = make_processed(n_train, n_valid, nframes, seed, nlabels, stats)
+    stats = stats or make_stats()
+    data = make_processed(n_train, n_valid, nframes, seed, nlabels, stats, clip_fn)
     np.savez(d / "processed_data.npz", **data)
     np.savez(d / "stats.npz", **stats)
     with open(d / "data_definition.json", "w") as f:

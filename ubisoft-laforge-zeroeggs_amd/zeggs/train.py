@@ -8,6 +8,7 @@ reference).  Differences (documented in DESIGN.md): the dataset lives in HBM and
 kernel; data parallelism over torch.distributed (RCCL) when WORLD_SIZE > 1; TensorBoard / sample-BVH rendering are
 optional host extras (skipped when tensorboard is not installed).
 """
+import copy
 import datetime
 import json
 import os
@@ -21,7 +22,24 @@ import torch
 from . import engine, modules, ops
 
 
+last_engine = None       # the TrainEngine of the most recent train() call (train() itself returns None, like the reference)
+
+
+def compact_copy(module):
+    """Deep copy of a module whose parameters are views of the engine's flat buffers, with every parameter in its
+    OWN storage (torch.save of the views would write the whole flat buffer into each file)."""
+    grads = [p.grad for p in module.parameters()]
+    for q in module.parameters():
+        q.grad = None
+    try:
+        return copy.deepcopy(module)        # Parameter.__deepcopy__ clones .data -> compact storage
+    finally:
+        for q, g in zip(module.parameters(), grads):
+            q.grad = g
+
+
 def train(models_dir, logs_dir, path_processed_data, path_data_definition, train_options, network_options):
+    global last_engine
     models_dir, logs_dir = Path(models_dir), Path(logs_dir)
     np.random.seed(train_options["seed"])
     torch.manual_seed(train_options["seed"])
@@ -59,6 +77,11 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
                                       use_vae=st_opt["use_vae"]).to(device)
     eng = engine.TrainEngine(se, de, st, ds, parents, dt, lr=train_options["learning_rate"], eps=train_options["eps"],
                              style_encoding_type=style_type, world_size=world, rank=rank)
+    last_engine = eng
+    # the common seed gave identical initial weights and gives the identical window permutation on every rank; the
+    # NOISE streams (dropout masks, VAE eps: the library's counter-hash RNG) must differ per rank, otherwise the
+    # global batch would see `world` copies of the same noise
+    ops.manual_seed(train_options["seed"] + 7919 * rank)
     iteration = epoch = 0
     if resume:
         ck = torch.load(paths["checkpoints"], map_location=device, weights_only=False)
@@ -70,9 +93,11 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
     example_len = st_opt["example_length"]
     gb = batchsize * world
     labels_onehot = None
-    if style_type == "label":
-        labels_onehot = torch.eye(nlabels, device=device)[torch.as_tensor(ds.ranges_train_labels, device=device)]
+    if style_type == "label":       # one-hot row per training range (dataset.py:150-151), gathered per window by a HIP kernel
+        labels_onehot = torch.as_tensor(np.eye(nlabels, dtype=np.float32)[ds.ranges_train_labels]).to(device)
     perm_rng = np.random.default_rng(train_options["seed"])           # identical on every rank
+    for _ in range(epoch):                                             # resume: replay the permutations already consumed
+        perm_rng.permutation(len(ds))
     while iteration < 1000 * train_options["niterations"]:
         start = datetime.datetime.now()
         perm = perm_rng.permutation(len(ds))
@@ -82,7 +107,7 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
             if st is not None:
                 st.train()
             idx = engine.shard_indices(perm, bi, batchsize, world, rank)
-            lab = labels_onehot[torch.as_tensor(ds.win_sample[idx].astype(np.int64), device=device)] \
+            lab = ops.gather_rows(labels_onehot, torch.as_tensor(ds.win_sample[idx].astype(np.int64)).to(device)) \
                 if labels_onehot is not None else None
             loss = eng.step(idx, example_len, labels=lab)
             # the example length of the NEXT iteration (train.py:228); seeded here so that all ranks agree
@@ -95,17 +120,24 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
                 sys.stdout.write(f"\r| epoch {epoch} | it {iteration} | batch {bi}/{nb} | loss {float(loss):.4f} "
                                  f"| {datetime.datetime.now() - start} |")
             if rank == 0 and iteration % train_options["generate_samples_step"] == 0:
+                snap = [compact_copy(m) if m is not None else None for m in (se, de, st)]
+                osd = eng.opt.state_dict()                 # moments are views of the flat buffers: store them compact
+                osd["state"] = {k: {kk: (vv.detach().clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+                                for k, v in osd["state"].items()}
                 for d in (models_dir, models_dir / str(iteration)):
                     d.mkdir(parents=True, exist_ok=True)
-                    torch.save(se, d / "speech_encoder.pt")
-                    torch.save(de, d / "decoder.pt")
+                    torch.save(snap[0], d / "speech_encoder.pt")
+                    torch.save(snap[1], d / "decoder.pt")
                     if st is not None:
-                        torch.save(st, d / "style_encoder.pt")
+                        torch.save(snap[2], d / "style_encoder.pt")
                     torch.save({"iteration": iteration, "epoch": epoch, "loss": loss.detach(),
-                                "optimizer_state_dict": eng.opt.state_dict()}, d / "checkpoints.pt")
-                    compat.save_state(d, se, de, st, meta={"iteration": iteration, "epoch": epoch})   # pickle-free twin
+                                "optimizer_state_dict": osd}, d / "checkpoints.pt")
+                    try:                                   # pickle-free twin (optional dependency: safetensors)
+                        compat.save_state(d, se, de, st, meta={"iteration": iteration, "epoch": epoch})
+                    except ImportError as e:
+                        print(f"\nwarning: safetensors twin not written ({e})")
             iteration += 1
         epoch += 1
     if rank == 0:
         print("\nDone!")
-    return eng
+    return None
