@@ -1,18 +1,25 @@
 #!/usr/bin/env python
 """Headline benchmark: gesture frames/sec of the ZeroEGGS training step on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE full training iteration of BASELINE.json configs[1]: configs_v1 networks
-(random-init, seed 1234), batch 32 per GPU of 256-frame windows cut from synthetic 60-fps 2-minute
-clips that are resident in HBM, style examples of length 384: gather -> speech encoder -> style
-VAE -> 255-step decoder rollout -> FK/L1 loss -> BPTT -> (RCCL all-reduce) -> fused RAdam.
-Nothing is skipped or cached inside the timed region; training-mode dropout is on.
-Prints ONE JSON line on rank 0 (contract: task statement / DESIGN.md "Measurement").
+N > 1 works both ways: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or as the plain command above -- bench.py then
+re-executes itself under torch.distributed.run on 127.0.0.1 with a free port (one rank per GPU over RCCL).
+
+A "step" is ONE full training iteration of BASELINE.json configs[1]: configs_v1 networks (random-init, seed 1234),
+batch 32 per GPU of 256-frame windows cut from synthetic 60-fps 2-minute clips that are resident in HBM, style
+examples of length 384: gather -> speech encoder -> style VAE -> 255-step decoder rollout -> FK/L1 loss -> BPTT ->
+(RCCL all-reduce) -> fused RAdam.  Nothing is skipped or cached inside the timed region; training-mode dropout is on.
+Prints ONE JSON line on rank 0 (contract: task statement / DESIGN.md "Measurement").  At N = 1 the line also carries
+the other BASELINE.json configs as extra keys: `decode` (B=1, 1800 frames), `decode_30min` (configs[4]),
+`v2_label_b64` (configs[3]) and the CPU baselines.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -29,15 +36,24 @@ from zeggs import engine, modules, ops, synth  # noqa: E402
 
 BATCH, WINDOW, EXAMPLE_LEN, CLIP_FRAMES = 32, 256, 384, 7200
 H, SP, ST = 1024, 64, 64
-XD = synth.POSE_IN + SP + ST
-# algorithmic bytes of ONE decoder step, forward: every per-step weight + bias read once
-STEP_WEIGHT_BYTES = 4 * (H * XD + 3 * H * (H + XD) + 3 * H * H + 3 * H * H + 3 * H * H + synth.POSE_OUT * H
-                         + H + 4 * 3 * H + synth.POSE_OUT)
 HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TFLOPS = 157.3
 
 
-def step_bytes(batch):
-    return STEP_WEIGHT_BYTES + batch * 4 * (synth.POSE_IN + SP + ST + 2 * H + synth.POSE_OUT + 2 * H)
+def step_weight_bytes(style=ST):
+    """algorithmic bytes of ONE decoder step: every per-step weight + bias read once"""
+    xd = synth.POSE_IN + SP + style
+    return 4 * (H * xd + 3 * H * (H + xd) + 3 * H * H + 3 * H * H + 3 * H * H + synth.POSE_OUT * H
+                + H + 4 * 3 * H + synth.POSE_OUT)
+
+
+def step_bytes(batch, style=ST):
+    return step_weight_bytes(style) + batch * 4 * (synth.POSE_IN + SP + style + 2 * H + synth.POSE_OUT + 2 * H)
+
+
+def step_flops(batch, style=ST):
+    xd = synth.POSE_IN + SP + style
+    return 2 * batch * (H * xd + 3 * H * (H + xd) + 3 * H * H + 3 * H * H + 3 * H * H + synth.POSE_OUT * H)
 
 
 def build_dataset(n_train=64, n_unique=4, seed=0):
@@ -53,20 +69,38 @@ def build_dataset(n_train=64, n_unique=4, seed=0):
     return data
 
 
-def build_nets(device):
+def build_nets(device, style=ST, with_style_encoder=True):
     torch.manual_seed(1234)
     se = modules.SpeechEncoder(synth.N_AUDIO, 64, SP)
-    de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, SP, ST, H, 2)
-    st = modules.StyleEncoder(synth.POSE_IN, 512, ST, type="attn", use_vae=True)
-    return se.to(device).train(), de.to(device).train(), st.to(device).train()
+    de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, SP, style, H, 2)
+    st = modules.StyleEncoder(synth.POSE_IN, 512, ST, type="attn", use_vae=True) if with_style_encoder else None
+    return se.to(device).train(), de.to(device).train(), (st.to(device).train() if st is not None else None)
 
 
-def cpu_baseline(data, iters=2):
-    """The CPU oracle (torch-CPU restatement of the reference, oracle/) timed on this host's cores on the SAME
-    workload shape (B=32, T=256, example 384): `iters` full iterations fwd+loss+bwd (+RAdam is negligible)."""
+def sweep_ms(which):
+    import ctypes as C
+    ms = C.c_float(0)
+    ops._check(ops.lib().zeggs_timing_ms(int(which), C.byref(ms)), "timing_ms")
+    return float(ms.value)
+
+
+# ----------------------------------------------------------------------------- CPU baselines
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_port_train(data, threads, iters=2):
+    """The CPU oracle (torch-CPU restatement of the reference, oracle/) on the SAME workload shape (B=32, T=256,
+    example 384): `iters` full iterations fwd+loss+bwd (RAdam is negligible)."""
     from oracle import loss as oloss
     from oracle import nets as onets
-    threads = min(64, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     torch.manual_seed(1234)
     se = modules.SpeechEncoder(synth.N_AUDIO, 64, SP)
@@ -99,20 +133,94 @@ def cpu_baseline(data, iters=2):
                 v.grad = None
         times.append(time.perf_counter() - t0)
     dt_ = float(np.mean(times[1:]))          # first iteration warms allocators / thread pools
-    return {"value": round(B * T / dt_, 1), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{iters} full training iterations (B={B}, T={T}, example {EXAMPLE_LEN}) of the torch-CPU "
-                      f"oracle, {dt_:.2f} s/iteration"}
+    return B * T / dt_, dt_
 
 
-def decode_rate(de, dev, T=1801):
-    """second half of BASELINE.json's metric: autoregressive decode frames/s (config 5 regime: B=1, no_grad ring
-    path, speech/style already encoded; 30 s of 60-fps frames), measured after the timed training steps."""
+def cpu_port_decode(frames=400):
+    from oracle import nets as onets
+    torch.set_num_threads(1)                 # generate.py:88 runs the decode on one thread
+    torch.manual_seed(1234)
+    de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, SP, ST, H, 2)
+    sd = {k: v.detach() for k, v in de.state_dict().items()}
+    stats = synth.make_stats()
+    c = synth.make_clip(frames, seed=1, stats=stats)
+    t = lambda k: torch.as_tensor(np.asarray(stats[k]), dtype=torch.float32)  # noqa: E731
+    W = {k: torch.as_tensor(v[None]) for k, v in c.items()}
+    speech, style = torch.randn(1, frames, 64) * 0.5, torch.randn(1, frames, 64) * 0.5
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        onets.decoder_rollout(sd, W["Y_root_pos"][:, 0], W["Y_root_rot"][:, 0], W["Y_root_vel"][:, 0], W["Y_root_vrt"][:, 0],
+                              W["Y_lpos"][:, 0], W["Y_ltxy"][:, 0], W["Y_lvel"][:, 0], W["Y_lvrt"][:, 0], W["Y_gaze_pos"],
+                              speech, style, t("anim_input_mean"), t("anim_input_std"), t("anim_output_mean"),
+                              t("anim_output_std"), synth.DT)
+        dt_ = time.perf_counter() - t0
+    return (frames - 1) / dt_
+
+
+def cpu_port_mel(seconds=10):
+    from oracle import mel as omel
+    wav = synth.synth_wav(16000 * seconds, seed=0).astype(np.float32) / 32768.0
+    t0 = time.perf_counter()
+    omel.preprocess_audio(wav, 60 * seconds)
+    return 60 * seconds / (time.perf_counter() - t0)
+
+
+def cpu_baselines(data):
+    """`cpu_baseline` (train), plus decode / mel legs.  kind = "reference": the unmodified reference timed here
+    through oracle/ref_timing.py (only where /root/reference exists -- the build container); otherwise kind =
+    "port": the oracle restatement timed on this host's cores, next to the reference's figures recorded on the
+    build box (profiles/r02_cpu_reference.json) and the port/reference ratio measured there."""
+    from oracle import ref_shims
+    rec_file = ROOT / "profiles" / "r02_cpu_reference.json"
+    recorded = json.load(open(rec_file)) if rec_file.exists() else None
+    if ref_shims.available():
+        from oracle import ref_timing
+        r = ref_timing.measure(iters=3, frames=600, train_threads=(None,), legs=("train", "decode", "mel"))
+        tr = next(iter(r["train"].values()))
+        train = {"value": tr["frames_per_s"], "unit": "frames/s", "cores": tr["threads"], "kind": "reference",
+                 "sample": f"{tr['iterations_timed']} steady iterations of the unmodified reference train() "
+                           f"(ZEGGS/train.py:29), B={BATCH} x {WINDOW}, {np.mean(tr['s_per_iteration']):.2f} s/iteration",
+                 "cpu": r["cpu"]}
+        dec = {"value": r["decode"]["threads_1"]["frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "reference",
+               "sample": "reference Decoder.forward, B=1, no_grad, 600 frames"}
+        mel = {"value": r["mel"]["anim_frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "reference",
+               "sample": "reference preprocess_audio on 10 s of 16 kHz audio"}
+        return train, dec, mel
+    threads = min(physical_cores(), 16)
+    fps, dt_ = cpu_port_train(data, threads)
+    train = {"value": round(fps, 1), "unit": "frames/s", "cores": threads, "kind": "port",
+             "sample": f"2 full training iterations (B={BATCH}, T={WINDOW}, example {EXAMPLE_LEN}) of the torch-CPU "
+                       f"oracle, {dt_:.2f} s/iteration"}
+    dec = {"value": round(cpu_port_decode(), 1), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "oracle decoder rollout, B=1, no_grad, 400 frames, 1 thread"}
+    mel = {"value": round(cpu_port_mel(), 1), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "oracle preprocess_audio on 10 s of 16 kHz audio"}
+    if recorded:
+        rt = recorded["train"]
+        train["reference_recorded"] = {"where": "build container, " + recorded["cpu"]["model"],
+                                       **{k: {"threads": v["threads"], "frames_per_s": v["frames_per_s"]} for k, v in rt.items()},
+                                       "port_on_same_box": recorded.get("port_on_build_box", {}).get("train")}
+        dec["reference_recorded"] = {k: v["frames_per_s"] for k, v in recorded["decode"].items()}
+        dec["reference_recorded"]["port_on_same_box"] = recorded.get("port_on_build_box", {}).get("decode")
+        mel["reference_recorded"] = {"anim_frames_per_s": recorded["mel"]["anim_frames_per_s"],
+                                     "port_on_same_box": recorded.get("port_on_build_box", {}).get("mel")}
+    return train, dec, mel
+
+
+# ----------------------------------------------------------------------------- extra configs (N = 1)
+def decode_args(de, dev, T):
     st = {k: torch.as_tensor(v, dtype=torch.float32, device=dev) for k, v in synth.make_stats().items() if k.startswith("anim")}
     g = torch.Generator(device="cpu").manual_seed(5)
     r = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
-    args = (de.eval(), r(1, synth.POSE_OUT), torch.zeros(1, 3, device=dev), torch.tensor([[1.0, 0, 0, 0]], device=dev),
+    return (de.eval(), r(1, synth.POSE_OUT), torch.zeros(1, 3, device=dev), torch.tensor([[1.0, 0, 0, 0]], device=dev),
             r(1, T, 3) * 10, r(1, T, SP) * 0.3, r(1, T, ST) * 0.3, st["anim_input_mean"], st["anim_input_std"],
             st["anim_output_mean"], st["anim_output_std"], synth.DT)
+
+
+def decode_rate(de, dev, T=1801):
+    """second half of BASELINE.json's metric: autoregressive decode frames/s (B=1, no_grad ring path, speech/style
+    already encoded; 30 s of 60-fps frames), with its own roofline entry (75.7 MB of weights per frame)."""
+    args = decode_args(de, dev, T)
     with torch.no_grad():
         ops.decoder_core(*args)
         torch.cuda.synchronize()
@@ -120,9 +228,106 @@ def decode_rate(de, dev, T=1801):
         ops.decoder_core(*args)
         torch.cuda.synchronize()
         dt_ = time.perf_counter() - t0
+        sweep = sweep_ms(0) * 1e-3 / (T - 1)
     de.train()
+    ach = step_bytes(1) / sweep / 1e9
     return {"value": round((T - 1) / dt_, 1), "unit": "frames/s", "us_per_frame": round(dt_ * 1e6 / (T - 1), 2),
-            "config": f"B=1 autoregressive rollout of {T - 1} frames, no_grad ring path (GEMV stage kernels)"}
+            "config": f"B=1 autoregressive rollout of {T - 1} frames, no_grad ring path",
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "us_per_step": round(sweep * 1e6, 2),
+                         "algorithmic_bytes_per_step": step_bytes(1)}}
+
+
+def decode_30min(se, de, dev, minutes=30.0, reps=3):
+    """BASELINE.json configs[4] shape: 30 min of 16 kHz audio -> device mel front-end -> speech encoder -> B=1
+    autoregressive decode of 108 000 frames (random-init nets, synthetic audio); decode repeated `reps` times."""
+    from zeggs import audio
+    n = int(minutes * 60 * 16000)
+    wav = (0.1 * np.random.default_rng(0).standard_normal(n)).astype(np.float32)
+    stats = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32, device=dev) for k, v in synth.make_stats().items()}
+    T = audio.n_anim_frames(n)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0
+
+    se.eval(), de.eval()
+    with torch.no_grad():
+        audio.mel_features(wav[:16000], 60)                                    # warm-up
+        feats, t_mel = timed(lambda: audio.mel_features(wav, T))
+        x = feats[None].contiguous()
+        ops.normalize_rows_(x, stats["audio_input_mean"], float(stats["audio_input_std"]))
+        se(x[:, :512].contiguous())                                           # warm-up
+        sp, t_se = timed(lambda: se(x))
+        args = decode_args(de, dev, T)
+        args = args[:5] + (sp,) + args[6:]
+        ts = []
+        for _ in range(reps):
+            out, t_dec = timed(lambda: ops.decoder_core(*args))
+            ts.append(t_dec)
+        finite = bool(torch.isfinite(out[0]).all() and torch.isfinite(feats).all())
+    se.train(), de.train()
+    t_dec = min(ts)
+    return {"frames": T, "mel_ms": round(t_mel * 1e3, 2), "speech_encoder_ms": round(t_se * 1e3, 2),
+            "decode_s": round(t_dec, 3), "decode_s_all": [round(v, 3) for v in ts],
+            "value": round((T - 1) / t_dec, 1), "unit": "frames/s",
+            "x_realtime": round(minutes * 60.0 / (t_mel + t_se + t_dec), 1), "finite": finite,
+            "frac_hbm": round(step_bytes(1) * (T - 1) / t_dec / 1e9 / HBM_PEAK_GBS, 4),
+            "config": f"{minutes:g} min WAV -> mel -> speech encoder -> B=1 decode of {T - 1} frames, 1 GPU"}
+
+
+def v2_label_b64(ds, dev, steps=10, warmup=3, batch=64, nlabels=9):
+    """BASELINE.json configs[3]: configs_v2.json = label conditioning (one-hot over 9 labels, no style encoder),
+    batch 64 x 256-frame windows: the MFMA-bound regime of the stage kernels (B >= 40)."""
+    se, de, _ = build_nets(dev, style=nlabels, with_style_encoder=False)
+    eng = engine.TrainEngine(se, de, None, ds, synth.PARENTS, synth.DT, style_encoding_type="label")
+    perm = np.random.default_rng(42).permutation(len(ds))
+    table = torch.as_tensor(np.eye(nlabels, dtype=np.float32)[np.arange(len(ds)) % nlabels]).to(dev)
+
+    def step(it):
+        idx = engine.shard_indices(perm, it % (len(ds) // batch), batch, 1, 0)
+        return eng.step(idx, None, labels=ops.gather_rows(table, torch.as_tensor(idx.astype(np.int64)).to(dev)))
+
+    for it in range(warmup):
+        step(it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(warmup, warmup + steps):
+        step(it)
+    torch.cuda.synchronize()
+    dt_ = (time.perf_counter() - t0) / steps
+    fwd, bwd = sweep_ms(0) * 1e-3 / (WINDOW - 1), sweep_ms(1) * 1e-3 / (WINDOW - 1)
+    fl = step_flops(batch, nlabels)
+    return {"value": round(batch * WINDOW / dt_, 1), "unit": "frames/s", "ms_per_step": round(dt_ * 1e3, 3),
+            "batch": batch, "window": WINDOW, "steps": steps,
+            "roofline": {"bound": "mfma", "kernel": "decoder forward step (3 launches of stage_k<4,...>, fp32 MFMA)",
+                         "achieved": round(fl / fwd / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(fl / fwd / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "us_per_step": round(fwd * 1e6, 2),
+                         "backward_us_per_step": round(bwd * 1e6, 2),
+                         "backward_frac": round(fl / bwd / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                         "iteration_tflops": round(3 * (WINDOW - 1) * fl / dt_ / 1e12, 2), "traffic": None},
+            "config": "configs_v2.json shape: label conditioning (9 one-hot labels), no style encoder, batch 64 x 256"}
+
+
+# ----------------------------------------------------------------------------- launcher
+def launch_command(argv, gpus, port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(launch_command(sys.argv[1:], a.gpus, port), env=env)
 
 
 def main():
@@ -131,30 +336,53 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip decode / decode_30min / v2_label_b64 (N = 1 only)")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="only rendezvous (gloo on CPU when no GPU is visible) and print the rank census")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    have_gpu = torch.cuda.is_available()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world,
-                                             device_id=torch.device("cuda", local))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+        if have_gpu:
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world,
+                                                 device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus {a.gpus}` (self-launching) "
+                         f"or torch.distributed.run with --nproc-per-node {a.gpus}")
+    census = None
+    if world > 1:
+        me = {"rank": rank, "local_rank": local,
+              "device": str(torch.cuda.get_device_properties(local).uuid) if have_gpu else "cpu"}
+        census = [None] * world
+        torch.distributed.all_gather_object(census, me)
+    if a.launch_selftest:
+        if rank == 0:
+            print(json.dumps({"launch_selftest": True, "world_size": world, "ranks": census}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    if have_gpu and local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPUs are visible")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    ops.set_option("timing", 1)
     data = build_dataset()
     ds = engine.DeviceDataset(data, WINDOW, dev)
     se, de, st = build_nets(dev)
     eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, world_size=world, rank=rank)
-    ops.manual_seed(1000 + rank)
-    perm_rng = np.random.default_rng(42)                    # same permutation on every rank
-    perm = perm_rng.permutation(len(ds))
+    ops.manual_seed(1000 + rank)                            # per-rank noise streams (dropout masks, VAE eps)
+    perm = np.random.default_rng(42).permutation(len(ds))   # same permutation on every rank
     gb = BATCH * world
 
     def indices(it):
         return engine.shard_indices(perm, it % (len(ds) // gb), BATCH, world, rank)
-
-    torch.manual_seed(77 + rank)
 
     def sync():
         if world > 1:
@@ -164,17 +392,29 @@ def main():
     for it in range(a.warmup):
         eng.step(indices(it), EXAMPLE_LEN)
     sync()
-    eng.decoder_fwd_events = []          # HIP events (torch's current stream = the stream the kernels run on)
+    eng.allreduce_events = [] if world > 1 else None
     sync()
     t0 = time.perf_counter()
     for it in range(a.warmup, a.warmup + a.steps):
         eng.step(indices(it), EXAMPLE_LEN)
     sync()
-    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    mine = time.perf_counter() - t0
+    fwd_in, bwd_in = sweep_ms(0), sweep_ms(1)               # the LAST timed iteration's stage sweeps (HIP events)
+    el = torch.tensor([mine], device=dev, dtype=torch.float64)
+    per_rank = None
     if world > 1:
+        allt = [torch.zeros_like(el) for _ in range(world)]
+        torch.distributed.all_gather(allt, el)
+        per_rank = [round(float(t) / a.steps * 1e3, 3) for t in allt]
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el)
-    loss = float(eng.step(indices(a.warmup + a.steps), EXAMPLE_LEN))
+    fw, bw = [fwd_in], [bwd_in]
+    loss = None
+    for k in range(3):                                       # a few more iterations, sweeps read after each one
+        loss = eng.step(indices(a.warmup + a.steps + k), EXAMPLE_LEN)
+        fw.append(sweep_ms(0))
+        bw.append(sweep_ms(1))
+    loss = float(loss)
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         out = {
@@ -187,25 +427,50 @@ def main():
                        "global_batch": gb, "window": WINDOW, "parallelism": f"dp{world}"},
             "final_loss": round(loss, 4),
         }
-        ev = eng.decoder_fwd_events[:a.steps]
-        probe = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e-3 / (WINDOW - 1)   # s per decoder step
-        ach = step_bytes(BATCH) / probe / 1e9
-        pmc_file = ROOT / "profiles" / "r01_decoder_step_pmc.json"
-        traffic = json.load(open(pmc_file))["traffic_bytes_per_step"] if pmc_file.exists() else None
-        out["roofline"] = {"bound": "hbm", "kernel": "decoder forward step = 3 launches of stage_k (GRU l0, GRU l1, "
-                                                     "layer2+pose integration+next layer0), per-step figures",
-                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "us_per_step": round(probe * 1e6, 2), "algorithmic_bytes_per_step": step_bytes(BATCH),
-                           "note": "HIP events around the 255-step forward rollout inside the timed iterations; "
-                                   "traffic = FETCH_SIZE(x2)+WRITE_SIZE from profiles/r01_decoder_step_pmc.json; at "
-                                   "B=32 the step is also at the fp32 MFMA ridge (1.24 GFLOP/step)"}
-        if world == 1:
+        nst = WINDOW - 1
+        f_us, b_us = float(np.mean(fw)) * 1e3 / nst, float(np.mean(bw)) * 1e3 / nst
+        pmc = None
+        for name in ("r02_decoder_step_pmc.json", "r01_decoder_step_pmc.json"):
+            if (ROOT / "profiles" / name).exists():
+                pmc = json.load(open(ROOT / "profiles" / name))
+                pmc["file"] = "profiles/" + name
+                break
+        ach = step_bytes(BATCH) / (f_us * 1e-6) / 1e9
+        ach_b = step_bytes(BATCH) / (b_us * 1e-6) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "stage_k, decoder forward step = 3 launches (GRU l0, GRU l1, layer2 + pose "
+                                      "integration + next step's layer0), per-step figures at B=32",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": pmc.get("traffic_bytes_per_step") if pmc else None,
+            "us_per_step": round(f_us, 2), "us_per_step_in_timed_region": round(fwd_in * 1e3 / nst, 2),
+            "algorithmic_bytes_per_step": step_bytes(BATCH),
+            "backward": {"kernel": "stage_k, BPTT step = 3 launches (transposed packs)", "achieved": round(ach_b, 1),
+                         "frac": round(ach_b / HBM_PEAK_GBS, 4), "us_per_step": round(b_us, 2),
+                         "us_per_step_in_timed_region": round(bwd_in * 1e3 / nst, 2),
+                         "traffic": pmc.get("traffic_bytes_per_step_backward") if pmc else None},
+            "mfma_frac_at_b32": round(step_flops(BATCH) / (f_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            "note": "HIP events (library hook zeggs_timing_ms, recorded on the stream the kernels run on) around the "
+                    "255-step stage sweeps: the last timed iteration + 3 more; traffic = FETCH_SIZE(x2)+WRITE_SIZE "
+                    f"from {pmc['file'] if pmc else 'n/a'}; at B=32 the step is also at the fp32 MFMA ridge"}
+        if world > 1:
+            ar = [e0.elapsed_time(e1) for e0, e1 in eng.allreduce_events[:a.steps]]
+            out["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "ranks": census}
+            out["per_rank_ms_per_step"] = per_rank
+            out["allreduce_ms"] = round(float(np.mean(ar)), 3) if ar else None
+            out["allreduce_bytes"] = int(eng.flat_g.numel() * 4)
+        out["cpu_baseline"] = None
+        if world == 1 and not a.no_extras:
             out["decode"] = decode_rate(de, dev)
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(data)
-        else:
-            out["cpu_baseline"] = None
+            out["roofline"]["decode_b1"] = out["decode"]["roofline"]
+            out["decode_30min"] = decode_30min(se, de, dev)
+            del eng
+            out["v2_label_b64"] = v2_label_b64(ds, dev)
+        if world == 1 and not a.no_cpu_baseline:
+            train_b, dec_b, mel_b = cpu_baselines(data)
+            out["cpu_baseline"] = train_b
+            if "decode" in out:
+                out["decode"]["cpu_baseline"] = dec_b
+            out["mel_cpu_baseline"] = mel_b
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -28,8 +28,12 @@ extern "C" {
 
 int zeggs_version(void);
 const char* zeggs_last_error(void);
-/* runtime switches: "decoder_fast" 1 (default) = fragment-packed stage kernels, 0 = generic GEMM path */
+/* runtime switches: "decoder_fast" 1 (default) = fragment-packed stage kernels, 0 = generic GEMM path;
+ * "timing" 1 = HIP events on the caller's stream around the decoder's steady-state stage sweeps */
 int zeggs_set_option(const char* name, int value);
+/* elapsed ms of the last recorded stage sweep: which = 0 forward (T-1 steps x 3 launches), 1 backward; blocks on
+ * the end event.  Measurement hook of bench.py (roofline figures); there is no reference counterpart. */
+int zeggs_timing_ms(int which, float* ms);
 
 /* ---------------------------------------------------------------- generic GEMM (tests / tools)
  * C(m,n) = act(alpha * sum_k A(m,k) B(k,n) + beta * C(m,n) + bias[n]), element strides, batched. */

@@ -84,3 +84,39 @@ def test_two_rank_gradient_allreduce_equals_global_batch():
     assert e0 < 1e-4 and e1 < 1e-4, (e0, e1)               # averaged shard grads == global-batch grads
     assert sums0 == sums1                                    # both ranks hold identical reduced gradients
     assert set(idx0).isdisjoint(idx1) and len(idx0) == len(idx1) == 1
+
+
+def test_bench_self_launches_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment re-executes itself under
+    torch.distributed.run on 127.0.0.1 (one rank per GPU; gloo on this GPU-less box) -- VERDICT r1 item 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--launch-selftest"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["world_size"] == 2 and [x["rank"] for x in out["ranks"]] == [0, 1]
+    sys.path.insert(0, str(root))
+    import bench
+    cmd = bench.launch_command(["--gpus", "8", "--steps", "20"], 8, 29511)
+    assert "--nproc-per-node=8" in cmd and cmd[-4:] == ["--gpus", "8", "--steps", "20"] and "127.0.0.1" in cmd
+
+
+def test_ranks_draw_different_noise_streams():
+    """train() re-seeds the library's noise stream with seed + 7919 * rank after the (common-seed) weight init, so two
+    data-parallel ranks draw different dropout masks / VAE eps."""
+    from zeggs import ops
+    seeds = []
+    for rank in (0, 1):
+        ops.manual_seed(1234 + 7919 * rank)
+        seeds.append([ops.next_seed() for _ in range(4)])
+    assert not set(seeds[0]) & set(seeds[1])
+    ops.manual_seed(1234)
+    again = [ops.next_seed() for _ in range(4)]
+    assert again == seeds[0]                     # and the stream is reproducible per rank

@@ -122,20 +122,27 @@ def _engine_iteration(gd, v):
 
 
 def _check_engine_iteration(gd, v):
+    """Gradients: 3e-4 of max|g| against the (reference-pinned) oracle run in FLOAT64 on the same iteration, and 1e-3
+    against the reference's own fp32 gradients, which themselves deviate from fp64 by 1-4e-4 of max|g| after BPTT
+    (oracle/make_golden_full.py:add_fp64_gradient_samples prints that floor)."""
     from oracle import radam as oradam
     eng, loss, w_before = _engine_iteration(gd, v)
     np.testing.assert_allclose(float(loss), gd["loss"][0], rtol=2e-5)
+    np.testing.assert_allclose(float(loss), gd["loss_fp64"][0], rtol=2e-5)
     np.testing.assert_allclose(eng.last_terms[:18].cpu().numpy(), gd["terms"][0], rtol=2e-4, atol=1e-6)
-    off, worst = 0, 0.0
+    off, worst64, worst32, floor = 0, 0.0, 0.0, 0.0
     for i, p in enumerate(eng.params):
         idx = helpers.sample_idx(p.numel())
         it = torch.as_tensor(idx, device=DEV)
         got = p.grad.flatten()[it].cpu().numpy()
-        ref = gd["grad_samples"][off:off + len(idx)]
-        scale = max(1e-7, float(np.abs(ref).max()))
-        e = float(np.abs(got - ref).max()) / scale
-        worst = max(worst, e)
-        assert e < 5e-4, f"param {i}: gradient off by {e:.2e} of max|g|"
+        ref32 = gd["grad_samples"][off:off + len(idx)]
+        ref64 = gd["grad_samples_fp64"][off:off + len(idx)]
+        scale = max(1e-7, float(np.abs(ref64).max()))
+        e64, e32 = float(np.abs(got - ref64).max()) / scale, float(np.abs(got - ref32).max()) / scale
+        worst64, worst32 = max(worst64, e64), max(worst32, e32)
+        floor = max(floor, float(np.abs(ref32 - ref64).max()) / scale)
+        assert e64 < 3e-4, f"param {i}: gradient off by {e64:.2e} of max|g| (vs fp64)"
+        assert e32 < 1e-3, f"param {i}: gradient off by {e32:.2e} of max|g| (vs the fp32 reference)"
         fp = helpers.fingerprint(p.grad)
         np.testing.assert_allclose(fp[1], gd["grad_fp"][i][1], rtol=2e-3, err_msg=f"param {i} |g| sum")
         # fused RAdam over the flat buffer: weights after the step vs the reference's
@@ -147,8 +154,9 @@ def _check_engine_iteration(gd, v):
         np.testing.assert_allclose(p.detach().flatten()[it].cpu().numpy(), pn, atol=2e-7)
         off += len(idx)
     assert off == len(gd["grad_samples"])
-    print(f"\nfull iteration vs reference: loss {float(loss):.6f} / {gd['loss'][0]:.6f}, worst gradient sample "
-          f"{worst:.2e} of max|g|")
+    print(f"\nfull iteration: loss {float(loss):.7f} (reference fp32 {gd['loss'][0]:.7f}, fp64 {gd['loss_fp64'][0]:.7f}); "
+          f"worst gradient sample {worst64:.2e} of max|g| vs fp64, {worst32:.2e} vs the fp32 reference "
+          f"(reference's own fp32-vs-fp64 floor {floor:.2e})")
 
 
 def test_train_iteration_b32_t256_ex384_vs_reference(golden_dir):
@@ -201,7 +209,7 @@ def test_style_encoder_embedding_wider_than_hidden():
     B, L = 2, 9
     x, eps = torch.randn(B, L, 40), torch.randn(B, 32)
     w64 = {k: v.detach().double().requires_grad_(True) for k, v in st.state_dict().items()}
-    z64, mu64, lv64 = onets.style_encoder(w64, x.double(), eps.double(), 1.0)
+    z64, mu64, lv64 = onets.style_encoder(w64, x.double(), eps.double(), 1.0, S=32)
     (z64.sum() + (mu64 * mu64).sum() + lv64.sum()).backward()
     st_g = st.to(DEV).eval()
     zg, mug, lvg = st_g(g(x), 1.0, eps=g(eps))

@@ -27,6 +27,27 @@
 
 int g_stage_variant = 0;
 
+// zeggs_set_option("timing", 1): HIP events on the caller's stream around the steady-state stage sweeps (the 3-launch
+// steps only, not the per-call packs), read back by zeggs_timing_ms -- bench.py's roofline figures
+int g_timing = 0;
+static hipEvent_t g_tev[4];
+static bool g_tev_ok = false;
+static void timing_mark(int i, hipStream_t s) {
+  if (!g_timing) return;
+  if (!g_tev_ok) {
+    for (int k = 0; k < 4; ++k) hipEventCreate(&g_tev[k]);
+    g_tev_ok = true;
+  }
+  hipEventRecord(g_tev[i], s);
+}
+extern "C" int zeggs_timing_ms(int which, float* ms) {
+  ZCHECK(which == 0 || which == 1, "timing: which = 0 (forward sweep) or 1 (backward sweep)");
+  ZCHECK(g_tev_ok, "timing: no sweep was recorded (zeggs_set_option(\"timing\", 1) first)");
+  ZCHECK(hipEventSynchronize(g_tev[2 * which + 1]) == hipSuccess, "timing: event not recorded");
+  ZCHECK(hipEventElapsedTime(ms, g_tev[2 * which], g_tev[2 * which + 1]) == hipSuccess, "timing: events incomplete");
+  return 0;
+}
+
 namespace {
 
 // zeggs_set_option("stage_variant", bits) -- measurement switches, all off in production:
@@ -871,6 +892,7 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   // 3 launches per step: layer2 of step t and layer0 of step t+1 run in ONE launch (variant 4096: 4 launches)
   const bool merged = !(g_stage_variant & 4096);
   if (merged && T > 2) ZTRY(dec_fast_pack_merged(d, P, st, w, s));
+  timing_mark(0, s);
   for (int t = 1; t < T; ++t) {
     const int c = t & 1, p = (t - 1) & 1;
     const long o = (long)t * sH;
@@ -932,6 +954,7 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     }
     ZTRY(launch_stage(a, s));
   }
+  timing_mark(1, s);
   return 0;
 }
 
@@ -952,6 +975,7 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   // 3 launches per step: the dx stage of step t also evaluates the layer-1 gate gradients of step t-1 (variant 8192:
   // separate launches).  The root-state carry is double-buffered: slot (t & 1) is read, slot ((t - 1) & 1) written.
   const bool merged = !(g_stage_variant & 8192) && T > 2;
+  if (t_hi == T - 1) timing_mark(2, s);
   for (int t = t_hi; t >= t_lo; --t) {
     const long o = (long)t * sH;
     StageArgs a = base_args(d, st, w);
@@ -1009,5 +1033,6 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     }
     ZTRY(launch_stage(a, s));
   }
+  if (t_lo <= 1) timing_mark(3, s);
   return 0;
 }

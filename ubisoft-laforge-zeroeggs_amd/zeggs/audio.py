@@ -85,13 +85,17 @@ def stft_frame_count(n_samples, n_fft=800, hop=200):
 
 # ----------------------------------------------------------------------------- BS.1770 loudness (host, O(n))
 def integrated_loudness(x, rate):
-    """ITU-R BS.1770-4 integrated loudness (mono/multi-channel), K-weighting + 400 ms / 75 % overlap gating.
-    Written from the recommendation (the reference calls pyloudnorm==0.1.0, not installed here): parity with the
-    reference for this stage is UNPINNED -- see DESIGN.md."""
+    """ITU-R BS.1770-4 integrated loudness (mono/multi-channel) as pyloudnorm==0.1.0 computes it (the reference's
+    dependency, ZEGGS/data_pipeline.py:34-39): K-weighting biquads re-derived for `rate`, 400 ms blocks with 75 %
+    overlap (block bounds = truncated floating-point products, kept literally), absolute (-70) and relative (-10 LU)
+    gates.  Checked against the restatement of pyloudnorm's published source in oracle/loudness.py; parity with
+    pyloudnorm itself is UNPINNED (package absent, no golden vectors) -- see DESIGN.md."""
     from scipy import signal
     x = np.asarray(x, dtype=np.float64)
     if x.ndim == 1:
         x = x[:, None]
+    if x.shape[0] < 0.4 * rate:
+        raise ValueError("Audio must have length greater than the block size.")       # pyloudnorm.util.valid_audio
 
     def biquad(kind, G, Q, fc):
         A = 10 ** (G / 40.0)
@@ -137,6 +141,9 @@ def integrated_loudness(x, rate):
 
 def normalize_loudness(x, rate, target=-20.0):
     lufs = integrated_loudness(x, rate)
+    if not np.isfinite(lufs):
+        # pyloudnorm would return gain = inf and NaN samples for digital silence; refuse instead of emitting NaN features
+        raise ValueError(f"integrated loudness is not finite ({lufs}): the signal is silent under the -70 LUFS gate")
     return np.asarray(x) * (10.0 ** ((target - lufs) / 20.0))
 
 

@@ -144,6 +144,7 @@ class TrainEngine:
         self.last_terms = None
         self.decoder_fwd_events = None      # bench.py: list of (start, end) HIP events around the forward rollout
         self.decoder_bwd_events = None      # bench.py: same around loss.backward() (BPTT + encoder backward)
+        self.allreduce_events = None        # bench.py: (start, end) HIP events around the gradient all-reduce
         self._one = torch.ones((), device=dev, dtype=torch.float32)     # upstream gradient of loss.backward()
 
     def step(self, idx, example_len, eps=None, labels=None):
@@ -184,7 +185,13 @@ class TrainEngine:
                 self.decoder_bwd_events.append((e2, e3))
         finally:
             ops.direct_param_grads(False)
+        if self.allreduce_events is not None:
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
         allreduce_mean_(self.flat_g, self.world, self.pg, prescaled=True)
+        if self.allreduce_events is not None:
+            a1.record()
+            self.allreduce_events.append((a0, a1))
         self.opt.step()
         self.iteration += 1
         self.last_terms = terms
