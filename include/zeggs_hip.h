@@ -167,6 +167,14 @@ int zeggs_decoder_fwd_state(const ZeggsDecDims*, const ZeggsDecParams*, const Ze
                             float* h_out, void* ws, size_t ws_bytes, void* stream);
 /* dpose [B,T,PO], drpos [B,T,3], drrot [B,T,4] (frame 0 ignored) -> parameter grads, dspeech [B,T,SP],
  * dstyle [B,T,ST] */
+/* "chain" option (zeggs_set_option("chain", 1), inference rollouts with B <= 2): consecutive stage launches alternate
+ * between the caller's stream and a library-owned second stream and hand over through device-side arrival counters, so
+ * each launch fetches its weights while its predecessor still runs.  Every device-side wait is bounded; this returns the
+ * error word of the last rollout on `ws` (0 = all hand-offs completed).  Synchronises the device. */
+int zeggs_decoder_chain_errors(const ZeggsDecDims*, int training, void* ws, size_t ws_bytes, int* out);
+/* measurement builds (-DZEGGS_CHTIME) only: 100 MHz wall-clock stamps of the phases of the last 16 chained launches */
+int zeggs_decoder_chain_stamps(const ZeggsDecDims*, int training, void* ws, size_t ws_bytes,
+                               unsigned long long* out /* host [16][2][16] */);
 int zeggs_decoder_bwd(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDecStats*, const float* gaze,
                       const float* pose, const float* rpos, const float* rrot, const float* dpose,
                       const float* drpos, const float* drrot, const ZeggsDecGrads*, float* dspeech,

@@ -122,9 +122,10 @@ def _engine_iteration(gd, v):
 
 
 def _check_engine_iteration(gd, v):
-    """Gradients: 3e-4 of max|g| against the (reference-pinned) oracle run in FLOAT64 on the same iteration, and 1e-3
-    against the reference's own fp32 gradients, which themselves deviate from fp64 by 1-4e-4 of max|g| after BPTT
-    (oracle/make_golden_full.py:add_fp64_gradient_samples prints that floor)."""
+    """Gradients are compared with BOTH the reference's own fp32 gradients and the (reference-pinned) oracle run in
+    FLOAT64 on the same iteration.  Those two differ from each other by 1-4e-4 of max|g| after 255 BPTT steps (the
+    floor printed below), so per tensor: within 3e-4 of max|g| of at least one of them, and within 3e-4 + that
+    tensor's own fp32-vs-fp64 floor of the other."""
     from oracle import radam as oradam
     eng, loss, w_before = _engine_iteration(gd, v)
     np.testing.assert_allclose(float(loss), gd["loss"][0], rtol=2e-5)
@@ -140,9 +141,10 @@ def _check_engine_iteration(gd, v):
         scale = max(1e-7, float(np.abs(ref64).max()))
         e64, e32 = float(np.abs(got - ref64).max()) / scale, float(np.abs(got - ref32).max()) / scale
         worst64, worst32 = max(worst64, e64), max(worst32, e32)
-        floor = max(floor, float(np.abs(ref32 - ref64).max()) / scale)
-        assert e64 < 3e-4, f"param {i}: gradient off by {e64:.2e} of max|g| (vs fp64)"
-        assert e32 < 1e-3, f"param {i}: gradient off by {e32:.2e} of max|g| (vs the fp32 reference)"
+        fl = float(np.abs(ref32 - ref64).max()) / scale
+        floor = max(floor, fl)
+        assert min(e32, e64) < 3e-4, f"param {i}: gradient off by {e32:.2e} (fp32 reference) / {e64:.2e} (fp64) of max|g|"
+        assert max(e32, e64) < 3e-4 + fl + 1e-6, f"param {i}: {e32:.2e} / {e64:.2e} of max|g|, reference floor {fl:.2e}"
         fp = helpers.fingerprint(p.grad)
         np.testing.assert_allclose(fp[1], gd["grad_fp"][i][1], rtol=2e-3, err_msg=f"param {i} |g| sum")
         # fused RAdam over the flat buffer: weights after the step vs the reference's

@@ -475,6 +475,40 @@ def test_decoder_gemv_decode_path_matches_mfma_path(B):
         assert float((a - b).abs().max()) < 5e-5
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_chained_decode_launches_match_plain_launches(B):
+    """option "chain": consecutive stage launches alternate between two streams and hand over through device-side
+    arrival counters (every launch fetches its weights while its predecessor runs).  Same arithmetic per stage up to the
+    summation order of the dot products; every bounded wait must have been satisfied."""
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).eval()
+    T = 400
+    stats = synth.make_stats()
+    s = {k: g(v) for k, v in helpers.stats_tensors().items()}
+    clips = [synth.make_clip(T, seed=600 + b, stats=stats) for b in range(B)]
+    tt = lambda k: g(torch.as_tensor(np.stack([c[k] for c in clips])))  # noqa: E731
+    pose0 = _pack_pose(tt("Y_root_vel"), tt("Y_root_vrt"), tt("Y_lpos"), tt("Y_ltxy"), tt("Y_lvel"), tt("Y_lvrt"))[:, 0]
+    torch.manual_seed(9)
+    speech, style = torch.randn(B, T, 64, device=DEV) * 0.5, torch.randn(B, T, 64, device=DEV) * 0.5
+    outs = []
+    try:
+        for v in (0, 1, 1):
+            ops.set_option("chain", v)
+            with torch.no_grad():
+                outs.append(ops.decoder_core(de, pose0.contiguous(), tt("Y_root_pos")[:, 0].contiguous(),
+                                             tt("Y_root_rot")[:, 0].contiguous(), tt("Y_gaze_pos"), speech, style,
+                                             s["in_mean"], s["in_std"], s["out_mean"], s["out_std"], synth.DT))
+            torch.cuda.synchronize()
+            assert ops.last_decoder_chain_errors() == 0
+    finally:
+        ops.set_option("chain", 0)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) < 5e-5
+    for a, b in zip(outs[1], outs[2]):
+        assert torch.equal(a, b)                   # deterministic: no race decides a value
+
+
 # ----------------------------------------------------------------------------- edge cases
 def _oracle_vs_hip_rollout(B, T, style_dim, tol=1e-4):
     torch.manual_seed(1234)

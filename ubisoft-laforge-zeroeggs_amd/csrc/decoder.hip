@@ -20,11 +20,13 @@ static int g_bwd_chunks = 1;   // BPTT sweep chunks whose weight-gradient GEMMs 
 extern int g_stage_variant;
 extern int g_gemm_wg_target;
 extern int g_timing;
+extern int g_chain;
 extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "decoder_fast") == 0) { g_decoder_fast = value; return 0; }
   if (strcmp(name, "stage_variant") == 0) { g_stage_variant = value; return 0; }
   if (strcmp(name, "gemm_wg_target") == 0) { g_gemm_wg_target = value; return 0; }
   if (strcmp(name, "timing") == 0) { g_timing = value; return 0; }
+  if (strcmp(name, "chain") == 0) { g_chain = value; return 0; }
   if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
   zeggs_set_error("unknown option %s", name);
   return -1;
@@ -516,6 +518,28 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
     ZLAUNCH_CHECK("dec_step");
   }
   return save_state();
+}
+
+// error word of the chained (run-ahead) stage launches of the last rollout that used `ws`: 0 = every hand-off wait was
+// satisfied; non-zero = a bounded spin gave up (the results of that rollout are invalid).  Synchronises the device.
+extern "C" int zeggs_decoder_chain_errors(const ZeggsDecDims* dp, int training, void* ws, size_t ws_bytes, int* out) {
+  Arena a(ws, ws_bytes);
+  DecWs w = carve_dec(*dp, training, a);
+  ZCHECK(a.ok() && w.chain, "chain_errors: workspace too small or no fast path for these dims");
+  unsigned v = 0;
+  ZCHECK(hipMemcpy(&v, w.chain + 4 * 8 * 32, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess, "chain_errors: copy failed");
+  *out = (int)v;
+  return 0;
+}
+// measurement builds (-DZEGGS_CHTIME): the phase stamps of the last 16 chained launches, 16 launches x {first, last
+// workgroup} x 16 stamps (100 MHz wall clock)
+extern "C" int zeggs_decoder_chain_stamps(const ZeggsDecDims* dp, int training, void* ws, size_t ws_bytes,
+                                          unsigned long long* out /* [16][2][16] host */) {
+  Arena a(ws, ws_bytes);
+  DecWs w = carve_dec(*dp, training, a);
+  ZCHECK(a.ok() && w.chain, "chain_stamps: workspace too small or no fast path for these dims");
+  ZCHECK(hipMemcpy(out, w.chain + 4 * 8 * 32 + 32, 16 * 2 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess, "copy failed");
+  return 0;
 }
 
 extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,

@@ -26,6 +26,7 @@
 #include "kernels.h"
 
 int g_stage_variant = 0;
+int g_chain = 0;   // zeggs_set_option("chain", 1): chained (run-ahead) stage launches, see struct Chain
 
 // zeggs_set_option("timing", 1): HIP events on the caller's stream around the steady-state stage sweeps (the 3-launch
 // steps only, not the per-call packs), read back by zeggs_timing_ms -- bench.py's roofline figures
@@ -70,6 +71,10 @@ struct Seg {
 struct Grp {
   Seg seg[3];
   int nseg, tiles, epi;
+  // chained GEMV: the per-tile contiguous pack that holds all segments' blocks in order (tkbcat blocks per tile); blocks
+  // from index kacc on accumulate into set 1
+  const float* wcat;
+  int tkbcat, kacc;
   const float *p0, *p1, *p2, *p3, *p4;
   float *o0, *o1, *o2, *o3, *o4, *o5;
 };
@@ -90,7 +95,65 @@ struct StageArgs {
   int gemv;                                // 1: tiny-batch decode, VALU dot products over canonical activations
   // speech/style columns of x_{t+1}, staged by the GRU layer-1 launch (all null: nothing to stage)
   float *cf_gin, *cf_x, *cf_cond;
+  // chained (run-ahead) launches: this launch was enqueued BEFORE its predecessor finished (alternating streams).  It
+  // pre-loads its weights, then waits until the predecessor's arrival counters (8 shards, one 128-byte line each)
+  // sum to wait_count, acquires, and only then touches activations; at its end every workgroup arrives on its own counters.
+  unsigned *ch_wait, *ch_arrive, *ch_err;
+  unsigned wait_count;
+  int ch_k;     // index of this launch in the chain (timestamps of the -DZEGGS_CHTIME build)
 };
+
+// -DZEGGS_CHTIME: wall-clock (100 MHz) stamps of the phases of a chained launch, first and last workgroup, for the last 16
+// launches of a rollout (tools/chain_time.py reads them from the workspace) -- measurement builds only
+#ifdef ZEGGS_CHTIME
+#define CHT(i)                                                                                                   \
+  do {                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    if (a.ch_err && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                        \
+      ((unsigned long long*)(a.ch_err + 32))[(((a.ch_k & 15) * 2 + (blockIdx.x != 0)) * 16) + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define CHT(i)
+#endif
+
+// ---- hand-off between chained launches (cdna_hip_programming.md, Guideline 16, counter form): payload stores are
+// write-through (agent-scope relaxed atomic stores lower to `global_store ... sc1`), every storing wave drains, ONE lane
+// per workgroup arrives; the consumer polls relaxed from 8 lanes (one shard each), ONE acquire, then plain loads.
+enum { CH_SHARDS = 8, CH_STRIDE = 32, CH_RING = 4, CH_SPIN_MAX = 1 << 22, CH_GPRE = 26, CH_GREG = 20 };
+typedef __attribute__((address_space(1))) unsigned gu32;
+__device__ __forceinline__ void st_pub(float* p, float v) {       // published (consumed by the NEXT chained launch)
+  __hip_atomic_store((gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int CH> __device__ __forceinline__ void st_out(float* p, float v) {
+  if constexpr (CH) st_pub(p, v); else *p = v;
+}
+__device__ __forceinline__ void chain_wait(const unsigned* flags, unsigned expect, unsigned* err) {
+  // called by wave 0 only (all 64 lanes); lanes 0..7 poll one shard each
+  const int lane = threadIdx.x & 63;
+  unsigned spins = 0;
+  for (;;) {
+    unsigned v = lane < CH_SHARDS ? __hip_atomic_load((gu32*)(flags + lane * CH_STRIDE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = __builtin_amdgcn_readfirstlane(v);
+    if (v >= expect) break;
+    if (++spins > CH_SPIN_MAX) {      // bounded: never hang the GPU; the host reads the error word
+      if (lane == 0) atomicOr(err, 1u);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void chain_arrive(unsigned* flags) {
+  // every storing wave drains its write-through stores, then ONE lane of the workgroup arrives
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_add((gu32*)(flags + (blockIdx.x & (CH_SHARDS - 1)) * CH_STRIDE), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // column permutation of the dX stage: tile 0 holds root_vel/vrt (0..5) AND the gaze columns (PO..PO+2)
 __host__ __device__ inline int perm_dx(int q, int PO) {
@@ -229,12 +292,20 @@ __device__ __forceinline__ void root_step(const ZeggsDecDims& d, const ZeggsDecS
   }
 }
 
-template <int NB, int FAM, int WAVES, int BV = 0>   // FAM 0: forward epilogues, 1: backward; BV > 0: GEMV mode for BV rows
-__global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
+// FAM 0: forward epilogues, 1: backward; BV > 0: GEMV mode for BV rows; CH: chained (run-ahead) launch
+template <int NB, int FAM, int WAVES, int BV = 0, int CH = 0>
+__global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageArgs a) {
   constexpr int NTHR = WAVES * 64;
   static_assert(16 * 16 * NB <= NTHR, "one epilogue item per thread");
-  __shared__ f4 red[WAVES][2][NB][64];
+  static_assert(!CH || (FAM == 0 && WAVES == 8), "chained launches: forward stages with 8 waves");
+  // chained GEMV: a wave parks ALL its weight blocks on chip before the hand-off -- GREG in registers, the rest in LDS --
+  // and stages its activation slice through LDS; the MFMA reduction scratch shrinks to what the GEMV reduce needs
+  constexpr bool CG = CH && BV > 0;
+  constexpr int GPRE = CH_GPRE, GREG = CH_GREG;
+  __shared__ f4 red[CG ? 1 : WAVES][2][NB][64];
   __shared__ f4 fin[2][NB][64];
+  __shared__ f4 xs[CG ? WAVES * BV * GPRE * 4 : 1];            // wave-private activation slices
+  __shared__ f4 wl[CG ? WAVES * (GPRE - GREG) * 64 : 1];       // wave-private weight blocks GREG .. GPRE-1
   // NB (template) = batch blocks of 16 rows handled by THIS workgroup; a.NB = batch blocks of the fragment layout.
   // With nsplit = a.NB / NB > 1 a tile is shared by nsplit workgroups (one per batch part): more workgroups for
   // the stages with few tiles; the parts of a tile are 8 ids apart so they land on the same XCD / L2.
@@ -260,6 +331,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
   float pre[7];
   float rt[10];
   const bool root = (tile == 0 && gi == 0 && tid < BP && eb < B);   // then ev == 0 and eb is this thread's batch row
+  auto fetch_operands = [&]() {
   switch (G.epi) {
     case EPI_ELU_HID: if constexpr (FAM == 0) {
       const int col = tile * 16 + ev;
@@ -348,6 +420,8 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       }
     } break;
   }
+  };
+  if constexpr (!CG) fetch_operands();   // chained GEMV: after the hand-off (the registers hold weights until then)
 
   if constexpr (BV > 0) {
     // ---- GEMV mode: batch <= 2 (autoregressive decode).  No MFMA padding to 16 batch rows: each lane owns
@@ -361,6 +435,69 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
     int TB = 0;
     for (int s = 0; s < G.nseg; ++s) TB += G.seg[s].kb;
     const int b0 = wave * TB / WAVES, b1 = (wave + 1) * TB / WAVES;
+    if constexpr (CH) {
+      // ---- chained launch: ALL of this wave's weight blocks (<= GPRE, checked by the host) are fetched into registers
+      // while the predecessor is still running; after the hand-off only the activation vector (a few KB, staged through a
+      // wave-private LDS slice) and the dot products remain on the critical path.
+      const int k0 = G.seg[0].kb, k1 = k0 + (G.nseg > 1 ? G.seg[1].kb : 0);
+      auto locate = [&](int gb, int& sidx, int& l) {
+        sidx = gb < k0 ? 0 : (gb < k1 ? 1 : 2);
+        l = gb - (sidx == 0 ? 0 : (sidx == 1 ? k0 : k1));
+      };
+      f4 wreg[GREG];
+      f4* wlw = wl + wave * ((GPRE - GREG) * 64) + lane;
+      const f4* wcat = (const f4*)G.wcat + ((long)tile * G.tkbcat + b0) * 64 + lane;
+      const int nblk = b1 - b0;
+      auto wload = [&](int i) -> f4 {
+        f4 v = wcat[(long)(i < nblk ? i : nblk - 1) * 64];     // clamped: branch-free, the surplus is zeroed
+        if (i >= nblk) v = f4{0.f, 0.f, 0.f, 0.f};
+        return v;
+      };
+      CHT(0);
+      // the LDS-parked blocks first (their registers are free again before the register-resident ones are fetched)
+#pragma unroll
+      for (int i = GREG; i < GPRE; ++i) wlw[(i - GREG) * 64] = wload(i);
+      CHT(1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < GREG; ++i) wreg[i] = wload(i);
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef ZEGGS_CHTIME
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      CHT(2);
+#endif
+      if (a.ch_wait) {
+        if (wave == 0) chain_wait(a.ch_wait, a.wait_count, a.ch_err);
+        __syncthreads();
+      }
+      CHT(3);
+      fetch_operands();
+      f4* xw = xs + wave * (BV * GPRE * 4);
+      for (int q = lane; q < BV * GPRE * 4; q += 64) {
+        const int b = q / (GPRE * 4), r = q % (GPRE * 4), i = r >> 2, e = r & 3;
+        const int gb = (b0 + i < b1) ? b0 + i : b1 - 1;
+        int sidx, l;
+        locate(gb, sidx, l);
+        const float* xc = sidx == 0 ? G.seg[0].xc : (sidx == 1 ? G.seg[1].xc : G.seg[2].xc);
+        const int ldx = sidx == 0 ? G.seg[0].ldx : (sidx == 1 ? G.seg[1].ldx : G.seg[2].ldx);
+        xw[q] = *(const f4*)(xc + (long)b * ldx + 16 * l + 4 * e);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the slice is written and read by this wave only
+      CHT(4);
+#pragma unroll
+      for (int i = 0; i < GPRE; ++i) {
+        if ((i & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads from piling up in registers
+        const bool acc1 = b0 + i >= G.kacc;
+#pragma unroll
+        for (int b = 0; b < BV; ++b) {
+          const f4 xv = xw[(b * GPRE + i) * 4 + (lane >> 4)];
+          const f4 wv = i < GREG ? wreg[i < GREG ? i : 0] : wlw[(i - GREG) * 64];
+          const float dd = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, wv.w * xv.w)));
+          av[0][b] += acc1 ? 0.f : dd;
+          av[1][b] += acc1 ? dd : 0.f;
+        }
+      }
+    } else {
     int base = 0;
     for (int s = 0; s < G.nseg; ++s) {
       const int kbs = G.seg[s].kb;
@@ -405,6 +542,8 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       }
       base += kbs;
     }
+    }
+    CHT(5);
     float* redf = (float*)red;   // [wave][2][BV][16]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -461,6 +600,7 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
     }
     __syncthreads();
 }
+  CHT(6);
   const float* finf = (const float*)fin;
   auto FV = [&](int i, int vcol, int bg) -> float {   // bg = global batch row (must belong to this part)
     const int b = bg - 16 * nb0;
@@ -476,8 +616,8 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       if (eact) {
         const int col = tile * 16 + ev;
         const float val = d_elu(FV(0, ev, eb) + pre[0]);
-        G.o0[(long)eb * a.GL + col] = val;
-        if (G.o1) G.o1[xf_index(eb, col, LNB)] = val;
+        st_out<CH>(&G.o0[(long)eb * a.GL + col], val);
+        if (G.o1) st_out<CH>(&G.o1[xf_index(eb, col, LNB)], val);
       }
     } break;
     case EPI_GRU_FWD: if constexpr (FAM == 0) {   // tile = 5 hidden units x (r, z, n); acc0 = input side, acc1 = hidden side
@@ -489,9 +629,9 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         const float nn = tanhf(FV(0, 10 + u, b) + pre[4] + r * nh);
         const long i = (long)b * H + U;
         const float h = (1.f - z) * nn + z * pre[6];
-        G.o0[i] = h;
-        if (G.o1) G.o1[xf_index(b, U, LNB)] = h;
-        if (G.o2) ((f4*)G.o2)[i] = f4{r, z, nn, nh};   // saved gates, one 16-byte store
+        st_out<CH>(&G.o0[i], h);
+        if (G.o1) st_out<CH>(&G.o1[xf_index(b, U, LNB)], h);
+        if (G.o2) ((f4*)G.o2)[i] = f4{r, z, nn, nh};   // saved gates, one 16-byte store (read by the backward pass only)
       }
       if (a.cf_gin || a.cf_x || a.cf_cond) {   // speech / style columns of x_{t+1} (inputs: independent of this step)
         const int XC = d.SP + d.ST;
@@ -499,9 +639,9 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
           const int b = e / XC, c = e % XC;
           const float val = c < d.SP ? a.speech[((long)b * d.T + t + 1) * d.SP + c]
                                      : a.style[((long)b * d.T + t + 1) * d.ST + (c - d.SP)];
-          if (a.cf_gin) a.cf_gin[(long)b * a.GL + H + d.PI + c] = val;
-          if (a.cf_x) a.cf_x[xf_index(b, d.PI + c, LNB)] = val;
-          if (a.cf_cond) a.cf_cond[xf_index(b, c, LNB)] = val;
+          if (a.cf_gin) st_out<CH>(&a.cf_gin[(long)b * a.GL + H + d.PI + c], val);
+          if (a.cf_x) st_out<CH>(&a.cf_x[xf_index(b, d.PI + c, LNB)], val);
+          if (a.cf_cond) st_out<CH>(&a.cf_cond[xf_index(b, c, LNB)], val);
         }
       }
     } break;
@@ -515,8 +655,8 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         a.pose[((long)b * d.T + t) * PO + col] = p;
         if (next) {
           const float e = (p - pre[3]) / pre[4];
-          if (gnext) gnext[(long)b * a.GL + H + col] = e;
-          if (xnext) xnext[xf_index(b, col, LNB)] = e;
+          if (gnext) st_out<CH>(&gnext[(long)b * a.GL + H + col], e);
+          if (xnext) st_out<CH>(&xnext[xf_index(b, col, LNB)], e);
         }
       }
       if (root) {
@@ -525,12 +665,15 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         for (int c = 0; c < 6; ++c) p[c] = (FV(0, c, b) + G.p0[c]) * a.st.out_std[c] + a.st.out_mean[c];
         V3 npos; Q4 nq;
         root_step(d, a.st, rt, p, next, npos, nq, genc);
-        float* op = a.rpos + ((long)b * d.T + t) * 3; op[0] = npos.x; op[1] = npos.y; op[2] = npos.z;
-        float* oq = a.rrot + ((long)b * d.T + t) * 4; oq[0] = nq.w; oq[1] = nq.x; oq[2] = nq.y; oq[3] = nq.z;
+        // (the root state is an epilogue operand of the launch three places down the chain, fetched before its hand-off wait)
+        float* op = a.rpos + ((long)b * d.T + t) * 3;
+        st_out<CH>(op, npos.x); st_out<CH>(op + 1, npos.y); st_out<CH>(op + 2, npos.z);
+        float* oq = a.rrot + ((long)b * d.T + t) * 4;
+        st_out<CH>(oq, nq.w); st_out<CH>(oq + 1, nq.x); st_out<CH>(oq + 2, nq.y); st_out<CH>(oq + 3, nq.z);
         if (next) {
           for (int k = 0; k < 3; ++k) {
-            if (gnext) gnext[(long)b * a.GL + H + PO + k] = genc[k];
-            if (xnext) xnext[xf_index(b, PO + k, LNB)] = genc[k];
+            if (gnext) st_out<CH>(&gnext[(long)b * a.GL + H + PO + k], genc[k]);
+            if (xnext) st_out<CH>(&xnext[xf_index(b, PO + k, LNB)], genc[k]);
           }
         }
       }
@@ -549,8 +692,8 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
         const int col = tile * 16 + ev;
         const float pa = FV(0, ev, eb) + pre[0] + pre[1] * gsh[ebl * 3] + pre[2] * gsh[ebl * 3 + 1] + pre[3] * gsh[ebl * 3 + 2];
         const float val = d_elu(pa);
-        G.o0[(long)eb * a.GL + col] = val;
-        if (G.o1) G.o1[xf_index(eb, col, LNB)] = val;
+        st_out<CH>(&G.o0[(long)eb * a.GL + col], val);
+        if (G.o1) st_out<CH>(&G.o1[xf_index(eb, col, LNB)], val);
       }
     } break;
     case EPI_GRU_BWD: if constexpr (FAM == 1) {   // dh = W^T delta + carry -> gate gradients of this layer
@@ -653,6 +796,15 @@ __global__ __launch_bounds__(WAVES * 64) void stage_k(StageArgs a) {
       }
     } break;
   }
+  CHT(7);
+  if constexpr (CH) {
+#ifdef ZEGGS_CHTIME
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CHT(8);
+#endif
+    chain_arrive(a.ch_arrive);
+    CHT(9);
+  }
 }
 
 // gradient wrt the raw output of the LAST step (no next step feeds on it)
@@ -694,11 +846,13 @@ struct PackArgs {
   int tiles, kb, mode, K, N, H, PO;
   long ld;
   int off;
+  int tkb;   // k-blocks per tile of the destination pack (>= kb: the pack holds further segments per tile)
 };
 // mode 0: rows (virtual col = source row)          V[vc][k] = src[vc*ld + off + k]
 // mode 1: GRU rows, tile = 5 units x (r,z,n)       V[g*5+u][k] = src[(g*H + tile*5+u)*ld + off + k]
 // mode 2: columns (transposed)                     V[vc][k] = src[k*ld + off + vc]
 // mode 3: columns with the dX permutation          V[q][k]  = src[k*ld + perm(q)]
+// mode 4: the rows of tile 0 for EVERY tile         V[vc][k] = src[(vc % 16)*ld + off + k]
 __global__ void pack_k(PackArgs p) {
   const long n = (long)p.tiles * p.kb * 64;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
@@ -707,9 +861,10 @@ __global__ void pack_k(PackArgs p) {
     const int kbi = (int)(tk % p.kb), tile = (int)(tk / p.kb);
     const int i = lane & 15, k0 = 16 * kbi + 4 * (lane >> 4);
     f4 v = f4{0.f, 0.f, 0.f, 0.f};
-    if (p.mode <= 1) {
+    if (p.mode <= 1 || p.mode == 4) {
       long row = -1;
       if (p.mode == 0) { if (tile * 16 + i < p.N) row = tile * 16 + i; }
+      else if (p.mode == 4) { if (i < p.N) row = i; }
       else { const int g = i / 5, u = i % 5, U = tile * 5 + u; if (g < 3 && U < p.H) row = (long)g * p.H + U; }
       if (row >= 0) {
         const float* s = p.src + row * p.ld + p.off;
@@ -724,13 +879,13 @@ __global__ void pack_k(PackArgs p) {
         for (int c = 0; c < 4; ++c) if (k0 + c < p.K) v[c] = p.src[(long)(k0 + c) * p.ld + col];
       }
     }
-    ((f4*)p.dst)[idx] = v;
+    ((f4*)p.dst)[((long)tile * p.tkb + kbi) * 64 + lane] = v;
   }
 }
 
 int pack(float* dst, const float* src, int tiles, int kb, int mode, int K, int N, int H, int PO, long ld, int off,
-         hipStream_t s) {
-  PackArgs p{dst, src, tiles, kb, mode, K, N, H, PO, ld, off};
+         hipStream_t s, int tkb = 0) {
+  PackArgs p{dst, src, tiles, kb, mode, K, N, H, PO, ld, off, tkb ? tkb : kb};
   long n = (long)tiles * kb * 64;
   long g = (n + 255) / 256;
   hipLaunchKernelGGL(pack_k, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, s, p);
@@ -738,8 +893,25 @@ int pack(float* dst, const float* src, int tiles, int kb, int mode, int K, int N
   return 0;
 }
 
+// grid size of a stage launch (same rule as launch_stage_f / launch_stage_gemv)
+int stage_nsplit(const StageArgs& a) {
+  if (a.gemv) return 1;
+  const bool few = (a.g[0].tiles < 160 && a.g[1].tiles < 160) || (g_stage_variant & 64);
+  return (few && a.NB % 2 == 0 && !(g_stage_variant & 32)) ? 2 : 1;
+}
+int stage_wgs(const StageArgs& a) { return (a.g[0].tiles + a.g[1].tiles) * stage_nsplit(a); }
+
 int launch_stage_gemv(const StageArgs& a, hipStream_t s) {
   const int wgs = a.g[0].tiles + a.g[1].tiles;
+  if (a.ch_arrive) {
+    switch (a.d.B) {
+      case 1: hipLaunchKernelGGL((stage_k<1, 0, 8, 1, 1>), dim3(wgs), dim3(512), 0, s, a); break;
+      case 2: hipLaunchKernelGGL((stage_k<1, 0, 8, 2, 1>), dim3(wgs), dim3(512), 0, s, a); break;
+      default: zeggs_set_error("gemv mode needs batch <= 2"); return -1;
+    }
+    ZLAUNCH_CHECK("decoder_stage_gemv_chained");
+    return 0;
+  }
   switch (a.d.B) {
     case 1: hipLaunchKernelGGL((stage_k<1, 0, 8, 1>), dim3(wgs), dim3(512), 0, s, a); break;
     case 2: hipLaunchKernelGGL((stage_k<1, 0, 8, 2>), dim3(wgs), dim3(512), 0, s, a); break;
@@ -752,8 +924,7 @@ int launch_stage_gemv(const StageArgs& a, hipStream_t s) {
 template <int FAM>
 int launch_stage_f(const StageArgs& a, hipStream_t s) {
   // stages with few tiles are split over the batch (two workgroups per tile) to occupy more CUs
-  const bool few = (a.g[0].tiles < 160 && a.g[1].tiles < 160) || (g_stage_variant & 64);
-  const int nsplit = (few && a.NB % 2 == 0 && !(g_stage_variant & 32)) ? 2 : 1;
+  const int nsplit = stage_nsplit(a);
   const int nbw = a.NB / nsplit;
   const int wgs = (a.g[0].tiles + a.g[1].tiles) * nsplit;
   const bool w8 = !(g_stage_variant & 128);   // 8 waves (2 workgroups per CU) for <= 32 batch rows per workgroup
@@ -782,8 +953,9 @@ int launch_stage(const StageArgs& a, hipStream_t s) {
   return launch_stage_f<0>(a, s);
 }
 
-inline Seg seg(const float* w, const float* x, int kb, int acc, const float* xc = nullptr, int ldx = 0, int fixed = 0) {
-  return Seg{w, x, kb, acc, xc, ldx, fixed, 0};
+inline Seg seg(const float* w, const float* x, int kb, int acc, const float* xc = nullptr, int ldx = 0, int fixed = 0,
+               int tkb = 0) {
+  return Seg{w, x, kb, acc, xc, ldx, fixed, tkb};
 }
 // k-blocks [kb0, kb0 + kb) of a pack with `tkb` blocks per tile
 inline Seg subseg(const float* w, const float* x, int kb0, int kb, int tkb, int acc) {
@@ -802,6 +974,46 @@ __global__ void merge_prep_k(float* W0s, float* vvec, const float* W0, const flo
   }
 }
 
+// ---- chained launches (host side): consecutive stage launches alternate between the caller's stream and a library-owned
+// second stream, so launch k+1 is resident and has fetched its weights while launch k still runs; the dependency is the
+// device-side arrival counter (ring of CH_RING slots, never reset inside a rollout: the host passes cumulative counts).
+struct ChainStream { hipStream_t s; hipEvent_t start, done; };
+int chain_stream(ChainStream** out) {
+  static ChainStream pool[16];
+  static bool ready[16] = {};
+  int dev = 0;
+  ZCHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "decoder chain: unsupported device index");
+  if (!ready[dev]) {
+    ZCHECK(hipStreamCreateWithFlags(&pool[dev].s, hipStreamNonBlocking) == hipSuccess, "chain stream creation failed");
+    ZCHECK(hipEventCreateWithFlags(&pool[dev].start, hipEventDisableTiming) == hipSuccess, "event creation failed");
+    ZCHECK(hipEventCreateWithFlags(&pool[dev].done, hipEventDisableTiming) == hipSuccess, "event creation failed");
+    ready[dev] = true;
+  }
+  *out = &pool[dev];
+  return 0;
+}
+struct Chain {
+  bool on = false;
+  hipStream_t s[2];
+  ChainStream* cs = nullptr;
+  unsigned* flags = nullptr;
+  unsigned* err = nullptr;
+  unsigned cum[CH_RING] = {0, 0, 0, 0};
+  long k = 0;
+  // fills the hand-off fields of `a` for the next launch with `wgs` workgroups and returns the stream to launch it on
+  hipStream_t next(StageArgs& a, int wgs) {
+    if (!on) return s[0];
+    const int slot = (int)(k % CH_RING), prev = (int)((k + CH_RING - 1) % CH_RING);
+    a.ch_wait = k > 0 ? flags + prev * (CH_SHARDS * CH_STRIDE) : nullptr;
+    a.wait_count = cum[prev];
+    a.ch_arrive = flags + slot * (CH_SHARDS * CH_STRIDE);
+    a.ch_err = err;
+    a.ch_k = (int)k;
+    cum[slot] += (unsigned)wgs;
+    return s[k++ & 1];
+  }
+};
+
 StageArgs base_args(const ZeggsDecDims& d, const ZeggsDecStats* st, const DecWs& w) {
   StageArgs a;
   memset(&a, 0, sizeof(a));
@@ -816,11 +1028,11 @@ int dec_fast_supported(const ZeggsDecDims& d) { return !d.film && d.H % 16 == 0 
 int dec_fast_pack_fwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s) {
   const int H = d.H, XD = w.XD;
   ZTRY(pack(w.pw_l0, P->l0_w, w.nTH, w.KBX, 0, XD, H, H, d.PO, XD, 0, s));
-  ZTRY(pack(w.pw_ih0h, P->w_ih0, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H + XD, 0, s));
-  ZTRY(pack(w.pw_ih0x, P->w_ih0, w.nT5, w.KBX, 1, XD, 3 * H, H, d.PO, H + XD, H, s));
-  ZTRY(pack(w.pw_hh0, P->w_hh0, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s));
-  ZTRY(pack(w.pw_ih1, P->w_ih1, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s));
-  ZTRY(pack(w.pw_hh1, P->w_hh1, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s));
+  ZTRY(pack(w.pw_ih0h, P->w_ih0, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H + XD, 0, s, w.TG0));
+  ZTRY(pack(w.pw_ih0x, P->w_ih0, w.nT5, w.KBX, 1, XD, 3 * H, H, d.PO, H + XD, H, s, w.TG0));
+  ZTRY(pack(w.pw_hh0, P->w_hh0, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s, w.TG0));
+  ZTRY(pack(w.pw_ih1, P->w_ih1, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s, w.TG1));
+  ZTRY(pack(w.pw_hh1, P->w_hh1, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s, w.TG1));
   ZTRY(pack(w.pw_l2, P->l2_w, w.nTPO, w.KBH, 0, H, d.PO, H, d.PO, H, 0, s));
   return 0;
 }
@@ -837,8 +1049,9 @@ int dec_fast_pack_merged(const ZeggsDecDims& d, const ZeggsDecParams* P, const Z
   ZLAUNCH_CHECK("merge_prep");
   ZTRY(gemm_nn(w.W0s, w.POL, P->l2_w, H, w.Mc, H, H, d.PO, H, 0.f, s));
   ZTRY(gemm_nt(w.vvec, w.POL, P->l0_w, XD, w.cvec, H, P->l0_b, 1, H, d.PO, ACT_NONE, 0.f, s));
-  ZTRY(pack(w.pw_m, w.Mc, w.nTH, w.KBH, 0, H, H, H, d.PO, H, 0, s));
-  ZTRY(pack(w.pw_c, P->l0_w, w.nTH, w.KBC, 0, d.SP + d.ST, H, H, d.PO, XD, d.PI, s));
+  ZTRY(pack(w.pw_m, w.Mc, w.nTH, w.KBH, 0, H, H, H, d.PO, H, 0, s, w.TMC));
+  ZTRY(pack(w.pw_c, P->l0_w, w.nTH, w.KBC, 0, d.SP + d.ST, H, H, d.PO, XD, d.PI, s, w.TMC));
+  ZTRY(pack(w.pw_l2c, P->l2_w, w.nTH, w.KBH, 4, H, 16, H, d.PO, H, 0, s, w.TMC));   // layer2's root tile, per tile
   return 0;
 }
 
@@ -892,6 +1105,23 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   // 3 launches per step: layer2 of step t and layer0 of step t+1 run in ONE launch (variant 4096: 4 launches)
   const bool merged = !(g_stage_variant & 4096);
   if (merged && T > 2) ZTRY(dec_fast_pack_merged(d, P, st, w, s));
+  Chain ch;
+  ch.s[0] = ch.s[1] = s;
+  {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing(s, &cap);
+    const int per_wave = (w.KBH + w.KBX + w.KBH + 7) / 8;            // the widest stage (GRU layer 0)
+    if (g_chain && gemv && T > 2 && cap == hipStreamCaptureStatusNone && per_wave <= CH_GPRE &&
+        !(g_stage_variant & (16384 | V_NOW | V_NOEPI))) {
+      ZTRY(chain_stream(&ch.cs));
+      ch.on = true;
+      ch.s[1] = ch.cs->s;
+      ch.flags = w.chain;                                            // zeroed by the k_fill above
+      ch.err = w.chain + CH_RING * CH_SHARDS * CH_STRIDE;
+      ZCHECK(hipEventRecord(ch.cs->start, s) == hipSuccess, "hipEventRecord failed");
+      ZCHECK(hipStreamWaitEvent(ch.s[1], ch.cs->start, 0) == hipSuccess, "hipStreamWaitEvent failed");
+    }
+  }
   timing_mark(0, s);
   for (int t = 1; t < T; ++t) {
     const int c = t & 1, p = (t - 1) & 1;
@@ -908,24 +1138,27 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
       // S1: hid = ELU(W0 x + b0)
       a.g[0] = Grp{}; a.g[1] = Grp{};
       a.g[0].seg[0] = seg(w.pw_l0, Xxf[c], w.KBX, 0, gin_c + H, w.GL); a.g[0].nseg = 1; a.g[0].tiles = w.nTH;
+      a.g[0].wcat = w.pw_l0; a.g[0].tkbcat = w.KBX; a.g[0].kacc = w.KBX;
       a.g[0].epi = EPI_ELU_HID;
       a.g[0].p0 = P->l0_b; a.g[0].o0 = w.Gin + cs(t) * sG; a.g[0].o1 = gemv ? nullptr : w.HIDxf;
-      ZTRY(launch_stage(a, s));
+      ZTRY(launch_stage(a, ch.next(a, stage_wgs(a))));
     }
     // S2: GRU layer 0
     a.g[0] = Grp{}; a.g[1] = Grp{};
-    a.g[0].seg[0] = seg(w.pw_ih0h, w.HIDxf, w.KBH, 0, gin_c, w.GL);
-    a.g[0].seg[1] = seg(w.pw_ih0x, Xxf[c], w.KBX, 0, gin_c + H, w.GL);
-    a.g[0].seg[2] = seg(w.pw_hh0, H0xf[p], w.KBH, 1, h0p, H);
+    a.g[0].seg[0] = seg(w.pw_ih0h, w.HIDxf, w.KBH, 0, gin_c, w.GL, 0, w.TG0);
+    a.g[0].seg[1] = seg(w.pw_ih0x, Xxf[c], w.KBX, 0, gin_c + H, w.GL, 0, w.TG0);
+    a.g[0].seg[2] = seg(w.pw_hh0, H0xf[p], w.KBH, 1, h0p, H, 0, w.TG0);
+    a.g[0].wcat = w.pw_g0; a.g[0].tkbcat = w.TG0; a.g[0].kacc = w.KBH + w.KBX;
     a.g[0].nseg = 3; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
     a.g[0].p0 = P->b_ih0; a.g[0].p1 = P->b_hh0; a.g[0].p2 = h0p;
     a.g[0].o0 = h0c; a.g[0].o1 = gemv ? nullptr : H0xf[c];
     if (training) a.g[0].o2 = w.GT0 + 4 * o;
-    ZTRY(launch_stage(a, s));
+    ZTRY(launch_stage(a, ch.next(a, stage_wgs(a))));
     // S3: GRU layer 1 (+ stages the speech/style columns of x_{t+1}: ring slots last read one step ago)
     a.g[0] = Grp{};
-    a.g[0].seg[0] = seg(w.pw_ih1, H0xf[c], w.KBH, 0, h0c, H);
-    a.g[0].seg[1] = seg(w.pw_hh1, H1xf[p], w.KBH, 1, h1p, H);
+    a.g[0].seg[0] = seg(w.pw_ih1, H0xf[c], w.KBH, 0, h0c, H, 0, w.TG1);
+    a.g[0].seg[1] = seg(w.pw_hh1, H1xf[p], w.KBH, 1, h1p, H, 0, w.TG1);
+    a.g[0].wcat = w.pw_g1; a.g[0].tkbcat = w.TG1; a.g[0].kacc = w.KBH;
     a.g[0].nseg = 2; a.g[0].tiles = w.nT5; a.g[0].epi = EPI_GRU_FWD;
     a.g[0].p0 = P->b_ih1; a.g[0].p1 = P->b_hh1; a.g[0].p2 = h1p;
     a.g[0].o0 = h1c; a.g[0].o1 = gemv ? nullptr : H1xf[c];
@@ -935,24 +1168,30 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
       a.cf_x = gemv ? nullptr : Xxf[(t + 1) & 1];
       a.cf_cond = (gemv || !merged) ? nullptr : w.CONDxf;
     }
-    ZTRY(launch_stage(a, s));
+    ZTRY(launch_stage(a, ch.next(a, stage_wgs(a))));
     a.cf_gin = a.cf_x = a.cf_cond = nullptr;
     // S4: y = W2 h1 + b2 -> pose[t], root integration, pose/gaze columns of x_{t+1}
     //     [merged: + hid_{t+1} = ELU(M h1 + Wc cond_{t+1} + W0[:, gaze] g_{t+1} + cvec) in the same launch]
     a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pw_l2, H1xf[c], w.KBH, 0, h1c, H); a.g[0].nseg = 1; a.g[0].tiles = w.nTPO;
+    a.g[0].wcat = w.pw_l2; a.g[0].tkbcat = w.KBH; a.g[0].kacc = w.KBH;
     a.g[0].epi = EPI_OUT_FWD;
     a.g[0].p0 = P->l2_b; a.g[0].o0 = next ? gin_n : nullptr;
     a.g[0].o1 = gemv ? nullptr : Xxf[(t + 1) & 1];
     if (merged && next) {
-      a.g[1].seg[0] = seg(w.pw_m, H1xf[c], w.KBH, 0, h1c, H);
-      a.g[1].seg[1] = seg(w.pw_c, w.CONDxf, w.KBC, 0, gin_n + H + d.PI, w.GL);
-      a.g[1].seg[2] = seg(w.pw_l2, H1xf[c], w.KBH, 1, h1c, H, 1);
+      a.g[1].seg[0] = seg(w.pw_m, H1xf[c], w.KBH, 0, h1c, H, 0, w.TMC);
+      a.g[1].seg[1] = seg(w.pw_c, w.CONDxf, w.KBC, 0, gin_n + H + d.PI, w.GL, 0, w.TMC);
+      a.g[1].seg[2] = seg(w.pw_l2, H1xf[c], w.KBH, 1, h1c, H, 1);      // every workgroup: layer2's tile 0 (L2-resident)
+      a.g[1].wcat = w.pw_mc; a.g[1].tkbcat = w.TMC; a.g[1].kacc = w.KBH + w.KBC;   // chained GEMV: the per-tile copy
       a.g[1].nseg = 3; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_HID_MERGED;
       a.g[1].p0 = w.cvec; a.g[1].p1 = P->l0_w; a.g[1].p2 = P->l2_b;
       a.g[1].o0 = gin_n; a.g[1].o1 = gemv ? nullptr : w.HIDxf;
     }
-    ZTRY(launch_stage(a, s));
+    ZTRY(launch_stage(a, ch.next(a, stage_wgs(a))));
+  }
+  if (ch.on) {   // the caller's stream continues after the last launch of the second stream
+    ZCHECK(hipEventRecord(ch.cs->done, ch.s[1]) == hipSuccess, "hipEventRecord failed");
+    ZCHECK(hipStreamWaitEvent(s, ch.cs->done, 0) == hipSuccess, "hipStreamWaitEvent failed");
   }
   timing_mark(1, s);
   return 0;

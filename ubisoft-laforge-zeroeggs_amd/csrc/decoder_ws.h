@@ -18,13 +18,19 @@ struct DecWs {
   float *A0, *A2, *F2, *GAM, *BET, *DGAM, *DBET, *D2, *dF2, *STm, *dSTm;
   // ---- fast path: fragment-packed weights (see decoder_fast.hip) and activations
   int NB, nT5, nTH, nTX, nTPO, nTGI, KBH, KBX, KBPO, KB3H;
-  float *pw_l0, *pw_ih0h, *pw_ih0x, *pw_hh0, *pw_ih1, *pw_hh1, *pw_l2;   // forward packs
+  // forward packs; the packs that feed one stage group are contiguous PER TILE (pw_g0 = [ih0h | ih0x | hh0],
+  // pw_g1 = [ih1 | hh1], pw_mc = [M | Wc | copy of layer2's tile 0]) so that a wave's share of the concatenated
+  // contraction is one address range (chained GEMV launches); the named pointers are sub-ranges (Seg.tkb = TG*)
+  float *pw_l0, *pw_ih0h, *pw_ih0x, *pw_hh0, *pw_ih1, *pw_hh1, *pw_l2;
+  float *pw_g0, *pw_g1, *pw_mc, *pw_l2c;
+  int TG0, TG1, TMC;
   float *pb_l2, *pb_ih1, *pb_hh1, *pb_ih0, *pb_hh0, *pb_l0, *pb_mt;      // backward (transposed) packs
   float *Xxf, *HIDxf, *H0xf, *H1xf;                                      // forward activation fragments (rings of 2)
   // merged layer2 -> layer0 stage: M = W0[:, :PO] diag(sigma_o / sigma_i) W2, Wc = W0[:, PI:], cvec = b0 + W0[:, :PO] v
   int KBC;
   float *W0s, *Mc, *vvec, *cvec, *pw_m, *pw_c, *CONDxf;
   float *DYxf, *DI1xf, *DH1xf, *DI0xf, *DH0xf, *D0xf, *Rxf, *dXa;         // backward fragments
+  unsigned* chain;     // arrival counters + error word of the chained (run-ahead) launches; zeroed with the forward fragments
   size_t xf_bytes_fwd, xf_bytes_bwd;
   float *xf_base_fwd, *xf_base_bwd;
 };
@@ -73,22 +79,23 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
   w.nTGI = w.nTH + w.nTX;
   w.KBH = d.H / 16; w.KBX = w.nTX; w.KBPO = w.nTPO; w.KB3H = 3 * d.H / 16;
   const long BLK = 256;   // floats per (tile, k-block) weight fragment = 64 lanes x 4
-  w.pw_l0 = a.f((long)w.nTH * w.KBX * BLK);
-  w.pw_ih0h = a.f((long)w.nT5 * w.KBH * BLK);
-  w.pw_ih0x = a.f((long)w.nT5 * w.KBX * BLK);
-  w.pw_hh0 = a.f((long)w.nT5 * w.KBH * BLK);
-  w.pw_ih1 = a.f((long)w.nT5 * w.KBH * BLK);
-  w.pw_hh1 = a.f((long)w.nT5 * w.KBH * BLK);
-  w.pw_l2 = a.f((long)w.nTPO * w.KBH * BLK);
   w.KBC = (d.SP + d.ST + 15) / 16;
-  w.pw_m = a.f((long)w.nTH * w.KBH * BLK);
-  w.pw_c = a.f((long)w.nTH * w.KBC * BLK);
+  w.TG0 = w.KBH + w.KBX + w.KBH; w.TG1 = 2 * w.KBH; w.TMC = w.KBH + w.KBC + w.KBH;
+  w.pw_l0 = a.f((long)w.nTH * w.KBX * BLK);
+  w.pw_g0 = a.f((long)w.nT5 * w.TG0 * BLK);
+  w.pw_ih0h = w.pw_g0; w.pw_ih0x = w.pw_g0 + w.KBH * BLK; w.pw_hh0 = w.pw_g0 + (w.KBH + w.KBX) * BLK;
+  w.pw_g1 = a.f((long)w.nT5 * w.TG1 * BLK);
+  w.pw_ih1 = w.pw_g1; w.pw_hh1 = w.pw_g1 + w.KBH * BLK;
+  w.pw_l2 = a.f((long)w.nTPO * w.KBH * BLK);
+  w.pw_mc = a.f((long)w.nTH * w.TMC * BLK);
+  w.pw_m = w.pw_mc; w.pw_c = w.pw_mc + w.KBH * BLK; w.pw_l2c = w.pw_mc + (w.KBH + w.KBC) * BLK;
   w.W0s = a.f(H * (long)w.POL); w.Mc = a.f(H * H); w.vvec = a.f(w.POL); w.cvec = a.f(H);
   const long XB = 256L * w.NB;  // floats per k-block of an activation fragment
   {
     size_t o0 = a.off;
     w.Xxf = a.f(2 * w.KBX * XB); w.HIDxf = a.f(w.KBH * XB); w.H0xf = a.f(2 * w.KBH * XB); w.H1xf = a.f(2 * w.KBH * XB);
     w.CONDxf = a.f(w.KBC * XB);
+    w.chain = (unsigned*)a.f(4096);
     w.xf_base_fwd = w.Xxf;
     w.xf_bytes_fwd = a.off - align_up(o0, 256);
   }

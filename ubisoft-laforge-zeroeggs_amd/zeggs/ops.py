@@ -428,6 +428,8 @@ class _DecoderFn(torch.autograd.Function):
         _check(L.zeggs_decoder_fwd(C.byref(d), C.byref(P), C.byref(S), _p(pose0), _p(rpos0), _p(rrot0), _p(gaze),
                                    _p(speech), _p(style), _p(pose), _p(rpos), _p(rrot), int(training), _p(ws),
                                    C.c_size_t(ws.numel()), _stream()), "decoder_fwd")
+        global _LAST_DECODER_WS
+        _LAST_DECODER_WS = (d, int(training), ws)
         if training:
             ctx.d, ctx.ws = d, ws
             ctx.save_for_backward(gaze, pose, rpos, rrot, *stats, *params)
@@ -452,6 +454,21 @@ class _DecoderFn(torch.autograd.Function):
                                    _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
                                    C.c_size_t(ctx.ws.numel()), _stream()), "decoder_bwd")
         return (None, None, None, None, dspeech, dstyle, None, None, None, None, None, None, None, *rets)
+
+
+_LAST_DECODER_WS = None
+
+
+def last_decoder_chain_errors():
+    """Error word of the chained (run-ahead) stage launches of the most recent decoder rollout (option "chain"):
+    0 = every device-side hand-off wait was satisfied.  Synchronises the device."""
+    if _LAST_DECODER_WS is None:
+        return 0
+    d, training, ws = _LAST_DECODER_WS
+    out = C.c_int(0)
+    _check(lib().zeggs_decoder_chain_errors(C.byref(d), training, _p(ws), C.c_size_t(ws.numel()), C.byref(out)),
+           "decoder_chain_errors")
+    return int(out.value)
 
 
 def decoder_core(dec, pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt):
