@@ -509,6 +509,37 @@ def test_chained_decode_launches_match_plain_launches(B):
         assert torch.equal(a, b)                   # deterministic: no race decides a value
 
 
+@pytest.mark.parametrize("T", [4, 5, 37, 600])
+def test_persistent_decode_kernel_matches_stage_launches(T):
+    """B=1 inference: the weight-stationary persistent kernel (one launch for all frames, weights in registers, data-tagged
+    granule exchange between CUs) against the chain of stage launches; also deterministic and resumable (streaming state)."""
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).eval()
+    stats = synth.make_stats()
+    s = {k: g(v) for k, v in helpers.stats_tensors().items()}
+    clip = synth.make_clip(max(T, 4), seed=611, stats=stats)
+    tt = lambda k: g(torch.as_tensor(clip[k][None, :T]))  # noqa: E731
+    pose0 = _pack_pose(tt("Y_root_vel"), tt("Y_root_vrt"), tt("Y_lpos"), tt("Y_ltxy"), tt("Y_lvel"), tt("Y_lvrt"))[:, 0]
+    torch.manual_seed(10)
+    speech, style = torch.randn(1, T, 64, device=DEV) * 0.5, torch.randn(1, T, 64, device=DEV) * 0.5
+    outs = []
+    try:
+        for v in (0, 1, 1):
+            ops.set_option("persistent", v)
+            with torch.no_grad():
+                outs.append(ops.decoder_core(de, pose0.contiguous(), tt("Y_root_pos")[:, 0].contiguous(),
+                                             tt("Y_root_rot")[:, 0].contiguous(), tt("Y_gaze_pos"), speech, style,
+                                             s["in_mean"], s["in_std"], s["out_mean"], s["out_std"], synth.DT))
+            torch.cuda.synchronize()
+    finally:
+        ops.set_option("persistent", 1)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) < 5e-5
+    for a, b in zip(outs[1], outs[2]):
+        assert torch.equal(a, b)
+
+
 # ----------------------------------------------------------------------------- edge cases
 def _oracle_vs_hip_rollout(B, T, style_dim, tol=1e-4):
     torch.manual_seed(1234)

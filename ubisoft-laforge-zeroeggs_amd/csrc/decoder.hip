@@ -21,12 +21,14 @@ extern int g_stage_variant;
 extern int g_gemm_wg_target;
 extern int g_timing;
 extern int g_chain;
+extern int g_persistent;
 extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "decoder_fast") == 0) { g_decoder_fast = value; return 0; }
   if (strcmp(name, "stage_variant") == 0) { g_stage_variant = value; return 0; }
   if (strcmp(name, "gemm_wg_target") == 0) { g_gemm_wg_target = value; return 0; }
   if (strcmp(name, "timing") == 0) { g_timing = value; return 0; }
   if (strcmp(name, "chain") == 0) { g_chain = value; return 0; }
+  if (strcmp(name, "persistent") == 0) { g_persistent = value; if (value) dec_persistent_set_state(-1); return 0; }
   if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
   zeggs_set_error("unknown option %s", name);
   return -1;
@@ -455,6 +457,31 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
     }
   }
   const bool fast = g_decoder_fast && dec_fast_supported(d);
+  // ---- batch-1 inference: the weight-stationary persistent kernel (one launch for all frames, decode_persistent.hip)
+  if (fast && !training && g_persistent && dec_persistent_state() != 0 && dec_persistent_supported(d, w)) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing(s, &cap);
+    // the first use on a process is validated (device sync + error word); never inside a stream capture
+    if (cap == hipStreamCaptureStatusNone || dec_persistent_state() == 1) {
+      float* gin1 = w.Gin + slot(1) * sG;
+      hipLaunchKernelGGL(dec_fill_cond_k, g1((long)B * (d.SP + d.ST)), dim3(256), 0, s, d, speech, style, w.Gin, GL, 1, 1,
+                         sG, 1);
+      ZLAUNCH_CHECK("dec_fill_cond");
+      ZTRY(gemm_nt(gin1 + H, GL, P->l0_w, XD, gin1, GL, P->l0_b, B, H, XD, ACT_ELU, 0.f, s));   // hid_1 = ELU(W0 x_1 + b0)
+      ZTRY(dec_fast_merge_prep(d, P, st, w, s));
+      dec_timing_mark(0, s);
+      ZTRY(dec_persistent_run(d, P, st, w, gaze, speech, style, pose, rpos, rrot, gin1, w.H0 + slot(0) * sH,
+                              w.H1 + slot(0) * sH, w.H0 + slot(T - 1) * sH, w.H1 + slot(T - 1) * sH, s));
+      dec_timing_mark(1, s);
+      if (dec_persistent_state() == 1) return save_state();
+      unsigned perr = 1;
+      ZCHECK(hipStreamSynchronize(s) == hipSuccess, "persistent decode: stream sync failed");
+      ZTRY(dec_persistent_errors(w, &perr));
+      dec_persistent_set_state(perr == 0 ? 1 : 0);
+      if (perr == 0) return save_state();
+      // a bounded sweep gave up (not every workgroup resident?): disabled for this process, the stage kernels redo the rollout
+    }
+  }
   if (fast) {
     if (!training && T > 1) {
       hipLaunchKernelGGL(dec_fill_cond_k, g1((long)B * (d.SP + d.ST)), dim3(256), 0, s, d, speech, style, w.Gin, GL, 1,

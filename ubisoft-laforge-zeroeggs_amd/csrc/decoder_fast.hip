@@ -1041,7 +1041,10 @@ int dec_fast_pack_fwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, 
 // reference only de-normalises / re-normalises the pose columns (ZEGGS/modules.py:60-76), which is affine, so
 //   W0 x_{t+1} + b0 = M h1_t + Wc cond_{t+1} + W0[:, gaze] g_{t+1} + cvec
 // with M = W0[:, :PO] diag(sigma_o/sigma_i) W2.  Only the 3 gaze columns depend on the (non-linear) root integration.
-int dec_fast_pack_merged(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s) {
+void dec_timing_mark(int i, hipStream_t s) { timing_mark(i, s); }
+
+// canonical operands of the folded stage: Mc = W0[:, :PO] diag(sigma_o/sigma_i) W2 [H,H], cvec [H]
+int dec_fast_merge_prep(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s) {
   const int H = d.H, XD = w.XD;
   const long n = (long)H * w.POL;
   hipLaunchKernelGGL(merge_prep_k, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, w.W0s,
@@ -1049,6 +1052,12 @@ int dec_fast_pack_merged(const ZeggsDecDims& d, const ZeggsDecParams* P, const Z
   ZLAUNCH_CHECK("merge_prep");
   ZTRY(gemm_nn(w.W0s, w.POL, P->l2_w, H, w.Mc, H, H, d.PO, H, 0.f, s));
   ZTRY(gemm_nt(w.vvec, w.POL, P->l0_w, XD, w.cvec, H, P->l0_b, 1, H, d.PO, ACT_NONE, 0.f, s));
+  return 0;
+}
+
+int dec_fast_pack_merged(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s) {
+  const int H = d.H, XD = w.XD;
+  ZTRY(dec_fast_merge_prep(d, P, st, w, s));
   ZTRY(pack(w.pw_m, w.Mc, w.nTH, w.KBH, 0, H, H, H, d.PO, H, 0, s, w.TMC));
   ZTRY(pack(w.pw_c, P->l0_w, w.nTH, w.KBC, 0, d.SP + d.ST, H, H, d.PO, XD, d.PI, s, w.TMC));
   ZTRY(pack(w.pw_l2c, P->l2_w, w.nTH, w.KBH, 4, H, 16, H, d.PO, H, 0, s, w.TMC));   // layer2's root tile, per tile

@@ -31,6 +31,8 @@ struct DecWs {
   float *W0s, *Mc, *vvec, *cvec, *pw_m, *pw_c, *CONDxf;
   float *DYxf, *DI1xf, *DH1xf, *DI0xf, *DH0xf, *D0xf, *Rxf, *dXa;         // backward fragments
   unsigned* chain;     // arrival counters + error word of the chained (run-ahead) launches; zeroed with the forward fragments
+  void* pgran;         // exchange granules + error word of the persistent decode kernel (decode_persistent.hip)
+  size_t pgran_bytes;
   size_t xf_bytes_fwd, xf_bytes_bwd;
   float *xf_base_fwd, *xf_base_bwd;
 };
@@ -96,6 +98,8 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
     w.Xxf = a.f(2 * w.KBX * XB); w.HIDxf = a.f(w.KBH * XB); w.H0xf = a.f(2 * w.KBH * XB); w.H1xf = a.f(2 * w.KBH * XB);
     w.CONDxf = a.f(w.KBC * XB);
     w.chain = (unsigned*)a.f(4096);
+    w.pgran_bytes = 36864;
+    w.pgran = a.raw(w.pgran_bytes);
     w.xf_base_fwd = w.Xxf;
     w.xf_bytes_fwd = a.off - align_up(o0, 256);
   }
@@ -117,7 +121,17 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
   return w;
 }
 
+// persistent weight-stationary decode (decode_persistent.hip)
+int dec_persistent_supported(const ZeggsDecDims& d, const DecWs& w);
+int dec_persistent_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
+                       const float* speech, const float* style, float* pose, float* rpos, float* rrot, const float* gin1,
+                       const float* h0_init, const float* h1_init, float* h0_fin, float* h1_fin, hipStream_t s);
+int dec_persistent_state();
+void dec_persistent_set_state(int v);
+int dec_persistent_errors(const DecWs& w, unsigned* out);
 // fast path entry points (decoder_fast.hip)
+int dec_fast_merge_prep(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s);
+void dec_timing_mark(int i, hipStream_t s);
 int dec_fast_supported(const ZeggsDecDims& d);
 int dec_fast_pack_fwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s);
 int dec_fast_pack_bwd(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s);
