@@ -229,10 +229,18 @@ def decode_rate(de, dev, T=1801):
         torch.cuda.synchronize()
         dt_ = time.perf_counter() - t0
         sweep = sweep_ms(0) * 1e-3 / (T - 1)
+        # the same rollout as a chain of stage launches (3 per frame), for comparison
+        ops.set_option("persistent", 0)
+        ops.decoder_core(*args)
+        torch.cuda.synchronize()
+        chain_us = sweep_ms(0) * 1e3 / (T - 1)
+        ops.set_option("persistent", 1)
     de.train()
     ach = step_bytes(1) / sweep / 1e9
     return {"value": round((T - 1) / dt_, 1), "unit": "frames/s", "us_per_frame": round(dt_ * 1e6 / (T - 1), 2),
-            "config": f"B=1 autoregressive rollout of {T - 1} frames, no_grad ring path",
+            "config": f"B=1 autoregressive rollout of {T - 1} frames, no_grad: weight-stationary persistent kernel "
+                      f"(one launch, weights in registers, granule exchange between CUs)",
+            "stage_launch_chain_us_per_frame": round(chain_us, 2),
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "us_per_step": round(sweep * 1e6, 2),
                          "algorithmic_bytes_per_step": step_bytes(1)}}

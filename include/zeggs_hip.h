@@ -165,9 +165,12 @@ int zeggs_decoder_fwd_state(const ZeggsDecDims*, const ZeggsDecParams*, const Ze
                             const float* rpos0, const float* rrot0, const float* gaze, const float* speech,
                             const float* style, float* pose, float* rpos, float* rrot, const float* h_in,
                             float* h_out, void* ws, size_t ws_bytes, void* stream);
-/* dpose [B,T,PO], drpos [B,T,3], drrot [B,T,4] (frame 0 ignored) -> parameter grads, dspeech [B,T,SP],
- * dstyle [B,T,ST] */
-/* "chain" option (zeggs_set_option("chain", 1), inference rollouts with B <= 2): consecutive stage launches alternate
+/* Inference rollouts with B = 1 (generate.py's regime) run as ONE persistent launch by default (option "persistent",
+ * csrc/decode_persistent.hip): every CU keeps its slice of the weights in registers for the whole rollout and the CUs
+ * exchange the 4-9 KB step vectors as data-tagged granules; the first use on a process is validated (bounded waits,
+ * error word, automatic fall-back to the stage launches).  zeggs_set_option("persistent", 0) forces the stage launches.
+ *
+ * "chain" option (zeggs_set_option("chain", 1), stage-launch rollouts with B <= 2; measured SLOWER, kept for the record): consecutive stage launches alternate
  * between the caller's stream and a library-owned second stream and hand over through device-side arrival counters, so
  * each launch fetches its weights while its predecessor still runs.  Every device-side wait is bounded; this returns the
  * error word of the last rollout on `ws` (0 = all hand-offs completed).  Synchronises the device. */
@@ -175,6 +178,8 @@ int zeggs_decoder_chain_errors(const ZeggsDecDims*, int training, void* ws, size
 /* measurement builds (-DZEGGS_CHTIME) only: 100 MHz wall-clock stamps of the phases of the last 16 chained launches */
 int zeggs_decoder_chain_stamps(const ZeggsDecDims*, int training, void* ws, size_t ws_bytes,
                                unsigned long long* out /* host [16][2][16] */);
+/* dpose [B,T,PO], drpos [B,T,3], drrot [B,T,4] (frame 0 ignored) -> parameter grads, dspeech [B,T,SP],
+ * dstyle [B,T,ST] */
 int zeggs_decoder_bwd(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDecStats*, const float* gaze,
                       const float* pose, const float* rpos, const float* rrot, const float* dpose,
                       const float* drpos, const float* drrot, const ZeggsDecGrads*, float* dspeech,

@@ -161,5 +161,14 @@ if __name__ == "__main__":
     ap.add_argument("--out", default=str(ROOT / "profiles" / "r02_cpu_reference.json"))
     a = ap.parse_args()
     res = measure(a.iters, a.frames)
+    # the oracle PORT on the same box (bench.py falls back to it where /root/reference is absent): the port/reference
+    # ratio measured here is what makes a port figure from another host comparable
+    sys.path.insert(0, str(ROOT))
+    import bench
+    threads = min(bench.physical_cores(), 16)
+    fps, dt_ = bench.cpu_port_train(bench.build_dataset(n_train=4), threads)
+    res["port_on_build_box"] = {"train": {"threads": threads, "frames_per_s": round(fps, 1), "s_per_iteration": round(dt_, 2)},
+                                "decode": {"threads": 1, "frames_per_s": round(bench.cpu_port_decode(), 1)},
+                                "mel": {"threads": 1, "anim_frames_per_s": round(bench.cpu_port_mel(), 1)}}
     Path(a.out).write_text(json.dumps(res, indent=1))
     print(json.dumps(res))

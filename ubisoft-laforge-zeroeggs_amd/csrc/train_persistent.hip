@@ -1,0 +1,441 @@
+// Weight-stationary persistent FORWARD rollout of the training step (batch <= 32): the 255 decoder steps of a window as
+// ONE launch.  Same idea as decode_persistent.hip -- the 75.7 MB of per-step weights fit in the register files of the
+// 256 CUs, so nothing is re-streamed per step -- but with batch 32 the products are MFMA tiles and the exchanged vectors
+// are 128 KB, so the details differ:
+//   * workgroup c (512 threads, one per CU) owns hidden units 4c..4c+3 of both GRU layers as ONE 16-row MFMA tile of
+//     virtual rows (r, z, n_input, n_hidden) x 4 units (the n gate needs its input and hidden sums apart:
+//     n = tanh(W_in x + b_in + r (W_hn h + b_hn)), nn.GRU), and one 16-row tile of the output stage: rows 4c..4c+3 of the
+//     folded layer0 (M = W0[:, :PO] diag(sigma_o/sigma_i) W2, decoder_fast.hip), output rows c, c+256, ... of layer2 and
+//     layer2's six root rows (the root integration is evaluated redundantly in every workgroup);
+//   * the 8 waves split the contraction; a wave keeps its k-blocks of the two GRU tiles in registers (26 + 16 float4 in
+//     MFMA A-fragment order, packed once per optimizer step by tp_pack_k) and of the output tile in LDS;
+//   * activations travel in B-fragment order through WRITE-ONCE, time-major operand buffers (one contiguous operand per
+//     phase and step: [hid_t | x_t | h0_{t-1}], [h0_t | h1_{t-1}], [h1_t | cond_{t+1}]), published with write-through
+//     stores; because no address is ever rewritten inside a rollout, a consumer needs no cache invalidation: it waits on
+//     the producers' arrival counter (sharded, monotonic) and then simply loads lines nobody has cached yet;
+//   * canonical copies (Gin, H0, H1, saved gates, pose / root outputs) are written exactly where the stage kernels write
+//     them, so the BPTT sweep and the weight-gradient GEMMs are unchanged.
+// Every wait is bounded; on give-up the error word is set and the host redoes the rollout with the stage kernels.
+#include "decoder_ws.h"
+#include "dec_math.h"
+#include "gemm.h"
+#include "kernels.h"
+
+int g_train_persistent = 0;      // zeggs_set_option("train_persistent", 0/1)
+static int g_tp_ok = -1;
+
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+constexpr int TH = 1024, TTHR = 512, TNCU = 256, TJ0 = 26, TJ1 = 16, TJ3 = 9, TSPIN = 1 << 21;
+constexpr int TSH = 8, TSTR = 32, TRING = 4;
+
+struct TArgs {
+  ZeggsDecDims d;
+  ZeggsDecStats st;
+  int XD, GL, KBX, KBC, KB0, KB3, POL;
+  const f4 *PW0, *PW1, *PW3;                 // per-workgroup fragment packs [256][KB][64]
+  float *G0, *G1, *G3;                       // operand fragments, time-major [T][KB*][NB][64][4]
+  float *Gin, *H0, *H1, *GT0, *GT1;          // canonical saves (time-major)
+  const float *b_ih0, *b_hh0, *b_ih1, *b_hh1, *cvec, *l0_w, *l2_b;
+  const float* gaze;
+  float *pose, *rpos, *rrot;
+  unsigned *cnt, *err;
+};
+
+__device__ __forceinline__ void stp(float* p, float v) {       // published: write-through
+  __hip_atomic_store((gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ long xfi(int b, int k, int NB) {   // B-fragment position of (batch row, k)
+  return ((((long)(k >> 4) * NB + (b >> 4)) * 64 + ((((k >> 2) & 3) << 4) | (b & 15))) << 2) | (k & 3);
+}
+
+// wave 0: lanes 0..7 poll one shard each until the sum reaches `expect`; returns false on give-up
+__device__ __forceinline__ bool tp_wait(const unsigned* c, unsigned expect) {
+  const int lane = threadIdx.x & 63;
+  for (unsigned spins = 0;; ++spins) {
+    unsigned v = lane < TSH ? __hip_atomic_load((gu32*)(c + lane * TSTR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (__builtin_amdgcn_readfirstlane(v) >= expect) return true;
+    if (spins > TSPIN) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// one phase's products: acc[nb] += W (registers or LDS, A fragments) x X (global B fragments), NJ k-blocks of this wave
+template <int NB, int NJ, bool WLDS>
+__device__ __forceinline__ void tp_mma(const f4 (&wr)[NJ], const f4* wl, const f4* __restrict__ xp, int nblk, f4 (&acc)[NB]) {
+  // two k-blocks per group, the next group's activation loads in flight while this one feeds the matrix cores
+  constexpr int NG = (NJ + 1) / 2;
+  f4 xa[2][NB], xb[2][NB];
+  auto load = [&](f4 (&x)[2][NB], int g) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = 2 * g + u;
+      const int ic = i < nblk ? i : nblk - 1;            // clamped (surplus weights are zero)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) x[u][nb] = xp[((long)ic * NB + nb) * 64];
+    }
+  };
+  auto comp = [&](const f4 (&x)[2][NB], int g) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = 2 * g + u;
+      if (i < NJ) {
+        const f4 wv = WLDS ? wl[i * 64] : wr[i < NJ ? i : 0];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], x[u][nb][c], acc[nb], 0, 0, 0);
+      }
+    }
+  };
+  load(xa, 0);
+#pragma unroll
+  for (int g = 0; g < NG; g += 2) {
+    if (g + 1 < NG) load(xb, g + 1);
+    comp(xa, g);
+    if (g + 2 < NG) load(xa, g + 2);
+    if (g + 1 < NG) comp(xb, g + 1);
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
+  constexpr int BP = 16 * NB;
+  __shared__ f4 red[8][NB][64];
+  __shared__ f4 fin[NB][64];
+  __shared__ f4 w3[8 * TJ3 * 64];             // output-stage weights of this workgroup (72 KB)
+  __shared__ float gsh[BP * 3];               // normalised gaze direction of x_{t+1} per batch row
+  __shared__ float cA[4][12];                 // biases of the 4 units: b_ih0, b_hh0, b_ih1, b_hh1 (r, z, n)
+  __shared__ float cB[16][8];                 // output-stage row constants
+  __shared__ int fail;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = blockIdx.x;
+  const ZeggsDecDims& d = a.d;
+  const int B = d.B, T = d.T, H = TH, PO = d.PO, GL = a.GL;
+  const long sG = (long)B * GL, sH = (long)B * H, XB = 256L * NB;
+  // this wave's k-block ranges
+  const int k0a = wave * a.KB0 / 8, n0 = (wave + 1) * a.KB0 / 8 - k0a;
+  const int k1a = wave * 16, n1 = 16;
+  const int k3a = wave * a.KB3 / 8, n3 = (wave + 1) * a.KB3 / 8 - k3a;
+  // ---------------------------------------------------------------- weights -> registers / LDS (once per rollout)
+  f4 wr0[TJ0], wr1[TJ1];
+  {
+    const f4* p0 = a.PW0 + ((long)c * a.KB0 + k0a) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < TJ0; ++i) { f4 v = p0[(long)(i < n0 ? i : n0 - 1) * 64]; wr0[i] = i < n0 ? v : f4{0.f, 0.f, 0.f, 0.f}; }
+    const f4* p1 = a.PW1 + ((long)c * 128 + k1a) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < TJ1; ++i) wr1[i] = p1[(long)i * 64];
+    const f4* p3 = a.PW3 + ((long)c * a.KB3 + k3a) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < TJ3; ++i) { f4 v = p3[(long)(i < n3 ? i : n3 - 1) * 64]; w3[(wave * TJ3 + i) * 64 + lane] = i < n3 ? v : f4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  if (tid < 4) {
+    const int U = 4 * c + tid;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      cA[tid][g] = a.b_ih0[g * H + U]; cA[tid][3 + g] = a.b_hh0[g * H + U];
+      cA[tid][6 + g] = a.b_ih1[g * H + U]; cA[tid][9 + g] = a.b_hh1[g * H + U];
+    }
+    cB[tid][0] = a.cvec[U];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cB[tid][1 + k] = a.l0_w[(long)U * a.XD + PO + k];
+  } else if (tid < 9) {
+    const int col = c + TNCU * (tid - 4);
+    const bool v = col < PO;
+    cB[tid][0] = v ? a.l2_b[col] : 0.f; cB[tid][1] = v ? a.st.out_std[col] : 0.f; cB[tid][2] = v ? a.st.out_mean[col] : 0.f;
+    cB[tid][3] = v ? a.st.in_mean[col] : 0.f; cB[tid][4] = v ? a.st.in_std[col] : 1.f; cB[tid][5] = v ? 1.f : 0.f;
+  } else if (tid < 15) {
+    cB[tid][0] = a.l2_b[tid - 9]; cB[tid][1] = a.st.out_std[tid - 9]; cB[tid][2] = a.st.out_mean[tid - 9];
+  }
+  if (tid == 0) fail = 0;
+  // GRU epilogue item of this thread: unit eu, batch row eb; the previous hidden values stay in registers for the rollout
+  const int eu = tid / BP, eb = tid % BP;
+  const bool gact = tid < 4 * BP && eb < B;
+  const int EU = 4 * c + (eu & 3);
+  float hp0 = 0.f, hp1 = 0.f;
+  if (gact) { hp0 = a.H0[(long)eb * H + EU]; hp1 = a.H1[(long)eb * H + EU]; }      // state before the first generated frame
+  __syncthreads();
+  const float* finf = (const float*)fin;
+  auto FV = [&](int vcol, int b) -> float {
+    return finf[((((b >> 4)) * 64 + (((vcol >> 2) << 4) | (b & 15))) << 2) | (vcol & 3)];
+  };
+  auto reduce = [&](f4 (&acc)[NB]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) red[wave][nb][lane] = acc[nb];
+    __syncthreads();
+    if (tid < NB * 64) {
+      const int nb = tid / 64, l = tid % 64;
+      f4 s = red[0][nb][l];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) s += red[w][nb][l];
+      fin[nb][l] = s;
+    }
+    __syncthreads();
+  };
+  auto wait_phase = [&](long p) {     // all workgroups have finished phase instance p (p < 0: nothing to wait for)
+    if (p >= 0) {
+      if (wave == 0 && !tp_wait(a.cnt + (p & (TRING - 1)) * (TSH * TSTR), (unsigned)((p / TRING + 1) * gridDim.x))) fail = 1;
+    }
+    __syncthreads();
+  };
+  auto arrive = [&](long p) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_fetch_add((gu32*)(a.cnt + (p & (TRING - 1)) * (TSH * TSTR) + (c & (TSH - 1)) * TSTR), 1u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  for (int t = 1; t < T; ++t) {
+    const bool next = t + 1 < T;
+    const long p1 = 3L * (t - 1), p2 = p1 + 1, p3 = p1 + 2;
+    f4 acc[NB];
+    // ================================================================ GRU layer 0 : [hid_t | x_t | h0_{t-1}]
+    wait_phase(p1 - 1);
+    if (fail) break;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+    tp_mma<NB, TJ0, false>(wr0, nullptr, (const f4*)(a.G0 + (long)t * a.KB0 * XB) + (long)k0a * NB * 64 + lane, n0, acc);
+    reduce(acc);
+    if (gact) {
+      const float* k_ = cA[eu];
+      const float r = d_sigmoid(FV(4 * eu, eb) + k_[0] + k_[3]);
+      const float z = d_sigmoid(FV(4 * eu + 1, eb) + k_[1] + k_[4]);
+      const float nh = FV(4 * eu + 3, eb) + k_[5];
+      const float nn = tanhf(FV(4 * eu + 2, eb) + k_[2] + r * nh);
+      const float h = (1.f - z) * nn + z * hp0;
+      hp0 = h;
+      const long i = (long)t * sH + (long)eb * H + EU;
+      a.H0[i] = h;
+      ((f4*)a.GT0)[i] = f4{r, z, nn, nh};
+      stp(a.G1 + (long)t * 128 * XB + xfi(eb, EU, NB), h);                                   // [h0_t | .] of layer 1
+      if (next) stp(a.G0 + (long)(t + 1) * a.KB0 * XB + (long)(64 + a.KBX) * XB + xfi(eb, EU, NB), h);   // [. | . | h0_t] of t+1
+    }
+    arrive(p1);
+    // ================================================================ GRU layer 1 : [h0_t | h1_{t-1}]
+    wait_phase(p2 - 1);
+    if (fail) break;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+    tp_mma<NB, TJ1, false>(wr1, nullptr, (const f4*)(a.G1 + (long)t * 128 * XB) + (long)k1a * NB * 64 + lane, n1, acc);
+    reduce(acc);
+    if (gact) {
+      const float* k_ = cA[eu];
+      const float r = d_sigmoid(FV(4 * eu, eb) + k_[6] + k_[9]);
+      const float z = d_sigmoid(FV(4 * eu + 1, eb) + k_[7] + k_[10]);
+      const float nh = FV(4 * eu + 3, eb) + k_[11];
+      const float nn = tanhf(FV(4 * eu + 2, eb) + k_[8] + r * nh);
+      const float h = (1.f - z) * nn + z * hp1;
+      hp1 = h;
+      const long i = (long)t * sH + (long)eb * H + EU;
+      a.H1[i] = h;
+      ((f4*)a.GT1)[i] = f4{r, z, nn, nh};
+      stp(a.G3 + (long)t * a.KB3 * XB + xfi(eb, EU, NB), h);                                 // [h1_t | .] of the output stage
+      if (next) stp(a.G1 + (long)(t + 1) * 128 * XB + 64 * XB + xfi(eb, EU, NB), h);        // [. | h1_t] of t+1
+    }
+    arrive(p2);
+    // ================================================================ output stage : [h1_t | cond_{t+1}]
+    wait_phase(p3 - 1);
+    if (fail) break;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+    tp_mma<NB, TJ3, true>(*(const f4(*)[TJ3])nullptr, w3 + wave * TJ3 * 64 + lane,
+                          (const f4*)(a.G3 + (long)t * a.KB3 * XB) + (long)k3a * NB * 64 + lane, n3, acc);
+    reduce(acc);
+    {
+      const int vc = tid / BP, b = tid % BP;
+      float* gnext = a.Gin + (long)(t + 1) * sG;                       // canonical [hid | x] row of step t+1
+      float* xnext = a.G0 + (long)(t + 1) * a.KB0 * XB;                // its fragment copy
+      if (vc == 9 && b < B) {     // root integration of batch row b (ZEGGS/modules.py:139-176), every workgroup
+        float p[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) p[q] = (FV(9 + q, b) + cB[9 + q][0]) * cB[9 + q][1] + cB[9 + q][2];
+        const float* rq = a.rrot + ((long)b * T + t - 1) * 4;
+        const float* rp = a.rpos + ((long)b * T + t - 1) * 3;
+        const Q4 q = Q4{rq[0], rq[1], rq[2], rq[3]};
+        const V3 pos = v3(rp[0], rp[1], rp[2]);
+        const V3 npos = quat_mul_vec(q, d.dt * v3(p[0], p[1], p[2])) + pos;
+        const V3 uu = quat_mul_vec(q, d.dt * v3(p[3], p[4], p[5]));
+        const Q4 nq = quat_mul(quat_exp(0.5f * uu), q);
+        float genc[3] = {0.f, 0.f, 0.f};
+        if (next) {
+          const float* gz = a.gaze + ((long)b * T + t + 1) * 3;
+          const V3 gd = quat_mul_vec(quat_inv(nq), v3(gz[0], gz[1], gz[2]) - npos);
+          genc[0] = (gd.x - a.st.in_mean[PO]) / a.st.in_std[PO];
+          genc[1] = (gd.y - a.st.in_mean[PO + 1]) / a.st.in_std[PO + 1];
+          genc[2] = (gd.z - a.st.in_mean[PO + 2]) / a.st.in_std[PO + 2];
+        }
+        gsh[b * 3] = genc[0]; gsh[b * 3 + 1] = genc[1]; gsh[b * 3 + 2] = genc[2];
+        if (c == 0) {
+          float* op = a.rpos + ((long)b * T + t) * 3;
+          stp(op, npos.x); stp(op + 1, npos.y); stp(op + 2, npos.z);     // read by every workgroup one step later
+          float* oq = a.rrot + ((long)b * T + t) * 4;
+          stp(oq, nq.w); stp(oq + 1, nq.x); stp(oq + 2, nq.y); stp(oq + 3, nq.z);
+          if (next)
+            for (int k = 0; k < 3; ++k) {
+              gnext[(long)b * GL + H + PO + k] = genc[k];
+              stp(xnext + 64 * XB + xfi(b, PO + k, NB), genc[k]);
+            }
+        }
+      } else if (vc >= 4 && vc < 9 && b < B && cB[vc][5] != 0.f) {
+        const float* k_ = cB[vc];
+        const int col = c + TNCU * (vc - 4);
+        const float pv = (FV(vc, b) + k_[0]) * k_[1] + k_[2];
+        a.pose[((long)b * T + t) * PO + col] = pv;
+        if (next) {
+          const float e = (pv - k_[3]) / k_[4];
+          gnext[(long)b * GL + H + col] = e;
+          stp(xnext + 64 * XB + xfi(b, col, NB), e);
+        }
+      }
+      __syncthreads();
+      if (next && vc < 4 && b < B) {
+        const float* k_ = cB[vc];
+        const int col = 4 * c + vc;
+        const float val = d_elu(FV(vc, b) + k_[0] + k_[1] * gsh[b * 3] + k_[2] * gsh[b * 3 + 1] + k_[3] * gsh[b * 3 + 2]);
+        gnext[(long)b * GL + col] = val;
+        stp(xnext + xfi(b, col, NB), val);
+      }
+    }
+    arrive(p3);
+  }
+  if (fail && tid == 0) atomicOr(a.err, 1u);
+}
+
+// value of virtual row i, contraction index k of workgroup c's tile for phase ph (0: GRU l0, 1: GRU l1, 3: output stage)
+struct TPackArgs {
+  f4 *PW0, *PW1, *PW3;
+  const float *w_ih0, *w_hh0, *w_ih1, *w_hh1, *l2_w, *l0_w, *Mc;
+  int XD, KBX, KBC, KB0, KB3, PO, PI, NC;
+};
+__device__ __forceinline__ float tp_value(const TPackArgs& p, int ph, int c, int i, int k) {
+  const int H = TH;
+  if (ph <= 1) {
+    const int u = i >> 2, g = i & 3, U = 4 * c + u;          // g: 0 r, 1 z, 2 n (input side), 3 n (hidden side)
+    const long row = (long)(g < 2 ? g : 2) * H + U;
+    if (ph == 0) {
+      const int KIN = H + p.XD;
+      if (k < H) return g == 3 ? 0.f : p.w_ih0[row * KIN + k];                                // hid
+      if (k < H + 16 * p.KBX) { const int kx = k - H; return (g == 3 || kx >= p.XD) ? 0.f : p.w_ih0[row * KIN + H + kx]; }
+      const int kh = k - H - 16 * p.KBX;
+      return g == 2 ? 0.f : p.w_hh0[row * H + kh];
+    }
+    if (k < H) return g == 3 ? 0.f : p.w_ih1[row * H + k];
+    return g == 2 ? 0.f : p.w_hh1[row * H + (k - H)];
+  }
+  if (i < 4) {
+    const long R = 4 * c + i;
+    if (k < H) return p.Mc[R * H + k];
+    return (k - H) < p.NC ? p.l0_w[R * p.XD + p.PI + (k - H)] : 0.f;
+  }
+  if (k >= H) return 0.f;
+  if (i < 9) { const int col = c + TNCU * (i - 4); return col < p.PO ? p.l2_w[(long)col * H + k] : 0.f; }
+  if (i < 15) return p.l2_w[(long)(i - 9) * H + k];
+  return 0.f;
+}
+__global__ void tp_pack_k(TPackArgs p) {
+  const long n0 = (long)TNCU * p.KB0 * 64, n1 = (long)TNCU * 128 * 64, n3 = (long)TNCU * p.KB3 * 64;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n0 + n1 + n3; idx += (long)gridDim.x * blockDim.x) {
+    int ph; long r = idx; f4* dst; int KB;
+    if (r < n0) { ph = 0; dst = p.PW0; KB = p.KB0; }
+    else if (r < n0 + n1) { ph = 1; r -= n0; dst = p.PW1; KB = 128; }
+    else { ph = 3; r -= n0 + n1; dst = p.PW3; KB = p.KB3; }
+    const int lane = (int)(r & 63);
+    const long ck = r >> 6;
+    const int kb = (int)(ck % KB), c = (int)(ck / KB);
+    const int i = lane & 15, kk = 16 * kb + 4 * (lane >> 4);
+    f4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = tp_value(p, ph, c, i, kk + q);
+    dst[r] = v;
+  }
+}
+
+// canonical [B, ld] (columns off .. off+K) -> fragments at k offset kofs of an operand buffer
+__global__ void tp_xfrag_k(float* xf, const float* src, long ld, int off, int K, int B, int NB, int kofs) {
+  long n = (long)B * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K), b = (int)(i / K);
+    xf[xfi(b, kofs + k, NB)] = src[(long)b * ld + off + k];
+  }
+}
+// speech / style columns of every step: x part of G0[t] (t >= 1) and the cond part of G3[t] (cond_{t+1})
+__global__ void tp_cond_k(ZeggsDecDims d, const float* speech, const float* style, float* G0, float* G3, int KB0, int KB3,
+                          int NB) {
+  const int XC = d.SP + d.ST;
+  const long XB = 256L * NB, n = (long)(d.T - 1) * d.B * XC;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % XC);
+    const long r = i / XC;
+    const int b = (int)(r % d.B), t = 1 + (int)(r / d.B);
+    const float v = cc < d.SP ? speech[((long)b * d.T + t) * d.SP + cc] : style[((long)b * d.T + t) * d.ST + (cc - d.SP)];
+    G0[(long)t * KB0 * XB + 64 * XB + xfi(b, d.PI + cc, NB)] = v;
+    if (t >= 2) G3[(long)(t - 1) * KB3 * XB + 64 * XB + xfi(b, cc, NB)] = v;
+  }
+}
+
+}  // namespace
+
+int dec_tp_supported(const ZeggsDecDims& d, const DecWs& w) {
+  return !d.film && d.H == TH && d.B <= 32 && d.T >= 4 && d.PI == d.PO + 3 && 64 + w.KBX + 64 <= 8 * TJ0 &&
+         64 + w.KBC <= 8 * TJ3 && d.PO <= 5 * TNCU && d.PO >= 16 && w.G0xf != nullptr;
+}
+int dec_tp_state() { return g_tp_ok; }
+void dec_tp_set_state(int v) { g_tp_ok = v; }
+
+// once per optimizer step: the per-workgroup fragment packs (needs Mc / cvec: dec_fast_merge_prep)
+int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s) {
+  TPackArgs p{(f4*)w.tp_w0, (f4*)w.tp_w1, (f4*)w.tp_w3, P->w_ih0, P->w_hh0, P->w_ih1, P->w_hh1, P->l2_w, P->l0_w, w.Mc,
+              w.XD, w.KBX, w.KBC, 64 + w.KBX + 64, 64 + w.KBC, d.PO, d.PI, d.SP + d.ST};
+  hipLaunchKernelGGL(tp_pack_k, dim3(8192), dim3(256), 0, s, p);
+  ZLAUNCH_CHECK("tp_pack");
+  return 0;
+}
+
+// the rollout; H0 / H1 slot 0, Gin slot 1 (hid_1 | x_1) and frame 0 of pose / rpos / rrot are prepared by the caller
+int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
+               const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s) {
+  const int B = d.B, H = d.H, NB = w.NB, KB0 = 64 + w.KBX + 64, KB3 = 64 + w.KBC;
+  const long XB = 256L * NB, sG = (long)B * w.GL;
+  int dev = 0, ncu = 0;
+  ZCHECK(hipGetDevice(&dev) == hipSuccess, "hipGetDevice failed");
+  ZCHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess, "device query failed");
+  ZCHECK(ncu >= TNCU, "persistent training rollout needs %d CUs (device has %d)", TNCU, ncu);
+  // operand buffers: zero (pad rows / pad columns must be finite), then the inputs that do not depend on the rollout
+  ZTRY(k_fill(w.G0xf, (long)d.T * KB0 * XB, 0.f, s));
+  ZTRY(k_fill(w.G1xf, (long)d.T * 128 * XB, 0.f, s));
+  ZTRY(k_fill(w.G3xf, (long)d.T * KB3 * XB, 0.f, s));
+  ZTRY(k_fill((float*)w.tp_cnt, 2048, 0.f, s));
+  hipLaunchKernelGGL(tp_cond_k, dim3(1024), dim3(256), 0, s, d, speech, style, w.G0xf, w.G3xf, KB0, KB3, NB);
+  auto conv = [&](float* xf, const float* src, long ld, int off, int K, int kofs) {
+    long n = (long)B * K, g = (n + 255) / 256;
+    hipLaunchKernelGGL(tp_xfrag_k, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, s, xf, src, ld, off, K, B, NB, kofs);
+  };
+  const float* gin1 = w.Gin + sG;
+  conv(w.G0xf + (long)KB0 * XB, gin1, w.GL, 0, H, 0);                         // hid_1
+  conv(w.G0xf + (long)KB0 * XB, gin1, w.GL, H, d.PI, 16 * 64);                // pose / gaze columns of x_1
+  conv(w.G0xf + (long)KB0 * XB, w.H0, H, 0, H, 16 * (64 + w.KBX));            // h0_0
+  conv(w.G1xf + 128 * XB, w.H1, H, 0, H, 16 * 64);                            // h1_0
+  ZLAUNCH_CHECK("tp_prologue");
+  TArgs a;
+  memset(&a, 0, sizeof(a));
+  a.d = d; a.st = *st; a.XD = w.XD; a.GL = w.GL; a.KBX = w.KBX; a.KBC = w.KBC; a.KB0 = KB0; a.KB3 = KB3; a.POL = w.POL;
+  a.PW0 = (const f4*)w.tp_w0; a.PW1 = (const f4*)w.tp_w1; a.PW3 = (const f4*)w.tp_w3;
+  a.G0 = w.G0xf; a.G1 = w.G1xf; a.G3 = w.G3xf;
+  a.Gin = w.Gin; a.H0 = w.H0; a.H1 = w.H1; a.GT0 = w.GT0; a.GT1 = w.GT1;
+  a.b_ih0 = P->b_ih0; a.b_hh0 = P->b_hh0; a.b_ih1 = P->b_ih1; a.b_hh1 = P->b_hh1; a.cvec = w.cvec; a.l0_w = P->l0_w;
+  a.l2_b = P->l2_b; a.gaze = gaze; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
+  a.cnt = w.tp_cnt; a.err = w.tp_cnt + TRING * TSH * TSTR;
+  if (NB == 1) hipLaunchKernelGGL((train_fwd_persistent_k<1>), dim3(TNCU), dim3(TTHR), 0, s, a);
+  else hipLaunchKernelGGL((train_fwd_persistent_k<2>), dim3(TNCU), dim3(TTHR), 0, s, a);
+  ZLAUNCH_CHECK("train_fwd_persistent");
+  return 0;
+}
+int dec_tp_errors(const DecWs& w, unsigned* out) {
+  ZCHECK(hipMemcpy(out, w.tp_cnt + TRING * TSH * TSTR, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess,
+         "persistent training rollout: error word copy failed");
+  return 0;
+}
