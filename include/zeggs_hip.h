@@ -174,6 +174,9 @@ int zeggs_decoder_fwd_state(const ZeggsDecDims*, const ZeggsDecParams*, const Ze
  * between the caller's stream and a library-owned second stream and hand over through device-side arrival counters, so
  * each launch fetches its weights while its predecessor still runs.  Every device-side wait is bounded; this returns the
  * error word of the last rollout on `ws` (0 = all hand-offs completed).  Synchronises the device. */
+int zeggs_persistent_state(int which /* 0: B=1 decode kernel, 1: training-forward kernel */);   /* 1 ok, 0 disabled, -1 unused */
+/* measurement builds (-DZEGGS_TPTIME) only: phase stamps of the last 4 steps of the persistent training rollout */
+int zeggs_tp_stamps(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned long long* out /* host [4][2][32] */);
 int zeggs_decoder_chain_errors(const ZeggsDecDims*, int training, void* ws, size_t ws_bytes, int* out);
 /* measurement builds (-DZEGGS_CHTIME) only: 100 MHz wall-clock stamps of the phases of the last 16 chained launches */
 int zeggs_decoder_chain_stamps(const ZeggsDecDims*, int training, void* ws, size_t ws_bytes,

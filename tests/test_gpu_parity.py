@@ -509,6 +509,28 @@ def test_chained_decode_launches_match_plain_launches(B):
         assert torch.equal(a, b)                   # deterministic: no race decides a value
 
 
+@pytest.mark.parametrize("B,T", [(32, 12), (17, 6), (5, 9), (32, 4)])
+def test_persistent_training_forward_matches_stage_launches(B, T):
+    """option "train_persistent" (off by default: measured no faster than the stage launches at B=32): the
+    forward rollout of a training step as one weight-stationary launch.  Outputs and, through the unchanged BPTT that
+    consumes what the forward saved, every gradient must agree with the stage-launch forward."""
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).train()
+    try:
+        ops.set_option("train_persistent", 0)
+        out0, g0, ds0, dy0 = _rollout_with_grads(de, B, T, 21)
+        ops.set_option("train_persistent", 1)
+        out1, g1, ds1, dy1 = _rollout_with_grads(de, B, T, 21)
+        assert ops.lib().zeggs_persistent_state(1) == 1            # it really ran (validated, not fallen back)
+    finally:
+        ops.set_option("train_persistent", 0)
+    for a, b in zip(out0, out1):
+        assert float((a - b).abs().max()) < 2e-5
+    assert relerr(ds1, ds0) < 1e-4 and relerr(dy1, dy0) < 1e-4
+    for k in g0:
+        assert relerr(g1[k], g0[k]) < 1e-4, k
+
+
 @pytest.mark.parametrize("T", [4, 5, 37, 600])
 def test_persistent_decode_kernel_matches_stage_launches(T):
     """B=1 inference: the weight-stationary persistent kernel (one launch for all frames, weights in registers, data-tagged
@@ -533,6 +555,7 @@ def test_persistent_decode_kernel_matches_stage_launches(T):
             torch.cuda.synchronize()
     finally:
         ops.set_option("persistent", 1)
+    assert ops.lib().zeggs_persistent_state(0) == 1               # validated on this process, not fallen back
     for a, b in zip(outs[0], outs[1]):
         assert torch.isfinite(b).all()
         assert float((a - b).abs().max()) < 5e-5

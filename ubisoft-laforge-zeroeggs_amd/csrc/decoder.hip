@@ -22,16 +22,23 @@ extern int g_gemm_wg_target;
 extern int g_timing;
 extern int g_chain;
 extern int g_persistent;
+extern int g_train_persistent;
 extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "decoder_fast") == 0) { g_decoder_fast = value; return 0; }
   if (strcmp(name, "stage_variant") == 0) { g_stage_variant = value; return 0; }
   if (strcmp(name, "gemm_wg_target") == 0) { g_gemm_wg_target = value; return 0; }
   if (strcmp(name, "timing") == 0) { g_timing = value; return 0; }
   if (strcmp(name, "chain") == 0) { g_chain = value; return 0; }
+  if (strcmp(name, "train_persistent") == 0) { g_train_persistent = value; if (value) dec_tp_set_state(-1); return 0; }
   if (strcmp(name, "persistent") == 0) { g_persistent = value; if (value) dec_persistent_set_state(-1); return 0; }
   if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
   zeggs_set_error("unknown option %s", name);
   return -1;
+}
+
+// 1: the persistent kernel was validated on this process, 0: it failed once and is disabled, -1: not used yet
+extern "C" int zeggs_persistent_state(int which /* 0 decode (B=1), 1 training forward */) {
+  return which == 0 ? dec_persistent_state() : dec_tp_state();
 }
 
 namespace {
@@ -480,6 +487,26 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
       dec_persistent_set_state(perr == 0 ? 1 : 0);
       if (perr == 0) return save_state();
       // a bounded sweep gave up (not every workgroup resident?): disabled for this process, the stage kernels redo the rollout
+    }
+  }
+  // ---- training, batch <= 32: the forward rollout as one persistent launch (train_persistent.hip)
+  if (fast && training && g_train_persistent && dec_tp_state() != 0 && dec_tp_supported(d, w)) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing(s, &cap);
+    if (cap == hipStreamCaptureStatusNone || dec_tp_state() == 1) {
+      float* gin1 = w.Gin + sG;
+      ZTRY(gemm_nt(gin1 + H, GL, P->l0_w, XD, gin1, GL, P->l0_b, B, H, XD, ACT_ELU, 0.f, s));   // hid_1 = ELU(W0 x_1 + b0)
+      ZTRY(dec_fast_merge_prep(d, P, st, w, s));
+      ZTRY(dec_tp_pack(d, P, w, s));
+      dec_timing_mark(0, s);
+      ZTRY(dec_tp_run(d, P, st, w, gaze, speech, style, pose, rpos, rrot, s));
+      dec_timing_mark(1, s);
+      if (dec_tp_state() == 1) return save_state();
+      unsigned perr = 1;
+      ZCHECK(hipStreamSynchronize(s) == hipSuccess, "persistent training rollout: stream sync failed");
+      ZTRY(dec_tp_errors(w, &perr));
+      dec_tp_set_state(perr == 0 ? 1 : 0);
+      if (perr == 0) return save_state();
     }
   }
   if (fast) {

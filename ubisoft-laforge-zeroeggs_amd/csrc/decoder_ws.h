@@ -33,6 +33,10 @@ struct DecWs {
   unsigned* chain;     // arrival counters + error word of the chained (run-ahead) launches; zeroed with the forward fragments
   void* pgran;         // exchange granules + error word of the persistent decode kernel (decode_persistent.hip)
   size_t pgran_bytes;
+  // persistent training rollout (train_persistent.hip): per-workgroup fragment packs, write-once time-major operand
+  // fragments [T][kb][NB][64][4] of the three phases, arrival counters + error word
+  float *tp_w0, *tp_w1, *tp_w3, *G0xf, *G1xf, *G3xf;
+  unsigned* tp_cnt;
   size_t xf_bytes_fwd, xf_bytes_bwd;
   float *xf_base_fwd, *xf_base_bwd;
 };
@@ -117,6 +121,12 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
     w.xf_base_bwd = w.DYxf;
     w.xf_bytes_bwd = a.off - align_up(o0, 256);
     w.dXa = a.f(B * (long)w.XD);
+    if (d.H == 1024 && d.B <= 32) {
+      const long KB0 = 64 + w.KBX + 64, KB3 = 64 + w.KBC;
+      w.tp_w0 = a.f(256L * KB0 * BLK); w.tp_w1 = a.f(256L * 128 * BLK); w.tp_w3 = a.f(256L * KB3 * BLK);
+      w.G0xf = a.f(T * KB0 * XB); w.G1xf = a.f(T * 128 * XB); w.G3xf = a.f(T * KB3 * XB);
+      w.tp_cnt = (unsigned*)a.f(4096);
+    }
   }
   return w;
 }
@@ -129,6 +139,14 @@ int dec_persistent_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
 int dec_persistent_state();
 void dec_persistent_set_state(int v);
 int dec_persistent_errors(const DecWs& w, unsigned* out);
+// persistent training rollout (train_persistent.hip)
+int dec_tp_supported(const ZeggsDecDims& d, const DecWs& w);
+int dec_tp_state();
+void dec_tp_set_state(int v);
+int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s);
+int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
+               const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s);
+int dec_tp_errors(const DecWs& w, unsigned* out);
 // fast path entry points (decoder_fast.hip)
 int dec_fast_merge_prep(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s);
 void dec_timing_mark(int i, hipStream_t s);

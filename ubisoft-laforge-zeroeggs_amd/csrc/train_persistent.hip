@@ -101,6 +101,20 @@ __device__ __forceinline__ void tp_mma(const f4 (&wr)[NJ], const f4* wl, const f
   }
 }
 
+// -DZEGGS_TPTIME: wall-clock (100 MHz) stamps of the phases of the LAST step, workgroups 0 and 255 (tools/tp_time.py)
+#ifdef ZEGGS_TPTIME
+#define TPT(i)                                                                                              \
+  do {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (t >= T - 4 && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                  \
+      ((unsigned long long*)(a.err + 32))[((t - (T - 4)) * 2 + (blockIdx.x != 0)) * 32 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define TPT(i)
+#endif
+
 template <int NB>
 __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   constexpr int BP = 16 * NB;
@@ -157,6 +171,17 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   const int EU = 4 * c + (eu & 3);
   float hp0 = 0.f, hp1 = 0.f;
   if (gact) { hp0 = a.H0[(long)eb * H + EU]; hp1 = a.H1[(long)eb * H + EU]; }      // state before the first generated frame
+  // root thread of batch row rb (thread 9*BP + rb): the root state of its row stays in registers for the rollout
+  const bool ract = tid >= 9 * BP && tid < 10 * BP && (tid - 9 * BP) < B;
+  const int rb = tid - 9 * BP;
+  Q4 rq_ = Q4{1.f, 0.f, 0.f, 0.f};
+  V3 rp_ = v3(0.f, 0.f, 0.f);
+  if (ract) {
+    const float* rq = a.rrot + (long)rb * T * 4;
+    const float* rp = a.rpos + (long)rb * T * 3;
+    rq_ = Q4{rq[0], rq[1], rq[2], rq[3]};
+    rp_ = v3(rp[0], rp[1], rp[2]);
+  }
   __syncthreads();
   const float* finf = (const float*)fin;
   auto FV = [&](int vcol, int b) -> float {
@@ -194,12 +219,16 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     const long p1 = 3L * (t - 1), p2 = p1 + 1, p3 = p1 + 2;
     f4 acc[NB];
     // ================================================================ GRU layer 0 : [hid_t | x_t | h0_{t-1}]
+    TPT(0);
     wait_phase(p1 - 1);
     if (fail) break;
+    TPT(1);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
     tp_mma<NB, TJ0, false>(wr0, nullptr, (const f4*)(a.G0 + (long)t * a.KB0 * XB) + (long)k0a * NB * 64 + lane, n0, acc);
+    TPT(2);
     reduce(acc);
+    TPT(3);
     if (gact) {
       const float* k_ = cA[eu];
       const float r = d_sigmoid(FV(4 * eu, eb) + k_[0] + k_[3]);
@@ -214,14 +243,19 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       stp(a.G1 + (long)t * 128 * XB + xfi(eb, EU, NB), h);                                   // [h0_t | .] of layer 1
       if (next) stp(a.G0 + (long)(t + 1) * a.KB0 * XB + (long)(64 + a.KBX) * XB + xfi(eb, EU, NB), h);   // [. | . | h0_t] of t+1
     }
+    TPT(4);
     arrive(p1);
+    TPT(5);
     // ================================================================ GRU layer 1 : [h0_t | h1_{t-1}]
     wait_phase(p2 - 1);
     if (fail) break;
+    TPT(6);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
     tp_mma<NB, TJ1, false>(wr1, nullptr, (const f4*)(a.G1 + (long)t * 128 * XB) + (long)k1a * NB * 64 + lane, n1, acc);
+    TPT(7);
     reduce(acc);
+    TPT(8);
     if (gact) {
       const float* k_ = cA[eu];
       const float r = d_sigmoid(FV(4 * eu, eb) + k_[6] + k_[9]);
@@ -236,15 +270,22 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       stp(a.G3 + (long)t * a.KB3 * XB + xfi(eb, EU, NB), h);                                 // [h1_t | .] of the output stage
       if (next) stp(a.G1 + (long)(t + 1) * 128 * XB + 64 * XB + xfi(eb, EU, NB), h);        // [. | h1_t] of t+1
     }
+    TPT(9);
     arrive(p2);
+    TPT(10);
     // ================================================================ output stage : [h1_t | cond_{t+1}]
+    float gz_[3] = {0.f, 0.f, 0.f};          // gaze target of frame t+1 (an input): in flight under the products
+    if (ract && next) { const float* gz = a.gaze + ((long)rb * T + t + 1) * 3; gz_[0] = gz[0]; gz_[1] = gz[1]; gz_[2] = gz[2]; }
     wait_phase(p3 - 1);
     if (fail) break;
+    TPT(11);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
     tp_mma<NB, TJ3, true>(*(const f4(*)[TJ3])nullptr, w3 + wave * TJ3 * 64 + lane,
                           (const f4*)(a.G3 + (long)t * a.KB3 * XB) + (long)k3a * NB * 64 + lane, n3, acc);
+    TPT(12);
     reduce(acc);
+    TPT(13);
     {
       const int vc = tid / BP, b = tid % BP;
       float* gnext = a.Gin + (long)(t + 1) * sG;                       // canonical [hid | x] row of step t+1
@@ -253,17 +294,15 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
         float p[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) p[q] = (FV(9 + q, b) + cB[9 + q][0]) * cB[9 + q][1] + cB[9 + q][2];
-        const float* rq = a.rrot + ((long)b * T + t - 1) * 4;
-        const float* rp = a.rpos + ((long)b * T + t - 1) * 3;
-        const Q4 q = Q4{rq[0], rq[1], rq[2], rq[3]};
-        const V3 pos = v3(rp[0], rp[1], rp[2]);
+        const Q4 q = rq_;
+        const V3 pos = rp_;
         const V3 npos = quat_mul_vec(q, d.dt * v3(p[0], p[1], p[2])) + pos;
         const V3 uu = quat_mul_vec(q, d.dt * v3(p[3], p[4], p[5]));
         const Q4 nq = quat_mul(quat_exp(0.5f * uu), q);
+        rq_ = nq; rp_ = npos;
         float genc[3] = {0.f, 0.f, 0.f};
         if (next) {
-          const float* gz = a.gaze + ((long)b * T + t + 1) * 3;
-          const V3 gd = quat_mul_vec(quat_inv(nq), v3(gz[0], gz[1], gz[2]) - npos);
+          const V3 gd = quat_mul_vec(quat_inv(nq), v3(gz_[0], gz_[1], gz_[2]) - npos);
           genc[0] = (gd.x - a.st.in_mean[PO]) / a.st.in_std[PO];
           genc[1] = (gd.y - a.st.in_mean[PO + 1]) / a.st.in_std[PO + 1];
           genc[2] = (gd.z - a.st.in_mean[PO + 2]) / a.st.in_std[PO + 2];
@@ -271,9 +310,9 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
         gsh[b * 3] = genc[0]; gsh[b * 3 + 1] = genc[1]; gsh[b * 3 + 2] = genc[2];
         if (c == 0) {
           float* op = a.rpos + ((long)b * T + t) * 3;
-          stp(op, npos.x); stp(op + 1, npos.y); stp(op + 2, npos.z);     // read by every workgroup one step later
+          op[0] = npos.x; op[1] = npos.y; op[2] = npos.z;
           float* oq = a.rrot + ((long)b * T + t) * 4;
-          stp(oq, nq.w); stp(oq + 1, nq.x); stp(oq + 2, nq.y); stp(oq + 3, nq.z);
+          oq[0] = nq.w; oq[1] = nq.x; oq[2] = nq.y; oq[3] = nq.z;
           if (next)
             for (int k = 0; k < 3; ++k) {
               gnext[(long)b * GL + H + PO + k] = genc[k];
@@ -300,7 +339,9 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
         stp(xnext + xfi(b, col, NB), val);
       }
     }
+    TPT(14);
     arrive(p3);
+    TPT(15);
   }
   if (fail && tid == 0) atomicOr(a.err, 1u);
 }
@@ -432,6 +473,13 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   if (NB == 1) hipLaunchKernelGGL((train_fwd_persistent_k<1>), dim3(TNCU), dim3(TTHR), 0, s, a);
   else hipLaunchKernelGGL((train_fwd_persistent_k<2>), dim3(TNCU), dim3(TTHR), 0, s, a);
   ZLAUNCH_CHECK("train_fwd_persistent");
+  return 0;
+}
+extern "C" int zeggs_tp_stamps(const ZeggsDecDims* dp, void* ws, size_t ws_bytes, unsigned long long* out /* [4][2][32] */) {
+  Arena a(ws, ws_bytes);
+  DecWs w = carve_dec(*dp, 1, a);
+  ZCHECK(a.ok() && w.tp_cnt, "tp_stamps: workspace");
+  ZCHECK(hipMemcpy(out, w.tp_cnt + TRING * TSH * TSTR + 32, 4 * 2 * 32 * 8, hipMemcpyDeviceToHost) == hipSuccess, "copy");
   return 0;
 }
 int dec_tp_errors(const DecWs& w, unsigned* out) {
