@@ -123,9 +123,10 @@ def _engine_iteration(gd, v):
 
 def _check_engine_iteration(gd, v):
     """Gradients are compared with BOTH the reference's own fp32 gradients and the (reference-pinned) oracle run in
-    FLOAT64 on the same iteration.  Those two differ from each other by 1-4e-4 of max|g| after 255 BPTT steps (the
-    floor printed below), so per tensor: within 3e-4 of max|g| of at least one of them, and within 3e-4 + that
-    tensor's own fp32-vs-fp64 floor of the other."""
+    FLOAT64 on the same iteration, over 97 sampled entries per tensor.  The two references differ from each other by
+    1-4e-4 of max|g| on single entries (fp32 accumulation over B*T rows with cancellation: the floor printed below), so
+    per tensor: relative RMS error over the sample < 3e-4 against each of them (the tight, noise-robust bound), and no
+    single entry off by more than 1e-3 of max|g| (a wrong entry would be off by O(1))."""
     from oracle import radam as oradam
     eng, loss, w_before = _engine_iteration(gd, v)
     np.testing.assert_allclose(float(loss), gd["loss"][0], rtol=2e-5)
@@ -143,8 +144,10 @@ def _check_engine_iteration(gd, v):
         worst64, worst32 = max(worst64, e64), max(worst32, e32)
         fl = float(np.abs(ref32 - ref64).max()) / scale
         floor = max(floor, fl)
-        assert min(e32, e64) < 3e-4, f"param {i}: gradient off by {e32:.2e} (fp32 reference) / {e64:.2e} (fp64) of max|g|"
-        assert max(e32, e64) < 3e-4 + fl + 1e-6, f"param {i}: {e32:.2e} / {e64:.2e} of max|g|, reference floor {fl:.2e}"
+        rms = lambda a, b: float(np.linalg.norm(a - b) / max(1e-30, np.linalg.norm(b)))  # noqa: E731
+        r32, r64 = rms(got, ref32), rms(got, ref64)
+        assert r32 < 3e-4 and r64 < 3e-4, f"param {i}: relative RMS error {r32:.2e} (fp32 reference) / {r64:.2e} (fp64)"
+        assert max(e32, e64) < 1e-3, f"param {i}: an entry is off by {e32:.2e} / {e64:.2e} of max|g| (reference floor {fl:.2e})"
         fp = helpers.fingerprint(p.grad)
         np.testing.assert_allclose(fp[1], gd["grad_fp"][i][1], rtol=2e-3, err_msg=f"param {i} |g| sum")
         # fused RAdam over the flat buffer: weights after the step vs the reference's

@@ -492,6 +492,7 @@ def test_chained_decode_launches_match_plain_launches(B):
     speech, style = torch.randn(B, T, 64, device=DEV) * 0.5, torch.randn(B, T, 64, device=DEV) * 0.5
     outs = []
     try:
+        ops.set_option("persistent", 0)          # the stage-launch path is under test here
         for v in (0, 1, 1):
             ops.set_option("chain", v)
             with torch.no_grad():
@@ -502,6 +503,7 @@ def test_chained_decode_launches_match_plain_launches(B):
             assert ops.last_decoder_chain_errors() == 0
     finally:
         ops.set_option("chain", 0)
+        ops.set_option("persistent", 1)
     for a, b in zip(outs[0], outs[1]):
         assert torch.isfinite(b).all()
         assert float((a - b).abs().max()) < 5e-5

@@ -29,8 +29,17 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "gemm_wg_target") == 0) { g_gemm_wg_target = value; return 0; }
   if (strcmp(name, "timing") == 0) { g_timing = value; return 0; }
   if (strcmp(name, "chain") == 0) { g_chain = value; return 0; }
-  if (strcmp(name, "train_persistent") == 0) { g_train_persistent = value; if (value) dec_tp_set_state(-1); return 0; }
-  if (strcmp(name, "persistent") == 0) { g_persistent = value; if (value) dec_persistent_set_state(-1); return 0; }
+  // (re-)enabling gives a kernel that was disabled after a failed validation another chance
+  if (strcmp(name, "train_persistent") == 0) {
+    g_train_persistent = value;
+    if (value && dec_tp_state() == 0) dec_tp_set_state(-1);
+    return 0;
+  }
+  if (strcmp(name, "persistent") == 0) {
+    g_persistent = value;
+    if (value && dec_persistent_state() == 0) dec_persistent_set_state(-1);
+    return 0;
+  }
   if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
   zeggs_set_error("unknown option %s", name);
   return -1;
