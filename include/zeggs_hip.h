@@ -243,6 +243,18 @@ size_t zeggs_mel_range_workspace_bytes(const ZeggsMelDims*, long k0, long k1);
 int zeggs_mel_features_range(const ZeggsMelDims*, const float* wav, long n_samples, int final, const double* filterbank,
                              long k0, long k1, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* Loudness normalisation pre-pass of preprocess_audio, ZEGGS/data_pipeline.py:34-39 (pyloudnorm 0.1.0: Meter(rate)
+ * .integrated_loudness + normalize.loudness to `target` LUFS; algorithm restated in oracle/loudness.py), mono, on the device:
+ * the two K-weighting biquads as chunk-parallel float64 recurrences, 400 ms gating-block energies, absolute / relative
+ * gates, gain.  Host-prepared inputs: coef[10] (both biquads: b0 b1 b2 a1 a2), trans[8] (their `chunk`-sample homogeneous
+ * state transitions), blk_lo / blk_hi [nblocks] (device; pyloudnorm's truncated block bounds).  f32_stages != 0 stores every
+ * filter stage's output through float32, as pyloudnorm does on float32 input.  result (device): [0] LUFS, [1] gain;
+ * gain32 (device float) feeds zeggs_scale_copy(dev_scale) to apply the gain without a host round trip. */
+size_t zeggs_loudness_workspace_bytes(long n_samples, int nblocks, long chunk);
+int zeggs_loudness_gain(const float* wav, long n_samples, int rate, double target, const double* coef, const double* trans,
+                        long chunk, const long* blk_lo, const long* blk_hi, int nblocks, int f32_stages, double* result,
+                        float* gain32, void* ws, size_t ws_bytes, void* stream);
+
 /* in-place feature normalisation (x - mean) / std of ZEGGS/train.py:232-234,239 ; stdv == NULL -> scalar std */
 int zeggs_normalize_rows(float* x, long rows, int width, long ld, const float* mean, const float* stdv,
                          float std_scalar, void* stream);

@@ -124,9 +124,9 @@ def _engine_iteration(gd, v):
 def _check_engine_iteration(gd, v):
     """Gradients are compared with BOTH the reference's own fp32 gradients and the (reference-pinned) oracle run in
     FLOAT64 on the same iteration, over 97 sampled entries per tensor.  The two references differ from each other by
-    1-4e-4 of max|g| on single entries (fp32 accumulation over B*T rows with cancellation: the floor printed below), so
-    per tensor: relative RMS error over the sample < 3e-4 against each of them (the tight, noise-robust bound), and no
-    single entry off by more than 1e-3 of max|g| (a wrong entry would be off by O(1))."""
+    1-4e-4 of the sample's largest entry (fp32 accumulation over B*T rows with cancellation: the floor printed below).
+    Per tensor: every sampled entry within 3e-4 of the TENSOR's max |g| of both references (the north-star bound), and a
+    relative RMS error over the sample below 5e-4 (catches a uniformly scaled or shifted tensor)."""
     from oracle import radam as oradam
     eng, loss, w_before = _engine_iteration(gd, v)
     np.testing.assert_allclose(float(loss), gd["loss"][0], rtol=2e-5)
@@ -139,15 +139,17 @@ def _check_engine_iteration(gd, v):
         got = p.grad.flatten()[it].cpu().numpy()
         ref32 = gd["grad_samples"][off:off + len(idx)]
         ref64 = gd["grad_samples_fp64"][off:off + len(idx)]
-        scale = max(1e-7, float(np.abs(ref64).max()))
+        scale = max(1e-7, float(np.abs(ref64).max()))          # largest SAMPLED entry (for the printed figures)
+        gmax = max(scale, float(p.grad.abs().max()))            # the tensor's max |g|
         e64, e32 = float(np.abs(got - ref64).max()) / scale, float(np.abs(got - ref32).max()) / scale
         worst64, worst32 = max(worst64, e64), max(worst32, e32)
         fl = float(np.abs(ref32 - ref64).max()) / scale
         floor = max(floor, fl)
         rms = lambda a, b: float(np.linalg.norm(a - b) / max(1e-30, np.linalg.norm(b)))  # noqa: E731
         r32, r64 = rms(got, ref32), rms(got, ref64)
-        assert r32 < 3e-4 and r64 < 3e-4, f"param {i}: relative RMS error {r32:.2e} (fp32 reference) / {r64:.2e} (fp64)"
-        assert max(e32, e64) < 1e-3, f"param {i}: an entry is off by {e32:.2e} / {e64:.2e} of max|g| (reference floor {fl:.2e})"
+        assert r32 < 5e-4 and r64 < 5e-4, f"param {i}: relative RMS error {r32:.2e} (fp32 reference) / {r64:.2e} (fp64)"
+        assert max(e32, e64) * scale < 3e-4 * gmax, \
+            f"param {i}: an entry is off by {e32 * scale / gmax:.2e} / {e64 * scale / gmax:.2e} of the tensor's max|g|"
         fp = helpers.fingerprint(p.grad)
         np.testing.assert_allclose(fp[1], gd["grad_fp"][i][1], rtol=2e-3, err_msg=f"param {i} |g| sum")
         # fused RAdam over the flat buffer: weights after the step vs the reference's
@@ -290,3 +292,32 @@ def test_lr_decay_at_iteration_1000_and_resume_restores_moments(tmp_path):
     st0 = eng2.opt.state[eng2.params[0]]
     assert st0["step"] > 1000 and float((st0["exp_avg"] - g(m_saved)).abs().max()) < 1.0   # moments continued, not reset
     assert float(st0["exp_avg"].abs().max()) > 0
+
+
+def test_device_loudness_normalisation_vs_pyloudnorm_restatement():
+    """zeggs_loudness_gain (chunk-parallel K-weighting biquads, gating, gain on the device) against oracle/loudness.py, the
+    restatement of pyloudnorm 0.1.0 (parity with pyloudnorm itself: unpinned, see its header): float64 and float32 input
+    (pyloudnorm stores each filter stage back into the input's dtype), silence gaps, blocks under the absolute gate, a clip
+    barely longer than one gating block, and a 3-minute signal spanning many chunks."""
+    from oracle import loudness as olo
+    from zeggs import audio
+    fs = 16000
+    rng = np.random.default_rng(5)
+    speech = synth.synth_wav(6 * fs + 321, seed=8).astype(np.float64) / 32768.0
+    sigs = dict(speech=speech, noise=0.05 * rng.standard_normal(3 * fs),
+                gap=np.concatenate([speech[:2 * fs], np.zeros(3 * fs), 0.3 * speech[2 * fs:4 * fs], np.zeros(2 * fs + 77)]),
+                quiet=np.concatenate([0.05 * rng.standard_normal(2 * fs), 1e-5 * rng.standard_normal(3 * fs)]),
+                short=speech[:int(0.4 * fs) + 3],
+                long=np.tile(synth.synth_wav(30 * fs, seed=9).astype(np.float64) / 32768.0, 6))
+    for name, x in sigs.items():
+        for dt, tol in ((np.float64, 1e-5), (np.float32, 2e-5)):   # float32 audio only reaches the device as float32
+            xin = x.astype(np.float32).astype(dt)                  # same samples for both sides
+            ref_l = olo.Meter(fs).integrated_loudness(xin)
+            y, lufs = audio.normalize_loudness_device(xin, fs, -20.0)
+            assert abs(lufs - ref_l) < tol, (name, dt, lufs, ref_l)
+            ref_y = olo.normalize_loudness(xin, ref_l, -20.0)
+            np.testing.assert_allclose(y.cpu().numpy(), ref_y.astype(np.float32), rtol=3e-6, atol=1e-9, err_msg=name)
+    with pytest.raises(ValueError):
+        audio.normalize_loudness_device(np.zeros(int(0.4 * fs) - 1), fs)
+    with pytest.raises(ValueError, match="finite"):
+        audio.normalize_loudness_device(np.zeros(2 * fs), fs)

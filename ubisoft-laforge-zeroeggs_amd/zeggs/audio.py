@@ -147,12 +147,76 @@ def normalize_loudness(x, rate, target=-20.0):
     return np.asarray(x) * (10.0 ** ((target - lufs) / 20.0))
 
 
+def _kweighting(rate):
+    """pyloudnorm's K-weighting biquads for `rate`: [(b, a), (b, a)] with a[0] == 1 (oracle/loudness.py: IIRfilter)."""
+    out = []
+    for kind, G, Q, fc in (("high_shelf", 4.0, 1 / np.sqrt(2), 1500.0), ("high_pass", 0.0, 0.5, 38.0)):
+        A = 10 ** (G / 40.0)
+        w0 = 2.0 * np.pi * (fc / rate)
+        alpha = np.sin(w0) / (2.0 * Q)
+        if kind == "high_shelf":
+            b0 = A * ((A + 1) + (A - 1) * np.cos(w0) + 2 * np.sqrt(A) * alpha)
+            b1 = -2 * A * ((A - 1) + (A + 1) * np.cos(w0))
+            b2 = A * ((A + 1) + (A - 1) * np.cos(w0) - 2 * np.sqrt(A) * alpha)
+            a0 = (A + 1) - (A - 1) * np.cos(w0) + 2 * np.sqrt(A) * alpha
+            a1 = 2 * ((A - 1) - (A + 1) * np.cos(w0))
+            a2 = (A + 1) - (A - 1) * np.cos(w0) - 2 * np.sqrt(A) * alpha
+        else:
+            b0, b1, b2 = (1 + np.cos(w0)) / 2, -(1 + np.cos(w0)), (1 + np.cos(w0)) / 2
+            a0, a1, a2 = 1 + alpha, -2 * np.cos(w0), 1 - alpha
+        out.append((np.array([b0, b1, b2]) / a0, np.array([a0, a1, a2]) / a0))
+    return out
+
+
+def normalize_loudness_device(wav, rate, target=-20.0, device="cuda", chunk=4096):
+    """Loudness normalisation of a MONO signal on the device (zeggs_loudness_gain): chunk-parallel K-weighting filters,
+    gating-block energies, gates and gain; returns (normalised float32 tensor on `device`, LUFS).  The only host work is
+    the integer gating-block table (pyloudnorm's truncated floating-point bounds, computed with its expression)."""
+    dev = torch.device(device)
+    f32 = torch.is_tensor(wav) and wav.dtype == torch.float32 or (not torch.is_tensor(wav) and np.asarray(wav).dtype == np.float32)
+    w = torch.as_tensor(np.asarray(wav, dtype=np.float32) if not torch.is_tensor(wav) else wav, dtype=torch.float32).to(dev).contiguous()
+    n = w.numel()
+    if w.dim() != 1:
+        raise ValueError("normalize_loudness_device: mono signals only")
+    if n < 0.4 * rate:
+        raise ValueError("Audio must have length greater than the block size.")       # pyloudnorm.util.valid_audio
+    T_g, step = 0.4, 1.0 - 0.75
+    nblocks = int(np.round(((n / rate - T_g) / (T_g * step))) + 1)
+    j = np.arange(nblocks)
+    lo = np.array([int(T_g * (jj * step) * rate) for jj in j], dtype=np.int64)
+    hi = np.minimum(np.array([int(T_g * (jj * step + 1) * rate) for jj in j], dtype=np.int64), n)
+    coef, trans = [], []
+    for b, a in _kweighting(rate):
+        coef += [b[0], b[1], b[2], a[1], a[2]]
+        trans += list(np.linalg.matrix_power(np.array([[-a[1], 1.0], [-a[2], 0.0]]), int(chunk)).ravel())
+    coef, trans = (C.c_double * 10)(*coef), (C.c_double * 8)(*trans)
+    L = ops.lib()
+    L.zeggs_loudness_workspace_bytes.restype = C.c_size_t
+    ws = torch.empty(int(L.zeggs_loudness_workspace_bytes(C.c_long(n), int(nblocks), C.c_long(chunk))), dtype=torch.uint8, device=dev)
+    lo_d, hi_d = torch.as_tensor(lo).to(dev), torch.as_tensor(hi).to(dev)
+    res = torch.empty(2, dtype=torch.float64, device=dev)
+    gain = torch.empty(1, dtype=torch.float32, device=dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    rc = L.zeggs_loudness_gain(ptr(w), C.c_long(n), int(rate), C.c_double(target), coef, trans, C.c_long(chunk), ptr(lo_d),
+                               ptr(hi_d), int(nblocks), int(bool(f32)), ptr(res), ptr(gain), ptr(ws), C.c_size_t(ws.numel()),
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise RuntimeError("zeggs_loudness_gain: " + L.zeggs_last_error().decode())
+    lufs = float(res[0])
+    if not np.isfinite(lufs):
+        raise ValueError(f"integrated loudness is not finite ({lufs}): the signal is silent under the -70 LUFS gate")
+    return ops.scale_copy(w, gain), lufs
+
+
 def preprocess_audio(audio_data, anim_fs, anim_length, params, feature_type, device="cuda"):
     """Drop-in for reference data_pipeline.preprocess_audio (same arguments, returns float32 ndarray
     [anim_length, 81]); `params` may be a dict or an attribute-style config."""
     g = (lambda k: params[k]) if isinstance(params, dict) else (lambda k: getattr(params, k))
     if g("normalize_loudness"):
-        audio_data = normalize_loudness(audio_data, g("sampling_rate"), -20.0)
+        if np.ndim(audio_data) == 1 and torch.device(device).type == "cuda":
+            audio_data, _ = normalize_loudness_device(audio_data, g("sampling_rate"), -20.0, device)   # no host pass
+        else:
+            audio_data = normalize_loudness(audio_data, g("sampling_rate"), -20.0)
     if g("pre_emphasis") or not (g("centered") and g("real_amplitude") and g("normalize_range")):
         raise NotImplementedError("only the shipped audio_conf (centered, real_amplitude, normalize_range, "
                                   "no pre-emphasis) has a HIP path")

@@ -373,6 +373,7 @@ class _VaeFn(torch.autograd.Function):
                                            _stream()), "vae_reparam_fwd")
         ctx.save_for_backward(enc, eps)
         ctx.t, ctx.S = temperature, S
+        ctx.set_materialize_grads(False)
         return z, mu, lv
 
     @staticmethod
@@ -433,6 +434,7 @@ class _DecoderFn(torch.autograd.Function):
         if training:
             ctx.d, ctx.ws = d, ws
             ctx.save_for_backward(gaze, pose, rpos, rrot, *stats, *params)
+            ctx.set_materialize_grads(False)      # missing output gradients are zero-filled by our own kernel in backward
         return pose, rpos, rrot
 
     @staticmethod
@@ -521,6 +523,7 @@ class _LossFn(torch.autograd.Function):
         ctx.save_for_backward(dpose, drpos, drrot, dmu, dlv)
         ctx.unit_grad = bool(unit_grad)
         ctx.mark_non_differentiable(terms)
+        ctx.set_materialize_grads(False)      # no zero-filled gradient for the (non-differentiable) terms vector
         loss = torch.empty((), device=dev, dtype=torch.float32)
         scale_copy(terms[18:19], out=loss)
         return loss, terms
@@ -528,6 +531,8 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gterms):
         dpose, drpos, drrot, dmu, dlv = ctx.saved_tensors
+        if g is None:
+            return (None,) * 14
         if not ctx.unit_grad:        # general case: scale by the upstream scalar (device side, no host sync)
             g = _f32c(g).reshape(1)
             dpose, drpos, drrot = scale_copy(dpose, g), scale_copy(drpos, g), scale_copy(drrot, g)
