@@ -446,8 +446,11 @@ def main():
         ach = step_bytes(BATCH) / (f_us * 1e-6) / 1e9
         ach_b = step_bytes(BATCH) / (b_us * 1e-6) / 1e9
         out["roofline"] = {
-            "bound": "hbm", "kernel": "stage_k, decoder forward step = 3 launches (GRU l0, GRU l1, layer2 + pose "
-                                      "integration + next step's layer0), per-step figures at B=32",
+            "bound": "hbm", "kernel": ("train_fwd_persistent_k: the 255 forward steps of a window as ONE weight-stationary "
+                                       "launch (3 phases per step, weights in registers)"
+                                       if ops.lib().zeggs_persistent_state(1) == 1 else
+                                       "stage_k, decoder forward step = 3 launches (GRU l0, GRU l1, layer2 + pose "
+                                       "integration + next step's layer0)") + ", per-step figures at B=32",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": pmc.get("traffic_bytes_per_step") if pmc else None,
             "us_per_step": round(f_us, 2), "us_per_step_in_timed_region": round(fwd_in * 1e3 / nst, 2),

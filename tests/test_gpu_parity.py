@@ -513,9 +513,9 @@ def test_chained_decode_launches_match_plain_launches(B):
 
 @pytest.mark.parametrize("B,T", [(32, 12), (17, 6), (5, 9), (32, 4)])
 def test_persistent_training_forward_matches_stage_launches(B, T):
-    """option "train_persistent" (off by default: measured no faster than the stage launches at B=32): the
-    forward rollout of a training step as one weight-stationary launch.  Outputs and, through the unchanged BPTT that
-    consumes what the forward saved, every gradient must agree with the stage-launch forward."""
+    """option "train_persistent" (default on for batch <= 32): the forward rollout of a training step as one
+    weight-stationary launch.  Outputs and, through the unchanged BPTT that consumes what the forward saved, every
+    gradient must agree with the stage-launch forward."""
     _, de, _ = helpers.build_nets()
     de = de.to(DEV).train()
     try:
@@ -525,7 +525,7 @@ def test_persistent_training_forward_matches_stage_launches(B, T):
         out1, g1, ds1, dy1 = _rollout_with_grads(de, B, T, 21)
         assert ops.lib().zeggs_persistent_state(1) == 1            # it really ran (validated, not fallen back)
     finally:
-        ops.set_option("train_persistent", 0)
+        ops.set_option("train_persistent", 1)
     for a, b in zip(out0, out1):
         assert float((a - b).abs().max()) < 2e-5
     assert relerr(ds1, ds0) < 1e-4 and relerr(dy1, dy0) < 1e-4

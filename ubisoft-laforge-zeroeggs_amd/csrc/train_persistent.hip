@@ -21,13 +21,24 @@
 #include "gemm.h"
 #include "kernels.h"
 
-int g_train_persistent = 0;      // zeggs_set_option("train_persistent", 0/1)
+int g_train_persistent = 1;      // zeggs_set_option("train_persistent", 0/1)
 static int g_tp_ok = -1;
 
 namespace {
 
 typedef __attribute__((address_space(1))) unsigned gu32;
-constexpr int TH = 1024, TTHR = 512, TNCU = 256, TJ0 = 26, TJ1 = 16, TJ3 = 9, TSPIN = 1 << 21;
+constexpr int TH = 1024, TTHR = 512, TNCU = 256, TSPIN = 1 << 21;
+// k-blocks of a wave per phase: first the OLD part of the operand (known one phase earlier: previous hidden state,
+// speech / style columns), then the FRESH part (produced by the preceding phase).  Block j of a part is k-block
+// lo + wave + 8 j: the parts are interleaved over the 8 waves so that every wave owns old work to do before the hand-off.
+constexpr int TNO0 = 9, TNF0 = 17, TNO1 = 8, TNF1 = 8, TNO3 = 1, TNF3 = 8;
+constexpr int TJ0 = TNO0 + TNF0, TJ1 = TNO1 + TNF1, TJ3 = TNO3 + TNF3;
+constexpr int TFR0 = 135;     // GRU layer 0: k-blocks [0, 135) = hid_t and the pose / gaze columns of x_t are fresh
+__host__ __device__ inline int tp_kb(int i, int wave, int NO, int old_lo, int old_hi, int fresh_hi) {
+  if (i < NO) { const int kb = old_lo + wave + 8 * i; return kb < old_hi ? kb : -1; }
+  const int kb = wave + 8 * (i - NO);
+  return kb < fresh_hi ? kb : -1;
+}
 constexpr int TSH = 8, TSTR = 32, TRING = 4;
 
 struct TArgs {
@@ -63,19 +74,21 @@ __device__ __forceinline__ bool tp_wait(const unsigned* c, unsigned expect) {
   }
 }
 
-// one phase's products: acc[nb] += W (registers or LDS, A fragments) x X (global B fragments), NJ k-blocks of this wave
-template <int NB, int NJ, bool WLDS>
-__device__ __forceinline__ void tp_mma(const f4 (&wr)[NJ], const f4* wl, const f4* __restrict__ xp, int nblk, f4 (&acc)[NB]) {
-  // two k-blocks per group, the next group's activation loads in flight while this one feeds the matrix cores
+// products of one part of a phase: blocks j = 0..NJ-1 of this wave are k-blocks kb0 + 8 j (< hi), their weights wr[OFF + j]
+// (registers) or wl[(OFF + j) * 64] (LDS).  Two blocks per group, the next group's activation loads in flight while this
+// one feeds the matrix cores.  Blocks past `hi` are clamped: their weights are zero (tp_pack_k).
+template <int NB, int NJT, int OFF, int NJ, bool WLDS>
+__device__ __forceinline__ void tp_mma(const f4 (&wr)[NJT], const f4* wl, const f4* __restrict__ xb, int kb0, int hi,
+                                       f4 (&acc)[NB]) {
   constexpr int NG = (NJ + 1) / 2;
-  f4 xa[2][NB], xb[2][NB];
+  f4 xa[2][NB], xq[2][NB];
   auto load = [&](f4 (&x)[2][NB], int g) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int i = 2 * g + u;
-      const int ic = i < nblk ? i : nblk - 1;            // clamped (surplus weights are zero)
+      int kb = kb0 + 8 * (2 * g + u);
+      kb = kb < hi ? kb : hi - 1;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) x[u][nb] = xp[((long)ic * NB + nb) * 64];
+      for (int nb = 0; nb < NB; ++nb) x[u][nb] = xb[((long)kb * NB + nb) * 64];
     }
   };
   auto comp = [&](const f4 (&x)[2][NB], int g) {
@@ -83,7 +96,7 @@ __device__ __forceinline__ void tp_mma(const f4 (&wr)[NJ], const f4* wl, const f
     for (int u = 0; u < 2; ++u) {
       const int i = 2 * g + u;
       if (i < NJ) {
-        const f4 wv = WLDS ? wl[i * 64] : wr[i < NJ ? i : 0];
+        const f4 wv = WLDS ? wl[(OFF + i) * 64] : wr[OFF + i < NJT ? OFF + i : 0];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -94,10 +107,10 @@ __device__ __forceinline__ void tp_mma(const f4 (&wr)[NJ], const f4* wl, const f
   load(xa, 0);
 #pragma unroll
   for (int g = 0; g < NG; g += 2) {
-    if (g + 1 < NG) load(xb, g + 1);
+    if (g + 1 < NG) load(xq, g + 1);
     comp(xa, g);
     if (g + 2 < NG) load(xa, g + 2);
-    if (g + 1 < NG) comp(xb, g + 1);
+    if (g + 1 < NG) comp(xq, g + 1);
   }
 }
 
@@ -129,22 +142,18 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   const ZeggsDecDims& d = a.d;
   const int B = d.B, T = d.T, H = TH, PO = d.PO, GL = a.GL;
   const long sG = (long)B * GL, sH = (long)B * H, XB = 256L * NB;
-  // this wave's k-block ranges
-  const int k0a = wave * a.KB0 / 8, n0 = (wave + 1) * a.KB0 / 8 - k0a;
-  const int k1a = wave * 16, n1 = 16;
-  const int k3a = wave * a.KB3 / 8, n3 = (wave + 1) * a.KB3 / 8 - k3a;
   // ---------------------------------------------------------------- weights -> registers / LDS (once per rollout)
   f4 wr0[TJ0], wr1[TJ1];
   {
-    const f4* p0 = a.PW0 + ((long)c * a.KB0 + k0a) * 64 + lane;
+    const f4* p0 = a.PW0 + ((long)(c * 8 + wave) * TJ0) * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < TJ0; ++i) { f4 v = p0[(long)(i < n0 ? i : n0 - 1) * 64]; wr0[i] = i < n0 ? v : f4{0.f, 0.f, 0.f, 0.f}; }
-    const f4* p1 = a.PW1 + ((long)c * 128 + k1a) * 64 + lane;
+    for (int i = 0; i < TJ0; ++i) wr0[i] = p0[(long)i * 64];
+    const f4* p1 = a.PW1 + ((long)(c * 8 + wave) * TJ1) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < TJ1; ++i) wr1[i] = p1[(long)i * 64];
-    const f4* p3 = a.PW3 + ((long)c * a.KB3 + k3a) * 64 + lane;
+    const f4* p3 = a.PW3 + ((long)(c * 8 + wave) * TJ3) * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < TJ3; ++i) { f4 v = p3[(long)(i < n3 ? i : n3 - 1) * 64]; w3[(wave * TJ3 + i) * 64 + lane] = i < n3 ? v : f4{0.f, 0.f, 0.f, 0.f}; }
+    for (int i = 0; i < TJ3; ++i) w3[(wave * TJ3 + i) * 64 + lane] = p3[(long)i * 64];
   }
   if (tid < 4) {
     const int U = 4 * c + tid;
@@ -220,12 +229,16 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     f4 acc[NB];
     // ================================================================ GRU layer 0 : [hid_t | x_t | h0_{t-1}]
     TPT(0);
-    wait_phase(p1 - 1);
-    if (fail) break;
-    TPT(1);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
-    tp_mma<NB, TJ0, false>(wr0, nullptr, (const f4*)(a.G0 + (long)t * a.KB0 * XB) + (long)k0a * NB * 64 + lane, n0, acc);
+    {
+      const f4* x0 = (const f4*)(a.G0 + (long)t * a.KB0 * XB) + lane;
+      tp_mma<NB, TJ0, 0, TNO0, false>(wr0, nullptr, x0, TFR0 + wave, a.KB0, acc);        // old part: before the hand-off
+      wait_phase(p1 - 1);
+      if (fail) break;
+      TPT(1);
+      tp_mma<NB, TJ0, TNO0, TNF0, false>(wr0, nullptr, x0, wave, TFR0, acc);              // fresh part
+    }
     TPT(2);
     reduce(acc);
     TPT(3);
@@ -247,12 +260,16 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     arrive(p1);
     TPT(5);
     // ================================================================ GRU layer 1 : [h0_t | h1_{t-1}]
-    wait_phase(p2 - 1);
-    if (fail) break;
-    TPT(6);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
-    tp_mma<NB, TJ1, false>(wr1, nullptr, (const f4*)(a.G1 + (long)t * 128 * XB) + (long)k1a * NB * 64 + lane, n1, acc);
+    {
+      const f4* x1 = (const f4*)(a.G1 + (long)t * 128 * XB) + lane;
+      tp_mma<NB, TJ1, 0, TNO1, false>(wr1, nullptr, x1, 64 + wave, 128, acc);             // h1_{t-1}: before the hand-off
+      wait_phase(p2 - 1);
+      if (fail) break;
+      TPT(6);
+      tp_mma<NB, TJ1, TNO1, TNF1, false>(wr1, nullptr, x1, wave, 64, acc);                // h0_t
+    }
     TPT(7);
     reduce(acc);
     TPT(8);
@@ -276,13 +293,17 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     // ================================================================ output stage : [h1_t | cond_{t+1}]
     float gz_[3] = {0.f, 0.f, 0.f};          // gaze target of frame t+1 (an input): in flight under the products
     if (ract && next) { const float* gz = a.gaze + ((long)rb * T + t + 1) * 3; gz_[0] = gz[0]; gz_[1] = gz[1]; gz_[2] = gz[2]; }
-    wait_phase(p3 - 1);
-    if (fail) break;
-    TPT(11);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
-    tp_mma<NB, TJ3, true>(*(const f4(*)[TJ3])nullptr, w3 + wave * TJ3 * 64 + lane,
-                          (const f4*)(a.G3 + (long)t * a.KB3 * XB) + (long)k3a * NB * 64 + lane, n3, acc);
+    {
+      const f4* x3 = (const f4*)(a.G3 + (long)t * a.KB3 * XB) + lane;
+      const f4* wl3 = w3 + wave * TJ3 * 64 + lane;
+      tp_mma<NB, TJ0, 0, TNO3, true>(wr0, wl3, x3, 64 + wave, a.KB3, acc);                // cond_{t+1}: before the hand-off
+      wait_phase(p3 - 1);
+      if (fail) break;
+      TPT(11);
+      tp_mma<NB, TJ0, TNO3, TNF3, true>(wr0, wl3, x3, wave, 64, acc);                     // h1_t
+    }
     TPT(12);
     reduce(acc);
     TPT(13);
@@ -378,19 +399,24 @@ __device__ __forceinline__ float tp_value(const TPackArgs& p, int ph, int c, int
   return 0.f;
 }
 __global__ void tp_pack_k(TPackArgs p) {
-  const long n0 = (long)TNCU * p.KB0 * 64, n1 = (long)TNCU * 128 * 64, n3 = (long)TNCU * p.KB3 * 64;
+  // destination order: [workgroup][wave][block i of the wave (old part, then fresh part)][64 lanes]
+  const long n0 = (long)TNCU * 8 * TJ0 * 64, n1 = (long)TNCU * 8 * TJ1 * 64, n3 = (long)TNCU * 8 * TJ3 * 64;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n0 + n1 + n3; idx += (long)gridDim.x * blockDim.x) {
-    int ph; long r = idx; f4* dst; int KB;
-    if (r < n0) { ph = 0; dst = p.PW0; KB = p.KB0; }
-    else if (r < n0 + n1) { ph = 1; r -= n0; dst = p.PW1; KB = 128; }
-    else { ph = 3; r -= n0 + n1; dst = p.PW3; KB = p.KB3; }
+    int ph, J; long r = idx; f4* dst;
+    if (r < n0) { ph = 0; dst = p.PW0; J = TJ0; }
+    else if (r < n0 + n1) { ph = 1; r -= n0; dst = p.PW1; J = TJ1; }
+    else { ph = 3; r -= n0 + n1; dst = p.PW3; J = TJ3; }
     const int lane = (int)(r & 63);
-    const long ck = r >> 6;
-    const int kb = (int)(ck % KB), c = (int)(ck / KB);
-    const int i = lane & 15, kk = 16 * kb + 4 * (lane >> 4);
-    f4 v;
+    const long cwi = r >> 6;
+    const int i = (int)(cwi % J), wave = (int)((cwi / J) & 7), c = (int)(cwi / (8L * J));
+    const int kb = ph == 0 ? tp_kb(i, wave, TNO0, TFR0, p.KB0, TFR0)
+                 : ph == 1 ? tp_kb(i, wave, TNO1, 64, 128, 64) : tp_kb(i, wave, TNO3, 64, p.KB3, 64);
+    const int row = lane & 15, kk = 16 * kb + 4 * (lane >> 4);
+    f4 v = f4{0.f, 0.f, 0.f, 0.f};
+    if (kb >= 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = tp_value(p, ph, c, i, kk + q);
+      for (int q = 0; q < 4; ++q) v[q] = tp_value(p, ph, c, row, kk + q);
+    }
     dst[r] = v;
   }
 }
@@ -421,8 +447,10 @@ __global__ void tp_cond_k(ZeggsDecDims d, const float* speech, const float* styl
 }  // namespace
 
 int dec_tp_supported(const ZeggsDecDims& d, const DecWs& w) {
-  return !d.film && d.H == TH && d.B <= 32 && d.T >= 4 && d.PI == d.PO + 3 && 64 + w.KBX + 64 <= 8 * TJ0 &&
-         64 + w.KBC <= 8 * TJ3 && d.PO <= 5 * TNCU && d.PO >= 16 && w.G0xf != nullptr;
+  const int KB0 = 64 + w.KBX + 64;
+  return !d.film && d.H == TH && d.B <= 32 && d.T >= 4 && d.PI == d.PO + 3 && 64 + (d.PI + 15) / 16 == TFR0 &&
+         KB0 > TFR0 && KB0 - TFR0 <= 8 * TNO0 && w.KBC >= 1 && w.KBC <= 8 * TNO3 && d.PO <= 5 * TNCU && d.PO >= 16 &&
+         w.G0xf != nullptr;
 }
 int dec_tp_state() { return g_tp_ok; }
 void dec_tp_set_state(int v) { g_tp_ok = v; }
