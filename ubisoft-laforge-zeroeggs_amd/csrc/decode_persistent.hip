@@ -345,6 +345,10 @@ int dec_persistent_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
 // 1: validated on this process, 0: failed (disabled), -1: unknown
 int dec_persistent_state() { return g_persistent_ok; }
 void dec_persistent_set_state(int v) { g_persistent_ok = v; }
+int dec_persistent_errptr(const DecWs& w, unsigned** out) {
+  *out = (unsigned*)((unsigned long long*)w.pgran + 3 * PH + 5 * PNCU);
+  return 0;
+}
 int dec_persistent_errors(const DecWs& w, unsigned* out) {
   const unsigned long long* g = (const unsigned long long*)w.pgran;
   ZCHECK(hipMemcpy(out, (const void*)(g + 3 * PH + 5 * PNCU), sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess,

@@ -45,6 +45,33 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   return -1;
 }
 
+// Error words of the persistent kernels are copied back asynchronously after every launch (pinned host word + event) and
+// inspected at the NEXT call: a kernel that was validated once but later could not run (not every workgroup resident, e.g.
+// the GPU is shared) is detected without a device synchronisation in the steady state.
+struct ErrWatch {
+  unsigned* host = nullptr;
+  hipEvent_t ev = nullptr;
+  bool pending = false;
+  int post(const unsigned* dev_word, hipStream_t s) {
+    if (!host) {
+      ZCHECK(hipHostMalloc((void**)&host, sizeof(unsigned), hipHostMallocDefault) == hipSuccess, "pinned word allocation failed");
+      ZCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "event creation failed");
+      *host = 0;
+    }
+    ZCHECK(hipMemcpyAsync(host, dev_word, sizeof(unsigned), hipMemcpyDeviceToHost, s) == hipSuccess, "error-word copy failed");
+    ZCHECK(hipEventRecord(ev, s) == hipSuccess, "hipEventRecord failed");
+    pending = true;
+    return 0;
+  }
+  // 0: nothing to report / still in flight, 1: the last inspected launch failed
+  int failed() {
+    if (!pending || hipEventQuery(ev) != hipSuccess) return 0;
+    pending = false;
+    return *host != 0;
+  }
+};
+static ErrWatch g_watch_decode, g_watch_train;
+
 // 1: the persistent kernel was validated on this process, 0: it failed once and is disabled, -1: not used yet
 extern "C" int zeggs_persistent_state(int which /* 0 decode (B=1), 1 training forward */) {
   return which == 0 ? dec_persistent_state() : dec_tp_state();
@@ -474,6 +501,14 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
   }
   const bool fast = g_decoder_fast && dec_fast_supported(d);
   // ---- batch-1 inference: the weight-stationary persistent kernel (one launch for all frames, decode_persistent.hip)
+  hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+  hipStreamIsCapturing(s, &cap0);          // (event queries are not allowed while a capture is in progress)
+  if (cap0 == hipStreamCaptureStatusNone && g_watch_decode.failed()) {
+    dec_persistent_set_state(0);
+    zeggs_set_error("persistent decode kernel: a bounded wait gave up in the PREVIOUS rollout (its outputs are invalid); "
+                    "the kernel is disabled for this process, repeat the call");
+    return -1;
+  }
   if (fast && !training && g_persistent && dec_persistent_state() != 0 && dec_persistent_supported(d, w)) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     hipStreamIsCapturing(s, &cap);
@@ -489,7 +524,10 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
       ZTRY(dec_persistent_run(d, P, st, w, gaze, speech, style, pose, rpos, rrot, gin1, w.H0 + slot(0) * sH,
                               w.H1 + slot(0) * sH, w.H0 + slot(T - 1) * sH, w.H1 + slot(T - 1) * sH, s));
       dec_timing_mark(1, s);
-      if (dec_persistent_state() == 1) return save_state();
+      if (dec_persistent_state() == 1) {
+        if (cap == hipStreamCaptureStatusNone) { unsigned* ew = nullptr; ZTRY(dec_persistent_errptr(w, &ew)); ZTRY(g_watch_decode.post(ew, s)); }
+        return save_state();
+      }
       unsigned perr = 1;
       ZCHECK(hipStreamSynchronize(s) == hipSuccess, "persistent decode: stream sync failed");
       ZTRY(dec_persistent_errors(w, &perr));
@@ -499,6 +537,12 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
     }
   }
   // ---- training, batch <= 32: the forward rollout as one persistent launch (train_persistent.hip)
+  if (cap0 == hipStreamCaptureStatusNone && g_watch_train.failed()) {
+    dec_tp_set_state(0);
+    zeggs_set_error("persistent training rollout: a bounded wait gave up in the PREVIOUS forward (its results are invalid); "
+                    "the kernel is disabled for this process, repeat the step");
+    return -1;
+  }
   if (fast && training && g_train_persistent && dec_tp_state() != 0 && dec_tp_supported(d, w)) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     hipStreamIsCapturing(s, &cap);
@@ -510,7 +554,10 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
       dec_timing_mark(0, s);
       ZTRY(dec_tp_run(d, P, st, w, gaze, speech, style, pose, rpos, rrot, s));
       dec_timing_mark(1, s);
-      if (dec_tp_state() == 1) return save_state();
+      if (dec_tp_state() == 1) {
+        if (cap == hipStreamCaptureStatusNone) { unsigned* ew = nullptr; ZTRY(dec_tp_errptr(w, &ew)); ZTRY(g_watch_train.post(ew, s)); }
+        return save_state();
+      }
       unsigned perr = 1;
       ZCHECK(hipStreamSynchronize(s) == hipSuccess, "persistent training rollout: stream sync failed");
       ZTRY(dec_tp_errors(w, &perr));

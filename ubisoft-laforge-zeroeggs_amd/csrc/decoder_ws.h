@@ -139,6 +139,7 @@ int dec_persistent_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
 int dec_persistent_state();
 void dec_persistent_set_state(int v);
 int dec_persistent_errors(const DecWs& w, unsigned* out);
+int dec_persistent_errptr(const DecWs& w, unsigned** out);
 // persistent training rollout (train_persistent.hip)
 int dec_tp_supported(const ZeggsDecDims& d, const DecWs& w);
 int dec_tp_state();
@@ -147,6 +148,7 @@ int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStr
 int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s);
 int dec_tp_errors(const DecWs& w, unsigned* out);
+int dec_tp_errptr(const DecWs& w, unsigned** out);
 // fast path entry points (decoder_fast.hip)
 int dec_fast_merge_prep(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s);
 void dec_timing_mark(int i, hipStream_t s);

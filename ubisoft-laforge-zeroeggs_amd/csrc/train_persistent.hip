@@ -70,7 +70,6 @@ __device__ __forceinline__ bool tp_wait(const unsigned* c, unsigned expect) {
     for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if (__builtin_amdgcn_readfirstlane(v) >= expect) return true;
     if (spins > TSPIN) return false;
-    __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -508,6 +507,10 @@ extern "C" int zeggs_tp_stamps(const ZeggsDecDims* dp, void* ws, size_t ws_bytes
   DecWs w = carve_dec(*dp, 1, a);
   ZCHECK(a.ok() && w.tp_cnt, "tp_stamps: workspace");
   ZCHECK(hipMemcpy(out, w.tp_cnt + TRING * TSH * TSTR + 32, 4 * 2 * 32 * 8, hipMemcpyDeviceToHost) == hipSuccess, "copy");
+  return 0;
+}
+int dec_tp_errptr(const DecWs& w, unsigned** out) {
+  *out = w.tp_cnt + TRING * TSH * TSTR;
   return 0;
 }
 int dec_tp_errors(const DecWs& w, unsigned* out) {
