@@ -345,6 +345,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip decode / decode_30min / v2_label_b64 (N = 1 only)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="initialise the RCCL process group and run the gradient all-reduce even at --gpus 1")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="only rendezvous (gloo on CPU when no GPU is visible) and print the rank census")
     a = ap.parse_args()
@@ -354,8 +356,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     have_gpu = torch.cuda.is_available()
-    if world > 1:
+    use_pg = world > 1 or a.force_process_group
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
         if have_gpu:
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world,
                                                  device_id=torch.device("cuda", local))
@@ -365,7 +373,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus {a.gpus}` (self-launching) "
                          f"or torch.distributed.run with --nproc-per-node {a.gpus}")
     census = None
-    if world > 1:
+    if use_pg:
         me = {"rank": rank, "local_rank": local,
               "device": str(torch.cuda.get_device_properties(local).uuid) if have_gpu else "cpu"}
         census = [None] * world
@@ -373,7 +381,7 @@ def main():
     if a.launch_selftest:
         if rank == 0:
             print(json.dumps({"launch_selftest": True, "world_size": world, "ranks": census}))
-        if world > 1:
+        if use_pg:
             torch.distributed.destroy_process_group()
         return
     if have_gpu and local >= torch.cuda.device_count():
@@ -384,7 +392,8 @@ def main():
     data = build_dataset()
     ds = engine.DeviceDataset(data, WINDOW, dev)
     se, de, st = build_nets(dev)
-    eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, world_size=world, rank=rank)
+    eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, world_size=world, rank=rank,
+                             force_allreduce=a.force_process_group)
     ops.manual_seed(1000 + rank)                            # per-rank noise streams (dropout masks, VAE eps)
     perm = np.random.default_rng(42).permutation(len(ds))   # same permutation on every rank
     gb = BATCH * world
@@ -393,14 +402,14 @@ def main():
         return engine.shard_indices(perm, it % (len(ds) // gb), BATCH, world, rank)
 
     def sync():
-        if world > 1:
+        if use_pg:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
     for it in range(a.warmup):
         eng.step(indices(it), EXAMPLE_LEN)
     sync()
-    eng.allreduce_events = [] if world > 1 else None
+    eng.allreduce_events = [] if use_pg else None
     sync()
     t0 = time.perf_counter()
     for it in range(a.warmup, a.warmup + a.steps):
@@ -410,7 +419,7 @@ def main():
     fwd_in, bwd_in = sweep_ms(0), sweep_ms(1)               # the LAST timed iteration's stage sweeps (HIP events)
     el = torch.tensor([mine], device=dev, dtype=torch.float64)
     per_rank = None
-    if world > 1:
+    if use_pg:
         allt = [torch.zeros_like(el) for _ in range(world)]
         torch.distributed.all_gather(allt, el)
         per_rank = [round(float(t) / a.steps * 1e3, 3) for t in allt]
@@ -422,7 +431,7 @@ def main():
         loss = eng.step(indices(a.warmup + a.steps + k), EXAMPLE_LEN)
         fw.append(sweep_ms(0))
         bw.append(sweep_ms(1))
-    loss = float(loss)
+    loss = float(loss.detach())
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         out = {
@@ -463,7 +472,7 @@ def main():
             "note": "HIP events (library hook zeggs_timing_ms, recorded on the stream the kernels run on) around the "
                     "255-step stage sweeps: the last timed iteration + 3 more; traffic = FETCH_SIZE(x2)+WRITE_SIZE "
                     f"from {pmc['file'] if pmc else 'n/a'}; at B=32 the step is also at the fp32 MFMA ridge"}
-        if world > 1:
+        if use_pg:
             ar = [e0.elapsed_time(e1) for e0, e1 in eng.allreduce_events[:a.steps]]
             out["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "ranks": census}
             out["per_rank_ms_per_step"] = per_rank
@@ -483,7 +492,7 @@ def main():
                 out["decode"]["cpu_baseline"] = dec_b
             out["mel_cpu_baseline"] = mel_b
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         torch.distributed.destroy_process_group()
 
 

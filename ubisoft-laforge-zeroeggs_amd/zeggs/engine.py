@@ -94,10 +94,10 @@ def shard_indices(perm, batch_index, per_rank_batch, world_size, rank):
     return perm[s + rank * per_rank_batch: s + (rank + 1) * per_rank_batch]
 
 
-def allreduce_mean_(flat_grad, world_size, group=None, prescaled=True):
+def allreduce_mean_(flat_grad, world_size, group=None, prescaled=True, force=False):
     """ONE collective per iteration over the flat gradient buffer (RCCL on GPUs, gloo in the CPU tests).  With
     prescaled=True every rank already multiplied its gradients by 1/world (the loss kernel's gscale)."""
-    if world_size > 1:
+    if world_size > 1 or force:      # force: exercise the collective on a single rank (bench.py --force-process-group)
         torch.distributed.all_reduce(flat_grad, op=torch.distributed.ReduceOp.SUM, group=group)
         if not prescaled:
             flat_grad.mul_(1.0 / world_size)
@@ -128,11 +128,12 @@ def flatten_parameters(modules):
 
 class TrainEngine:
     def __init__(self, speech_encoder, decoder, style_encoder, dataset, parents, dt, lr=1e-4, eps=1e-5,
-                 style_encoding_type="example", world_size=1, rank=0, process_group=None):
+                 style_encoding_type="example", world_size=1, rank=0, process_group=None, force_allreduce=False):
         self.se, self.de, self.st = speech_encoder, decoder, style_encoder
         self.ds = dataset
         self.dt = float(dt)
         self.world, self.rank, self.pg = world_size, rank, process_group
+        self.force_allreduce = force_allreduce
         self.style_type = style_encoding_type
         dev = dataset.device
         self.parents = torch.as_tensor(np.asarray(parents), dtype=torch.int32, device=dev)
@@ -188,7 +189,7 @@ class TrainEngine:
         if self.allreduce_events is not None:
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a0.record()
-        allreduce_mean_(self.flat_g, self.world, self.pg, prescaled=True)
+        allreduce_mean_(self.flat_g, self.world, self.pg, prescaled=True, force=self.force_allreduce)
         if self.allreduce_events is not None:
             a1.record()
             self.allreduce_events.append((a0, a1))
