@@ -511,9 +511,9 @@ def test_chained_decode_launches_match_plain_launches(B):
         assert float((a - b).abs().max()) < 2e-5
 
 
-@pytest.mark.parametrize("B,T", [(32, 12), (17, 6), (5, 9), (32, 4)])
+@pytest.mark.parametrize("B,T", [(32, 12), (17, 6), (5, 9), (32, 4), (64, 6), (40, 5)])
 def test_persistent_training_forward_matches_stage_launches(B, T):
-    """option "train_persistent" (default on for batch <= 32): the forward rollout of a training step as one
+    """option "train_persistent" (default on for batch <= 64): the forward rollout of a training step as one
     weight-stationary launch.  Outputs and, through the unchanged BPTT that consumes what the forward saved, every
     gradient must agree with the stage-launch forward."""
     _, de, _ = helpers.build_nets()

@@ -121,7 +121,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
     w.xf_base_bwd = w.DYxf;
     w.xf_bytes_bwd = a.off - align_up(o0, 256);
     w.dXa = a.f(B * (long)w.XD);
-    if (d.H == 1024 && d.B <= 32) {
+    if (d.H == 1024 && d.B <= 64) {
       const long KB0 = 64 + w.KBX + 64, KB3 = 64 + w.KBC;
       w.tp_w0 = a.f(256L * 8 * 26 * BLK); w.tp_w1 = a.f(256L * 8 * 16 * BLK); w.tp_w3 = a.f(256L * 8 * 9 * BLK);   // [wg][wave][block]
       w.G0xf = a.f(T * KB0 * XB); w.G1xf = a.f(T * 128 * XB); w.G3xf = a.f(T * KB3 * XB);

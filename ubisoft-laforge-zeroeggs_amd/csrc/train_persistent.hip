@@ -79,21 +79,22 @@ __device__ __forceinline__ bool tp_wait(const unsigned* c, unsigned expect) {
 template <int NB, int NJT, int OFF, int NJ, bool WLDS>
 __device__ __forceinline__ void tp_mma(const f4 (&wr)[NJT], const f4* wl, const f4* __restrict__ xb, int kb0, int hi,
                                        f4 (&acc)[NB]) {
-  constexpr int NG = (NJ + 1) / 2;
-  f4 xa[2][NB], xq[2][NB];
-  auto load = [&](f4 (&x)[2][NB], int g) {
+  constexpr int GU = NB >= 3 ? 1 : 2;                 // k-blocks per group: GU * NB float4 of activations per buffer
+  constexpr int NG = (NJ + GU - 1) / GU;
+  f4 xa[GU][NB], xq[GU][NB];
+  auto load = [&](f4 (&x)[GU][NB], int g) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      int kb = kb0 + 8 * (2 * g + u);
+    for (int u = 0; u < GU; ++u) {
+      int kb = kb0 + 8 * (GU * g + u);
       kb = kb < hi ? kb : hi - 1;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) x[u][nb] = xb[((long)kb * NB + nb) * 64];
     }
   };
-  auto comp = [&](const f4 (&x)[2][NB], int g) {
+  auto comp = [&](const f4 (&x)[GU][NB], int g) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int i = 2 * g + u;
+    for (int u = 0; u < GU; ++u) {
+      const int i = GU * g + u;
       if (i < NJ) {
         const f4 wv = WLDS ? wl[(OFF + i) * 64] : wr[OFF + i < NJT ? OFF + i : 0];
 #pragma unroll
@@ -179,9 +180,10 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   const int EU = 4 * c + (eu & 3);
   float hp0 = 0.f, hp1 = 0.f;
   if (gact) { hp0 = a.H0[(long)eb * H + EU]; hp1 = a.H1[(long)eb * H + EU]; }      // state before the first generated frame
-  // root thread of batch row rb (thread 9*BP + rb): the root state of its row stays in registers for the rollout
-  const bool ract = tid >= 9 * BP && tid < 10 * BP && (tid - 9 * BP) < B;
-  const int rb = tid - 9 * BP;
+  // root thread of batch row rb (the LAST B threads: the first ones carry the GRU items): the root state of its row stays
+  // in registers for the rollout
+  const int rb = TTHR - 1 - tid;
+  const bool ract = rb < B;
   Q4 rq_ = Q4{1.f, 0.f, 0.f, 0.f};
   V3 rp_ = v3(0.f, 0.f, 0.f);
   if (ract) {
@@ -307,10 +309,10 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     reduce(acc);
     TPT(13);
     {
-      const int vc = tid / BP, b = tid % BP;
       float* gnext = a.Gin + (long)(t + 1) * sG;                       // canonical [hid | x] row of step t+1
       float* xnext = a.G0 + (long)(t + 1) * a.KB0 * XB;                // its fragment copy
-      if (vc == 9 && b < B) {     // root integration of batch row b (ZEGGS/modules.py:139-176), every workgroup
+      if (ract) {                 // root integration of batch row rb (ZEGGS/modules.py:139-176), every workgroup
+        const int b = rb;
         float p[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) p[q] = (FV(9 + q, b) + cB[9 + q][0]) * cB[9 + q][1] + cB[9 + q][2];
@@ -339,19 +341,24 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
               stp(xnext + 64 * XB + xfi(b, PO + k, NB), genc[k]);
             }
         }
-      } else if (vc >= 4 && vc < 9 && b < B && cB[vc][5] != 0.f) {
-        const float* k_ = cB[vc];
-        const int col = c + TNCU * (vc - 4);
-        const float pv = (FV(vc, b) + k_[0]) * k_[1] + k_[2];
-        a.pose[((long)b * T + t) * PO + col] = pv;
-        if (next) {
-          const float e = (pv - k_[3]) / k_[4];
-          gnext[(long)b * GL + H + col] = e;
-          stp(xnext + 64 * XB + xfi(b, col, NB), e);
+      }
+      for (int item = tid; item < 5 * BP; item += TTHR) {       // layer2 rows: pose_t and the pose columns of x_{t+1}
+        const int vc = 4 + item / BP, b = item % BP;
+        if (b < B && cB[vc][5] != 0.f) {
+          const float* k_ = cB[vc];
+          const int col = c + TNCU * (vc - 4);
+          const float pv = (FV(vc, b) + k_[0]) * k_[1] + k_[2];
+          a.pose[((long)b * T + t) * PO + col] = pv;
+          if (next) {
+            const float e = (pv - k_[3]) / k_[4];
+            gnext[(long)b * GL + H + col] = e;
+            stp(xnext + 64 * XB + xfi(b, col, NB), e);
+          }
         }
       }
       __syncthreads();
-      if (next && vc < 4 && b < B) {
+      if (next && tid < 4 * BP && tid % BP < B) {                 // folded layer0 rows: hid_{t+1}
+        const int vc = tid / BP, b = tid % BP;
         const float* k_ = cB[vc];
         const int col = 4 * c + vc;
         const float val = d_elu(FV(vc, b) + k_[0] + k_[1] * gsh[b * 3] + k_[2] * gsh[b * 3 + 1] + k_[3] * gsh[b * 3 + 2]);
@@ -447,7 +454,7 @@ __global__ void tp_cond_k(ZeggsDecDims d, const float* speech, const float* styl
 
 int dec_tp_supported(const ZeggsDecDims& d, const DecWs& w) {
   const int KB0 = 64 + w.KBX + 64;
-  return !d.film && d.H == TH && d.B <= 32 && d.T >= 4 && d.PI == d.PO + 3 && 64 + (d.PI + 15) / 16 == TFR0 &&
+  return !d.film && d.H == TH && d.B <= 64 && d.T >= 4 && d.PI == d.PO + 3 && 64 + (d.PI + 15) / 16 == TFR0 &&
          KB0 > TFR0 && KB0 - TFR0 <= 8 * TNO0 && w.KBC >= 1 && w.KBC <= 8 * TNO3 && d.PO <= 5 * TNCU && d.PO >= 16 &&
          w.G0xf != nullptr;
 }
@@ -497,8 +504,12 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   a.b_ih0 = P->b_ih0; a.b_hh0 = P->b_hh0; a.b_ih1 = P->b_ih1; a.b_hh1 = P->b_hh1; a.cvec = w.cvec; a.l0_w = P->l0_w;
   a.l2_b = P->l2_b; a.gaze = gaze; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
   a.cnt = w.tp_cnt; a.err = w.tp_cnt + TRING * TSH * TSTR;
-  if (NB == 1) hipLaunchKernelGGL((train_fwd_persistent_k<1>), dim3(TNCU), dim3(TTHR), 0, s, a);
-  else hipLaunchKernelGGL((train_fwd_persistent_k<2>), dim3(TNCU), dim3(TTHR), 0, s, a);
+  switch (NB) {
+    case 1: hipLaunchKernelGGL((train_fwd_persistent_k<1>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((train_fwd_persistent_k<2>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((train_fwd_persistent_k<3>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
+    default: hipLaunchKernelGGL((train_fwd_persistent_k<4>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
+  }
   ZLAUNCH_CHECK("train_fwd_persistent");
   return 0;
 }
