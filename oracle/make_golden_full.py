@@ -298,7 +298,6 @@ def add_fp64_gradient_samples():
     FLOAT64 on the same iteration: the reference's own fp32 gradients carry 1-4e-4 of max|g| of rounding noise after
     BPTT, so the GPU tests assert the tight tolerance against these and a looser one against the fp32 reference."""
     sys.path.insert(0, str(ROOT / "tests"))
-    import helpers
     from test_oracle_full_shapes import oracle_full_iteration
     for tag, v in (("trainv2", "v2"), ("train32", "v1")):
         path = GOLD / f"full_{tag}.npz"

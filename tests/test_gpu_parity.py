@@ -594,6 +594,12 @@ def test_decoder_label_conditioning_dims():
     _oracle_vs_hip_rollout(B=3, T=5, style_dim=19)
 
 
+def test_decoder_b1_label_conditioning_vs_oracle():
+    """B=1 with the label-conditioning width (one-hot over 19 labels): the persistent decode kernel against the oracle."""
+    _oracle_vs_hip_rollout(B=1, T=12, style_dim=19)
+    assert ops.lib().zeggs_persistent_state(0) == 1
+
+
 def test_decoder_shortest_sequences():
     _oracle_vs_hip_rollout(B=2, T=2, style_dim=64)       # one generated frame
     _oracle_vs_hip_rollout(B=2, T=1, style_dim=64)       # nothing to generate: outputs = the given first pose
