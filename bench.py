@@ -311,7 +311,9 @@ def v2_label_b64(ds, dev, steps=10, warmup=3, batch=64, nlabels=9):
     fl = step_flops(batch, nlabels)
     return {"value": round(batch * WINDOW / dt_, 1), "unit": "frames/s", "ms_per_step": round(dt_ * 1e3, 3),
             "batch": batch, "window": WINDOW, "steps": steps,
-            "roofline": {"bound": "mfma", "kernel": "decoder forward step (3 launches of stage_k<4,...>, fp32 MFMA)",
+            "roofline": {"bound": "mfma", "kernel": ("train_fwd_persistent_k<4> (one weight-stationary launch per window)"
+                                                     if ops.lib().zeggs_persistent_state(1) == 1 else
+                                                     "3 launches of stage_k<4,...> per step") + ", forward step, fp32 MFMA",
                          "achieved": round(fl / fwd / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(fl / fwd / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "us_per_step": round(fwd * 1e6, 2),
                          "backward_us_per_step": round(bwd * 1e6, 2),

@@ -61,14 +61,19 @@ __device__ __forceinline__ long xfi(int b, int k, int NB) {   // B-fragment posi
   return ((((long)(k >> 4) * NB + (b >> 4)) * 64 + ((((k >> 2) & 3) << 4) | (b & 15))) << 2) | (k & 3);
 }
 
-// wave 0: lanes 0..7 poll one shard each until the sum reaches `expect`; returns false on give-up
-__device__ __forceinline__ bool tp_wait(const unsigned* c, unsigned expect) {
+// Arrival slots: workgroup c publishes "I have finished phase instance p" by storing p + 1 into slot[c] (a write-through
+// store, no read-modify-write to serialise); a consumer's wave 0 loads all 256 slots with one 16-byte load per lane and
+// waits until every slot has reached p + 1.  Epochs are monotonic and a workgroup can run at most one phase ahead of the
+// slowest one, so one 1 KB array serves every phase.  Returns false on give-up.
+typedef __attribute__((address_space(1))) unsigned long long gu64t;
+__device__ __forceinline__ bool tp_wait(const unsigned* slots, unsigned expect) {
   const int lane = threadIdx.x & 63;
+  const gu64t* q = (const gu64t*)(slots + 4 * lane);
   for (unsigned spins = 0;; ++spins) {
-    unsigned v = lane < TSH ? __hip_atomic_load((gu32*)(c + lane * TSTR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (__builtin_amdgcn_readfirstlane(v) >= expect) return true;
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ok = (unsigned)a >= expect && (unsigned)(a >> 32) >= expect && (unsigned)b >= expect && (unsigned)(b >> 32) >= expect;
+    if (__all(ok)) return true;
     if (spins > TSPIN) return false;
   }
 }
@@ -212,16 +217,14 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   };
   auto wait_phase = [&](long p) {     // all workgroups have finished phase instance p (p < 0: nothing to wait for)
     if (p >= 0) {
-      if (wave == 0 && !tp_wait(a.cnt + (p & (TRING - 1)) * (TSH * TSTR), (unsigned)((p / TRING + 1) * gridDim.x))) fail = 1;
+      if (wave == 0 && !tp_wait(a.cnt, (unsigned)(p + 1))) fail = 1;
     }
     __syncthreads();
   };
   auto arrive = [&](long p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0)
-      __hip_atomic_fetch_add((gu32*)(a.cnt + (p & (TRING - 1)) * (TSH * TSTR) + (c & (TSH - 1)) * TSTR), 1u, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store((gu32*)(a.cnt + c), (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
   for (int t = 1; t < T; ++t) {
