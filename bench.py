@@ -346,6 +346,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="ONE blocking all-reduce after the backward instead of the overlapped decoder-slice exchange")
     ap.add_argument("--no-extras", action="store_true", help="skip decode / decode_30min / v2_label_b64 (N = 1 only)")
     ap.add_argument("--force-process-group", action="store_true",
                     help="initialise the RCCL process group and run the gradient all-reduce even at --gpus 1")
@@ -395,7 +397,7 @@ def main():
     ds = engine.DeviceDataset(data, WINDOW, dev)
     se, de, st = build_nets(dev)
     eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, world_size=world, rank=rank,
-                             force_allreduce=a.force_process_group)
+                             force_allreduce=a.force_process_group, overlap_allreduce=not a.no_overlap)
     ops.manual_seed(1000 + rank)                            # per-rank noise streams (dropout masks, VAE eps)
     perm = np.random.default_rng(42).permutation(len(ds))   # same permutation on every rank
     gb = BATCH * world
@@ -480,6 +482,9 @@ def main():
             out["per_rank_ms_per_step"] = per_rank
             out["allreduce_ms"] = round(float(np.mean(ar)), 3) if ar else None
             out["allreduce_bytes"] = int(eng.flat_g.numel() * 4)
+            out["allreduce_note"] = ("allreduce_ms = the EXPOSED part: the decoder slice (91 % of the payload) is reduced "
+                                     "underneath the encoders' backward" if eng.overlap_allreduce else
+                                     "one blocking all-reduce of the flat gradient buffer after the backward")
         out["cpu_baseline"] = None
         if world == 1 and not a.no_extras:
             out["decode"] = decode_rate(de, dev)

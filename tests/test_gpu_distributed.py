@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _step(world, rank, per_rank):
+def _step(world, rank, per_rank, overlap=True):
     """one optimizer step of the engine on this rank's shard; returns the flat parameter vector after the step"""
     import helpers
     from zeggs import engine, synth
@@ -32,7 +32,8 @@ def _step(world, rank, per_rank):
     T, L = 6, 8
     data = synth.make_processed(2, 0, T + 10, seed=8)
     ds = engine.DeviceDataset(data, T, dev)
-    eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, world_size=world, rank=rank)
+    eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, world_size=world, rank=rank,
+                             overlap_allreduce=overlap)
     perm = np.random.default_rng(5).permutation(len(ds))
     gb = per_rank * world
     eps_all = torch.randn(gb, 64, generator=torch.Generator().manual_seed(3)).to(dev)
@@ -42,14 +43,14 @@ def _step(world, rank, per_rank):
     return eng.flat_p.detach().cpu().clone(), float(loss)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, overlap=True):
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     sys.path[:0] = [str(root), str(root / "ubisoft-laforge-zeroeggs_amd"), str(root / "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    p, loss = _step(world, rank, per_rank=2)
+    p, loss = _step(world, rank, per_rank=2, overlap=overlap)
     out[rank] = (p.numpy(), loss)
     dist.destroy_process_group()
 
@@ -69,3 +70,17 @@ def test_two_rank_engine_step_equals_single_process_global_batch():
     d_par, d_ref = p0 - init, ref - init
     assert float(d_ref.abs().max()) > 0
     assert float((d_par - d_ref).abs().max()) <= 2e-3 * float(d_ref.abs().max())
+
+
+def test_overlapped_allreduce_equals_the_single_collective():
+    """The decoder slice's all-reduce is started from the decoder backward (underneath the encoders' backward) and the
+    encoder slices follow: same sums as ONE collective over the whole flat buffer."""
+    world = 2
+    mgr = mp.Manager()
+    a, b = mgr.dict(), mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), a, True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), b, False), nprocs=world, join=True)
+    for r in range(world):
+        d = np.abs(a[r][0] - b[r][0]).max()
+        assert d <= 1e-7, d          # split-K atomics in the prologue GEMMs: not bitwise run to run
+        assert np.array_equal(a[r][0], a[0][0]) and np.array_equal(b[r][0], b[0][0])

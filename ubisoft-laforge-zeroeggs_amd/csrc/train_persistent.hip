@@ -34,6 +34,8 @@ constexpr int TH = 1024, TTHR = 512, TNCU = 256, TSPIN = 1 << 21;
 constexpr int TNO0 = 9, TNF0 = 17, TNO1 = 8, TNF1 = 8, TNO3 = 1, TNF3 = 8;
 constexpr int TJ0 = TNO0 + TNF0, TJ1 = TNO1 + TNF1, TJ3 = TNO3 + TNF3;
 constexpr int TFR0 = 135;     // GRU layer 0: k-blocks [0, 135) = hid_t and the pose / gaze columns of x_t are fresh
+// old-part k-blocks of GRU layer 0 parked in LDS instead of registers (as many as the LDS budget of the variant allows)
+constexpr int tl0(int nb) { return nb <= 2 ? 8 : nb == 3 ? 6 : 5; }
 __host__ __device__ inline int tp_kb(int i, int wave, int NO, int old_lo, int old_hi, int fresh_hi) {
   if (i < NO) { const int kb = old_lo + wave + 8 * i; return kb < old_hi ? kb : -1; }
   const int kb = wave + 8 * (i - NO);
@@ -139,6 +141,8 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   __shared__ f4 red[8][NB][64];
   __shared__ f4 fin[NB][64];
   __shared__ f4 w3[8 * TJ3 * 64];             // output-stage weights of this workgroup (72 KB)
+  constexpr int TL0 = tl0(NB);
+  __shared__ f4 w0l[8 * TL0 * 64];            // the first TL0 (old-part) k-blocks of GRU layer 0: relieves the register file
   __shared__ float gsh[BP * 3];               // normalised gaze direction of x_{t+1} per batch row
   __shared__ float cA[4][12];                 // biases of the 4 units: b_ih0, b_hh0, b_ih1, b_hh1 (r, z, n)
   __shared__ float cB[16][8];                 // output-stage row constants
@@ -148,11 +152,13 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   const int B = d.B, T = d.T, H = TH, PO = d.PO, GL = a.GL;
   const long sG = (long)B * GL, sH = (long)B * H, XB = 256L * NB;
   // ---------------------------------------------------------------- weights -> registers / LDS (once per rollout)
-  f4 wr0[TJ0], wr1[TJ1];
+  f4 wr0[TJ0 - TL0], wr1[TJ1];
   {
     const f4* p0 = a.PW0 + ((long)(c * 8 + wave) * TJ0) * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < TJ0; ++i) wr0[i] = p0[(long)i * 64];
+    for (int i = 0; i < TL0; ++i) w0l[(wave * TL0 + i) * 64 + lane] = p0[(long)i * 64];
+#pragma unroll
+    for (int i = TL0; i < TJ0; ++i) wr0[i - TL0] = p0[(long)i * 64];
     const f4* p1 = a.PW1 + ((long)(c * 8 + wave) * TJ1) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < TJ1; ++i) wr1[i] = p1[(long)i * 64];
@@ -237,11 +243,13 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
     {
       const f4* x0 = (const f4*)(a.G0 + (long)t * a.KB0 * XB) + lane;
-      tp_mma<NB, TJ0, 0, TNO0, false>(wr0, nullptr, x0, TFR0 + wave, a.KB0, acc);        // old part: before the hand-off
+      // old part (before the hand-off): its first TL0 blocks come from LDS
+      tp_mma<NB, TJ0 - TL0, 0, TL0, true>(wr0, w0l + wave * TL0 * 64 + lane, x0, TFR0 + wave, a.KB0, acc);
+      tp_mma<NB, TJ0 - TL0, 0, TNO0 - TL0, false>(wr0, nullptr, x0, TFR0 + wave + 8 * TL0, a.KB0, acc);
       wait_phase(p1 - 1);
       if (fail) break;
       TPT(1);
-      tp_mma<NB, TJ0, TNO0, TNF0, false>(wr0, nullptr, x0, wave, TFR0, acc);              // fresh part
+      tp_mma<NB, TJ0 - TL0, TNO0 - TL0, TNF0, false>(wr0, nullptr, x0, wave, TFR0, acc);  // fresh part
     }
     TPT(2);
     reduce(acc);
@@ -302,11 +310,11 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     {
       const f4* x3 = (const f4*)(a.G3 + (long)t * a.KB3 * XB) + lane;
       const f4* wl3 = w3 + wave * TJ3 * 64 + lane;
-      tp_mma<NB, TJ0, 0, TNO3, true>(wr0, wl3, x3, 64 + wave, a.KB3, acc);                // cond_{t+1}: before the hand-off
+      tp_mma<NB, TJ0 - TL0, 0, TNO3, true>(wr0, wl3, x3, 64 + wave, a.KB3, acc);          // cond_{t+1}: before the hand-off
       wait_phase(p3 - 1);
       if (fail) break;
       TPT(11);
-      tp_mma<NB, TJ0, TNO3, TNF3, true>(wr0, wl3, x3, wave, 64, acc);                     // h1_t
+      tp_mma<NB, TJ0 - TL0, TNO3, TNF3, true>(wr0, wl3, x3, wave, 64, acc);               // h1_t
     }
     TPT(12);
     reduce(acc);

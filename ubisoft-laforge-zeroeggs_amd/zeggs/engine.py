@@ -128,17 +128,24 @@ def flatten_parameters(modules):
 
 class TrainEngine:
     def __init__(self, speech_encoder, decoder, style_encoder, dataset, parents, dt, lr=1e-4, eps=1e-5,
-                 style_encoding_type="example", world_size=1, rank=0, process_group=None, force_allreduce=False):
+                 style_encoding_type="example", world_size=1, rank=0, process_group=None, force_allreduce=False,
+                 overlap_allreduce=True):
         self.se, self.de, self.st = speech_encoder, decoder, style_encoder
         self.ds = dataset
         self.dt = float(dt)
         self.world, self.rank, self.pg = world_size, rank, process_group
         self.force_allreduce = force_allreduce
+        self.overlap_allreduce = overlap_allreduce
         self.style_type = style_encoding_type
         dev = dataset.device
         self.parents = torch.as_tensor(np.asarray(parents), dtype=torch.int32, device=dev)
         mods = [speech_encoder, decoder] + ([style_encoder] if style_encoding_type == "example" else [])
         self.params, self.flat_p, self.flat_g = flatten_parameters(mods)
+        # the decoder's slice of the flat buffers (module order above): its gradients are final when the decoder
+        # backward returns, 91 % of the payload, while the encoders' backward still has to run
+        lo = sum(p.numel() for p in speech_encoder.parameters())
+        self._dec_range = (lo, lo + sum(p.numel() for p in decoder.parameters()))
+        self._dec_work = None
         self.opt = RAdam(self.params, lr=lr, eps=eps)
         self.opt.attach_flat(self.flat_p, self.flat_g)
         self.iteration = 0
@@ -148,12 +155,24 @@ class TrainEngine:
         self.allreduce_events = None        # bench.py: (start, end) HIP events around the gradient all-reduce
         self._one = torch.ones((), device=dev, dtype=torch.float32)     # upstream gradient of loss.backward()
 
+    def _reduce_decoder_grads(self):
+        """ops hook (after the decoder backward was enqueued): start the all-reduce of the decoder's gradient slice; it
+        runs on the process group's stream, ordered after the kernels already on the current stream, underneath the
+        encoders' backward.  Same collective sequence on every rank: decoder slice, then the encoder slices."""
+        lo, hi = self._dec_range
+        self._dec_work = torch.distributed.all_reduce(self.flat_g[lo:hi], op=torch.distributed.ReduceOp.SUM,
+                                                      group=self.pg, async_op=True)
+
     def step(self, idx, example_len, eps=None, labels=None):
         """One training iteration on window indices `idx` (this rank's slice). Returns the loss tensor (device)."""
         ds, T = self.ds, self.ds.window
         b = ds.batch(idx, example_len if self.style_type == "example" else None)
         ops.fill_(self.flat_g)
         ops.direct_param_grads(True)        # *_bwd kernels write straight into the flat gradient buffer
+        overlap = self.overlap_allreduce and (self.world > 1 or self.force_allreduce)
+        self._dec_work = None
+        if overlap:
+            ops.set_after_decoder_backward(self._reduce_decoder_grads)
         try:
             speech = self.se(b["audio"])
             mu = logvar = None
@@ -186,10 +205,23 @@ class TrainEngine:
                 self.decoder_bwd_events.append((e2, e3))
         finally:
             ops.direct_param_grads(False)
-        if self.allreduce_events is not None:
+            ops.set_after_decoder_backward(None)
+        if self.allreduce_events is not None:       # with the overlap on: the EXPOSED part of the exchange
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a0.record()
-        allreduce_mean_(self.flat_g, self.world, self.pg, prescaled=True, force=self.force_allreduce)
+        if self._dec_work is not None:
+            # the decoder slice has been in flight since the decoder backward returned; now the encoders' slices
+            lo, hi = self._dec_range
+            works = [self._dec_work]
+            for part in (self.flat_g[:lo], self.flat_g[hi:]):
+                if part.numel():
+                    works.append(torch.distributed.all_reduce(part, op=torch.distributed.ReduceOp.SUM, group=self.pg,
+                                                              async_op=True))
+            for w in works:
+                w.wait()
+            self._dec_work = None
+        else:
+            allreduce_mean_(self.flat_g, self.world, self.pg, prescaled=True, force=self.force_allreduce)
         if self.allreduce_events is not None:
             a1.record()
             self.allreduce_events.append((a0, a1))

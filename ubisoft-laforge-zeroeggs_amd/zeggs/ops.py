@@ -134,6 +134,17 @@ def direct_param_grads(on):
     _DIRECT_GRADS = bool(on)
 
 
+_AFTER_DECODER_BWD = None
+
+
+def set_after_decoder_backward(fn):
+    """Engine hook: `fn()` runs right after zeggs_decoder_bwd has been enqueued in direct-gradient mode, i.e. when
+    every decoder parameter gradient of the iteration is final in stream order (the encoders' backward follows).
+    engine.TrainEngine starts the all-reduce of the decoder's slice of the flat gradient buffer there."""
+    global _AFTER_DECODER_BWD
+    _AFTER_DECODER_BWD = fn
+
+
 def _grad_targets(orig_params, params):
     """-> (tensors the backward kernel writes, values returned to autograd)"""
     outs, rets = [], []
@@ -455,6 +466,8 @@ class _DecoderFn(torch.autograd.Function):
         _check(L.zeggs_decoder_bwd(C.byref(d), C.byref(P), C.byref(S), _p(gaze), _p(pose), _p(rpos), _p(rrot),
                                    _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
                                    C.c_size_t(ctx.ws.numel()), _stream()), "decoder_bwd")
+        if _AFTER_DECODER_BWD is not None and _DIRECT_GRADS and all(r is None for r in rets):
+            _AFTER_DECODER_BWD()
         return (None, None, None, None, dspeech, dstyle, None, None, None, None, None, None, None, *rets)
 
 
