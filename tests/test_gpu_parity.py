@@ -432,10 +432,29 @@ def test_train_api_runs_and_checkpoints(tmp_path):
                                  "use_vae": True}}
     train_opt = dict(niterations=0.004, batchsize=4, window=8, change_pace=True, learning_rate=1e-4,
                      learning_rate_decay=0.995, eps=1e-5, resume=False, use_gpu=True, thread_count=1, seed=1234,
-                     use_tensorboard=False, style_encoding_type="example", generate_samples_step=3, use_script=False)
+                     use_tensorboard=True, style_encoding_type="example", generate_samples_step=3, use_script=False)
     (tmp_path / "models").mkdir(), (tmp_path / "logs").mkdir()
     assert train(tmp_path / "models", tmp_path / "logs", npz, jsn, train_opt, net_opt) is None     # like the reference
     eng = train_mod.last_engine
+    # sample animations of the checkpoint iterations (train.py:516-760): 3 train + 3 valid clips, ground + prediction
+    from zeggs import anim
+    samples = sorted((tmp_path / "logs" / "samples").glob("iteration_0_*.bvh"))
+    assert len(samples) == 12 and len(list((tmp_path / "logs" / "samples").glob("iteration_3_*.bvh"))) == 12
+    for split in ("train", "valid"):
+        gt = anim.bvh_load(next((tmp_path / "logs" / "samples").glob(f"iteration_0_{split}_ground_0_*.bvh")))
+        pr = anim.bvh_load(next((tmp_path / "logs" / "samples").glob(f"iteration_0_{split}_predict_0_*.bvh")))
+        assert gt["rotations"].shape == pr["rotations"].shape == (40, 75, 3)
+        assert np.isfinite(pr["rotations"]).all() and np.isfinite(pr["positions"]).all()
+        assert np.abs(gt["rotations"][0] - pr["rotations"][0]).max() < 1e-3     # frame 0 = the given first pose
+        assert np.abs(gt["positions"][0] - pr["positions"][0]).max() < 1e-4
+    # the loss terms of every iteration under logs/tb (SummaryWriter events, or scalars.jsonl without tensorboard)
+    tb = list((tmp_path / "logs" / "tb").iterdir())
+    assert tb
+    if (tmp_path / "logs" / "tb" / "scalars.jsonl").exists():
+        import json
+        rows = [json.loads(x) for x in open(tmp_path / "logs" / "tb" / "scalars.jsonl")]
+        assert len(rows) == eng.iteration and set(rows[0]["losses/losses"]) == set(train_mod.LOSS_TAGS)
+        assert abs(sum(rows[-1]["losses/losses"].values()) / 18 - rows[-1]["losses/total_loss"]) < 1e-4
     assert eng.iteration >= 4 and torch.isfinite(eng.last_terms).all()
     # every parameter is saved in its own storage (not the engine's whole flat buffer per file)
     assert (tmp_path / "models" / "speech_encoder.pt").stat().st_size < 2 * 4 * sum(p.numel() for p in eng.se.parameters()) + 65536

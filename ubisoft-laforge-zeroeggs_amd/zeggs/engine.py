@@ -35,6 +35,12 @@ class DeviceDataset:
         self.PO = self.pose.shape[1]
         self.ranges_train = np.asarray(data["ranges_train"]).astype(np.int64)
         self.ranges_train_labels = np.asarray(data["ranges_train_labels"]).astype(np.int64)
+        # validation clips: only rendered as sample animations at checkpoints (train.py:632-760), never trained on
+        has_valid = "ranges_valid" in getattr(data, "files", data)
+        self.ranges_valid = np.asarray(data["ranges_valid"]).astype(np.int64).reshape(-1, 2) if has_valid \
+            else np.zeros((0, 2), np.int64)
+        self.ranges_valid_labels = np.asarray(data["ranges_valid_labels"]).astype(np.int64) if has_valid \
+            else np.zeros(0, np.int64)
         # window table (dataset.py:79-96): one window per start frame in [range_start, range_end - window)
         counts = np.maximum(self.ranges_train[:, 1] - window - self.ranges_train[:, 0], 0)
         self.win_sample = np.repeat(np.arange(len(counts)), counts).astype(np.int16)
@@ -64,6 +70,35 @@ class DeviceDataset:
         k = np.arange(example_len)[None, :]
         rows = np.where(k < cur[:, None], start[:, None] + k, end[:, None] - example_len + k)
         return rows.astype(np.int64)
+
+    def sample_clip(self, split, seconds=None, range_index=None):
+        """dataset.py:206-233 `get_sample`: one whole clip (cut to `seconds` at 60 fps), batch 1, on the device.
+        -> dict(audio [1,T,F] normalised, pose [1,T,PO], rpos, rrot, gaze, label, frames (s, e), range_index)."""
+        ranges, labels = (self.ranges_train, self.ranges_train_labels) if split == "train" \
+            else (self.ranges_valid, self.ranges_valid_labels)
+        if range_index is None:
+            range_index = int(np.random.randint(len(ranges)))
+        s, e = (int(v) for v in ranges[range_index])
+        if seconds is not None:
+            e = min(s + seconds * 60, e)
+        audio = self.audio[s:e][None].clone()
+        ops.normalize_rows_(audio, self.audio_mean, self.audio_std)
+        return dict(audio=audio, pose=self.pose[s:e][None], rpos=self.rpos[s:e][None], rrot=self.rrot[s:e][None],
+                    gaze=self.gaze[s:e][None].contiguous(), label=int(labels[range_index]), frames=(s, e),
+                    range_index=range_index)
+
+    def clip_example(self, frames, example_len):
+        """dataset.py:176-204 `get_example(se, se, L)` as the reference calls it for sample rendering (train.py:544):
+        the clip's own frames [s, e] (no gaze), tail repeated up to `example_len`, normalised.  [1, L', PO+3]"""
+        s, e = frames
+        end = min(e + 1, self.n_frames)
+        ex = ops.fill_(torch.empty(end - s, self.PO + 3, device=self.device))
+        ex[:, :self.PO] = self.pose[s:end]
+        if end - s < example_len:
+            ex = torch.cat([ex, ex[-example_len + (end - s):]], dim=0)
+        ex = ex[None].contiguous()
+        ops.normalize_rows_(ex, self.in_mean, self.in_std)
+        return ex
 
     def batch(self, idx, example_len):
         """Gather one batch (normalised where the reference normalises before the nets)."""

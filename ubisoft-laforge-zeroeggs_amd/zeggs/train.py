@@ -5,8 +5,10 @@ reads processed_data.npz + data_definition.json, writes models_dir/{speech_encod
 checkpoints}.pt (+ models_dir/<iteration>/) every `generate_samples_step` iterations INCLUDING iteration 0, steps
 the exponential LR decay every 1000 iterations, stops after niterations*1000 iterations (checked per epoch, like the
 reference).  Differences (documented in DESIGN.md): the dataset lives in HBM and batches are gathered by a HIP
-kernel; data parallelism over torch.distributed (RCCL) when WORLD_SIZE > 1; TensorBoard / sample-BVH rendering are
-optional host extras (skipped when tensorboard is not installed).
+kernel; data parallelism over torch.distributed (RCCL) when WORLD_SIZE > 1.  Like the reference it renders three
+training and three validation clips (ground truth + prediction) to logs_dir/samples/*.bvh at every checkpoint
+(train.py:516-760) and logs the loss terms under logs_dir/tb when `use_tensorboard` is set (TensorBoard event files
+when the tensorboard package is importable, a scalars.jsonl with the same tags otherwise).
 """
 import copy
 import datetime
@@ -36,6 +38,85 @@ def compact_copy(module):
     finally:
         for q, g in zip(module.parameters(), grads):
             q.grad = g
+
+
+LOSS_TAGS = ("loss_root_pos", "loss_root_rot", "loss_root_vel", "loss_root_vrt", "loss_lpos", "loss_lrot", "loss_lvel",
+             "loss_lvrt", "loss_cpos", "loss_crot", "loss_cvel", "loss_cvrt", "loss_ldvl", "loss_ldvt", "loss_cdvl",
+             "loss_cdvt", "loss_gaze", "loss_kl_div")          # train.py:440-462, the order of the loss kernel's terms
+
+
+class ScalarLog:
+    """`use_tensorboard` sink (train.py:100-103,437-463): a SummaryWriter when tensorboard is installed, else the
+    same tags as JSON lines in <dir>/scalars.jsonl."""
+
+    def __init__(self, directory):
+        directory = Path(directory)
+        directory.mkdir(parents=True, exist_ok=True)
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            self.writer, self.file = SummaryWriter(log_dir=str(directory), flush_secs=10), None
+        except ImportError:
+            self.writer, self.file = None, open(directory / "scalars.jsonl", "a")
+
+    def add(self, iteration, loss, terms):
+        terms = terms[:len(LOSS_TAGS)].tolist()            # one device -> host copy
+        loss = float(loss.detach())
+        if self.writer is not None:
+            self.writer.add_scalar("losses/total_loss", loss, iteration)
+            self.writer.add_scalars("losses/losses", dict(zip(LOSS_TAGS, terms)), iteration)
+        else:
+            self.file.write(json.dumps({"iteration": iteration, "losses/total_loss": loss,
+                                        "losses/losses": dict(zip(LOSS_TAGS, terms))}) + "\n")
+            self.file.flush()
+
+    def close(self):
+        (self.writer or self.file).close()
+
+
+def render_samples(samples_dir, iteration, ds, se, de, st, details, example_len, count=3, seconds=30):
+    """train.py:516-760: `count` random training clips and `count` validation clips (cut to 30 s), each written as
+    ground truth and as the decoder's free-running prediction from the clip's first pose, speech and style (its own
+    frames as the style example, or its label).  Nets in eval mode, no_grad; B = 1 rollouts."""
+    from . import anim
+    J = len(details["parents"])
+    parents, names, dt = np.asarray(details["parents"]), details["bone_names"], details["dt"]
+    nlabels = len(details["label_names"])
+    was_training = [m.training for m in (se, de, st) if m is not None]
+    for m in (se, de, st):
+        if m is not None:
+            m.eval()
+    written = []
+    try:
+        with torch.no_grad():
+            for split in ("train", "valid"):
+                if len(ds.ranges_train if split == "train" else ds.ranges_valid) == 0:
+                    continue
+                for i in range(count):
+                    c = ds.sample_clip(split, seconds)
+                    T = c["pose"].shape[1]
+                    speech = se(c["audio"])
+                    if st is not None:
+                        z, _, _ = st(ds.clip_example(c["frames"], example_len))
+                    else:
+                        z = torch.zeros(1, nlabels, device=ds.device)
+                        z[0, c["label"]] = 1.0
+                    style = z[:, None].repeat(1, T, 1).contiguous()
+                    pose, rpos, rrot = ops.decoder_core(de, c["pose"][:, 0].contiguous(), c["rpos"][:, 0].contiguous(),
+                                                        c["rrot"][:, 0].contiguous(), c["gaze"], speech, style,
+                                                        ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, dt)
+                    label = details["label_names"][c["label"]]
+                    for kind, P, rp, rr in (("ground", c["pose"], c["rpos"], c["rrot"]), ("predict", pose, rpos, rrot)):
+                        path = samples_dir / f"iteration_{iteration}_{split}_{kind}_{i}_{label}.bvh"
+                        try:
+                            anim.write_bvh(str(path), rp[0], rr[0], P[0, :, 6:6 + 3 * J].reshape(T, J, 3),
+                                           P[0, :, 6 + 3 * J:6 + 9 * J].reshape(T, J, 2, 3), parents, names, "zyx", dt)
+                            written.append(path)
+                        except (PermissionError, OSError) as e:     # train.py:626-627: report and go on
+                            print(e)
+    finally:
+        for m, tr in zip([m for m in (se, de, st) if m is not None], was_training):
+            m.train(tr)
+    return written
 
 
 def train(models_dir, logs_dir, path_processed_data, path_data_definition, train_options, network_options):
@@ -90,6 +171,7 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
         eng.opt.attach_flat(eng.flat_p, eng.flat_g, keep_state=True)
         eng.iteration = iteration
     (logs_dir / "samples").mkdir(parents=True, exist_ok=True)
+    scalars = ScalarLog(logs_dir / "tb") if (train_options.get("use_tensorboard") and rank == 0) else None
     example_len = st_opt["example_length"]
     gb = batchsize * world
     labels_onehot = None
@@ -116,6 +198,8 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
             if (iteration + 1) % 1000 == 0:
                 for g in eng.opt.param_groups:
                     g["lr"] *= train_options["learning_rate_decay"]
+            if scalars is not None:
+                scalars.add(iteration, loss, eng.last_terms)
             if rank == 0 and iteration % 50 == 0:
                 sys.stdout.write(f"\r| epoch {epoch} | it {iteration} | batch {bi}/{nb} | loss {float(loss):.4f} "
                                  f"| {datetime.datetime.now() - start} |")
@@ -136,8 +220,11 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
                         compat.save_state(d, se, de, st, meta={"iteration": iteration, "epoch": epoch})
                     except ImportError as e:
                         print(f"\nwarning: safetensors twin not written ({e})")
+                render_samples(logs_dir / "samples", iteration, ds, se, de, st, details, st_opt["example_length"])
             iteration += 1
         epoch += 1
+    if scalars is not None:
+        scalars.close()
     if rank == 0:
         print("\nDone!")
     return None
