@@ -50,6 +50,11 @@ def _worker(rank, world, port, out, overlap=True):
     sys.path[:0] = [str(root), str(root / "ubisoft-laforge-zeroeggs_amd"), str(root / "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    # both ranks share ONE GPU here; the persistent (weight-stationary) kernels need every CU of the device for
+    # themselves (one process per GPU, as bench.py / train() run), so the two co-tenant ranks use the stage launches
+    from zeggs import ops
+    ops.set_option("train_persistent", 0)
+    ops.set_option("persistent", 0)
     p, loss = _step(world, rank, per_rank=2, overlap=overlap)
     out[rank] = (p.numpy(), loss)
     dist.destroy_process_group()
