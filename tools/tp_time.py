@@ -32,10 +32,14 @@ print("state", ops.lib().zeggs_persistent_state(1))
 d, training, ws = ops._LAST_DECODER_WS
 buf = (C.c_ulonglong * (4 * 2 * 32))()
 ops._check(ops.lib().zeggs_tp_stamps(C.byref(d), ops._p(ws), C.c_size_t(ws.numel()), buf), "stamps")
-st = np.array(buf[:], dtype=np.uint64).reshape(4, 2, 32).astype(np.float64) / 100.0
+raw = np.array(buf[:], dtype=np.uint64).reshape(4, 2, 32).astype(np.float64)
+st = raw / 100.0
 names = ["P1 start", "waited", "mma", "reduced", "epilogue", "arrived", "P2 waited", "mma", "reduced", "epilogue", "arrived",
          "P3 waited", "mma", "reduced", "epilogue", "arrived"]
 for k in range(1, 4):
     for wg in (0, 1):
         r = st[k, wg, :16]
         print(f"step T-{4 - k} wg {'0  ' if wg == 0 else '255'}: " + "  ".join(f"{n}:{v - r[0]:6.2f}" for n, v in zip(names[1:], r[1:])))
+for k in range(1, 4):
+    cyc, us = raw[k, 0, 17] - raw[k, 0, 16], st[k, 0, 15] - st[k, 0, 0]
+    print(f"step T-{4 - k}: {cyc:.0f} shader-clock cycles in {us:.2f} us -> {cyc / us:.0f} MHz")

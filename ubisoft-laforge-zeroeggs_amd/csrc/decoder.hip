@@ -23,6 +23,7 @@ extern int g_timing;
 extern int g_chain;
 extern int g_persistent;
 extern int g_train_persistent;
+extern int g_bwd_persistent;
 extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "decoder_fast") == 0) { g_decoder_fast = value; return 0; }
   if (strcmp(name, "stage_variant") == 0) { g_stage_variant = value; return 0; }
@@ -33,6 +34,11 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "train_persistent") == 0) {
     g_train_persistent = value;
     if (value && dec_tp_state() == 0) dec_tp_set_state(-1);
+    return 0;
+  }
+  if (strcmp(name, "bwd_persistent") == 0) {
+    g_bwd_persistent = value;
+    if (value && dec_bp_state() == 0) dec_bp_set_state(-1);
     return 0;
   }
   if (strcmp(name, "persistent") == 0) {
@@ -70,11 +76,11 @@ struct ErrWatch {
     return *host != 0;
   }
 };
-static ErrWatch g_watch_decode, g_watch_train;
+static ErrWatch g_watch_decode, g_watch_train, g_watch_bwd;
 
 // 1: the persistent kernel was validated on this process, 0: it failed once and is disabled, -1: not used yet
-extern "C" int zeggs_persistent_state(int which /* 0 decode (B=1), 1 training forward */) {
-  return which == 0 ? dec_persistent_state() : dec_tp_state();
+extern "C" int zeggs_persistent_state(int which /* 0 decode (B=1), 1 training forward, 2 BPTT sweep */) {
+  return which == 0 ? dec_persistent_state() : which == 1 ? dec_tp_state() : dec_bp_state();
 }
 
 namespace {
@@ -671,7 +677,38 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   bool wgrads_done = false;
   SideStream* ss = nullptr;
   const bool fast_path = g_decoder_fast && dec_fast_supported(d);
-  if (fast_path) {
+  // ---- batch <= 32: the whole sweep as one persistent launch (train_bwd_persistent.hip)
+  bool swept = false;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  hipStreamIsCapturing(s, &cap);
+  if (cap == hipStreamCaptureStatusNone && g_watch_bwd.failed()) {
+    dec_bp_set_state(0);
+    zeggs_set_error("persistent BPTT sweep: a bounded wait gave up in the PREVIOUS backward (its gradients are invalid); "
+                    "the kernel is disabled for this process, repeat the step");
+    return -1;
+  }
+  if (fast_path && g_bwd_persistent && dec_bp_state() != 0 && dec_bp_supported(d, w) &&
+      (cap == hipStreamCaptureStatusNone || dec_bp_state() == 1)) {
+    ZTRY(dec_bp_run(d, P, st, w, gaze, pose, rpos, rrot, dpose, drpos, drrot, s));
+    if (dec_bp_state() == 1) {
+      if (cap == hipStreamCaptureStatusNone) { unsigned* ew = nullptr; ZTRY(dec_bp_errptr(w, &ew)); ZTRY(g_watch_bwd.post(ew, s)); }
+      swept = true;
+    } else {      // first use on this process: validate (a bounded wait that gave up means not every workgroup was resident)
+      unsigned perr = 1;
+      ZCHECK(hipStreamSynchronize(s) == hipSuccess, "persistent BPTT sweep: stream sync failed");
+      ZTRY(dec_bp_errors(w, &perr));
+      dec_bp_set_state(perr == 0 ? 1 : 0);
+      swept = perr == 0;
+      if (!swept) {   // the stage kernels redo the sweep from clean carries
+        ZTRY(k_fill(w.dH0c, sH, 0.f, s));
+        ZTRY(k_fill(w.dH1c, sH, 0.f, s));
+        ZTRY(k_fill(w.carry, (long)2 * B * 8, 0.f, s));
+      }
+    }
+  }
+  if (swept) {
+    // nothing left to do here: DY, DI*, DH*, D0, DX and the final carries are in place
+  } else if (fast_path) {
     ZTRY(dec_fast_pack_bwd(d, P, st, w, s));
     // The sweep is a chain of small dependent launches that leaves most of the chip idle; the weight-gradient
     // GEMMs of the steps already swept run beside it on a low-priority stream, chunk by chunk.

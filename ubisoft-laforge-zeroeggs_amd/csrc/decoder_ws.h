@@ -37,6 +37,11 @@ struct DecWs {
   // fragments [T][kb][NB][64][4] of the three phases, arrival counters + error word
   float *tp_w0, *tp_w1, *tp_w3, *G0xf, *G1xf, *G3xf;
   unsigned* tp_cnt;
+  // persistent BPTT sweep (train_bwd_persistent.hip): per-workgroup weight tiles (register part, LDS part), write-once
+  // time-major operands dy / [DI1 | dn_h1] / [DI0 | dn_h0] / D0 in the 4x4x1 B layout, dXa of the root / gaze columns,
+  // arrival slots + error word
+  float *bp_wr, *bp_wl, *bp_opy, *bp_op1, *bp_op0, *bp_opd, *bp_sp;
+  unsigned* bp_cnt;
   size_t xf_bytes_fwd, xf_bytes_bwd;
   float *xf_base_fwd, *xf_base_bwd;
 };
@@ -127,6 +132,13 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
       w.G0xf = a.f(T * KB0 * XB); w.G1xf = a.f(T * 128 * XB); w.G3xf = a.f(T * KB3 * XB);
       w.tp_cnt = (unsigned*)a.f(4096);
     }
+    if (d.H == 1024 && d.B <= 32) {
+      w.bp_wr = a.f(256L * 8 * 113 * 64); w.bp_wl = a.f(256L * 8 * 64 * 64);
+      w.bp_opy = a.f(T * (long)((d.PO + 15) / 16) * 512);
+      w.bp_op1 = a.f(T * 4 * H * 32); w.bp_op0 = a.f(T * 4 * H * 32); w.bp_opd = a.f(T * H * 32);
+      w.bp_sp = a.f(T * 9 * 32);
+      w.bp_cnt = (unsigned*)a.f(4096);
+    }
   }
   return w;
 }
@@ -149,6 +161,15 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
                const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s);
 int dec_tp_errors(const DecWs& w, unsigned* out);
 int dec_tp_errptr(const DecWs& w, unsigned** out);
+// persistent BPTT sweep (train_bwd_persistent.hip)
+int dec_bp_supported(const ZeggsDecDims& d, const DecWs& w);
+int dec_bp_state();
+void dec_bp_set_state(int v);
+int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
+               const float* pose, const float* rpos, const float* rrot, const float* dpose, const float* drpos,
+               const float* drrot, hipStream_t s);
+int dec_bp_errors(const DecWs& w, unsigned* out);
+int dec_bp_errptr(const DecWs& w, unsigned** out);
 // fast path entry points (decoder_fast.hip)
 int dec_fast_merge_prep(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s);
 void dec_timing_mark(int i, hipStream_t s);

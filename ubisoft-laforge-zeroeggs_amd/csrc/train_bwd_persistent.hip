@@ -1,0 +1,577 @@
+// Weight-stationary persistent BPTT sweep of the training step (batch <= 32): the 255 backward decoder steps of a window
+// as ONE launch -- the backward mirror of train_persistent.hip.
+//
+// Why a different tile shape than the forward kernel.  The transposed products of a step (W_ih1^T, W_hh1^T, W_ih0^T, W_hh0^T,
+// W0^T, W2^T: 80 MB) give every one of the 256 workgroups 4 + 4 + 4 + 5 + 4 output rows; with the 16-row tiles of
+// v_mfma_f32_16x16x4_f32 the padded fragments (530-650 KB per CU) do not fit the 512 KB register file + 160 KB LDS of a CU.
+// v_mfma_f32_4x4x1_16b_f32 has 4-row tiles: with cbsz = 3 the 16 blocks of the instruction are 8 batch groups x 2 k-halves
+// that share the A values of block `abid`, i.e. ONE VGPR holds a [4 rows x 16 k] weight tile with no padding and eight
+// instructions (abid = 0..7) multiply it with a [16 k x 32 batch] operand block (measured: 131 TFLOP/s = 85 % of the 16x16x4
+// rate, tools/mfma4_probe.hip).  The per-CU weights are then 354 KB: 113 VGPRs per lane + 128 KB of LDS.
+//
+// Per step t (T-1 .. 1) four phases, each ending in a grid hand-off (arrival slots, as in train_persistent.hip):
+//   P1  dH1 = W2^T dy_t + carry1           -> layer-1 gate gradients DI1_t, dn_h1 (GRU backward);  carry1 = dH1 * z
+//   P2  dH0 = W_ih1^T DI1_t + carry0       -> layer-0 gate gradients DI0_t, dn_h0;                 carry0 = dH0 * z
+//   P3  [carry1 += W_hh1^T (DI1 r,z | dn_h1): operand one phase old, done before the wait]
+//       dGin = W_ih0^T DI0_t               -> D0_t = dhid * ELU'(hid_t), dXa (kept in LDS by the row's owner)
+//   P4  [carry0 += W_hh0^T (DI0 r,z | dn_h0)]
+//       dx_t = dXa + W0^T D0_t             -> speech / style columns to DX[t]; pose columns -> dy_{t-1}
+//                                             (devectorize / vectorize backward; the 9 root / gaze columns belong to
+//                                             workgroup 0, whose first 32 threads carry the root-integration adjoint)
+// Workgroup c owns hidden units 4c..4c+3 of both layers (the carries never leave its registers), rows 4c..4c+3 of dhid and
+// rows 5c..5c+4 of dx.  Operands travel through WRITE-ONCE time-major buffers in the B layout of the instruction
+// ([k-block][2][64 lanes][4]: lane = 32 * k-half + batch row), published with write-through stores; the canonical copies
+// (DI1, DH1, DI0, DH0, D0, DY, DX) are written where the stage kernels write them, so the weight-gradient GEMMs and the
+// CellStateEncoder backward are unchanged.  Every wait is bounded; on give-up the error word is set.
+#include "decoder_ws.h"
+#include "dec_math.h"
+#include "kernels.h"
+
+int g_bwd_persistent = 1;        // zeggs_set_option("bwd_persistent", 0/1)
+static int g_bp_ok = -1;
+
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64t;
+constexpr int BH = 1024, BTHR = 512, BNCU = 256, BSPIN = 1 << 21;
+// blocks (16 k each) per wave and part; block j of a wave is enumeration index e = wave + 8 j of the part
+constexpr int NJ1 = 9;      // P1: dy_t                        71 blocks (PO = 1131)
+constexpr int NJ2 = 24;     // P2: DI1_t                      192 blocks
+constexpr int NJC = 24;     // carry products: r,z rows of DI (128 blocks) + dn_h (64 blocks)
+constexpr int NJ3 = 24;     // P3: DI0_t, 3 row groups        192 blocks
+constexpr int NJ4 = 8;      // P4: D0_t, 3 row groups          64 blocks
+// register-resident weight tiles of a wave (one VGPR each): [P1 | P2 | C1 | C0 | P4 (j*3+rg) | tail of P3]
+constexpr int O1 = 0, O2 = O1 + NJ1, OC1 = O2 + NJ2, OC0 = OC1 + NJC, O4 = OC0 + NJC, O3T = O4 + 3 * NJ4;
+constexpr int L3 = 64;      // P3 tiles p = j*3+rg < L3 live in LDS
+constexpr int NWR = O3T + (3 * NJ3 - L3);     // 113
+constexpr int NSP = 9;      // root / gaze columns of x: 0..5, PO..PO+2
+
+struct BArgs {
+  ZeggsDecDims d;
+  ZeggsDecStats st;
+  int XD, GL, POL, KBY;
+  const float *PWR, *PWL;                    // [256][8][NWR][64], [256][8][L3][64]
+  float *OPY, *OP1, *OP0, *OPD, *SP;         // operands (time-major, write-once), dXa of the root / gaze columns [T][9][32]
+  const float *Gin, *H0, *H1, *GT0, *GT1;    // forward saves
+  float *DY, *DI1, *DH1, *DI0, *DH0, *D0, *DX, *dH0c, *dH1c;
+  const float *dpose, *drpos, *drrot, *gaze, *pose, *rpos, *rrot;
+  const float* carry;                        // root adjoint after frame T-1 [B][8]
+  unsigned *cnt, *err;
+};
+
+__device__ __forceinline__ void stp(float* p, float v) {       // published: write-through
+  __hip_atomic_store((gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// position of (batch row b, contraction index k) in an operand buffer: lane 32 * ((k >> 3) & 1) + b reads
+// float4 q = (k >> 2) & 1 of block k >> 4, element k & 3 (= abid & 3 of the instruction that consumes it)
+__host__ __device__ inline long op_idx(int b, int k) {
+  return ((((long)(k >> 4) * 2 + ((k >> 2) & 1)) * 64 + ((((k >> 3) & 1) << 5) | b)) << 2) | (k & 3);
+}
+
+__device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect) {
+  const int lane = threadIdx.x & 63;
+  const gu64t* q = (const gu64t*)(slots + 4 * lane);
+  for (unsigned spins = 0;; ++spins) {
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ok = (unsigned)a >= expect && (unsigned)(a >> 32) >= expect && (unsigned)b >= expect && (unsigned)(b >> 32) >= expect;
+    if (__all(ok)) return true;
+    if (spins > BSPIN) return false;
+  }
+}
+
+// enumeration index e of a part -> k-block of its operand buffer.  CARRY parts skip the n rows of DI (blocks 128..191)
+template <bool CARRY>
+__host__ __device__ inline int part_kb(int e) { return CARRY ? (e < 128 ? e : e + 64) : e; }
+
+// products of one part: blocks j = 0..NJ-1 of this wave, NRG row groups; weight tile (j, rg) = wr[OFF + j*NRG + rg], or for
+// LSPLIT > 0: tiles p = j*NRG+rg < LSPLIT from LDS (wl[p*64]), the rest from wr[OFF + p - LSPLIT].
+// Two blocks per group, the next group's operand loads are kept ahead of this group's products by scheduling fences.
+template <int NRG, int NJ, int OFF, int LSPLIT, bool CARRY>
+__device__ __forceinline__ void bp_mma(const float (&wr)[NWR], const float* wl, const f4* __restrict__ xb, int wave, int nblk,
+                                       f4 (&acc)[NRG]) {
+  constexpr int GU = 2, NG = (NJ + GU - 1) / GU;
+  f4 xa[GU][2], xq[GU][2];
+  auto load = [&](f4 (&x)[GU][2], int g) {
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      int e = wave + 8 * (GU * g + u);
+      e = e < nblk ? e : nblk - 1;              // past the end: the weights of that slot are zero (bp_pack_k)
+      const int kb = part_kb<CARRY>(e);
+      x[u][0] = xb[(long)(kb * 2) * 64];
+      x[u][1] = xb[(long)(kb * 2 + 1) * 64];
+    }
+  };
+  auto comp = [&](const f4 (&x)[GU][2], int g) {
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const int j = GU * g + u;
+      if (j < NJ) {
+#pragma unroll
+        for (int rg = 0; rg < NRG; ++rg) {
+          const int p = j * NRG + rg;
+          const float wv = (LSPLIT > 0 && p < LSPLIT) ? wl[p * 64] : wr[OFF + (p >= LSPLIT ? p - LSPLIT : 0)];
+          acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, x[u][0][0], acc[rg], 3, 0, 0);
+          acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, x[u][0][1], acc[rg], 3, 1, 0);
+          acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, x[u][0][2], acc[rg], 3, 2, 0);
+          acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, x[u][0][3], acc[rg], 3, 3, 0);
+          acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, x[u][1][0], acc[rg], 3, 4, 0);
+          acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, x[u][1][1], acc[rg], 3, 5, 0);
+          acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, x[u][1][2], acc[rg], 3, 6, 0);
+          acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, x[u][1][3], acc[rg], 3, 7, 0);
+        }
+      }
+    }
+  };
+  load(xa, 0);
+#pragma unroll
+  for (int g = 0; g < NG; g += 2) {
+    if (g + 1 < NG) load(xq, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    comp(xa, g);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 2 < NG) load(xa, g + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < NG) comp(xq, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// backward of the root integration of frame f with the adjoint carry in registers (decoder_fast.hip root_bwd, decoder.hip
+// dec_devec_bwd_k): cr = gradient wrt (root_pos_f, root_rot_f) arriving from the later frames.
+// g6: in = dpose[f][0:6] + dx/sigma_i ; out = total gradient wrt pose[f][0:6] (de-normalised output space)
+__device__ __forceinline__ void root_bwd_reg(const ZeggsDecDims& d, const ZeggsDecStats& st, int b, int f, bool has_next,
+                                             const float (&dgd_in)[3], const float* gaze, const float* pose, const float* rpos,
+                                             const float* rrot, const float* drpos, const float* drrot, float (&cr)[7],
+                                             float (&g6)[6]) {
+  const float* a = drpos + ((long)b * d.T + f) * 3;
+  const float* e = drrot + ((long)b * d.T + f) * 4;
+  V3 g_rp = v3(cr[0] + a[0], cr[1] + a[1], cr[2] + a[2]);
+  Q4 g_rr = Q4{cr[3] + e[0], cr[4] + e[1], cr[5] + e[2], cr[6] + e[3]};
+  const float* rq = rrot + ((long)b * d.T + f) * 4;
+  const float* rp = rpos + ((long)b * d.T + f) * 3;
+  const Q4 q_t = Q4{rq[0], rq[1], rq[2], rq[3]};
+  const V3 p_t = v3(rp[0], rp[1], rp[2]);
+  if (has_next) {
+    const float* gz = gaze + ((long)b * d.T + f + 1) * 3;
+    const V3 dgd = v3(dgd_in[0] / st.in_std[d.PO], dgd_in[1] / st.in_std[d.PO + 1], dgd_in[2] / st.in_std[d.PO + 2]);
+    Q4 dqi; V3 dv;
+    qmv_bwd(quat_inv(q_t), v3(gz[0], gz[1], gz[2]) - p_t, dgd, dqi, dv);
+    g_rr.w += dqi.w; g_rr.x -= dqi.x; g_rr.y -= dqi.y; g_rr.z -= dqi.z;
+    g_rp = g_rp - dv;
+  }
+  const float* pq = rrot + ((long)b * d.T + f - 1) * 4;
+  const Q4 q_p = Q4{pq[0], pq[1], pq[2], pq[3]};
+  const float* pt = pose + ((long)b * d.T + f) * d.PO;
+  const V3 vel = v3(pt[0], pt[1], pt[2]), vrt = v3(pt[3], pt[4], pt[5]);
+  Q4 dq1; V3 dv1;
+  qmv_bwd(q_p, d.dt * vel, g_rp, dq1, dv1);
+  const V3 u = quat_mul_vec(q_p, d.dt * vrt);
+  QExpCtx ec;
+  const Q4 E = quat_exp_ctx(0.5f * u, ec);
+  Q4 dE, dqy;
+  qmul_bwd(E, q_p, g_rr, dE, dqy);
+  const V3 du = 0.5f * qexp_bwd_ctx(0.5f * u, dE, ec);
+  Q4 dq2; V3 dv2;
+  qmv_bwd(q_p, d.dt * vrt, du, dq2, dv2);
+  g6[0] += d.dt * dv1.x; g6[1] += d.dt * dv1.y; g6[2] += d.dt * dv1.z;
+  g6[3] += d.dt * dv2.x; g6[4] += d.dt * dv2.y; g6[5] += d.dt * dv2.z;
+  cr[0] = g_rp.x; cr[1] = g_rp.y; cr[2] = g_rp.z;
+  cr[3] = dq1.w + dqy.w + dq2.w; cr[4] = dq1.x + dqy.x + dq2.x;
+  cr[5] = dq1.y + dqy.y + dq2.y; cr[6] = dq1.z + dqy.z + dq2.z;
+}
+
+// row of dx owned by slot s of workgroup c in P4 (-1: empty).  Workgroup 0: the root / gaze columns; others: 5c..5c+4
+// without the root / gaze columns (their dXa reaches workgroup 0 through SP)
+__host__ __device__ inline int special_index(int row, int PO) { return row < 6 ? row : (row >= PO && row < PO + 3 ? 6 + row - PO : -1); }
+__host__ __device__ inline int p4_row(int c, int s, int PO, int XD) {
+  if (c == 0) return s < 6 ? s : (s < NSP ? PO + s - 6 : -1);
+  if (s >= 5) return -1;
+  const int r = 5 * c + s;
+  return (r < XD && special_index(r, PO) < 0) ? r : -1;
+}
+__host__ __device__ inline int p3_row(int c, int s, int XD) {      // dXa slot s (0..7) of workgroup c
+  const int r = 5 * c + s;
+  return (s < 5 && r < XD) ? r : -1;
+}
+
+#ifdef ZEGGS_BPTIME
+#define BPT(i)                                                                                              \
+  do {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (t <= 3 && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                      \
+      ((unsigned long long*)(a.err + 32))[((3 - t) * 2 + (blockIdx.x != 0)) * 32 + (i)] = wall_clock64();     \
+  } while (0)
+#else
+#define BPT(i) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
+  __shared__ float wl3[8 * L3 * 64];          // P3 weight tiles of this workgroup (128 KB)
+  __shared__ float red[8][16][32];            // per-wave partial sums [row][batch]
+  __shared__ float dxa[8][32];                // dXa of this workgroup's dx rows (P3 -> P4)
+  __shared__ float sp9[NSP][32];              // workgroup 0: dx of the root / gaze columns
+  __shared__ int fail;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = blockIdx.x;
+  const ZeggsDecDims& d = a.d;
+  const int B = d.B, T = d.T, H = BH, PO = d.PO, PI = d.PI, XD = a.XD, GL = a.GL, POL = a.POL;
+  const long sH = (long)B * H, s3 = 3 * sH, sG = (long)B * GL;
+  // ---------------------------------------------------------------- weights -> registers / LDS (once per sweep)
+  float wr[NWR];
+  {
+    const float* p = a.PWR + ((long)(c * 8 + wave) * NWR) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) wr[i] = p[(long)i * 64];
+    const float* q = a.PWL + ((long)(c * 8 + wave) * L3) * 64 + lane;
+#pragma unroll 8
+    for (int i = 0; i < L3; ++i) wl3[(wave * L3 + i) * 64 + lane] = q[(long)i * 64];
+  }
+  if (tid == 0) fail = 0;
+  const float* wl = wl3 + wave * L3 * 64 + lane;
+  // epilogue item of this thread: output row er (0..15) of the phase, batch row eb
+  const int er = tid >> 5, eb = tid & 31;
+  const bool bact = eb < B;
+  const int U = 4 * c + (er & 3);               // hidden unit / dhid row of the GRU items (er < 4, er 4..7)
+  float c1 = 0.f, c0 = 0.f;                     // carries dH1c / dH0c of (U, eb): threads er < 4
+  // P4 item: slot s4 = er - 4 (0..11)
+  const int s4 = er - 4;
+  const int row4 = er >= 4 ? p4_row(c, s4, PO, XD) : -1;
+  float si4 = 1.f, so4 = 0.f;
+  if (row4 >= 0 && row4 < PI) { si4 = a.st.in_std[row4]; so4 = row4 < PO ? a.st.out_std[row4] : 0.f; }
+  // P3 dXa item: slot er - 8
+  const int row3 = er >= 8 ? p3_row(c, er - 8, XD) : -1;
+  const int sp3 = row3 >= 0 ? special_index(row3, PO) : -1;
+  // root thread of batch row eb (workgroup 0, first 32 threads): adjoint of (root_pos, root_rot) in registers
+  float cr[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool ract = c == 0 && tid < 32 && bact;
+  if (ract) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) cr[i] = a.carry[eb * 8 + i];
+  }
+  __syncthreads();
+
+  auto wait_phase = [&](long p) {     // all workgroups have finished phase instance p (p < 0: nothing to wait for)
+    if (p >= 0) {
+      if (wave == 0 && !bp_wait(a.cnt, (unsigned)(p + 1))) fail = 1;
+    }
+    __syncthreads();
+  };
+  auto arrive = [&](long p) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store((gu32*)(a.cnt + c), (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // wave partial sums -> red[wave][row0 + 4 rg + i][batch]  (the two k-halves of the accumulator lanes are added first)
+  auto put = [&](const f4& v, int row0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float s = v[i] + __shfl_xor(v[i], 32);
+      if (lane < 32) red[wave][row0 + i][lane] = s;
+    }
+  };
+  auto total = [&]() -> float {       // sum over the 8 waves of this thread's (er, eb)
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += red[w][er][eb];
+    return s;
+  };
+  // GRU backward of one (unit, batch row): g = total gradient wrt h_t; writes the gate gradients, returns g * z
+  auto gru_bwd = [&](float g, const f4& gt, float hp, float* DI, float* DHc, float* OP, long t) -> float {
+    const float r = gt[0], z = gt[1], nn = gt[2], nh = gt[3];
+    const float dn = g * (1.f - z);
+    const float dz = g * (hp - nn);
+    const float dan = dn * (1.f - nn * nn);
+    const float dar = dan * nh * r * (1.f - r);
+    const float daz = dz * z * (1.f - z);
+    float* di = DI + t * s3 + (long)eb * 3 * H;
+    di[U] = dar; di[H + U] = daz; di[2 * H + U] = dan;
+    DHc[t * sH + (long)eb * H + U] = dan * r;          // hidden side: only its n rows differ from di
+    float* op = OP + t * (4L * H * 32);
+    stp(op + op_idx(eb, U), dar); stp(op + op_idx(eb, H + U), daz); stp(op + op_idx(eb, 2 * H + U), dan);
+    stp(op + op_idx(eb, 3 * H + U), dan * r);
+    return g * z;
+  };
+
+  for (int t = T - 1; t >= 1; --t) {
+    const long sidx = T - 1 - t, pA = 4 * sidx, pB = pA + 1, pC = pA + 2, pD = pA + 3;
+    // ================================================================ P1 : dH1 = W2^T dy_t + carry1 -> layer-1 gates
+    BPT(0);
+    {
+      f4 gt = f4{0.f, 0.f, 0.f, 0.f};
+      float hp = 0.f;
+      if (er < 4 && bact) {
+        gt = ((const f4*)a.GT1)[(long)t * sH + (long)eb * H + U];
+        hp = a.H1[(long)(t - 1) * sH + (long)eb * H + U];
+      }
+      f4 acc[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+      wait_phase(pA - 1);
+      if (fail) break;
+      BPT(1);
+      bp_mma<1, NJ1, O1, 0, false>(wr, nullptr, (const f4*)(a.OPY + (long)t * a.KBY * 512) + lane, wave, a.KBY, acc);
+      BPT(2);
+      put(acc[0], 0);
+      __syncthreads();
+      if (er < 4 && bact) c1 = gru_bwd(total() + c1, gt, hp, a.DI1, a.DH1, a.OP1, t);
+      BPT(3);
+      arrive(pA);
+      BPT(4);
+    }
+    // ================================================================ P2 : dH0 = W_ih1^T DI1_t + carry0 -> layer-0 gates
+    {
+      f4 gt = f4{0.f, 0.f, 0.f, 0.f};
+      float hp = 0.f;
+      if (er < 4 && bact) {
+        gt = ((const f4*)a.GT0)[(long)t * sH + (long)eb * H + U];
+        hp = a.H0[(long)(t - 1) * sH + (long)eb * H + U];
+      }
+      f4 acc[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+      wait_phase(pB - 1);
+      if (fail) break;
+      BPT(5);
+      bp_mma<1, NJ2, O2, 0, false>(wr, nullptr, (const f4*)(a.OP1 + (long)t * (4L * H * 32)) + lane, wave, 192, acc);
+      BPT(6);
+      put(acc[0], 0);
+      __syncthreads();
+      if (er < 4 && bact) c0 = gru_bwd(total() + c0, gt, hp, a.DI0, a.DH0, a.OP0, t);
+      BPT(7);
+      arrive(pB);
+      BPT(8);
+    }
+    // ================================================================ P3 : carry1 += W_hh1^T (.) ; dGin = W_ih0^T DI0_t
+    {
+      float hid = 0.f;
+      if (er >= 4 && er < 8 && bact) hid = a.Gin[(long)t * sG + (long)eb * GL + U];
+      f4 accc[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+      // old operand (DI1_t, dn_h1: complete since the P1 hand-off): before the wait
+      bp_mma<1, NJC, OC1, 0, true>(wr, nullptr, (const f4*)(a.OP1 + (long)t * (4L * H * 32)) + lane, wave, 192, accc);
+      f4 acc[3] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+      wait_phase(pC - 1);
+      if (fail) break;
+      BPT(9);
+      bp_mma<3, NJ3, O3T, L3, false>(wr, wl, (const f4*)(a.OP0 + (long)t * (4L * H * 32)) + lane, wave, 192, acc);
+      BPT(10);
+      put(accc[0], 0); put(acc[0], 4); put(acc[1], 8); put(acc[2], 12);
+      __syncthreads();
+      if (bact) {
+        const float v = total();
+        if (er < 4) c1 += v;
+        else if (er < 8) {
+          const float d0 = v * d_elu_grad_from_out(hid);
+          a.D0[(long)t * sH + (long)eb * H + U] = d0;
+          stp(a.OPD + (long)t * (H * 32L) + op_idx(eb, U), d0);
+        } else if (row3 >= 0) {
+          dxa[er - 8][eb] = v;
+          if (sp3 >= 0) stp(a.SP + ((long)t * NSP + sp3) * 32 + eb, v);
+        }
+      }
+      BPT(11);
+      arrive(pC);
+      BPT(12);
+    }
+    // ================================================================ P4 : carry0 += W_hh0^T (.) ; dx_t = dXa + W0^T D0_t
+    {
+      float dpo = 0.f;
+      if (t > 1 && bact && row4 >= 6 && row4 < PO && c != 0) dpo = a.dpose[((long)eb * T + t - 1) * PO + row4];
+      f4 accc[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+      bp_mma<1, NJC, OC0, 0, true>(wr, nullptr, (const f4*)(a.OP0 + (long)t * (4L * H * 32)) + lane, wave, 192, accc);
+      f4 acc[3] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+      wait_phase(pD - 1);
+      if (fail) break;
+      BPT(13);
+      float spv = 0.f;                                     // workgroup 0: dXa of the root / gaze columns (other owners)
+      if (c == 0 && er >= 4 && s4 < NSP && bact) spv = a.SP[((long)t * NSP + s4) * 32 + eb];
+      bp_mma<3, NJ4, O4, 0, false>(wr, nullptr, (const f4*)(a.OPD + (long)t * (H * 32L)) + lane, wave, 64, acc);
+      BPT(14);
+      put(accc[0], 0); put(acc[0], 4); put(acc[1], 8); put(acc[2], 12);
+      __syncthreads();
+      if (bact) {
+        const float v = total();
+        if (er < 4) c0 += v;
+        else if (c == 0) {
+          if (s4 < NSP) sp9[s4][eb] = v + spv;
+        } else if (row4 >= 0) {
+          const float dx = v + dxa[s4][eb];
+          if (row4 >= PI) a.DX[((long)t * B + eb) * XD + row4] = dx;       // speech / style columns
+          else if (t > 1 && row4 < PO) {                                     // pose columns -> dy_{t-1}
+            const float gy = (dpo + dx / si4) * so4;
+            a.DY[((long)(t - 1) * B + eb) * POL + row4] = gy;
+            stp(a.OPY + (long)(t - 1) * a.KBY * 512 + op_idx(eb, row4), gy);
+          }
+        }
+      }
+      if (c == 0) {
+        __syncthreads();
+        if (ract && t > 1) {
+          float g6[6], dgd[3];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) g6[q] = a.dpose[((long)eb * T + t - 1) * PO + q] + sp9[q][eb] / a.st.in_std[q];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) dgd[q] = sp9[6 + q][eb];
+          root_bwd_reg(d, a.st, eb, t - 1, true, dgd, a.gaze, a.pose, a.rpos, a.rrot, a.drpos, a.drrot, cr, g6);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            const float gy = g6[q] * a.st.out_std[q];
+            a.DY[((long)(t - 1) * B + eb) * POL + q] = gy;
+            stp(a.OPY + (long)(t - 1) * a.KBY * 512 + op_idx(eb, q), gy);
+          }
+        }
+      }
+      BPT(15);
+      arrive(pD);
+      BPT(16);
+    }
+  }
+  if (!fail && er < 4 && bact) {     // gradients wrt the initial hidden states (CellStateEncoder backward)
+    a.dH1c[(long)eb * H + U] = c1;
+    a.dH0c[(long)eb * H + U] = c0;
+  }
+  if (fail && tid == 0) atomicOr(a.err, 1u);
+}
+
+// ---------------------------------------------------------------- weight tiles (once per optimizer step)
+struct BPackArgs {
+  float *PWR, *PWL;
+  const float *w_ih0, *w_hh0, *w_ih1, *w_hh1, *l2_w, *l0_w;
+  int XD, PO, KBY;
+};
+// weight of output row `i` (0..3) of row group rg, contraction index k, for tile (part, workgroup c)
+//   part 0 P1, 1 P2, 2 C1, 3 C0, 4 P4, 5 P3
+__device__ __forceinline__ float bp_value(const BPackArgs& p, int part, int c, int rg, int i, int kb, int kk) {
+  const int H = BH, U = 4 * c + i, k = 16 * kb + kk;
+  switch (part) {
+    case 0: return k < p.PO ? p.l2_w[(long)k * H + U] : 0.f;                       // dH1[U] += W2[k][U] dy[k]
+    case 1: return p.w_ih1[(long)k * H + U];                                      // dH0[U] += W_ih1[g][U] DI1[g]
+    case 2: return p.w_hh1[(long)(k < 2 * H ? k : k - H) * H + U];                // operand [DI1 (3H) | dn_h1 (H)], n rows skipped
+    case 3: return p.w_hh0[(long)(k < 2 * H ? k : k - H) * H + U];
+    case 4: {
+      const int row = p4_row(c, 4 * rg + i, p.PO, p.XD);
+      return row >= 0 ? p.l0_w[(long)k * p.XD + row] : 0.f;                        // dx[row] += W0[m][row] D0[m]
+    }
+    default: {
+      const long ld = H + p.XD;
+      if (rg == 0) return p.w_ih0[(long)k * ld + U];                              // dhid
+      const int row = p3_row(c, 4 * (rg - 1) + i, p.XD);
+      return row >= 0 ? p.w_ih0[(long)k * ld + H + row] : 0.f;                    // dXa
+    }
+  }
+}
+__global__ void bp_pack_k(BPackArgs p) {
+  const long nr = (long)BNCU * 8 * NWR * 64, nl = (long)BNCU * 8 * L3 * 64;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < nr + nl; idx += (long)gridDim.x * blockDim.x) {
+    const bool lds = idx >= nr;
+    const long r = lds ? idx - nr : idx;
+    const int lane = (int)(r & 63);
+    const long cws = r >> 6;
+    const int per = lds ? L3 : NWR;
+    const int slot = (int)(cws % per), wave = (int)((cws / per) & 7), c = (int)(cws / (8L * per));
+    int part, j, rg;
+    if (lds) { part = 5; j = slot / 3; rg = slot % 3; }
+    else if (slot < O2) { part = 0; j = slot - O1; rg = 0; }
+    else if (slot < OC1) { part = 1; j = slot - O2; rg = 0; }
+    else if (slot < OC0) { part = 2; j = slot - OC1; rg = 0; }
+    else if (slot < O4) { part = 3; j = slot - OC0; rg = 0; }
+    else if (slot < O3T) { part = 4; j = (slot - O4) / 3; rg = (slot - O4) % 3; }
+    else { part = 5; const int q = slot - O3T + L3; j = q / 3; rg = q % 3; }
+    const int nblk = part == 0 ? p.KBY : (part == 4 ? 64 : 192);
+    const int e = wave + 8 * j;
+    float v = 0.f;
+    if (e < nblk) {
+      const int kb = (part == 2 || part == 3) ? part_kb<true>(e) : e;
+      v = bp_value(p, part, c, rg, lane & 3, kb, lane >> 2);
+    }
+    (lds ? p.PWL : p.PWR)[r] = v;
+  }
+}
+
+// canonical [B, ld] -> operand layout
+__global__ void bp_to_op_k(float* op, const float* src, long ld, int K, int B) {
+  const long n = (long)B * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K), b = (int)(i / K);
+    op[op_idx(b, k)] = src[(long)b * ld + k];
+  }
+}
+// gradient wrt the raw output of the LAST frame (no next step feeds on it) + the root adjoint it leaves behind
+__global__ void bp_dy_last_k(ZeggsDecDims d, ZeggsDecStats st, const float* dpose, const float* drpos, const float* drrot,
+                             const float* gaze, const float* pose, const float* rpos, const float* rrot, float* carry,
+                             float* dy, int POL) {
+  const int b = blockIdx.x, t = d.T - 1;
+  const float* dpb = dpose + ((long)b * d.T + t) * d.PO;
+  for (int cc = 6 + threadIdx.x; cc < d.PO; cc += blockDim.x) dy[(long)b * POL + cc] = dpb[cc] * st.out_std[cc];
+  if (threadIdx.x == 0) {
+    float g6[6], cr[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dgd[3] = {0.f, 0.f, 0.f};
+    for (int q = 0; q < 6; ++q) g6[q] = dpb[q];
+    root_bwd_reg(d, st, b, t, false, dgd, gaze, pose, rpos, rrot, drpos, drrot, cr, g6);
+    for (int q = 0; q < 6; ++q) dy[(long)b * POL + q] = g6[q] * st.out_std[q];
+    for (int q = 0; q < 7; ++q) carry[b * 8 + q] = cr[q];
+  }
+}
+
+}  // namespace
+
+int dec_bp_supported(const ZeggsDecDims& d, const DecWs& w) {
+  return !d.film && d.H == BH && d.B <= 32 && d.T >= 3 && d.PI == d.PO + 3 && d.PO >= 16 && (d.PO + 15) / 16 <= 8 * NJ1 &&
+         w.XD <= 5 * BNCU && w.bp_wr != nullptr;
+}
+int dec_bp_state() { return g_bp_ok; }
+void dec_bp_set_state(int v) { g_bp_ok = v; }
+
+// the whole sweep t = T-1 .. 1; leaves DY, DI*, DH*, D0, DX (speech / style columns), dH0c, dH1c as the stage sweep does
+int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
+               const float* pose, const float* rpos, const float* rrot, const float* dpose, const float* drpos,
+               const float* drrot, hipStream_t s) {
+  const int B = d.B, T = d.T, H = d.H, KBY = (d.PO + 15) / 16;
+  int dev = 0, ncu = 0;
+  ZCHECK(hipGetDevice(&dev) == hipSuccess, "hipGetDevice failed");
+  ZCHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess, "device query failed");
+  ZCHECK(ncu >= BNCU, "persistent BPTT sweep needs %d CUs (device has %d)", BNCU, ncu);
+  BPackArgs p{w.bp_wr, w.bp_wl, P->w_ih0, P->w_hh0, P->w_ih1, P->w_hh1, P->l2_w, P->l0_w, w.XD, d.PO, KBY};
+  hipLaunchKernelGGL(bp_pack_k, dim3(8192), dim3(256), 0, s, p);
+  ZLAUNCH_CHECK("bp_pack");
+  // the pad k rows of dy (PO .. 16 KBY) must be finite: zero the operand once; every other operand element that is read
+  // with a non-zero weight is written by the sweep (pad batch lanes only ever feed pad batch columns)
+  ZTRY(k_fill(w.bp_opy, (long)T * KBY * 512, 0.f, s));
+  ZTRY(k_fill((float*)w.bp_cnt, 2048, 0.f, s));
+  float* dyl = w.DY + (long)(T - 1) * B * w.POL;
+  hipLaunchKernelGGL(bp_dy_last_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, gaze, pose, rpos, rrot, w.carry,
+                     dyl, w.POL);
+  hipLaunchKernelGGL(bp_to_op_k, dim3((B * d.PO + 255) / 256), dim3(256), 0, s, w.bp_opy + (long)(T - 1) * KBY * 512, dyl,
+                     (long)w.POL, d.PO, B);
+  ZLAUNCH_CHECK("bp_prologue");
+  BArgs a;
+  memset(&a, 0, sizeof(a));
+  a.d = d; a.st = *st; a.XD = w.XD; a.GL = w.GL; a.POL = w.POL; a.KBY = KBY;
+  a.PWR = w.bp_wr; a.PWL = w.bp_wl;
+  a.OPY = w.bp_opy; a.OP1 = w.bp_op1; a.OP0 = w.bp_op0; a.OPD = w.bp_opd; a.SP = w.bp_sp;
+  a.Gin = w.Gin; a.H0 = w.H0; a.H1 = w.H1; a.GT0 = w.GT0; a.GT1 = w.GT1;
+  a.DY = w.DY; a.DI1 = w.DI1; a.DH1 = w.DH1; a.DI0 = w.DI0; a.DH0 = w.DH0; a.D0 = w.D0; a.DX = w.DX;
+  a.dH0c = w.dH0c; a.dH1c = w.dH1c;
+  a.dpose = dpose; a.drpos = drpos; a.drrot = drrot; a.gaze = gaze; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
+  a.carry = w.carry;
+  a.cnt = w.bp_cnt; a.err = w.bp_cnt + 1024;
+  dec_timing_mark(2, s);
+  hipLaunchKernelGGL(train_bwd_persistent_k, dim3(BNCU), dim3(BTHR), 0, s, a);
+  dec_timing_mark(3, s);
+  ZLAUNCH_CHECK("train_bwd_persistent");
+  (void)H;
+  return 0;
+}
+extern "C" int zeggs_bp_stamps(const ZeggsDecDims* dp, void* ws, size_t ws_bytes, unsigned long long* out /* [3][2][32] */) {
+  Arena a(ws, ws_bytes);
+  DecWs w = carve_dec(*dp, 1, a);
+  ZCHECK(a.ok() && w.bp_cnt, "bp_stamps: workspace");
+  ZCHECK(hipMemcpy(out, w.bp_cnt + 1024 + 32, 3 * 2 * 32 * 8, hipMemcpyDeviceToHost) == hipSuccess, "copy");
+  return 0;
+}
+int dec_bp_errptr(const DecWs& w, unsigned** out) {
+  *out = w.bp_cnt + 1024;
+  return 0;
+}
+int dec_bp_errors(const DecWs& w, unsigned* out) {
+  ZCHECK(hipMemcpy(out, w.bp_cnt + 1024, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess,
+         "persistent BPTT sweep: error word copy failed");
+  return 0;
+}

@@ -111,13 +111,19 @@ __device__ __forceinline__ void tp_mma(const f4 (&wr)[NJT], const f4* wl, const 
       }
     }
   };
+  // the scheduling fences keep the next group's loads AHEAD of this group's products (left alone, the compiler sinks
+  // every load next to its first use to shorten live ranges, which exposes the whole load latency per block)
   load(xa, 0);
 #pragma unroll
   for (int g = 0; g < NG; g += 2) {
     if (g + 1 < NG) load(xq, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
     comp(xa, g);
+    __builtin_amdgcn_sched_barrier(0);
     if (g + 2 < NG) load(xa, g + 2);
+    __builtin_amdgcn_sched_barrier(0);
     if (g + 1 < NG) comp(xq, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -128,8 +134,11 @@ __device__ __forceinline__ void tp_mma(const f4 (&wr)[NJT], const f4* wl, const 
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    if (t >= T - 4 && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                  \
-      ((unsigned long long*)(a.err + 32))[((t - (T - 4)) * 2 + (blockIdx.x != 0)) * 32 + (i)] = wall_clock64(); \
+    if (t >= T - 4 && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {                \
+      unsigned long long* sl_ = (unsigned long long*)(a.err + 32) + ((t - (T - 4)) * 2 + (blockIdx.x != 0)) * 32; \
+      sl_[(i)] = wall_clock64();                                                                            \
+      if ((i) == 0 || (i) == 15) sl_[16 + ((i) == 15)] = clock64();   /* shader-clock cycles of the step */  \
+    }                                                                                                       \
   } while (0)
 #else
 #define TPT(i)
