@@ -12,9 +12,11 @@
 // Per step t (T-1 .. 1) four phases, each ending in a grid hand-off (arrival slots, as in train_persistent.hip):
 //   P1  dH1 = W2^T dy_t + carry1           -> layer-1 gate gradients DI1_t, dn_h1 (GRU backward);  carry1 = dH1 * z
 //   P2  dH0 = W_ih1^T DI1_t + carry0       -> layer-0 gate gradients DI0_t, dn_h0;                 carry0 = dH0 * z
-//   P3  [carry1 += W_hh1^T (DI1 r,z | dn_h1): operand one phase old, done before the wait]
+//       carry1 += W_hh1[r,z]^T DI1_t[r,z]     (second row group over the same operand blocks: the r, z rows are shared)
+//   P3  [carry1 += W_hh1[n]^T dn_h1: operand one phase old, done before the wait -- it hides the hand-off latency]
 //       dGin = W_ih0^T DI0_t               -> D0_t = dhid * ELU'(hid_t), dXa (kept in LDS by the row's owner)
-//   P4  [carry0 += W_hh0^T (DI0 r,z | dn_h0)]
+//       carry0 += W_hh0[r,z]^T DI0_t[r,z]
+//   P4  [carry0 += W_hh0[n]^T dn_h0]
 //       dx_t = dXa + W0^T D0_t             -> speech / style columns to DX[t]; pose columns -> dy_{t-1}
 //                                             (devectorize / vectorize backward; the 9 root / gaze columns belong to
 //                                             workgroup 0, whose first 32 threads carry the root-integration adjoint)
@@ -35,16 +37,20 @@ namespace {
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64t;
 constexpr int BH = 1024, BTHR = 512, BNCU = 256, BSPIN = 1 << 21;
-// blocks (16 k each) per wave and part; block j of a wave is enumeration index e = wave + 8 j of the part
-constexpr int NJ1 = 9;      // P1: dy_t                        71 blocks (PO = 1131)
-constexpr int NJ2 = 24;     // P2: DI1_t                      192 blocks
-constexpr int NJC = 24;     // carry products: r,z rows of DI (128 blocks) + dn_h (64 blocks)
-constexpr int NJ3 = 24;     // P3: DI0_t, 3 row groups        192 blocks
-constexpr int NJ4 = 8;      // P4: D0_t, 3 row groups          64 blocks
-// register-resident weight tiles of a wave (one VGPR each): [P1 | P2 | C1 | C0 | P4 (j*3+rg) | tail of P3]
-constexpr int O1 = 0, O2 = O1 + NJ1, OC1 = O2 + NJ2, OC0 = OC1 + NJC, O4 = OC0 + NJC, O3T = O4 + 3 * NJ4;
-constexpr int L3 = 64;      // P3 tiles p = j*3+rg < L3 live in LDS
-constexpr int NWR = O3T + (3 * NJ3 - L3);     // 113
+// blocks (16 k each) per wave and part; block j of a wave is enumeration index e = wave + 8 j of the part.  Every workgroup
+// streams the whole operand of a part through its CU (2 KB per block), which is what bounds the single-row-group parts, so
+// the carry products share the r, z blocks (0..127) of DI with the main product of the phase and only their dn_h blocks
+// (192..255 of the operand) are separate "old" work.
+constexpr int NJ1 = 9;      // P1: dy_t                                   71 blocks (PO = 1131), 1 row group
+constexpr int NJA = 16;     // P2 / P3, blocks 0..127 of DI (r, z rows):  main row groups + the carry row group
+constexpr int NJB = 8;      // P2 / P3, blocks 128..191 (n rows):         main row groups
+constexpr int NJT = 8;      // carry tails: blocks 192..255 (dn_h), 1 row group, before the wait of the NEXT phase
+constexpr int NJ4 = 8;      // P4: D0_t                                   64 blocks, 3 row groups
+// register-resident weight tiles of a wave (one VGPR each); the 64 tiles of P3's first part live in LDS
+constexpr int O1 = 0, O2A = O1 + NJ1, O2B = O2A + 2 * NJA, OT1 = O2B + NJB, O3B = OT1 + NJT, OT0 = O3B + 3 * NJB,
+              O4 = OT0 + NJT;
+constexpr int NWR = O4 + 3 * NJ4;             // 113
+constexpr int L3 = 4 * NJA;                   // 64
 constexpr int NSP = 9;      // root / gaze columns of x: 0..5, PO..PO+2
 
 struct BArgs {
@@ -81,24 +87,20 @@ __device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect) 
   }
 }
 
-// enumeration index e of a part -> k-block of its operand buffer.  CARRY parts skip the n rows of DI (blocks 128..191)
-template <bool CARRY>
-__host__ __device__ inline int part_kb(int e) { return CARRY ? (e < 128 ? e : e + 64) : e; }
-
-// products of one part: blocks j = 0..NJ-1 of this wave, NRG row groups; weight tile (j, rg) = wr[OFF + j*NRG + rg], or for
-// LSPLIT > 0: tiles p = j*NRG+rg < LSPLIT from LDS (wl[p*64]), the rest from wr[OFF + p - LSPLIT].
+// products of one part: blocks j = 0..NJ-1 of this wave are k-blocks kb0 + wave + 8 j (< kb0 + nblk) of the operand, NRG row
+// groups; weight tile (j, rg) = wr[OFF + j*NRG + rg] or, for LDS, wl[(j*NRG + rg) * 64].
 // Two blocks per group, the next group's operand loads are kept ahead of this group's products by scheduling fences.
-template <int NRG, int NJ, int OFF, int LSPLIT, bool CARRY>
-__device__ __forceinline__ void bp_mma(const float (&wr)[NWR], const float* wl, const f4* __restrict__ xb, int wave, int nblk,
-                                       f4 (&acc)[NRG]) {
-  constexpr int GU = 2, NG = (NJ + GU - 1) / GU;
+template <int NRG, int NJ, int OFF, bool LDS>
+__device__ __forceinline__ void bp_mma(const float (&wr)[NWR], const float* wl, const f4* __restrict__ xb, int wave, int kb0,
+                                       int nblk, f4* acc) {
+  constexpr int GU = NRG >= 3 ? 1 : 2, NG = (NJ + GU - 1) / GU;     // operand blocks per group (matrix-core bound parts: 1)
   f4 xa[GU][2], xq[GU][2];
   auto load = [&](f4 (&x)[GU][2], int g) {
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
       int e = wave + 8 * (GU * g + u);
       e = e < nblk ? e : nblk - 1;              // past the end: the weights of that slot are zero (bp_pack_k)
-      const int kb = part_kb<CARRY>(e);
+      const int kb = kb0 + e;
       x[u][0] = xb[(long)(kb * 2) * 64];
       x[u][1] = xb[(long)(kb * 2 + 1) * 64];
     }
@@ -111,7 +113,7 @@ __device__ __forceinline__ void bp_mma(const float (&wr)[NWR], const float* wl, 
 #pragma unroll
         for (int rg = 0; rg < NRG; ++rg) {
           const int p = j * NRG + rg;
-          const float wv = (LSPLIT > 0 && p < LSPLIT) ? wl[p * 64] : wr[OFF + (p >= LSPLIT ? p - LSPLIT : 0)];
+          const float wv = LDS ? wl[p * 64] : wr[OFF + p];
           acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, x[u][0][0], acc[rg], 3, 0, 0);
           acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, x[u][0][1], acc[rg], 3, 1, 0);
           acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, x[u][0][2], acc[rg], 3, 2, 0);
@@ -138,33 +140,53 @@ __device__ __forceinline__ void bp_mma(const float (&wr)[NWR], const float* wl, 
   }
 }
 
+// inputs of the root-integration backward of frame f (forward outputs and upstream gradients: old data).  NRI items per
+// batch row; workgroup 0 fetches them with all its threads into LDS ahead of the products (root_item), the root thread of a
+// row reads them back (RootIn::from_lds)
+constexpr int NRI = 33;
+__device__ __forceinline__ float root_item(const float* drpos, const float* drrot, const float* rrot, const float* rpos,
+                                           const float* gaze, const float* pose, const float* dpose, int T, int PO, int b, int f,
+                                           bool has_next, int item) {
+  const long bf = (long)b * T + f;
+  if (item < 3) return drpos[bf * 3 + item];
+  if (item < 7) return drrot[bf * 4 + item - 3];
+  if (item < 11) return rrot[bf * 4 + item - 7];
+  if (item < 14) return rpos[bf * 3 + item - 11];
+  if (item < 17) return has_next ? gaze[(bf + 1) * 3 + item - 14] : 0.f;
+  if (item < 21) return rrot[(bf - 1) * 4 + item - 17];
+  if (item < 27) return pose[bf * PO + item - 21];
+  return dpose[bf * PO + item - 27];
+}
+struct RootIn {
+  float a[3], e[4], rq[4], rp[3], gz[3], pq[4], pt[6], dp[6];
+  template <class F>
+  __device__ __forceinline__ void gather(F get) {      // get(item) -> value
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { a[i] = get(i); rp[i] = get(11 + i); gz[i] = get(14 + i); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { e[i] = get(3 + i); rq[i] = get(7 + i); pq[i] = get(17 + i); }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { pt[i] = get(21 + i); dp[i] = get(27 + i); }
+  }
+};
 // backward of the root integration of frame f with the adjoint carry in registers (decoder_fast.hip root_bwd, decoder.hip
 // dec_devec_bwd_k): cr = gradient wrt (root_pos_f, root_rot_f) arriving from the later frames.
 // g6: in = dpose[f][0:6] + dx/sigma_i ; out = total gradient wrt pose[f][0:6] (de-normalised output space)
-__device__ __forceinline__ void root_bwd_reg(const ZeggsDecDims& d, const ZeggsDecStats& st, int b, int f, bool has_next,
-                                             const float (&dgd_in)[3], const float* gaze, const float* pose, const float* rpos,
-                                             const float* rrot, const float* drpos, const float* drrot, float (&cr)[7],
-                                             float (&g6)[6]) {
-  const float* a = drpos + ((long)b * d.T + f) * 3;
-  const float* e = drrot + ((long)b * d.T + f) * 4;
-  V3 g_rp = v3(cr[0] + a[0], cr[1] + a[1], cr[2] + a[2]);
-  Q4 g_rr = Q4{cr[3] + e[0], cr[4] + e[1], cr[5] + e[2], cr[6] + e[3]};
-  const float* rq = rrot + ((long)b * d.T + f) * 4;
-  const float* rp = rpos + ((long)b * d.T + f) * 3;
-  const Q4 q_t = Q4{rq[0], rq[1], rq[2], rq[3]};
-  const V3 p_t = v3(rp[0], rp[1], rp[2]);
+__device__ __forceinline__ void root_bwd_reg(const ZeggsDecDims& d, const float* gaze_in_std /* [3] */, const RootIn& ri,
+                                             const float (&dgd_in)[3], float (&cr)[7], float (&g6)[6], bool has_next = true) {
+  V3 g_rp = v3(cr[0] + ri.a[0], cr[1] + ri.a[1], cr[2] + ri.a[2]);
+  Q4 g_rr = Q4{cr[3] + ri.e[0], cr[4] + ri.e[1], cr[5] + ri.e[2], cr[6] + ri.e[3]};
+  const Q4 q_t = Q4{ri.rq[0], ri.rq[1], ri.rq[2], ri.rq[3]};
+  const V3 p_t = v3(ri.rp[0], ri.rp[1], ri.rp[2]);
   if (has_next) {
-    const float* gz = gaze + ((long)b * d.T + f + 1) * 3;
-    const V3 dgd = v3(dgd_in[0] / st.in_std[d.PO], dgd_in[1] / st.in_std[d.PO + 1], dgd_in[2] / st.in_std[d.PO + 2]);
+    const V3 dgd = v3(dgd_in[0] / gaze_in_std[0], dgd_in[1] / gaze_in_std[1], dgd_in[2] / gaze_in_std[2]);
     Q4 dqi; V3 dv;
-    qmv_bwd(quat_inv(q_t), v3(gz[0], gz[1], gz[2]) - p_t, dgd, dqi, dv);
+    qmv_bwd(quat_inv(q_t), v3(ri.gz[0], ri.gz[1], ri.gz[2]) - p_t, dgd, dqi, dv);
     g_rr.w += dqi.w; g_rr.x -= dqi.x; g_rr.y -= dqi.y; g_rr.z -= dqi.z;
     g_rp = g_rp - dv;
   }
-  const float* pq = rrot + ((long)b * d.T + f - 1) * 4;
-  const Q4 q_p = Q4{pq[0], pq[1], pq[2], pq[3]};
-  const float* pt = pose + ((long)b * d.T + f) * d.PO;
-  const V3 vel = v3(pt[0], pt[1], pt[2]), vrt = v3(pt[3], pt[4], pt[5]);
+  const Q4 q_p = Q4{ri.pq[0], ri.pq[1], ri.pq[2], ri.pq[3]};
+  const V3 vel = v3(ri.pt[0], ri.pt[1], ri.pt[2]), vrt = v3(ri.pt[3], ri.pt[4], ri.pt[5]);
   Q4 dq1; V3 dv1;
   qmv_bwd(q_p, d.dt * vel, g_rp, dq1, dv1);
   const V3 u = quat_mul_vec(q_p, d.dt * vrt);
@@ -175,6 +197,78 @@ __device__ __forceinline__ void root_bwd_reg(const ZeggsDecDims& d, const ZeggsD
   const V3 du = 0.5f * qexp_bwd_ctx(0.5f * u, dE, ec);
   Q4 dq2; V3 dv2;
   qmv_bwd(q_p, d.dt * vrt, du, dq2, dv2);
+  g6[0] += d.dt * dv1.x; g6[1] += d.dt * dv1.y; g6[2] += d.dt * dv1.z;
+  g6[3] += d.dt * dv2.x; g6[4] += d.dt * dv2.y; g6[5] += d.dt * dv2.z;
+  cr[0] = g_rp.x; cr[1] = g_rp.y; cr[2] = g_rp.z;
+  cr[3] = dq1.w + dqy.w + dq2.w; cr[4] = dq1.x + dqy.x + dq2.x;
+  cr[5] = dq1.y + dqy.y + dq2.y; cr[6] = dq1.z + dqy.z + dq2.z;
+}
+
+// The same backward split in two for the persistent kernel: everything that depends on forward data only (the rotations,
+// quat_exp and its sine / cosine) is evaluated one phase ahead by the root thread and parked in its LDS column (33 values,
+// in place of the raw inputs); what is left behind the hand-off is linear in the incoming gradients.
+struct RootPre { Q4 qti; V3 w; Q4 qp; V3 dvel, dvrt, hu; Q4 E; float ea, eb_, ec; float dp[6]; };
+// backward of quat_exp at a prepared point x: du = ea * g_v + (eb_ * g_w + ec * <g_v, x>) * x   (dec_math.h qexp_bwd_ctx with the
+// divisions by the norm done when the frame was prepared)
+__device__ __forceinline__ void qexp_bwd_coef(V3 x, const QExpCtx& c, float& ea, float& eb_, float& ec) {
+  if (c.h < 1e-5f) {
+    const float n = sqrtf(1.f + c.h * c.h), ne = n + 1e-5f, k = 1.f / (n * ne * ne);
+    ea = 1.f / ne; eb_ = -k; ec = -k;
+  } else {
+    const float s = c.sh / c.h, ds = (c.h * c.ch - c.sh) / (c.h * c.h);
+    ea = s; eb_ = -s; ec = ds / c.h;
+  }
+}
+__device__ __forceinline__ void root_prepare(const ZeggsDecDims& d, const RootIn& ri, RootPre& o) {
+  o.qti = quat_inv(Q4{ri.rq[0], ri.rq[1], ri.rq[2], ri.rq[3]});
+  o.w = v3(ri.gz[0], ri.gz[1], ri.gz[2]) - v3(ri.rp[0], ri.rp[1], ri.rp[2]);
+  o.qp = Q4{ri.pq[0], ri.pq[1], ri.pq[2], ri.pq[3]};
+  o.dvel = d.dt * v3(ri.pt[0], ri.pt[1], ri.pt[2]);
+  o.dvrt = d.dt * v3(ri.pt[3], ri.pt[4], ri.pt[5]);
+  o.hu = 0.5f * quat_mul_vec(o.qp, o.dvrt);
+  QExpCtx ctx;
+  o.E = quat_exp_ctx(o.hu, ctx);
+  qexp_bwd_coef(o.hu, ctx, o.ea, o.eb_, o.ec);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) o.dp[i] = ri.dp[i];
+}
+template <class F>
+__device__ __forceinline__ void root_pre_store(const RootPre& o, F put) {      // put(slot, value)
+  put(0, o.qti.w); put(1, o.qti.x); put(2, o.qti.y); put(3, o.qti.z); put(4, o.w.x); put(5, o.w.y); put(6, o.w.z);
+  put(7, o.qp.w); put(8, o.qp.x); put(9, o.qp.y); put(10, o.qp.z); put(11, o.dvel.x); put(12, o.dvel.y); put(13, o.dvel.z);
+  put(14, o.dvrt.x); put(15, o.dvrt.y); put(16, o.dvrt.z); put(17, o.hu.x); put(18, o.hu.y); put(19, o.hu.z);
+  put(20, o.E.w); put(21, o.E.x); put(22, o.E.y); put(23, o.E.z); put(24, o.ea); put(25, o.eb_); put(26, o.ec);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) put(27 + i, o.dp[i]);
+}
+template <class F>
+__device__ __forceinline__ void root_pre_load(RootPre& o, F get) {
+  o.qti = Q4{get(0), get(1), get(2), get(3)}; o.w = v3(get(4), get(5), get(6));
+  o.qp = Q4{get(7), get(8), get(9), get(10)}; o.dvel = v3(get(11), get(12), get(13));
+  o.dvrt = v3(get(14), get(15), get(16)); o.hu = v3(get(17), get(18), get(19));
+  o.E = Q4{get(20), get(21), get(22), get(23)}; o.ea = get(24); o.eb_ = get(25); o.ec = get(26);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) o.dp[i] = get(27 + i);
+}
+// cr: adjoint of (root_pos_f, root_rot_f) INCLUDING this frame's direct loss gradients (drpos / drrot were added when the
+// frame was prepared)
+__device__ __forceinline__ void root_apply(const ZeggsDecDims& d, const float* gaze_rstd /* 1 / in_std[PO..PO+2] */,
+                                           const RootPre& o, const float (&dgd_in)[3], float (&cr)[7], float (&g6)[6]) {
+  V3 g_rp = v3(cr[0], cr[1], cr[2]);
+  Q4 g_rr = Q4{cr[3], cr[4], cr[5], cr[6]};
+  const V3 dgd = v3(dgd_in[0] * gaze_rstd[0], dgd_in[1] * gaze_rstd[1], dgd_in[2] * gaze_rstd[2]);
+  Q4 dqi; V3 dv;
+  qmv_bwd(o.qti, o.w, dgd, dqi, dv);
+  g_rr.w += dqi.w; g_rr.x -= dqi.x; g_rr.y -= dqi.y; g_rr.z -= dqi.z;
+  g_rp = g_rp - dv;
+  Q4 dq1; V3 dv1;
+  qmv_bwd(o.qp, o.dvel, g_rp, dq1, dv1);
+  Q4 dE, dqy;
+  qmul_bwd(o.E, o.qp, g_rr, dE, dqy);
+  const V3 gv = v3(dE.x, dE.y, dE.z);
+  const V3 du = 0.5f * (o.ea * gv + (o.eb_ * dE.w + o.ec * dot(gv, o.hu)) * o.hu);
+  Q4 dq2; V3 dv2;
+  qmv_bwd(o.qp, o.dvrt, du, dq2, dv2);
   g6[0] += d.dt * dv1.x; g6[1] += d.dt * dv1.y; g6[2] += d.dt * dv1.z;
   g6[3] += d.dt * dv2.x; g6[4] += d.dt * dv2.y; g6[5] += d.dt * dv2.z;
   cr[0] = g_rp.x; cr[1] = g_rp.y; cr[2] = g_rp.z;
@@ -211,9 +305,12 @@ __host__ __device__ inline int p3_row(int c, int s, int XD) {      // dXa slot s
 
 __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   __shared__ float wl3[8 * L3 * 64];          // P3 weight tiles of this workgroup (128 KB)
-  __shared__ float red[8][16][32];            // per-wave partial sums [row][batch]
+  __shared__ float red[8][20][32];            // per-wave partial sums [row][batch]
   __shared__ float dxa[8][32];                // dXa of this workgroup's dx rows (P3 -> P4)
   __shared__ float sp9[NSP][32];              // workgroup 0: dx of the root / gaze columns
+  __shared__ float rin[NRI][32];              // workgroup 0: inputs of the root-integration backward of this step
+  __shared__ float rst[16];
+  __shared__ float crs[7][32];                // workgroup 0: adjoint of (root_pos, root_rot) per batch row                   // in_std[0..5], in_std[PO..PO+2], out_std[0..5]
   __shared__ int fail;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = blockIdx.x;
   const ZeggsDecDims& d = a.d;
@@ -230,6 +327,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
     for (int i = 0; i < L3; ++i) wl3[(wave * L3 + i) * 64 + lane] = q[(long)i * 64];
   }
   if (tid == 0) fail = 0;
+  if (tid < 15) rst[tid] = tid < 6 ? 1.f / a.st.in_std[tid] : tid < 9 ? 1.f / a.st.in_std[d.PO + tid - 6] : a.st.out_std[tid - 9];
   const float* wl = wl3 + wave * L3 * 64 + lane;
   // epilogue item of this thread: output row er (0..15) of the phase, batch row eb
   const int er = tid >> 5, eb = tid & 31;
@@ -244,18 +342,17 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   // P3 dXa item: slot er - 8
   const int row3 = er >= 8 ? p3_row(c, er - 8, XD) : -1;
   const int sp3 = row3 >= 0 ? special_index(row3, PO) : -1;
-  // root thread of batch row eb (workgroup 0, first 32 threads): adjoint of (root_pos, root_rot) in registers
-  float cr[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // root thread of batch row eb (workgroup 0, first 32 threads); the adjoint of (root_pos, root_rot) lives in LDS
   const bool ract = c == 0 && tid < 32 && bact;
   if (ract) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) cr[i] = a.carry[eb * 8 + i];
+    for (int i = 0; i < 7; ++i) crs[i][eb] = a.carry[eb * 8 + i];
   }
   __syncthreads();
 
   auto wait_phase = [&](long p) {     // all workgroups have finished phase instance p (p < 0: nothing to wait for)
     if (p >= 0) {
-      if (wave == 0 && !bp_wait(a.cnt, (unsigned)(p + 1))) fail = 1;
+      if (wave == 1 && !bp_wait(a.cnt, (unsigned)(p + 1))) fail = 1;     // (wave 0 of workgroup 0 prepares the root frame meanwhile)
     }
     __syncthreads();
   };
@@ -272,10 +369,10 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       if (lane < 32) red[wave][row0 + i][lane] = s;
     }
   };
-  auto total = [&]() -> float {       // sum over the 8 waves of this thread's (er, eb)
+  auto total = [&](int row) -> float {       // sum over the 8 waves of (row, eb)
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) s += red[w][er][eb];
+    for (int w = 0; w < 8; ++w) s += red[w][row][eb];
     return s;
   };
   // GRU backward of one (unit, batch row): g = total gradient wrt h_t; writes the gate gradients, returns g * z
@@ -295,8 +392,11 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
     return g * z;
   };
 
+  const long OPS = 4L * H * 32;       // floats per step of OP1 / OP0
   for (int t = T - 1; t >= 1; --t) {
     const long sidx = T - 1 - t, pA = 4 * sidx, pB = pA + 1, pC = pA + 2, pD = pA + 3;
+    const f4* op1 = (const f4*)(a.OP1 + (long)t * OPS) + lane;
+    const f4* op0 = (const f4*)(a.OP0 + (long)t * OPS) + lane;
     // ================================================================ P1 : dH1 = W2^T dy_t + carry1 -> layer-1 gates
     BPT(0);
     {
@@ -310,54 +410,89 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       wait_phase(pA - 1);
       if (fail) break;
       BPT(1);
-      bp_mma<1, NJ1, O1, 0, false>(wr, nullptr, (const f4*)(a.OPY + (long)t * a.KBY * 512) + lane, wave, a.KBY, acc);
+      bp_mma<1, NJ1, O1, false>(wr, nullptr, (const f4*)(a.OPY + (long)t * a.KBY * 512) + lane, wave, 0, a.KBY, acc);
       BPT(2);
       put(acc[0], 0);
       __syncthreads();
-      if (er < 4 && bact) c1 = gru_bwd(total() + c1, gt, hp, a.DI1, a.DH1, a.OP1, t);
+      if (er < 4 && bact) c1 = gru_bwd(total(er) + c1, gt, hp, a.DI1, a.DH1, a.OP1, t);
       BPT(3);
       arrive(pA);
       BPT(4);
     }
     // ================================================================ P2 : dH0 = W_ih1^T DI1_t + carry0 -> layer-0 gates
-    {
+    {                                                                   //      carry1 += W_hh1[r,z]^T DI1_t[r,z]
       f4 gt = f4{0.f, 0.f, 0.f, 0.f};
       float hp = 0.f;
       if (er < 4 && bact) {
         gt = ((const f4*)a.GT0)[(long)t * sH + (long)eb * H + U];
         hp = a.H0[(long)(t - 1) * sH + (long)eb * H + U];
       }
-      f4 acc[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+      f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
       wait_phase(pB - 1);
       if (fail) break;
       BPT(5);
-      bp_mma<1, NJ2, O2, 0, false>(wr, nullptr, (const f4*)(a.OP1 + (long)t * (4L * H * 32)) + lane, wave, 192, acc);
+      // workgroup 0: everything the root-integration backward of frame t-1 reads (forward outputs and loss gradients:
+      // old data), fetched by all threads underneath this phase's products and parked in LDS
+      float rv[3] = {0.f, 0.f, 0.f};
+      const bool rfetch = c == 0 && t > 1;
+      if (rfetch) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int idx = tid + q * BTHR;
+          if (idx < 33 * 32 && (idx & 31) < B)
+            rv[q] = root_item(a.drpos, a.drrot, a.rrot, a.rpos, a.gaze, a.pose, a.dpose, T, PO, idx & 31, t - 1, true, idx >> 5);
+        }
+      }
+      bp_mma<2, NJA, O2A, false>(wr, nullptr, op1, wave, 0, 128, acc);
+      bp_mma<1, NJB, O2B, false>(wr, nullptr, op1, wave, 128, 64, acc);
+      if (rfetch) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int idx = tid + q * BTHR;
+          if (idx < 33 * 32) rin[idx >> 5][idx & 31] = rv[q];
+        }
+      }
       BPT(6);
-      put(acc[0], 0);
+      put(acc[0], 0); put(acc[1], 4);
       __syncthreads();
-      if (er < 4 && bact) c0 = gru_bwd(total() + c0, gt, hp, a.DI0, a.DH0, a.OP0, t);
+      if (er < 4 && bact) {
+        c1 += total(4 + er);
+        c0 = gru_bwd(total(er) + c0, gt, hp, a.DI0, a.DH0, a.OP0, t);
+      }
       BPT(7);
       arrive(pB);
       BPT(8);
     }
-    // ================================================================ P3 : carry1 += W_hh1^T (.) ; dGin = W_ih0^T DI0_t
+    // ================================================================ P3 : dGin = W_ih0^T DI0_t ; carry0 += W_hh0[r,z]^T DI0_t[r,z]
     {
       float hid = 0.f;
       if (er >= 4 && er < 8 && bact) hid = a.Gin[(long)t * sG + (long)eb * GL + U];
-      f4 accc[1] = {f4{0.f, 0.f, 0.f, 0.f}};
-      // old operand (DI1_t, dn_h1: complete since the P1 hand-off): before the wait
-      bp_mma<1, NJC, OC1, 0, true>(wr, nullptr, (const f4*)(a.OP1 + (long)t * (4L * H * 32)) + lane, wave, 192, accc);
-      f4 acc[3] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+      f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+      // carry1 += W_hh1[n]^T dn_h1 : the operand is one phase old -- done before the wait, it hides the hand-off latency
+      bp_mma<1, NJT, OT1, false>(wr, nullptr, op1, wave, 192, 64, acct);
+      if (ract && t > 1) {      // root thread: the gradient-independent half of the root backward of frame t-1 (in place)
+        RootIn ri;
+        ri.gather([&](int item) { return rin[item][eb]; });
+        RootPre pre;
+        root_prepare(d, ri, pre);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) crs[q][eb] += ri.a[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) crs[3 + q][eb] += ri.e[q];
+        root_pre_store(pre, [&](int slot, float v) { rin[slot][eb] = v; });
+      }
+      f4 acc[4] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
       wait_phase(pC - 1);
       if (fail) break;
       BPT(9);
-      bp_mma<3, NJ3, O3T, L3, false>(wr, wl, (const f4*)(a.OP0 + (long)t * (4L * H * 32)) + lane, wave, 192, acc);
+      bp_mma<4, NJA, 0, true>(wr, wl, op0, wave, 0, 128, acc);          // dhid | dXa slots 0..3 | dXa slots 4..7 | carry0
+      bp_mma<3, NJB, O3B, false>(wr, nullptr, op0, wave, 128, 64, acc);
       BPT(10);
-      put(accc[0], 0); put(acc[0], 4); put(acc[1], 8); put(acc[2], 12);
+      put(acct[0], 0); put(acc[0], 4); put(acc[1], 8); put(acc[2], 12); put(acc[3], 16);
       __syncthreads();
       if (bact) {
-        const float v = total();
-        if (er < 4) c1 += v;
+        const float v = total(er);
+        if (er < 4) { c1 += v; c0 += total(16 + er); }
         else if (er < 8) {
           const float d0 = v * d_elu_grad_from_out(hid);
           a.D0[(long)t * sH + (long)eb * H + U] = d0;
@@ -371,24 +506,24 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       arrive(pC);
       BPT(12);
     }
-    // ================================================================ P4 : carry0 += W_hh0^T (.) ; dx_t = dXa + W0^T D0_t
+    // ================================================================ P4 : dx_t = dXa + W0^T D0_t -> DX[t], dy_{t-1}
     {
       float dpo = 0.f;
       if (t > 1 && bact && row4 >= 6 && row4 < PO && c != 0) dpo = a.dpose[((long)eb * T + t - 1) * PO + row4];
-      f4 accc[1] = {f4{0.f, 0.f, 0.f, 0.f}};
-      bp_mma<1, NJC, OC0, 0, true>(wr, nullptr, (const f4*)(a.OP0 + (long)t * (4L * H * 32)) + lane, wave, 192, accc);
+      f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+      bp_mma<1, NJT, OT0, false>(wr, nullptr, op0, wave, 192, 64, acct);      // carry0 += W_hh0[n]^T dn_h0 (before the wait)
       f4 acc[3] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
       wait_phase(pD - 1);
       if (fail) break;
       BPT(13);
       float spv = 0.f;                                     // workgroup 0: dXa of the root / gaze columns (other owners)
       if (c == 0 && er >= 4 && s4 < NSP && bact) spv = a.SP[((long)t * NSP + s4) * 32 + eb];
-      bp_mma<3, NJ4, O4, 0, false>(wr, nullptr, (const f4*)(a.OPD + (long)t * (H * 32L)) + lane, wave, 64, acc);
+      bp_mma<3, NJ4, O4, false>(wr, nullptr, (const f4*)(a.OPD + (long)t * (H * 32L)) + lane, wave, 0, 64, acc);
       BPT(14);
-      put(accc[0], 0); put(acc[0], 4); put(acc[1], 8); put(acc[2], 12);
+      put(acct[0], 0); put(acc[0], 4); put(acc[1], 8); put(acc[2], 12);
       __syncthreads();
       if (bact) {
-        const float v = total();
+        const float v = total(er);
         if (er < 4) c0 += v;
         else if (c == 0) {
           if (s4 < NSP) sp9[s4][eb] = v + spv;
@@ -404,16 +539,25 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       }
       if (c == 0) {
         __syncthreads();
+        BPT(17);
         if (ract && t > 1) {
-          float g6[6], dgd[3];
+          float g6[6], dgd[3], cr[7];
 #pragma unroll
-          for (int q = 0; q < 6; ++q) g6[q] = a.dpose[((long)eb * T + t - 1) * PO + q] + sp9[q][eb] / a.st.in_std[q];
+          for (int q = 0; q < 7; ++q) cr[q] = crs[q][eb];
+          RootPre pre;
+          root_pre_load(pre, [&](int slot) { return rin[slot][eb]; });
+#pragma unroll
+          for (int q = 0; q < 6; ++q) g6[q] = pre.dp[q] + sp9[q][eb] * rst[q];
 #pragma unroll
           for (int q = 0; q < 3; ++q) dgd[q] = sp9[6 + q][eb];
-          root_bwd_reg(d, a.st, eb, t - 1, true, dgd, a.gaze, a.pose, a.rpos, a.rrot, a.drpos, a.drrot, cr, g6);
+          BPT(18);
+          root_apply(d, rst + 6, pre, dgd, cr, g6);
+          BPT(19);
+#pragma unroll
+          for (int q = 0; q < 7; ++q) crs[q][eb] = cr[q];
 #pragma unroll
           for (int q = 0; q < 6; ++q) {
-            const float gy = g6[q] * a.st.out_std[q];
+            const float gy = g6[q] * rst[9 + q];
             a.DY[((long)(t - 1) * B + eb) * POL + q] = gy;
             stp(a.OPY + (long)(t - 1) * a.KBY * 512 + op_idx(eb, q), gy);
           }
@@ -437,25 +581,21 @@ struct BPackArgs {
   const float *w_ih0, *w_hh0, *w_ih1, *w_hh1, *l2_w, *l0_w;
   int XD, PO, KBY;
 };
-// weight of output row `i` (0..3) of row group rg, contraction index k, for tile (part, workgroup c)
-//   part 0 P1, 1 P2, 2 C1, 3 C0, 4 P4, 5 P3
-__device__ __forceinline__ float bp_value(const BPackArgs& p, int part, int c, int rg, int i, int kb, int kk) {
+// weight of output row i (0..3) of a tile for contraction index k = 16 kb + kk of its operand (workgroup c).  Tile kinds:
+//   0 dH1 (W2^T)   1 dH0 (W_ih1^T)   2 carry1 (W_hh1^T)   3 carry0 (W_hh0^T)   4 dx slots 4 rg + i (W0^T)
+//   5 dhid (W_ih0^T, hid columns)   6 / 7 dXa slots 0..3 / 4..7 (W_ih0^T, x columns)
+// the operands of kinds 2 / 3 are [DI (3H) | dn_h (H)]: k < 2H are the r, z rows of W_hh, k >= 3H its n rows
+__device__ __forceinline__ float bp_value(const BPackArgs& p, int kind, int c, int rg, int i, int kb, int kk) {
   const int H = BH, U = 4 * c + i, k = 16 * kb + kk;
-  switch (part) {
-    case 0: return k < p.PO ? p.l2_w[(long)k * H + U] : 0.f;                       // dH1[U] += W2[k][U] dy[k]
-    case 1: return p.w_ih1[(long)k * H + U];                                      // dH0[U] += W_ih1[g][U] DI1[g]
-    case 2: return p.w_hh1[(long)(k < 2 * H ? k : k - H) * H + U];                // operand [DI1 (3H) | dn_h1 (H)], n rows skipped
+  const long ld0 = H + p.XD;
+  switch (kind) {
+    case 0: return k < p.PO ? p.l2_w[(long)k * H + U] : 0.f;
+    case 1: return p.w_ih1[(long)k * H + U];
+    case 2: return p.w_hh1[(long)(k < 2 * H ? k : k - H) * H + U];
     case 3: return p.w_hh0[(long)(k < 2 * H ? k : k - H) * H + U];
-    case 4: {
-      const int row = p4_row(c, 4 * rg + i, p.PO, p.XD);
-      return row >= 0 ? p.l0_w[(long)k * p.XD + row] : 0.f;                        // dx[row] += W0[m][row] D0[m]
-    }
-    default: {
-      const long ld = H + p.XD;
-      if (rg == 0) return p.w_ih0[(long)k * ld + U];                              // dhid
-      const int row = p3_row(c, 4 * (rg - 1) + i, p.XD);
-      return row >= 0 ? p.w_ih0[(long)k * ld + H + row] : 0.f;                    // dXa
-    }
+    case 4: { const int row = p4_row(c, 4 * rg + i, p.PO, p.XD); return row >= 0 ? p.l0_w[(long)k * p.XD + row] : 0.f; }
+    case 5: return p.w_ih0[(long)k * ld0 + U];
+    default: { const int row = p3_row(c, 4 * (kind - 6) + i, p.XD); return row >= 0 ? p.w_ih0[(long)k * ld0 + H + row] : 0.f; }
   }
 }
 __global__ void bp_pack_k(BPackArgs p) {
@@ -467,21 +607,20 @@ __global__ void bp_pack_k(BPackArgs p) {
     const long cws = r >> 6;
     const int per = lds ? L3 : NWR;
     const int slot = (int)(cws % per), wave = (int)((cws / per) & 7), c = (int)(cws / (8L * per));
-    int part, j, rg;
-    if (lds) { part = 5; j = slot / 3; rg = slot % 3; }
-    else if (slot < O2) { part = 0; j = slot - O1; rg = 0; }
-    else if (slot < OC1) { part = 1; j = slot - O2; rg = 0; }
-    else if (slot < OC0) { part = 2; j = slot - OC1; rg = 0; }
-    else if (slot < O4) { part = 3; j = slot - OC0; rg = 0; }
-    else if (slot < O3T) { part = 4; j = (slot - O4) / 3; rg = (slot - O4) % 3; }
-    else { part = 5; const int q = slot - O3T + L3; j = q / 3; rg = q % 3; }
-    const int nblk = part == 0 ? p.KBY : (part == 4 ? 64 : 192);
+    int kind, j, rg = 0, kb0, nblk;
+    if (lds) {                 // P3, blocks 0..127 of [DI0 | dn_h0]: dhid | dXa 0..3 | dXa 4..7 | carry0
+      j = slot / 4; rg = slot % 4; kb0 = 0; nblk = 128;
+      kind = rg == 0 ? 5 : rg == 1 ? 6 : rg == 2 ? 7 : 3;
+    } else if (slot < O2A) { kind = 0; j = slot - O1; kb0 = 0; nblk = p.KBY; }
+    else if (slot < O2B) { j = (slot - O2A) / 2; rg = (slot - O2A) % 2; kind = rg == 0 ? 1 : 2; kb0 = 0; nblk = 128; }
+    else if (slot < OT1) { kind = 1; j = slot - O2B; kb0 = 128; nblk = 64; }
+    else if (slot < O3B) { kind = 2; j = slot - OT1; kb0 = 192; nblk = 64; }
+    else if (slot < OT0) { j = (slot - O3B) / 3; rg = (slot - O3B) % 3; kind = 5 + rg; kb0 = 128; nblk = 64; }
+    else if (slot < O4) { kind = 3; j = slot - OT0; kb0 = 192; nblk = 64; }
+    else { kind = 4; j = (slot - O4) / 3; rg = (slot - O4) % 3; kb0 = 0; nblk = 64; }
     const int e = wave + 8 * j;
     float v = 0.f;
-    if (e < nblk) {
-      const int kb = (part == 2 || part == 3) ? part_kb<true>(e) : e;
-      v = bp_value(p, part, c, rg, lane & 3, kb, lane >> 2);
-    }
+    if (e < nblk) v = bp_value(p, kind, c, rg, lane & 3, kb0 + e, lane >> 2);
     (lds ? p.PWL : p.PWR)[r] = v;
   }
 }
@@ -503,8 +642,10 @@ __global__ void bp_dy_last_k(ZeggsDecDims d, ZeggsDecStats st, const float* dpos
   for (int cc = 6 + threadIdx.x; cc < d.PO; cc += blockDim.x) dy[(long)b * POL + cc] = dpb[cc] * st.out_std[cc];
   if (threadIdx.x == 0) {
     float g6[6], cr[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dgd[3] = {0.f, 0.f, 0.f};
+    RootIn ri;
+    ri.gather([&](int item) { return root_item(drpos, drrot, rrot, rpos, gaze, pose, dpose, d.T, d.PO, b, t, false, item); });
     for (int q = 0; q < 6; ++q) g6[q] = dpb[q];
-    root_bwd_reg(d, st, b, t, false, dgd, gaze, pose, rpos, rrot, drpos, drrot, cr, g6);
+    root_bwd_reg(d, st.in_std + d.PO, ri, dgd, cr, g6, false);
     for (int q = 0; q < 6; ++q) dy[(long)b * POL + q] = g6[q] * st.out_std[q];
     for (int q = 0; q < 7; ++q) carry[b * 8 + q] = cr[q];
   }
