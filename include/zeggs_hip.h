@@ -174,9 +174,14 @@ int zeggs_decoder_fwd_state(const ZeggsDecDims*, const ZeggsDecParams*, const Ze
  * between the caller's stream and a library-owned second stream and hand over through device-side arrival counters, so
  * each launch fetches its weights while its predecessor still runs.  Every device-side wait is bounded; this returns the
  * error word of the last rollout on `ws` (0 = all hand-offs completed).  Synchronises the device. */
-int zeggs_persistent_state(int which /* 0: B=1 decode kernel, 1: training-forward kernel */);   /* 1 ok, 0 disabled, -1 unused */
+int zeggs_persistent_state(int which /* 0: B=1 decode kernel, 1: training-forward kernel, 2: BPTT sweep */);   /* 1 ok, 0 disabled, -1 unused */
 /* measurement builds (-DZEGGS_TPTIME) only: phase stamps of the last 4 steps of the persistent training rollout */
 int zeggs_tp_stamps(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned long long* out /* host [4][2][32] */);
+/* Training backward with batch <= 32: the BPTT sweep of zeggs_decoder_bwd (replaces the per-step autograd of
+ * ZEGGS/train.py:425 through modules.py:100-151) runs as ONE persistent launch by default (option "bwd_persistent",
+ * csrc/train_bwd_persistent.hip: transposed weights resident as 4-row v_mfma_f32_4x4x1 tiles, four grid hand-offs per step).
+ * Same validation / fall-back protocol as the other persistent kernels.  -DZEGGS_BPTIME builds: phase stamps of steps 3..1 */
+int zeggs_bp_stamps(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned long long* out /* host [3][2][32] */);
 int zeggs_decoder_chain_errors(const ZeggsDecDims*, int training, void* ws, size_t ws_bytes, int* out);
 /* measurement builds (-DZEGGS_CHTIME) only: 100 MHz wall-clock stamps of the phases of the last 16 chained launches */
 int zeggs_decoder_chain_stamps(const ZeggsDecDims*, int training, void* ws, size_t ws_bytes,

@@ -552,6 +552,35 @@ def test_persistent_training_forward_matches_stage_launches(B, T):
         assert relerr(g1[k], g0[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("B,T,style_dim", [(32, 12, 64), (17, 6, 64), (5, 9, 64), (1, 7, 64), (32, 3, 64), (20, 5, 9)])
+def test_persistent_bptt_sweep_matches_stage_launches(B, T, style_dim):
+    """option "bwd_persistent" (default on for batch <= 32): the backward decoder steps of a window as one weight-stationary
+    launch on 4-row MFMA tiles.  Same forward either way; every parameter gradient, dspeech and dstyle must agree with the
+    stage-launch sweep (which the oracle / reference fixtures pin) to fp32 rounding.  style_dim 9 = label conditioning."""
+    torch.manual_seed(1234)
+    from zeggs import modules
+    if style_dim == 64:
+        _, de, _ = helpers.build_nets()
+    else:
+        de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, 64, style_dim, 1024, 2)
+    de = de.to(DEV).train()
+    try:
+        ops.set_option("bwd_persistent", 0)
+        out0, g0, ds0, dy0 = _rollout_with_grads(de, B, T, 23, style_dim)
+        ops.set_option("bwd_persistent", 1)
+        out1, g1, ds1, dy1 = _rollout_with_grads(de, B, T, 23, style_dim)
+        assert ops.lib().zeggs_persistent_state(2) == 1            # it really ran (validated, not fallen back)
+        out2, g2, ds2, dy2 = _rollout_with_grads(de, B, T, 23, style_dim)      # steady state (no validation sync)
+    finally:
+        ops.set_option("bwd_persistent", 1)
+    for a, b in zip(out0, out1):
+        assert float((a - b).abs().max()) < 2e-5
+    for gx, dsx, dyx in ((g1, ds1, dy1), (g2, ds2, dy2)):
+        assert relerr(dsx, ds0) < 2e-5 and relerr(dyx, dy0) < 2e-5
+        for k in g0:
+            assert relerr(gx[k], g0[k]) < 2e-5, k
+
+
 @pytest.mark.parametrize("T", [4, 5, 37, 600])
 def test_persistent_decode_kernel_matches_stage_launches(T):
     """B=1 inference: the weight-stationary persistent kernel (one launch for all frames, weights in registers, data-tagged

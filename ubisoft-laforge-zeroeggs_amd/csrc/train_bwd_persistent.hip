@@ -69,6 +69,11 @@ struct BArgs {
 __device__ __forceinline__ void stp(float* p, float v) {       // published: write-through
   __hip_atomic_store((gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// 16 bytes, write-through: one lane publishes 4 consecutive contraction indices (k % 4 == 0) of its batch row, a half-wave
+// of batch rows 512 contiguous bytes -- whole lines instead of byte-masked partial writes
+__device__ __forceinline__ void stp4(float* p, f4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
 // position of (batch row b, contraction index k) in an operand buffer: lane 32 * ((k >> 3) & 1) + b reads
 // float4 q = (k >> 2) & 1 of block k >> 4, element k & 3 (= abid & 3 of the instruction that consumes it)
 __host__ __device__ inline long op_idx(int b, int k) {
@@ -87,12 +92,15 @@ __device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect) 
   }
 }
 
-// products of one part: blocks j = 0..NJ-1 of this wave are k-blocks kb0 + wave + 8 j (< kb0 + nblk) of the operand, NRG row
-// groups; weight tile (j, rg) = wr[OFF + j*NRG + rg] or, for LDS, wl[(j*NRG + rg) * 64].
+// products of one part: slot j = 0..NJ-1 of this wave is k-block kb0 + wave + 8 j (< kb0 + nblk) of the operand, NRG row groups;
+// (measured: starting every workgroup's walk at a different block, so that an XCD pulls a fresh operand in faster, is 3 % slower) weight tile (j, rg) = wr[OFF + j*NRG + rg] or, for LDS, wl[(j*NRG + rg) * 64].
 // Two blocks per group, the next group's operand loads are kept ahead of this group's products by scheduling fences.
 template <int NRG, int NJ, int OFF, bool LDS>
 __device__ __forceinline__ void bp_mma(const float (&wr)[NWR], const float* wl, const f4* __restrict__ xb, int wave, int kb0,
                                        int nblk, f4* acc) {
+#ifdef ZEGGS_BP_NOMMA             /* timing experiments only (results invalid) */
+  return;
+#endif
   constexpr int GU = NRG >= 3 ? 1 : 2, NG = (NJ + GU - 1) / GU;     // operand blocks per group (matrix-core bound parts: 1)
   f4 xa[GU][2], xq[GU][2];
   auto load = [&](f4 (&x)[GU][2], int g) {
@@ -276,18 +284,19 @@ __device__ __forceinline__ void root_apply(const ZeggsDecDims& d, const float* g
   cr[5] = dq1.y + dqy.y + dq2.y; cr[6] = dq1.z + dqy.z + dq2.z;
 }
 
-// row of dx owned by slot s of workgroup c in P4 (-1: empty).  Workgroup 0: the root / gaze columns; others: 5c..5c+4
-// without the root / gaze columns (their dXa reaches workgroup 0 through SP)
+// dx rows: workgroup c owns rows 8c .. 8c+7 (two aligned groups of four: one 16-byte store each); its dXa (P3) stays in
+// LDS for P4.  The 9 root / gaze columns (0..5, PO..PO+2) are the exception: whoever owns them in P3 sends their dXa to
+// workgroup 0 through SP, and workgroup 0 owns them in P4 (slots 0..7 = rows 0..7, slots 8..10 = PO..PO+2).
 __host__ __device__ inline int special_index(int row, int PO) { return row < 6 ? row : (row >= PO && row < PO + 3 ? 6 + row - PO : -1); }
-__host__ __device__ inline int p4_row(int c, int s, int PO, int XD) {
-  if (c == 0) return s < 6 ? s : (s < NSP ? PO + s - 6 : -1);
-  if (s >= 5) return -1;
-  const int r = 5 * c + s;
-  return (r < XD && special_index(r, PO) < 0) ? r : -1;
-}
 __host__ __device__ inline int p3_row(int c, int s, int XD) {      // dXa slot s (0..7) of workgroup c
-  const int r = 5 * c + s;
-  return (s < 5 && r < XD) ? r : -1;
+  const int r = 8 * c + s;
+  return r < XD ? r : -1;
+}
+__host__ __device__ inline int p4_row(int c, int s, int PO, int XD) {      // dx slot s (0..11) of workgroup c, -1: empty
+  if (c == 0) return s < 8 ? s : (s < 11 ? PO + s - 8 : -1);
+  if (s >= 8) return -1;
+  const int r = 8 * c + s;
+  return (r < XD && special_index(r, PO) < 0) ? r : -1;
 }
 
 #ifdef ZEGGS_BPTIME
@@ -307,6 +316,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   __shared__ float wl3[8 * L3 * 64];          // P3 weight tiles of this workgroup (128 KB)
   __shared__ float red[8][20][32];            // per-wave partial sums [row][batch]
   __shared__ float dxa[8][32];                // dXa of this workgroup's dx rows (P3 -> P4)
+  __shared__ f4 ex[4][32];                    // epilogue exchange: 4 consecutive rows of a batch row -> one 16-byte store
   __shared__ float sp9[NSP][32];              // workgroup 0: dx of the root / gaze columns
   __shared__ float rin[NRI][32];              // workgroup 0: inputs of the root-integration backward of this step
   __shared__ float rst[16];
@@ -334,6 +344,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   const bool bact = eb < B;
   const int U = 4 * c + (er & 3);               // hidden unit / dhid row of the GRU items (er < 4, er 4..7)
   float c1 = 0.f, c0 = 0.f;                     // carries dH1c / dH0c of (U, eb): threads er < 4
+  const int U0 = 4 * c;
   // P4 item: slot s4 = er - 4 (0..11)
   const int s4 = er - 4;
   const int row4 = er >= 4 ? p4_row(c, s4, PO, XD) : -1;
@@ -351,13 +362,17 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   __syncthreads();
 
   auto wait_phase = [&](long p) {     // all workgroups have finished phase instance p (p < 0: nothing to wait for)
+#ifndef ZEGGS_BP_NOWAIT
     if (p >= 0) {
       if (wave == 1 && !bp_wait(a.cnt, (unsigned)(p + 1))) fail = 1;     // (wave 0 of workgroup 0 prepares the root frame meanwhile)
     }
+#endif
     __syncthreads();
   };
   auto arrive = [&](long p) {
+#ifndef ZEGGS_BP_NODRAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
     if (tid == 0) __hip_atomic_store((gu32*)(a.cnt + c), (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
@@ -375,21 +390,28 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
     for (int w = 0; w < 8; ++w) s += red[w][row][eb];
     return s;
   };
-  // GRU backward of one (unit, batch row): g = total gradient wrt h_t; writes the gate gradients, returns g * z
-  auto gru_bwd = [&](float g, const f4& gt, float hp, float* DI, float* DHc, float* OP, long t) -> float {
+  // GRU backward of one (unit, batch row): g = total gradient wrt h_t; leaves the gate gradients in the exchange buffer
+  // (kind 0 r, 1 z, 2 n, 3 hidden-side n), returns g * z
+  auto gru_bwd = [&](float g, const f4& gt, float hp) -> float {
     const float r = gt[0], z = gt[1], nn = gt[2], nh = gt[3];
     const float dn = g * (1.f - z);
     const float dz = g * (hp - nn);
     const float dan = dn * (1.f - nn * nn);
     const float dar = dan * nh * r * (1.f - r);
     const float daz = dz * z * (1.f - z);
-    float* di = DI + t * s3 + (long)eb * 3 * H;
-    di[U] = dar; di[H + U] = daz; di[2 * H + U] = dan;
-    DHc[t * sH + (long)eb * H + U] = dan * r;          // hidden side: only its n rows differ from di
-    float* op = OP + t * (4L * H * 32);
-    stp(op + op_idx(eb, U), dar); stp(op + op_idx(eb, H + U), daz); stp(op + op_idx(eb, 2 * H + U), dan);
-    stp(op + op_idx(eb, 3 * H + U), dan * r);
+    ((float*)&ex[0][eb])[er] = dar; ((float*)&ex[1][eb])[er] = daz; ((float*)&ex[2][eb])[er] = dan;
+    ((float*)&ex[3][eb])[er] = dan * r;          // hidden side: only its n rows differ from the input side
     return g * z;
+  };
+  // ... and 128 threads (gate kind, batch row) store them: canonical DI [B][3H] / DH [B][H] and the operand of the next phase
+  auto gru_store = [&](float* DI, float* DHc, float* OP, long t) {
+    if (tid < 128 && bact) {
+      const int kind = tid >> 5;
+      const f4 v = ex[kind][eb];
+      if (kind < 3) *(f4*)(DI + t * s3 + (long)eb * 3 * H + kind * H + U0) = v;
+      else *(f4*)(DHc + t * sH + (long)eb * H + U0) = v;
+      stp4(OP + t * (4L * H * 32) + op_idx(eb, kind * H + U0), v);
+    }
   };
 
   const long OPS = 4L * H * 32;       // floats per step of OP1 / OP0
@@ -414,7 +436,9 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       BPT(2);
       put(acc[0], 0);
       __syncthreads();
-      if (er < 4 && bact) c1 = gru_bwd(total(er) + c1, gt, hp, a.DI1, a.DH1, a.OP1, t);
+      if (er < 4 && bact) c1 = gru_bwd(total(er) + c1, gt, hp);
+      __syncthreads();
+      gru_store(a.DI1, a.DH1, a.OP1, t);
       BPT(3);
       arrive(pA);
       BPT(4);
@@ -457,8 +481,10 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       __syncthreads();
       if (er < 4 && bact) {
         c1 += total(4 + er);
-        c0 = gru_bwd(total(er) + c0, gt, hp, a.DI0, a.DH0, a.OP0, t);
+        c0 = gru_bwd(total(er) + c0, gt, hp);
       }
+      __syncthreads();
+      gru_store(a.DI0, a.DH0, a.OP0, t);
       BPT(7);
       arrive(pB);
       BPT(8);
@@ -493,14 +519,17 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       if (bact) {
         const float v = total(er);
         if (er < 4) { c1 += v; c0 += total(16 + er); }
-        else if (er < 8) {
-          const float d0 = v * d_elu_grad_from_out(hid);
-          a.D0[(long)t * sH + (long)eb * H + U] = d0;
-          stp(a.OPD + (long)t * (H * 32L) + op_idx(eb, U), d0);
-        } else if (row3 >= 0) {
+        else if (er < 8) ((float*)&ex[0][eb])[er - 4] = v * d_elu_grad_from_out(hid);
+        else if (row3 >= 0) {
           dxa[er - 8][eb] = v;
           if (sp3 >= 0) stp(a.SP + ((long)t * NSP + sp3) * 32 + eb, v);
         }
+      }
+      __syncthreads();
+      if (tid < 32 && bact) {
+        const f4 v = ex[0][eb];
+        *(f4*)(a.D0 + (long)t * sH + (long)eb * H + U0) = v;
+        stp4(a.OPD + (long)t * (H * 32L) + op_idx(eb, U0), v);
       }
       BPT(11);
       arrive(pC);
@@ -509,7 +538,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
     // ================================================================ P4 : dx_t = dXa + W0^T D0_t -> DX[t], dy_{t-1}
     {
       float dpo = 0.f;
-      if (t > 1 && bact && row4 >= 6 && row4 < PO && c != 0) dpo = a.dpose[((long)eb * T + t - 1) * PO + row4];
+      if (t > 1 && bact && row4 >= 6 && row4 < PO) dpo = a.dpose[((long)eb * T + t - 1) * PO + row4];
       f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
       bp_mma<1, NJT, OT0, false>(wr, nullptr, op0, wave, 192, 64, acct);      // carry0 += W_hh0[n]^T dn_h0 (before the wait)
       f4 acc[3] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
@@ -517,7 +546,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       if (fail) break;
       BPT(13);
       float spv = 0.f;                                     // workgroup 0: dXa of the root / gaze columns (other owners)
-      if (c == 0 && er >= 4 && s4 < NSP && bact) spv = a.SP[((long)t * NSP + s4) * 32 + eb];
+      if (c == 0 && er >= 4 && bact && (s4 < 6 || (s4 >= 8 && s4 < 11))) spv = a.SP[((long)t * NSP + (s4 < 6 ? s4 : s4 - 2)) * 32 + eb];
       bp_mma<3, NJ4, O4, false>(wr, nullptr, (const f4*)(a.OPD + (long)t * (H * 32L)) + lane, wave, 0, 64, acc);
       BPT(14);
       put(acct[0], 0); put(acc[0], 4); put(acc[1], 8); put(acc[2], 12);
@@ -525,41 +554,53 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       if (bact) {
         const float v = total(er);
         if (er < 4) c0 += v;
-        else if (c == 0) {
-          if (s4 < NSP) sp9[s4][eb] = v + spv;
-        } else if (row4 >= 0) {
-          const float dx = v + dxa[s4][eb];
-          if (row4 >= PI) a.DX[((long)t * B + eb) * XD + row4] = dx;       // speech / style columns
-          else if (t > 1 && row4 < PO) {                                     // pose columns -> dy_{t-1}
-            const float gy = (dpo + dx / si4) * so4;
-            a.DY[((long)(t - 1) * B + eb) * POL + row4] = gy;
-            stp(a.OPY + (long)(t - 1) * a.KBY * 512 + op_idx(eb, row4), gy);
+        else {
+          float gy = 0.f;
+          if (c == 0 && (s4 < 6 || s4 >= 8)) {               // root / gaze columns: to the root thread of the batch row
+            if (s4 < 11) sp9[s4 < 6 ? s4 : s4 - 2][eb] = v + spv;
+          } else if (row4 >= 0) {
+            const float dx = v + dxa[s4][eb];
+            if (row4 >= PI) a.DX[((long)t * B + eb) * XD + row4] = dx;       // speech / style columns
+            else if (row4 < PO) gy = (dpo + dx / si4) * so4;                   // pose columns -> dy_{t-1}
           }
+          ((float*)&ex[s4 >> 2][eb])[s4 & 3] = gy;
         }
       }
-      if (c == 0) {
-        __syncthreads();
-        BPT(17);
-        if (ract && t > 1) {
-          float g6[6], dgd[3], cr[7];
+      __syncthreads();
+      if (t > 1) {
+        float* dyc = a.DY + ((long)(t - 1) * B + eb) * POL;
+        float* opy = a.OPY + (long)(t - 1) * a.KBY * 512;
+        if (c != 0) {
+          const int g = tid >> 5, rb = 8 * c + 4 * g;          // groups 0, 1 of this workgroup's rows
+          if (tid < 64 && bact && rb < PO) {
+            const f4 v = ex[g][eb];
+            *(f4*)(dyc + rb) = v;
+            stp4(opy + op_idx(eb, rb), v);
+          }
+        } else {
+          BPT(17);
+          if (ract) {
+            float g6[6], dgd[3], cr[7];
 #pragma unroll
-          for (int q = 0; q < 7; ++q) cr[q] = crs[q][eb];
-          RootPre pre;
-          root_pre_load(pre, [&](int slot) { return rin[slot][eb]; });
+            for (int q = 0; q < 7; ++q) cr[q] = crs[q][eb];
+            RootPre pre;
+            root_pre_load(pre, [&](int slot) { return rin[slot][eb]; });
 #pragma unroll
-          for (int q = 0; q < 6; ++q) g6[q] = pre.dp[q] + sp9[q][eb] * rst[q];
+            for (int q = 0; q < 6; ++q) g6[q] = pre.dp[q] + sp9[q][eb] * rst[q];
 #pragma unroll
-          for (int q = 0; q < 3; ++q) dgd[q] = sp9[6 + q][eb];
-          BPT(18);
-          root_apply(d, rst + 6, pre, dgd, cr, g6);
-          BPT(19);
+            for (int q = 0; q < 3; ++q) dgd[q] = sp9[6 + q][eb];
+            BPT(18);
+#ifndef ZEGGS_BP_NOROOT          /* timing experiment only: what the root-integration backward costs on the critical path */
+            root_apply(d, rst + 6, pre, dgd, cr, g6);
+#endif
+            BPT(19);
 #pragma unroll
-          for (int q = 0; q < 7; ++q) crs[q][eb] = cr[q];
-#pragma unroll
-          for (int q = 0; q < 6; ++q) {
-            const float gy = g6[q] * rst[9 + q];
-            a.DY[((long)(t - 1) * B + eb) * POL + q] = gy;
-            stp(a.OPY + (long)(t - 1) * a.KBY * 512 + op_idx(eb, q), gy);
+            for (int q = 0; q < 7; ++q) crs[q][eb] = cr[q];
+            const f4 v0 = f4{g6[0] * rst[9], g6[1] * rst[10], g6[2] * rst[11], g6[3] * rst[12]};
+            const f4 e1 = ex[1][eb];                           // rows 6, 7 are ordinary pose columns
+            const f4 v1 = f4{g6[4] * rst[13], g6[5] * rst[14], e1[2], e1[3]};
+            *(f4*)dyc = v0; *(f4*)(dyc + 4) = v1;
+            stp4(opy + op_idx(eb, 0), v0); stp4(opy + op_idx(eb, 4), v1);
           }
         }
       }
@@ -655,7 +696,7 @@ __global__ void bp_dy_last_k(ZeggsDecDims d, ZeggsDecStats st, const float* dpos
 
 int dec_bp_supported(const ZeggsDecDims& d, const DecWs& w) {
   return !d.film && d.H == BH && d.B <= 32 && d.T >= 3 && d.PI == d.PO + 3 && d.PO >= 16 && (d.PO + 15) / 16 <= 8 * NJ1 &&
-         w.XD <= 5 * BNCU && w.bp_wr != nullptr;
+         w.XD <= 8 * BNCU && w.bp_wr != nullptr;
 }
 int dec_bp_state() { return g_bp_ok; }
 void dec_bp_set_state(int v) { g_bp_ok = v; }
