@@ -182,6 +182,8 @@ int zeggs_tp_stamps(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned lon
  * csrc/train_bwd_persistent.hip: transposed weights resident as 4-row v_mfma_f32_4x4x1 tiles, four grid hand-offs per step).
  * Same validation / fall-back protocol as the other persistent kernels.  -DZEGGS_BPTIME builds: phase stamps of steps 3..1 */
 int zeggs_bp_stamps(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned long long* out /* host [3][2][32] */);
+/* -DZEGGS_BPSTAT builds: 100 MHz ticks every workgroup spent polling for the hand-off into phase 1..4, summed over the sweep */
+int zeggs_bp_waits(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned long long* out /* host [4][256][4]: polling, products-done -> arrived, P4 epilogue split of thread 0 */);
 int zeggs_decoder_chain_errors(const ZeggsDecDims*, int training, void* ws, size_t ws_bytes, int* out);
 /* measurement builds (-DZEGGS_CHTIME) only: 100 MHz wall-clock stamps of the phases of the last 16 chained launches */
 int zeggs_decoder_chain_stamps(const ZeggsDecDims*, int training, void* ws, size_t ws_bytes,

@@ -137,7 +137,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
       w.bp_opy = a.f(T * (long)((d.PO + 15) / 16) * 512);
       w.bp_op1 = a.f(T * 4 * H * 32); w.bp_op0 = a.f(T * 4 * H * 32); w.bp_opd = a.f(T * H * 32);
       w.bp_sp = a.f(T * 9 * 32);
-      w.bp_cnt = (unsigned*)a.f(4096);
+      w.bp_cnt = (unsigned*)a.f(16384);      // arrival slots | error word (+1024) | stamps | per-workgroup wait statistics (+1536)
     }
   }
   return w;

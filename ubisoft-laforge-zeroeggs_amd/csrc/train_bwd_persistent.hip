@@ -9,14 +9,16 @@
 // instructions (abid = 0..7) multiply it with a [16 k x 32 batch] operand block (measured: 131 TFLOP/s = 85 % of the 16x16x4
 // rate, tools/mfma4_probe.hip).  The per-CU weights are then 354 KB: 113 VGPRs per lane + 128 KB of LDS.
 //
-// Per step t (T-1 .. 1) four phases, each ending in a grid hand-off (arrival slots, as in train_persistent.hip):
-//   P1  dH1 = W2^T dy_t + carry1           -> layer-1 gate gradients DI1_t, dn_h1 (GRU backward);  carry1 = dH1 * z
-//   P2  dH0 = W_ih1^T DI1_t + carry0       -> layer-0 gate gradients DI0_t, dn_h0;                 carry0 = dH0 * z
-//       carry1 += W_hh1[r,z]^T DI1_t[r,z]     (second row group over the same operand blocks: the r, z rows are shared)
-//   P3  [carry1 += W_hh1[n]^T dn_h1: operand one phase old, done before the wait -- it hides the hand-off latency]
+// Per step t (T-1 .. 1) four phases, each ending in a grid hand-off (arrival slots, as in train_persistent.hip).  A hand-off
+// costs ~2.5 us (store drain, flag, poll); the carry products W_hh^T (.) are not needed before the NEXT step, so they are
+// cut into pieces that run in the windows before the waits ("old" operands, in brackets):
+//   P1  [carry0 += first half of W_hh0^T (DI0 r,z | dn_h0) of step t+1]
+//       dH1 = W2^T dy_t + carry1           -> layer-1 gate gradients DI1_t, dn_h1 (GRU backward);  carry1 = dH1 * z
+//   P2  [carry0 += second half of W_hh0^T (.) of step t+1]
+//       dH0 = W_ih1^T DI1_t + carry0       -> layer-0 gate gradients DI0_t, dn_h0;                 carry0 = dH0 * z
+//   P3  [carry1 += first half of W_hh1^T (DI1_t r,z | dn_h1)]
 //       dGin = W_ih0^T DI0_t               -> D0_t = dhid * ELU'(hid_t), dXa (kept in LDS by the row's owner)
-//       carry0 += W_hh0[r,z]^T DI0_t[r,z]
-//   P4  [carry0 += W_hh0[n]^T dn_h0]
+//   P4  [carry1 += second half of W_hh1^T (.)]
 //       dx_t = dXa + W0^T D0_t             -> speech / style columns to DX[t]; pose columns -> dy_{t-1}
 //                                             (devectorize / vectorize backward; the 9 root / gaze columns belong to
 //                                             workgroup 0, whose first 32 threads carry the root-integration adjoint)
@@ -38,19 +40,20 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64t;
 constexpr int BH = 1024, BTHR = 512, BNCU = 256, BSPIN = 1 << 21;
 // blocks (16 k each) per wave and part; block j of a wave is enumeration index e = wave + 8 j of the part.  Every workgroup
-// streams the whole operand of a part through its CU (2 KB per block), which is what bounds the single-row-group parts, so
-// the carry products share the r, z blocks (0..127) of DI with the main product of the phase and only their dn_h blocks
-// (192..255 of the operand) are separate "old" work.
-constexpr int NJ1 = 9;      // P1: dy_t                                   71 blocks (PO = 1131), 1 row group
-constexpr int NJA = 16;     // P2 / P3, blocks 0..127 of DI (r, z rows):  main row groups + the carry row group
-constexpr int NJB = 8;      // P2 / P3, blocks 128..191 (n rows):         main row groups
-constexpr int NJT = 8;      // carry tails: blocks 192..255 (dn_h), 1 row group, before the wait of the NEXT phase
-constexpr int NJ4 = 8;      // P4: D0_t                                   64 blocks, 3 row groups
-// register-resident weight tiles of a wave (one VGPR each); the 64 tiles of P3's first part live in LDS
-constexpr int O1 = 0, O2A = O1 + NJ1, O2B = O2A + 2 * NJA, OT1 = O2B + NJB, O3B = OT1 + NJT, OT0 = O3B + 3 * NJB,
-              O4 = OT0 + NJT;
+// streams the whole operand of a part through its CU (2 KB per block, ~90 GB/s per CU when all CUs read the same lines),
+// which is what bounds the single-row-group parts.
+constexpr int NJ1 = 9;      // P1: dy_t                                    71 blocks (PO = 1131), 1 row group
+constexpr int NJ2A = 16;    // P2: DI1_t blocks 0..127 (tiles in LDS)      1 row group
+constexpr int NJ2B = 8;     // P2: DI1_t blocks 128..191
+constexpr int NJC = 12;     // a carry half: 96 of the 192 blocks [DI r,z (0..127) | dn_h (192..255)], 1 row group
+constexpr int NJA = 16;     // P3, blocks 0..127 of DI0 (tiles in LDS):    dhid | dXa | dXa
+constexpr int NJB = 8;      // P3, blocks 128..191
+constexpr int NJ4 = 8;      // P4: D0_t                                    64 blocks, 3 row groups
+// register-resident weight tiles of a wave (one VGPR each); the tiles of P3's first part and of P2's first part live in LDS
+constexpr int O1 = 0, O2B = O1 + NJ1, OC1A = O2B + NJ2B, OC1B = OC1A + NJC, O3B = OC1B + NJC, OC0A = O3B + 3 * NJB,
+              OC0B = OC0A + NJC, O4 = OC0B + NJC;
 constexpr int NWR = O4 + 3 * NJ4;             // 113
-constexpr int L3 = 4 * NJA;                   // 64
+constexpr int L3A = 3 * NJA, L3 = L3A + NJ2A; // 48 + 16 = 64 LDS tiles per wave
 constexpr int NSP = 9;      // root / gaze columns of x: 0..5, PO..PO+2
 
 struct BArgs {
@@ -72,6 +75,9 @@ __device__ __forceinline__ void stp(float* p, float v) {       // published: wri
 // 16 bytes, write-through: one lane publishes 4 consecutive contraction indices (k % 4 == 0) of its batch row, a half-wave
 // of batch rows 512 contiguous bytes -- whole lines instead of byte-masked partial writes
 __device__ __forceinline__ void stp4(float* p, f4 v) {
+  // NOTE the "memory" clobber is required (without it the results are corrupted), and with it the compiler drains every store
+  // it knows to be in flight (s_waitcnt vmcnt(0): about a microsecond) before this one: call stp4 BEFORE the plain stores of an
+  // epilogue, never after them
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 // position of (batch row b, contraction index k) in an operand buffer: lane 32 * ((k >> 3) & 1) + b reads
@@ -89,26 +95,34 @@ __device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect) 
     const bool ok = (unsigned)a >= expect && (unsigned)(a >> 32) >= expect && (unsigned)b >= expect && (unsigned)(b >> 32) >= expect;
     if (__all(ok)) return true;
     if (spins > BSPIN) return false;
+#ifdef ZEGGS_BP_SLEEP
+    __builtin_amdgcn_s_sleep(ZEGGS_BP_SLEEP);      // 64 clocks per unit: thins out the polling traffic of the 256 waiting workgroups
+#endif
   }
 }
 
 // products of one part: slot j = 0..NJ-1 of this wave is k-block kb0 + wave + 8 j (< kb0 + nblk) of the operand, NRG row groups;
 // (measured: starting every workgroup's walk at a different block, so that an XCD pulls a fresh operand in faster, is 3 % slower) weight tile (j, rg) = wr[OFF + j*NRG + rg] or, for LDS, wl[(j*NRG + rg) * 64].
 // Two blocks per group, the next group's operand loads are kept ahead of this group's products by scheduling fences.
-template <int NRG, int NJ, int OFF, bool LDS>
+// SKIPN: the part walks the list [0..127] + [192..255] of the operand's blocks (carry products: the n rows of DI are not theirs)
+template <int NRG, int NJ, int OFF, bool LDS, bool SKIPN = false>
 __device__ __forceinline__ void bp_mma(const float (&wr)[NWR], const float* wl, const f4* __restrict__ xb, int wave, int kb0,
                                        int nblk, f4* acc) {
 #ifdef ZEGGS_BP_NOMMA             /* timing experiments only (results invalid) */
   return;
 #endif
   constexpr int GU = NRG >= 3 ? 1 : 2, NG = (NJ + GU - 1) / GU;     // operand blocks per group (matrix-core bound parts: 1)
+  // the block offsets are cheap scalar arithmetic; hidden from the optimiser's loop-invariant code motion, which otherwise
+  // keeps ~100 of them (one per block of every part) live across the whole time loop and spills registers for it
+  asm volatile("" : "+s"(wave));
   f4 xa[GU][2], xq[GU][2];
   auto load = [&](f4 (&x)[GU][2], int g) {
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
       int e = wave + 8 * (GU * g + u);
       e = e < nblk ? e : nblk - 1;              // past the end: the weights of that slot are zero (bp_pack_k)
-      const int kb = kb0 + e;
+      int kb = kb0 + e;
+      if (SKIPN) kb = kb < 128 ? kb : kb + 64;
       x[u][0] = xb[(long)(kb * 2) * 64];
       x[u][1] = xb[(long)(kb * 2 + 1) * 64];
     }
@@ -249,35 +263,37 @@ __device__ __forceinline__ void root_pre_store(const RootPre& o, F put) {      /
 #pragma unroll
   for (int i = 0; i < 6; ++i) put(27 + i, o.dp[i]);
 }
-template <class F>
-__device__ __forceinline__ void root_pre_load(RootPre& o, F get) {
-  o.qti = Q4{get(0), get(1), get(2), get(3)}; o.w = v3(get(4), get(5), get(6));
-  o.qp = Q4{get(7), get(8), get(9), get(10)}; o.dvel = v3(get(11), get(12), get(13));
-  o.dvrt = v3(get(14), get(15), get(16)); o.hu = v3(get(17), get(18), get(19));
-  o.E = Q4{get(20), get(21), get(22), get(23)}; o.ea = get(24); o.eb_ = get(25); o.ec = get(26);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) o.dp[i] = get(27 + i);
-}
 // cr: adjoint of (root_pos_f, root_rot_f) INCLUDING this frame's direct loss gradients (drpos / drrot were added when the
-// frame was prepared)
-__device__ __forceinline__ void root_apply(const ZeggsDecDims& d, const float* gaze_rstd /* 1 / in_std[PO..PO+2] */,
-                                           const RootPre& o, const float (&dgd_in)[3], float (&cr)[7], float (&g6)[6]) {
+// frame was prepared).  The prepared values are fetched (get(slot), see root_pre_store) right where they are used: the
+// workgroup's registers are full of weights, and 33 values loaded up front get spilled to scratch around this code.
+template <class F>
+__device__ __forceinline__ void root_apply(const ZeggsDecDims& d, const float* gaze_rstd /* 1 / in_std[PO..PO+2] */, F get,
+                                           const float (&dgd_in)[3], float (&cr)[7], float (&g6)[6]) {
   V3 g_rp = v3(cr[0], cr[1], cr[2]);
   Q4 g_rr = Q4{cr[3], cr[4], cr[5], cr[6]};
-  const V3 dgd = v3(dgd_in[0] * gaze_rstd[0], dgd_in[1] * gaze_rstd[1], dgd_in[2] * gaze_rstd[2]);
-  Q4 dqi; V3 dv;
-  qmv_bwd(o.qti, o.w, dgd, dqi, dv);
-  g_rr.w += dqi.w; g_rr.x -= dqi.x; g_rr.y -= dqi.y; g_rr.z -= dqi.z;
-  g_rp = g_rp - dv;
+  {
+    const V3 dgd = v3(dgd_in[0] * gaze_rstd[0], dgd_in[1] * gaze_rstd[1], dgd_in[2] * gaze_rstd[2]);
+    Q4 dqi; V3 dv;
+    qmv_bwd(Q4{get(0), get(1), get(2), get(3)}, v3(get(4), get(5), get(6)), dgd, dqi, dv);
+    g_rr.w += dqi.w; g_rr.x -= dqi.x; g_rr.y -= dqi.y; g_rr.z -= dqi.z;
+    g_rp = g_rp - dv;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const Q4 qp = Q4{get(7), get(8), get(9), get(10)};
   Q4 dq1; V3 dv1;
-  qmv_bwd(o.qp, o.dvel, g_rp, dq1, dv1);
-  Q4 dE, dqy;
-  qmul_bwd(o.E, o.qp, g_rr, dE, dqy);
-  const V3 gv = v3(dE.x, dE.y, dE.z);
-  const V3 du = 0.5f * (o.ea * gv + (o.eb_ * dE.w + o.ec * dot(gv, o.hu)) * o.hu);
-  Q4 dq2; V3 dv2;
-  qmv_bwd(o.qp, o.dvrt, du, dq2, dv2);
+  qmv_bwd(qp, v3(get(11), get(12), get(13)), g_rp, dq1, dv1);
   g6[0] += d.dt * dv1.x; g6[1] += d.dt * dv1.y; g6[2] += d.dt * dv1.z;
+  __builtin_amdgcn_sched_barrier(0);
+  Q4 dE, dqy;
+  qmul_bwd(Q4{get(20), get(21), get(22), get(23)}, qp, g_rr, dE, dqy);
+  __builtin_amdgcn_sched_barrier(0);
+  V3 du;
+  {
+    const V3 hu = v3(get(17), get(18), get(19)), gv = v3(dE.x, dE.y, dE.z);
+    du = 0.5f * (get(24) * gv + (get(25) * dE.w + get(26) * dot(gv, hu)) * hu);
+  }
+  Q4 dq2; V3 dv2;
+  qmv_bwd(qp, v3(get(14), get(15), get(16)), du, dq2, dv2);
   g6[3] += d.dt * dv2.x; g6[4] += d.dt * dv2.y; g6[5] += d.dt * dv2.z;
   cr[0] = g_rp.x; cr[1] = g_rp.y; cr[2] = g_rp.z;
   cr[3] = dq1.w + dqy.w + dq2.w; cr[4] = dq1.x + dqy.x + dq2.x;
@@ -314,7 +330,7 @@ __host__ __device__ inline int p4_row(int c, int s, int PO, int XD) {      // dx
 
 __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   __shared__ float wl3[8 * L3 * 64];          // P3 weight tiles of this workgroup (128 KB)
-  __shared__ float red[8][20][32];            // per-wave partial sums [row][batch]
+  __shared__ float red[8][16][32];            // per-wave partial sums [row][batch]
   __shared__ float dxa[8][32];                // dXa of this workgroup's dx rows (P3 -> P4)
   __shared__ f4 ex[4][32];                    // epilogue exchange: 4 consecutive rows of a batch row -> one 16-byte store
   __shared__ float sp9[NSP][32];              // workgroup 0: dx of the root / gaze columns
@@ -339,20 +355,31 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   if (tid == 0) fail = 0;
   if (tid < 15) rst[tid] = tid < 6 ? 1.f / a.st.in_std[tid] : tid < 9 ? 1.f / a.st.in_std[d.PO + tid - 6] : a.st.out_std[tid - 9];
   const float* wl = wl3 + wave * L3 * 64 + lane;
-  // epilogue item of this thread: output row er (0..15) of the phase, batch row eb
-  const int er = tid >> 5, eb = tid & 31;
-  const bool bact = eb < B;
-  const int U = 4 * c + (er & 3);               // hidden unit / dhid row of the GRU items (er < 4, er 4..7)
-  float c1 = 0.f, c0 = 0.f;                     // carries dH1c / dH0c of (U, eb): threads er < 4
+  // epilogue item of this thread: output row er (0..15) of the phase, batch row eb.  The derived indices are re-derived from an
+  // opaque copy of the thread index at the start of every phase (refresh): left alone, the optimiser hoists every per-thread
+  // 64-bit address they feed (a few dozen) out of the time loop and spills registers to keep them
+  int er = tid >> 5, eb = tid & 31;
+  bool bact = eb < B;
+  int U = 4 * c + (er & 3);                     // hidden unit / dhid row of the GRU items (er < 4, er 4..7)
   const int U0 = 4 * c;
-  // P4 item: slot s4 = er - 4 (0..11)
-  const int s4 = er - 4;
-  const int row4 = er >= 4 ? p4_row(c, s4, PO, XD) : -1;
+  int s4 = er - 4;                              // P4 item: dx slot 0..11
+  int row4 = er >= 4 ? p4_row(c, s4, PO, XD) : -1;
+  int row3 = er >= 8 ? p3_row(c, er - 8, XD) : -1;     // P3 dXa item: slot er - 8
+  int sp3 = row3 >= 0 ? special_index(row3, PO) : -1;
+  float c1 = 0.f, c0 = 0.f;                     // carries dH1c / dH0c of (U, eb): threads er < 4
   float si4 = 1.f, so4 = 0.f;
   if (row4 >= 0 && row4 < PI) { si4 = a.st.in_std[row4]; so4 = row4 < PO ? a.st.out_std[row4] : 0.f; }
-  // P3 dXa item: slot er - 8
-  const int row3 = er >= 8 ? p3_row(c, er - 8, XD) : -1;
-  const int sp3 = row3 >= 0 ? special_index(row3, PO) : -1;
+  auto refresh = [&]() {
+    int tx = tid;
+    asm volatile("" : "+v"(tx));
+    er = tx >> 5; eb = tx & 31;
+    bact = eb < B;
+    U = 4 * c + (er & 3);
+    s4 = er - 4;
+    row4 = er >= 4 ? p4_row(c, s4, PO, XD) : -1;
+    row3 = er >= 8 ? p3_row(c, er - 8, XD) : -1;
+    sp3 = row3 >= 0 ? special_index(row3, PO) : -1;
+  };
   // root thread of batch row eb (workgroup 0, first 32 threads); the adjoint of (root_pos, root_rot) lives in LDS
   const bool ract = c == 0 && tid < 32 && bact;
   if (ract) {
@@ -361,10 +388,30 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   }
   __syncthreads();
 
+#ifdef ZEGGS_BPSTAT
+  unsigned long long wsum[4] = {0, 0, 0, 0};      // 100 MHz ticks this workgroup spent polling, per phase kind
+  unsigned long long esum[4] = {0, 0, 0, 0};      // ... and between the end of the products and its arrival, per phase
+  unsigned long long e0_ = 0, q4[6] = {0, 0, 0, 0, 0, 0}, q0_ = 0;     // thread 0: P4 epilogue split
+#define BPQ0() q0_ = wall_clock64()
+#define BPQ(k) do { const unsigned long long n_ = wall_clock64(); q4[k] += n_ - q0_; q0_ = n_; } while (0)
+#define BPS0() e0_ = wall_clock64()
+#define BPS1(k) esum[k] += wall_clock64() - e0_
+#else
+#define BPS0() do {} while (0)
+#define BPS1(k) do {} while (0)
+#define BPQ0() do {} while (0)
+#define BPQ(k) do {} while (0)
+#endif
   auto wait_phase = [&](long p) {     // all workgroups have finished phase instance p (p < 0: nothing to wait for)
 #ifndef ZEGGS_BP_NOWAIT
     if (p >= 0) {
+#ifdef ZEGGS_BPSTAT
+      const unsigned long long w0 = wall_clock64();
+#endif
       if (wave == 1 && !bp_wait(a.cnt, (unsigned)(p + 1))) fail = 1;     // (wave 0 of workgroup 0 prepares the root frame meanwhile)
+#ifdef ZEGGS_BPSTAT
+      wsum[(p + 1) & 3] += wall_clock64() - w0;
+#endif
     }
 #endif
     __syncthreads();
@@ -380,8 +427,9 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   auto put = [&](const f4& v, int row0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float s = v[i] + __shfl_xor(v[i], 32);
-      if (lane < 32) red[wave][row0 + i][lane] = s;
+      const unsigned x = __float_as_uint(v[i]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);     // [1]: lanes < 32 get lane + 32's value
+      if (lane < 32) red[wave][row0 + i][lane] = v[i] + __uint_as_float(sw[1]);
     }
   };
   auto total = [&](int row) -> float {       // sum over the 8 waves of (row, eb)
@@ -389,6 +437,12 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
 #pragma unroll
     for (int w = 0; w < 8; ++w) s += red[w][row][eb];
     return s;
+  };
+  // a carry piece computed in the window before a wait: reduced right there (rows 0..3 of red), off the critical path
+  auto window_total = [&](const f4& v) -> float {
+    put(v, 0);
+    __syncthreads();
+    return (er < 4 && bact) ? total(er) : 0.f;      // (the next writer of red comes after the barrier of wait_phase)
   };
   // GRU backward of one (unit, batch row): g = total gradient wrt h_t; leaves the gate gradients in the exchange buffer
   // (kind 0 r, 1 z, 2 n, 3 hidden-side n), returns g * z
@@ -408,9 +462,9 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
     if (tid < 128 && bact) {
       const int kind = tid >> 5;
       const f4 v = ex[kind][eb];
+      stp4(OP + t * (4L * H * 32) + op_idx(eb, kind * H + U0), v);
       if (kind < 3) *(f4*)(DI + t * s3 + (long)eb * 3 * H + kind * H + U0) = v;
       else *(f4*)(DHc + t * sH + (long)eb * H + U0) = v;
-      stp4(OP + t * (4L * H * 32) + op_idx(eb, kind * H + U0), v);
     }
   };
 
@@ -422,11 +476,17 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
     // ================================================================ P1 : dH1 = W2^T dy_t + carry1 -> layer-1 gates
     BPT(0);
     {
+      refresh();
       f4 gt = f4{0.f, 0.f, 0.f, 0.f};
       float hp = 0.f;
       if (er < 4 && bact) {
         gt = ((const f4*)a.GT1)[(long)t * sH + (long)eb * H + U];
         hp = a.H1[(long)(t - 1) * sH + (long)eb * H + U];
+      }
+      if (t < T - 1) {      // window: carry0 += first half of W_hh0^T (DI0 r,z | dn_h0) of step t+1
+        f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+        bp_mma<1, NJC, OC0A, false, true>(wr, nullptr, (const f4*)(a.OP0 + (long)(t + 1) * OPS) + lane, wave, 0, 96, acct);
+        c0 += window_total(acct[0]);
       }
       f4 acc[1] = {f4{0.f, 0.f, 0.f, 0.f}};
       wait_phase(pA - 1);
@@ -434,6 +494,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       BPT(1);
       bp_mma<1, NJ1, O1, false>(wr, nullptr, (const f4*)(a.OPY + (long)t * a.KBY * 512) + lane, wave, 0, a.KBY, acc);
       BPT(2);
+      BPS0();
       put(acc[0], 0);
       __syncthreads();
       if (er < 4 && bact) c1 = gru_bwd(total(er) + c1, gt, hp);
@@ -441,17 +502,24 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       gru_store(a.DI1, a.DH1, a.OP1, t);
       BPT(3);
       arrive(pA);
+      BPS1(0);
       BPT(4);
     }
     // ================================================================ P2 : dH0 = W_ih1^T DI1_t + carry0 -> layer-0 gates
-    {                                                                   //      carry1 += W_hh1[r,z]^T DI1_t[r,z]
+    {
+      refresh();
       f4 gt = f4{0.f, 0.f, 0.f, 0.f};
       float hp = 0.f;
       if (er < 4 && bact) {
         gt = ((const f4*)a.GT0)[(long)t * sH + (long)eb * H + U];
         hp = a.H0[(long)(t - 1) * sH + (long)eb * H + U];
       }
-      f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+      if (t < T - 1) {      // window: carry0 += second half of W_hh0^T (.) of step t+1
+        f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+        bp_mma<1, NJC, OC0B, false, true>(wr, nullptr, (const f4*)(a.OP0 + (long)(t + 1) * OPS) + lane, wave, 96, 96, acct);
+        c0 += window_total(acct[0]);
+      }
+      f4 acc[1] = {f4{0.f, 0.f, 0.f, 0.f}};
       wait_phase(pB - 1);
       if (fail) break;
       BPT(5);
@@ -467,8 +535,8 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
             rv[q] = root_item(a.drpos, a.drrot, a.rrot, a.rpos, a.gaze, a.pose, a.dpose, T, PO, idx & 31, t - 1, true, idx >> 5);
         }
       }
-      bp_mma<2, NJA, O2A, false>(wr, nullptr, op1, wave, 0, 128, acc);
-      bp_mma<1, NJB, O2B, false>(wr, nullptr, op1, wave, 128, 64, acc);
+      bp_mma<1, NJ2A, 0, true>(wr, wl + L3A * 64, op1, wave, 0, 128, acc);
+      bp_mma<1, NJ2B, O2B, false>(wr, nullptr, op1, wave, 128, 64, acc);
       if (rfetch) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -477,25 +545,27 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
         }
       }
       BPT(6);
-      put(acc[0], 0); put(acc[1], 4);
+      BPS0();
+      put(acc[0], 0);
       __syncthreads();
-      if (er < 4 && bact) {
-        c1 += total(4 + er);
-        c0 = gru_bwd(total(er) + c0, gt, hp);
-      }
+      if (er < 4 && bact) c0 = gru_bwd(total(er) + c0, gt, hp);
       __syncthreads();
       gru_store(a.DI0, a.DH0, a.OP0, t);
       BPT(7);
       arrive(pB);
+      BPS1(1);
       BPT(8);
     }
     // ================================================================ P3 : dGin = W_ih0^T DI0_t ; carry0 += W_hh0[r,z]^T DI0_t[r,z]
     {
+      refresh();
       float hid = 0.f;
       if (er >= 4 && er < 8 && bact) hid = a.Gin[(long)t * sG + (long)eb * GL + U];
-      f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
-      // carry1 += W_hh1[n]^T dn_h1 : the operand is one phase old -- done before the wait, it hides the hand-off latency
-      bp_mma<1, NJT, OT1, false>(wr, nullptr, op1, wave, 192, 64, acct);
+      {     // window: carry1 += first half of W_hh1^T (DI1_t r,z | dn_h1) -- the operand is one phase old
+        f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+        bp_mma<1, NJC, OC1A, false, true>(wr, nullptr, op1, wave, 0, 96, acct);
+        c1 += window_total(acct[0]);
+      }
       if (ract && t > 1) {      // root thread: the gradient-independent half of the root backward of frame t-1 (in place)
         RootIn ri;
         ri.gather([&](int item) { return rin[item][eb]; });
@@ -507,20 +577,21 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
         for (int q = 0; q < 4; ++q) crs[3 + q][eb] += ri.e[q];
         root_pre_store(pre, [&](int slot, float v) { rin[slot][eb] = v; });
       }
-      f4 acc[4] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+      f4 acc[3] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
       wait_phase(pC - 1);
       if (fail) break;
       BPT(9);
-      bp_mma<4, NJA, 0, true>(wr, wl, op0, wave, 0, 128, acc);          // dhid | dXa slots 0..3 | dXa slots 4..7 | carry0
+      bp_mma<3, NJA, 0, true>(wr, wl, op0, wave, 0, 128, acc);          // dhid | dXa slots 0..3 | dXa slots 4..7
       bp_mma<3, NJB, O3B, false>(wr, nullptr, op0, wave, 128, 64, acc);
       BPT(10);
-      put(acct[0], 0); put(acc[0], 4); put(acc[1], 8); put(acc[2], 12); put(acc[3], 16);
+      BPS0();
+      put(acc[0], 0); put(acc[1], 4); put(acc[2], 8);
       __syncthreads();
       if (bact) {
-        const float v = total(er);
-        if (er < 4) { c1 += v; c0 += total(16 + er); }
-        else if (er < 8) ((float*)&ex[0][eb])[er - 4] = v * d_elu_grad_from_out(hid);
+        if (er < 4) {}
+        else if (er < 8) ((float*)&ex[0][eb])[er - 4] = total(er - 4) * d_elu_grad_from_out(hid);
         else if (row3 >= 0) {
+          const float v = total(er - 4);
           dxa[er - 8][eb] = v;
           if (sp3 >= 0) stp(a.SP + ((long)t * NSP + sp3) * 32 + eb, v);
         }
@@ -528,33 +599,42 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       __syncthreads();
       if (tid < 32 && bact) {
         const f4 v = ex[0][eb];
-        *(f4*)(a.D0 + (long)t * sH + (long)eb * H + U0) = v;
         stp4(a.OPD + (long)t * (H * 32L) + op_idx(eb, U0), v);
+        *(f4*)(a.D0 + (long)t * sH + (long)eb * H + U0) = v;
       }
       BPT(11);
       arrive(pC);
+      BPS1(2);
       BPT(12);
     }
     // ================================================================ P4 : dx_t = dXa + W0^T D0_t -> DX[t], dy_{t-1}
     {
+      refresh();
       float dpo = 0.f;
       if (t > 1 && bact && row4 >= 6 && row4 < PO) dpo = a.dpose[((long)eb * T + t - 1) * PO + row4];
-      f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
-      bp_mma<1, NJT, OT0, false>(wr, nullptr, op0, wave, 192, 64, acct);      // carry0 += W_hh0[n]^T dn_h0 (before the wait)
+      {     // window: carry1 += second half of W_hh1^T (DI1_t r,z | dn_h1)
+        f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+        bp_mma<1, NJC, OC1B, false, true>(wr, nullptr, op1, wave, 96, 96, acct);
+        c1 += window_total(acct[0]);
+      }
       f4 acc[3] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
       wait_phase(pD - 1);
       if (fail) break;
       BPT(13);
       float spv = 0.f;                                     // workgroup 0: dXa of the root / gaze columns (other owners)
+#ifndef ZEGGS_BP_NOSPV      /* timing experiment only */
       if (c == 0 && er >= 4 && bact && (s4 < 6 || (s4 >= 8 && s4 < 11))) spv = a.SP[((long)t * NSP + (s4 < 6 ? s4 : s4 - 2)) * 32 + eb];
+#endif
       bp_mma<3, NJ4, O4, false>(wr, nullptr, (const f4*)(a.OPD + (long)t * (H * 32L)) + lane, wave, 0, 64, acc);
       BPT(14);
-      put(acct[0], 0); put(acc[0], 4); put(acc[1], 8); put(acc[2], 12);
+      BPS0();
+      BPQ0();
+      put(acc[0], 0); put(acc[1], 4); put(acc[2], 8);
       __syncthreads();
-      if (bact) {
-        const float v = total(er);
-        if (er < 4) c0 += v;
-        else {
+      BPQ(0);
+      if (bact && er >= 4) {
+        const float v = total(er - 4);
+        {
           float gy = 0.f;
           if (c == 0 && (s4 < 6 || s4 >= 8)) {               // root / gaze columns: to the root thread of the batch row
             if (s4 < 11) sp9[s4 < 6 ? s4 : s4 - 2][eb] = v + spv;
@@ -567,6 +647,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
         }
       }
       __syncthreads();
+      BPQ(1);
       if (t > 1) {
         float* dyc = a.DY + ((long)(t - 1) * B + eb) * POL;
         float* opy = a.OPY + (long)(t - 1) * a.KBY * 512;
@@ -574,8 +655,8 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
           const int g = tid >> 5, rb = 8 * c + 4 * g;          // groups 0, 1 of this workgroup's rows
           if (tid < 64 && bact && rb < PO) {
             const f4 v = ex[g][eb];
-            *(f4*)(dyc + rb) = v;
             stp4(opy + op_idx(eb, rb), v);
+            *(f4*)(dyc + rb) = v;
           }
         } else {
           BPT(17);
@@ -583,10 +664,9 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
             float g6[6], dgd[3], cr[7];
 #pragma unroll
             for (int q = 0; q < 7; ++q) cr[q] = crs[q][eb];
-            RootPre pre;
-            root_pre_load(pre, [&](int slot) { return rin[slot][eb]; });
+            auto pre = [&](int slot) { return rin[slot][eb]; };
 #pragma unroll
-            for (int q = 0; q < 6; ++q) g6[q] = pre.dp[q] + sp9[q][eb] * rst[q];
+            for (int q = 0; q < 6; ++q) g6[q] = pre(27 + q) + sp9[q][eb] * rst[q];
 #pragma unroll
             for (int q = 0; q < 3; ++q) dgd[q] = sp9[6 + q][eb];
             BPT(18);
@@ -599,20 +679,51 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
             const f4 v0 = f4{g6[0] * rst[9], g6[1] * rst[10], g6[2] * rst[11], g6[3] * rst[12]};
             const f4 e1 = ex[1][eb];                           // rows 6, 7 are ordinary pose columns
             const f4 v1 = f4{g6[4] * rst[13], g6[5] * rst[14], e1[2], e1[3]};
-            *(f4*)dyc = v0; *(f4*)(dyc + 4) = v1;
+#if defined(ZEGGS_BP_X3)        /* timing experiments only */
+            { float* o2 = a.OPY; float* d2 = a.DY + (long)eb * POL; stp4(o2 + op_idx(eb, 0), v0); stp4(o2 + op_idx(eb, 4), v1); *(f4*)d2 = v0; *(f4*)(d2 + 4) = v1; }
+#elif defined(ZEGGS_BP_X4)
             stp4(opy + op_idx(eb, 0), v0); stp4(opy + op_idx(eb, 4), v1);
+#elif defined(ZEGGS_BP_X5)
+            if (v0[0] + v1[0] == 123.456f) stp4(opy + op_idx(eb, 0), v0);
+#else
+            stp4(opy + op_idx(eb, 0), v0); stp4(opy + op_idx(eb, 4), v1);
+            *(f4*)dyc = v0; *(f4*)(dyc + 4) = v1;
+#endif
           }
         }
       }
       BPT(15);
+      BPQ(2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      BPQ(3);
       arrive(pD);
+      BPQ(4);
+      BPS1(3);
       BPT(16);
     }
+  }
+  if (!fail) {          // the carry0 pieces of step 1 (their windows would have been in a step 0)
+    f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+    bp_mma<1, NJC, OC0A, false, true>(wr, nullptr, (const f4*)(a.OP0 + OPS) + lane, wave, 0, 96, acct);
+    bp_mma<1, NJC, OC0B, false, true>(wr, nullptr, (const f4*)(a.OP0 + OPS) + lane, wave, 96, 96, acct);
+    c0 += window_total(acct[0]);
   }
   if (!fail && er < 4 && bact) {     // gradients wrt the initial hidden states (CellStateEncoder backward)
     a.dH1c[(long)eb * H + U] = c1;
     a.dH0c[(long)eb * H + U] = c0;
   }
+#ifdef ZEGGS_BPSTAT
+  if (tid == 64) {      // wave 1 polls
+    unsigned long long* o = (unsigned long long*)(a.err + 512) + 4 * c;
+    for (int i = 0; i < 4; ++i) o[i] = wsum[i];
+    unsigned long long* o2 = (unsigned long long*)(a.err + 512) + 4 * 256 + 4 * c;
+    for (int i = 0; i < 4; ++i) o2[i] = esum[i];
+  }
+  if (tid == 0) {
+    unsigned long long* o3 = (unsigned long long*)(a.err + 512) + 8 * 256 + 8 * c;
+    for (int i = 0; i < 6; ++i) o3[i] = q4[i];
+  }
+#endif
   if (fail && tid == 0) atomicOr(a.err, 1u);
 }
 
@@ -649,19 +760,25 @@ __global__ void bp_pack_k(BPackArgs p) {
     const int per = lds ? L3 : NWR;
     const int slot = (int)(cws % per), wave = (int)((cws / per) & 7), c = (int)(cws / (8L * per));
     int kind, j, rg = 0, kb0, nblk;
-    if (lds) {                 // P3, blocks 0..127 of [DI0 | dn_h0]: dhid | dXa 0..3 | dXa 4..7 | carry0
-      j = slot / 4; rg = slot % 4; kb0 = 0; nblk = 128;
-      kind = rg == 0 ? 5 : rg == 1 ? 6 : rg == 2 ? 7 : 3;
-    } else if (slot < O2A) { kind = 0; j = slot - O1; kb0 = 0; nblk = p.KBY; }
-    else if (slot < O2B) { j = (slot - O2A) / 2; rg = (slot - O2A) % 2; kind = rg == 0 ? 1 : 2; kb0 = 0; nblk = 128; }
-    else if (slot < OT1) { kind = 1; j = slot - O2B; kb0 = 128; nblk = 64; }
-    else if (slot < O3B) { kind = 2; j = slot - OT1; kb0 = 192; nblk = 64; }
-    else if (slot < OT0) { j = (slot - O3B) / 3; rg = (slot - O3B) % 3; kind = 5 + rg; kb0 = 128; nblk = 64; }
-    else if (slot < O4) { kind = 3; j = slot - OT0; kb0 = 192; nblk = 64; }
+    bool skipn = false;
+    if (lds && slot < L3A) {   // P3, blocks 0..127 of DI0: dhid | dXa 0..3 | dXa 4..7
+      j = slot / 3; rg = slot % 3; kb0 = 0; nblk = 128; kind = 5 + rg;
+    } else if (lds) { kind = 1; j = slot - L3A; kb0 = 0; nblk = 128; }          // P2, blocks 0..127 of DI1
+    else if (slot < O2B) { kind = 0; j = slot - O1; kb0 = 0; nblk = p.KBY; }
+    else if (slot < OC1A) { kind = 1; j = slot - O2B; kb0 = 128; nblk = 64; }
+    else if (slot < OC1B) { kind = 2; j = slot - OC1A; kb0 = 0; nblk = 96; skipn = true; }
+    else if (slot < O3B) { kind = 2; j = slot - OC1B; kb0 = 96; nblk = 96; skipn = true; }
+    else if (slot < OC0A) { j = (slot - O3B) / 3; rg = (slot - O3B) % 3; kind = 5 + rg; kb0 = 128; nblk = 64; }
+    else if (slot < OC0B) { kind = 3; j = slot - OC0A; kb0 = 0; nblk = 96; skipn = true; }
+    else if (slot < O4) { kind = 3; j = slot - OC0B; kb0 = 96; nblk = 96; skipn = true; }
     else { kind = 4; j = (slot - O4) / 3; rg = (slot - O4) % 3; kb0 = 0; nblk = 64; }
     const int e = wave + 8 * j;
     float v = 0.f;
-    if (e < nblk) v = bp_value(p, kind, c, rg, lane & 3, kb0 + e, lane >> 2);
+    if (e < nblk) {
+      int kb = kb0 + e;
+      if (skipn) kb = kb < 128 ? kb : kb + 64;
+      v = bp_value(p, kind, c, rg, lane & 3, kb, lane >> 2);
+    }
     (lds ? p.PWL : p.PWR)[r] = v;
   }
 }
@@ -746,6 +863,14 @@ extern "C" int zeggs_bp_stamps(const ZeggsDecDims* dp, void* ws, size_t ws_bytes
   DecWs w = carve_dec(*dp, 1, a);
   ZCHECK(a.ok() && w.bp_cnt, "bp_stamps: workspace");
   ZCHECK(hipMemcpy(out, w.bp_cnt + 1024 + 32, 3 * 2 * 32 * 8, hipMemcpyDeviceToHost) == hipSuccess, "copy");
+  return 0;
+}
+// -DZEGGS_BPSTAT builds: 100 MHz ticks every workgroup spent polling for the hand-off INTO phase P1..P4, summed over the sweep
+extern "C" int zeggs_bp_waits(const ZeggsDecDims* dp, void* ws, size_t ws_bytes, unsigned long long* out /* host [4][256][4] */) {
+  Arena a(ws, ws_bytes);
+  DecWs w = carve_dec(*dp, 1, a);
+  ZCHECK(a.ok() && w.bp_cnt, "bp_waits: workspace");
+  ZCHECK(hipMemcpy(out, w.bp_cnt + 1024 + 512, 4 * 256 * 4 * 8, hipMemcpyDeviceToHost) == hipSuccess, "copy");
   return 0;
 }
 int dec_bp_errptr(const DecWs& w, unsigned** out) {
