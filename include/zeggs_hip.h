@@ -177,6 +177,8 @@ int zeggs_decoder_fwd_state(const ZeggsDecDims*, const ZeggsDecParams*, const Ze
 int zeggs_persistent_state(int which /* 0: B=1 decode kernel, 1: training-forward kernel, 2: BPTT sweep */);   /* 1 ok, 0 disabled, -1 unused */
 /* measurement builds (-DZEGGS_TPTIME) only: phase stamps of the last 4 steps of the persistent training rollout */
 int zeggs_tp_stamps(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned long long* out /* host [4][2][32] */);
+/* -DZEGGS_TPSTAT builds: 100 MHz ticks every workgroup spent polling for the hand-off into phase 1..3 of the rollout */
+int zeggs_tp_waits(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned long long* out /* host [256][4] */);
 /* Training backward with batch <= 32: the BPTT sweep of zeggs_decoder_bwd (replaces the per-step autograd of
  * ZEGGS/train.py:425 through modules.py:100-151) runs as ONE persistent launch by default (option "bwd_persistent",
  * csrc/train_bwd_persistent.hip: transposed weights resident as 4-row v_mfma_f32_4x4x1 tiles, four grid hand-offs per step).

@@ -130,7 +130,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
       const long KB0 = 64 + w.KBX + 64, KB3 = 64 + w.KBC;
       w.tp_w0 = a.f(256L * 8 * 26 * BLK); w.tp_w1 = a.f(256L * 8 * 16 * BLK); w.tp_w3 = a.f(256L * 8 * 9 * BLK);   // [wg][wave][block]
       w.G0xf = a.f(T * KB0 * XB); w.G1xf = a.f(T * 128 * XB); w.G3xf = a.f(T * KB3 * XB);
-      w.tp_cnt = (unsigned*)a.f(4096);
+      w.tp_cnt = (unsigned*)a.f(8192);      // arrival slots | error word (+1024) | stamps | wait statistics (+1536)
     }
     if (d.H == 1024 && d.B <= 32) {
       w.bp_wr = a.f(256L * 8 * 113 * 64); w.bp_wl = a.f(256L * 8 * 64 * 64);

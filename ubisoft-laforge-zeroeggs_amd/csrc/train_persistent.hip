@@ -33,6 +33,10 @@ constexpr int TH = 1024, TTHR = 512, TNCU = 256, TSPIN = 1 << 21;
 // lo + wave + 8 j: the parts are interleaved over the 8 waves so that every wave owns old work to do before the hand-off.
 constexpr int TNO0 = 9, TNF0 = 17, TNO1 = 8, TNF1 = 8, TNO3 = 1, TNF3 = 8;
 constexpr int TJ0 = TNO0 + TNF0, TJ1 = TNO1 + TNF1, TJ3 = TNO3 + TNF3;
+// old blocks of GRU layer 0 done one window early / of GRU layer 1 done in layer 0's window (batch <= 32; the wider variants
+// have no registers to spare for a second live accumulator)
+constexpr int ts0(int nb) { return nb <= 2 ? 5 : 0; }
+constexpr int ts1(int nb) { return nb <= 2 ? 2 : 0; }
 constexpr int TFR0 = 135;     // GRU layer 0: k-blocks [0, 135) = hid_t and the pose / gaze columns of x_t are fresh
 // old-part k-blocks of GRU layer 0 parked in LDS instead of registers (as many as the LDS budget of the variant allows)
 constexpr int tl0(int nb) { return nb <= 2 ? 8 : nb == 3 ? 6 : 5; }
@@ -86,8 +90,12 @@ __device__ __forceinline__ bool tp_wait(const unsigned* slots, unsigned expect) 
 template <int NB, int NJT, int OFF, int NJ, bool WLDS>
 __device__ __forceinline__ void tp_mma(const f4 (&wr)[NJT], const f4* wl, const f4* __restrict__ xb, int kb0, int hi,
                                        f4 (&acc)[NB]) {
+  if constexpr (NJ <= 0) return;
   constexpr int GU = NB >= 3 ? 1 : 2;                 // k-blocks per group: GU * NB float4 of activations per buffer
   constexpr int NG = (NJ + GU - 1) / GU;
+  // the block offsets are cheap scalar arithmetic; hidden from the optimiser's loop-invariant code motion, which otherwise keeps
+  // one per block of every part live across the whole time loop and spills registers for it (train_bwd_persistent.hip)
+  asm volatile("" : "+s"(kb0));
   f4 xa[GU][NB], xq[GU][NB];
   auto load = [&](f4 (&x)[GU][NB], int g) {
 #pragma unroll
@@ -150,7 +158,8 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   __shared__ f4 red[8][NB][64];
   __shared__ f4 fin[NB][64];
   __shared__ f4 w3[8 * TJ3 * 64];             // output-stage weights of this workgroup (72 KB)
-  constexpr int TL0 = tl0(NB);
+  constexpr int TL0 = tl0(NB), TS0 = ts0(NB), TS1 = ts1(NB);
+  constexpr bool SPREAD = TS0 > 0;       // old parts spread over all three hand-off windows
   __shared__ f4 w0l[8 * TL0 * 64];            // the first TL0 (old-part) k-blocks of GRU layer 0: relieves the register file
   __shared__ float gsh[BP * 3];               // normalised gaze direction of x_{t+1} per batch row
   __shared__ float cA[4][12];                 // biases of the 4 units: b_ih0, b_hh0, b_ih1, b_hh1 (r, z, n)
@@ -195,15 +204,17 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   }
   if (tid == 0) fail = 0;
   // GRU epilogue item of this thread: unit eu, batch row eb; the previous hidden values stay in registers for the rollout
-  const int eu = tid / BP, eb = tid % BP;
-  const bool gact = tid < 4 * BP && eb < B;
-  const int EU = 4 * c + (eu & 3);
+  // (re-derived from an opaque copy of the thread index at the top of every step: the per-thread addresses they feed are not
+  //  worth a register pair each for the whole rollout)
+  int eu = tid / BP, eb = tid % BP;
+  bool gact = tid < 4 * BP && eb < B;
+  int EU = 4 * c + (eu & 3);
   float hp0 = 0.f, hp1 = 0.f;
   if (gact) { hp0 = a.H0[(long)eb * H + EU]; hp1 = a.H1[(long)eb * H + EU]; }      // state before the first generated frame
   // root thread of batch row rb (the LAST B threads: the first ones carry the GRU items): the root state of its row stays
   // in registers for the rollout
-  const int rb = TTHR - 1 - tid;
-  const bool ract = rb < B;
+  int rb = TTHR - 1 - tid;
+  bool ract = rb < B;
   Q4 rq_ = Q4{1.f, 0.f, 0.f, 0.f};
   V3 rp_ = v3(0.f, 0.f, 0.f);
   if (ract) {
@@ -230,9 +241,18 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     }
     __syncthreads();
   };
+#ifdef ZEGGS_TPSTAT
+  unsigned long long wsum[3] = {0, 0, 0};      // 100 MHz ticks this workgroup spent polling, per phase kind
+#endif
   auto wait_phase = [&](long p) {     // all workgroups have finished phase instance p (p < 0: nothing to wait for)
     if (p >= 0) {
+#ifdef ZEGGS_TPSTAT
+      const unsigned long long w0 = wall_clock64();
+#endif
       if (wave == 0 && !tp_wait(a.cnt, (unsigned)(p + 1))) fail = 1;
+#ifdef ZEGGS_TPSTAT
+      wsum[(p + 1) % 3] += wall_clock64() - w0;
+#endif
     }
     __syncthreads();
   };
@@ -242,15 +262,46 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     if (tid == 0) __hip_atomic_store((gu32*)(a.cnt + c), (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
+  f4 acc1[NB], acc2[NB];        // accumulators of GRU layer 0 / 1: started in the windows of earlier phases
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc1[nb] = f4{0.f, 0.f, 0.f, 0.f};
+  tp_mma<NB, TJ0 - TL0, 0, TS0, true>(wr0, w0l + wave * TL0 * 64 + lane, (const f4*)(a.G0 + (long)a.KB0 * XB) + lane, TFR0 + wave,
+                                      a.KB0, acc1);     // step 1 has no previous output stage to hide these behind
   for (int t = 1; t < T; ++t) {
+    {
+      int tx = tid;
+      asm volatile("" : "+v"(tx));
+      eu = tx / BP; eb = tx % BP;
+      gact = tx < 4 * BP && eb < B;
+      EU = 4 * c + (eu & 3);
+      rb = TTHR - 1 - tx;
+      ract = rb < B;
+    }
     const bool next = t + 1 < T;
     const long p1 = 3L * (t - 1), p2 = p1 + 1, p3 = p1 + 2;
     f4 acc[NB];
     // ================================================================ GRU layer 0 : [hid_t | x_t | h0_{t-1}]
+    // The old parts of the three phases (18 blocks per wave) are spread over the three hand-off windows, ~6 blocks each: a
+    // hand-off (store drain, flag, poll) takes about as long as 7 blocks of products.
     TPT(0);
+    if constexpr (SPREAD) {
+      const f4* x0 = (const f4*)(a.G0 + (long)t * a.KB0 * XB) + lane;
+      const f4* x1 = (const f4*)(a.G1 + (long)t * 128 * XB) + lane;
+      // window: the rest of this phase's old part (its first TS0 blocks ran in the window of the previous output stage) ...
+      if constexpr (TL0 > TS0)
+        tp_mma<NB, TJ0 - TL0, TS0, TL0 - TS0, true>(wr0, w0l + wave * TL0 * 64 + lane, x0, TFR0 + wave + 8 * TS0, a.KB0, acc1);
+      tp_mma<NB, TJ0 - TL0, 0, TNO0 - TL0, false>(wr0, nullptr, x0, TFR0 + wave + 8 * TL0, a.KB0, acc1);
+      // ... and the first blocks of GRU layer 1's old part (h1_{t-1})
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
-    {
+      for (int nb = 0; nb < NB; ++nb) acc2[nb] = f4{0.f, 0.f, 0.f, 0.f};
+      tp_mma<NB, TJ1, 0, TS1, false>(wr1, nullptr, x1, 64 + wave, 128, acc2);
+      wait_phase(p1 - 1);
+      if (fail) break;
+      TPT(1);
+      tp_mma<NB, TJ0 - TL0, TNO0 - TL0, TNF0, false>(wr0, nullptr, x0, wave, TFR0, acc1);  // fresh part
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
       const f4* x0 = (const f4*)(a.G0 + (long)t * a.KB0 * XB) + lane;
       // old part (before the hand-off): its first TL0 blocks come from LDS
       tp_mma<NB, TJ0 - TL0, 0, TL0, true>(wr0, w0l + wave * TL0 * 64 + lane, x0, TFR0 + wave, a.KB0, acc);
@@ -261,7 +312,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       tp_mma<NB, TJ0 - TL0, TNO0 - TL0, TNF0, false>(wr0, nullptr, x0, wave, TFR0, acc);  // fresh part
     }
     TPT(2);
-    reduce(acc);
+    reduce(*(SPREAD ? &acc1 : &acc));
     TPT(3);
     if (gact) {
       const float* k_ = cA[eu];
@@ -281,9 +332,16 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     arrive(p1);
     TPT(5);
     // ================================================================ GRU layer 1 : [h0_t | h1_{t-1}]
+    if constexpr (SPREAD) {
+      const f4* x1 = (const f4*)(a.G1 + (long)t * 128 * XB) + lane;
+      tp_mma<NB, TJ1, TS1, TNO1 - TS1, false>(wr1, nullptr, x1, 64 + wave + 8 * TS1, 128, acc2);   // window: rest of the old part
+      wait_phase(p2 - 1);
+      if (fail) break;
+      TPT(6);
+      tp_mma<NB, TJ1, TNO1, TNF1, false>(wr1, nullptr, x1, wave, 64, acc2);               // h0_t
+    } else {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
-    {
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
       const f4* x1 = (const f4*)(a.G1 + (long)t * 128 * XB) + lane;
       tp_mma<NB, TJ1, 0, TNO1, false>(wr1, nullptr, x1, 64 + wave, 128, acc);             // h1_{t-1}: before the hand-off
       wait_phase(p2 - 1);
@@ -292,7 +350,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       tp_mma<NB, TJ1, TNO1, TNF1, false>(wr1, nullptr, x1, wave, 64, acc);                // h0_t
     }
     TPT(7);
-    reduce(acc);
+    reduce(*(SPREAD ? &acc2 : &acc));
     TPT(8);
     if (gact) {
       const float* k_ = cA[eu];
@@ -320,6 +378,12 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       const f4* x3 = (const f4*)(a.G3 + (long)t * a.KB3 * XB) + lane;
       const f4* wl3 = w3 + wave * TJ3 * 64 + lane;
       tp_mma<NB, TJ0 - TL0, 0, TNO3, true>(wr0, wl3, x3, 64 + wave, a.KB3, acc);          // cond_{t+1}: before the hand-off
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc1[nb] = f4{0.f, 0.f, 0.f, 0.f};
+      if (SPREAD && next) {     // window: the first TS0 old blocks of the NEXT step's GRU layer 0 (h0_t, published two hand-offs ago)
+        const f4* x0n = (const f4*)(a.G0 + (long)(t + 1) * a.KB0 * XB) + lane;
+        tp_mma<NB, TJ0 - TL0, 0, TS0, true>(wr0, w0l + wave * TL0 * 64 + lane, x0n, TFR0 + wave, a.KB0, acc1);
+      }
       wait_phase(p3 - 1);
       if (fail) break;
       TPT(11);
@@ -390,6 +454,12 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     arrive(p3);
     TPT(15);
   }
+#ifdef ZEGGS_TPSTAT
+  if (tid == 0) {
+    unsigned long long* o = (unsigned long long*)(a.err + 512) + 4 * c;
+    for (int i = 0; i < 3; ++i) o[i] = wsum[i];
+  }
+#endif
   if (fail && tid == 0) atomicOr(a.err, 1u);
 }
 
@@ -538,6 +608,14 @@ extern "C" int zeggs_tp_stamps(const ZeggsDecDims* dp, void* ws, size_t ws_bytes
   DecWs w = carve_dec(*dp, 1, a);
   ZCHECK(a.ok() && w.tp_cnt, "tp_stamps: workspace");
   ZCHECK(hipMemcpy(out, w.tp_cnt + TRING * TSH * TSTR + 32, 4 * 2 * 32 * 8, hipMemcpyDeviceToHost) == hipSuccess, "copy");
+  return 0;
+}
+// -DZEGGS_TPSTAT builds: 100 MHz ticks every workgroup spent polling for the hand-off into phase 1..3, summed over the rollout
+extern "C" int zeggs_tp_waits(const ZeggsDecDims* dp, void* ws, size_t ws_bytes, unsigned long long* out /* host [256][4] */) {
+  Arena a(ws, ws_bytes);
+  DecWs w = carve_dec(*dp, 1, a);
+  ZCHECK(a.ok() && w.tp_cnt, "tp_waits: workspace");
+  ZCHECK(hipMemcpy(out, w.tp_cnt + TRING * TSH * TSTR + 512, 256 * 4 * 8, hipMemcpyDeviceToHost) == hipSuccess, "copy");
   return 0;
 }
 int dec_tp_errptr(const DecWs& w, unsigned** out) {
