@@ -468,7 +468,10 @@ def main():
             "traffic": pmc.get("traffic_bytes_per_step") if pmc else None,
             "us_per_step": round(f_us, 2), "us_per_step_in_timed_region": round(fwd_in * 1e3 / nst, 2),
             "algorithmic_bytes_per_step": step_bytes(BATCH),
-            "backward": {"kernel": "stage_k, BPTT step = 3 launches (transposed packs)", "achieved": round(ach_b, 1),
+            "backward": {"kernel": ("train_bwd_persistent_k: the 255 BPTT steps of a window as ONE weight-stationary launch "
+                                    "(4 phases per step, transposed weights as 4-row v_mfma_f32_4x4x1 tiles in registers / LDS)"
+                                    if ops.lib().zeggs_persistent_state(2) == 1 else
+                                    "stage_k, BPTT step = 3 launches (transposed packs)"), "achieved": round(ach_b, 1),
                          "frac": round(ach_b / HBM_PEAK_GBS, 4), "us_per_step": round(b_us, 2),
                          "us_per_step_in_timed_region": round(bwd_in * 1e3 / nst, 2),
                          "traffic": pmc.get("traffic_bytes_per_step_backward") if pmc else None},

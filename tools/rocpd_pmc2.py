@@ -36,11 +36,15 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
        "fetch_correction": "x2 (MI355X_MICROARCH.md)", "algorithmic_bytes_per_step": ALGO}
 steps = 2 * (T_TRAIN - 1)
 tpk = lambda k: "train_fwd_persistent_k" in k  # noqa: E731
+bpk = lambda k: "train_bwd_persistent_k" in k  # noqa: E731
 for name, f in (("forward", 0), ("backward", 1)):
     pred = fam(f)
     if f == 0 and group(fetch, tpk)[0]:       # the forward sweep is one persistent launch per rollout
         pred = tpk
         out["forward_kernel"] = "train_fwd_persistent_k (one launch per rollout; its weights are fetched once per rollout)"
+    if f == 1 and group(fetch, bpk)[0]:       # ... and so is the BPTT sweep
+        pred = bpk
+        out["backward_kernel"] = "train_bwd_persistent_k (one launch per sweep; its weight tiles are fetched once per sweep)"
     nf, kf = group(fetch, pred)
     nw, kw = group(write, pred)
     fb, wb = 2 * 1024 * kf / steps, 1024 * kw / steps
