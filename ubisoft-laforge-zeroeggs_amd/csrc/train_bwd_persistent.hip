@@ -95,9 +95,6 @@ __device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect) 
     const bool ok = (unsigned)a >= expect && (unsigned)(a >> 32) >= expect && (unsigned)b >= expect && (unsigned)(b >> 32) >= expect;
     if (__all(ok)) return true;
     if (spins > BSPIN) return false;
-#ifdef ZEGGS_BP_SLEEP
-    __builtin_amdgcn_s_sleep(ZEGGS_BP_SLEEP);      // 64 clocks per unit: thins out the polling traffic of the 256 waiting workgroups
-#endif
   }
 }
 
@@ -108,9 +105,6 @@ __device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect) 
 template <int NRG, int NJ, int OFF, bool LDS, bool SKIPN = false>
 __device__ __forceinline__ void bp_mma(const float (&wr)[NWR], const float* wl, const f4* __restrict__ xb, int wave, int kb0,
                                        int nblk, f4* acc) {
-#ifdef ZEGGS_BP_NOMMA             /* timing experiments only (results invalid) */
-  return;
-#endif
   constexpr int GU = NRG >= 3 ? 1 : 2, NG = (NJ + GU - 1) / GU;     // operand blocks per group (matrix-core bound parts: 1)
   // the block offsets are cheap scalar arithmetic; hidden from the optimiser's loop-invariant code motion, which otherwise
   // keeps ~100 of them (one per block of every part) live across the whole time loop and spills registers for it
@@ -403,7 +397,6 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
 #define BPQ(k) do {} while (0)
 #endif
   auto wait_phase = [&](long p) {     // all workgroups have finished phase instance p (p < 0: nothing to wait for)
-#ifndef ZEGGS_BP_NOWAIT
     if (p >= 0) {
 #ifdef ZEGGS_BPSTAT
       const unsigned long long w0 = wall_clock64();
@@ -413,13 +406,10 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       wsum[(p + 1) & 3] += wall_clock64() - w0;
 #endif
     }
-#endif
     __syncthreads();
   };
   auto arrive = [&](long p) {
-#ifndef ZEGGS_BP_NODRAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     __syncthreads();
     if (tid == 0) __hip_atomic_store((gu32*)(a.cnt + c), (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
@@ -622,9 +612,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       if (fail) break;
       BPT(13);
       float spv = 0.f;                                     // workgroup 0: dXa of the root / gaze columns (other owners)
-#ifndef ZEGGS_BP_NOSPV      /* timing experiment only */
       if (c == 0 && er >= 4 && bact && (s4 < 6 || (s4 >= 8 && s4 < 11))) spv = a.SP[((long)t * NSP + (s4 < 6 ? s4 : s4 - 2)) * 32 + eb];
-#endif
       bp_mma<3, NJ4, O4, false>(wr, nullptr, (const f4*)(a.OPD + (long)t * (H * 32L)) + lane, wave, 0, 64, acc);
       BPT(14);
       BPS0();
@@ -670,25 +658,15 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) dgd[q] = sp9[6 + q][eb];
             BPT(18);
-#ifndef ZEGGS_BP_NOROOT          /* timing experiment only: what the root-integration backward costs on the critical path */
             root_apply(d, rst + 6, pre, dgd, cr, g6);
-#endif
             BPT(19);
 #pragma unroll
             for (int q = 0; q < 7; ++q) crs[q][eb] = cr[q];
             const f4 v0 = f4{g6[0] * rst[9], g6[1] * rst[10], g6[2] * rst[11], g6[3] * rst[12]};
             const f4 e1 = ex[1][eb];                           // rows 6, 7 are ordinary pose columns
             const f4 v1 = f4{g6[4] * rst[13], g6[5] * rst[14], e1[2], e1[3]};
-#if defined(ZEGGS_BP_X3)        /* timing experiments only */
-            { float* o2 = a.OPY; float* d2 = a.DY + (long)eb * POL; stp4(o2 + op_idx(eb, 0), v0); stp4(o2 + op_idx(eb, 4), v1); *(f4*)d2 = v0; *(f4*)(d2 + 4) = v1; }
-#elif defined(ZEGGS_BP_X4)
-            stp4(opy + op_idx(eb, 0), v0); stp4(opy + op_idx(eb, 4), v1);
-#elif defined(ZEGGS_BP_X5)
-            if (v0[0] + v1[0] == 123.456f) stp4(opy + op_idx(eb, 0), v0);
-#else
             stp4(opy + op_idx(eb, 0), v0); stp4(opy + op_idx(eb, 4), v1);
             *(f4*)dyc = v0; *(f4*)(dyc + 4) = v1;
-#endif
           }
         }
       }
