@@ -556,7 +556,7 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
       float* gin1 = w.Gin + sG;
       ZTRY(gemm_nt(gin1 + H, GL, P->l0_w, XD, gin1, GL, P->l0_b, B, H, XD, ACT_ELU, 0.f, s));   // hid_1 = ELU(W0 x_1 + b0)
       ZTRY(dec_fast_merge_prep(d, P, st, w, s));
-      ZTRY(dec_tp_pack(d, P, w, s));
+      ZTRY(dec_tp_pack(d, P, st, w, s));
       dec_timing_mark(0, s);
       ZTRY(dec_tp_run(d, P, st, w, gaze, speech, style, pose, rpos, rrot, s));
       dec_timing_mark(1, s);

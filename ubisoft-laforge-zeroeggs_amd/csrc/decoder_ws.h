@@ -36,6 +36,7 @@ struct DecWs {
   // persistent training rollout (train_persistent.hip): per-workgroup fragment packs, write-once time-major operand
   // fragments [T][kb][NB][64][4] of the three phases, arrival counters + error word
   float *tp_w0, *tp_w1, *tp_w3, *G0xf, *G1xf, *G3xf;
+  float *tp_n0s, *tp_n0, *tp_cv0, *tp_p1x;   // fold of GRU layer 0's pose columns onto h1_{t-1} (train_persistent.hip)
   unsigned* tp_cnt;
   // persistent BPTT sweep (train_bwd_persistent.hip): per-workgroup weight tiles (register part, LDS part), write-once
   // time-major operands dy / [DI1 | dn_h1] / [DI0 | dn_h0] / D0 in the 4x4x1 B layout, dXa of the root / gaze columns,
@@ -130,6 +131,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
       const long KB0 = 64 + w.KBX + 64, KB3 = 64 + w.KBC;
       w.tp_w0 = a.f(256L * 8 * 26 * BLK); w.tp_w1 = a.f(256L * 8 * 16 * BLK); w.tp_w3 = a.f(256L * 8 * 9 * BLK);   // [wg][wave][block]
       w.G0xf = a.f(T * KB0 * XB); w.G1xf = a.f(T * 128 * XB); w.G3xf = a.f(T * KB3 * XB);
+      w.tp_n0s = a.f(3 * H * (long)w.POL); w.tp_n0 = a.f(3 * H * H); w.tp_cv0 = a.f(3 * H); w.tp_p1x = a.f(B * 3 * H);
       w.tp_cnt = (unsigned*)a.f(8192);      // arrival slots | error word (+1024) | stamps | wait statistics (+1536)
     }
     if (d.H == 1024 && d.B <= 32) {
@@ -156,7 +158,7 @@ int dec_persistent_errptr(const DecWs& w, unsigned** out);
 int dec_tp_supported(const ZeggsDecDims& d, const DecWs& w);
 int dec_tp_state();
 void dec_tp_set_state(int v);
-int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s);
+int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s);
 int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s);
 int dec_tp_errors(const DecWs& w, unsigned* out);

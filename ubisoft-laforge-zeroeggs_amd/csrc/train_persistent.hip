@@ -31,13 +31,21 @@ constexpr int TH = 1024, TTHR = 512, TNCU = 256, TSPIN = 1 << 21;
 // k-blocks of a wave per phase: first the OLD part of the operand (known one phase earlier: previous hidden state,
 // speech / style columns), then the FRESH part (produced by the preceding phase).  Block j of a part is k-block
 // lo + wave + 8 j: the parts are interleaved over the 8 waves so that every wave owns old work to do before the hand-off.
-constexpr int TNO0 = 9, TNF0 = 17, TNO1 = 8, TNF1 = 8, TNO3 = 1, TNF3 = 8;
+constexpr int TNO0 = 17, TNF0 = 9, TNO1 = 8, TNF1 = 8, TNO3 = 1, TNF3 = 8;
 constexpr int TJ0 = TNO0 + TNF0, TJ1 = TNO1 + TNF1, TJ3 = TNO3 + TNF3;
-// old blocks of GRU layer 0 done one window early / of GRU layer 1 done in layer 0's window (batch <= 32; the wider variants
-// have no registers to spare for a second live accumulator)
-constexpr int ts0(int nb) { return nb <= 2 ? 5 : 0; }
-constexpr int ts1(int nb) { return nb <= 2 ? 2 : 0; }
-constexpr int TFR0 = 135;     // GRU layer 0: k-blocks [0, 135) = hid_t and the pose / gaze columns of x_t are fresh
+// GRU layer 0 operand of a step, in k-blocks: [hid_t (64) | gaze direction of x_t (1) | speech / style of x_t (TKC, zero
+// padded) | h0_{t-1} (64) | h1_{t-1} (64)].  The POSE columns of x_t are not an operand: between the output stage of step t-1
+// and this product the reference only de-normalises / re-normalises them (modules.py:60-76), so
+//   W_ih0[:, pose] x_t[pose] = N0 h1_{t-1} + cv0,  N0 = W_ih0[:, pose] diag(sigma_o / sigma_i) W2  (re-derived per optimizer step),
+// which turns 71 blocks that had to wait for the output stage into 64 that are old by then.  (Step 1 takes x_1 from the given
+// first pose instead: its product comes from a small prologue GEMM and the h1 slot of that step stays zero.)
+// Only k-blocks [0, TFR0) are fresh; the old ones are ordered [cond | h0 | h1]: h0_{t-1} is two hand-offs old when the previous
+// output stage waits, h1_{t-1} one.
+constexpr int TKC = 8, TFR0 = 65, TKH0 = TFR0 + TKC, TKH1 = TKH0 + 64, TKB0 = TKH1 + 64;      // 65, 73, 137, 201
+// old blocks of GRU layer 0 done one window early (cond + h0_{t-1}: in front of the previous output stage) / of GRU layer 1 done
+// in layer 0's window (batch <= 32; the wider variants have no registers to spare for a second live accumulator)
+constexpr int ts0(int nb) { return nb <= 2 ? 9 : 0; }
+constexpr int ts1(int nb) { return 0 * nb; }
 // old-part k-blocks of GRU layer 0 parked in LDS instead of registers (as many as the LDS budget of the variant allows)
 constexpr int tl0(int nb) { return nb <= 2 ? 8 : nb == 3 ? 6 : 5; }
 __host__ __device__ inline int tp_kb(int i, int wave, int NO, int old_lo, int old_hi, int fresh_hi) {
@@ -55,6 +63,7 @@ struct TArgs {
   float *G0, *G1, *G3;                       // operand fragments, time-major [T][KB*][NB][64][4]
   float *Gin, *H0, *H1, *GT0, *GT1;          // canonical saves (time-major)
   const float *b_ih0, *b_hh0, *b_ih1, *b_hh1, *cvec, *l0_w, *l2_b;
+  const float *cv0, *p1x;                    // folded pose term of GRU layer 0: constant [3H], step-1 product [B][3H]
   const float* gaze;
   float *pose, *rpos, *rrot;
   unsigned *cnt, *err;
@@ -62,6 +71,12 @@ struct TArgs {
 
 __device__ __forceinline__ void stp(float* p, float v) {       // published: write-through
   __hip_atomic_store((gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 16 bytes, write-through: the four hidden units of this workgroup are four consecutive k of one batch row = one float4 of the
+// operand layout.  The "memory" clobber is required (results are corrupted without it) and makes the compiler drain the stores
+// it knows about first, so stp4 goes BEFORE the plain stores of an epilogue (train_bwd_persistent.hip).
+__device__ __forceinline__ void stp4(float* p, f4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ long xfi(int b, int k, int NB) {   // B-fragment position of (batch row, k)
   return ((((long)(k >> 4) * NB + (b >> 4)) * 64 + ((((k >> 2) & 3) << 4) | (b & 15))) << 2) | (k & 3);
@@ -163,6 +178,8 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   __shared__ f4 w0l[8 * TL0 * 64];            // the first TL0 (old-part) k-blocks of GRU layer 0: relieves the register file
   __shared__ float gsh[BP * 3];               // normalised gaze direction of x_{t+1} per batch row
   __shared__ float cA[4][12];                 // biases of the 4 units: b_ih0, b_hh0, b_ih1, b_hh1 (r, z, n)
+  __shared__ f4 ex[BP];                       // epilogue exchange: the 4 units of a batch row -> one 16-byte store
+  __shared__ float cV[4][3];                  // constant of the folded pose columns of GRU layer 0 (r, z, n), steps t > 1
   __shared__ float cB[16][8];                 // output-stage row constants
   __shared__ int fail;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = blockIdx.x;
@@ -190,6 +207,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     for (int g = 0; g < 3; ++g) {
       cA[tid][g] = a.b_ih0[g * H + U]; cA[tid][3 + g] = a.b_hh0[g * H + U];
       cA[tid][6 + g] = a.b_ih1[g * H + U]; cA[tid][9 + g] = a.b_hh1[g * H + U];
+      cV[tid][g] = a.cv0[g * H + U];
     }
     cB[tid][0] = a.cvec[U];
 #pragma unroll
@@ -215,6 +233,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   // in registers for the rollout
   int rb = TTHR - 1 - tid;
   bool ract = rb < B;
+  int tb = tid;                 // opaque per-step copy of the thread index for the store threads (one per batch row)
   Q4 rq_ = Q4{1.f, 0.f, 0.f, 0.f};
   V3 rp_ = v3(0.f, 0.f, 0.f);
   if (ract) {
@@ -265,8 +284,11 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   f4 acc1[NB], acc2[NB];        // accumulators of GRU layer 0 / 1: started in the windows of earlier phases
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) acc1[nb] = f4{0.f, 0.f, 0.f, 0.f};
-  tp_mma<NB, TJ0 - TL0, 0, TS0, true>(wr0, w0l + wave * TL0 * 64 + lane, (const f4*)(a.G0 + (long)a.KB0 * XB) + lane, TFR0 + wave,
-                                      a.KB0, acc1);     // step 1 has no previous output stage to hide these behind
+  if constexpr (SPREAD) {     // step 1 has no previous output stage to hide these behind
+    const f4* x01 = (const f4*)(a.G0 + (long)a.KB0 * XB) + lane;
+    tp_mma<NB, TJ0 - TL0, 0, TL0, true>(wr0, w0l + wave * TL0 * 64 + lane, x01, TFR0 + wave, a.KB0, acc1);
+    tp_mma<NB, TJ0 - TL0, 0, TS0 - TL0, false>(wr0, nullptr, x01, TFR0 + wave + 8 * TL0, a.KB0, acc1);
+  }
   for (int t = 1; t < T; ++t) {
     {
       int tx = tid;
@@ -276,6 +298,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       EU = 4 * c + (eu & 3);
       rb = TTHR - 1 - tx;
       ract = rb < B;
+      tb = tx;
     }
     const bool next = t + 1 < T;
     const long p1 = 3L * (t - 1), p2 = p1 + 1, p3 = p1 + 2;
@@ -287,14 +310,12 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     if constexpr (SPREAD) {
       const f4* x0 = (const f4*)(a.G0 + (long)t * a.KB0 * XB) + lane;
       const f4* x1 = (const f4*)(a.G1 + (long)t * 128 * XB) + lane;
-      // window: the rest of this phase's old part (its first TS0 blocks ran in the window of the previous output stage) ...
-      if constexpr (TL0 > TS0)
-        tp_mma<NB, TJ0 - TL0, TS0, TL0 - TS0, true>(wr0, w0l + wave * TL0 * 64 + lane, x0, TFR0 + wave + 8 * TS0, a.KB0, acc1);
-      tp_mma<NB, TJ0 - TL0, 0, TNO0 - TL0, false>(wr0, nullptr, x0, TFR0 + wave + 8 * TL0, a.KB0, acc1);
-      // ... and the first blocks of GRU layer 1's old part (h1_{t-1})
+      // window: the rest of this phase's old part, h1_{t-1} through the fold (cond and h0_{t-1} ran in the window of the previous
+      // output stage)
+      tp_mma<NB, TJ0 - TL0, TS0 - TL0, TNO0 - TS0, false>(wr0, nullptr, x0, TFR0 + wave + 8 * TS0, a.KB0, acc1);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc2[nb] = f4{0.f, 0.f, 0.f, 0.f};
-      tp_mma<NB, TJ1, 0, TS1, false>(wr1, nullptr, x1, 64 + wave, 128, acc2);
+      if constexpr (TS1 > 0) tp_mma<NB, TJ1, 0, TS1, false>(wr1, nullptr, x1, 64 + wave, 128, acc2);
       wait_phase(p1 - 1);
       if (fail) break;
       TPT(1);
@@ -316,17 +337,27 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     TPT(3);
     if (gact) {
       const float* k_ = cA[eu];
-      const float r = d_sigmoid(FV(4 * eu, eb) + k_[0] + k_[3]);
-      const float z = d_sigmoid(FV(4 * eu + 1, eb) + k_[1] + k_[4]);
+      // pose columns of x_t: N0 h1_{t-1} (in the products) + cv0; step 1: the product with the given first pose
+      float xr, xz, xn;
+      if (t == 1) { const float* q = a.p1x + (long)eb * 3 * H + EU; xr = q[0]; xz = q[H]; xn = q[2 * H]; }
+      else { xr = cV[eu][0]; xz = cV[eu][1]; xn = cV[eu][2]; }
+      const float r = d_sigmoid(FV(4 * eu, eb) + k_[0] + xr + k_[3]);
+      const float z = d_sigmoid(FV(4 * eu + 1, eb) + k_[1] + xz + k_[4]);
       const float nh = FV(4 * eu + 3, eb) + k_[5];
-      const float nn = tanhf(FV(4 * eu + 2, eb) + k_[2] + r * nh);
+      const float nn = tanhf(FV(4 * eu + 2, eb) + k_[2] + xn + r * nh);
       const float h = (1.f - z) * nn + z * hp0;
       hp0 = h;
       const long i = (long)t * sH + (long)eb * H + EU;
-      a.H0[i] = h;
       ((f4*)a.GT0)[i] = f4{r, z, nn, nh};
-      stp(a.G1 + (long)t * 128 * XB + xfi(eb, EU, NB), h);                                   // [h0_t | .] of layer 1
-      if (next) stp(a.G0 + (long)(t + 1) * a.KB0 * XB + (long)(64 + a.KBX) * XB + xfi(eb, EU, NB), h);   // [. | . | h0_t] of t+1
+      ((float*)&ex[eb])[eu] = h;
+    }
+    __syncthreads();
+    if (tb < B) {       // one thread per batch row publishes the workgroup's four units
+      const f4 v = ex[tb];
+      const long o = xfi(tb, 4 * c, NB);
+      stp4(a.G1 + (long)t * 128 * XB + o, v);                                                // [h0_t | .] of layer 1
+      if (next) stp4(a.G0 + (long)(t + 1) * a.KB0 * XB + (long)TKH0 * XB + o, v);            // h0 slot of layer 0, step t+1
+      *(f4*)(a.H0 + (long)t * sH + (long)tb * H + 4 * c) = v;
     }
     TPT(4);
     arrive(p1);
@@ -361,10 +392,19 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       const float h = (1.f - z) * nn + z * hp1;
       hp1 = h;
       const long i = (long)t * sH + (long)eb * H + EU;
-      a.H1[i] = h;
       ((f4*)a.GT1)[i] = f4{r, z, nn, nh};
-      stp(a.G3 + (long)t * a.KB3 * XB + xfi(eb, EU, NB), h);                                 // [h1_t | .] of the output stage
-      if (next) stp(a.G1 + (long)(t + 1) * 128 * XB + 64 * XB + xfi(eb, EU, NB), h);        // [. | h1_t] of t+1
+      ((float*)&ex[eb])[eu] = h;
+    }
+    __syncthreads();
+    if (tb < B) {
+      const f4 v = ex[tb];
+      const long o = xfi(tb, 4 * c, NB);
+      stp4(a.G3 + (long)t * a.KB3 * XB + o, v);                                              // [h1_t | .] of the output stage
+      if (next) {
+        stp4(a.G1 + (long)(t + 1) * 128 * XB + 64 * XB + o, v);                              // [. | h1_t] of t+1
+        stp4(a.G0 + (long)(t + 1) * a.KB0 * XB + (long)TKH1 * XB + o, v);                    // h1 slot of layer 0, step t+1 (fold)
+      }
+      *(f4*)(a.H1 + (long)t * sH + (long)tb * H + 4 * c) = v;
     }
     TPT(9);
     arrive(p2);
@@ -380,9 +420,12 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       tp_mma<NB, TJ0 - TL0, 0, TNO3, true>(wr0, wl3, x3, 64 + wave, a.KB3, acc);          // cond_{t+1}: before the hand-off
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc1[nb] = f4{0.f, 0.f, 0.f, 0.f};
-      if (SPREAD && next) {     // window: the first TS0 old blocks of the NEXT step's GRU layer 0 (h0_t, published two hand-offs ago)
-        const f4* x0n = (const f4*)(a.G0 + (long)(t + 1) * a.KB0 * XB) + lane;
-        tp_mma<NB, TJ0 - TL0, 0, TS0, true>(wr0, w0l + wave * TL0 * 64 + lane, x0n, TFR0 + wave, a.KB0, acc1);
+      if constexpr (SPREAD) {
+        if (next) {     // window: cond and h0_t blocks of the NEXT step's GRU layer 0 (h0_t was published two hand-offs ago)
+          const f4* x0n = (const f4*)(a.G0 + (long)(t + 1) * a.KB0 * XB) + lane;
+          tp_mma<NB, TJ0 - TL0, 0, TL0, true>(wr0, w0l + wave * TL0 * 64 + lane, x0n, TFR0 + wave, a.KB0, acc1);
+          tp_mma<NB, TJ0 - TL0, 0, TS0 - TL0, false>(wr0, nullptr, x0n, TFR0 + wave + 8 * TL0, a.KB0, acc1);
+        }
       }
       wait_phase(p3 - 1);
       if (fail) break;
@@ -422,7 +465,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
           if (next)
             for (int k = 0; k < 3; ++k) {
               gnext[(long)b * GL + H + PO + k] = genc[k];
-              stp(xnext + 64 * XB + xfi(b, PO + k, NB), genc[k]);
+              stp(xnext + 64 * XB + xfi(b, k, NB), genc[k]);                 // the gaze block of layer 0's operand
             }
         }
       }
@@ -435,8 +478,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
           a.pose[((long)b * T + t) * PO + col] = pv;
           if (next) {
             const float e = (pv - k_[3]) / k_[4];
-            gnext[(long)b * GL + H + col] = e;
-            stp(xnext + 64 * XB + xfi(b, col, NB), e);
+            gnext[(long)b * GL + H + col] = e;        // (canonical only: the products take the pose columns through the fold)
           }
         }
       }
@@ -446,8 +488,14 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
         const float* k_ = cB[vc];
         const int col = 4 * c + vc;
         const float val = d_elu(FV(vc, b) + k_[0] + k_[1] * gsh[b * 3] + k_[2] * gsh[b * 3 + 1] + k_[3] * gsh[b * 3 + 2]);
-        gnext[(long)b * GL + col] = val;
-        stp(xnext + xfi(b, col, NB), val);
+        ((float*)&ex[b])[vc] = val;
+        (void)col;
+      }
+      __syncthreads();
+      if (next && tb < B) {
+        const f4 v = ex[tb];
+        stp4(xnext + xfi(tb, 4 * c, NB), v);
+        *(f4*)(gnext + (long)tb * GL + 4 * c) = v;
       }
     }
     TPT(14);
@@ -466,7 +514,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
 // value of virtual row i, contraction index k of workgroup c's tile for phase ph (0: GRU l0, 1: GRU l1, 3: output stage)
 struct TPackArgs {
   f4 *PW0, *PW1, *PW3;
-  const float *w_ih0, *w_hh0, *w_ih1, *w_hh1, *l2_w, *l0_w, *Mc;
+  const float *w_ih0, *w_hh0, *w_ih1, *w_hh1, *l2_w, *l0_w, *Mc, *n0;
   int XD, KBX, KBC, KB0, KB3, PO, PI, NC;
 };
 __device__ __forceinline__ float tp_value(const TPackArgs& p, int ph, int c, int i, int k) {
@@ -477,9 +525,10 @@ __device__ __forceinline__ float tp_value(const TPackArgs& p, int ph, int c, int
     if (ph == 0) {
       const int KIN = H + p.XD;
       if (k < H) return g == 3 ? 0.f : p.w_ih0[row * KIN + k];                                // hid
-      if (k < H + 16 * p.KBX) { const int kx = k - H; return (g == 3 || kx >= p.XD) ? 0.f : p.w_ih0[row * KIN + H + kx]; }
-      const int kh = k - H - 16 * p.KBX;
-      return g == 2 ? 0.f : p.w_hh0[row * H + kh];
+      if (k < 16 * TFR0) { const int j = k - H; return (g == 3 || j >= 3) ? 0.f : p.w_ih0[row * KIN + H + p.PO + j]; }   // gaze
+      if (k < 16 * TKH0) { const int j = k - 16 * TFR0; return (g == 3 || j >= p.NC) ? 0.f : p.w_ih0[row * KIN + H + p.PI + j]; }
+      if (k < 16 * TKH1) return g == 2 ? 0.f : p.w_hh0[row * H + (k - 16 * TKH0)];           // h0_{t-1}
+      return g == 3 ? 0.f : p.n0[row * H + (k - 16 * TKH1)];                                  // h1_{t-1} through the fold
     }
     if (k < H) return g == 3 ? 0.f : p.w_ih1[row * H + k];
     return g == 2 ? 0.f : p.w_hh1[row * H + (k - H)];
@@ -535,26 +584,46 @@ __global__ void tp_cond_k(ZeggsDecDims d, const float* speech, const float* styl
     const long r = i / XC;
     const int b = (int)(r % d.B), t = 1 + (int)(r / d.B);
     const float v = cc < d.SP ? speech[((long)b * d.T + t) * d.SP + cc] : style[((long)b * d.T + t) * d.ST + (cc - d.SP)];
-    G0[(long)t * KB0 * XB + 64 * XB + xfi(b, d.PI + cc, NB)] = v;
+    G0[(long)t * KB0 * XB + (long)TFR0 * XB + xfi(b, cc, NB)] = v;
     if (t >= 2) G3[(long)(t - 1) * KB3 * XB + 64 * XB + xfi(b, cc, NB)] = v;
+  }
+}
+
+// S[r][c] = W[r * ld + c] * sigma_o[c] / sigma_i[c]  (c < PO; zero padded to POL columns): the pose columns of W_ih0, rescaled from
+// normalised-input to raw-output units
+__global__ void tp_scale_cols_k(float* S, const float* W, long ld, ZeggsDecStats st, int rows, int PO, int POL) {
+  const long n = (long)rows * POL;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % POL);
+    const long r = i / POL;
+    S[i] = c < PO ? W[r * ld + c] * (st.out_std[c] / st.in_std[c]) : 0.f;
   }
 }
 
 }  // namespace
 
 int dec_tp_supported(const ZeggsDecDims& d, const DecWs& w) {
-  const int KB0 = 64 + w.KBX + 64;
-  return !d.film && d.H == TH && d.B <= 64 && d.T >= 4 && d.PI == d.PO + 3 && 64 + (d.PI + 15) / 16 == TFR0 &&
-         KB0 > TFR0 && KB0 - TFR0 <= 8 * TNO0 && w.KBC >= 1 && w.KBC <= 8 * TNO3 && d.PO <= 5 * TNCU && d.PO >= 16 &&
-         w.G0xf != nullptr;
+  return !d.film && d.H == TH && d.B <= 64 && d.T >= 4 && d.PI == d.PO + 3 && d.SP + d.ST <= 16 * TKC && w.KBC >= 1 &&
+         w.KBC <= 8 * TNO3 && d.PO <= 5 * TNCU && d.PO >= 16 && w.G0xf != nullptr;
 }
 int dec_tp_state() { return g_tp_ok; }
 void dec_tp_set_state(int v) { g_tp_ok = v; }
 
 // once per optimizer step: the per-workgroup fragment packs (needs Mc / cvec: dec_fast_merge_prep)
-int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s) {
-  TPackArgs p{(f4*)w.tp_w0, (f4*)w.tp_w1, (f4*)w.tp_w3, P->w_ih0, P->w_hh0, P->w_ih1, P->w_hh1, P->l2_w, P->l0_w, w.Mc,
-              w.XD, w.KBX, w.KBC, 64 + w.KBX + 64, 64 + w.KBC, d.PO, d.PI, d.SP + d.ST};
+int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s) {
+  const int H = d.H, KIN = H + w.XD;
+  // the fold of GRU layer 0's pose columns: N0 = W_ih0[:, pose] diag(sigma_o/sigma_i) W2 [3H, H], cv0 = W_ih0[:, pose] v [3H]
+  // (v = (b2 sigma_o + mu_o - mu_i) / sigma_i: dec_fast_merge_prep)
+  {
+    const long n = 3L * H * w.POL;
+    hipLaunchKernelGGL(tp_scale_cols_k, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, w.tp_n0s,
+                       P->w_ih0 + H, (long)KIN, *st, 3 * H, d.PO, w.POL);
+    ZLAUNCH_CHECK("tp_scale_cols");
+    ZTRY(gemm_nn(w.tp_n0s, w.POL, P->l2_w, H, w.tp_n0, H, 3 * H, d.PO, H, 0.f, s));
+    ZTRY(gemm_nt(w.vvec, w.POL, P->w_ih0 + H, KIN, w.tp_cv0, 3 * H, nullptr, 1, 3 * H, d.PO, ACT_NONE, 0.f, s));
+  }
+  TPackArgs p{(f4*)w.tp_w0, (f4*)w.tp_w1, (f4*)w.tp_w3, P->w_ih0, P->w_hh0, P->w_ih1, P->w_hh1, P->l2_w, P->l0_w, w.Mc, w.tp_n0,
+              w.XD, w.KBX, w.KBC, TKB0, 64 + w.KBC, d.PO, d.PI, d.SP + d.ST};
   hipLaunchKernelGGL(tp_pack_k, dim3(8192), dim3(256), 0, s, p);
   ZLAUNCH_CHECK("tp_pack");
   return 0;
@@ -563,7 +632,7 @@ int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStr
 // the rollout; H0 / H1 slot 0, Gin slot 1 (hid_1 | x_1) and frame 0 of pose / rpos / rrot are prepared by the caller
 int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s) {
-  const int B = d.B, H = d.H, NB = w.NB, KB0 = 64 + w.KBX + 64, KB3 = 64 + w.KBC;
+  const int B = d.B, H = d.H, NB = w.NB, KB0 = TKB0, KB3 = 64 + w.KBC;
   const long XB = 256L * NB, sG = (long)B * w.GL;
   int dev = 0, ncu = 0;
   ZCHECK(hipGetDevice(&dev) == hipSuccess, "hipGetDevice failed");
@@ -581,9 +650,11 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   };
   const float* gin1 = w.Gin + sG;
   conv(w.G0xf + (long)KB0 * XB, gin1, w.GL, 0, H, 0);                         // hid_1
-  conv(w.G0xf + (long)KB0 * XB, gin1, w.GL, H, d.PI, 16 * 64);                // pose / gaze columns of x_1
-  conv(w.G0xf + (long)KB0 * XB, w.H0, H, 0, H, 16 * (64 + w.KBX));            // h0_0
-  conv(w.G1xf + 128 * XB, w.H1, H, 0, H, 16 * 64);                            // h1_0
+  conv(w.G0xf + (long)KB0 * XB, gin1, w.GL, H + d.PO, 3, 16 * 64);            // gaze direction of x_1
+  conv(w.G0xf + (long)KB0 * XB, w.H0, H, 0, H, 16 * TKH0);                    // h0_0 (the h1 slot of step 1 stays zero:
+  conv(w.G1xf + 128 * XB, w.H1, H, 0, H, 16 * 64);                            // h1_0  its pose columns are the given first pose)
+  // ... whose product with W_ih0 is one small GEMM: p1x[b][3H] = x_1[b][pose] W_ih0[:, pose]^T
+  ZTRY(gemm_nt(gin1 + H, w.GL, P->w_ih0 + H, H + w.XD, w.tp_p1x, 3 * H, nullptr, B, 3 * H, d.PO, ACT_NONE, 0.f, s));
   ZLAUNCH_CHECK("tp_prologue");
   TArgs a;
   memset(&a, 0, sizeof(a));
@@ -592,7 +663,7 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   a.G0 = w.G0xf; a.G1 = w.G1xf; a.G3 = w.G3xf;
   a.Gin = w.Gin; a.H0 = w.H0; a.H1 = w.H1; a.GT0 = w.GT0; a.GT1 = w.GT1;
   a.b_ih0 = P->b_ih0; a.b_hh0 = P->b_hh0; a.b_ih1 = P->b_ih1; a.b_hh1 = P->b_hh1; a.cvec = w.cvec; a.l0_w = P->l0_w;
-  a.l2_b = P->l2_b; a.gaze = gaze; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
+  a.l2_b = P->l2_b; a.cv0 = w.tp_cv0; a.p1x = w.tp_p1x; a.gaze = gaze; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
   a.cnt = w.tp_cnt; a.err = w.tp_cnt + TRING * TSH * TSTR;
   switch (NB) {
     case 1: hipLaunchKernelGGL((train_fwd_persistent_k<1>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
