@@ -95,6 +95,7 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
   __shared__ float rs[16];
   __shared__ float rootst[12];            // rrot(4) rpos(3) genc(3)
   __shared__ float cst[16][16];
+  __shared__ float cg[6];                 // gaze columns of x: in_mean[PO..PO+2], 1 / in_std[PO..PO+2]
   __shared__ int fail;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = blockIdx.x;
   const ZeggsDecDims& d = a.d;
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
   if (tid < 4) rootst[tid] = a.rrot[tid];
   if (tid >= 4 && tid < 7) rootst[tid] = a.rpos[tid - 4];
   if (tid == 0) fail = 0;
+  if (tid >= 32 && tid < 38) cg[tid - 32] = tid < 35 ? a.st.in_mean[PO + tid - 32] : 1.f / a.st.in_std[PO + tid - 35];
   __syncthreads();
   for (int i = tid; i < KIN; i += PTHR) xcat[i] = a.gin1[i];     // [hid_1 | x_1]
   bool bad = false;
@@ -275,9 +277,9 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
         nq = quat_mul(quat_exp(0.5f * uu), q);
         if (next) {
           const V3 gd = quat_mul_vec(quat_inv(nq), v3(rt[7], rt[8], rt[9]) - npos);
-          genc[0] = (gd.x - a.st.in_mean[PO]) / a.st.in_std[PO];
-          genc[1] = (gd.y - a.st.in_mean[PO + 1]) / a.st.in_std[PO + 1];
-          genc[2] = (gd.z - a.st.in_mean[PO + 2]) / a.st.in_std[PO + 2];
+          genc[0] = (gd.x - cg[0]) * cg[3];
+          genc[1] = (gd.y - cg[1]) * cg[4];
+          genc[2] = (gd.z - cg[2]) * cg[5];
         }
       }
       rootst[0] = nq.w; rootst[1] = nq.x; rootst[2] = nq.y; rootst[3] = nq.z;

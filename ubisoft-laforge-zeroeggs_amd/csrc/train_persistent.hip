@@ -179,6 +179,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   __shared__ float gsh[BP * 3];               // normalised gaze direction of x_{t+1} per batch row
   __shared__ float cA[4][12];                 // biases of the 4 units: b_ih0, b_hh0, b_ih1, b_hh1 (r, z, n)
   __shared__ f4 ex[BP];                       // epilogue exchange: the 4 units of a batch row -> one 16-byte store
+  __shared__ float cG[6];                     // gaze columns of x: in_mean[PO..PO+2], 1 / in_std[PO..PO+2]
   __shared__ float cV[4][3];                  // constant of the folded pose columns of GRU layer 0 (r, z, n), steps t > 1
   __shared__ float cB[16][8];                 // output-stage row constants
   __shared__ int fail;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   } else if (tid < 15) {
     cB[tid][0] = a.l2_b[tid - 9]; cB[tid][1] = a.st.out_std[tid - 9]; cB[tid][2] = a.st.out_mean[tid - 9];
   }
+  if (tid >= 32 && tid < 38) cG[tid - 32] = tid < 35 ? a.st.in_mean[PO + tid - 32] : 1.f / a.st.in_std[PO + tid - 35];
   if (tid == 0) fail = 0;
   // GRU epilogue item of this thread: unit eu, batch row eb; the previous hidden values stay in registers for the rollout
   // (re-derived from an opaque copy of the thread index at the top of every step: the per-thread addresses they feed are not
@@ -452,9 +454,9 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
         float genc[3] = {0.f, 0.f, 0.f};
         if (next) {
           const V3 gd = quat_mul_vec(quat_inv(nq), v3(gz_[0], gz_[1], gz_[2]) - npos);
-          genc[0] = (gd.x - a.st.in_mean[PO]) / a.st.in_std[PO];
-          genc[1] = (gd.y - a.st.in_mean[PO + 1]) / a.st.in_std[PO + 1];
-          genc[2] = (gd.z - a.st.in_mean[PO + 2]) / a.st.in_std[PO + 2];
+          genc[0] = (gd.x - cG[0]) * cG[3];
+          genc[1] = (gd.y - cG[1]) * cG[4];
+          genc[2] = (gd.z - cG[2]) * cG[5];
         }
         gsh[b * 3] = genc[0]; gsh[b * 3 + 1] = genc[1]; gsh[b * 3 + 2] = genc[2];
         if (c == 0) {
