@@ -186,6 +186,25 @@ __global__ __launch_bounds__(256) void colsum_k(float* out, const float* x, long
   if (ph == 0 && c < C) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
+// the same with 16-byte loads: a block covers 256 columns (64 lanes x float4) x 4 row phases
+__global__ __launch_bounds__(256) void colsum4_k(float* out, const float* x, long R, int C, long ld, long rows_per_block) {
+  __shared__ f4 red[4][64];
+  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cl) * 4;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > R) r1 = R;
+  f4 s = f4{0.f, 0.f, 0.f, 0.f};
+  if (c < C)
+    for (long r = r0 + ph; r < r1; r += 4) s += *(const f4*)(x + r * ld + c);
+  red[ph][cl] = s;
+  __syncthreads();
+  if (ph == 0 && c < C) {
+    const f4 t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    atomicAdd(out + c, t[0]); atomicAdd(out + c + 1, t[1]); atomicAdd(out + c + 2, t[2]); atomicAdd(out + c + 3, t[3]);
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_v_k(float* out, RowView x, long R, int C, long rows_per_block) {
   __shared__ float red[4][64];
   int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
@@ -385,8 +404,14 @@ int k_colsum(float* out, const float* x, long R, int C, long ld, float beta, hip
   if (beta == 0.f) { ZTRY(k_fill(out, C, 0.f, s)); }
   else if (beta != 1.f) { L1D(scale_k, (long)C, s, out, (long)C, beta); }
   long rpb = 256;
-  dim3 grid(cdiv(C, 64), cdiv(R, rpb));
-  hipLaunchKernelGGL(colsum_k, grid, dim3(256), 0, s, out, x, R, C, ld, rpb);
+  if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && C >= 256) {
+    rpb = 128;        // 4x fewer column blocks: keep the grid large
+    dim3 grid(cdiv(C, 256), cdiv(R, rpb));
+    hipLaunchKernelGGL(colsum4_k, grid, dim3(256), 0, s, out, x, R, C, ld, rpb);
+  } else {
+    dim3 grid(cdiv(C, 64), cdiv(R, rpb));
+    hipLaunchKernelGGL(colsum_k, grid, dim3(256), 0, s, out, x, R, C, ld, rpb);
+  }
   ZLAUNCH_CHECK("colsum");
   return 0;
 }

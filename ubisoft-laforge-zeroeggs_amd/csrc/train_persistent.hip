@@ -568,6 +568,13 @@ __global__ void tp_pack_k(TPackArgs p) {
   }
 }
 
+// zero k-blocks [kb0, kb0 + nkb) of every step of a time-major operand buffer (the blocks that hold pad columns: everything
+// else is written by the rollout or its prologue before it is read, and pad BATCH rows only ever feed pad batch columns)
+__global__ void tp_zero_blocks_k(float* G, long KB, long XB, int kb0, int nkb, int t0, int t1) {
+  const long per = (long)nkb * XB, n = (long)(t1 - t0) * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    G[((long)t0 + i / per) * KB * XB + (long)kb0 * XB + i % per] = 0.f;
+}
 // canonical [B, ld] (columns off .. off+K) -> fragments at k offset kofs of an operand buffer
 __global__ void tp_xfrag_k(float* xf, const float* src, long ld, int off, int K, int B, int NB, int kofs) {
   long n = (long)B * K;
@@ -641,9 +648,10 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   ZCHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess, "device query failed");
   ZCHECK(ncu >= TNCU, "persistent training rollout needs %d CUs (device has %d)", TNCU, ncu);
   // operand buffers: zero (pad rows / pad columns must be finite), then the inputs that do not depend on the rollout
-  ZTRY(k_fill(w.G0xf, (long)d.T * KB0 * XB, 0.f, s));
-  ZTRY(k_fill(w.G1xf, (long)d.T * 128 * XB, 0.f, s));
-  ZTRY(k_fill(w.G3xf, (long)d.T * KB3 * XB, 0.f, s));
+  // (only the blocks with pad columns: the gaze + speech / style blocks of G0, the cond blocks of G3, the h1 slot of step 1)
+  hipLaunchKernelGGL(tp_zero_blocks_k, dim3(1024), dim3(256), 0, s, w.G0xf, (long)KB0, XB, 64, 1 + TKC, 1, d.T);
+  hipLaunchKernelGGL(tp_zero_blocks_k, dim3(256), dim3(256), 0, s, w.G0xf, (long)KB0, XB, TKH1, 64, 1, 2);
+  hipLaunchKernelGGL(tp_zero_blocks_k, dim3(1024), dim3(256), 0, s, w.G3xf, (long)KB3, XB, 64, KB3 - 64, 1, d.T);
   ZTRY(k_fill((float*)w.tp_cnt, 2048, 0.f, s));
   hipLaunchKernelGGL(tp_cond_k, dim3(1024), dim3(256), 0, s, d, speech, style, w.G0xf, w.G3xf, KB0, KB3, NB);
   auto conv = [&](float* xf, const float* src, long ld, int off, int K, int kofs) {
