@@ -2,7 +2,7 @@
 // as ONE launch -- the backward mirror of train_persistent.hip.
 //
 // Why a different tile shape than the forward kernel.  The transposed products of a step (W_ih1^T, W_hh1^T, W_ih0^T, W_hh0^T,
-// W0^T, W2^T: 80 MB) give every one of the 256 workgroups 4 + 4 + 4 + 5 + 4 output rows; with the 16-row tiles of
+// W0^T, W2^T: 80 MB) give every one of the 256 workgroups 4 + 4 + 4 + 8 + 4 output rows; with the 16-row tiles of
 // v_mfma_f32_16x16x4_f32 the padded fragments (530-650 KB per CU) do not fit the 512 KB register file + 160 KB LDS of a CU.
 // v_mfma_f32_4x4x1_16b_f32 has 4-row tiles: with cbsz = 3 the 16 blocks of the instruction are 8 batch groups x 2 k-halves
 // that share the A values of block `abid`, i.e. ONE VGPR holds a [4 rows x 16 k] weight tile with no padding and eight
@@ -23,7 +23,7 @@
 //                                             (devectorize / vectorize backward; the 9 root / gaze columns belong to
 //                                             workgroup 0, whose first 32 threads carry the root-integration adjoint)
 // Workgroup c owns hidden units 4c..4c+3 of both layers (the carries never leave its registers), rows 4c..4c+3 of dhid and
-// rows 5c..5c+4 of dx.  Operands travel through WRITE-ONCE time-major buffers in the B layout of the instruction
+// rows 8c..8c+7 of dx (c < 158: two aligned groups of four = one 16-byte store each).  Operands travel through WRITE-ONCE time-major buffers in the B layout of the instruction
 // ([k-block][2][64 lanes][4]: lane = 32 * k-half + batch row), published with write-through stores; the canonical copies
 // (DI1, DH1, DI0, DH0, D0, DY, DX) are written where the stage kernels write them, so the weight-gradient GEMMs and the
 // CellStateEncoder backward are unchanged.  Every wait is bounded; on give-up the error word is set.

@@ -1,4 +1,4 @@
-// Weight-stationary persistent FORWARD rollout of the training step (batch <= 32): the 255 decoder steps of a window as
+// Weight-stationary persistent FORWARD rollout of the training step (batch <= 64): the 255 decoder steps of a window as
 // ONE launch.  Same idea as decode_persistent.hip -- the 75.7 MB of per-step weights fit in the register files of the
 // 256 CUs, so nothing is re-streamed per step -- but with batch 32 the products are MFMA tiles and the exchanged vectors
 // are 128 KB, so the details differ:
@@ -10,9 +10,12 @@
 //   * the 8 waves split the contraction; a wave keeps its k-blocks of the two GRU tiles in registers (26 + 16 float4 in
 //     MFMA A-fragment order, packed once per optimizer step by tp_pack_k) and of the output tile in LDS;
 //   * activations travel in B-fragment order through WRITE-ONCE, time-major operand buffers (one contiguous operand per
-//     phase and step: [hid_t | x_t | h0_{t-1}], [h0_t | h1_{t-1}], [h1_t | cond_{t+1}]), published with write-through
-//     stores; because no address is ever rewritten inside a rollout, a consumer needs no cache invalidation: it waits on
-//     the producers' arrival counter (sharded, monotonic) and then simply loads lines nobody has cached yet;
+//     phase and step: [hid_t | gaze, speech, style of x_t | h0_{t-1} | h1_{t-1}] -- the pose columns of x_t are folded onto
+//     h1_{t-1}, see TKC below --, [h0_t | h1_{t-1}], [h1_t | cond_{t+1}]), published with 16-byte write-through stores;
+//     because no address is ever rewritten inside a rollout, a consumer needs no cache invalidation: it waits until every
+//     workgroup's arrival slot has reached the phase and then simply loads lines nobody has cached yet;
+//   * the part of every contraction that does not depend on the preceding phase runs in the window BEFORE the hand-off
+//     wait (batch <= 32: spread evenly over the three windows of a step), which hides most of the hand-off latency;
 //   * canonical copies (Gin, H0, H1, saved gates, pose / root outputs) are written exactly where the stage kernels write
 //     them, so the BPTT sweep and the weight-gradient GEMMs are unchanged.
 // Every wait is bounded; on give-up the error word is set and the host redoes the rollout with the stage kernels.
