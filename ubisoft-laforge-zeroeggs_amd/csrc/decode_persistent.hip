@@ -175,16 +175,21 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
   bool bad = false;
 
   for (int t = 1; t < T; ++t) {
+    // opaque per-frame copy of the thread index: left alone, the optimiser hoists the per-thread granule / output addresses out
+    // of the frame loop and spills them; their reloads (scratch + s_waitcnt vmcnt(0)) then sit right in front of the publishing
+    // stores, on the critical path of every exchange
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
     const bool next = t + 1 < T;
     // ================================================================ GRU layer 0: operands [hid_t | x_t | h0_{t-1}]
     if (t > 1) {
       if (!gather<2>(a.g_hid, wave * 128, wave * 128 + 128, (unsigned)t, xcat)) bad = true;
       const int per = (PO + 7) / 8;
       if (!gather<3>(a.g_xp, wave * per, min(PO, wave * per + per), (unsigned)t, xcat + H)) bad = true;
-      if (tid < 3) xcat[H + PO + tid] = rootst[7 + tid];                       // gaze direction of x_t (local)
-      if (tid >= 64 && tid < 64 + NC) xcat[H + PI + (tid - 64)] = cond[tid - 64];   // speech / style of frame t
+      if (tq < 3) xcat[H + PO + tq] = rootst[7 + tq];                       // gaze direction of x_t (local)
+      if (tq >= 64 && tq < 64 + NC) xcat[H + PI + (tq - 64)] = cond[tq - 64];   // speech / style of frame t
     }
-    for (int i = tid; i < H; i += PTHR) xcat[KIN + i] = h0s[i];
+    for (int i = tq; i < H; i += PTHR) xcat[KIN + i] = h0s[i];
     if (bad) fail = 1;
     __syncthreads();
     if (fail) break;
@@ -204,20 +209,20 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
       if (lane == 0) { part[wave][0] = sr; part[wave][1] = sz; part[wave][2] = sni; part[wave][3] = snh; }
     }
     __syncthreads();
-    if (tid < 4) {
-      const int Uu = 4 * c + tid;
-      const float* k_ = cst[tid];
-      const float r = d_sigmoid(part[2 * tid][0] + part[2 * tid + 1][0] + k_[0] + k_[3]);
-      const float z = d_sigmoid(part[2 * tid][1] + part[2 * tid + 1][1] + k_[1] + k_[4]);
-      const float nh = part[2 * tid][3] + part[2 * tid + 1][3] + k_[5];
-      const float nn = tanhf(part[2 * tid][2] + part[2 * tid + 1][2] + k_[2] + r * nh);
+    if (tq < 4) {
+      const int Uu = 4 * c + tq;
+      const float* k_ = cst[tq];
+      const float r = d_sigmoid(part[2 * tq][0] + part[2 * tq + 1][0] + k_[0] + k_[3]);
+      const float z = d_sigmoid(part[2 * tq][1] + part[2 * tq + 1][1] + k_[1] + k_[4]);
+      const float nh = part[2 * tq][3] + part[2 * tq + 1][3] + k_[5];
+      const float nn = tanhf(part[2 * tq][2] + part[2 * tq + 1][2] + k_[2] + r * nh);
       publish(a.g_h0 + Uu, (unsigned)t, (1.f - z) * nn + z * h0s[Uu]);
     }
     __syncthreads();      // the old h0 has been read everywhere before the sweep overwrites it
     // ================================================================ GRU layer 1: operands [h0_t | h1_{t-1}]
     if (!gather<2>(a.g_h0, wave * 128, wave * 128 + 128, (unsigned)t, h0s)) fail = 1;
-    if (next && tid < NC)      // speech / style columns of frame t+1 (inputs), staged while the sweep is in flight
-      cond[tid] = tid < d.SP ? a.speech[(long)(t + 1) * d.SP + tid] : a.style[(long)(t + 1) * d.ST + (tid - d.SP)];
+    if (next && tq < NC)      // speech / style columns of frame t+1 (inputs), staged while the sweep is in flight
+      cond[tq] = tq < d.SP ? a.speech[(long)(t + 1) * d.SP + tq] : a.style[(long)(t + 1) * d.ST + (tq - d.SP)];
     __syncthreads();
     if (fail) break;
     {
@@ -234,13 +239,13 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
       if (lane == 0) { part[wave][0] = sr; part[wave][1] = sz; part[wave][2] = sni; part[wave][3] = snh; }
     }
     __syncthreads();
-    if (tid < 4) {
-      const int Uu = 4 * c + tid;
-      const float* k_ = cst[tid];
-      const float r = d_sigmoid(part[2 * tid][0] + part[2 * tid + 1][0] + k_[6] + k_[9]);
-      const float z = d_sigmoid(part[2 * tid][1] + part[2 * tid + 1][1] + k_[7] + k_[10]);
-      const float nh = part[2 * tid][3] + part[2 * tid + 1][3] + k_[11];
-      const float nn = tanhf(part[2 * tid][2] + part[2 * tid + 1][2] + k_[8] + r * nh);
+    if (tq < 4) {
+      const int Uu = 4 * c + tq;
+      const float* k_ = cst[tq];
+      const float r = d_sigmoid(part[2 * tq][0] + part[2 * tq + 1][0] + k_[6] + k_[9]);
+      const float z = d_sigmoid(part[2 * tq][1] + part[2 * tq + 1][1] + k_[7] + k_[10]);
+      const float nh = part[2 * tq][3] + part[2 * tq + 1][3] + k_[11];
+      const float nn = tanhf(part[2 * tq][2] + part[2 * tq + 1][2] + k_[8] + r * nh);
       publish(a.g_h1 + Uu, (unsigned)t, (1.f - z) * nn + z * h1s[Uu]);
     }
     __syncthreads();
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
       if (lane == 0) { rs[2 * wave] = s0; rs[2 * wave + 1] = s1; }
     }
     __syncthreads();
-    if (tid == 0) {       // root integration (ZEGGS/modules.py:139-176), evaluated in every workgroup
+    if (tq == 0) {       // root integration (ZEGGS/modules.py:139-176), evaluated in every workgroup
       float p[6], rt[10], genc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 6; ++q) p[q] = (rs[9 + q] + cst[9 + q][0]) * cst[9 + q][1] + cst[9 + q][2];
@@ -289,17 +294,18 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
         float* op = a.rpos + (long)t * 3; op[0] = npos.x; op[1] = npos.y; op[2] = npos.z;
         float* oq = a.rrot + (long)t * 4; oq[0] = nq.w; oq[1] = nq.x; oq[2] = nq.y; oq[3] = nq.z;
       }
-    } else if (tid >= 4 && tid < 9 && cst[tid][5] != 0.f) {
-      const float* k_ = cst[tid];
-      const int ocol = c + PNCU * (tid - 4);
-      const float pv = (rs[tid] + k_[0]) * k_[1] + k_[2];
+    } else if (tq >= 64 && tq < 69 && cst[tq - 60][5] != 0.f) {      // (second wave: not behind the root thread's branch)
+      const int r = tq - 60;
+      const float* k_ = cst[r];
+      const int ocol = c + PNCU * (r - 4);
+      const float pv = (rs[r] + k_[0]) * k_[1] + k_[2];
       a.pose[(long)t * PO + ocol] = pv;
       if (next) publish(a.g_xp + ocol, (unsigned)(t + 1), (pv - k_[3]) / k_[4]);
     }
     __syncthreads();      // gaze direction of x_{t+1}
-    if (next && tid < 4)
-      publish(a.g_hid + 4 * c + tid, (unsigned)(t + 1),
-              d_elu(rs[tid] + cst[tid][12] + cst[tid][13] * rootst[7] + cst[tid][14] * rootst[8] + cst[tid][15] * rootst[9]));
+    if (next && tq < 4)
+      publish(a.g_hid + 4 * c + tq, (unsigned)(t + 1),
+              d_elu(rs[tq] + cst[tq][12] + cst[tq][13] * rootst[7] + cst[tq][14] * rootst[8] + cst[tq][15] * rootst[9]));
   }
   if (fail) {
     if (tid == 0) atomicOr(a.err, 1u);
