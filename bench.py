@@ -317,6 +317,8 @@ def v2_label_b64(ds, dev, steps=10, warmup=3, batch=64, nlabels=9):
                          "achieved": round(fl / fwd / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(fl / fwd / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "us_per_step": round(fwd * 1e6, 2),
                          "backward_us_per_step": round(bwd * 1e6, 2),
+                         "backward_kernel": ("train_bwd_persistent_k, two sweeps of 32 batch rows"
+                                             if ops.lib().zeggs_persistent_state(2) == 1 else "3 launches of stage_k<4,...> per step"),
                          "backward_frac": round(fl / bwd / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                          "iteration_tflops": round(3 * (WINDOW - 1) * fl / dt_ / 1e12, 2), "traffic": None},
             "config": "configs_v2.json shape: label conditioning (9 one-hot labels), no style encoder, batch 64 x 256"}

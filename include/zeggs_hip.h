@@ -179,7 +179,7 @@ int zeggs_persistent_state(int which /* 0: B=1 decode kernel, 1: training-forwar
 int zeggs_tp_stamps(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned long long* out /* host [4][2][32] */);
 /* -DZEGGS_TPSTAT builds: 100 MHz ticks every workgroup spent polling for the hand-off into phase 1..3 of the rollout */
 int zeggs_tp_waits(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned long long* out /* host [256][4] */);
-/* Training backward with batch <= 32: the BPTT sweep of zeggs_decoder_bwd (replaces the per-step autograd of
+/* Training backward with batch <= 64 (33..64: two sweeps of 32 rows): the BPTT sweep of zeggs_decoder_bwd (replaces the per-step autograd of
  * ZEGGS/train.py:425 through modules.py:100-151) runs as ONE persistent launch by default (option "bwd_persistent",
  * csrc/train_bwd_persistent.hip: transposed weights resident as 4-row v_mfma_f32_4x4x1 tiles, four grid hand-offs per step).
  * Same validation / fall-back protocol as the other persistent kernels.  -DZEGGS_BPTIME builds: phase stamps of steps 3..1 */

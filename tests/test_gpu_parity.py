@@ -552,10 +552,11 @@ def test_persistent_training_forward_matches_stage_launches(B, T):
         assert relerr(g1[k], g0[k]) < 1e-4, k
 
 
-@pytest.mark.parametrize("B,T,style_dim", [(32, 12, 64), (17, 6, 64), (5, 9, 64), (1, 7, 64), (32, 3, 64), (20, 5, 9)])
+@pytest.mark.parametrize("B,T,style_dim", [(32, 12, 64), (17, 6, 64), (5, 9, 64), (1, 7, 64), (32, 3, 64), (20, 5, 9), (64, 6, 9),
+                                           (40, 5, 64)])
 def test_persistent_bptt_sweep_matches_stage_launches(B, T, style_dim):
-    """option "bwd_persistent" (default on for batch <= 32): the backward decoder steps of a window as one weight-stationary
-    launch on 4-row MFMA tiles.  Same forward either way; every parameter gradient, dspeech and dstyle must agree with the
+    """option "bwd_persistent" (default on for batch <= 64): the backward decoder steps of a window as one weight-stationary
+    launch on 4-row MFMA tiles (batch 33..64: two sweeps of <= 32 rows).  Same forward either way; every parameter gradient, dspeech and dstyle must agree with the
     stage-launch sweep (which the oracle / reference fixtures pin) to fp32 rounding.  style_dim 9 = label conditioning."""
     torch.manual_seed(1234)
     from zeggs import modules

@@ -134,7 +134,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
       w.tp_n0s = a.f(3 * H * (long)w.POL); w.tp_n0 = a.f(3 * H * H); w.tp_cv0 = a.f(3 * H); w.tp_p1x = a.f(B * 3 * H);
       w.tp_cnt = (unsigned*)a.f(8192);      // arrival slots | error word (+1024) | stamps | wait statistics (+1536)
     }
-    if (d.H == 1024 && d.B <= 32) {
+    if (d.H == 1024 && d.B <= 64) {
       w.bp_wr = a.f(256L * 8 * 113 * 64); w.bp_wl = a.f(256L * 8 * 64 * 64);
       w.bp_opy = a.f(T * (long)((d.PO + 15) / 16) * 512);
       w.bp_op1 = a.f(T * 4 * H * 32); w.bp_op0 = a.f(T * 4 * H * 32); w.bp_opd = a.f(T * H * 32);

@@ -1,5 +1,5 @@
-// Weight-stationary persistent BPTT sweep of the training step (batch <= 32): the 255 backward decoder steps of a window
-// as ONE launch -- the backward mirror of train_persistent.hip.
+// Weight-stationary persistent BPTT sweep of the training step: the 255 backward decoder steps of a window as ONE launch for
+// up to 32 batch rows (33..64 rows: two launches, the rows are independent) -- the backward mirror of train_persistent.hip.
 //
 // Why a different tile shape than the forward kernel.  The transposed products of a step (W_ih1^T, W_hh1^T, W_ih0^T, W_hh0^T,
 // W0^T, W2^T: 80 MB) give every one of the 256 workgroups 4 + 4 + 4 + 8 + 4 output rows; with the 16-row tiles of
@@ -60,6 +60,8 @@ struct BArgs {
   ZeggsDecDims d;
   ZeggsDecStats st;
   int XD, GL, POL, KBY;
+  int Bact;                                  // batch rows of THIS sweep (<= 32); d.B is the full batch = the row stride of every array,
+                                             // whose base pointers the host offsets to the first row of the sweep
   const float *PWR, *PWL;                    // [256][8][NWR][64], [256][8][L3][64]
   float *OPY, *OP1, *OP0, *OPD, *SP;         // operands (time-major, write-once), dXa of the root / gaze columns [T][9][32]
   const float *Gin, *H0, *H1, *GT0, *GT1;    // forward saves
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   // opaque copy of the thread index at the start of every phase (refresh): left alone, the optimiser hoists every per-thread
   // 64-bit address they feed (a few dozen) out of the time loop and spills registers to keep them
   int er = tid >> 5, eb = tid & 31;
-  bool bact = eb < B;
+  bool bact = eb < a.Bact;
   int U = 4 * c + (er & 3);                     // hidden unit / dhid row of the GRU items (er < 4, er 4..7)
   const int U0 = 4 * c;
   int s4 = er - 4;                              // P4 item: dx slot 0..11
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
     int tx = tid;
     asm volatile("" : "+v"(tx));
     er = tx >> 5; eb = tx & 31;
-    bact = eb < B;
+    bact = eb < a.Bact;
     U = 4 * c + (er & 3);
     s4 = er - 4;
     row4 = er >= 4 ? p4_row(c, s4, PO, XD) : -1;
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
           const int idx = tid + q * BTHR;
-          if (idx < 33 * 32 && (idx & 31) < B)
+          if (idx < 33 * 32 && (idx & 31) < a.Bact)
             rv[q] = root_item(a.drpos, a.drrot, a.rrot, a.rpos, a.gaze, a.pose, a.dpose, T, PO, idx & 31, t - 1, true, idx >> 5);
         }
       }
@@ -790,7 +792,7 @@ __global__ void bp_dy_last_k(ZeggsDecDims d, ZeggsDecStats st, const float* dpos
 }  // namespace
 
 int dec_bp_supported(const ZeggsDecDims& d, const DecWs& w) {
-  return !d.film && d.H == BH && d.B <= 32 && d.T >= 3 && d.PI == d.PO + 3 && d.PO >= 16 && (d.PO + 15) / 16 <= 8 * NJ1 &&
+  return !d.film && d.H == BH && d.B <= 64 && d.T >= 3 && d.PI == d.PO + 3 && d.PO >= 16 && (d.PO + 15) / 16 <= 8 * NJ1 &&
          w.XD <= 8 * BNCU && w.bp_wr != nullptr;
 }
 int dec_bp_state() { return g_bp_ok; }
@@ -811,28 +813,36 @@ int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   // the pad k rows of dy (PO .. 16 KBY) must be finite: zero the operand once; every other operand element that is read
   // with a non-zero weight is written by the sweep (pad batch lanes only ever feed pad batch columns)
   ZTRY(k_fill(w.bp_opy, (long)T * KBY * 512, 0.f, s));
-  ZTRY(k_fill((float*)w.bp_cnt, 2048, 0.f, s));
   float* dyl = w.DY + (long)(T - 1) * B * w.POL;
   hipLaunchKernelGGL(bp_dy_last_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, gaze, pose, rpos, rrot, w.carry,
                      dyl, w.POL);
-  hipLaunchKernelGGL(bp_to_op_k, dim3((B * d.PO + 255) / 256), dim3(256), 0, s, w.bp_opy + (long)(T - 1) * KBY * 512, dyl,
-                     (long)w.POL, d.PO, B);
-  ZLAUNCH_CHECK("bp_prologue");
-  BArgs a;
-  memset(&a, 0, sizeof(a));
-  a.d = d; a.st = *st; a.XD = w.XD; a.GL = w.GL; a.POL = w.POL; a.KBY = KBY;
-  a.PWR = w.bp_wr; a.PWL = w.bp_wl;
-  a.OPY = w.bp_opy; a.OP1 = w.bp_op1; a.OP0 = w.bp_op0; a.OPD = w.bp_opd; a.SP = w.bp_sp;
-  a.Gin = w.Gin; a.H0 = w.H0; a.H1 = w.H1; a.GT0 = w.GT0; a.GT1 = w.GT1;
-  a.DY = w.DY; a.DI1 = w.DI1; a.DH1 = w.DH1; a.DI0 = w.DI0; a.DH0 = w.DH0; a.D0 = w.D0; a.DX = w.DX;
-  a.dH0c = w.dH0c; a.dH1c = w.dH1c;
-  a.dpose = dpose; a.drpos = drpos; a.drrot = drrot; a.gaze = gaze; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
-  a.carry = w.carry;
-  a.cnt = w.bp_cnt; a.err = w.bp_cnt + 1024;
+  ZLAUNCH_CHECK("bp_dy_last");
+  ZTRY(k_fill((float*)w.bp_cnt, 2048, 0.f, s));       // arrival slots + error word
   dec_timing_mark(2, s);
-  hipLaunchKernelGGL(train_bwd_persistent_k, dim3(BNCU), dim3(BTHR), 0, s, a);
+  // batch rows are independent in the sweep: 33..64 rows run as two sweeps of <= 32 rows through the same operand buffers
+  for (int b0 = 0; b0 < B; b0 += 32) {
+    const int Bact = B - b0 < 32 ? B - b0 : 32;
+    const long o = b0;
+    if (b0) ZTRY(k_fill((float*)w.bp_cnt, 256, 0.f, s));   // the arrival slots start over; the error word accumulates
+    hipLaunchKernelGGL(bp_to_op_k, dim3((Bact * d.PO + 255) / 256), dim3(256), 0, s, w.bp_opy + (long)(T - 1) * KBY * 512,
+                       dyl + o * w.POL, (long)w.POL, d.PO, Bact);
+    ZLAUNCH_CHECK("bp_prologue");
+    BArgs a;
+    memset(&a, 0, sizeof(a));
+    a.d = d; a.st = *st; a.XD = w.XD; a.GL = w.GL; a.POL = w.POL; a.KBY = KBY; a.Bact = Bact;
+    a.PWR = w.bp_wr; a.PWL = w.bp_wl;
+    a.OPY = w.bp_opy; a.OP1 = w.bp_op1; a.OP0 = w.bp_op0; a.OPD = w.bp_opd; a.SP = w.bp_sp;
+    a.Gin = w.Gin + o * w.GL; a.H0 = w.H0 + o * H; a.H1 = w.H1 + o * H; a.GT0 = w.GT0 + o * H * 4; a.GT1 = w.GT1 + o * H * 4;
+    a.DY = w.DY + o * w.POL; a.DI1 = w.DI1 + o * 3 * H; a.DH1 = w.DH1 + o * H; a.DI0 = w.DI0 + o * 3 * H; a.DH0 = w.DH0 + o * H;
+    a.D0 = w.D0 + o * H; a.DX = w.DX + o * w.XD; a.dH0c = w.dH0c + o * H; a.dH1c = w.dH1c + o * H;
+    a.dpose = dpose + o * T * d.PO; a.drpos = drpos + o * T * 3; a.drrot = drrot + o * T * 4; a.gaze = gaze + o * T * 3;
+    a.pose = pose + o * T * d.PO; a.rpos = rpos + o * T * 3; a.rrot = rrot + o * T * 4;
+    a.carry = w.carry + o * 8;
+    a.cnt = w.bp_cnt; a.err = w.bp_cnt + 1024;
+    hipLaunchKernelGGL(train_bwd_persistent_k, dim3(BNCU), dim3(BTHR), 0, s, a);
+    ZLAUNCH_CHECK("train_bwd_persistent");
+  }
   dec_timing_mark(3, s);
-  ZLAUNCH_CHECK("train_bwd_persistent");
   (void)H;
   return 0;
 }
