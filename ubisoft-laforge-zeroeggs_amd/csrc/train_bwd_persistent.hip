@@ -579,9 +579,8 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       BPS0();
       put(acc[0], 0); put(acc[1], 4); put(acc[2], 8);
       __syncthreads();
-      if (bact) {
-        if (er < 4) {}
-        else if (er < 8) ((float*)&ex[0][eb])[er - 4] = total(er - 4) * d_elu_grad_from_out(hid);
+      if (bact && er >= 4) {           // (threads er < 4 carry the GRU items: nothing of theirs in this phase's products)
+        if (er < 8) ((float*)&ex[0][eb])[er - 4] = total(er - 4) * d_elu_grad_from_out(hid);
         else if (row3 >= 0) {
           const float v = total(er - 4);
           dxa[er - 8][eb] = v;
