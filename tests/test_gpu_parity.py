@@ -945,6 +945,54 @@ def test_decoder_rollout_is_graph_capturable():
         assert float((ref2[0] - ref1[0]).abs().max()) > 1e-3       # the replay really consumed the new speech
 
 
+def test_decoder_training_step_is_graph_capturable():
+    """forward rollout + BPTT of the decoder (both persistent sweeps, validated by a warm-up) captured into ONE HIP graph and
+    replayed on new inputs: same gradients as the eager call"""
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).train()
+    B, T = 4, 7
+    s = {k: g(v) for k, v in helpers.stats_tensors().items()}
+    stats = synth.make_stats()
+    clips = [synth.make_clip(T, seed=820 + b, stats=stats) for b in range(B)]
+    tt = lambda k: g(torch.as_tensor(np.stack([c[k] for c in clips])))  # noqa: E731
+    pose0 = _pack_pose(tt("Y_root_vel"), tt("Y_root_vrt"), tt("Y_lpos"), tt("Y_ltxy"), tt("Y_lvel"), tt("Y_lvrt"))[:, 0].contiguous()
+    rp0, rr0, gaze = tt("Y_root_pos")[:, 0].contiguous(), tt("Y_root_rot")[:, 0].contiguous(), tt("Y_gaze_pos")
+    torch.manual_seed(13)
+    speech = (torch.randn(B, T, 64, device=DEV) * 0.5).requires_grad_(True)
+    style = torch.randn(B, T, 64, device=DEV) * 0.5
+    wgt = torch.randn(B, T, synth.POSE_OUT, device=DEV)
+
+    def step():
+        de.zero_grad(set_to_none=False)
+        if speech.grad is not None:
+            speech.grad.zero_()
+        pose, rp, rr = ops.decoder_core(de, pose0, rp0, rr0, gaze, speech, style, s["in_mean"], s["in_std"], s["out_mean"],
+                                        s["out_std"], synth.DT)
+        ((pose * wgt).sum() + rp.sum() + rr.sum()).backward()
+
+    step()                                              # eager: validates the persistent kernels on this process
+    torch.cuda.synchronize()
+    assert ops.lib().zeggs_persistent_state(1) == 1 and ops.lib().zeggs_persistent_state(2) == 1
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()                                          # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    with torch.no_grad():
+        speech.copy_(torch.randn(B, T, 64, device=DEV) * 0.5)          # new input in the captured buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    got = (speech.grad.clone(), de.recurrent_decoder.layer1.weight_hh_l0.grad.clone(), de.recurrent_decoder.layer2.weight.grad.clone())
+    step()                                              # eager on the same input
+    torch.cuda.synchronize()
+    ref = (speech.grad, de.recurrent_decoder.layer1.weight_hh_l0.grad, de.recurrent_decoder.layer2.weight.grad)
+    for a, b in zip(got, ref):
+        assert float(b.abs().max()) > 0 and relerr(a, b) < 2e-5
+
+
 # ----------------------------------------------------------------------------- loud failures
 def test_c_abi_rejects_bad_arguments_loudly():
     """error behaviour of the boundary: -1 + zeggs_last_error(), never a silent fallback"""
