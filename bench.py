@@ -350,6 +350,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="ONE blocking all-reduce after the backward instead of the overlapped decoder-slice exchange")
+    ap.add_argument("--no-wgrad-overlap", action="store_true",
+                    help="decoder weight-gradient GEMMs on the main stream instead of beside the encoders' backward")
     ap.add_argument("--no-extras", action="store_true", help="skip decode / decode_30min / v2_label_b64 (N = 1 only)")
     ap.add_argument("--force-process-group", action="store_true",
                     help="initialise the RCCL process group and run the gradient all-reduce even at --gpus 1")
@@ -399,7 +401,8 @@ def main():
     ds = engine.DeviceDataset(data, WINDOW, dev)
     se, de, st = build_nets(dev)
     eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, world_size=world, rank=rank,
-                             force_allreduce=a.force_process_group, overlap_allreduce=not a.no_overlap)
+                             force_allreduce=a.force_process_group, overlap_allreduce=not a.no_overlap,
+                             overlap_wgrads=not a.no_wgrad_overlap)
     ops.manual_seed(1000 + rank)                            # per-rank noise streams (dropout masks, VAE eps)
     perm = np.random.default_rng(42).permutation(len(ds))   # same permutation on every rank
     gb = BATCH * world

@@ -196,6 +196,14 @@ int zeggs_decoder_bwd(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDec
                       const float* pose, const float* rpos, const float* rrot, const float* dpose,
                       const float* drpos, const float* drrot, const ZeggsDecGrads*, float* dspeech,
                       float* dstyle, void* ws, size_t ws_bytes, void* stream);
+/* With zeggs_set_option("defer_wgrads", 1) zeggs_decoder_bwd leaves out the weight / bias gradients of the recurrent
+ * layers (layer0, the GRU, layer2 of ZEGGS/modules.py:165-185: seven GEMMs with K = B (T-1) that read only what the sweep
+ * saved in `ws`); the caller runs them with zeggs_decoder_wgrads on a second stream, e.g. zeggs_side_stream (low priority,
+ * owned by the library, one per device), beside the encoders' backward, and joins the streams before the optimizer step
+ * (zeggs/ops.py: _DecoderFn.backward, zeggs/engine.py).  The reference has no counterpart: its autograd runs every
+ * backward op on one stream (ZEGGS/train.py:425). */
+int zeggs_decoder_wgrads(const ZeggsDecDims*, const ZeggsDecGrads*, void* ws, size_t ws_bytes, void* stream);
+int zeggs_side_stream(void** out /* hipStream_t */);
 
 /* ---------------------------------------------------------------- training loss
  * replaces the inline loss of ZEGGS/train.py:276-421 (xform_orthogonalize_from_xy, xform_fk_vel of

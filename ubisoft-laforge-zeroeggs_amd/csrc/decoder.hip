@@ -16,6 +16,7 @@
 #include "decoder_ws.h"
 
 static int g_decoder_fast = 1;
+static int g_defer_wgrads = 0;  // zeggs_decoder_bwd leaves the recurrent weight gradients to zeggs_decoder_wgrads (caller's second stream)
 static int g_bwd_chunks = 1;   // BPTT sweep chunks whose weight-gradient GEMMs overlap the rest of the sweep (1: serial)
 extern int g_stage_variant;
 extern int g_gemm_wg_target;
@@ -47,6 +48,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
     return 0;
   }
   if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
+  if (strcmp(name, "defer_wgrads") == 0) { g_defer_wgrads = value != 0; return 0; }
   zeggs_set_error("unknown option %s", name);
   return -1;
 }
@@ -658,6 +660,26 @@ extern "C" int zeggs_decoder_chain_stamps(const ZeggsDecDims* dp, int training, 
   return 0;
 }
 
+// The recurrent layers' weight / bias gradients of the sweep zeggs_decoder_bwd just ran on `ws` with the option "defer_wgrads"
+// set: seven large GEMMs (K = B (T-1)) that read only the sweep's saves, so the caller can run them on a second stream
+// beside the CellStateEncoder / encoder backward (many small launches that leave the chip mostly idle).
+extern "C" int zeggs_decoder_wgrads(const ZeggsDecDims* dp, const ZeggsDecGrads* G, void* ws, size_t ws_bytes, void* stream) {
+  const ZeggsDecDims& d = *dp;
+  Arena a(ws, ws_bytes);
+  DecWs w = carve_dec(d, 1, a);
+  ZCHECK(a.ok(), "decoder wgrads: workspace too small (was the forward run with training=1?)");
+  ZCHECK(d.T > 1, "decoder wgrads: T must be > 1");
+  const bool fast_path = g_decoder_fast && dec_fast_supported(d);
+  return dec_recurrent_wgrads(d, w, G, 1, d.T - 1, 0.f, fast_path ? 1 : 0, (hipStream_t)stream);
+}
+// the library's low-priority second stream of the current device (also used by the chunked stage-launch sweep)
+extern "C" int zeggs_side_stream(void** out) {
+  SideStream* ss = nullptr;
+  ZTRY(side_stream(&ss));
+  *out = (void*)ss->s;
+  return 0;
+}
+
 extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
                                  const float* gaze, const float* pose, const float* rpos, const float* rrot,
                                  const float* dpose, const float* drpos, const float* drrot, const ZeggsDecGrads* G,
@@ -773,7 +795,7 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   }
   }
   // ---- CellStateEncoder backward: dH0c / dH1c are the grads wrt its two output halves
-  if (!wgrads_done) ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, s));
+  if (!wgrads_done && !g_defer_wgrads) ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, s));
   {
     // out = [H0_init | H1_init] = cse_b W2^T + b2
     ZTRY(gemm_tn(w.dH0c, H, w.cse_b, H, G->c2_w, H, B, H, H, 0.f, s));

@@ -164,13 +164,19 @@ def flatten_parameters(modules):
 class TrainEngine:
     def __init__(self, speech_encoder, decoder, style_encoder, dataset, parents, dt, lr=1e-4, eps=1e-5,
                  style_encoding_type="example", world_size=1, rank=0, process_group=None, force_allreduce=False,
-                 overlap_allreduce=True):
+                 overlap_allreduce=True, overlap_wgrads=True):
         self.se, self.de, self.st = speech_encoder, decoder, style_encoder
         self.ds = dataset
         self.dt = float(dt)
         self.world, self.rank, self.pg = world_size, rank, process_group
         self.force_allreduce = force_allreduce
         self.overlap_allreduce = overlap_allreduce
+        # the decoder's weight-gradient GEMMs on the library's second stream, beside the encoders' backward
+        on_gpu = overlap_wgrads and torch.device(dataset.device).type == "cuda"
+        self.wgrad_stream = ops.side_stream(dataset.device) if on_gpu else None
+        # the speech encoder (a short chain of small launches, forward and -- autograd replays a node on the stream of its
+        # forward -- backward) beside the style encoder
+        self.aux_stream = torch.cuda.Stream(device=dataset.device) if on_gpu else None
         self.style_type = style_encoding_type
         dev = dataset.device
         self.parents = torch.as_tensor(np.asarray(parents), dtype=torch.int32, device=dev)
@@ -208,14 +214,25 @@ class TrainEngine:
         self._dec_work = None
         if overlap:
             ops.set_after_decoder_backward(self._reduce_decoder_grads)
+        ops.set_wgrad_stream(self.wgrad_stream)
         try:
-            speech = self.se(b["audio"])
+            cur = torch.cuda.current_stream() if self.aux_stream is not None else None
+            if self.aux_stream is not None:
+                self.aux_stream.wait_stream(cur)            # the batch was gathered on the current stream
+                b["audio"].record_stream(self.aux_stream)
+                with torch.cuda.stream(self.aux_stream):
+                    speech = self.se(b["audio"])
+            else:
+                speech = self.se(b["audio"])
             mu = logvar = None
             if self.style_type == "example":
                 z, mu, logvar = self.st(b["example"], 1.0, eps=eps)
             else:
                 z = labels
             style = ops.broadcast_time(z, T)
+            if self.aux_stream is not None:
+                cur.wait_stream(self.aux_stream)
+                speech.record_stream(cur)
             ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
             if self.decoder_fwd_events is not None:
                 e0 = ev()
@@ -241,6 +258,11 @@ class TrainEngine:
         finally:
             ops.direct_param_grads(False)
             ops.set_after_decoder_backward(None)
+            ops.set_wgrad_stream(None)
+        if self.wgrad_stream is not None:      # join: every decoder gradient is final from here on in stream order
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+        if self.aux_stream is not None:        # ... and the speech encoder's
+            torch.cuda.current_stream().wait_stream(self.aux_stream)
         if self.allreduce_events is not None:       # with the overlap on: the EXPOSED part of the exchange
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a0.record()

@@ -145,6 +145,30 @@ def set_after_decoder_backward(fn):
     _AFTER_DECODER_BWD = fn
 
 
+_WGRAD_STREAM = None
+_SIDE_STREAMS = {}
+
+
+def side_stream(device=None):
+    """The library's low-priority second stream of `device` as a torch stream (zeggs_side_stream)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _SIDE_STREAMS:
+        with torch.cuda.device(idx):
+            h = C.c_void_p(0)
+            _check(lib().zeggs_side_stream(C.byref(h)), "side_stream")
+            _SIDE_STREAMS[idx] = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx))
+    return _SIDE_STREAMS[idx]
+
+
+def set_wgrad_stream(stream):
+    """Engine hook (direct-gradient mode only): the decoder backward leaves the weight-gradient GEMMs of its recurrent layers
+    to `stream` (zeggs_decoder_wgrads), where they run beside the encoders' backward; the CALLER joins (`wait_stream`) before
+    it reads a decoder gradient.  None: everything on the current stream."""
+    global _WGRAD_STREAM
+    _WGRAD_STREAM = stream
+
+
 def _grad_targets(orig_params, params):
     """-> (tensors the backward kernel writes, values returned to autograd)"""
     outs, rets = [], []
@@ -463,10 +487,28 @@ class _DecoderFn(torch.autograd.Function):
         P = _ptrs(DecPtrs, DEC_FIELDS, params)
         G = _ptrs(DecPtrs, DEC_FIELDS, grads)
         S = _ptrs(DecStats, ("in_mean", "in_std", "out_mean", "out_std"), stats)
-        _check(L.zeggs_decoder_bwd(C.byref(d), C.byref(P), C.byref(S), _p(gaze), _p(pose), _p(rpos), _p(rrot),
-                                   _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
-                                   C.c_size_t(ctx.ws.numel()), _stream()), "decoder_bwd")
-        if _AFTER_DECODER_BWD is not None and _DIRECT_GRADS and all(r is None for r in rets):
+        direct = _DIRECT_GRADS and all(r is None for r in rets)
+        side = _WGRAD_STREAM if direct and not torch.cuda.is_current_stream_capturing() else None
+        if side is not None:
+            _check(L.zeggs_set_option(b"defer_wgrads", 1), "set_option")
+        try:
+            _check(L.zeggs_decoder_bwd(C.byref(d), C.byref(P), C.byref(S), _p(gaze), _p(pose), _p(rpos), _p(rrot),
+                                       _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
+                                       C.c_size_t(ctx.ws.numel()), _stream()), "decoder_bwd")
+        finally:
+            if side is not None:
+                _check(L.zeggs_set_option(b"defer_wgrads", 0), "set_option")
+        if side is not None:
+            # the recurrent layers' weight gradients read only what the sweep left in the workspace: second stream, beside
+            # the CellStateEncoder / encoder backward that follows on this one
+            side.wait_stream(torch.cuda.current_stream())
+            ctx.ws.record_stream(side)
+            with torch.cuda.stream(side):
+                _check(L.zeggs_decoder_wgrads(C.byref(d), C.byref(G), _p(ctx.ws), C.c_size_t(ctx.ws.numel()),
+                                              C.c_void_p(side.cuda_stream)), "decoder_wgrads")
+                if _AFTER_DECODER_BWD is not None:
+                    _AFTER_DECODER_BWD()          # (the collective it starts is ordered after the GEMMs of `side`)
+        elif _AFTER_DECODER_BWD is not None and direct:
             _AFTER_DECODER_BWD()
         return (None, None, None, None, dspeech, dstyle, None, None, None, None, None, None, None, *rets)
 
