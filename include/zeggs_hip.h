@@ -196,13 +196,19 @@ int zeggs_decoder_bwd(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDec
                       const float* pose, const float* rpos, const float* rrot, const float* dpose,
                       const float* drpos, const float* drrot, const ZeggsDecGrads*, float* dspeech,
                       float* dstyle, void* ws, size_t ws_bytes, void* stream);
-/* With zeggs_set_option("defer_wgrads", 1) zeggs_decoder_bwd leaves out the weight / bias gradients of the recurrent
- * layers (layer0, the GRU, layer2 of ZEGGS/modules.py:165-185: seven GEMMs with K = B (T-1) that read only what the sweep
- * saved in `ws`); the caller runs them with zeggs_decoder_wgrads on a second stream, e.g. zeggs_side_stream (low priority,
- * owned by the library, one per device), beside the encoders' backward, and joins the streams before the optimizer step
- * (zeggs/ops.py: _DecoderFn.backward, zeggs/engine.py).  The reference has no counterpart: its autograd runs every
- * backward op on one stream (ZEGGS/train.py:425). */
-int zeggs_decoder_wgrads(const ZeggsDecDims*, const ZeggsDecGrads*, void* ws, size_t ws_bytes, void* stream);
+/* With zeggs_set_option("defer_wgrads", 1) zeggs_decoder_bwd enqueues the weight-gradient GEMMs of the recurrent layers
+ * (layer0, the GRU, layer2 of ZEGGS/modules.py:165-185: seven GEMMs with K = B (T-1) that read only what the sweep saved in
+ * `ws`) on zeggs_side_stream (low priority, owned by the library, one per device) right after the sweep and returns WITHOUT
+ * joining: they run beside the CellStateEncoder backward and whatever the caller enqueues next (the encoders' backward).
+ * The caller makes every consumer of the decoder's weight gradients (all-reduce, optimizer) wait for that stream and keeps
+ * `ws` alive until then (zeggs/ops.py: _DecoderFn.backward, zeggs/engine.py).  The reference has no counterpart: its
+ * autograd runs every backward op on one stream (ZEGGS/train.py:425). */
+/* The weight-only preparation of a training step on `ws` (merged / folded matrices and the fragment packs of the two
+ * persistent sweeps; the reference has no counterpart, its GEMMs read nn.Parameter storage directly): may run on a second
+ * stream beside the encoders' forward.  Returns a bit mask, 1: zeggs_decoder_fwd may be called with option "fwd_prepared",
+ * 2: zeggs_decoder_bwd with "bwd_prepared" (they then skip this work); 0: nothing done; < 0: error. */
+int zeggs_decoder_prepare(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDecStats*, void* ws, size_t ws_bytes,
+                          void* stream);
 int zeggs_side_stream(void** out /* hipStream_t */);
 
 /* ---------------------------------------------------------------- training loss

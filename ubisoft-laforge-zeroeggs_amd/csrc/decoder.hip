@@ -16,7 +16,8 @@
 #include "decoder_ws.h"
 
 static int g_decoder_fast = 1;
-static int g_defer_wgrads = 0;  // zeggs_decoder_bwd leaves the recurrent weight gradients to zeggs_decoder_wgrads (caller's second stream)
+static int g_fwd_prepared = 0, g_bwd_prepared = 0;   // zeggs_decoder_prepare has run on this workspace (the caller vouches)
+static int g_defer_wgrads = 0;  // zeggs_decoder_bwd runs the recurrent weight-gradient GEMMs on the library's second stream and does NOT join
 static int g_bwd_chunks = 1;   // BPTT sweep chunks whose weight-gradient GEMMs overlap the rest of the sweep (1: serial)
 extern int g_stage_variant;
 extern int g_gemm_wg_target;
@@ -49,6 +50,8 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   }
   if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
   if (strcmp(name, "defer_wgrads") == 0) { g_defer_wgrads = value != 0; return 0; }
+  if (strcmp(name, "fwd_prepared") == 0) { g_fwd_prepared = value != 0; return 0; }
+  if (strcmp(name, "bwd_prepared") == 0) { g_bwd_prepared = value != 0; return 0; }
   zeggs_set_error("unknown option %s", name);
   return -1;
 }
@@ -359,50 +362,51 @@ __global__ void add_style0_grad_k(ZeggsDecDims d, const float* dcse_in, float* d
 // weight gradients of the recurrent part for the steps t_lo..t_hi: contraction over the flattened (t, b) rows
 // compact != 0 (fast path): DH0 / DH1 hold only the n rows of the hidden-side gate gradients, [T][B][H]; their r, z rows
 // are the r, z rows of DI0 / DI1.
+// what: 1 = the weight gradients (GEMMs), 2 = the bias gradients (column sums), 3 = both
 int dec_recurrent_wgrads(const ZeggsDecDims& d, const DecWs& w, const ZeggsDecGrads* G, int t_lo, int t_hi, float beta,
-                         int compact, hipStream_t s) {
+                         int compact, hipStream_t s, int what = 3) {
   const int B = d.B, H = d.H, GL = w.GL, XD = w.XD, POL = w.POL;
   const long sG = (long)B * GL, sH = (long)B * H, s3 = 3 * sH, sY = (long)B * POL;
   const int M = (t_hi - t_lo + 1) * B;
   const long o = t_lo;
   if (d.film) {
     const long sg = (long)B * 2 * H, sS = (long)B * d.ST;
-    ZTRY(gemm_tn(w.DY + o * sY, POL, w.F2 + o * sH, H, G->l3_w, H, M, d.PO, H, beta, s));
-    ZTRY(k_colsum(G->l3_b, w.DY + o * sY, M, d.PO, POL, beta, s));
-    ZTRY(gemm_tn(w.D2 + o * sH, H, w.H1 + o * sH, H, G->l2_w, H, M, H, H, beta, s));
-    ZTRY(k_colsum(G->l2_b, w.D2 + o * sH, M, H, H, beta, s));
-    ZTRY(gemm_tn(w.DGAM + o * sg, 2 * H, w.STm + o * sS, d.ST, G->g_w, d.ST, M, 2 * H, d.ST, beta, s));
-    ZTRY(k_colsum(G->g_b, w.DGAM + o * sg, M, 2 * H, 2 * H, beta, s));
-    ZTRY(gemm_tn(w.DBET + o * sg, 2 * H, w.STm + o * sS, d.ST, G->be_w, d.ST, M, 2 * H, d.ST, beta, s));
-    ZTRY(k_colsum(G->be_b, w.DBET + o * sg, M, 2 * H, 2 * H, beta, s));
+    if (what & 1) ZTRY(gemm_tn(w.DY + o * sY, POL, w.F2 + o * sH, H, G->l3_w, H, M, d.PO, H, beta, s));
+    if (what & 2) ZTRY(k_colsum(G->l3_b, w.DY + o * sY, M, d.PO, POL, beta, s));
+    if (what & 1) ZTRY(gemm_tn(w.D2 + o * sH, H, w.H1 + o * sH, H, G->l2_w, H, M, H, H, beta, s));
+    if (what & 2) ZTRY(k_colsum(G->l2_b, w.D2 + o * sH, M, H, H, beta, s));
+    if (what & 1) ZTRY(gemm_tn(w.DGAM + o * sg, 2 * H, w.STm + o * sS, d.ST, G->g_w, d.ST, M, 2 * H, d.ST, beta, s));
+    if (what & 2) ZTRY(k_colsum(G->g_b, w.DGAM + o * sg, M, 2 * H, 2 * H, beta, s));
+    if (what & 1) ZTRY(gemm_tn(w.DBET + o * sg, 2 * H, w.STm + o * sS, d.ST, G->be_w, d.ST, M, 2 * H, d.ST, beta, s));
+    if (what & 2) ZTRY(k_colsum(G->be_b, w.DBET + o * sg, M, 2 * H, 2 * H, beta, s));
   } else {
-    ZTRY(gemm_tn(w.DY + o * sY, POL, w.H1 + o * sH, H, G->l2_w, H, M, d.PO, H, beta, s));
-    ZTRY(k_colsum(G->l2_b, w.DY + o * sY, M, d.PO, POL, beta, s));
+    if (what & 1) ZTRY(gemm_tn(w.DY + o * sY, POL, w.H1 + o * sH, H, G->l2_w, H, M, d.PO, H, beta, s));
+    if (what & 2) ZTRY(k_colsum(G->l2_b, w.DY + o * sY, M, d.PO, POL, beta, s));
   }
-  ZTRY(gemm_tn(w.DI1 + o * s3, 3 * H, w.H0 + o * sH, H, G->w_ih1, H, M, 3 * H, H, beta, s));
-  ZTRY(k_colsum(G->b_ih1, w.DI1 + o * s3, M, 3 * H, 3 * H, beta, s));
+  if (what & 1) ZTRY(gemm_tn(w.DI1 + o * s3, 3 * H, w.H0 + o * sH, H, G->w_ih1, H, M, 3 * H, H, beta, s));
+  if (what & 2) ZTRY(k_colsum(G->b_ih1, w.DI1 + o * s3, M, 3 * H, 3 * H, beta, s));
   if (compact) {
-    ZTRY(gemm_tn(w.DI1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, M, 2 * H, H, beta, s));
-    ZTRY(gemm_tn(w.DH1 + o * sH, H, w.H1 + (o - 1) * sH, H, G->w_hh1 + 2L * H * H, H, M, H, H, beta, s));
-    ZTRY(k_colsum(G->b_hh1, w.DI1 + o * s3, M, 2 * H, 3 * H, beta, s));
-    ZTRY(k_colsum(G->b_hh1 + 2 * H, w.DH1 + o * sH, M, H, H, beta, s));
+    if (what & 1) ZTRY(gemm_tn(w.DI1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, M, 2 * H, H, beta, s));
+    if (what & 1) ZTRY(gemm_tn(w.DH1 + o * sH, H, w.H1 + (o - 1) * sH, H, G->w_hh1 + 2L * H * H, H, M, H, H, beta, s));
+    if (what & 2) ZTRY(k_colsum(G->b_hh1, w.DI1 + o * s3, M, 2 * H, 3 * H, beta, s));
+    if (what & 2) ZTRY(k_colsum(G->b_hh1 + 2 * H, w.DH1 + o * sH, M, H, H, beta, s));
   } else {
-    ZTRY(gemm_tn(w.DH1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, M, 3 * H, H, beta, s));
-    ZTRY(k_colsum(G->b_hh1, w.DH1 + o * s3, M, 3 * H, 3 * H, beta, s));
+    if (what & 1) ZTRY(gemm_tn(w.DH1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, M, 3 * H, H, beta, s));
+    if (what & 2) ZTRY(k_colsum(G->b_hh1, w.DH1 + o * s3, M, 3 * H, 3 * H, beta, s));
   }
-  ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.Gin + o * sG, GL, G->w_ih0, H + XD, M, 3 * H, H + XD, beta, s));
-  ZTRY(k_colsum(G->b_ih0, w.DI0 + o * s3, M, 3 * H, 3 * H, beta, s));
+  if (what & 1) ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.Gin + o * sG, GL, G->w_ih0, H + XD, M, 3 * H, H + XD, beta, s));
+  if (what & 2) ZTRY(k_colsum(G->b_ih0, w.DI0 + o * s3, M, 3 * H, 3 * H, beta, s));
   if (compact) {
-    ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 2 * H, H, beta, s));
-    ZTRY(gemm_tn(w.DH0 + o * sH, H, w.H0 + (o - 1) * sH, H, G->w_hh0 + 2L * H * H, H, M, H, H, beta, s));
-    ZTRY(k_colsum(G->b_hh0, w.DI0 + o * s3, M, 2 * H, 3 * H, beta, s));
-    ZTRY(k_colsum(G->b_hh0 + 2 * H, w.DH0 + o * sH, M, H, H, beta, s));
+    if (what & 1) ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 2 * H, H, beta, s));
+    if (what & 1) ZTRY(gemm_tn(w.DH0 + o * sH, H, w.H0 + (o - 1) * sH, H, G->w_hh0 + 2L * H * H, H, M, H, H, beta, s));
+    if (what & 2) ZTRY(k_colsum(G->b_hh0, w.DI0 + o * s3, M, 2 * H, 3 * H, beta, s));
+    if (what & 2) ZTRY(k_colsum(G->b_hh0 + 2 * H, w.DH0 + o * sH, M, H, H, beta, s));
   } else {
-    ZTRY(gemm_tn(w.DH0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 3 * H, H, beta, s));
-    ZTRY(k_colsum(G->b_hh0, w.DH0 + o * s3, M, 3 * H, 3 * H, beta, s));
+    if (what & 1) ZTRY(gemm_tn(w.DH0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 3 * H, H, beta, s));
+    if (what & 2) ZTRY(k_colsum(G->b_hh0, w.DH0 + o * s3, M, 3 * H, 3 * H, beta, s));
   }
-  ZTRY(gemm_tn(w.D0 + o * sH, H, w.Gin + o * sG + H, GL, G->l0_w, XD, M, H, XD, beta, s));
-  ZTRY(k_colsum(G->l0_b, w.D0 + o * sH, M, H, H, beta, s));
+  if (what & 1) ZTRY(gemm_tn(w.D0 + o * sH, H, w.Gin + o * sG + H, GL, G->l0_w, XD, M, H, XD, beta, s));
+  if (what & 2) ZTRY(k_colsum(G->l0_b, w.D0 + o * sH, M, H, H, beta, s));
   return 0;
 }
 
@@ -557,8 +561,10 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
     if (cap == hipStreamCaptureStatusNone || dec_tp_state() == 1) {
       float* gin1 = w.Gin + sG;
       ZTRY(gemm_nt(gin1 + H, GL, P->l0_w, XD, gin1, GL, P->l0_b, B, H, XD, ACT_ELU, 0.f, s));   // hid_1 = ELU(W0 x_1 + b0)
-      ZTRY(dec_fast_merge_prep(d, P, st, w, s));
-      ZTRY(dec_tp_pack(d, P, st, w, s));
+      if (!g_fwd_prepared) {
+        ZTRY(dec_fast_merge_prep(d, P, st, w, s));
+        ZTRY(dec_tp_pack(d, P, st, w, s));
+      }
       dec_timing_mark(0, s);
       ZTRY(dec_tp_run(d, P, st, w, gaze, speech, style, pose, rpos, rrot, s));
       dec_timing_mark(1, s);
@@ -660,17 +666,28 @@ extern "C" int zeggs_decoder_chain_stamps(const ZeggsDecDims* dp, int training, 
   return 0;
 }
 
-// The recurrent layers' weight / bias gradients of the sweep zeggs_decoder_bwd just ran on `ws` with the option "defer_wgrads"
-// set: seven large GEMMs (K = B (T-1)) that read only the sweep's saves, so the caller can run them on a second stream
-// beside the CellStateEncoder / encoder backward (many small launches that leave the chip mostly idle).
-extern "C" int zeggs_decoder_wgrads(const ZeggsDecDims* dp, const ZeggsDecGrads* G, void* ws, size_t ws_bytes, void* stream) {
+// Everything the two persistent sweeps of a training step need that depends on the WEIGHTS only (the merged / folded
+// matrices, the per-workgroup fragment packs of both kernels): the caller may run it on a second stream beside the encoders'
+// forward and passes "fwd_prepared" / "bwd_prepared" to the calls that follow on the same workspace.  Returns a bit mask
+// (1: forward packs ready, 2: backward packs ready; 0: these dimensions take another path, nothing was done), < 0 on error.
+extern "C" int zeggs_decoder_prepare(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st, void* ws,
+                                     size_t ws_bytes, void* stream) {
   const ZeggsDecDims& d = *dp;
+  hipStream_t s = (hipStream_t)stream;
   Arena a(ws, ws_bytes);
   DecWs w = carve_dec(d, 1, a);
-  ZCHECK(a.ok(), "decoder wgrads: workspace too small (was the forward run with training=1?)");
-  ZCHECK(d.T > 1, "decoder wgrads: T must be > 1");
-  const bool fast_path = g_decoder_fast && dec_fast_supported(d);
-  return dec_recurrent_wgrads(d, w, G, 1, d.T - 1, 0.f, fast_path ? 1 : 0, (hipStream_t)stream);
+  ZCHECK(a.ok(), "decoder prepare: workspace too small");
+  const bool fast = g_decoder_fast && dec_fast_supported(d);
+  // only once the kernels have been validated on this process (the first use takes the ordinary path)
+  if (!(fast && d.T > 1 && g_train_persistent && dec_tp_state() == 1 && dec_tp_supported(d, w))) return 0;
+  ZTRY(dec_fast_merge_prep(d, P, st, w, s));
+  ZTRY(dec_tp_pack(d, P, st, w, s));
+  int mask = 1;
+  if (g_bwd_persistent && dec_bp_state() == 1 && dec_bp_supported(d, w)) {
+    ZTRY(dec_bp_pack(d, P, w, s));
+    mask |= 2;
+  }
+  return mask;
 }
 // the library's low-priority second stream of the current device (also used by the chunked stage-launch sweep)
 extern "C" int zeggs_side_stream(void** out) {
@@ -711,7 +728,7 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   }
   if (fast_path && g_bwd_persistent && dec_bp_state() != 0 && dec_bp_supported(d, w) &&
       (cap == hipStreamCaptureStatusNone || dec_bp_state() == 1)) {
-    ZTRY(dec_bp_run(d, P, st, w, gaze, pose, rpos, rrot, dpose, drpos, drrot, s));
+    ZTRY(dec_bp_run(d, P, st, w, gaze, pose, rpos, rrot, dpose, drpos, drrot, s, g_bwd_prepared != 0));
     if (dec_bp_state() == 1) {
       if (cap == hipStreamCaptureStatusNone) { unsigned* ew = nullptr; ZTRY(dec_bp_errptr(w, &ew)); ZTRY(g_watch_bwd.post(ew, s)); }
       swept = true;
@@ -794,8 +811,21 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
     ZTRY(gemm_nn(w.D0 + o, H, P->l0_w, XD, dx, XD, B, H, XD, 1.f, s));
   }
   }
+  // ---- weight gradients of the recurrent layers.  Option "defer_wgrads": the seven large GEMMs (K = B (T-1), they read only
+  // what the sweep saved) start NOW on the library's second stream, beside the CellStateEncoder backward below and whatever the
+  // caller enqueues on `s` after this call (the encoders' backward); the small bias sums stay on `s`.  No join here: the
+  // caller makes every consumer of the decoder gradients wait for zeggs_side_stream.
+  bool deferred = false;
+  if (!wgrads_done && g_defer_wgrads && cap == hipStreamCaptureStatusNone) {
+    ZTRY(side_stream(&ss));
+    ZCHECK(hipEventRecord(ss->chunk, s) == hipSuccess, "hipEventRecord failed");
+    ZCHECK(hipStreamWaitEvent(ss->s, ss->chunk, 0) == hipSuccess, "hipStreamWaitEvent failed");
+    ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, ss->s, 1));
+    deferred = true;
+  } else if (!wgrads_done) {
+    ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, s));
+  }
   // ---- CellStateEncoder backward: dH0c / dH1c are the grads wrt its two output halves
-  if (!wgrads_done && !g_defer_wgrads) ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, s));
   {
     // out = [H0_init | H1_init] = cse_b W2^T + b2
     ZTRY(gemm_tn(w.dH0c, H, w.cse_b, H, G->c2_w, H, B, H, H, 0.f, s));
@@ -825,6 +855,7 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   }
   hipLaunchKernelGGL(add_style0_grad_k, g1((long)B * d.ST), dim3(256), 0, s, d, w.t1, dstyle);
   ZLAUNCH_CHECK("dec_bwd_tail");
+  if (deferred) ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, s, 2));     // bias sums
   if (wgrads_done) ZCHECK(hipStreamWaitEvent(s, ss->done, 0) == hipSuccess, "hipStreamWaitEvent failed");   // join
   return 0;
 }

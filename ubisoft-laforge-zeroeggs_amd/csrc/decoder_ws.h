@@ -167,9 +167,10 @@ int dec_tp_errptr(const DecWs& w, unsigned** out);
 int dec_bp_supported(const ZeggsDecDims& d, const DecWs& w);
 int dec_bp_state();
 void dec_bp_set_state(int v);
+int dec_bp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s);      // weight tiles + operand pads (weights only)
 int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                const float* pose, const float* rpos, const float* rrot, const float* dpose, const float* drpos,
-               const float* drrot, hipStream_t s);
+               const float* drrot, hipStream_t s, bool packed = false);
 int dec_bp_errors(const DecWs& w, unsigned* out);
 int dec_bp_errptr(const DecWs& w, unsigned** out);
 // fast path entry points (decoder_fast.hip)

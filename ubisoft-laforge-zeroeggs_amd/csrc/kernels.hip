@@ -360,7 +360,9 @@ int k_layernorm_fwd(float* y, const float* x, const float* res, const float* gam
 }
 int k_layernorm_bwd_v(RowView dx, RowView dy, RowView x, RowView res, const float* gamma, const float* mean,
                       const float* rstd, float* dgamma, float* dbeta, int R, int C, hipStream_t s) {
-  const int rpb = 64;
+  // 4 rows per wave: a row is three dependent round trips (load, wave reduction, store), so the kernel lives on the number of
+  // waves in flight; the price is one atomic per column and block (R / 16 blocks onto C addresses)
+  const int rpb = 16;
   ZCHECK(C <= 512, "layernorm_bwd: C=%d > 512 unsupported", C);
   if (C <= 128)
     hipLaunchKernelGGL((layernorm_bwd_k<2>), dim3(cdiv(R, rpb)), dim3(256), 0, s, dx, dy, x, res, gamma, mean, rstd,

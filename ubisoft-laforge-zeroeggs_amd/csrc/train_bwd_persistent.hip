@@ -798,20 +798,26 @@ int dec_bp_state() { return g_bp_ok; }
 void dec_bp_set_state(int v) { g_bp_ok = v; }
 
 // the whole sweep t = T-1 .. 1; leaves DY, DI*, DH*, D0, DX (speech / style columns), dH0c, dH1c as the stage sweep does
-int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
-               const float* pose, const float* rpos, const float* rrot, const float* dpose, const float* drpos,
-               const float* drrot, hipStream_t s) {
-  const int B = d.B, T = d.T, H = d.H, KBY = (d.PO + 15) / 16;
-  int dev = 0, ncu = 0;
-  ZCHECK(hipGetDevice(&dev) == hipSuccess, "hipGetDevice failed");
-  ZCHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess, "device query failed");
-  ZCHECK(ncu >= BNCU, "persistent BPTT sweep needs %d CUs (device has %d)", BNCU, ncu);
+// what depends on the weights and the dimensions only (zeggs_decoder_prepare runs it ahead of the forward, on a second stream)
+int dec_bp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s) {
+  const int T = d.T, KBY = (d.PO + 15) / 16;
   BPackArgs p{w.bp_wr, w.bp_wl, P->w_ih0, P->w_hh0, P->w_ih1, P->w_hh1, P->l2_w, P->l0_w, w.XD, d.PO, KBY};
   hipLaunchKernelGGL(bp_pack_k, dim3(8192), dim3(256), 0, s, p);
   ZLAUNCH_CHECK("bp_pack");
   // the pad k rows of dy (PO .. 16 KBY) must be finite: zero the operand once; every other operand element that is read
   // with a non-zero weight is written by the sweep (pad batch lanes only ever feed pad batch columns)
   ZTRY(k_fill(w.bp_opy, (long)T * KBY * 512, 0.f, s));
+  return 0;
+}
+int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
+               const float* pose, const float* rpos, const float* rrot, const float* dpose, const float* drpos,
+               const float* drrot, hipStream_t s, bool packed) {
+  const int B = d.B, T = d.T, H = d.H, KBY = (d.PO + 15) / 16;
+  int dev = 0, ncu = 0;
+  ZCHECK(hipGetDevice(&dev) == hipSuccess, "hipGetDevice failed");
+  ZCHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess, "device query failed");
+  ZCHECK(ncu >= BNCU, "persistent BPTT sweep needs %d CUs (device has %d)", BNCU, ncu);
+  if (!packed) ZTRY(dec_bp_pack(d, P, w, s));
   float* dyl = w.DY + (long)(T - 1) * B * w.POL;
   hipLaunchKernelGGL(bp_dy_last_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, gaze, pose, rpos, rrot, w.carry,
                      dyl, w.POL);

@@ -187,6 +187,7 @@ class TrainEngine:
         lo = sum(p.numel() for p in speech_encoder.parameters())
         self._dec_range = (lo, lo + sum(p.numel() for p in decoder.parameters()))
         self._dec_work = None
+        self._dec_shape = None              # (B, speech width, style width) of the last decoder call: what to prepare for
         self.opt = RAdam(self.params, lr=lr, eps=eps)
         self.opt.attach_flat(self.flat_p, self.flat_g)
         self.iteration = 0
@@ -217,6 +218,11 @@ class TrainEngine:
         ops.set_wgrad_stream(self.wgrad_stream)
         try:
             cur = torch.cuda.current_stream() if self.aux_stream is not None else None
+            if self.wgrad_stream is not None and self._dec_shape is not None and self._dec_shape[0] == len(idx):
+                # the weight-only packs of the decoder sweeps, beside the encoders' forward
+                Bd, SP, ST = self._dec_shape
+                ops.decoder_prepare(self.de, Bd, T, SP, ST, ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, self.dt,
+                                    self.wgrad_stream)
             if self.aux_stream is not None:
                 self.aux_stream.wait_stream(cur)            # the batch was gathered on the current stream
                 b["audio"].record_stream(self.aux_stream)
@@ -237,6 +243,7 @@ class TrainEngine:
             if self.decoder_fwd_events is not None:
                 e0 = ev()
                 e0.record()
+            self._dec_shape = (speech.shape[0], speech.shape[2], style.shape[2])
             pose, orp, orr = ops.decoder_core(self.de, b["pose0"], b["rpos0"], b["rrot0"], b["gaze"], speech, style,
                                               ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, self.dt)
             if self.decoder_fwd_events is not None:

@@ -162,10 +162,12 @@ def side_stream(device=None):
 
 
 def set_wgrad_stream(stream):
-    """Engine hook (direct-gradient mode only): the decoder backward leaves the weight-gradient GEMMs of its recurrent layers
-    to `stream` (zeggs_decoder_wgrads), where they run beside the encoders' backward; the CALLER joins (`wait_stream`) before
-    it reads a decoder gradient.  None: everything on the current stream."""
+    """Engine hook (direct-gradient mode only): `stream` = side_stream(): the decoder backward lets the library run the
+    weight-gradient GEMMs of its recurrent layers there (option "defer_wgrads"), beside the encoders' backward; the CALLER
+    joins (`wait_stream`) before it reads a decoder gradient.  None: everything on the current stream."""
     global _WGRAD_STREAM
+    if stream is not None and stream.cuda_stream != side_stream(stream.device).cuda_stream:
+        raise ValueError("set_wgrad_stream: the stream must be ops.side_stream() (the library enqueues the GEMMs itself)")
     _WGRAD_STREAM = stream
 
 
@@ -440,6 +442,37 @@ def decoder_param_list(dec):
     return ps
 
 
+_PREPARED = None
+
+
+def decoder_prepare(dec, B, T, SP, ST, in_mean, in_std, out_mean, out_std, dt, stream):
+    """Weight-only preparation of the NEXT training-mode decoder_core call with these dimensions (zeggs_decoder_prepare) on
+    `stream`, beside whatever the current stream does meanwhile (the encoders' forward); that call picks the prepared
+    workspace up and waits for it.  The weights must not change in between."""
+    global _PREPARED
+    _PREPARED = None
+    params = [_f32c(t) for t in decoder_param_list(dec)]
+    stats = [_f32c(t) for t in (in_mean, in_std, out_mean, out_std)]
+    PO, H = int(stats[2].numel()), dec.recurrent_decoder.layer1.hidden_size
+    d = DecDims(int(B), int(T), PO + 3, PO, int(SP), int(ST), H, float(dt), 1 if len(params) == len(DEC_FIELDS) else 0)
+    L = lib()
+    ws = _ws(L.zeggs_decoder_workspace_bytes(C.byref(d), 1), params[0].device)
+    P = _ptrs(DecPtrs, DEC_FIELDS, params)
+    S = _ptrs(DecStats, ("in_mean", "in_std", "out_mean", "out_std"), stats)
+    stream.wait_stream(torch.cuda.current_stream())       # the optimizer step that produced these weights
+    ws.record_stream(stream)
+    with torch.cuda.stream(stream):
+        mask = L.zeggs_decoder_prepare(C.byref(d), C.byref(P), C.byref(S), _p(ws), C.c_size_t(ws.numel()),
+                                       C.c_void_p(stream.cuda_stream))
+        _check(min(mask, 0), "decoder_prepare")
+        ev = torch.cuda.Event()
+        ev.record(stream)
+    if mask > 0:
+        key = (d.B, d.T, d.PI, d.PO, d.SP, d.ST, d.H, d.film, tuple(t.data_ptr() for t in params))
+        _PREPARED = (key, ws, ev, int(mask))
+    return int(mask)
+
+
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt, H, grad_mode,
@@ -454,20 +487,35 @@ class _DecoderFn(torch.autograd.Function):
         training = bool(grad_mode) and any(ctx.needs_input_grad)
         d = DecDims(B, T, PO + 3, PO, SP, ST, H, float(dt), 1 if len(params) == len(DEC_FIELDS) else 0)
         L = lib()
-        ws = _ws(L.zeggs_decoder_workspace_bytes(C.byref(d), int(training)), pose0.device)
+        global _PREPARED
+        prep, _PREPARED = _PREPARED, None
+        mask = 0
+        if prep is not None and training and prep[0] == (d.B, d.T, d.PI, d.PO, d.SP, d.ST, d.H, d.film,
+                                                         tuple(t.data_ptr() for t in params)):
+            _, ws, ev, mask = prep                          # packs of this step's weights, made on a second stream
+            torch.cuda.current_stream().wait_event(ev)
+        else:
+            ws = _ws(L.zeggs_decoder_workspace_bytes(C.byref(d), int(training)), pose0.device)
         dev = pose0.device
         pose = torch.empty(B, T, PO, device=dev, dtype=torch.float32)
         rpos = torch.empty(B, T, 3, device=dev, dtype=torch.float32)
         rrot = torch.empty(B, T, 4, device=dev, dtype=torch.float32)
         P = _ptrs(DecPtrs, DEC_FIELDS, params)
         S = _ptrs(DecStats, ("in_mean", "in_std", "out_mean", "out_std"), stats)
-        _check(L.zeggs_decoder_fwd(C.byref(d), C.byref(P), C.byref(S), _p(pose0), _p(rpos0), _p(rrot0), _p(gaze),
-                                   _p(speech), _p(style), _p(pose), _p(rpos), _p(rrot), int(training), _p(ws),
-                                   C.c_size_t(ws.numel()), _stream()), "decoder_fwd")
+        if mask & 1:
+            _check(L.zeggs_set_option(b"fwd_prepared", 1), "set_option")
+        try:
+            _check(L.zeggs_decoder_fwd(C.byref(d), C.byref(P), C.byref(S), _p(pose0), _p(rpos0), _p(rrot0), _p(gaze),
+                                       _p(speech), _p(style), _p(pose), _p(rpos), _p(rrot), int(training), _p(ws),
+                                       C.c_size_t(ws.numel()), _stream()), "decoder_fwd")
+        finally:
+            if mask & 1:
+                _check(L.zeggs_set_option(b"fwd_prepared", 0), "set_option")
         global _LAST_DECODER_WS
         _LAST_DECODER_WS = (d, int(training), ws)
         if training:
             ctx.d, ctx.ws = d, ws
+            ctx.bwd_prepared = bool(mask & 2)
             ctx.save_for_backward(gaze, pose, rpos, rrot, *stats, *params)
             ctx.set_materialize_grads(False)      # missing output gradients are zero-filled by our own kernel in backward
         return pose, rpos, rrot
@@ -491,6 +539,8 @@ class _DecoderFn(torch.autograd.Function):
         side = _WGRAD_STREAM if direct and not torch.cuda.is_current_stream_capturing() else None
         if side is not None:
             _check(L.zeggs_set_option(b"defer_wgrads", 1), "set_option")
+        if ctx.bwd_prepared:
+            _check(L.zeggs_set_option(b"bwd_prepared", 1), "set_option")
         try:
             _check(L.zeggs_decoder_bwd(C.byref(d), C.byref(P), C.byref(S), _p(gaze), _p(pose), _p(rpos), _p(rrot),
                                        _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
@@ -498,15 +548,15 @@ class _DecoderFn(torch.autograd.Function):
         finally:
             if side is not None:
                 _check(L.zeggs_set_option(b"defer_wgrads", 0), "set_option")
+            if ctx.bwd_prepared:
+                _check(L.zeggs_set_option(b"bwd_prepared", 0), "set_option")
         if side is not None:
-            # the recurrent layers' weight gradients read only what the sweep left in the workspace: second stream, beside
-            # the CellStateEncoder / encoder backward that follows on this one
-            side.wait_stream(torch.cuda.current_stream())
+            # the library has put the recurrent layers' weight-gradient GEMMs on its second stream (they read only what the
+            # sweep left in the workspace), beside the CellStateEncoder / encoder backward on this one
             ctx.ws.record_stream(side)
-            with torch.cuda.stream(side):
-                _check(L.zeggs_decoder_wgrads(C.byref(d), C.byref(G), _p(ctx.ws), C.c_size_t(ctx.ws.numel()),
-                                              C.c_void_p(side.cuda_stream)), "decoder_wgrads")
-                if _AFTER_DECODER_BWD is not None:
+            if _AFTER_DECODER_BWD is not None:
+                side.wait_stream(torch.cuda.current_stream())       # the bias sums stayed on this stream
+                with torch.cuda.stream(side):
                     _AFTER_DECODER_BWD()          # (the collective it starts is ordered after the GEMMs of `side`)
         elif _AFTER_DECODER_BWD is not None and direct:
             _AFTER_DECODER_BWD()
