@@ -352,6 +352,7 @@ def main():
                     help="ONE blocking all-reduce after the backward instead of the overlapped decoder-slice exchange")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
                     help="decoder weight-gradient GEMMs on the main stream instead of beside the encoders' backward")
+    ap.add_argument("--no-prefetch", action="store_true", help="gather every batch at the start of its own step")
     ap.add_argument("--no-extras", action="store_true", help="skip decode / decode_30min / v2_label_b64 (N = 1 only)")
     ap.add_argument("--force-process-group", action="store_true",
                     help="initialise the RCCL process group and run the gradient all-reduce even at --gpus 1")
@@ -415,14 +416,18 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for it in range(a.warmup):
-        eng.step(indices(it), EXAMPLE_LEN)
+    def run(first, last):       # steps first .. last-1; the next batch is gathered beside the current step (never across `last`:
+        for it in range(first, last):                       # the timed region gathers exactly its own K batches)
+            eng.step(indices(it), EXAMPLE_LEN)
+            if it + 1 < last and not (a.no_wgrad_overlap or a.no_prefetch):
+                eng.prefetch(indices(it + 1), EXAMPLE_LEN)
+
+    run(0, a.warmup)
     sync()
     eng.allreduce_events = [] if use_pg else None
     sync()
     t0 = time.perf_counter()
-    for it in range(a.warmup, a.warmup + a.steps):
-        eng.step(indices(it), EXAMPLE_LEN)
+    run(a.warmup, a.warmup + a.steps)
     sync()
     mine = time.perf_counter() - t0
     fwd_in, bwd_in = sweep_ms(0), sweep_ms(1)               # the LAST timed iteration's stage sweeps (HIP events)

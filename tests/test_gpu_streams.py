@@ -25,6 +25,9 @@ def _run(overlap, steps=4, B=8, T=24, L=32):
         eps = torch.randn(B, 64, generator=gen).to(dev)
         idx = engine.shard_indices(perm, k, B, 1, 0)
         losses.append(eng.step(idx, L, eps=eps))
+        if overlap and k + 1 < steps:
+            eng.prefetch(engine.shard_indices(perm, k + 1, B, 1, 0), L)      # picked up by the next step
+            assert eng._prefetched is not None
     torch.cuda.synchronize()
     return eng.flat_p.detach().cpu().numpy().copy(), [float(x.detach()) for x in losses]
 

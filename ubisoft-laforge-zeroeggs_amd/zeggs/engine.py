@@ -16,6 +16,38 @@ from .modules import kl_div_weight
 from .optimizers import RAdam
 
 
+class _IndexUploader:
+    """Host -> device copies of the (small) index arrays of a batch through a ring of PINNED staging buffers: a copy from
+    pageable memory blocks the host until everything queued before it on the stream has finished, i.e. once per step the
+    host would fall in line with the GPU and then feed the ~100 small launches in front of the forward rollout one at a
+    time.  A slot is reused only after the copy out of it has completed (event)."""
+
+    SLOTS = 8
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.slots = [None] * self.SLOTS          # (pinned int64 buffer, event of its last copy)
+        self.k = 0
+
+    def __call__(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.int64)
+        if self.device.type != "cuda":
+            return torch.as_tensor(arr).to(self.device)
+        i, self.k = self.k % self.SLOTS, self.k + 1
+        buf, ev = self.slots[i] if self.slots[i] is not None else (None, None)
+        if ev is not None:
+            ev.synchronize()
+        if buf is None or buf.numel() < arr.size:
+            buf = torch.empty(max(arr.size, 1024), dtype=torch.int64).pin_memory()
+        host = buf[:arr.size].view(arr.shape)
+        host.copy_(torch.from_numpy(arr))
+        out = host.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.slots[i] = (buf, ev)
+        return out
+
+
 class DeviceDataset:
     """The arrays of processed_data.npz resident in HBM (reference dataset.py:41-96 keeps them on the host)."""
 
@@ -25,6 +57,7 @@ class DeviceDataset:
         self.n_frames = n
         self.window = window
         self.device = device
+        self._upload = _IndexUploader(device)
         pose = torch.cat([f("Y_root_vel").reshape(n, -1), f("Y_root_vrt").reshape(n, -1), f("Y_lpos").reshape(n, -1),
                           f("Y_ltxy").reshape(n, -1), f("Y_lvel").reshape(n, -1), f("Y_lvrt").reshape(n, -1)], dim=1)
         self.pose = pose.to(device).contiguous()                 # [N, PO] reference output-vector layout
@@ -104,7 +137,7 @@ class DeviceDataset:
         """Gather one batch (normalised where the reference normalises before the nets)."""
         dev = self.device
         B, T = len(idx), self.window
-        starts = torch.as_tensor(self.win_start[idx]).to(dev, non_blocking=True)
+        starts = self._upload(self.win_start[idx])
         out = dict(audio=ops.gather_windows(self.audio, starts, T), pose=ops.gather_windows(self.pose, starts, T),
                    rpos=ops.gather_windows(self.rpos, starts, T), rrot=ops.gather_windows(self.rrot, starts, T),
                    gaze=ops.gather_windows(self.gaze, starts, T),
@@ -113,7 +146,7 @@ class DeviceDataset:
                    rrot0=ops.gather_rows(self.rrot, starts))
         ops.normalize_rows_(out["audio"], self.audio_mean, self.audio_std)
         if example_len is not None:
-            rows = torch.as_tensor(self.example_rows(idx, example_len)).to(dev, non_blocking=True)
+            rows = self._upload(self.example_rows(idx, example_len))
             ex = ops.fill_(torch.empty(B, example_len, self.PO + 3, device=dev))      # gaze slot = 0 (dataset.py:194)
             ops.gather_rows(self.pose, rows, out=ex, out_ld=self.PO + 3)
             ops.normalize_rows_(ex, self.in_mean, self.in_std)
@@ -188,6 +221,8 @@ class TrainEngine:
         self._dec_range = (lo, lo + sum(p.numel() for p in decoder.parameters()))
         self._dec_work = None
         self._dec_shape = None              # (B, speech width, style width) of the last decoder call: what to prepare for
+        self._prefetched = None             # (key, batch, event): the next step's batch, gathered on the third stream
+        self.prefetch_hits = 0
         self.opt = RAdam(self.params, lr=lr, eps=eps)
         self.opt.attach_flat(self.flat_p, self.flat_g)
         self.iteration = 0
@@ -205,10 +240,32 @@ class TrainEngine:
         self._dec_work = torch.distributed.all_reduce(self.flat_g[lo:hi], op=torch.distributed.ReduceOp.SUM,
                                                       group=self.pg, async_op=True)
 
+    def prefetch(self, idx, example_len):
+        """Gather the batch of a LATER step now, on the third stream (beside whatever the chip is doing: the gather is a
+        handful of small copies that depend on nothing but the resident dataset).  step() picks it up if it is called with
+        the same indices.  No-op without the side streams."""
+        if self.aux_stream is None:
+            return
+        ex_len = example_len if self.style_type == "example" else None
+        with torch.cuda.stream(self.aux_stream):
+            b = self.ds.batch(idx, ex_len)
+            ev = torch.cuda.Event()
+            ev.record(self.aux_stream)
+        self._prefetched = ((np.asarray(idx).tobytes(), ex_len), b, ev)
+
     def step(self, idx, example_len, eps=None, labels=None):
         """One training iteration on window indices `idx` (this rank's slice). Returns the loss tensor (device)."""
         ds, T = self.ds, self.ds.window
-        b = ds.batch(idx, example_len if self.style_type == "example" else None)
+        ex_len = example_len if self.style_type == "example" else None
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre[0] == (np.asarray(idx).tobytes(), ex_len):
+            b = pre[1]
+            self.prefetch_hits += 1
+            torch.cuda.current_stream().wait_event(pre[2])
+            for t in b.values():
+                t.record_stream(torch.cuda.current_stream())
+        else:
+            b = ds.batch(idx, ex_len)
         ops.fill_(self.flat_g)
         ops.direct_param_grads(True)        # *_bwd kernels write straight into the flat gradient buffer
         overlap = self.overlap_allreduce and (self.world > 1 or self.force_allreduce)

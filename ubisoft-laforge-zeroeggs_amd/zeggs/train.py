@@ -195,6 +195,8 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
             # the example length of the NEXT iteration (train.py:228); seeded here so that all ranks agree
             example_len = 2 * random.Random(train_options["seed"] * 1000003 + iteration).randint(
                 st_opt["example_length"] // 2, st_opt["example_length"])
+            if bi + 1 < nb:         # the next batch is gathered on a side stream while this iteration is still running
+                eng.prefetch(engine.shard_indices(perm, bi + 1, batchsize, world, rank), example_len)
             if (iteration + 1) % 1000 == 0:
                 for g in eng.opt.param_groups:
                     g["lr"] *= train_options["learning_rate_decay"]
