@@ -62,6 +62,9 @@ __device__ __forceinline__ void load_full(float (&r)[E], const float* p) {
   }
 }
 
+#ifndef ZEGGS_GEMM_SWIZZLE
+#define ZEGGS_GEMM_SWIZZLE 1
+#endif
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   constexpr int NT = WM * WN * 64;
@@ -75,8 +78,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m_base = blockIdx.y * BM, n_base = blockIdx.x * BN;
-  const int zz = blockIdx.z;
+  // Tile order.  Workgroups go to the 8 XCDs round-robin in launch order, and every XCD has its own L2: XCD k takes the k-th
+  // CONTIGUOUS eighth of the tile list instead of every eighth tile, and within a k-split the list walks groups of GEMM_GM tile
+  // rows column by column, so the tiles in flight on an XCD share a few A row panels and B column panels.
+  int bx = blockIdx.x, by = blockIdx.y, zz = blockIdx.z;
+  if (ZEGGS_GEMM_SWIZZLE) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, plane = gx * gy, total = plane * gridDim.z;
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = L & 7, idx = L >> 3, q = total >> 3, r = total & 7;
+    const unsigned Lp = xcd * q + (xcd < r ? xcd : r) + idx;
+    const unsigned pid = Lp % plane;
+    zz = (int)(Lp / plane);
+    constexpr unsigned GM = 4;
+    const unsigned width = GM * gx, group = pid / width, first = group * GM, gsz = gy - first < GM ? gy - first : GM;
+    by = (int)(first + (pid % width) % gsz);
+    bx = (int)((pid % width) / gsz);
+  }
+  const int m_base = by * BM, n_base = bx * BN;
   const int z = zz / g.splitk, ks = zz % g.splitk;
   const long z0 = z / g.nb1, z1 = z % g.nb1;
   const float* A = g.A + z0 * g.bsA0 + z1 * g.bsA1;
