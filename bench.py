@@ -498,6 +498,10 @@ def main():
             out["allreduce_note"] = ("allreduce_ms = the EXPOSED part: the decoder slice (91 % of the payload) is reduced "
                                      "underneath the encoders' backward" if eng.overlap_allreduce else
                                      "one blocking all-reduce of the flat gradient buffer after the backward")
+        out["streams"] = ("single stream" if eng.wgrad_stream is None else
+                          "decoder weight-gradient GEMMs and the weight-only packs of the next sweeps on the library's second "
+                          "stream, speech encoder and the next batch's gather on a third"
+                          + ("" if not a.no_prefetch else " (no batch prefetch)"))
         out["cpu_baseline"] = None
         if world == 1 and not a.no_extras:
             out["decode"] = decode_rate(de, dev)
