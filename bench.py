@@ -16,6 +16,7 @@ the other BASELINE.json configs as extra keys: `decode` (B=1, 1800 frames), `dec
 `v2_label_b64` (configs[3]) and the CPU baselines.
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -24,8 +25,10 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # three engine streams + RCCL's: see zeggs/__init__.py (before HIP initialises)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 for p in (ROOT, ROOT / "ubisoft-laforge-zeroeggs_amd"):
@@ -515,9 +518,17 @@ def main():
             if "decode" in out:
                 out["decode"]["cpu_baseline"] = dec_b
             out["mel_cpu_baseline"] = mel_b
-        print(json.dumps(out))
+    # RCCL writes its version banner through C stdio, which a pipe buffers until exit: every rank pushes it out BEFORE the last
+    # barrier, so that rank 0's JSON line is the last thing on stdout
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
     if use_pg:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
