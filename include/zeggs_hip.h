@@ -202,7 +202,11 @@ int zeggs_decoder_bwd(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDec
  * joining: they run beside the CellStateEncoder backward and whatever the caller enqueues next (the encoders' backward).
  * The caller makes every consumer of the decoder's weight gradients (all-reduce, optimizer) wait for that stream and keeps
  * `ws` alive until then (zeggs/ops.py: _DecoderFn.backward, zeggs/engine.py).  The reference has no counterpart: its
- * autograd runs every backward op on one stream (ZEGGS/train.py:425). */
+ * autograd runs every backward op on one stream (ZEGGS/train.py:425).
+ * "defer_wgrads" = 2 (data-parallel runs): only the GEMMs of layer2 and GRU layer 1 are enqueued there -- with the bias sums
+ * and the CellStateEncoder gradients that is the SECOND half of the decoder's parameters in module order; the caller starts
+ * its all-reduce and lets zeggs_decoder_wgrads(what = 4) compute the first half (GRU layer 0, layer0) underneath it. */
+int zeggs_decoder_wgrads(const ZeggsDecDims*, const ZeggsDecGrads*, void* ws, size_t ws_bytes, int what, void* stream);
 /* The weight-only preparation of a training step on `ws` (merged / folded matrices and the fragment packs of the two
  * persistent sweeps; the reference has no counterpart, its GEMMs read nn.Parameter storage directly): may run on a second
  * stream beside the encoders' forward.  Returns a bit mask, 1: zeggs_decoder_fwd may be called with option "fwd_prepared",

@@ -49,7 +49,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
     return 0;
   }
   if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
-  if (strcmp(name, "defer_wgrads") == 0) { g_defer_wgrads = value != 0; return 0; }
+  if (strcmp(name, "defer_wgrads") == 0) { g_defer_wgrads = value < 0 ? 0 : value; return 0; }   // 1: all GEMMs, 2: first half only
   if (strcmp(name, "fwd_prepared") == 0) { g_fwd_prepared = value != 0; return 0; }
   if (strcmp(name, "bwd_prepared") == 0) { g_bwd_prepared = value != 0; return 0; }
   zeggs_set_error("unknown option %s", name);
@@ -362,9 +362,11 @@ __global__ void add_style0_grad_k(ZeggsDecDims d, const float* dcse_in, float* d
 // weight gradients of the recurrent part for the steps t_lo..t_hi: contraction over the flattened (t, b) rows
 // compact != 0 (fast path): DH0 / DH1 hold only the n rows of the hidden-side gate gradients, [T][B][H]; their r, z rows
 // are the r, z rows of DI0 / DI1.
-// what: 1 = the weight gradients (GEMMs), 2 = the bias gradients (column sums), 3 = both
+// what: 1 = weight gradients (GEMMs) of layer2 and GRU layer 1, 4 = of GRU layer 0 and layer0 (the two halves of the decoder's
+// slice of a flat gradient buffer in parameter order: the caller can all-reduce the first while the second is computed),
+// 2 = the bias gradients (column sums); 7 = everything
 int dec_recurrent_wgrads(const ZeggsDecDims& d, const DecWs& w, const ZeggsDecGrads* G, int t_lo, int t_hi, float beta,
-                         int compact, hipStream_t s, int what = 3) {
+                         int compact, hipStream_t s, int what = 7) {
   const int B = d.B, H = d.H, GL = w.GL, XD = w.XD, POL = w.POL;
   const long sG = (long)B * GL, sH = (long)B * H, s3 = 3 * sH, sY = (long)B * POL;
   const int M = (t_hi - t_lo + 1) * B;
@@ -394,18 +396,18 @@ int dec_recurrent_wgrads(const ZeggsDecDims& d, const DecWs& w, const ZeggsDecGr
     if (what & 1) ZTRY(gemm_tn(w.DH1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, M, 3 * H, H, beta, s));
     if (what & 2) ZTRY(k_colsum(G->b_hh1, w.DH1 + o * s3, M, 3 * H, 3 * H, beta, s));
   }
-  if (what & 1) ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.Gin + o * sG, GL, G->w_ih0, H + XD, M, 3 * H, H + XD, beta, s));
+  if (what & 4) ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.Gin + o * sG, GL, G->w_ih0, H + XD, M, 3 * H, H + XD, beta, s));
   if (what & 2) ZTRY(k_colsum(G->b_ih0, w.DI0 + o * s3, M, 3 * H, 3 * H, beta, s));
   if (compact) {
-    if (what & 1) ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 2 * H, H, beta, s));
-    if (what & 1) ZTRY(gemm_tn(w.DH0 + o * sH, H, w.H0 + (o - 1) * sH, H, G->w_hh0 + 2L * H * H, H, M, H, H, beta, s));
+    if (what & 4) ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 2 * H, H, beta, s));
+    if (what & 4) ZTRY(gemm_tn(w.DH0 + o * sH, H, w.H0 + (o - 1) * sH, H, G->w_hh0 + 2L * H * H, H, M, H, H, beta, s));
     if (what & 2) ZTRY(k_colsum(G->b_hh0, w.DI0 + o * s3, M, 2 * H, 3 * H, beta, s));
     if (what & 2) ZTRY(k_colsum(G->b_hh0 + 2 * H, w.DH0 + o * sH, M, H, H, beta, s));
   } else {
-    if (what & 1) ZTRY(gemm_tn(w.DH0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 3 * H, H, beta, s));
+    if (what & 4) ZTRY(gemm_tn(w.DH0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 3 * H, H, beta, s));
     if (what & 2) ZTRY(k_colsum(G->b_hh0, w.DH0 + o * s3, M, 3 * H, 3 * H, beta, s));
   }
-  if (what & 1) ZTRY(gemm_tn(w.D0 + o * sH, H, w.Gin + o * sG + H, GL, G->l0_w, XD, M, H, XD, beta, s));
+  if (what & 4) ZTRY(gemm_tn(w.D0 + o * sH, H, w.Gin + o * sG + H, GL, G->l0_w, XD, M, H, XD, beta, s));
   if (what & 2) ZTRY(k_colsum(G->l0_b, w.D0 + o * sH, M, H, H, beta, s));
   return 0;
 }
@@ -666,6 +668,18 @@ extern "C" int zeggs_decoder_chain_stamps(const ZeggsDecDims* dp, int training, 
   return 0;
 }
 
+// Second half of the deferred weight gradients (option "defer_wgrads" = 2): the GEMMs of GRU layer 0 and layer0 (what = 4) on the
+// caller's stream -- normally zeggs_side_stream again, behind the first half and the all-reduce the caller has started on it.
+extern "C" int zeggs_decoder_wgrads(const ZeggsDecDims* dp, const ZeggsDecGrads* G, void* ws, size_t ws_bytes, int what,
+                                    void* stream) {
+  const ZeggsDecDims& d = *dp;
+  Arena a(ws, ws_bytes);
+  DecWs w = carve_dec(d, 1, a);
+  ZCHECK(a.ok(), "decoder wgrads: workspace too small (was the forward run with training=1?)");
+  ZCHECK(d.T > 1, "decoder wgrads: T must be > 1");
+  const bool fast_path = g_decoder_fast && dec_fast_supported(d);
+  return dec_recurrent_wgrads(d, w, G, 1, d.T - 1, 0.f, fast_path ? 1 : 0, (hipStream_t)stream, what & 5);
+}
 // Everything the two persistent sweeps of a training step need that depends on the WEIGHTS only (the merged / folded
 // matrices, the per-workgroup fragment packs of both kernels): the caller may run it on a second stream beside the encoders'
 // forward and passes "fwd_prepared" / "bwd_prepared" to the calls that follow on the same workspace.  Returns a bit mask
@@ -820,7 +834,9 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
     ZTRY(side_stream(&ss));
     ZCHECK(hipEventRecord(ss->chunk, s) == hipSuccess, "hipEventRecord failed");
     ZCHECK(hipStreamWaitEvent(ss->s, ss->chunk, 0) == hipSuccess, "hipStreamWaitEvent failed");
-    ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, ss->s, 1));
+    // (value 2: only the first half of the parameter order here -- the caller all-reduces it while zeggs_decoder_wgrads
+    //  computes the second half)
+    ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, ss->s, g_defer_wgrads == 2 ? 1 : 5));
     deferred = true;
   } else if (!wgrads_done) {
     ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, s));

@@ -219,6 +219,11 @@ class TrainEngine:
         # backward returns, 91 % of the payload, while the encoders' backward still has to run
         lo = sum(p.numel() for p in speech_encoder.parameters())
         self._dec_range = (lo, lo + sum(p.numel() for p in decoder.parameters()))
+        # ... in two halves when the weight-gradient GEMMs run on the side stream: [lo, split) = layer0 + GRU layer 0 is computed
+        # last (ops._DecoderFn.backward), underneath the exchange of [split, hi)
+        names = [n for n, _ in decoder.named_parameters()]
+        cut = names.index("recurrent_decoder.layer1.weight_ih_l1") if "recurrent_decoder.layer1.weight_ih_l1" in names else 0
+        self._dec_split = lo + sum(p.numel() for p in list(decoder.parameters())[:cut])
         self._dec_work = None
         self._dec_shape = None              # (B, speech width, style width) of the last decoder call: what to prepare for
         self._prefetched = None             # (key, batch, event): the next step's batch, gathered on the third stream
@@ -232,13 +237,16 @@ class TrainEngine:
         self.allreduce_events = None        # bench.py: (start, end) HIP events around the gradient all-reduce
         self._one = torch.ones((), device=dev, dtype=torch.float32)     # upstream gradient of loss.backward()
 
-    def _reduce_decoder_grads(self):
-        """ops hook (after the decoder backward was enqueued): start the all-reduce of the decoder's gradient slice; it
-        runs on the process group's stream, ordered after the kernels already on the current stream, underneath the
-        encoders' backward.  Same collective sequence on every rank: decoder slice, then the encoder slices."""
+    def _reduce_decoder_grads(self, part=None):
+        """ops hook (decoder gradients final in stream order): start the all-reduce of the decoder's gradient slice -- all of
+        it (part None), or its second / first half in parameter order (part 0 / 1, ops.set_after_decoder_backward); it runs on
+        the process group's stream, ordered after the kernels already on the current stream, underneath the encoders'
+        backward.  Same collective sequence on every rank: decoder slice(s), then the encoder slices."""
         lo, hi = self._dec_range
-        self._dec_work = torch.distributed.all_reduce(self.flat_g[lo:hi], op=torch.distributed.ReduceOp.SUM,
-                                                      group=self.pg, async_op=True)
+        a, b = (lo, hi) if part is None else (self._dec_split, hi) if part == 0 else (lo, self._dec_split)
+        if b > a:
+            self._dec_work = (self._dec_work or []) + [torch.distributed.all_reduce(
+                self.flat_g[a:b], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)]
 
     def prefetch(self, idx, example_len):
         """Gather the batch of a LATER step now, on the third stream (beside whatever the chip is doing: the gather is a
@@ -333,7 +341,7 @@ class TrainEngine:
         if self._dec_work is not None:
             # the decoder slice has been in flight since the decoder backward returned; now the encoders' slices
             lo, hi = self._dec_range
-            works = [self._dec_work]
+            works = list(self._dec_work)
             for part in (self.flat_g[:lo], self.flat_g[hi:]):
                 if part.numel():
                     works.append(torch.distributed.all_reduce(part, op=torch.distributed.ReduceOp.SUM, group=self.pg,

@@ -138,9 +138,11 @@ _AFTER_DECODER_BWD = None
 
 
 def set_after_decoder_backward(fn):
-    """Engine hook: `fn()` runs right after zeggs_decoder_bwd has been enqueued in direct-gradient mode, i.e. when
-    every decoder parameter gradient of the iteration is final in stream order (the encoders' backward follows).
-    engine.TrainEngine starts the all-reduce of the decoder's slice of the flat gradient buffer there."""
+    """Engine hook: `fn(part)` runs when decoder parameter gradients of the iteration are final in stream order (the encoders'
+    backward follows) and engine.TrainEngine starts their all-reduce: part None = all of them (single-stream schedule, right
+    after zeggs_decoder_bwd); with the weight-gradient GEMMs on the side stream, part 0 = the parameters from GRU layer 1 on
+    in module order (layer2, CellStateEncoder), then part 1 = layer0 and GRU layer 0, whose GEMMs run underneath part 0's
+    exchange."""
     global _AFTER_DECODER_BWD
     _AFTER_DECODER_BWD = fn
 
@@ -537,8 +539,11 @@ class _DecoderFn(torch.autograd.Function):
         S = _ptrs(DecStats, ("in_mean", "in_std", "out_mean", "out_std"), stats)
         direct = _DIRECT_GRADS and all(r is None for r in rets)
         side = _WGRAD_STREAM if direct and not torch.cuda.is_current_stream_capturing() else None
+        # with a gradient exchange waiting (engine hook) the deferred GEMMs come in two halves of the parameter order, so that
+        # the all-reduce of one runs underneath the GEMMs of the other
+        chunked = side is not None and _AFTER_DECODER_BWD is not None
         if side is not None:
-            _check(L.zeggs_set_option(b"defer_wgrads", 1), "set_option")
+            _check(L.zeggs_set_option(b"defer_wgrads", 2 if chunked else 1), "set_option")
         if ctx.bwd_prepared:
             _check(L.zeggs_set_option(b"bwd_prepared", 1), "set_option")
         try:
@@ -554,12 +559,15 @@ class _DecoderFn(torch.autograd.Function):
             # the library has put the recurrent layers' weight-gradient GEMMs on its second stream (they read only what the
             # sweep left in the workspace), beside the CellStateEncoder / encoder backward on this one
             ctx.ws.record_stream(side)
-            if _AFTER_DECODER_BWD is not None:
-                side.wait_stream(torch.cuda.current_stream())       # the bias sums stayed on this stream
+            if chunked:
+                side.wait_stream(torch.cuda.current_stream())       # the bias sums / CellStateEncoder gradients stayed on this stream
                 with torch.cuda.stream(side):
-                    _AFTER_DECODER_BWD()          # (the collective it starts is ordered after the GEMMs of `side`)
+                    _AFTER_DECODER_BWD(0)         # layer2, GRU layer 1, CellStateEncoder: final behind the GEMMs already on `side`
+                    _check(L.zeggs_decoder_wgrads(C.byref(d), C.byref(G), _p(ctx.ws), C.c_size_t(ctx.ws.numel()), 4,
+                                                  C.c_void_p(side.cuda_stream)), "decoder_wgrads")
+                    _AFTER_DECODER_BWD(1)         # layer0, GRU layer 0
         elif _AFTER_DECODER_BWD is not None and direct:
-            _AFTER_DECODER_BWD()
+            _AFTER_DECODER_BWD(None)
         return (None, None, None, None, dspeech, dstyle, None, None, None, None, None, None, None, *rets)
 
 
