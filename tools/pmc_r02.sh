@@ -18,6 +18,6 @@ done
 python $R/tools/rocpd_pmc2.py $(find $O/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $O/pmc_WRITE_SIZE -name "*.db" | head -1) $O/r02_decoder_step_pmc.json
 rm -rf $O/ks $O/ks2 $O/ks3 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 # one training iteration as a timeline (start offset, duration, queue of every dispatch) + how much of it ran concurrently
-rm -rf $O/tl; rocprofv3 --kernel-trace -d $O/tl -o k -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $O/tl.log 2>&1
+rm -rf $O/tl; rocprofv3 --kernel-trace -d $O/tl -o k -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $O/tl.log 2>&1
 python $R/tools/rocpd_timeline.py $(find $O/tl -name "*.db" | head -1) $O/r02_iteration_timeline.csv 2> $O/r02_iteration_timeline_summary.txt
 rm -rf $O/tl

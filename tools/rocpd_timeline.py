@@ -16,8 +16,11 @@ rows = list(db.execute(f"select {name}, {gx}, {st}, {en}, {qid if qid else 0} fr
 rad = [i for i, r in enumerate(rows) if "radam_k" in r[0]]
 if len(rad) < 2:
     sys.exit("need two radam_k dispatches")
-it = rows[rad[-2] + 1: rad[-1] + 1]
-t0 = rows[rad[-2]][3]
+# the shortest of the last few iterations (the bench's trailing iterations are separated by host-side event reads)
+pairs = list(zip(rad[-6:-1], rad[-5:]))
+lo, hi = min(pairs, key=lambda ab: rows[ab[1]][3] - rows[ab[0]][3])
+it = rows[lo + 1: hi + 1]
+t0 = rows[lo][3]
 out = csv.writer(open(sys.argv[2], "w", newline="") if len(sys.argv) > 2 else sys.stdout)
 out.writerow(["start_us", "dur_us", "queue", "grid_x", "kernel"])
 for n, g, s, e, q in it:

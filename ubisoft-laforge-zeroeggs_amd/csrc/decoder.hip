@@ -827,17 +827,17 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   }
   // ---- weight gradients of the recurrent layers.  Option "defer_wgrads": the seven large GEMMs (K = B (T-1), they read only
   // what the sweep saved) start NOW on the library's second stream, beside the CellStateEncoder backward below and whatever the
-  // caller enqueues on `s` after this call (the encoders' backward); the small bias sums stay on `s`.  No join here: the
-  // caller makes every consumer of the decoder gradients wait for zeggs_side_stream.
-  bool deferred = false;
+  // caller enqueues on `s` after this call (the encoders' backward).  No join here: the caller makes every consumer of the
+  // decoder gradients wait for zeggs_side_stream.
   if (!wgrads_done && g_defer_wgrads && cap == hipStreamCaptureStatusNone) {
     ZTRY(side_stream(&ss));
     ZCHECK(hipEventRecord(ss->chunk, s) == hipSuccess, "hipEventRecord failed");
     ZCHECK(hipStreamWaitEvent(ss->s, ss->chunk, 0) == hipSuccess, "hipStreamWaitEvent failed");
     // (value 2: only the first half of the parameter order here -- the caller all-reduces it while zeggs_decoder_wgrads
     //  computes the second half)
-    ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, ss->s, g_defer_wgrads == 2 ? 1 : 5));
-    deferred = true;
+    // The bias sums (a dozen column sums over the same saves) go with them: since the split-K retune the GEMMs are the shorter
+    // of the two queues.
+    ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, ss->s, (g_defer_wgrads == 2 ? 1 : 5) | 2));
   } else if (!wgrads_done) {
     ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, s));
   }
@@ -871,7 +871,6 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   }
   hipLaunchKernelGGL(add_style0_grad_k, g1((long)B * d.ST), dim3(256), 0, s, d, w.t1, dstyle);
   ZLAUNCH_CHECK("dec_bwd_tail");
-  if (deferred) ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, s, 2));     // bias sums
   if (wgrads_done) ZCHECK(hipStreamWaitEvent(s, ss->done, 0) == hipSuccess, "hipStreamWaitEvent failed");   // join
   return 0;
 }

@@ -16,7 +16,8 @@
 #include "gemm.h"
 #include "kernels.h"
 
-int g_gemm_wg_target = 3072;   // split-K aims at this many workgroups (6 per CU; measured sweep in tools/gemm_bench.py)
+int g_gemm_wg_target = 6144;   // split-K aims at this many workgroups (24 per CU = 6 rounds of 4 resident ones; sweep 1536..12288 in
+                               // tools/gemm_bench.py: 3072 -> 6144 is 10-14 % on the weight-gradient shapes, flat beyond)
 
 namespace {
 
@@ -62,11 +63,16 @@ __device__ __forceinline__ void load_full(float (&r)[E], const float* p) {
   }
 }
 
+// four workgroups (waves per SIMD) resident per CU: the compiler then keeps the 64 accumulators + operands in 101 VGPRs
+// instead of 78 + 64 AGPRs (3 per SIMD); 1-5 % on the training shapes
+#ifndef ZEGGS_GEMM_MINB
+#define ZEGGS_GEMM_MINB 4
+#endif
 #ifndef ZEGGS_GEMM_SWIZZLE
 #define ZEGGS_GEMM_SWIZZLE 1
 #endif
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(WM* WN * 64, ZEGGS_GEMM_MINB) void gemm_kernel(GemmArgs g) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MT = TM / 32, NTL = TN / 32;
@@ -293,7 +299,7 @@ int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   // few output tiles but a long contraction (weight gradients): split K over workgroups, combine with fp32 atomics
   const bool can_split = nbatch == 1 && (g.beta == 0.f || g.beta == 1.f) && g.bias == nullptr && g.act == ACT_NONE &&
                          g.scn == 1 && g.scm == g.N && ktiles >= 64;
-  if (tiles < g_gemm_wg_target * 5 / 6 && can_split) {        // aim at ~3 workgroups per CU (one wave per SIMD each)
+  if (tiles < g_gemm_wg_target * 5 / 6 && can_split) {
     long sk = (g_gemm_wg_target + tiles - 1) / tiles;
     if (sk > ktiles / 16) sk = ktiles / 16;
     if (sk > 32) sk = 32;

@@ -560,7 +560,7 @@ class _DecoderFn(torch.autograd.Function):
             # sweep left in the workspace), beside the CellStateEncoder / encoder backward on this one
             ctx.ws.record_stream(side)
             if chunked:
-                side.wait_stream(torch.cuda.current_stream())       # the bias sums / CellStateEncoder gradients stayed on this stream
+                side.wait_stream(torch.cuda.current_stream())       # the CellStateEncoder gradients come from this stream
                 with torch.cuda.stream(side):
                     _AFTER_DECODER_BWD(0)         # layer2, GRU layer 1, CellStateEncoder: final behind the GEMMs already on `side`
                     _check(L.zeggs_decoder_wgrads(C.byref(d), C.byref(G), _p(ctx.ws), C.c_size_t(ctx.ws.numel()), 4,
