@@ -10,11 +10,11 @@ from zeggs import engine, synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(overlap, steps=4, B=8, T=24, L=32):
+def _run(overlap, steps=4, B=8, T=24, L=32, clip=None):
     dev = torch.device("cuda:0")
     se, de, st = helpers.build_nets()
     se, de, st = se.to(dev).eval(), de.to(dev).eval(), st.to(dev).eval()        # eval: no dropout masks to agree on
-    data = synth.make_processed(3, 0, T + 40, seed=11)
+    data = synth.make_processed(3, 0, clip or T + 40, seed=11)
     ds = engine.DeviceDataset(data, T, dev)
     eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, overlap_wgrads=overlap)
     assert (eng.wgrad_stream is not None) == overlap and (eng.aux_stream is not None) == overlap
@@ -40,3 +40,13 @@ def test_side_streams_give_the_single_stream_weights():
     assert np.allclose(l1, l0, rtol=1e-5, atol=1e-6), (l1, l0)
     p2, _ = _run(True)                                            # and run to run
     assert np.abs(p1 - p2).max() <= 2e-6
+
+
+def test_side_streams_at_the_bench_shape():
+    """batch 32 x 256 frames, example 384 (both persistent sweeps, their packs prepared on the second stream, the next batch
+    prefetched): five optimizer steps end in the weights of the single-stream schedule"""
+    p1, l1 = _run(True, steps=5, B=32, T=256, L=384, clip=900)
+    p0, l0 = _run(False, steps=5, B=32, T=256, L=384, clip=900)
+    assert np.isfinite(p1).all() and np.isfinite(l1).all()
+    assert np.abs(p1 - p0).max() <= 5e-6, np.abs(p1 - p0).max()
+    assert np.allclose(l1, l0, rtol=2e-5, atol=1e-6), (l1, l0)
