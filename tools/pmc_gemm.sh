@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc_gemm
-ZEGGS_GEMM_BENCH_TARGETS=3072 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/pmc_gemm -o p -- python $R/tools/gemm_bench.py > $R/gpurun_out/pmc_gemm.log 2>&1
+ZEGGS_GEMM_BENCH_TARGETS=6144 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/pmc_gemm -o p -- python $R/tools/gemm_bench.py > $R/gpurun_out/pmc_gemm.log 2>&1
 python - <<PY
 import sqlite3, glob, json
 db = sqlite3.connect(glob.glob("$R/gpurun_out/pmc_gemm/**/*.db", recursive=True)[0])
