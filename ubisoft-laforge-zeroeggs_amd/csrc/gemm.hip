@@ -68,6 +68,9 @@ __device__ __forceinline__ void load_full(float (&r)[E], const float* p) {
 #ifndef ZEGGS_GEMM_MINB
 #define ZEGGS_GEMM_MINB 4
 #endif
+#ifndef ZEGGS_GEMM_HALF_TILES
+#define ZEGGS_GEMM_HALF_TILES 1
+#endif
 #ifndef ZEGGS_GEMM_SWIZZLE
 #define ZEGGS_GEMM_SWIZZLE 1
 #endif
@@ -308,6 +311,10 @@ int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
       if (g.beta == 0.f) ZTRY(k_fill(g.C, (long)g.M * g.N, 0.f, s));   // beta == 1: the atomics accumulate onto C
     }
   }
+  // 1 .. 2 tiles of 128 x 128 per CU and no split (bias / activation epilogue): half the CUs would carry two tiles, the others one;
+  // 128 x 64 tiles give every CU the same share (the style encoder's first conv: 384 -> 768 tiles)
+  if (ZEGGS_GEMM_HALF_TILES && big && g.splitk == 1 && tiles > 256 && tiles < 512 && g.N % 64 == 0)
+    return launch_cfg<128, 64, 2, 2>(g, nbatch, s);
   if (big && (tiles * g.splitk >= 128 || g.splitk > 1)) return launch_cfg<128, 128, 2, 2>(g, nbatch, s);
   return launch_cfg<64, 64, 2, 2>(g, nbatch, s);
 }
