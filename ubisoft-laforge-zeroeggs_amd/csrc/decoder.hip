@@ -568,7 +568,7 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
         ZTRY(dec_tp_pack(d, P, st, w, s));
       }
       dec_timing_mark(0, s);
-      ZTRY(dec_tp_run(d, P, st, w, gaze, speech, style, pose, rpos, rrot, s));
+      ZTRY(dec_tp_run(d, P, st, w, gaze, speech, style, pose, rpos, rrot, s, g_fwd_prepared != 0));
       dec_timing_mark(1, s);
       if (dec_tp_state() == 1) {
         if (cap == hipStreamCaptureStatusNone) { unsigned* ew = nullptr; ZTRY(dec_tp_errptr(w, &ew)); ZTRY(g_watch_train.post(ew, s)); }
@@ -696,9 +696,16 @@ extern "C" int zeggs_decoder_prepare(const ZeggsDecDims* dp, const ZeggsDecParam
   if (!(fast && d.T > 1 && g_train_persistent && dec_tp_state() == 1 && dec_tp_supported(d, w))) return 0;
   ZTRY(dec_fast_merge_prep(d, P, st, w, s));
   ZTRY(dec_tp_pack(d, P, st, w, s));
+  ZTRY(dec_tp_zero(d, w, s));
   int mask = 1;
   if (g_bwd_persistent && dec_bp_state() == 1 && dec_bp_supported(d, w)) {
     ZTRY(dec_bp_pack(d, P, w, s));
+    // ... and the zero state the backward starts from (carries, frame-0 slot of DX, arrival slots + error word)
+    ZTRY(k_fill(w.dH0c, (long)d.B * d.H, 0.f, s));
+    ZTRY(k_fill(w.dH1c, (long)d.B * d.H, 0.f, s));
+    ZTRY(k_fill(w.carry, (long)2 * d.B * 8, 0.f, s));
+    ZTRY(k_fill(w.DX, (long)d.B * w.XD, 0.f, s));
+    ZTRY(dec_bp_zero_slots(w, s));
     mask |= 2;
   }
   return mask;
@@ -722,10 +729,12 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   ZCHECK(a.ok(), "decoder bwd: workspace too small (was the forward run with training=1?)");
   const int B = d.B, T = d.T, H = d.H, GL = w.GL, XD = w.XD, CI = d.PI + d.ST, POL = w.POL;
   const long sG = (long)B * GL, sH = (long)B * H, s3 = 3 * sH;
-  ZTRY(k_fill(w.dH0c, sH, 0.f, s));
-  ZTRY(k_fill(w.dH1c, sH, 0.f, s));
-  ZTRY(k_fill(w.carry, (long)2 * B * 8, 0.f, s));
-  ZTRY(k_fill(w.DX, (long)B * XD, 0.f, s));          // slot t = 0 unused but read by the scatter
+  if (!g_bwd_prepared) {      // (zeggs_decoder_prepare has done it)
+    ZTRY(k_fill(w.dH0c, sH, 0.f, s));
+    ZTRY(k_fill(w.dH1c, sH, 0.f, s));
+    ZTRY(k_fill(w.carry, (long)2 * B * 8, 0.f, s));
+    ZTRY(k_fill(w.DX, (long)B * XD, 0.f, s));          // slot t = 0 unused but read by the scatter
+  }
   ZCHECK(T > 1, "decoder bwd: T must be > 1");
   bool wgrads_done = false;
   SideStream* ss = nullptr;

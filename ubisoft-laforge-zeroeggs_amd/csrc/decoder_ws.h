@@ -159,15 +159,18 @@ int dec_tp_supported(const ZeggsDecDims& d, const DecWs& w);
 int dec_tp_state();
 void dec_tp_set_state(int v);
 int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s);
+int dec_tp_zero(const ZeggsDecDims& d, DecWs& w, hipStream_t s);
 int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
-               const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s);
+               const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s,
+               bool zeroed = false);
 int dec_tp_errors(const DecWs& w, unsigned* out);
 int dec_tp_errptr(const DecWs& w, unsigned** out);
 // persistent BPTT sweep (train_bwd_persistent.hip)
 int dec_bp_supported(const ZeggsDecDims& d, const DecWs& w);
 int dec_bp_state();
 void dec_bp_set_state(int v);
-int dec_bp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s);      // weight tiles + operand pads (weights only)
+int dec_bp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s);
+int dec_bp_zero_slots(DecWs& w, hipStream_t s);      // weight tiles + operand pads (weights only)
 int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                const float* pose, const float* rpos, const float* rrot, const float* dpose, const float* drpos,
                const float* drrot, hipStream_t s, bool packed = false);

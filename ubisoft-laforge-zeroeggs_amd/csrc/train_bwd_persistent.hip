@@ -809,6 +809,9 @@ int dec_bp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStr
   ZTRY(k_fill(w.bp_opy, (long)T * KBY * 512, 0.f, s));
   return 0;
 }
+int dec_bp_zero_slots(DecWs& w, hipStream_t s) {        // arrival slots + error word
+  return k_fill((float*)w.bp_cnt, 2048, 0.f, s);
+}
 int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                const float* pose, const float* rpos, const float* rrot, const float* dpose, const float* drpos,
                const float* drrot, hipStream_t s, bool packed) {
@@ -822,7 +825,7 @@ int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   hipLaunchKernelGGL(bp_dy_last_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, gaze, pose, rpos, rrot, w.carry,
                      dyl, w.POL);
   ZLAUNCH_CHECK("bp_dy_last");
-  ZTRY(k_fill((float*)w.bp_cnt, 2048, 0.f, s));       // arrival slots + error word
+  if (!packed) ZTRY(dec_bp_zero_slots(w, s));         // (prepared: zeggs_decoder_prepare has zeroed them)
   dec_timing_mark(2, s);
   // batch rows are independent in the sweep: 33..64 rows run as two sweeps of <= 32 rows through the same operand buffers
   for (int b0 = 0; b0 < B; b0 += 32) {

@@ -642,8 +642,20 @@ int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSt
 }
 
 // the rollout; H0 / H1 slot 0, Gin slot 1 (hid_1 | x_1) and frame 0 of pose / rpos / rrot are prepared by the caller
+// operand buffers: zero what is read but never written (pad rows / pad columns must be finite: only the blocks with pad
+// columns -- the gaze + speech / style blocks of G0, the cond blocks of G3, the h1 slot of step 1), and the arrival slots + error
+// word.  Depends on nothing but the dimensions: zeggs_decoder_prepare runs it ahead of the forward.
+int dec_tp_zero(const ZeggsDecDims& d, DecWs& w, hipStream_t s) {
+  const int KB0 = TKB0, KB3 = 64 + w.KBC;
+  const long XB = 256L * w.NB;
+  hipLaunchKernelGGL(tp_zero_blocks_k, dim3(1024), dim3(256), 0, s, w.G0xf, (long)KB0, XB, 64, 1 + TKC, 1, d.T);
+  hipLaunchKernelGGL(tp_zero_blocks_k, dim3(256), dim3(256), 0, s, w.G0xf, (long)KB0, XB, TKH1, 64, 1, 2);
+  hipLaunchKernelGGL(tp_zero_blocks_k, dim3(1024), dim3(256), 0, s, w.G3xf, (long)KB3, XB, 64, KB3 - 64, 1, d.T);
+  ZTRY(k_fill((float*)w.tp_cnt, 2048, 0.f, s));
+  return 0;
+}
 int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
-               const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s) {
+               const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s, bool zeroed) {
   const int B = d.B, H = d.H, NB = w.NB, KB0 = TKB0, KB3 = 64 + w.KBC;
   const long XB = 256L * NB, sG = (long)B * w.GL;
   int dev = 0, ncu = 0;
@@ -652,10 +664,7 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   ZCHECK(ncu >= TNCU, "persistent training rollout needs %d CUs (device has %d)", TNCU, ncu);
   // operand buffers: zero (pad rows / pad columns must be finite), then the inputs that do not depend on the rollout
   // (only the blocks with pad columns: the gaze + speech / style blocks of G0, the cond blocks of G3, the h1 slot of step 1)
-  hipLaunchKernelGGL(tp_zero_blocks_k, dim3(1024), dim3(256), 0, s, w.G0xf, (long)KB0, XB, 64, 1 + TKC, 1, d.T);
-  hipLaunchKernelGGL(tp_zero_blocks_k, dim3(256), dim3(256), 0, s, w.G0xf, (long)KB0, XB, TKH1, 64, 1, 2);
-  hipLaunchKernelGGL(tp_zero_blocks_k, dim3(1024), dim3(256), 0, s, w.G3xf, (long)KB3, XB, 64, KB3 - 64, 1, d.T);
-  ZTRY(k_fill((float*)w.tp_cnt, 2048, 0.f, s));
+  if (!zeroed) ZTRY(dec_tp_zero(d, w, s));
   hipLaunchKernelGGL(tp_cond_k, dim3(1024), dim3(256), 0, s, d, speech, style, w.G0xf, w.G3xf, KB0, KB3, NB);
   auto conv = [&](float* xf, const float* src, long ld, int off, int K, int kofs) {
     long n = (long)B * K, g = (n + 255) / 256;
