@@ -419,11 +419,16 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    step_events = []
+
     def run(first, last):       # steps first .. last-1; the next batch is gathered beside the current step (never across `last`:
         for it in range(first, last):                       # the timed region gathers exactly its own K batches)
             eng.step(indices(it), EXAMPLE_LEN)
             if it + 1 < last and not (a.no_wgrad_overlap or a.no_prefetch):
                 eng.prefetch(indices(it + 1), EXAMPLE_LEN)
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            step_events.append(e)
 
     run(0, a.warmup)
     sync()
@@ -433,6 +438,9 @@ def main():
     run(a.warmup, a.warmup + a.steps)
     sync()
     mine = time.perf_counter() - t0
+    if os.environ.get("ZEGGS_BENCH_STEP_TIMES"):
+        print("step ends (ms since the previous):", " ".join(f"{x.elapsed_time(y):.2f}" for x, y in zip(step_events, step_events[1:])),
+              file=sys.stderr)
     fwd_in, bwd_in = sweep_ms(0), sweep_ms(1)               # the LAST timed iteration's stage sweeps (HIP events)
     el = torch.tensor([mine], device=dev, dtype=torch.float64)
     per_rank = None

@@ -20,9 +20,12 @@ class _IndexUploader:
     """Host -> device copies of the (small) index arrays of a batch through a ring of PINNED staging buffers: a copy from
     pageable memory blocks the host until everything queued before it on the stream has finished, i.e. once per step the
     host would fall in line with the GPU and then feed the ~100 small launches in front of the forward rollout one at a
-    time.  A slot is reused only after the copy out of it has completed (event)."""
+    time.  A slot is reused only after the copy out of it has completed (event) -- which also bounds how far the host runs
+    ahead: two batches with 4 slots.  That is deliberate: while the host enqueues further ahead than that (after a device
+    synchronisation it does, unthrottled) the iterations in flight measured 0.9 ms slower each (8 slots: 4 slow iterations
+    after every synchronisation, 16 slots: 7, 4 slots: 1)."""
 
-    SLOTS = 8
+    SLOTS = 4
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -333,6 +336,7 @@ class TrainEngine:
             ops.set_wgrad_stream(None)
         if self.wgrad_stream is not None:      # join: every decoder gradient is final from here on in stream order
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+            ops.release_wgrad_workspaces()
         if self.aux_stream is not None:        # ... and the speech encoder's
             torch.cuda.current_stream().wait_stream(self.aux_stream)
         if self.allreduce_events is not None:       # with the overlap on: the EXPOSED part of the exchange

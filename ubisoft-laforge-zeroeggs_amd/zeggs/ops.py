@@ -163,6 +163,15 @@ def side_stream(device=None):
     return _SIDE_STREAMS[idx]
 
 
+_WGRAD_KEEPALIVE = []
+
+
+def release_wgrad_workspaces():
+    """After the caller has made its stream wait for side_stream(): the decoder workspaces the deferred weight-gradient GEMMs
+    were reading may go back to the allocator (they were kept alive here instead of `record_stream`-ed, see decoder_prepare)."""
+    _WGRAD_KEEPALIVE.clear()
+
+
 def set_wgrad_stream(stream):
     """Engine hook (direct-gradient mode only): `stream` = side_stream(): the decoder backward lets the library run the
     weight-gradient GEMMs of its recurrent layers there (option "defer_wgrads"), beside the encoders' backward; the CALLER
@@ -462,7 +471,9 @@ def decoder_prepare(dec, B, T, SP, ST, in_mean, in_std, out_mean, out_std, dt, s
     P = _ptrs(DecPtrs, DEC_FIELDS, params)
     S = _ptrs(DecStats, ("in_mean", "in_std", "out_mean", "out_std"), stats)
     stream.wait_stream(torch.cuda.current_stream())       # the optimizer step that produced these weights
-    ws.record_stream(stream)
+    # (no record_stream: the workspace belongs to the current stream's pool and its next user there -- the forward that picks
+    #  it up, or whoever gets the block after it -- comes after a wait for `stream`; a recorded stream would park the block
+    #  in the allocator's pending list, and every device synchronisation would then cost a few iterations of re-allocation)
     with torch.cuda.stream(stream):
         mask = L.zeggs_decoder_prepare(C.byref(d), C.byref(P), C.byref(S), _p(ws), C.c_size_t(ws.numel()),
                                        C.c_void_p(stream.cuda_stream))
@@ -558,7 +569,7 @@ class _DecoderFn(torch.autograd.Function):
         if side is not None:
             # the library has put the recurrent layers' weight-gradient GEMMs on its second stream (they read only what the
             # sweep left in the workspace), beside the CellStateEncoder / encoder backward on this one
-            ctx.ws.record_stream(side)
+            _WGRAD_KEEPALIVE.append(ctx.ws)      # read by `side` until the caller joins it (release_wgrad_workspaces)
             if chunked:
                 side.wait_stream(torch.cuda.current_stream())       # the CellStateEncoder gradients come from this stream
                 with torch.cuda.stream(side):
