@@ -13,7 +13,8 @@ examples of length 384: gather -> speech encoder -> style VAE -> 255-step decode
 (RCCL all-reduce) -> fused RAdam.  Nothing is skipped or cached inside the timed region; training-mode dropout is on.
 Prints ONE JSON line on rank 0 (contract: task statement / DESIGN.md "Measurement").  At N = 1 the line also carries
 the other BASELINE.json configs as extra keys: `decode` (B=1, 1800 frames), `decode_30min` (configs[4]),
-`v2_label_b64` (configs[3]) and the CPU baselines.
+`generate_30min` (configs[4] through generate_gesture(), per-stage ms), `v2_label_b64` (configs[3]) and the CPU baselines
+(the unmodified reference timed on this box: oracle/ref_timing.py).
 """
 import argparse
 import ctypes
@@ -59,10 +60,23 @@ def step_flops(batch, style=ST):
     return 2 * batch * (H * xd + 3 * H * (H + xd) + 3 * H * H + 3 * H * H + 3 * H * H + synth.POSE_OUT * H)
 
 
-def build_dataset(n_train=64, n_unique=4, seed=0):
-    """64 two-minute 60-fps clips (n_unique distinct, tiled: the content does not affect the timing)."""
+def build_dataset(n_train=64, n_unique=4, seed=0, shared=None):
+    """64 two-minute 60-fps clips (n_unique distinct, tiled: the content does not affect the timing).
+    shared = (path, is_builder, barrier): multi-rank runs synthesise the distinct clips ONCE -- the builder rank writes them
+    to `path` (/dev/shm), the others map them after the barrier -- so that start-up does not put N copies of the generator
+    on the host's cores."""
     stats = synth.make_stats()
-    base = [synth.make_clip(CLIP_FRAMES, seed=seed * 1000 + i, stats=stats) for i in range(n_unique)]
+    if shared is not None:
+        path, is_builder, barrier = shared
+        if is_builder:
+            base = [synth.make_clip(CLIP_FRAMES, seed=seed * 1000 + i, stats=stats) for i in range(n_unique)]
+            np.savez(path, **{f"{i}.{k}": v for i, c in enumerate(base) for k, v in c.items()})
+        barrier()
+        if not is_builder:
+            z = np.load(path, mmap_mode="r")
+            base = [{k.split(".", 1)[1]: z[k] for k in z.files if k.startswith(f"{i}.")} for i in range(n_unique)]
+    else:
+        base = [synth.make_clip(CLIP_FRAMES, seed=seed * 1000 + i, stats=stats) for i in range(n_unique)]
     clips = [base[i % n_unique] for i in range(n_train)]
     data = {k: np.concatenate([c[k] for c in clips], axis=0) for k in clips[0]}
     bounds = np.arange(n_train + 1) * CLIP_FRAMES
@@ -170,20 +184,32 @@ def cpu_port_mel(seconds=10):
 
 def cpu_baselines(data):
     """`cpu_baseline` (train), plus decode / mel legs.  kind = "reference": the unmodified reference timed here
-    through oracle/ref_timing.py (only where /root/reference exists -- the build container); otherwise kind =
-    "port": the oracle restatement timed on this host's cores, next to the reference's figures recorded on the
-    build box (profiles/r02_cpu_reference.json) and the port/reference ratio measured there."""
+    through oracle/ref_timing.py -- from /root/reference in the build container, from the oracle/_ref snapshot
+    (oracle/build_ref.py, travels with the built .so) on the GPU box; only if neither exists kind = "port": the oracle
+    restatement timed on this host's cores, next to the reference's figures recorded on the build box
+    (profiles/r02_cpu_reference.json) and the port/reference ratio measured there."""
     from oracle import ref_shims
     rec_file = ROOT / "profiles" / "r02_cpu_reference.json"
     recorded = json.load(open(rec_file)) if rec_file.exists() else None
     if ref_shims.available():
+        # the reference ITSELF on this box's host cores (on the GPU box: the byte-for-byte snapshot oracle/build_ref.py left in
+        # oracle/_ref/): train() with every core (the headline baseline) and with thread_count = 1 (the shipped config value,
+        # configs_v1.json:37); bounded samples (2 + 1 steady iterations; iteration 0 = checkpoint + sample rendering is skipped)
         from oracle import ref_timing
-        r = ref_timing.measure(iters=3, frames=600, train_threads=(None,), legs=("train", "decode", "mel"))
+        ncpu = os.cpu_count() or 1
+        r = ref_timing.measure(iters=2, frames=600, train_threads=(None,), legs=("train", "decode", "mel"))
         tr = next(iter(r["train"].values()))
         train = {"value": tr["frames_per_s"], "unit": "frames/s", "cores": tr["threads"], "kind": "reference",
                  "sample": f"{tr['iterations_timed']} steady iterations of the unmodified reference train() "
-                           f"(ZEGGS/train.py:29), B={BATCH} x {WINDOW}, {np.mean(tr['s_per_iteration']):.2f} s/iteration",
-                 "cpu": r["cpu"]}
+                           f"(ZEGGS/train.py:29), B={BATCH} x {WINDOW}, {np.mean(tr['s_per_iteration']):.2f} s/iteration, "
+                           f"thread_count={tr['threads']} (all logical cores of this box)",
+                 "source": r["reference"], "cpu": r["cpu"]}
+        if ncpu > 1 and not os.environ.get("ZEGGS_BENCH_SKIP_1THREAD"):
+            r1 = ref_timing.measure(iters=1, train_threads=(1,), legs=("train",))
+            t1 = next(iter(r1["train"].values()))
+            train["thread_count_1"] = {"value": t1["frames_per_s"], "cores": 1, "iterations_timed": t1["iterations_timed"],
+                                       "s_per_iteration": round(float(np.mean(t1["s_per_iteration"])), 2),
+                                       "note": "the shipped configs_v1.json value (thread_count: 1)"}
         dec = {"value": r["decode"]["threads_1"]["frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "reference",
                "sample": "reference Decoder.forward, B=1, no_grad, 600 frames"}
         mel = {"value": r["mel"]["anim_frames_per_s"], "unit": "frames/s", "cores": 1, "kind": "reference",
@@ -290,6 +316,65 @@ def decode_30min(se, de, dev, minutes=30.0, reps=3):
             "config": f"{minutes:g} min WAV -> mel -> speech encoder -> B=1 decode of {T - 1} frames, 1 GPU"}
 
 
+def generate_30min(dev, minutes=30.0, exemplar_frames=CLIP_FRAMES):
+    """BASELINE.json configs[4] through the REAL entry point: zeggs.generate.generate_gesture() (ZEGGS/generate.py:22-411)
+    on a 30-minute 16 kHz WAV with a 7 200-frame exemplar BVH (also the first pose), random-init configs_v1 nets saved as
+    the reference's whole-module pickles, loudness normalisation on.  Per-stage wall ms (device stages bracketed by a
+    synchronisation; `_host` stages are Python / NumPy on the host: file parsing and BVH text, which north_star leaves there)."""
+    import shutil
+    import tempfile
+    import scipy.io.wavfile as wavfile
+    from zeggs import anim, generate
+    tmp = Path(tempfile.mkdtemp(prefix="zeggs_gen30_"))
+    try:
+        net, data, res = tmp / "net", tmp / "data", tmp / "res"
+        net.mkdir(), data.mkdir()
+        torch.manual_seed(1234)
+        se = modules.SpeechEncoder(synth.N_AUDIO, 64, SP)
+        de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, SP, ST, H, 2)
+        st = modules.StyleEncoder(synth.POSE_IN, 512, ST, type="attn", use_vae=True)
+        torch.save(se, net / "speech_encoder.pt"), torch.save(de, net / "decoder.pt"), torch.save(st, net / "style_encoder.pt")
+        np.savez(data / "stats.npz", **synth.make_stats())
+        json.dump(synth.data_definition(), open(data / "data_definition.json", "w"))
+        conf = dict(audio_conf=dict(pre_emphasis=False, pre_emph_coeff=0.97, centered=True, real_amplitude=True,
+                                    normalize_mel_bins=True, normalize_range=True, min_clipping=1e-5, sampling_rate=16000,
+                                    mel_fmin=20, mel_fmax=7600, n_mel_channels=80, filter_length=800, hop_length=200,
+                                    resample_method="linear", normalize_loudness=True),
+                    audio_feature_type=["mel_spec", "energy"])
+        json.dump(conf, open(data / "data_pipeline_conf.json", "w"))
+        n = int(minutes * 60 * 16000)
+        rng = np.random.default_rng(2)
+        env = 0.55 + 0.45 * np.sin(2 * np.pi * 4.0 * np.arange(n) / 16000.0)
+        wavfile.write(tmp / "long.wav", 16000, (rng.standard_normal(n) * env * 3000).astype(np.int16))
+        wavfile.write(tmp / "short.wav", 16000, synth.synth_wav(160000, seed=0))
+        anim.bvh_save(tmp / "ex.bvh", synth.make_bvh_clip(exemplar_frames, seed=3))
+        kw = dict(style_encoding_type="example", blend_type="add", blend_ratio=[1.0], first_pose=tmp / "ex.bvh",
+                  temperature=1.0, seed=1234)
+        generate.generate_gesture(tmp / "short.wav", [(tmp / "ex.bvh", None)], net, data, res, file_name="warm", **kw)
+        torch.cuda.synchronize()
+        generate.PROFILE = prof = {}
+        t0 = time.perf_counter()
+        enc = generate.generate_gesture(tmp / "long.wav", [(tmp / "ex.bvh", None)], net, data, res, file_name="out", **kw)
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t0
+        generate.PROFILE = None
+        with open(res / "out.bvh") as fh:
+            for line in fh:
+                if line.startswith("Frames:"):
+                    frames = int(line.split()[1])
+                    break
+        dev_ms = sum(v for k, v in prof.items() if k.endswith("_device"))
+        host_ms = sum(v for k, v in prof.items() if k.endswith("_host"))
+        return {"frames": frames, "total_s": round(total, 2), "device_stages_ms": round(dev_ms, 1),
+                "host_stages_ms": round(host_ms, 1), "stages_ms": {k: round(v, 2) for k, v in prof.items()},
+                "x_realtime_device_stages": round(minutes * 60e3 / dev_ms, 1), "x_realtime_total": round(minutes * 60 / total, 1),
+                "bvh_bytes": (res / "out.bvh").stat().st_size, "style_encoding_finite": bool(torch.isfinite(enc).all()),
+                "config": f"generate_gesture(): {minutes:g} min 16 kHz WAV, {exemplar_frames}-frame exemplar BVH (= first pose), "
+                          f"loudness normalisation on, B=1 decode of {frames - 1} frames, BVH written"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def v2_label_b64(ds, dev, steps=10, warmup=3, batch=64, nlabels=9):
     """BASELINE.json configs[3]: configs_v2.json = label conditioning (one-hot over 9 labels, no style encoder),
     batch 64 x 256-frame windows: the MFMA-bound regime of the stage kernels (B >= 40)."""
@@ -333,16 +418,28 @@ def launch_command(argv, gpus, port):
             "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
 
 
+def launch_env(base=None):
+    """Environment of the ranks: dmabuf IPC for RCCL, 8 hardware queues (the engine's three streams + RCCL's must not share
+    one: DESIGN.md section 6), a bounded host thread pool per rank."""
+    env = dict(os.environ if base is None else base)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return env
+
+
+def rank_device(local_rank):
+    """one process per GPU: LOCAL_RANK k drives GPU k of the node"""
+    return torch.device("cuda", int(local_rank))
+
+
 def self_launch(a):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes)
-    env.setdefault("OMP_NUM_THREADS", "4")
-    return subprocess.call(launch_command(sys.argv[1:], a.gpus, port), env=env)
+    return subprocess.call(launch_command(sys.argv[1:], a.gpus, port), env=launch_env())
 
 
 def main():
@@ -357,6 +454,7 @@ def main():
                     help="decoder weight-gradient GEMMs on the main stream instead of beside the encoders' backward")
     ap.add_argument("--no-prefetch", action="store_true", help="gather every batch at the start of its own step")
     ap.add_argument("--no-extras", action="store_true", help="skip decode / decode_30min / v2_label_b64 (N = 1 only)")
+    ap.add_argument("--no-generate", action="store_true", help="skip generate_30min (configs[4] through generate_gesture())")
     ap.add_argument("--force-process-group", action="store_true",
                     help="initialise the RCCL process group and run the gradient all-reduce even at --gpus 1")
     ap.add_argument("--launch-selftest", action="store_true",
@@ -398,10 +496,20 @@ def main():
         return
     if have_gpu and local >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPUs are visible")
-    dev = torch.device("cuda", local)
+    dev = rank_device(local)
     torch.cuda.set_device(dev)
     ops.set_option("timing", 1)
-    data = build_dataset()
+    shared = None
+    if world > 1:       # one synthetic-dataset build per node: rank 0 writes /dev/shm, the others map it
+        shm = Path("/dev/shm" if Path("/dev/shm").is_dir() else "/tmp") / f"zeggs_bench_{os.environ.get('MASTER_PORT', '0')}.npz"
+        shared = (shm, rank == 0, torch.distributed.barrier)
+    t_data = time.perf_counter()
+    data = build_dataset(shared=shared)
+    t_data = time.perf_counter() - t_data
+    if shared is not None:
+        torch.distributed.barrier()
+        if rank == 0:
+            shm.unlink(missing_ok=True)
     ds = engine.DeviceDataset(data, WINDOW, dev)
     se, de, st = build_nets(dev)
     eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, world_size=world, rank=rank,
@@ -442,6 +550,9 @@ def main():
         print("step ends (ms since the previous):", " ".join(f"{x.elapsed_time(y):.2f}" for x, y in zip(step_events, step_events[1:])),
               file=sys.stderr)
     fwd_in, bwd_in = sweep_ms(0), sweep_ms(1)               # the LAST timed iteration's stage sweeps (HIP events)
+    # per-iteration times from the HIP events recorded behind every optimizer step of the timed region
+    ev = step_events[a.warmup:a.warmup + a.steps]          # (intervals between the timed steps only: K - 1 of them)
+    step_ms = np.array([x.elapsed_time(y) for x, y in zip(ev, ev[1:])]) if len(ev) > 1 else np.zeros(0)
     el = torch.tensor([mine], device=dev, dtype=torch.float64)
     per_rank = None
     if use_pg:
@@ -457,6 +568,14 @@ def main():
         fw.append(sweep_ms(0))
         bw.append(sweep_ms(1))
     loss = float(loss.detach())
+    ar_blocking = None
+    if use_pg:      # the whole exchange un-overlapped (3 more iterations): what the overlap hides = blocking - exposed
+        keep, eng.overlap_allreduce, eng.allreduce_events = (eng.overlap_allreduce, list(eng.allreduce_events or [])), False, []
+        for k in range(3):
+            eng.step(indices(a.warmup + a.steps + 3 + k), EXAMPLE_LEN)
+        torch.cuda.synchronize()
+        ar_blocking = float(np.mean([e0.elapsed_time(e1) for e0, e1 in eng.allreduce_events]))
+        eng.overlap_allreduce, eng.allreduce_events = keep
     if rank == 0:
         ms = elapsed / a.steps * 1e3
         out = {
@@ -469,6 +588,11 @@ def main():
                        "global_batch": gb, "window": WINDOW, "parallelism": f"dp{world}"},
             "final_loss": round(loss, 4),
         }
+        if len(step_ms):
+            out["step_ms_hip_events"] = {"n": int(len(step_ms)), "p50": round(float(np.percentile(step_ms, 50)), 3),
+                                         "p95": round(float(np.percentile(step_ms, 95)), 3),
+                                         "min": round(float(step_ms.min()), 3), "max": round(float(step_ms.max()), 3)}
+        out["dataset_build_s"] = round(t_data, 2)
         nst = WINDOW - 1
         f_us, b_us = float(np.mean(fw)) * 1e3 / nst, float(np.mean(bw)) * 1e3 / nst
         pmc = None
@@ -505,7 +629,14 @@ def main():
             out["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "ranks": census}
             out["per_rank_ms_per_step"] = per_rank
             out["allreduce_ms"] = round(float(np.mean(ar)), 3) if ar else None
-            out["allreduce_bytes"] = int(eng.flat_g.numel() * 4)
+            out["allreduce_exposed_ms"] = out["allreduce_ms"]
+            out["allreduce_blocking_ms"] = round(ar_blocking, 3)
+            out["allreduce_overlapped_ms"] = round(max(0.0, ar_blocking - (out["allreduce_ms"] or 0.0)), 3) if eng.overlap_allreduce else 0.0
+            out["per_gpu_frames_per_sec"] = round(BATCH * WINDOW * a.steps / elapsed, 1)
+            # what one of these ranks would do alone: the iteration without the exposed part of the exchange (to be checked
+            # against the N = 1 line of the same build)
+            out["n1_equivalent_frames_per_sec"] = round(BATCH * WINDOW / max(1e-9, (ms - (out["allreduce_ms"] or 0.0)) * 1e-3), 1)
+            out["allreduce_bytes"] = int(eng.flat_gx.numel() * 4)
             out["allreduce_note"] = ("allreduce_ms = the EXPOSED part: the decoder slice (91 % of the payload) is reduced "
                                      "underneath the encoders' backward" if eng.overlap_allreduce else
                                      "one blocking all-reduce of the flat gradient buffer after the backward")
@@ -518,6 +649,8 @@ def main():
             out["decode"] = decode_rate(de, dev)
             out["roofline"]["decode_b1"] = out["decode"]["roofline"]
             out["decode_30min"] = decode_30min(se, de, dev)
+            if not a.no_generate:
+                out["generate_30min"] = generate_30min(dev)
             del eng
             out["v2_label_b64"] = v2_label_b64(ds, dev)
         if world == 1 and not a.no_cpu_baseline:

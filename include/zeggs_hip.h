@@ -8,9 +8,18 @@
  * Conventions
  *   - plain pointers + sizes, no torch types; all tensors contiguous row-major fp32 DEVICE
  *     memory unless stated; quaternions (w,x,y,z); int64 indices where stated.
- *   - the caller owns all memory.  The library never allocates, frees or synchronises the
- *     device; it only enqueues kernels on `stream` (a hipStream_t passed as void*), so every
- *     call is hipGraph-capturable.
+ *   - the caller owns all memory.  The library never allocates or frees device memory and does
+ *     not synchronise the device (one documented exception: the FIRST use of each persistent
+ *     kernel on a process is validated with a stream synchronisation, never inside a capture);
+ *     it only enqueues kernels on `stream` (a hipStream_t passed as void*), so every call is
+ *     hipGraph-capturable.
+ *   - no per-call state is global: what a call needs beyond its arguments travels in the
+ *     ZeggsDecCall struct of the *_ex entry points (prepared workspaces, the stream of deferred
+ *     weight-gradient GEMMs, the caller-owned status words).  zeggs_set_option holds process-wide
+ *     TUNING switches only (kernel selection, measurement hooks); the only other process-wide
+ *     facts are "this persistent kernel was validated / disabled on this process"
+ *     (zeggs_persistent_state) and the thread-local last-error string.  Two engines with their own
+ *     workspaces and streams can therefore interleave calls in one process.
  *   - scratch + activations saved for backward live in a caller-provided workspace whose
  *     size is returned by the matching *_workspace_bytes(); fwd and bwd of one module must be
  *     given the SAME workspace (bwd reads what fwd saved).
@@ -28,7 +37,9 @@ extern "C" {
 
 int zeggs_version(void);
 const char* zeggs_last_error(void);
-/* runtime switches: "decoder_fast" 1 (default) = fragment-packed stage kernels, 0 = generic GEMM path;
+/* process-wide TUNING switches: "decoder_fast" 1 (default) = fragment-packed stage kernels, 0 = generic GEMM path;
+ * "persistent" / "train_persistent" / "bwd_persistent" 0/1 = the three weight-stationary persistent kernels;
+ * "persistent_spin" = bound of their device-side waits (polls; 0: the first unsatisfied wait gives up -- test hook);
  * "timing" 1 = HIP events on the caller's stream around the decoder's steady-state stage sweeps */
 int zeggs_set_option(const char* name, int value);
 /* elapsed ms of the last recorded stage sweep: which = 0 forward (T-1 steps x 3 launches), 1 backward; blocks on
@@ -196,23 +207,54 @@ int zeggs_decoder_bwd(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDec
                       const float* pose, const float* rpos, const float* rrot, const float* dpose,
                       const float* drpos, const float* drrot, const ZeggsDecGrads*, float* dspeech,
                       float* dstyle, void* ws, size_t ws_bytes, void* stream);
-/* With zeggs_set_option("defer_wgrads", 1) zeggs_decoder_bwd enqueues the weight-gradient GEMMs of the recurrent layers
- * (layer0, the GRU, layer2 of ZEGGS/modules.py:165-185: seven GEMMs with K = B (T-1) that read only what the sweep saved in
- * `ws`) on zeggs_side_stream (low priority, owned by the library, one per device) right after the sweep and returns WITHOUT
- * joining: they run beside the CellStateEncoder backward and whatever the caller enqueues next (the encoders' backward).
- * The caller makes every consumer of the decoder's weight gradients (all-reduce, optimizer) wait for that stream and keeps
- * `ws` alive until then (zeggs/ops.py: _DecoderFn.backward, zeggs/engine.py).  The reference has no counterpart: its
- * autograd runs every backward op on one stream (ZEGGS/train.py:425).
- * "defer_wgrads" = 2 (data-parallel runs): only the GEMMs of layer2 and GRU layer 1 are enqueued there -- with the bias sums
- * and the CellStateEncoder gradients that is the SECOND half of the decoder's parameters in module order; the caller starts
- * its all-reduce and lets zeggs_decoder_wgrads(what = 4) compute the first half (GRU layer 0, layer0) underneath it. */
+/* Per-call controls of zeggs_decoder_fwd_ex / zeggs_decoder_bwd_ex (NULL or all-zero = the plain calls above).
+ *   prepared      bit 0 (fwd) / bit 1 (bwd): zeggs_decoder_prepare has run on THIS workspace with THESE weights and returned
+ *                 that bit -> the call skips the weight-only packs / the zero state it starts from.
+ *   defer_wgrads  bwd only.  1: the weight-gradient GEMMs of the recurrent layers (layer0, the GRU, layer2 of
+ *                 ZEGGS/modules.py:165-185: seven GEMMs with K = B (T-1) that read only what the sweep saved in `ws`) and their
+ *                 bias sums are enqueued on `wgrad_stream` right after the sweep (ordered behind it by an event) and the call
+ *                 returns WITHOUT joining: they run beside the CellStateEncoder backward and whatever the caller enqueues next
+ *                 (the encoders' backward).  The caller makes every consumer of the decoder's weight gradients (all-reduce,
+ *                 optimizer) wait for that stream and keeps `ws` alive until then (zeggs/ops.py, zeggs/engine.py).  The
+ *                 reference has no counterpart: its autograd runs every backward op on one stream (ZEGGS/train.py:425).
+ *                 2 (data-parallel runs): only the GEMMs of layer2 and GRU layer 1 go there -- with the bias sums and the
+ *                 CellStateEncoder gradients that is the SECOND half of the decoder's parameters in module order; the caller
+ *                 starts its all-reduce and lets zeggs_decoder_wgrads(what = 4) compute the first half underneath it.
+ *   wgrad_stream  hipStream_t of the deferred GEMMs (required when defer_wgrads != 0; e.g. zeggs_side_stream).
+ *   status        caller-owned DEVICE words [ZEGGS_STATUS_WORDS], zeroed by the caller once, or NULL.  A persistent kernel
+ *                 whose bounded wait gives up after its validated first use (e.g. a co-tenant holds CUs) ORs its
+ *                 ZEGGS_GAVE_UP_* bit into status[0] (sticky) and writes NaN into what its consumers read first;
+ *                 zeggs_radam_step_guarded turns the optimizer step of such an iteration into a counted no-op (status[1]),
+ *                 so nothing invalid reaches the weights before the host has looked (zeggs/engine.py re-runs the lost steps
+ *                 on the stage kernels; zeggs/ops.py re-runs an inference rollout). */
+#define ZEGGS_STATUS_WORDS 4
+#define ZEGGS_GAVE_UP_DECODE 1u    /* decode_persistent_k   (B = 1 inference rollout) */
+#define ZEGGS_GAVE_UP_TRAIN_FWD 2u /* train_fwd_persistent_k (training rollout) */
+#define ZEGGS_GAVE_UP_BPTT 4u      /* train_bwd_persistent_k (BPTT sweep) */
+typedef struct {
+  int prepared;
+  int defer_wgrads;
+  void* wgrad_stream;
+  unsigned* status;
+} ZeggsDecCall;
+int zeggs_decoder_fwd_ex(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDecStats*, const float* pose0,
+                         const float* rpos0, const float* rrot0, const float* gaze, const float* speech,
+                         const float* style, float* pose, float* rpos, float* rrot, int training, void* ws,
+                         size_t ws_bytes, void* stream, const ZeggsDecCall* call);
+int zeggs_decoder_bwd_ex(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDecStats*, const float* gaze,
+                         const float* pose, const float* rpos, const float* rrot, const float* dpose,
+                         const float* drpos, const float* drrot, const ZeggsDecGrads*, float* dspeech,
+                         float* dstyle, void* ws, size_t ws_bytes, void* stream, const ZeggsDecCall* call);
+/* second half of the deferred weight gradients (ZeggsDecCall.defer_wgrads = 2): what = 4 -> GRU layer 0 and layer0 */
 int zeggs_decoder_wgrads(const ZeggsDecDims*, const ZeggsDecGrads*, void* ws, size_t ws_bytes, int what, void* stream);
 /* The weight-only preparation of a training step on `ws` (merged / folded matrices and the fragment packs of the two
  * persistent sweeps; the reference has no counterpart, its GEMMs read nn.Parameter storage directly): may run on a second
- * stream beside the encoders' forward.  Returns a bit mask, 1: zeggs_decoder_fwd may be called with option "fwd_prepared",
- * 2: zeggs_decoder_bwd with "bwd_prepared" (they then skip this work); 0: nothing done; < 0: error. */
+ * stream beside the encoders' forward.  Returns the bit mask for ZeggsDecCall.prepared (1: forward packs ready, 2: backward
+ * packs and zero state ready; 0: nothing done, these dimensions take another path); < 0: error. */
 int zeggs_decoder_prepare(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDecStats*, void* ws, size_t ws_bytes,
                           void* stream);
+/* a low-priority stream per device, created on first use and never destroyed (a convenience for ZeggsDecCall.wgrad_stream;
+ * any stream of the caller's will do) */
 int zeggs_side_stream(void** out /* hipStream_t */);
 
 /* ---------------------------------------------------------------- training loss
@@ -238,6 +280,12 @@ int zeggs_loss_fwd_bwd(const ZeggsLossDims*, const int* parents, const float* o_
  * optimizers.py:64-84 computed by the caller). */
 int zeggs_radam_step(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
                      float step_scale, int rectified, void* stream);
+/* the same step, skipped on the DEVICE (p, m, v untouched, status[1] += 1) when status[0] != 0 (a persistent sweep of this
+ * rank gave up: ZeggsDecCall.status) or gflag != NULL and gflag[0] != 0 (the flag of all ranks, summed by the gradient
+ * all-reduce: zeggs_status_flag writes this rank's 0 / 1 into the float that travels with the gradients) */
+int zeggs_radam_step_guarded(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
+                             float step_scale, int rectified, unsigned* status, const float* gflag, void* stream);
+int zeggs_status_flag(const unsigned* status, float* dst /* device float */, void* stream);
 
 /* ---------------------------------------------------------------- batch gather
  * replaces SGDataset.__getitem__/get_example + default collate, ZEGGS/dataset.py:110-204, reading

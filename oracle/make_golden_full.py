@@ -3,7 +3,8 @@
 TEST INFRASTRUCTURE -- see oracle/__init__.py.  Run from the repo root (build container only, needs
 /root/reference):
 
-    python -m oracle.make_golden_full [stats dec32 rollout train32 trainv2 mel10 style512]
+    python -m oracle.make_golden_full [stats dec32 rollout train32 trainv2 mel10 style512 style7200 speech_trained
+                                        rollout108k trainv2_256 | fp64 [tag ...]]
 
 Where oracle/make_golden.py pins the algorithms on toy shapes with synthetic statistics, this script pins the
 shapes bench.py times and the dynamic range of the reference's own normalisation statistics
@@ -18,6 +19,13 @@ anim_output_std):
   full_trainv2.npz  ONE complete reference train() iteration in label mode (configs_v2), B=64, window=32
   full_mel10.npz    reference preprocess_audio on the 10 s synthetic WAV (BASELINE configs[0])
   full_style512.npz reference StyleEncoder (attn, VAE) forward at example length 512, B=4
+  full_trainv2_256.npz the label-mode iteration at the shape bench.py times for configs[3]: B=64, window=256 (round 3)
+  full_rollout108k.npz reference Decoder.forward, B=1, 108 000 free-running frames (configs[4]: 30 min of audio), in
+                    fp64 and fp32 (~20 CPU-minutes, once), strided samples (round 3)
+  full_style7200.npz reference StyleEncoder forward on a 7 200-frame exemplar (configs[4]), B=1 (round 3)
+  full_speech_trained.npz the SHIPPED trained data/outputs/v1/saved_models/speech_encoder.pt run on the 10 s mel
+                    features, + its state dict (the GPU test loads the pickle itself through zeggs.compat when
+                    oracle/_ref/ holds it, else these weights) (round 3)
 
 Inputs are NOT stored: the tests regenerate them from the same seeds through zeggs.synth (the fixture keeps
 checksums of the inputs so that a drifting generator is detected, and the outputs are stored strided).
@@ -264,10 +272,109 @@ def gold_style512(ref):
     print("full_style512.npz", z.shape)
 
 
+def long_decoder_inputs(st, T, seed):
+    """B=1 inputs of a T-frame free-running decode (tests/helpers.py: long_decoder_inputs): first pose of a seeded clip,
+    a smooth gaze target and speech / style encodings over T frames (no [T, 1131] pose table: only frame 0 is read)."""
+    c = synth.make_clip_stats(8, seed=seed, stats=st)
+    W = {k: torch.as_tensor(v[None, :1]) for k, v in c.items() if k != "Y_gaze_pos"}
+    rng = np.random.default_rng(seed + 7)
+    gaze = np.array([[10.0, 150.0, 100.0]]) + synth._smooth(rng, T, 3, 2.0, k=241)
+    W["Y_gaze_pos"] = torch.as_tensor(gaze[None].astype(np.float32))
+    env = 0.5 + 0.25 * synth._smooth(rng, T, 1, 1.0, k=121)
+    speech = torch.as_tensor((rng.standard_normal((1, T, 64)) * env[None]).astype(np.float32))
+    style = torch.as_tensor(np.repeat(rng.standard_normal((1, 1, 64)).astype(np.float32) * 0.5, T, axis=1))
+    return W, speech, style
+
+
+def gold_rollout108k(ref):
+    """configs[4]: the B=1 decode of 30 minutes of audio = 108 000 frames (ZEGGS/generate.py:367, modules.py:100-151),
+    reference in fp64 (the yardstick) and in fp32 (its own deviation).  ~7 + ~12 CPU-minutes; stored strided."""
+    import time
+    st = real_stats("v1")
+    _, de, _ = build_ref_nets(ref)
+    de.eval()
+    T = 108000
+    W, speech, style = long_decoder_inputs(st, T, seed=9300)
+    torch.set_num_threads(1)
+    t0 = time.time()
+    O32 = run_decoder(de, W, speech, style, st)
+    t32 = time.time() - t0
+    print(f"reference fp32, 1 thread: {t32:.1f} s = {(T - 1) / t32:.1f} frames/s", flush=True)
+    torch.set_num_threads(8)
+    t0 = time.time()
+    O64 = run_decoder(de.double(), W, speech, style, st, torch.float64)
+    print(f"reference fp64, 8 threads: {time.time() - t0:.1f} s", flush=True)
+    floor = {n: float((a.double() - b).abs().max()) for n, a, b in zip(NAMES, O32, O64)}
+    pose = pose_rows(O64).numpy()[0]
+    pose32 = pose_rows(O32).numpy()[0]
+    out = dict(T=np.int64(T), seed=np.int64(9300), root_pos_every100=O64[0].numpy()[0][::100],
+               root_rot_every100=O64[1].numpy()[0][::100], pose_every500=pose[::500].astype(np.float64),
+               pose_last=pose[-1], ref_fp32_floor=np.array([floor[n] for n in NAMES]),
+               ref_fp32_pose_err_every500=np.abs(pose32[::500] - pose[::500]).max(axis=1),
+               ref_fp32_root_pos_err_every100=(O32[0].double() - O64[0]).abs().max(dim=2)[0][0].numpy()[::100],
+               ref_fp32_seconds_1thread=np.float64(t32),
+               in_check=np.stack([checksum(W[k]) for k in sorted(W)] + [checksum(speech), checksum(style)]))
+    np.savez_compressed(GOLD / "full_rollout108k.npz", **out)
+    print("full_rollout108k.npz  reference fp32-vs-fp64 floor:", floor)
+
+
+def exemplar_rows(st, L, seed):
+    c = synth.make_clip_stats(L, seed=seed, stats=st)
+    return np.concatenate([c["Y_root_vel"], c["Y_root_vrt"], c["Y_lpos"].reshape(L, -1), c["Y_ltxy"].reshape(L, -1),
+                           c["Y_lvel"].reshape(L, -1), c["Y_lvrt"].reshape(L, -1), np.zeros((L, 3), np.float32)], axis=1)
+
+
+def gold_style7200(ref):
+    """configs[4]: the style exemplar is a whole 2-minute BVH = 7 200 frames through StyleEncoderAttn
+    (ZEGGS/generate.py:190-262, modules.py:391-420), B=1."""
+    st = real_stats("v1")
+    _, _, sty = build_ref_nets(ref)
+    sty.eval()
+    L = 7200
+    im, isd, _, _ = tensors(st)
+    ex = torch.as_tensor(exemplar_rows(st, L, 9400)[None])
+    eps = torch.as_tensor(np.random.default_rng(29).standard_normal((1, 64)).astype(np.float32))
+    orig = torch.randn_like
+    torch.randn_like = lambda x, *a, **k: eps.to(x.dtype)
+    try:
+        with torch.no_grad():
+            z, mu, logvar = sty((ex - im) / isd, 1.0)
+            sty64 = sty.double()
+            z64, mu64, lv64 = sty64(((ex - im) / isd).double(), 1.0)
+    finally:
+        torch.randn_like = orig
+    np.savez_compressed(GOLD / "full_style7200.npz", L=np.int64(L), seed=np.int64(9400), eps=eps.numpy(), z=z.numpy(),
+                        mu=mu.numpy(), logvar=logvar.numpy(), z64=z64.numpy(), mu64=mu64.numpy(), logvar64=lv64.numpy(),
+                        ex_check=checksum(ex.numpy()))
+    print("full_style7200.npz", z.shape, "reference fp32-vs-fp64:", float((z.double() - z64).abs().max()),
+          float((mu.double() - mu64).abs().max()), float((logvar.double() - lv64).abs().max()))
+
+
+def gold_speech_trained(ref):
+    """The one trained artefact the reference ships (data/outputs/v1/saved_models/speech_encoder.pt, loaded by
+    ZEGGS/generate.py:130-137) on the 10 s clip's mel features normalised with the real audio statistics."""
+    st = real_stats("v1")
+    path = "/root/reference/data/outputs/v1/saved_models/speech_encoder.pt"
+    net = ref.torch_load(path, map_location="cpu")
+    net.eval()
+    feat = np.load(GOLD / "full_mel10.npz")["feat"]
+    x = (torch.as_tensor(feat)[None] - torch.as_tensor(st["audio_input_mean"])) / torch.as_tensor(st["audio_input_std"])
+    with torch.no_grad():
+        y = net(x)
+        y64 = net.double()(x.double())
+    out = dict(out=y.numpy(), out64=y64.numpy(), x_check=checksum(x.numpy()),
+               file_bytes=np.int64(Path(path).stat().st_size))
+    for k, v in net.float().state_dict().items():
+        out["w." + k] = v.numpy()
+    np.savez_compressed(GOLD / "full_speech_trained.npz", **out)
+    print("full_speech_trained.npz", y.shape, "fp32-vs-fp64", float((y.double() - y64).abs().max()),
+          "max |out|", float(y.abs().max()))
+
+
 def main():
     torch.set_num_threads(8)
-    if sys.argv[1:] == ["fp64"]:            # needs the fixtures only, not /root/reference
-        return add_fp64_gradient_samples()
+    if sys.argv[1:2] == ["fp64"]:           # needs the fixtures only, not /root/reference
+        return add_fp64_gradient_samples(sys.argv[2:])
     assert ref_shims.available(), "/root/reference is required to (re)generate golden vectors"
     ref = ref_shims.load()
     which = sys.argv[1:] or ["stats", "dec32", "rollout", "train32", "trainv2", "mel10", "style512", "fp64"]
@@ -281,6 +388,15 @@ def main():
         gold_dec32(ref)
     if "rollout" in which:
         gold_rollout(ref)
+    if "style7200" in which:
+        gold_style7200(ref)
+    if "speech_trained" in which:
+        gold_speech_trained(ref)
+    if "rollout108k" in which:
+        gold_rollout108k(ref)
+    if "trainv2_256" in which:
+        record_train_iteration(ref, "trainv2_256", "v2", B=64, window=256, example_length=256, style_type="label",
+                               n_train=2, nframes=700, nlabels=9)
     if "trainv2" in which:
         record_train_iteration(ref, "trainv2", "v2", B=64, window=32, example_length=32, style_type="label",
                                n_train=4, nframes=160, nlabels=9)
@@ -293,14 +409,16 @@ def main():
 
 
 
-def add_fp64_gradient_samples():
+def add_fp64_gradient_samples(only=()):
     """Augment full_train32.npz / full_trainv2.npz with the gradient samples of the (reference-pinned) oracle run in
     FLOAT64 on the same iteration: the reference's own fp32 gradients carry 1-4e-4 of max|g| of rounding noise after
     BPTT, so the GPU tests assert the tight tolerance against these and a looser one against the fp32 reference."""
     sys.path.insert(0, str(ROOT / "tests"))
     from test_oracle_full_shapes import oracle_full_iteration
-    for tag, v in (("trainv2", "v2"), ("train32", "v1")):
+    for tag, v in (("trainv2", "v2"), ("train32", "v1"), ("trainv2_256", "v2")):
         path = GOLD / f"full_{tag}.npz"
+        if only and tag not in only:
+            continue
         gd = dict(np.load(path))
         loss, terms, ws = oracle_full_iteration(np.load(path), v, torch.float64)
         plist = [t for w in ws for t in w.values()]

@@ -1,9 +1,10 @@
-"""Import the UNMODIFIED reference (/root/reference/ZEGGS) in the build container.
+"""Import the UNMODIFIED reference: /root/reference/ZEGGS in the build container, or -- where that does not exist
+(the GPU box) -- the byte-for-byte snapshot oracle/build_ref.py left in the git-ignored oracle/_ref/, unpacked into a
+temporary directory.
 
 TEST INFRASTRUCTURE -- see oracle/__init__.py.  Only used by
-oracle/make_golden.py (fixture generation) and by bench.py's optional
-cpu_baseline kind="reference" probe when /root/reference exists; nothing on the
-GPU box reads /root/reference.
+oracle/make_golden*.py (fixture generation, build container only) and by bench.py's
+cpu_baseline kind="reference" leg (oracle/ref_timing.py); nothing on the GPU box reads /root/reference.
 
 The shims replace *missing third-party packages / binaries* only (tensorboard,
 omegaconf, sox, ffmpeg check, scipy.signal.hann alias); no reference source is
@@ -15,10 +16,35 @@ import types
 from pathlib import Path
 
 REF = Path("/root/reference/ZEGGS")
+SNAPSHOT = Path(__file__).resolve().parent / "_ref" / "zeggs_reference.tar.gz"
+_root = None
+
+
+def root():
+    """Directory that holds ZEGGS/, configs/ and data/processed_v*/ of the reference (None: neither source exists)."""
+    global _root
+    if _root is None:
+        if REF.is_dir():
+            _root = REF.parent
+        elif SNAPSHOT.exists():
+            import atexit
+            import shutil
+            import tarfile
+            import tempfile
+            tmp = Path(tempfile.mkdtemp(prefix="zeggs_ref_snapshot_"))
+            atexit.register(shutil.rmtree, str(tmp), ignore_errors=True)
+            with tarfile.open(SNAPSHOT) as tar:
+                tar.extractall(tmp)
+            _root = tmp
+    return _root
 
 
 def available():
-    return REF.is_dir()
+    return root() is not None
+
+
+def source():
+    return "unmodified /root/reference/ZEGGS" if REF.is_dir() else "oracle/_ref snapshot of the unmodified reference (oracle/build_ref.py)"
 
 
 def load():
@@ -28,6 +54,7 @@ def load():
 
     if "zeggs_ref_loaded" in sys.modules:
         return sys.modules["zeggs_ref_loaded"]
+    REF = root() / "ZEGGS"              # noqa: N806  (the live checkout or the unpacked snapshot)
     sys.path.insert(0, str(REF))
     tb = types.ModuleType("torch.utils.tensorboard")
     tb.SummaryWriter = type("SummaryWriter", (), {

@@ -1,9 +1,9 @@
 """Time the UNMODIFIED reference's CPU path (the baseline BASELINE.md section 3 / SURVEY.md 8(d) ask for).
 
-TEST / MEASUREMENT INFRASTRUCTURE -- see oracle/__init__.py.  Needs /root/reference (build container, or any
-host that has the reference checked out there); bench.py calls `measure()` for its `cpu_baseline` leg when the
-reference is present (kind = "reference") and otherwise falls back to the oracle port plus the figures this
-script recorded in profiles/r02_cpu_reference.json.
+TEST / MEASUREMENT INFRASTRUCTURE -- see oracle/__init__.py.  Needs the reference: /root/reference (build container) or
+the snapshot oracle/build_ref.py left in oracle/_ref/ (it travels to the GPU box); bench.py calls `measure()` for its
+`cpu_baseline` leg when either is present (kind = "reference") and otherwise falls back to the oracle port plus the
+figures this script recorded in profiles/r02_cpu_reference.json.
 
     python -m oracle.ref_timing [--iters 5] [--frames 3000] [--out profiles/r02_cpu_reference.json]
 
@@ -110,7 +110,7 @@ def time_decode(ref, threads, frames):
 
 
 def time_mel(ref, seconds=10):
-    conf = json.load(open("/root/reference/data/processed_v1/data_pipeline_conf.json"))
+    conf = json.load(open(ref_shims.root() / "data" / "processed_v1" / "data_pipeline_conf.json"))
     conf["audio_conf"]["normalize_loudness"] = False       # pyloudnorm is not installed
     ac = ref.DictConfig(conf["audio_conf"])
     n = 16000 * seconds
@@ -126,10 +126,10 @@ def time_mel(ref, seconds=10):
 
 
 def measure(iters=5, frames=3000, train_threads=(1, None), legs=("train", "decode", "mel")):
-    assert ref_shims.available(), "/root/reference is required"
+    assert ref_shims.available(), "/root/reference or the oracle/_ref snapshot (oracle/build_ref.py) is required"
     ref = ref_shims.load()
     ncpu = os.cpu_count() or 1
-    out = {"cpu": cpu_info(), "reference": "unmodified /root/reference/ZEGGS through oracle/ref_shims.py",
+    out = {"cpu": cpu_info(), "reference": ref_shims.source() + " through oracle/ref_shims.py",
            "workload": f"configs_v1.json nets, batch {BATCH} x {WINDOW}-frame windows of synthetic 60-fps 2-minute "
                        f"clips (8 clips resident), style example length drawn in [256, 512] as train.py:228 does"}
     if "train" in legs:

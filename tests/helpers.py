@@ -88,3 +88,24 @@ def full_dataset(gd, v):
     st = real_stats(v)
     return synth.make_processed(int(gd["n_train"]), 1, int(gd["nframes"]), int(gd["data_seed"]), int(gd["nlabels"]), st,
                                 synth.make_clip_stats)
+
+
+def long_decoder_inputs(st, T, seed):
+    """The B=1 inputs of oracle/make_golden_full.py:long_decoder_inputs (a T-frame free-running decode: only the first
+    pose, the gaze target and the speech / style encodings exist)."""
+    c = synth.make_clip_stats(8, seed=seed, stats=st)
+    W = {k: torch.as_tensor(v[None, :1]) for k, v in c.items() if k != "Y_gaze_pos"}
+    rng = np.random.default_rng(seed + 7)
+    gaze = np.array([[10.0, 150.0, 100.0]]) + synth._smooth(rng, T, 3, 2.0, k=241)
+    W["Y_gaze_pos"] = torch.as_tensor(gaze[None].astype(np.float32))
+    env = 0.5 + 0.25 * synth._smooth(rng, T, 1, 1.0, k=121)
+    speech = torch.as_tensor((rng.standard_normal((1, T, 64)) * env[None]).astype(np.float32))
+    style = torch.as_tensor(np.repeat(rng.standard_normal((1, 1, 64)).astype(np.float32) * 0.5, T, axis=1))
+    return W, speech, style
+
+
+def exemplar_rows(st, L, seed):
+    """[L, 1134] un-normalised style-exemplar rows of a seeded clip (gaze slot zero, dataset.py:194)."""
+    c = synth.make_clip_stats(L, seed=seed, stats=st)
+    return np.concatenate([c["Y_root_vel"], c["Y_root_vrt"], c["Y_lpos"].reshape(L, -1), c["Y_ltxy"].reshape(L, -1),
+                           c["Y_lvel"].reshape(L, -1), c["Y_lvrt"].reshape(L, -1), np.zeros((L, 3), np.float32)], axis=1)

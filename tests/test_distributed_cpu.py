@@ -106,6 +106,31 @@ def test_bench_self_launches_ranks_without_a_launcher():
     import bench
     cmd = bench.launch_command(["--gpus", "8", "--steps", "20"], 8, 29511)
     assert "--nproc-per-node=8" in cmd and cmd[-4:] == ["--gpus", "8", "--steps", "20"] and "127.0.0.1" in cmd
+    # the ranks' environment: dmabuf IPC for RCCL, 8 hardware queues (engine streams + RCCL's), and LOCAL_RANK k -> GPU k
+    env8 = bench.launch_env({})
+    assert env8["GPU_MAX_HW_QUEUES"] == "8" and env8["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "OMP_NUM_THREADS" in env8
+    assert bench.launch_env({"GPU_MAX_HW_QUEUES": "4"})["GPU_MAX_HW_QUEUES"] == "4"          # the user's setting wins
+    assert [bench.rank_device(k).index for k in range(8)] == list(range(8))
+
+
+def test_bench_dataset_is_built_once_and_shared_between_ranks(tmp_path):
+    """multi-rank start-up: the builder rank writes the distinct synthetic clips, the others map them -- same dataset"""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    saved = bench.CLIP_FRAMES
+    bench.CLIP_FRAMES = 300
+    try:
+        calls = []
+        a = bench.build_dataset(n_train=4, n_unique=2, shared=(tmp_path / "d.npz", True, lambda: calls.append(1)))
+        b = bench.build_dataset(n_train=4, n_unique=2, shared=(tmp_path / "d.npz", False, lambda: calls.append(1)))
+        c = bench.build_dataset(n_train=4, n_unique=2)
+    finally:
+        bench.CLIP_FRAMES = saved
+    assert calls == [1, 1]
+    for k in a:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])) and np.array_equal(np.asarray(a[k]), np.asarray(c[k])), k
 
 
 def test_ranks_draw_different_noise_streams():

@@ -25,7 +25,8 @@ def test_flatten_parameters_keeps_state_dict_and_views():
     import helpers
     se, de, st = helpers.build_nets()
     before = {k: v.clone() for k, v in de.state_dict().items()}
-    params, flat_p, flat_g = engine.flatten_parameters([se, de, st])
+    params, flat_p, flat_g, flat_gx = engine.flatten_parameters([se, de, st])
+    assert flat_gx.numel() % 4 == 0 and flat_gx.numel() >= flat_g.numel() + 4 and flat_gx.data_ptr() == flat_g.data_ptr()
     assert flat_p.numel() == 25543147 == sum(p.numel() for p in params)
     for k, v in de.state_dict().items():
         assert torch.equal(v, before[k])

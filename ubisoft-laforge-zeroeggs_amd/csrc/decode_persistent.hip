@@ -30,12 +30,13 @@
 #include "kernels.h"
 
 int g_persistent = 1;           // zeggs_set_option("persistent", 0/1)
+int g_persistent_spin = 1 << 21;   // bound of every device-side wait of the three persistent kernels ("persistent_spin")
 static int g_persistent_ok = -1;   // -1 not validated yet, 0 failed once (disabled), 1 validated on this process
 
 namespace {
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
-constexpr int PH = 1024, PTHR = 512, PNCU = 256, J0 = 26, J1 = 16, J3 = 18, PSPIN = 1 << 21;
+constexpr int PH = 1024, PTHR = 512, PNCU = 256, J0 = 26, J1 = 16, J3 = 18;
 
 struct PArgs {
   ZeggsDecDims d;
@@ -48,6 +49,8 @@ struct PArgs {
   float *h0_fin, *h1_fin;      // state after the last frame (streaming), may be null
   unsigned long long *g_h0, *g_h1, *g_hid, *g_xp;
   unsigned* err;
+  unsigned* status;         // caller-owned sticky give-up flags (ZeggsDecCall.status), may be null
+  unsigned spin;            // bound of every sweep (option "persistent_spin")
   int XD;
 };
 
@@ -59,7 +62,7 @@ __device__ __forceinline__ void publish(unsigned long long* g, unsigned epoch, f
 // This wave sweeps granules [lo, hi) (lane-strided, at most PER per lane) until every tag equals `epoch`, and drops the
 // values into dst[i] (LDS).  Returns false when the bounded sweep gave up.
 template <int PER>
-__device__ __forceinline__ bool gather(const unsigned long long* g, int lo, int hi, unsigned epoch, float* dst) {
+__device__ __forceinline__ bool gather(const unsigned long long* g, int lo, int hi, unsigned epoch, float* dst, unsigned limit) {
   const int lane = threadIdx.x & 63;
   for (unsigned spins = 0;; ++spins) {
     bool ok = true;
@@ -77,7 +80,7 @@ __device__ __forceinline__ bool gather(const unsigned long long* g, int lo, int 
       else ok = false;
     }
     if (__all(ok)) return true;
-    if (spins > PSPIN) return false;
+    if (spins >= limit) return false;
   }
 }
 
@@ -183,9 +186,9 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
     const bool next = t + 1 < T;
     // ================================================================ GRU layer 0: operands [hid_t | x_t | h0_{t-1}]
     if (t > 1) {
-      if (!gather<2>(a.g_hid, wave * 128, wave * 128 + 128, (unsigned)t, xcat)) bad = true;
+      if (!gather<2>(a.g_hid, wave * 128, wave * 128 + 128, (unsigned)t, xcat, a.spin)) bad = true;
       const int per = (PO + 7) / 8;
-      if (!gather<3>(a.g_xp, wave * per, min(PO, wave * per + per), (unsigned)t, xcat + H)) bad = true;
+      if (!gather<3>(a.g_xp, wave * per, min(PO, wave * per + per), (unsigned)t, xcat + H, a.spin)) bad = true;
       if (tq < 3) xcat[H + PO + tq] = rootst[7 + tq];                       // gaze direction of x_t (local)
       if (tq >= 64 && tq < 64 + NC) xcat[H + PI + (tq - 64)] = cond[tq - 64];   // speech / style of frame t
     }
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
     }
     __syncthreads();      // the old h0 has been read everywhere before the sweep overwrites it
     // ================================================================ GRU layer 1: operands [h0_t | h1_{t-1}]
-    if (!gather<2>(a.g_h0, wave * 128, wave * 128 + 128, (unsigned)t, h0s)) fail = 1;
+    if (!gather<2>(a.g_h0, wave * 128, wave * 128 + 128, (unsigned)t, h0s, a.spin)) fail = 1;
     if (next && tq < NC)      // speech / style columns of frame t+1 (inputs), staged while the sweep is in flight
       cond[tq] = tq < d.SP ? a.speech[(long)(t + 1) * d.SP + tq] : a.style[(long)(t + 1) * d.ST + (tq - d.SP)];
     __syncthreads();
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
     }
     __syncthreads();
     // ================================================================ output: y_t = W2 h1_t + b2, root, x_{t+1}, hid_{t+1}
-    if (!gather<2>(a.g_h1, wave * 128, wave * 128 + 128, (unsigned)t, h1s)) fail = 1;
+    if (!gather<2>(a.g_h1, wave * 128, wave * 128 + 128, (unsigned)t, h1s, a.spin)) fail = 1;
     __syncthreads();
     if (fail) break;
     {
@@ -307,8 +310,17 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
       publish(a.g_hid + 4 * c + tq, (unsigned)(t + 1),
               d_elu(rs[tq] + cst[tq][12] + cst[tq][13] * rootst[7] + cst[tq][14] * rootst[8] + cst[tq][15] * rootst[9]));
   }
-  if (fail) {
-    if (tid == 0) atomicOr(a.err, 1u);
+  if (fail) {     // a bounded sweep gave up: error word, the caller's sticky status, and NaN in what a consumer reads first
+    if (tid == 0) {
+      atomicOr(a.err, 1u);
+      if (a.status) atomicOr(a.status, ZEGGS_GAVE_UP_DECODE);
+    }
+    if (c == 0) {
+      const float qnan = __uint_as_float(0x7fc00000u);
+      for (int i = tid; i < PO; i += PTHR) a.pose[(long)(T - 1) * PO + i] = qnan;
+      if (tid < 3) a.rpos[(long)(T - 1) * 3 + tid] = qnan;
+      if (tid < 4) a.rrot[(long)(T - 1) * 4 + tid] = qnan;
+    }
     return;
   }
   if (c == 0 && a.h0_fin)
@@ -327,7 +339,8 @@ int dec_persistent_supported(const ZeggsDecDims& d, const DecWs& w) {
 // the first frame); Mc / cvec are the folded layer0 operands (dec_fast_merge_prep).
 int dec_persistent_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                        const float* speech, const float* style, float* pose, float* rpos, float* rrot, const float* gin1,
-                       const float* h0_init, const float* h1_init, float* h0_fin, float* h1_fin, hipStream_t s) {
+                       const float* h0_init, const float* h1_init, float* h0_fin, float* h1_fin, hipStream_t s,
+                       unsigned* status) {
   int dev = 0, ncu = 0;
   ZCHECK(hipGetDevice(&dev) == hipSuccess, "hipGetDevice failed");
   ZCHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess, "device query failed");
@@ -345,6 +358,7 @@ int dec_persistent_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   a.g_h0 = g; a.g_h1 = g + PH; a.g_hid = g + 2 * PH; a.g_xp = g + 3 * PH;
   a.err = (unsigned*)(g + 3 * PH + 5 * PNCU);
   a.XD = w.XD;
+  a.status = status; a.spin = (unsigned)g_persistent_spin;
   hipLaunchKernelGGL(decode_persistent_k, dim3(PNCU), dim3(PTHR), 0, s, a);
   ZLAUNCH_CHECK("decode_persistent");
   return 0;

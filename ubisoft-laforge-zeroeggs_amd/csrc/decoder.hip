@@ -16,8 +16,6 @@
 #include "decoder_ws.h"
 
 static int g_decoder_fast = 1;
-static int g_fwd_prepared = 0, g_bwd_prepared = 0;   // zeggs_decoder_prepare has run on this workspace (the caller vouches)
-static int g_defer_wgrads = 0;  // zeggs_decoder_bwd runs the recurrent weight-gradient GEMMs on the library's second stream and does NOT join
 static int g_bwd_chunks = 1;   // BPTT sweep chunks whose weight-gradient GEMMs overlap the rest of the sweep (1: serial)
 extern int g_stage_variant;
 extern int g_gemm_wg_target;
@@ -49,40 +47,19 @@ extern "C" int zeggs_set_option(const char* name, int value) {
     return 0;
   }
   if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
-  if (strcmp(name, "defer_wgrads") == 0) { g_defer_wgrads = value < 0 ? 0 : value; return 0; }   // 1: all GEMMs, 2: first half only
-  if (strcmp(name, "fwd_prepared") == 0) { g_fwd_prepared = value != 0; return 0; }
-  if (strcmp(name, "bwd_prepared") == 0) { g_bwd_prepared = value != 0; return 0; }
+  // bound of every device-side wait of the persistent kernels (polls); 0 makes the first unsatisfied wait give up: the
+  // tests use it to drive the give-up path (tests/test_gpu_giveup.py)
+  if (strcmp(name, "persistent_spin") == 0) { g_persistent_spin = value < 0 ? 0 : value; return 0; }
   zeggs_set_error("unknown option %s", name);
   return -1;
 }
 
-// Error words of the persistent kernels are copied back asynchronously after every launch (pinned host word + event) and
-// inspected at the NEXT call: a kernel that was validated once but later could not run (not every workgroup resident, e.g.
-// the GPU is shared) is detected without a device synchronisation in the steady state.
-struct ErrWatch {
-  unsigned* host = nullptr;
-  hipEvent_t ev = nullptr;
-  bool pending = false;
-  int post(const unsigned* dev_word, hipStream_t s) {
-    if (!host) {
-      ZCHECK(hipHostMalloc((void**)&host, sizeof(unsigned), hipHostMallocDefault) == hipSuccess, "pinned word allocation failed");
-      ZCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "event creation failed");
-      *host = 0;
-    }
-    ZCHECK(hipMemcpyAsync(host, dev_word, sizeof(unsigned), hipMemcpyDeviceToHost, s) == hipSuccess, "error-word copy failed");
-    ZCHECK(hipEventRecord(ev, s) == hipSuccess, "hipEventRecord failed");
-    pending = true;
-    return 0;
-  }
-  // 0: nothing to report / still in flight, 1: the last inspected launch failed
-  int failed() {
-    if (!pending || hipEventQuery(ev) != hipSuccess) return 0;
-    pending = false;
-    return *host != 0;
-  }
-};
-static ErrWatch g_watch_decode, g_watch_train, g_watch_bwd;
-
+// What tells a caller that a persistent kernel gave up AFTER its first (validated) use -- e.g. a co-tenant took CUs, so not
+// every workgroup was resident and a bounded wait ran out: (1) the kernel ORs its bit into the caller-owned sticky status word
+// (ZeggsDecCall.status) that zeggs_radam_step_guarded reads on the device -- the optimizer step of that iteration is then a
+// no-op, nothing invalid reaches the weights -- and that the caller inspects whenever it likes; (2) it writes NaN into what its
+// consumers read first (last output frame / the carries of the CellStateEncoder backward).  The library keeps no per-process
+// watch state of its own.
 // 1: the persistent kernel was validated on this process, 0: it failed once and is disabled, -1: not used yet
 extern "C" int zeggs_persistent_state(int which /* 0 decode (B=1), 1 training forward, 2 BPTT sweep */) {
   return which == 0 ? dec_persistent_state() : which == 1 ? dec_tp_state() : dec_bp_state();
@@ -431,6 +408,21 @@ int side_stream(SideStream** out) {
   return 0;
 }
 
+// fork event of a deferred-GEMM hand-over: stream-ordered use only (record on one stream, wait on another, both enqueued
+// before this returns), so one event per device is enough; events carry no data and are created once
+int fork_event(hipEvent_t* out) {
+  static hipEvent_t pool[16];
+  static bool ready[16] = {};
+  int dev = 0;
+  ZCHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "decoder bwd: unsupported device index");
+  if (!ready[dev]) {
+    ZCHECK(hipEventCreateWithFlags(&pool[dev], hipEventDisableTiming) == hipSuccess, "event creation failed");
+    ready[dev] = true;
+  }
+  *out = pool[dev];
+  return 0;
+}
+
 inline dim3 g1(long n) { long g = (n + 255) / 256; return dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))); }
 
 }  // namespace
@@ -444,14 +436,22 @@ extern "C" size_t zeggs_decoder_workspace_bytes(const ZeggsDecDims* d, int train
 static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
                             const float* pose0, const float* rpos0, const float* rrot0, const float* gaze,
                             const float* speech, const float* style, float* pose, float* rpos, float* rrot,
-                            int training, const float* h_in, float* h_out, void* ws, size_t ws_bytes, void* stream);
+                            int training, const float* h_in, float* h_out, void* ws, size_t ws_bytes, void* stream,
+                            const ZeggsDecCall* call);
 
 extern "C" int zeggs_decoder_fwd(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
                                  const float* pose0, const float* rpos0, const float* rrot0, const float* gaze,
                                  const float* speech, const float* style, float* pose, float* rpos, float* rrot,
                                  int training, void* ws, size_t ws_bytes, void* stream) {
   return decoder_fwd_impl(dp, P, st, pose0, rpos0, rrot0, gaze, speech, style, pose, rpos, rrot, training, nullptr,
-                          nullptr, ws, ws_bytes, stream);
+                          nullptr, ws, ws_bytes, stream, nullptr);
+}
+extern "C" int zeggs_decoder_fwd_ex(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
+                                    const float* pose0, const float* rpos0, const float* rrot0, const float* gaze,
+                                    const float* speech, const float* style, float* pose, float* rpos, float* rrot,
+                                    int training, void* ws, size_t ws_bytes, void* stream, const ZeggsDecCall* call) {
+  return decoder_fwd_impl(dp, P, st, pose0, rpos0, rrot0, gaze, speech, style, pose, rpos, rrot, training, nullptr,
+                          nullptr, ws, ws_bytes, stream, call);
 }
 
 // Chunked (streaming) decode: frame 0 of the chunk is the last frame already produced (its pose / root state come in as
@@ -462,15 +462,18 @@ extern "C" int zeggs_decoder_fwd_state(const ZeggsDecDims* dp, const ZeggsDecPar
                                        const float* speech, const float* style, float* pose, float* rpos, float* rrot,
                                        const float* h_in, float* h_out, void* ws, size_t ws_bytes, void* stream) {
   return decoder_fwd_impl(dp, P, st, pose0, rpos0, rrot0, gaze, speech, style, pose, rpos, rrot, 0, h_in, h_out, ws,
-                          ws_bytes, stream);
+                          ws_bytes, stream, nullptr);
 }
 
 static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
                             const float* pose0, const float* rpos0, const float* rrot0, const float* gaze,
                             const float* speech, const float* style, float* pose, float* rpos, float* rrot,
-                            int training, const float* h_in, float* h_out, void* ws, size_t ws_bytes, void* stream) {
+                            int training, const float* h_in, float* h_out, void* ws, size_t ws_bytes, void* stream,
+                            const ZeggsDecCall* call) {
   const ZeggsDecDims& d = *dp;
   hipStream_t s = (hipStream_t)stream;
+  const bool fwd_prepared = call && (call->prepared & 1);
+  unsigned* status = call ? call->status : nullptr;
   ZCHECK(d.PI == d.PO + 3, "decoder: pose_input_size must be pose_output_size + 3 (gaze)");
   ZCHECK(d.B >= 1 && d.T >= 1, "decoder: empty batch or sequence");
   Arena a(ws, ws_bytes);
@@ -515,14 +518,6 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
   }
   const bool fast = g_decoder_fast && dec_fast_supported(d);
   // ---- batch-1 inference: the weight-stationary persistent kernel (one launch for all frames, decode_persistent.hip)
-  hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
-  hipStreamIsCapturing(s, &cap0);          // (event queries are not allowed while a capture is in progress)
-  if (cap0 == hipStreamCaptureStatusNone && g_watch_decode.failed()) {
-    dec_persistent_set_state(0);
-    zeggs_set_error("persistent decode kernel: a bounded wait gave up in the PREVIOUS rollout (its outputs are invalid); "
-                    "the kernel is disabled for this process, repeat the call");
-    return -1;
-  }
   if (fast && !training && g_persistent && dec_persistent_state() != 0 && dec_persistent_supported(d, w)) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     hipStreamIsCapturing(s, &cap);
@@ -536,12 +531,10 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
       ZTRY(dec_fast_merge_prep(d, P, st, w, s));
       dec_timing_mark(0, s);
       ZTRY(dec_persistent_run(d, P, st, w, gaze, speech, style, pose, rpos, rrot, gin1, w.H0 + slot(0) * sH,
-                              w.H1 + slot(0) * sH, w.H0 + slot(T - 1) * sH, w.H1 + slot(T - 1) * sH, s));
+                              w.H1 + slot(0) * sH, w.H0 + slot(T - 1) * sH, w.H1 + slot(T - 1) * sH, s,
+                              dec_persistent_state() == 1 ? status : nullptr));
       dec_timing_mark(1, s);
-      if (dec_persistent_state() == 1) {
-        if (cap == hipStreamCaptureStatusNone) { unsigned* ew = nullptr; ZTRY(dec_persistent_errptr(w, &ew)); ZTRY(g_watch_decode.post(ew, s)); }
-        return save_state();
-      }
+      if (dec_persistent_state() == 1) return save_state();
       unsigned perr = 1;
       ZCHECK(hipStreamSynchronize(s) == hipSuccess, "persistent decode: stream sync failed");
       ZTRY(dec_persistent_errors(w, &perr));
@@ -551,29 +544,22 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
     }
   }
   // ---- training, batch <= 32: the forward rollout as one persistent launch (train_persistent.hip)
-  if (cap0 == hipStreamCaptureStatusNone && g_watch_train.failed()) {
-    dec_tp_set_state(0);
-    zeggs_set_error("persistent training rollout: a bounded wait gave up in the PREVIOUS forward (its results are invalid); "
-                    "the kernel is disabled for this process, repeat the step");
-    return -1;
-  }
   if (fast && training && g_train_persistent && dec_tp_state() != 0 && dec_tp_supported(d, w)) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     hipStreamIsCapturing(s, &cap);
     if (cap == hipStreamCaptureStatusNone || dec_tp_state() == 1) {
       float* gin1 = w.Gin + sG;
       ZTRY(gemm_nt(gin1 + H, GL, P->l0_w, XD, gin1, GL, P->l0_b, B, H, XD, ACT_ELU, 0.f, s));   // hid_1 = ELU(W0 x_1 + b0)
-      if (!g_fwd_prepared) {
+      if (!fwd_prepared) {
         ZTRY(dec_fast_merge_prep(d, P, st, w, s));
         ZTRY(dec_tp_pack(d, P, st, w, s));
       }
       dec_timing_mark(0, s);
-      ZTRY(dec_tp_run(d, P, st, w, gaze, speech, style, pose, rpos, rrot, s, g_fwd_prepared != 0));
+      // (the first, validated use reports through the workspace's own error word: a give-up there is handled right below)
+      ZTRY(dec_tp_run(d, P, st, w, gaze, speech, style, pose, rpos, rrot, s, fwd_prepared,
+                      dec_tp_state() == 1 ? status : nullptr));
       dec_timing_mark(1, s);
-      if (dec_tp_state() == 1) {
-        if (cap == hipStreamCaptureStatusNone) { unsigned* ew = nullptr; ZTRY(dec_tp_errptr(w, &ew)); ZTRY(g_watch_train.post(ew, s)); }
-        return save_state();
-      }
+      if (dec_tp_state() == 1) return save_state();
       unsigned perr = 1;
       ZCHECK(hipStreamSynchronize(s) == hipSuccess, "persistent training rollout: stream sync failed");
       ZTRY(dec_tp_errors(w, &perr));
@@ -682,7 +668,7 @@ extern "C" int zeggs_decoder_wgrads(const ZeggsDecDims* dp, const ZeggsDecGrads*
 }
 // Everything the two persistent sweeps of a training step need that depends on the WEIGHTS only (the merged / folded
 // matrices, the per-workgroup fragment packs of both kernels): the caller may run it on a second stream beside the encoders'
-// forward and passes "fwd_prepared" / "bwd_prepared" to the calls that follow on the same workspace.  Returns a bit mask
+// forward and passes ZeggsDecCall.prepared to the zeggs_decoder_fwd_ex / _bwd_ex calls that follow on the same workspace.  Returns a bit mask
 // (1: forward packs ready, 2: backward packs ready; 0: these dimensions take another path, nothing was done), < 0 on error.
 extern "C" int zeggs_decoder_prepare(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st, void* ws,
                                      size_t ws_bytes, void* stream) {
@@ -722,14 +708,26 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
                                  const float* gaze, const float* pose, const float* rpos, const float* rrot,
                                  const float* dpose, const float* drpos, const float* drrot, const ZeggsDecGrads* G,
                                  float* dspeech, float* dstyle, void* ws, size_t ws_bytes, void* stream) {
+  return zeggs_decoder_bwd_ex(dp, P, st, gaze, pose, rpos, rrot, dpose, drpos, drrot, G, dspeech, dstyle, ws, ws_bytes, stream,
+                              nullptr);
+}
+extern "C" int zeggs_decoder_bwd_ex(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
+                                    const float* gaze, const float* pose, const float* rpos, const float* rrot,
+                                    const float* dpose, const float* drpos, const float* drrot, const ZeggsDecGrads* G,
+                                    float* dspeech, float* dstyle, void* ws, size_t ws_bytes, void* stream,
+                                    const ZeggsDecCall* call) {
   const ZeggsDecDims& d = *dp;
   hipStream_t s = (hipStream_t)stream;
+  const bool bwd_prepared = call && (call->prepared & 2);
+  const int defer_wgrads = call ? call->defer_wgrads : 0;
+  unsigned* status = call ? call->status : nullptr;
+  ZCHECK(defer_wgrads == 0 || call->wgrad_stream != nullptr, "decoder bwd: defer_wgrads needs ZeggsDecCall.wgrad_stream");
   Arena a(ws, ws_bytes);
   DecWs w = carve_dec(d, 1, a);
   ZCHECK(a.ok(), "decoder bwd: workspace too small (was the forward run with training=1?)");
   const int B = d.B, T = d.T, H = d.H, GL = w.GL, XD = w.XD, CI = d.PI + d.ST, POL = w.POL;
   const long sG = (long)B * GL, sH = (long)B * H, s3 = 3 * sH;
-  if (!g_bwd_prepared) {      // (zeggs_decoder_prepare has done it)
+  if (!bwd_prepared) {      // (zeggs_decoder_prepare has done it)
     ZTRY(k_fill(w.dH0c, sH, 0.f, s));
     ZTRY(k_fill(w.dH1c, sH, 0.f, s));
     ZTRY(k_fill(w.carry, (long)2 * B * 8, 0.f, s));
@@ -743,17 +741,11 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   bool swept = false;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   hipStreamIsCapturing(s, &cap);
-  if (cap == hipStreamCaptureStatusNone && g_watch_bwd.failed()) {
-    dec_bp_set_state(0);
-    zeggs_set_error("persistent BPTT sweep: a bounded wait gave up in the PREVIOUS backward (its gradients are invalid); "
-                    "the kernel is disabled for this process, repeat the step");
-    return -1;
-  }
   if (fast_path && g_bwd_persistent && dec_bp_state() != 0 && dec_bp_supported(d, w) &&
       (cap == hipStreamCaptureStatusNone || dec_bp_state() == 1)) {
-    ZTRY(dec_bp_run(d, P, st, w, gaze, pose, rpos, rrot, dpose, drpos, drrot, s, g_bwd_prepared != 0));
+    ZTRY(dec_bp_run(d, P, st, w, gaze, pose, rpos, rrot, dpose, drpos, drrot, s, bwd_prepared,
+                    dec_bp_state() == 1 ? status : nullptr));
     if (dec_bp_state() == 1) {
-      if (cap == hipStreamCaptureStatusNone) { unsigned* ew = nullptr; ZTRY(dec_bp_errptr(w, &ew)); ZTRY(g_watch_bwd.post(ew, s)); }
       swept = true;
     } else {      // first use on this process: validate (a bounded wait that gave up means not every workgroup was resident)
       unsigned perr = 1;
@@ -838,15 +830,17 @@ extern "C" int zeggs_decoder_bwd(const ZeggsDecDims* dp, const ZeggsDecParams* P
   // what the sweep saved) start NOW on the library's second stream, beside the CellStateEncoder backward below and whatever the
   // caller enqueues on `s` after this call (the encoders' backward).  No join here: the caller makes every consumer of the
   // decoder gradients wait for zeggs_side_stream.
-  if (!wgrads_done && g_defer_wgrads && cap == hipStreamCaptureStatusNone) {
-    ZTRY(side_stream(&ss));
-    ZCHECK(hipEventRecord(ss->chunk, s) == hipSuccess, "hipEventRecord failed");
-    ZCHECK(hipStreamWaitEvent(ss->s, ss->chunk, 0) == hipSuccess, "hipStreamWaitEvent failed");
+  if (!wgrads_done && defer_wgrads && cap == hipStreamCaptureStatusNone) {
+    hipStream_t gs = (hipStream_t)call->wgrad_stream;
+    hipEvent_t fork = nullptr;
+    ZTRY(fork_event(&fork));
+    ZCHECK(hipEventRecord(fork, s) == hipSuccess, "hipEventRecord failed");
+    ZCHECK(hipStreamWaitEvent(gs, fork, 0) == hipSuccess, "hipStreamWaitEvent failed");
     // (value 2: only the first half of the parameter order here -- the caller all-reduces it while zeggs_decoder_wgrads
     //  computes the second half)
     // The bias sums (a dozen column sums over the same saves) go with them: since the split-K retune the GEMMs are the shorter
     // of the two queues.
-    ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, ss->s, (g_defer_wgrads == 2 ? 1 : 5) | 2));
+    ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, gs, (defer_wgrads == 2 ? 1 : 5) | 2));
   } else if (!wgrads_done) {
     ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, s));
   }

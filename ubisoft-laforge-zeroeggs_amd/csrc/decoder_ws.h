@@ -145,11 +145,13 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
   return w;
 }
 
+extern int g_persistent_spin;      // bound of the device-side waits of the persistent kernels (option "persistent_spin")
 // persistent weight-stationary decode (decode_persistent.hip)
 int dec_persistent_supported(const ZeggsDecDims& d, const DecWs& w);
 int dec_persistent_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                        const float* speech, const float* style, float* pose, float* rpos, float* rrot, const float* gin1,
-                       const float* h0_init, const float* h1_init, float* h0_fin, float* h1_fin, hipStream_t s);
+                       const float* h0_init, const float* h1_init, float* h0_fin, float* h1_fin, hipStream_t s,
+                       unsigned* status = nullptr);
 int dec_persistent_state();
 void dec_persistent_set_state(int v);
 int dec_persistent_errors(const DecWs& w, unsigned* out);
@@ -162,7 +164,7 @@ int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSt
 int dec_tp_zero(const ZeggsDecDims& d, DecWs& w, hipStream_t s);
 int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s,
-               bool zeroed = false);
+               bool zeroed = false, unsigned* status = nullptr);
 int dec_tp_errors(const DecWs& w, unsigned* out);
 int dec_tp_errptr(const DecWs& w, unsigned** out);
 // persistent BPTT sweep (train_bwd_persistent.hip)
@@ -173,7 +175,7 @@ int dec_bp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStr
 int dec_bp_zero_slots(DecWs& w, hipStream_t s);      // weight tiles + operand pads (weights only)
 int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                const float* pose, const float* rpos, const float* rrot, const float* dpose, const float* drpos,
-               const float* drrot, hipStream_t s, bool packed = false);
+               const float* drrot, hipStream_t s, bool packed = false, unsigned* status = nullptr);
 int dec_bp_errors(const DecWs& w, unsigned* out);
 int dec_bp_errptr(const DecWs& w, unsigned** out);
 // fast path entry points (decoder_fast.hip)

@@ -21,7 +21,14 @@ namespace {
 // RAdam (reference optimizers.py:59-97): v = b2 v + (1-b2) g^2 ; m = b1 m + (1-b1) g ; p -= scale * m/(sqrt(v)+eps)
 // 16-byte vector accesses: 16 B read x4 + 12 B written per parameter = the algorithmic 28 B/param.
 __global__ __launch_bounds__(256) void radam_k(float* p, const float* g, float* m, float* v, long n4, long n,
-                                                float b1, float b2, float eps, float scale, int rect) {
+                                                float b1, float b2, float eps, float scale, int rect,
+                                                unsigned* status, const float* gflag) {
+  // guarded step (zeggs_radam_step_guarded): a persistent sweep of this iteration gave up on this rank (sticky status word) or
+  // on another one (gflag: the all-reduced flag) -> the gradients are invalid, the whole step is a no-op and is counted
+  if (status && (status[0] != 0u || (gflag && gflag[0] != 0.f))) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(status + 1, 1u);
+    return;
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f4 pv = ((f4*)p)[i], gv = ((const f4*)g)[i], mv = ((f4*)m)[i], vv = ((f4*)v)[i];
 #pragma unroll
@@ -40,6 +47,11 @@ __global__ __launch_bounds__(256) void radam_k(float* p, const float* g, float* 
     p[i] += rect ? -scale * (mv / (sqrtf(vv) + eps)) : -scale * mv;
     m[i] = mv; v[i] = vv;
   }
+}
+
+// dst[0] = 1 if a sticky give-up bit is set, else 0: the float that travels with the gradient all-reduce (sum over ranks)
+__global__ void status_flag_k(const unsigned* status, float* dst) {
+  if (threadIdx.x == 0) dst[0] = status[0] != 0u ? 1.f : 0.f;
 }
 
 __global__ void vae_fwd_k(const float* enc, const float* eps, float* z, float* mu_out, float* lv_out, int B, int S,
@@ -147,8 +159,25 @@ extern "C" int zeggs_radam_step(float* p, const float* g, float* m, float* v, lo
   if (n <= 0) return 0;
   long n4 = n / 4;
   hipLaunchKernelGGL(radam_k, dim3(g1(n4 > 0 ? n4 : 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
-                     beta2, eps, step_scale, rectified);
+                     beta2, eps, step_scale, rectified, (unsigned*)nullptr, (const float*)nullptr);
   ZLAUNCH_CHECK("radam");
+  return 0;
+}
+extern "C" int zeggs_radam_step_guarded(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2,
+                                        float eps, float step_scale, int rectified, unsigned* status, const float* gflag,
+                                        void* stream) {
+  ZCHECK(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "radam: buffers must be 16-byte aligned");
+  ZCHECK(status != nullptr, "radam (guarded): the status words are required");
+  if (n <= 0) return 0;
+  long n4 = n / 4;
+  hipLaunchKernelGGL(radam_k, dim3(g1(n4 > 0 ? n4 : 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
+                     beta2, eps, step_scale, rectified, status, gflag);
+  ZLAUNCH_CHECK("radam");
+  return 0;
+}
+extern "C" int zeggs_status_flag(const unsigned* status, float* dst, void* stream) {
+  hipLaunchKernelGGL(status_flag_k, dim3(1), dim3(64), 0, (hipStream_t)stream, status, dst);
+  ZLAUNCH_CHECK("status_flag");
   return 0;
 }
 

@@ -38,7 +38,7 @@ namespace {
 
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64t;
-constexpr int BH = 1024, BTHR = 512, BNCU = 256, BSPIN = 1 << 21;
+constexpr int BH = 1024, BTHR = 512, BNCU = 256;
 // blocks (16 k each) per wave and part; block j of a wave is enumeration index e = wave + 8 j of the part.  Every workgroup
 // streams the whole operand of a part through its CU (2 KB per block, ~90 GB/s per CU when all CUs read the same lines),
 // which is what bounds the single-row-group parts.
@@ -69,6 +69,8 @@ struct BArgs {
   const float *dpose, *drpos, *drrot, *gaze, *pose, *rpos, *rrot;
   const float* carry;                        // root adjoint after frame T-1 [B][8]
   unsigned *cnt, *err;
+  unsigned* status;                          // caller-owned sticky give-up flags (ZeggsDecCall.status), may be null
+  unsigned spin;                             // bound of every wait (option "persistent_spin")
 };
 
 __device__ __forceinline__ void stp(float* p, float v) {       // published: write-through
@@ -88,7 +90,7 @@ __host__ __device__ inline long op_idx(int b, int k) {
   return ((((long)(k >> 4) * 2 + ((k >> 2) & 1)) * 64 + ((((k >> 3) & 1) << 5) | b)) << 2) | (k & 3);
 }
 
-__device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect) {
+__device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect, unsigned limit) {
   const int lane = threadIdx.x & 63;
   const gu64t* q = (const gu64t*)(slots + 4 * lane);
   for (unsigned spins = 0;; ++spins) {
@@ -96,7 +98,7 @@ __device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect) 
     const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool ok = (unsigned)a >= expect && (unsigned)(a >> 32) >= expect && (unsigned)b >= expect && (unsigned)(b >> 32) >= expect;
     if (__all(ok)) return true;
-    if (spins > BSPIN) return false;
+    if (spins >= limit) return false;
   }
 }
 
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
 #ifdef ZEGGS_BPSTAT
       const unsigned long long w0 = wall_clock64();
 #endif
-      if (wave == 1 && !bp_wait(a.cnt, (unsigned)(p + 1))) fail = 1;     // (wave 0 of workgroup 0 prepares the root frame meanwhile)
+      if (wave == 1 && !bp_wait(a.cnt, (unsigned)(p + 1), a.spin)) fail = 1;     // (wave 0 of workgroup 0 prepares the root frame meanwhile)
 #ifdef ZEGGS_BPSTAT
       wsum[(p + 1) & 3] += wall_clock64() - w0;
 #endif
@@ -703,7 +705,17 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
     for (int i = 0; i < 6; ++i) o3[i] = q4[i];
   }
 #endif
-  if (fail && tid == 0) atomicOr(a.err, 1u);
+  if (fail) {     // a bounded wait gave up: error word, the caller's sticky status, NaN in the carries the CellStateEncoder backward reads
+    if (tid == 0) {
+      atomicOr(a.err, 1u);
+      if (a.status) atomicOr(a.status, ZEGGS_GAVE_UP_BPTT);
+    }
+    if (er < 4 && bact) {
+      const float qnan = __uint_as_float(0x7fc00000u);
+      a.dH1c[(long)eb * H + U] = qnan;
+      a.dH0c[(long)eb * H + U] = qnan;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- weight tiles (once per optimizer step)
@@ -814,7 +826,7 @@ int dec_bp_zero_slots(DecWs& w, hipStream_t s) {        // arrival slots + error
 }
 int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                const float* pose, const float* rpos, const float* rrot, const float* dpose, const float* drpos,
-               const float* drrot, hipStream_t s, bool packed) {
+               const float* drrot, hipStream_t s, bool packed, unsigned* status) {
   const int B = d.B, T = d.T, H = d.H, KBY = (d.PO + 15) / 16;
   int dev = 0, ncu = 0;
   ZCHECK(hipGetDevice(&dev) == hipSuccess, "hipGetDevice failed");
@@ -847,6 +859,7 @@ int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
     a.pose = pose + o * T * d.PO; a.rpos = rpos + o * T * 3; a.rrot = rrot + o * T * 4;
     a.carry = w.carry + o * 8;
     a.cnt = w.bp_cnt; a.err = w.bp_cnt + 1024;
+    a.status = status; a.spin = (unsigned)g_persistent_spin;
     hipLaunchKernelGGL(train_bwd_persistent_k, dim3(BNCU), dim3(BTHR), 0, s, a);
     ZLAUNCH_CHECK("train_bwd_persistent");
   }

@@ -30,7 +30,7 @@ static int g_tp_ok = -1;
 namespace {
 
 typedef __attribute__((address_space(1))) unsigned gu32;
-constexpr int TH = 1024, TTHR = 512, TNCU = 256, TSPIN = 1 << 21;
+constexpr int TH = 1024, TTHR = 512, TNCU = 256;
 // k-blocks of a wave per phase: first the OLD part of the operand (known one phase earlier: previous hidden state,
 // speech / style columns), then the FRESH part (produced by the preceding phase).  Block j of a part is k-block
 // lo + wave + 8 j: the parts are interleaved over the 8 waves so that every wave owns old work to do before the hand-off.
@@ -70,6 +70,8 @@ struct TArgs {
   const float* gaze;
   float *pose, *rpos, *rrot;
   unsigned *cnt, *err;
+  unsigned* status;                          // caller-owned sticky give-up flags (ZeggsDecCall.status), may be null
+  unsigned spin;                             // bound of every wait (option "persistent_spin")
 };
 
 __device__ __forceinline__ void stp(float* p, float v) {       // published: write-through
@@ -90,7 +92,7 @@ __device__ __forceinline__ long xfi(int b, int k, int NB) {   // B-fragment posi
 // waits until every slot has reached p + 1.  Epochs are monotonic and a workgroup can run at most one phase ahead of the
 // slowest one, so one 1 KB array serves every phase.  Returns false on give-up.
 typedef __attribute__((address_space(1))) unsigned long long gu64t;
-__device__ __forceinline__ bool tp_wait(const unsigned* slots, unsigned expect) {
+__device__ __forceinline__ bool tp_wait(const unsigned* slots, unsigned expect, unsigned limit) {
   const int lane = threadIdx.x & 63;
   const gu64t* q = (const gu64t*)(slots + 4 * lane);
   for (unsigned spins = 0;; ++spins) {
@@ -98,7 +100,7 @@ __device__ __forceinline__ bool tp_wait(const unsigned* slots, unsigned expect) 
     const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool ok = (unsigned)a >= expect && (unsigned)(a >> 32) >= expect && (unsigned)b >= expect && (unsigned)(b >> 32) >= expect;
     if (__all(ok)) return true;
-    if (spins > TSPIN) return false;
+    if (spins >= limit) return false;
   }
 }
 
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
 #ifdef ZEGGS_TPSTAT
       const unsigned long long w0 = wall_clock64();
 #endif
-      if (wave == 0 && !tp_wait(a.cnt, (unsigned)(p + 1))) fail = 1;
+      if (wave == 0 && !tp_wait(a.cnt, (unsigned)(p + 1), a.spin)) fail = 1;
 #ifdef ZEGGS_TPSTAT
       wsum[(p + 1) % 3] += wall_clock64() - w0;
 #endif
@@ -513,7 +515,15 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     for (int i = 0; i < 3; ++i) o[i] = wsum[i];
   }
 #endif
-  if (fail && tid == 0) atomicOr(a.err, 1u);
+  if (fail) {     // a bounded wait gave up: error word, the caller's sticky status, NaN in the last frame of every output row
+    if (tid == 0) {
+      atomicOr(a.err, 1u);
+      if (a.status) atomicOr(a.status, ZEGGS_GAVE_UP_TRAIN_FWD);
+    }
+    const float qnan = __uint_as_float(0x7fc00000u);
+    for (int i = c * TTHR + tid; i < B * PO; i += TNCU * TTHR) a.pose[((long)(i / PO) * T + T - 1) * PO + i % PO] = qnan;
+    if (c == 0 && tid < B) { a.rpos[((long)tid * T + T - 1) * 3] = qnan; a.rrot[((long)tid * T + T - 1) * 4] = qnan; }
+  }
 }
 
 // value of virtual row i, contraction index k of workgroup c's tile for phase ph (0: GRU l0, 1: GRU l1, 3: output stage)
@@ -655,7 +665,8 @@ int dec_tp_zero(const ZeggsDecDims& d, DecWs& w, hipStream_t s) {
   return 0;
 }
 int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
-               const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s, bool zeroed) {
+               const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s, bool zeroed,
+               unsigned* status) {
   const int B = d.B, H = d.H, NB = w.NB, KB0 = TKB0, KB3 = 64 + w.KBC;
   const long XB = 256L * NB, sG = (long)B * w.GL;
   int dev = 0, ncu = 0;
@@ -687,6 +698,7 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   a.b_ih0 = P->b_ih0; a.b_hh0 = P->b_hh0; a.b_ih1 = P->b_ih1; a.b_hh1 = P->b_hh1; a.cvec = w.cvec; a.l0_w = P->l0_w;
   a.l2_b = P->l2_b; a.cv0 = w.tp_cv0; a.p1x = w.tp_p1x; a.gaze = gaze; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
   a.cnt = w.tp_cnt; a.err = w.tp_cnt + TRING * TSH * TSTR;
+  a.status = status; a.spin = (unsigned)g_persistent_spin;
   switch (NB) {
     case 1: hipLaunchKernelGGL((train_fwd_persistent_k<1>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
     case 2: hipLaunchKernelGGL((train_fwd_persistent_k<2>), dim3(TNCU), dim3(TTHR), 0, s, a); break;

@@ -195,6 +195,11 @@ def write_bvh(filename, root_pos, root_rot, lpos, ltxy, parents, names, order, d
     if order != "zyx":
         raise NotImplementedError("only the 'zyx' channel order of the ZeroEGGS rigs is supported")
     positions, euler = bvh_channels(root_pos, root_rot, lpos, ltxy, start_position, start_rotation)
+    write_bvh_channels(filename, positions, euler, parents, names, order, dt)
+
+
+def write_bvh_channels(filename, positions, euler, parents, names, order, dt):
+    """the file half of write_bvh: device channel tables (bvh_channels) -> BVH text"""
     positions = positions.cpu().numpy()
     bvh_save(filename, dict(order=order, offsets=positions[0], names=names, frametime=dt, parents=parents,
                             positions=positions, rotations=euler.cpu().numpy()))

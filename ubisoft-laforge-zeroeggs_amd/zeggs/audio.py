@@ -211,9 +211,17 @@ def normalize_loudness_device(wav, rate, target=-20.0, device="cuda", chunk=4096
 def preprocess_audio(audio_data, anim_fs, anim_length, params, feature_type, device="cuda"):
     """Drop-in for reference data_pipeline.preprocess_audio (same arguments, returns float32 ndarray
     [anim_length, 81]); `params` may be a dict or an attribute-style config."""
+    return preprocess_audio_device(audio_data, anim_fs, anim_length, params, feature_type, device).cpu().numpy()
+
+
+def preprocess_audio_device(audio_data, anim_fs, anim_length, params, feature_type, device="cuda"):
+    """preprocess_audio with the feature table left on the device (what generate_gesture() feeds the speech encoder)."""
     g = (lambda k: params[k]) if isinstance(params, dict) else (lambda k: getattr(params, k))
     if g("normalize_loudness"):
-        if np.ndim(audio_data) == 1 and torch.device(device).type == "cuda":
+        # the device pre-pass measures float32 samples (what a 16-bit WAV read gives); float64 input keeps the host path,
+        # which filters and gates in float64 exactly as pyloudnorm does on such input (ADVICE r2)
+        is32 = (audio_data.dtype == torch.float32) if torch.is_tensor(audio_data) else (np.asarray(audio_data).dtype == np.float32)
+        if np.ndim(audio_data) == 1 and torch.device(device).type == "cuda" and is32:
             audio_data, _ = normalize_loudness_device(audio_data, g("sampling_rate"), -20.0, device)   # no host pass
         else:
             audio_data = normalize_loudness(audio_data, g("sampling_rate"), -20.0)
@@ -231,4 +239,4 @@ def preprocess_audio(audio_data, anim_fs, anim_length, params, feature_type, dev
         cols.append(feat[:, :-1])
     if "energy" in feature_type:
         cols.append(feat[:, -1:])
-    return torch.cat(cols, dim=1).cpu().numpy()
+    return torch.cat(cols, dim=1)

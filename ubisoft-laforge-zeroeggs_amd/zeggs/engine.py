@@ -8,6 +8,10 @@ This is the host-side runtime that `zeggs.train.train()` and `bench.py` drive.  
 Data parallelism: one process per GPU, every rank holds the full nets + dataset and takes its
 contiguous slice of the global batch; gradients are averaged with ONE all-reduce per iteration.
 """
+import collections
+import copy
+import warnings
+
 import numpy as np
 import torch
 
@@ -182,7 +186,10 @@ def flatten_parameters(modules):
     dev = params[0].device
     total = sum(p.numel() for p in params)
     flat_p = torch.empty(total, device=dev, dtype=torch.float32)
-    flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
+    # 4 floats behind the gradients: [0] = "a persistent sweep gave up on some rank" (rides on the gradient all-reduce,
+    # TrainEngine._guard), reachable as flat_g.tail
+    flat_gx = torch.zeros((total + 3) // 4 * 4 + 4, device=dev, dtype=torch.float32)
+    flat_g = flat_gx[:total]
     off = 0
     for p in params:
         n = p.numel()
@@ -194,7 +201,7 @@ def flatten_parameters(modules):
         for sub in m.modules():
             if isinstance(sub, torch.nn.GRU):
                 sub._flat_weights = [getattr(sub, n) for n in sub._flat_weights_names]
-    return params, flat_p, flat_g
+    return params, flat_p, flat_g, flat_gx
 
 
 class TrainEngine:
@@ -217,7 +224,8 @@ class TrainEngine:
         dev = dataset.device
         self.parents = torch.as_tensor(np.asarray(parents), dtype=torch.int32, device=dev)
         mods = [speech_encoder, decoder] + ([style_encoder] if style_encoding_type == "example" else [])
-        self.params, self.flat_p, self.flat_g = flatten_parameters(mods)
+        self.params, self.flat_p, self.flat_g, self.flat_gx = flatten_parameters(mods)
+        self._gflag = self.flat_gx[self.flat_gx.numel() - 4:self.flat_gx.numel() - 3]
         # the decoder's slice of the flat buffers (module order above): its gradients are final when the decoder
         # backward returns, 91 % of the payload, while the encoders' backward still has to run
         lo = sum(p.numel() for p in speech_encoder.parameters())
@@ -233,6 +241,18 @@ class TrainEngine:
         self.prefetch_hits = 0
         self.opt = RAdam(self.params, lr=lr, eps=eps)
         self.opt.attach_flat(self.flat_p, self.flat_g)
+        # Give-up protocol of the persistent sweeps (include/zeggs_hip.h: ZeggsDecCall.status).  The kernels OR into status[0]
+        # (sticky); the fused RAdam step reads it ON THE DEVICE (in data-parallel runs: the flag of all ranks, summed with the
+        # gradients) and skips itself, counting in status[1] -- nothing invalid reaches the weights however far the host runs
+        # ahead.  The host reads the counter back asynchronously with a fixed lag (the same iteration on every rank) and then
+        # re-runs the lost steps on the stage kernels (_recover).
+        self.status = self._status_host = None
+        self._status_ring = []
+        self._history = collections.deque(maxlen=8)
+        self.recovered_steps = 0
+        if torch.device(dev).type == "cuda":
+            self.status = ops.new_status(dev)
+            self.opt.attach_guard(self.status, self._gflag if (world_size > 1 or force_allreduce) else None)
         self.iteration = 0
         self.last_terms = None
         self.decoder_fwd_events = None      # bench.py: list of (start, end) HIP events around the forward rollout
@@ -264,8 +284,61 @@ class TrainEngine:
             ev.record(self.aux_stream)
         self._prefetched = ((np.asarray(idx).tobytes(), ex_len), b, ev)
 
-    def step(self, idx, example_len, eps=None, labels=None):
+    STATUS_LAG = 3       # iterations between a step and the host's look at its skip counter (identical on every rank)
+
+    def _post_status(self):
+        """After the optimizer step: copy the status words to a pinned slot (asynchronous) for the look STATUS_LAG steps on."""
+        k = self.iteration % (self.STATUS_LAG + 1)
+        while len(self._status_ring) <= self.STATUS_LAG:
+            self._status_ring.append([torch.zeros(ops.STATUS_WORDS, dtype=torch.int32).pin_memory(), None])
+        slot = self._status_ring[k]
+        slot[0].copy_(self.status, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+
+    def _check_status(self):
+        """Before a step: the skip counter as of STATUS_LAG steps ago (its copy has long completed: no stall)."""
+        if not self._status_ring or self.iteration < self.STATUS_LAG:
+            return
+        slot = self._status_ring[(self.iteration - self.STATUS_LAG) % (self.STATUS_LAG + 1)]
+        if slot[1] is None:
+            return
+        slot[1].synchronize()
+        if int(slot[0][1]) > 0:
+            self._recover()
+
+    def _recover(self):
+        """A persistent sweep gave up (on this or another rank): the device skipped every optimizer step since.  Disable the
+        persistent training kernels for this process, clear the words, and re-run the lost steps -- same windows, same noise
+        seeds -- on the stage kernels."""
+        torch.cuda.synchronize()
+        st = self.status.cpu()
+        bits, n = int(st[0]), int(st[1])
+        warnings.warn(f"zeggs: persistent sweep gave up on this rank: {[v for b, v in ops.GAVE_UP.items() if bits & b]}; "
+                      f"{n} optimizer step(s) were skipped on the device and are re-run on the stage kernels "
+                      "(train_persistent / bwd_persistent disabled for this process)")
+        ops.set_option("train_persistent", 0)
+        ops.set_option("bwd_persistent", 0)
+        ops.fill_(self.status.view(torch.float32))
+        for slot in self._status_ring:
+            slot[1] = None
+        redo = list(self._history)[-n:] if n > 0 else []
+        if len(redo) < n:
+            raise RuntimeError(f"zeggs: {n} optimizer steps were skipped but only {len(redo)} are in the replay history")
+        self.iteration -= n
+        self.opt.rewind(n)
+        self._prefetched = None
+        self.recovered_steps += n
+        for h in redo:
+            ops._seed_rng.bit_generator.state = copy.deepcopy(h["seed_state"])
+            self.step(h["idx"], h["example_len"], eps=h["eps"], labels=h["labels"], _replay=True)
+
+    def step(self, idx, example_len, eps=None, labels=None, _replay=False):
         """One training iteration on window indices `idx` (this rank's slice). Returns the loss tensor (device)."""
+        if self.status is not None and not _replay:
+            self._check_status()
+            self._history.append(dict(idx=np.array(idx, copy=True), example_len=example_len, eps=eps, labels=labels,
+                                      seed_state=copy.deepcopy(ops._seed_rng.bit_generator.state)))
         ds, T = self.ds, self.ds.window
         ex_len = example_len if self.style_type == "example" else None
         pre, self._prefetched = self._prefetched, None
@@ -277,8 +350,9 @@ class TrainEngine:
                 t.record_stream(torch.cuda.current_stream())
         else:
             b = ds.batch(idx, ex_len)
-        ops.fill_(self.flat_g)
+        ops.fill_(self.flat_gx)
         ops.direct_param_grads(True)        # *_bwd kernels write straight into the flat gradient buffer
+        ops.set_status(self.status)
         overlap = self.overlap_allreduce and (self.world > 1 or self.force_allreduce)
         self._dec_work = None
         if overlap:
@@ -334,6 +408,7 @@ class TrainEngine:
             ops.direct_param_grads(False)
             ops.set_after_decoder_backward(None)
             ops.set_wgrad_stream(None)
+            ops.set_status(None)
         if self.wgrad_stream is not None:      # join: every decoder gradient is final from here on in stream order
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             ops.release_wgrad_workspaces()
@@ -342,11 +417,14 @@ class TrainEngine:
         if self.allreduce_events is not None:       # with the overlap on: the EXPOSED part of the exchange
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a0.record()
+        guarded_dp = self.status is not None and (self.world > 1 or self.force_allreduce)
+        if guarded_dp:      # this rank's give-up flag joins the last slice of the exchange (summed over the ranks)
+            ops.status_flag(self.status, self._gflag)
         if self._dec_work is not None:
             # the decoder slice has been in flight since the decoder backward returned; now the encoders' slices
             lo, hi = self._dec_range
             works = list(self._dec_work)
-            for part in (self.flat_g[:lo], self.flat_g[hi:]):
+            for part in (self.flat_g[:lo], self.flat_gx[hi:]):
                 if part.numel():
                     works.append(torch.distributed.all_reduce(part, op=torch.distributed.ReduceOp.SUM, group=self.pg,
                                                               async_op=True))
@@ -354,11 +432,13 @@ class TrainEngine:
                 w.wait()
             self._dec_work = None
         else:
-            allreduce_mean_(self.flat_g, self.world, self.pg, prescaled=True, force=self.force_allreduce)
+            allreduce_mean_(self.flat_gx, self.world, self.pg, prescaled=True, force=self.force_allreduce)
         if self.allreduce_events is not None:
             a1.record()
             self.allreduce_events.append((a0, a1))
         self.opt.step()
+        if self.status is not None:
+            self._post_status()
         self.iteration += 1
         self.last_terms = terms
         return loss

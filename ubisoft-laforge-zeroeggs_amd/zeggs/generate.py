@@ -16,6 +16,26 @@ from scipy.io import wavfile
 
 from . import anim, audio, compat
 
+PROFILE = None      # bench.py sets this to a dict: generate_gesture() then adds the wall-clock ms of each stage to it (device
+                    # stages bracketed by a synchronisation -- measurement only, the default path never synchronises for it)
+
+
+class _stage:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PROFILE is not None:
+            import time
+            torch.cuda.synchronize()
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            import time
+            torch.cuda.synchronize()
+            PROFILE[self.name] = PROFILE.get(self.name, 0.0) + (time.perf_counter() - self.t0) * 1e3
+
 
 def split_by_ratio(length, ratio):
     """integer frame splits of the "stitch" blend (reference helpers.py:26-37: truncation, last end = length)"""
@@ -89,11 +109,14 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
 
     with torch.no_grad():
         if audio_file is not None:
-            _, wav = read_wav_mono16k(audio_file)
+            with _stage("wav_read_host"):
+                _, wav = read_wav_mono16k(audio_file)
             n_frames = audio.n_anim_frames(len(wav))
-            feats = torch.as_tensor(audio.preprocess_audio(wav, 60, n_frames, pipe_conf["audio_conf"],
-                                                           pipe_conf["audio_feature_type"]), device=device)
-            speech = speech_net(((feats[None] - audio_mean) / audio_std).contiguous())
+            with _stage("loudness+mel_device"):
+                feats = audio.preprocess_audio_device(wav, 60, n_frames, pipe_conf["audio_conf"],
+                                                      pipe_conf["audio_feature_type"], device)
+            with _stage("speech_encoder_device"):
+                speech = speech_net(((feats[None] - audio_mean) / audio_std).contiguous())
 
         encodings, feat = [], None
         anim_name = "style"
@@ -101,14 +124,17 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
             if style_encoding_type == "example":
                 if isinstance(style[0], (pathlib.PurePath, str)):
                     anim_name = Path(style[0]).stem
-                    clip = anim.bvh_load(style[0])
+                    with _stage("exemplar_bvh_parse_host"):
+                        clip = anim.bvh_load(style[0])
                     if style[1] is not None:
                         clip["rotations"] = clip["rotations"][style[1][0]:style[1][1]]
                         clip["positions"] = clip["positions"][style[1][0]:style[1][1]]
                     assert int(np.ceil(1 / clip["frametime"])) == 60
-                    feat = anim.preprocess_animation(clip, device)
-                    ex = (_example_features(feat) - in_mean) / in_std
-                    z, _, _ = style_net(ex[None].contiguous(), temperature)
+                    with _stage("exemplar_features_device"):
+                        feat = anim.preprocess_animation(clip, device)
+                        ex = (_example_features(feat) - in_mean) / in_std
+                    with _stage("style_encoder_device"):
+                        z, _, _ = style_net(ex[None].contiguous(), temperature)
                     encodings.append(z)
                 elif isinstance(style[0], np.ndarray):
                     anim_name = style[1]
@@ -138,25 +164,31 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
 
         if audio_file is not None:
             if first_pose is not None:
-                clip = anim.bvh_load(first_pose) if isinstance(first_pose, (pathlib.PurePath, str)) else dict(first_pose)
-                feat = anim.preprocess_animation(clip, device)
+                with _stage("first_pose_bvh_parse_host"):
+                    clip = anim.bvh_load(first_pose) if isinstance(first_pose, (pathlib.PurePath, str)) else dict(first_pose)
+                with _stage("first_pose_features_device"):
+                    feat = anim.preprocess_animation(clip, device)
             g = lambda a: a[0:1].to(torch.float32).contiguous()  # noqa: E731
             root_pos, root_rot, root_vel, root_vrt, lpos, lrot, ltxy, lvel, lvrt = feat[:9]
             gaze_pos = feat[14]
             if final.dim() == 2:
                 final = final.unsqueeze(1).repeat(1, speech.shape[1], 1)
             gaze = g(gaze_pos).repeat(speech.shape[1], 1)[None]
-            out = decoder(g(root_pos), g(root_rot), g(root_vel), g(root_vrt), g(lpos), g(ltxy), g(lvel), g(lvrt),
-                          gaze.contiguous(), speech, final.contiguous(), None, in_mean, in_std, out_mean, out_std, dt)
+            with _stage("decode_device"):
+                out = decoder(g(root_pos), g(root_rot), g(root_vel), g(root_vrt), g(lpos), g(ltxy), g(lvel), g(lvrt),
+                              gaze.contiguous(), speech, final.contiguous(), None, in_mean, in_std, out_mean, out_std, dt)
             V_root_pos, V_root_rot, _, _, V_lpos, V_ltxy = out[0], out[1], out[2], out[3], out[4], out[5]
             if file_name is None:
                 file_name = f"audio_{Path(audio_file).stem}_label_{anim_name}"
             try:
-                anim.write_bvh(str(results_path / (file_name + ".bvh")), V_root_pos[0], V_root_rot[0], V_lpos[0],
-                               V_ltxy[0], parents=parents,
-                               names=bone_names, order="zyx", dt=dt, start_position=np.array([0, 0, 0]),
-                               start_rotation=np.array([1, 0, 0, 0]))
-                copyfile(audio_file, str(results_path / (file_name + ".wav")))
+                with _stage("pose_to_bvh_device"):
+                    channels = anim.bvh_channels(V_root_pos[0], V_root_rot[0], V_lpos[0], V_ltxy[0], np.array([0, 0, 0]),
+                                                 np.array([1, 0, 0, 0]))
+                with _stage("bvh_text_write_host"):
+                    anim.write_bvh_channels(str(results_path / (file_name + ".bvh")), *channels, parents=parents,
+                                            names=bone_names, order="zyx", dt=dt)
+                with _stage("wav_copy_host"):
+                    copyfile(audio_file, str(results_path / (file_name + ".wav")))
             except (PermissionError, OSError) as e:
                 print(e)
     return final

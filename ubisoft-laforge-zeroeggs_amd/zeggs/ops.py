@@ -57,6 +57,14 @@ DecPtrs = _ptr_struct("DecPtrs", DEC_FIELDS)
 DecStats = _ptr_struct("DecStats", ("in_mean", "in_std", "out_mean", "out_std"))
 
 
+class DecCall(C.Structure):       # mirrors ZeggsDecCall: the per-call controls of zeggs_decoder_fwd_ex / _bwd_ex
+    _fields_ = [("prepared", C.c_int), ("defer_wgrads", C.c_int), ("wgrad_stream", C.c_void_p), ("status", C.c_void_p)]
+
+
+STATUS_WORDS = 4                                   # ZEGGS_STATUS_WORDS
+GAVE_UP = {1: "B=1 decode kernel", 2: "training rollout", 4: "BPTT sweep"}     # ZEGGS_GAVE_UP_* bits of status[0]
+
+
 def lib():
     """Load the HIP library (built by __graft_entry__.build() / csrc/build.sh)."""
     global _LIB
@@ -173,13 +181,28 @@ def release_wgrad_workspaces():
 
 
 def set_wgrad_stream(stream):
-    """Engine hook (direct-gradient mode only): `stream` = side_stream(): the decoder backward lets the library run the
-    weight-gradient GEMMs of its recurrent layers there (option "defer_wgrads"), beside the encoders' backward; the CALLER
+    """Engine hook (direct-gradient mode only): the decoder backward lets the library enqueue the weight-gradient GEMMs of
+    its recurrent layers on `stream` (ZeggsDecCall.defer_wgrads / .wgrad_stream), beside the encoders' backward; the CALLER
     joins (`wait_stream`) before it reads a decoder gradient.  None: everything on the current stream."""
     global _WGRAD_STREAM
-    if stream is not None and stream.cuda_stream != side_stream(stream.device).cuda_stream:
-        raise ValueError("set_wgrad_stream: the stream must be ops.side_stream() (the library enqueues the GEMMs itself)")
     _WGRAD_STREAM = stream
+
+
+_STATUS = None
+_INFER_STATUS = {}
+
+
+def new_status(device):
+    """Zeroed status words (ZeggsDecCall.status): [0] sticky ZEGGS_GAVE_UP_* bits, [1] optimizer steps skipped because of them."""
+    t = torch.empty(STATUS_WORDS, dtype=torch.int32, device=device)
+    fill_(t.view(torch.float32))
+    return t
+
+
+def set_status(status):
+    """Engine hook: the device status words the training-mode decoder calls report give-ups into (None: none)."""
+    global _STATUS
+    _STATUS = status
 
 
 def _grad_targets(orig_params, params):
@@ -456,12 +479,21 @@ def decoder_param_list(dec):
 _PREPARED = None
 
 
+def _drop_prepared():
+    """Forget a preparation nobody picked up (an eval / no_grad call, another batch size, an exception in between): the
+    prepare kernels may still be WRITING the workspace on the side stream, and the block goes back to the current stream's
+    pool -- so the current stream waits for them first."""
+    global _PREPARED
+    prep, _PREPARED = _PREPARED, None
+    if prep is not None:
+        torch.cuda.current_stream().wait_event(prep[2])
+
+
 def decoder_prepare(dec, B, T, SP, ST, in_mean, in_std, out_mean, out_std, dt, stream):
     """Weight-only preparation of the NEXT training-mode decoder_core call with these dimensions (zeggs_decoder_prepare) on
     `stream`, beside whatever the current stream does meanwhile (the encoders' forward); that call picks the prepared
     workspace up and waits for it.  The weights must not change in between."""
-    global _PREPARED
-    _PREPARED = None
+    _drop_prepared()
     params = [_f32c(t) for t in decoder_param_list(dec)]
     stats = [_f32c(t) for t in (in_mean, in_std, out_mean, out_std)]
     PO, H = int(stats[2].numel()), dec.recurrent_decoder.layer1.hidden_size
@@ -500,34 +532,56 @@ class _DecoderFn(torch.autograd.Function):
         training = bool(grad_mode) and any(ctx.needs_input_grad)
         d = DecDims(B, T, PO + 3, PO, SP, ST, H, float(dt), 1 if len(params) == len(DEC_FIELDS) else 0)
         L = lib()
+        dev = pose0.device
         global _PREPARED
-        prep, _PREPARED = _PREPARED, None
+        prep = _PREPARED
         mask = 0
         if prep is not None and training and prep[0] == (d.B, d.T, d.PI, d.PO, d.SP, d.ST, d.H, d.film,
                                                          tuple(t.data_ptr() for t in params)):
+            _PREPARED = None
             _, ws, ev, mask = prep                          # packs of this step's weights, made on a second stream
             torch.cuda.current_stream().wait_event(ev)
         else:
+            _drop_prepared()                                # (waits for the side stream before the block is released)
             ws = _ws(L.zeggs_decoder_workspace_bytes(C.byref(d), int(training)), pose0.device)
-        dev = pose0.device
         pose = torch.empty(B, T, PO, device=dev, dtype=torch.float32)
         rpos = torch.empty(B, T, 3, device=dev, dtype=torch.float32)
         rrot = torch.empty(B, T, 4, device=dev, dtype=torch.float32)
         P = _ptrs(DecPtrs, DEC_FIELDS, params)
         S = _ptrs(DecStats, ("in_mean", "in_std", "out_mean", "out_std"), stats)
-        if mask & 1:
-            _check(L.zeggs_set_option(b"fwd_prepared", 1), "set_option")
-        try:
-            _check(L.zeggs_decoder_fwd(C.byref(d), C.byref(P), C.byref(S), _p(pose0), _p(rpos0), _p(rrot0), _p(gaze),
-                                       _p(speech), _p(style), _p(pose), _p(rpos), _p(rrot), int(training), _p(ws),
-                                       C.c_size_t(ws.numel()), _stream()), "decoder_fwd")
-        finally:
-            if mask & 1:
-                _check(L.zeggs_set_option(b"fwd_prepared", 0), "set_option")
+        capturing = torch.cuda.is_current_stream_capturing()
+        if training:
+            status = _STATUS
+        else:           # inference: a per-device status word, inspected right after the rollout (below)
+            status = _INFER_STATUS.get(dev.index)
+            if status is None and not capturing:
+                status = _INFER_STATUS[dev.index] = new_status(dev)
+        call = DecCall(int(mask) & 1, 0, None, status.data_ptr() if status is not None else None)
+
+        def run():
+            _check(L.zeggs_decoder_fwd_ex(C.byref(d), C.byref(P), C.byref(S), _p(pose0), _p(rpos0), _p(rrot0), _p(gaze),
+                                          _p(speech), _p(style), _p(pose), _p(rpos), _p(rrot), int(training), _p(ws),
+                                          C.c_size_t(ws.numel()), _stream(), C.byref(call)), "decoder_fwd")
+        run()
+        if not training and status is not None and not capturing:
+            # an inference rollout's outputs are consumed right away (BVH export, sample rendering): look at the sticky
+            # give-up word first.  (One 16-byte read-back per rollout; inside a capture the NaN poisoning is what is left.)
+            bits = int(status[0].item())
+            if bits:
+                import warnings
+                warnings.warn("zeggs: a persistent decode kernel gave up (" +
+                              ", ".join(n for b, n in GAVE_UP.items() if bits & b) +
+                              "; another tenant on the GPU?); it is disabled for this process and the rollout is redone "
+                              "on the stage kernels")
+                set_option("persistent", 0)
+                fill_(status.view(torch.float32))
+                run()
         global _LAST_DECODER_WS
-        _LAST_DECODER_WS = (d, int(training), ws)
+        if _CHAIN_DIAGNOSTICS:          # (diagnostic of the off-by-default "chain" option only: pins the workspace)
+            _LAST_DECODER_WS = (d, int(training), ws)
         if training:
             ctx.d, ctx.ws = d, ws
+            ctx.status = status
             ctx.bwd_prepared = bool(mask & 2)
             ctx.save_for_backward(gaze, pose, rpos, rrot, *stats, *params)
             ctx.set_materialize_grads(False)      # missing output gradients are zero-filled by our own kernel in backward
@@ -553,19 +607,12 @@ class _DecoderFn(torch.autograd.Function):
         # with a gradient exchange waiting (engine hook) the deferred GEMMs come in two halves of the parameter order, so that
         # the all-reduce of one runs underneath the GEMMs of the other
         chunked = side is not None and _AFTER_DECODER_BWD is not None
-        if side is not None:
-            _check(L.zeggs_set_option(b"defer_wgrads", 2 if chunked else 1), "set_option")
-        if ctx.bwd_prepared:
-            _check(L.zeggs_set_option(b"bwd_prepared", 1), "set_option")
-        try:
-            _check(L.zeggs_decoder_bwd(C.byref(d), C.byref(P), C.byref(S), _p(gaze), _p(pose), _p(rpos), _p(rrot),
-                                       _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
-                                       C.c_size_t(ctx.ws.numel()), _stream()), "decoder_bwd")
-        finally:
-            if side is not None:
-                _check(L.zeggs_set_option(b"defer_wgrads", 0), "set_option")
-            if ctx.bwd_prepared:
-                _check(L.zeggs_set_option(b"bwd_prepared", 0), "set_option")
+        call = DecCall(2 if ctx.bwd_prepared else 0, 0 if side is None else (2 if chunked else 1),
+                       side.cuda_stream if side is not None else None,
+                       ctx.status.data_ptr() if ctx.status is not None else None)
+        _check(L.zeggs_decoder_bwd_ex(C.byref(d), C.byref(P), C.byref(S), _p(gaze), _p(pose), _p(rpos), _p(rrot),
+                                      _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
+                                      C.c_size_t(ctx.ws.numel()), _stream(), C.byref(call)), "decoder_bwd")
         if side is not None:
             # the library has put the recurrent layers' weight-gradient GEMMs on its second stream (they read only what the
             # sweep left in the workspace), beside the CellStateEncoder / encoder backward on this one
@@ -583,6 +630,7 @@ class _DecoderFn(torch.autograd.Function):
 
 
 _LAST_DECODER_WS = None
+_CHAIN_DIAGNOSTICS = False      # set by set_option("chain", 1): keep the last decoder workspace for last_decoder_chain_errors()
 
 
 def last_decoder_chain_errors():
@@ -675,9 +723,23 @@ def training_loss(o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze, parents,
 
 
 # ----------------------------------------------------------------------------- optimizer / data
-def radam_step(p, g, m, v, beta1, beta2, eps, step_scale, rectified):
-    _check(lib().zeggs_radam_step(_p(p), _p(g), _p(m), _p(v), C.c_long(p.numel()), C.c_float(beta1), C.c_float(beta2),
-                                  C.c_float(eps), C.c_float(step_scale), int(rectified), _stream()), "radam_step")
+def radam_step(p, g, m, v, beta1, beta2, eps, step_scale, rectified, status=None, gflag=None):
+    """status (int32[STATUS_WORDS], device): the guarded step -- a no-op on the device, counted in status[1], when a
+    persistent sweep of the iteration gave up here (status[0]) or on another rank (gflag, a device float)."""
+    if status is None:
+        _check(lib().zeggs_radam_step(_p(p), _p(g), _p(m), _p(v), C.c_long(p.numel()), C.c_float(beta1),
+                                      C.c_float(beta2), C.c_float(eps), C.c_float(step_scale), int(rectified),
+                                      _stream()), "radam_step")
+    else:
+        _check(lib().zeggs_radam_step_guarded(_p(p), _p(g), _p(m), _p(v), C.c_long(p.numel()), C.c_float(beta1),
+                                              C.c_float(beta2), C.c_float(eps), C.c_float(step_scale), int(rectified),
+                                              C.c_void_p(status.data_ptr()), _p(gflag) if gflag is not None else None,
+                                              _stream()), "radam_step_guarded")
+
+
+def status_flag(status, dst):
+    """dst[0] (device float) = 1.0 if status[0] has a give-up bit, else 0.0 -- the word that rides on the gradient all-reduce"""
+    _check(lib().zeggs_status_flag(C.c_void_p(status.data_ptr()), _p(dst), _stream()), "status_flag")
 
 
 def gather_windows(frames, starts, T):
@@ -713,4 +775,9 @@ def normalize_rows_(x, mean, std):
 
 def set_option(name, value):
     """Runtime switches of the library (e.g. "decoder_fast": 1 packed stage kernels / 0 generic GEMM path)."""
+    global _CHAIN_DIAGNOSTICS, _LAST_DECODER_WS
     _check(lib().zeggs_set_option(name.encode(), int(value)), "set_option")
+    if name == "chain":
+        _CHAIN_DIAGNOSTICS = bool(value)
+        if not value:
+            _LAST_DECODER_WS = None

@@ -43,6 +43,20 @@ class RAdam(Optimizer):
         super().__init__(params, defaults)
         self._flat = None      # (p, g, m, v) flat buffers when attached
         self._step = 0
+        self._guard = None     # (status words, all-reduced flag or None): the flat step is skipped ON THE DEVICE on a give-up
+
+    def attach_guard(self, status, gflag=None):
+        """zeggs_radam_step_guarded for the flat step: `status` = the engine's sticky give-up words, `gflag` = the device
+        float that carries every rank's flag through the gradient all-reduce (data-parallel runs)."""
+        self._guard = (status, gflag)
+
+    def rewind(self, nsteps):
+        """Steps the device skipped (status[1]) never happened: the bias corrections must not count them."""
+        self._step = max(0, self._step - int(nsteps))
+        for group in self.param_groups:
+            for q in group["params"]:
+                if "step" in self.state[q]:
+                    self.state[q]["step"] = self._step
 
     def attach_flat(self, flat_p, flat_g, keep_state=False):
         """Run the step as ONE kernel over flat buffers (all params must be views of flat_p in order).
@@ -73,7 +87,8 @@ class RAdam(Optimizer):
                 step = self._step
                 rect, scale, active = radam_scalars(step, group["lr"], beta1, beta2, self.degenerated_to_sgd)
                 p, g, m, v = self._flat
-                ops.radam_step(p, g, m, v, beta1, beta2, group["eps"], scale if active else 0.0, rect)
+                st, gf = self._guard if self._guard is not None else (None, None)
+                ops.radam_step(p, g, m, v, beta1, beta2, group["eps"], scale if active else 0.0, rect, st, gf)
                 for q in group["params"]:
                     self.state[q]["step"] = step
                 continue
