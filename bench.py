@@ -197,12 +197,15 @@ def cpu_baselines(data):
         # configs_v1.json:37); bounded samples (2 + 1 steady iterations; iteration 0 = checkpoint + sample rendering is skipped)
         from oracle import ref_timing
         ncpu = os.cpu_count() or 1
-        r = ref_timing.measure(iters=2, frames=600, train_threads=(None,), legs=("train", "decode", "mel"))
+        # "all cores" = the physical cores, capped at 32 threads: torch's intra-op pool gets SLOWER beyond that on this
+        # workload (hundreds of sub-millisecond ops per decoder step, each a fork-join over the pool)
+        nthr = max(1, min(physical_cores(), 32))
+        r = ref_timing.measure(iters=2, frames=600, train_threads=(nthr,), legs=("train", "decode", "mel"))
         tr = next(iter(r["train"].values()))
         train = {"value": tr["frames_per_s"], "unit": "frames/s", "cores": tr["threads"], "kind": "reference",
                  "sample": f"{tr['iterations_timed']} steady iterations of the unmodified reference train() "
                            f"(ZEGGS/train.py:29), B={BATCH} x {WINDOW}, {np.mean(tr['s_per_iteration']):.2f} s/iteration, "
-                           f"thread_count={tr['threads']} (all logical cores of this box)",
+                           f"thread_count={tr['threads']} (of {ncpu} logical / {physical_cores()} physical cores of this box)",
                  "source": r["reference"], "cpu": r["cpu"]}
         if ncpu > 1 and not os.environ.get("ZEGGS_BENCH_SKIP_1THREAD"):
             r1 = ref_timing.measure(iters=1, train_threads=(1,), legs=("train",))

@@ -383,6 +383,10 @@ typedef struct {
 int zeggs_pose_to_bvh(const ZeggsBvhDims*, const float* root_pos, const float* root_rot, const float* lpos,
                       const float* ltxy, double* positions, double* euler_deg, void* stream);
 
+/* HOST helper of write_bvh / bvh.save (ZEGGS/anim/bvh.py: one text row per frame, "%f" per channel, a space after every
+ * number): appends (append != 0) or writes `rows` x `cols` HOST doubles to `path`.  No device work. */
+int zeggs_write_table_text(const char* path, int append, const double* table /* host */, long rows, int cols);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,7 +53,17 @@ def load():
     import torch
 
     if "zeggs_ref_loaded" in sys.modules:
-        return sys.modules["zeggs_ref_loaded"]
+        ns = sys.modules["zeggs_ref_loaded"]
+        for k, v in ns.ref_entries.items():      # (re-)claim the top-level names, see release()
+            _saved.setdefault(k, sys.modules.get(k))
+            sys.modules[k] = v
+        return ns
+    # The reference's files import each other by TOP-LEVEL name (`from modules import ...`) and its checkpoints pickle
+    # classes under those names; zeggs.compat.alias_reference_modules() may have bound `modules` / `optimizers` to the drop-in
+    # classes in this process.  The reference takes the names while it runs; release() gives them back.
+    for k in ("modules", "optimizers", "train", "generate", "data_pipeline", "dataset", "helpers", "utils", "anim"):
+        if k in sys.modules:
+            _saved[k] = sys.modules.pop(k)
     REF = root() / "ZEGGS"              # noqa: N806  (the live checkout or the unpacked snapshot)
     sys.path.insert(0, str(REF))
     tb = types.ModuleType("torch.utils.tensorboard")
@@ -99,5 +109,21 @@ def load():
         return _orig_load(*a, **k)
 
     ns.torch_load = _load
+    ns.ref_entries = {k: sys.modules[k] for k in ("modules", "optimizers", "train", "generate", "data_pipeline", "dataset",
+                                                  "helpers") if k in sys.modules}
     sys.modules["zeggs_ref_loaded"] = ns
     return ns
+
+
+_saved = {}
+
+
+def release():
+    """Give the top-level module names the reference occupied back to whoever held them before load() (the drop-in aliases of
+    zeggs.compat) -- the loaded reference stays usable through the namespace load() returned until the next load()."""
+    for k, v in list(_saved.items()):
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+    _saved.clear()

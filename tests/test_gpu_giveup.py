@@ -68,7 +68,6 @@ def test_training_giveup_is_skipped_on_device_and_replayed_on_the_stage_kernels(
     assert any("gave up" in str(w.message) for w in rec)
     assert eng.recovered_steps == engine.TrainEngine.STATUS_LAG and eng.iteration == steps == eng.opt._step
     assert int(eng.status.cpu()[0]) == 0 and int(eng.status.cpu()[1]) == 0
-    assert ops.lib().zeggs_persistent_state(1) != 1 or True
     w = eng.flat_p.detach().cpu().numpy()
     assert np.isfinite(w).all()
     # steps 0..1 ran on the persistent kernels (1e-6 apart from the stage kernels), everything after on the stage kernels
@@ -100,8 +99,8 @@ def test_inference_giveup_redoes_the_rollout_on_the_stage_launches(restore_optio
         warnings.simplefilter("always")
         redone = _rollout(de, 40)
     assert any("gave up" in str(w.message) for w in rec)
-    for a, b in zip(redone, stage):
-        assert torch.isfinite(a).all() and torch.equal(a, b)   # the stage launches' frames, bit for bit
+    for a, b in zip(redone, stage):      # the stage launches' frames (run to run they differ by the prologue GEMMs' split-K atomics)
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) < 2e-6
 
 
 def test_two_decoders_interleave_in_one_process(restore_options):

@@ -24,6 +24,8 @@ extern int g_chain;
 extern int g_persistent;
 extern int g_train_persistent;
 extern int g_bwd_persistent;
+extern int g_fused_attention;
+extern int g_gemm_streamk;
 extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "decoder_fast") == 0) { g_decoder_fast = value; return 0; }
   if (strcmp(name, "stage_variant") == 0) { g_stage_variant = value; return 0; }
@@ -46,6 +48,8 @@ extern "C" int zeggs_set_option(const char* name, int value) {
     if (value && dec_persistent_state() == 0) dec_persistent_set_state(-1);
     return 0;
   }
+  if (strcmp(name, "gemm_streamk") == 0) { g_gemm_streamk = value != 0; return 0; }
+  if (strcmp(name, "fused_attention") == 0) { g_fused_attention = value != 0; return 0; }
   if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
   // bound of every device-side wait of the persistent kernels (polls); 0 makes the first unsatisfied wait give up: the
   // tests use it to drive the give-up path (tests/test_gpu_giveup.py)

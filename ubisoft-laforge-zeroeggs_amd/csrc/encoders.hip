@@ -145,6 +145,9 @@ struct StyleWs {
   float *xp, *c1, *m1, *r1, *a1p, *c2, *m2, *r2, *h, *qkv, *P, *Pd, *O, *ao, *ma, *ra, *ap, *f1p, *f2, *mf, *rf, *f;
   // scratch (backward)
   float *S, *t0, *t1, *t2, *t3, *dqkv, *dwf;
+  // fused attention (attention.hip): row log-sum-exp (saved) and rowsum(dO . O) (backward scratch) instead of S / P / Pd
+  float *lse, *dsum;
+  int fused;
 };
 
 StyleWs carve_style(const ZeggsStyleDims& d, Arena& a) {
@@ -161,15 +164,24 @@ StyleWs carve_style(const ZeggsStyleDims& d, Arena& a) {
   w.c2 = a.f(BL * E); w.m2 = a.f(BL); w.r2 = a.f(BL);
   w.h = a.f(BL * E);
   w.qkv = a.f(BL * 3 * E);
-  w.P = a.f(B * NH * L * L);
-  w.Pd = d.dropout ? a.f(B * NH * L * L) : nullptr;
+  // (the choice depends on the dimensions and a process-wide tuning switch only: forward and backward of one call pair carve
+  //  the same layout unless the switch is flipped in between)
+  w.fused = attn_fused_supported(E, NH);
+  w.lse = w.dsum = nullptr;
+  if (w.fused) {
+    w.P = w.Pd = nullptr;
+    w.lse = a.f(B * NH * L); w.dsum = a.f(B * NH * L);
+  } else {
+    w.P = a.f(B * NH * L * L);
+    w.Pd = d.dropout ? a.f(B * NH * L * L) : nullptr;
+  }
   w.O = a.f(BL * E);
   w.ao = a.f(BL * E); w.ma = a.f(BL); w.ra = a.f(BL);
   w.ap = a.f(B * LP * E);
   w.f1p = a.f(B * LP * E);
   w.f2 = a.f(BL * E); w.mf = a.f(BL); w.rf = a.f(BL);
   w.f = a.f(BL * E);
-  w.S = a.f(B * NH * L * L);
+  w.S = w.fused ? nullptr : a.f(B * NH * L * L);
   long big = BL * (long)(H > 3 * E ? H : 3 * E);
   // t0 / t3 hold padded rows of width H AND of width E (k_pad_rows(..., E)); dwf holds the packed weight gradient of
   // every conv in turn (3*C*H, 3*H*E, 3*E*E): size them for the widest user, whatever the option dictionary says
@@ -220,6 +232,9 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
   ZTRY(k_add_rows_bcast(w.h, pos, B, L, E, s));
   // multi-head self attention
   ZTRY(gemm_nt(w.h, E, P->in_w, E, w.qkv, 3 * E, P->in_b, (int)BL, 3 * E, E, ACT_NONE, 0.f, s));
+  if (w.fused) {      // softmax(Q K^T / sqrt(hd)) -> dropout -> . V in one kernel (attention.hip)
+    ZTRY(k_attn_fwd(w.qkv, w.O, w.lse, B, L, E, NH, p1, d.seed + 3, s));
+  } else {
   {
     GemmArgs g = gemm_args(w.qkv, w.qkv + E, w.S, L, L, HD);            // S = Q K^T / sqrt(hd)
     g.sam = 3 * E; g.sak = 1; g.sbk = 1; g.sbn = 3 * E; g.scm = L; g.scn = 1;
@@ -235,6 +250,7 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
     g.nb1 = NH; g.bsA0 = (long)NH * L * L; g.bsA1 = (long)L * L; g.bsB0 = (long)L * 3 * E; g.bsB1 = HD;
     g.bsC0 = (long)L * E; g.bsC1 = HD;
     ZTRY(launch_gemm(g, B * NH, s));
+  }
   }
   ZTRY(gemm_nt(w.O, E, P->out_w, E, w.ao, E, P->out_b, (int)BL, E, E, ACT_NONE, 0.f, s));
   ZTRY(k_dropout(w.ao, BL * E, p1, d.seed + 4, s));
@@ -296,6 +312,9 @@ extern "C" int zeggs_style_encoder_bwd(const ZeggsStyleDims* dp, const ZeggsStyl
   ZTRY(gemm_tn(t1, E, w.O, E, G->out_w, E, (int)BL, E, E, 0.f, s));
   ZTRY(k_colsum(G->out_b, t1, BL, E, E, 0.f, s));
   ZTRY(gemm_nn(t1, E, P->out_w, E, t2, E, (int)BL, E, E, 0.f, s));              // t2 = dO [BL,E]
+  if (w.fused) {      // dQ, dK, dV with the probabilities recomputed from the saved row log-sum-exp (attention.hip)
+    ZTRY(k_attn_bwd(w.qkv, w.O, w.lse, t2, w.dqkv, w.dsum, B, L, E, NH, p1, d.seed + 3, s));
+  } else {
   const float* Pm = w.Pd ? w.Pd : w.P;
   {
     GemmArgs g = gemm_args(t2, w.qkv + 2 * E, w.S, L, L, HD);                   // dPd = dO V^T  -> S
@@ -326,6 +345,7 @@ extern "C" int zeggs_style_encoder_bwd(const ZeggsStyleDims* dp, const ZeggsStyl
     g.nb1 = NH; g.bsA0 = (long)NH * L * L; g.bsA1 = (long)L * L; g.bsB0 = (long)L * 3 * E; g.bsB1 = HD;
     g.bsC0 = (long)L * 3 * E; g.bsC1 = HD; g.alpha = sc;
     ZTRY(launch_gemm(g, B * NH, s));
+  }
   }
   ZTRY(gemm_tn(w.dqkv, 3 * E, w.h, E, G->in_w, E, (int)BL, 3 * E, E, 0.f, s));
   ZTRY(k_colsum(G->in_b, w.dqkv, BL, 3 * E, 3 * E, 0.f, s));

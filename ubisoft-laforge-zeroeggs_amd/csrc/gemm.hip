@@ -74,42 +74,21 @@ __device__ __forceinline__ void load_full(float (&r)[E], const float* p) {
 #ifndef ZEGGS_GEMM_SWIZZLE
 #define ZEGGS_GEMM_SWIZZLE 1
 #endif
+// One output tile (m_base, n_base) of batch entry (A, B, C) over the k-tiles [t_begin, ntiles) of its contraction (a tile has
+// nkt * kbatch of them).  atomic: the result is a partial sum -> fp32 atomics onto C (split-K / stream-K segments).
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
-__global__ __launch_bounds__(WM* WN * 64, ZEGGS_GEMM_MINB) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const float* A, const float* B, float* C, int m_base, int n_base,
+                                          int t_begin, int ntiles, bool atomic, float* As2base, float* Bs2base) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MT = TM / 32, NTL = TN / 32;
   constexpr int EA = BM * BK / NT, EB = BN * BK / NT;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   static_assert(EA >= 1 && EB >= 1 && (EA == 1 || EA == 2 || EA == 4 || EA == 8), "tile/threads");
-  __shared__ __attribute__((aligned(16))) float As2[2][BK * LDA];   // double-buffered: one barrier per k-tile
-  __shared__ __attribute__((aligned(16))) float Bs2[2][BK * LDB];
-
+  float (*As2)[BK * LDA] = (float (*)[BK * LDA])As2base;
+  float (*Bs2)[BK * LDB] = (float (*)[BK * LDB])Bs2base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  // Tile order.  Workgroups go to the 8 XCDs round-robin in launch order, and every XCD has its own L2: XCD k takes the k-th
-  // CONTIGUOUS eighth of the tile list instead of every eighth tile, and within a k-split the list walks groups of GEMM_GM tile
-  // rows column by column, so the tiles in flight on an XCD share a few A row panels and B column panels.
-  int bx = blockIdx.x, by = blockIdx.y, zz = blockIdx.z;
-  if (ZEGGS_GEMM_SWIZZLE) {
-    const unsigned gx = gridDim.x, gy = gridDim.y, plane = gx * gy, total = plane * gridDim.z;
-    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    const unsigned xcd = L & 7, idx = L >> 3, q = total >> 3, r = total & 7;
-    const unsigned Lp = xcd * q + (xcd < r ? xcd : r) + idx;
-    const unsigned pid = Lp % plane;
-    zz = (int)(Lp / plane);
-    constexpr unsigned GM = 4;
-    const unsigned width = GM * gx, group = pid / width, first = group * GM, gsz = gy - first < GM ? gy - first : GM;
-    by = (int)(first + (pid % width) % gsz);
-    bx = (int)((pid % width) / gsz);
-  }
-  const int m_base = by * BM, n_base = bx * BN;
-  const int z = zz / g.splitk, ks = zz % g.splitk;
-  const long z0 = z / g.nb1, z1 = z % g.nb1;
-  const float* A = g.A + z0 * g.bsA0 + z1 * g.bsA1;
-  const float* B = g.B + z0 * g.bsB0 + z1 * g.bsB1;
-  float* C = g.C + z0 * g.bsC0 + z1 * g.bsC1;
-
   // loader coordinates
   int a_r, a_c, b_r, b_c;  // (row within tile along the non-contiguous dim, start along the contiguous dim)
   if constexpr (AKC) { a_r = tid / (BK / EA); a_c = (tid % (BK / EA)) * EA; }   // a_r = m, a_c = k0
@@ -118,8 +97,6 @@ __global__ __launch_bounds__(WM* WN * 64, ZEGGS_GEMM_MINB) void gemm_kernel(Gemm
   else               { b_r = tid / (BN / EB); b_c = (tid % (BN / EB)) * EB; }   // b_r = k, b_c = n0
 
   const int nkt = (g.K + BK - 1) / BK;
-  const int ntiles_all = nkt * g.kbatch;
-  const int t_begin = (int)((long)ntiles_all * ks / g.splitk), ntiles = (int)((long)ntiles_all * (ks + 1) / g.splitk);
   float ra[EA], rb[EB];
 
   // interior blocks take a branch-free path (unguarded vector loads); edge blocks / the K tail use guarded loads
@@ -222,12 +199,77 @@ __global__ __launch_bounds__(WM* WN * 64, ZEGGS_GEMM_MINB) void gemm_kernel(Gemm
         const int m = m_base + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (m >= g.M) continue;
         float* cp = C + (long)m * g.scm + (long)n * g.scn;
-        if (g.splitk > 1) { atomicAdd(cp, g.alpha * acc[i][j][r]); continue; }
+        if (atomic) { atomicAdd(cp, g.alpha * acc[i][j][r]); continue; }
         float v = g.alpha * acc[i][j][r] + bv;
         if (g.beta != 0.f) v += g.beta * (*cp);
         *cp = d_act(v, g.act);
       }
     }
+}
+
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
+__global__ __launch_bounds__(WM* WN * 64, ZEGGS_GEMM_MINB) void gemm_kernel(GemmArgs g) {
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  __shared__ __attribute__((aligned(16))) float As2[2][BK * LDA];   // double-buffered: one barrier per k-tile
+  __shared__ __attribute__((aligned(16))) float Bs2[2][BK * LDB];
+  // Tile order.  Workgroups go to the 8 XCDs round-robin in launch order, and every XCD has its own L2: XCD k takes the k-th
+  // CONTIGUOUS eighth of the tile list instead of every eighth tile, and within a k-split the list walks groups of GEMM_GM tile
+  // rows column by column, so the tiles in flight on an XCD share a few A row panels and B column panels.
+  int bx = blockIdx.x, by = blockIdx.y, zz = blockIdx.z;
+  if (ZEGGS_GEMM_SWIZZLE) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, plane = gx * gy, total = plane * gridDim.z;
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = L & 7, idx = L >> 3, q = total >> 3, r = total & 7;
+    const unsigned Lp = xcd * q + (xcd < r ? xcd : r) + idx;
+    const unsigned pid = Lp % plane;
+    zz = (int)(Lp / plane);
+    constexpr unsigned GM = 4;
+    const unsigned width = GM * gx, group = pid / width, first = group * GM, gsz = gy - first < GM ? gy - first : GM;
+    by = (int)(first + (pid % width) % gsz);
+    bx = (int)((pid % width) / gsz);
+  }
+  const int m_base = by * BM, n_base = bx * BN;
+  const int z = zz / g.splitk, ks = zz % g.splitk;
+  const long z0 = z / g.nb1, z1 = z % g.nb1;
+  const float* A = g.A + z0 * g.bsA0 + z1 * g.bsA1;
+  const float* B = g.B + z0 * g.bsB0 + z1 * g.bsB1;
+  float* C = g.C + z0 * g.bsC0 + z1 * g.bsC1;
+
+  const int ntiles_all = ((g.K + BK - 1) / BK) * g.kbatch;
+  const int t_begin = (int)((long)ntiles_all * ks / g.splitk), ntiles = (int)((long)ntiles_all * (ks + 1) / g.splitk);
+  gemm_tile<BM, BN, WM, WN, AKC, BKC>(g, A, B, C, m_base, n_base, t_begin, ntiles, g.splitk > 1, &As2[0][0], &Bs2[0][0]);
+}
+
+// Stream-K form of the split contraction (weight gradients: few output tiles, K = B (T-1) ~ 8000): the (tile, k-tile) iteration
+// space is cut into gridDim.x EQUAL contiguous ranges, one per workgroup, all resident at once (4 per CU) -- every CU gets the
+// same number of matrix-core passes whatever the tile count, and a workgroup runs ~100 k-tiles per epilogue instead of the ~16
+// of the 6144-workgroup split (its pipeline fill, its 16 K atomics per tile and the zero-fill of C amortise over six times the
+// work).  A range that crosses a tile boundary finishes the first tile's share and starts the next: at most two epilogues,
+// always atomics onto the zeroed C.  g.splitk carries the number of k-tiles per output tile here.
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
+__global__ __launch_bounds__(WM* WN * 64, ZEGGS_GEMM_MINB) void gemm_streamk_kernel(GemmArgs g, int tiles_x, int tiles_y) {
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  __shared__ __attribute__((aligned(16))) float As2[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs2[2][BK * LDB];
+  const int kt = g.splitk;                                     // k-tiles of one output tile
+  const long total = (long)tiles_x * tiles_y * kt;
+  // XCD k (workgroups k, k + 8, ...) takes the k-th contiguous eighth of the ranges: neighbouring tiles share its L2
+  const unsigned nwg = gridDim.x, w = blockIdx.x, xcd = w & 7, idx = w >> 3, q = nwg >> 3, r = nwg & 7;
+  const unsigned wl = xcd * q + (xcd < r ? xcd : r) + idx;
+  long it = total * wl / nwg;
+  const long it_end = total * (wl + 1) / nwg;
+  while (it < it_end) {
+    const int tile = (int)(it / kt), k0 = (int)(it % kt);
+    const long left = it_end - it;
+    const int k1 = (long)(kt - k0) < left ? kt : k0 + (int)left;
+    // tiles walk groups of 4 tile rows column by column (as the plain kernel's XCD-aware order does)
+    constexpr int GM = 4;
+    const int width = GM * tiles_x, group = tile / width, first = group * GM, gsz = tiles_y - first < GM ? tiles_y - first : GM;
+    const int by = first + (tile % width) % gsz, bx = (tile % width) / gsz;
+    gemm_tile<BM, BN, WM, WN, AKC, BKC>(g, g.A, g.B, g.C, by * BM, bx * BN, k0, k1, true, &As2[0][0], &Bs2[0][0]);
+    __syncthreads();                                           // the LDS buffers start over
+    it += k1 - k0;
+  }
 }
 
 // skinny-M helpers: zero / finish a strided [M, N] row block (split-K accumulates with atomics, bias + activation follow)
@@ -258,7 +300,31 @@ int launch_cfg(const GemmArgs& g, int nbatch, hipStream_t s) {
   return 0;
 }
 
+int launch_streamk(GemmArgs g, hipStream_t s) {
+  constexpr int BM = 128, BN = 128;
+  const int tx = cdiv(g.N, BN), ty = cdiv(g.M, BM);
+  const int kt = cdiv(g.K, BK) * g.kbatch;
+  g.splitk = kt;
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  long nwg = (long)ncu * ZEGGS_GEMM_MINB;
+  const long total = (long)tx * ty * kt;
+  if (nwg > total / 8) nwg = total / 8 > 0 ? total / 8 : 1;     // at least 8 k-tiles per workgroup
+  dim3 grid((unsigned)nwg), block(256);
+  const bool akc = (g.sak == 1), bkc = (g.sbk == 1) && (g.sbn != 1 || g.N == 1);
+  if (!akc && g.sam != 1) { zeggs_set_error("gemm: A has no unit stride (sam=%ld sak=%ld)", g.sam, g.sak); return -1; }
+  if (!bkc && g.sbn != 1) { zeggs_set_error("gemm: B has no unit stride (sbk=%ld sbn=%ld)", g.sbk, g.sbn); return -1; }
+  if (akc && bkc) hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, 2, 2, true, true>), grid, block, 0, s, g, tx, ty);
+  else if (akc && !bkc) hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, 2, 2, true, false>), grid, block, 0, s, g, tx, ty);
+  else if (!akc && bkc) hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, 2, 2, false, true>), grid, block, 0, s, g, tx, ty);
+  else hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, 2, 2, false, false>), grid, block, 0, s, g, tx, ty);
+  ZLAUNCH_CHECK("gemm_streamk");
+  return 0;
+}
+
 }  // namespace
+
+int g_gemm_streamk = 1;        // zeggs_set_option("gemm_streamk", 0/1): stream-K instead of the many-workgroup split-K
 
 int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || nbatch <= 0) return 0;
@@ -302,6 +368,10 @@ int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   // few output tiles but a long contraction (weight gradients): split K over workgroups, combine with fp32 atomics
   const bool can_split = nbatch == 1 && (g.beta == 0.f || g.beta == 1.f) && g.bias == nullptr && g.act == ACT_NONE &&
                          g.scn == 1 && g.scm == g.N && ktiles >= 64;
+  if (g_gemm_streamk && can_split && big && g.nb1 == 1 && tiles < 1024 * 3 && ktiles >= 64) {
+    if (g.beta == 0.f) ZTRY(k_fill(g.C, (long)g.M * g.N, 0.f, s));     // beta == 1: the atomics accumulate onto C
+    return launch_streamk(g, s);
+  }
   if (tiles < g_gemm_wg_target * 5 / 6 && can_split) {
     long sk = (g_gemm_wg_target + tiles - 1) / tiles;
     if (sk > ktiles / 16) sk = ktiles / 16;

@@ -57,3 +57,9 @@ int k_add_rows_bcast(float* h, const float* table, int B, int L, int C, hipStrea
 // pooled[b,c] = sum_l f[b,l,c] / L ; bwd: df[b,l,c] = dpooled[b,c] / L
 int k_meanpool_fwd(float* out, const float* f, int B, int L, int C, hipStream_t s);
 int k_meanpool_bwd(float* df, const float* dout, int B, int L, int C, hipStream_t s);
+
+// fused multi-head attention of the style encoder (attention.hip); head dimension 32 only (attn_fused_supported)
+int attn_fused_supported(int E, int NH);
+int k_attn_fwd(const float* qkv, float* O, float* lse, int B, int L, int E, int NH, float p, uint64_t seed, hipStream_t s);
+int k_attn_bwd(const float* qkv, const float* O, const float* lse, const float* dO, float* dqkv, float* dsum, int B, int L,
+               int E, int NH, float p, uint64_t seed, hipStream_t s);
