@@ -147,9 +147,11 @@ def _check_engine_iteration(gd, v):
         floor = max(floor, fl)
         rms = lambda a, b: float(np.linalg.norm(a - b) / max(1e-30, np.linalg.norm(b)))  # noqa: E731
         r32, r64 = rms(got, ref32), rms(got, ref64)
-        # (against the fp32 reference its own noise -- its relative RMS distance from the fp64 run -- comes on top)
-        assert r64 < 5e-4 and r32 < 5e-4 + rms(ref32, ref64), \
-            f"param {i}: relative RMS error {r32:.2e} (fp32 reference, whose own fp64 distance is {rms(ref32, ref64):.2e}) / {r64:.2e} (fp64)"
+        # within 5e-4 of (at least) one of the two references, and of the other within 5e-4 plus the references' OWN mutual
+        # distance (for the tensors with the smallest gradients the fp32 reference sits up to 7e-4 from the fp64 run)
+        mutual = rms(ref32, ref64)
+        assert min(r32, r64) < 5e-4 and max(r32, r64) < 5e-4 + mutual, \
+            f"param {i}: relative RMS error {r32:.2e} (fp32 reference) / {r64:.2e} (fp64); the references differ by {mutual:.2e}"
         assert max(e32, e64) * scale < 3e-4 * gmax, \
             f"param {i}: an entry is off by {e32 * scale / gmax:.2e} / {e64 * scale / gmax:.2e} of the tensor's max|g|"
         fp = helpers.fingerprint(p.grad)

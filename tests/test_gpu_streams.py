@@ -45,7 +45,12 @@ def test_side_streams_give_the_single_stream_weights():
 def test_side_streams_at_the_bench_shape():
     """batch 32 x 256 frames, example 384 (both persistent sweeps, their packs prepared on the second stream, the next batch
     prefetched): five optimizer steps end in the weights of the single-stream schedule"""
+    from zeggs import ops
+    hits = ops.prepared_hits
     p1, l1 = _run(True, steps=5, B=32, T=256, L=384, clip=900)
+    # from the second step on (the first one validates the kernels) the forward picks up the workspace whose packs were made
+    # on the second stream: a silent miss costs 0.4 ms per iteration (the packs run twice)
+    assert ops.prepared_hits - hits >= 3, ops.prepared_hits - hits
     p0, l0 = _run(False, steps=5, B=32, T=256, L=384, clip=900)
     assert np.isfinite(p1).all() and np.isfinite(l1).all()
     assert np.abs(p1 - p0).max() <= 5e-6, np.abs(p1 - p0).max()

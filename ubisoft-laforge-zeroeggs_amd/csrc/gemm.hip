@@ -325,6 +325,7 @@ int launch_streamk(GemmArgs g, hipStream_t s) {
 }  // namespace
 
 int g_gemm_streamk = 1;        // zeggs_set_option("gemm_streamk", 0/1): stream-K instead of the many-workgroup split-K
+int g_gemm_mid_split = 1;      // zeggs_set_option("gemm_mid_split", 0/1): split K of the latency-bound narrow-output products
 
 int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || nbatch <= 0) return 0;
@@ -365,6 +366,40 @@ int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   const bool big = g.M > 64 && g.N > 64;
   const long tiles = big ? (long)cdiv(g.M, 128) * cdiv(g.N, 128) * nbatch : (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nbatch;
   const long ktiles = (long)cdiv(g.K, 16) * g.kbatch;
+  // Mid-size products with a narrow output (the style / speech encoders' convolutions and projections: M = B L = 12 288 rows,
+  // N = 128, K = 384 .. 1536): 100 - 400 output tiles walk 24 - 96 k-tiles each with one or two workgroups per CU -- every
+  // k-tile pays its global-load latency in the open (75 - 200 us for 1 - 5 GFLOP).  Split K over a few workgroups per tile
+  // (fp32 atomics onto a zeroed C; bias + activation, if any, in a tiny second pass -- the skinny-M recipe above for any M).
+  {
+    const bool flat_c = g.nb1 == 1 && g.scn == 1 && (nbatch == 1 || g.bsC0 == (long)g.M * g.scm);
+    const bool plain_beta = g.beta == 0.f || (g.beta == 1.f && g.bias == nullptr && g.act == ACT_NONE);
+    const long tiles64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nbatch;
+    const bool streamk_case = g_gemm_streamk && nbatch == 1 && g.bias == nullptr && g.act == ACT_NONE && g.scm == g.N && big &&
+                              ktiles >= 64 && tiles < 1024 * 3;
+    if (g_gemm_mid_split && flat_c && plain_beta && !streamk_case && tiles64 >= 32 && tiles64 < 768 && ktiles >= 16) {
+      long sk = (1024 + tiles64 - 1) / tiles64;
+      if (sk > ktiles / 6) sk = ktiles / 6;
+      if (sk > 8) sk = 8;
+      if (sk > 1) {
+        const float* bias = g.bias;
+        const int act = g.act;
+        const int rows = nbatch * g.M;
+        const long n = (long)rows * g.N, blocks = (n + 255) / 256;
+        if (g.beta == 0.f) {
+          hipLaunchKernelGGL(rows_fill_k, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, g.C, rows, g.N, g.scm);
+          ZLAUNCH_CHECK("gemm_rows_fill");
+        }
+        g.bias = nullptr; g.act = ACT_NONE; g.splitk = (int)sk;
+        ZTRY((launch_cfg<64, 64, 2, 2>(g, nbatch, s)));
+        if (bias || act != ACT_NONE) {
+          hipLaunchKernelGGL(rows_bias_act_k, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, s, g.C, bias, rows,
+                             g.N, g.scm, act);
+          ZLAUNCH_CHECK("gemm_rows_bias_act");
+        }
+        return 0;
+      }
+    }
+  }
   // few output tiles but a long contraction (weight gradients): split K over workgroups, combine with fp32 atomics
   const bool can_split = nbatch == 1 && (g.beta == 0.f || g.beta == 1.f) && g.bias == nullptr && g.act == ACT_NONE &&
                          g.scn == 1 && g.scm == g.N && ktiles >= 64;

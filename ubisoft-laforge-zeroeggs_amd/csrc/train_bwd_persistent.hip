@@ -463,6 +463,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   };
 
   const long OPS = 4L * H * 32;       // floats per step of OP1 / OP0
+  f4 w0[1] = {f4{0.f, 0.f, 0.f, 0.f}}, w1[1] = {f4{0.f, 0.f, 0.f, 0.f}};      // window partial sums of carry0 / carry1 (see P1)
   for (int t = T - 1; t >= 1; --t) {
     const long sidx = T - 1 - t, pA = 4 * sidx, pB = pA + 1, pC = pA + 2, pD = pA + 3;
     const f4* op1 = (const f4*)(a.OP1 + (long)t * OPS) + lane;
@@ -477,12 +478,13 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
         gt = ((const f4*)a.GT1)[(long)t * sH + (long)eb * H + U];
         hp = a.H1[(long)(t - 1) * sH + (long)eb * H + U];
       }
-      if (t < T - 1) {      // window: carry0 += first half of W_hh0^T (DI0 r,z | dn_h0) of step t+1
-        f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
-        bp_mma<1, NJC, OC0A, false, true>(wr, nullptr, (const f4*)(a.OP0 + (long)(t + 1) * OPS) + lane, wave, 0, 96, acct);
-        c0 += window_total(acct[0]);
-      }
-      f4 acc[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+      // window: carry0 += first half of W_hh0^T (DI0 r,z | dn_h0) of step t+1.  The partial sums of a carry's two windows stay
+      // in this wave's accumulator registers and become the START of the main product of the phase that consumes the carry
+      // (w0: P2 of this step, w1: P1 of the next one): its reduction adds them up -- no reduction (LDS round trip + barrier)
+      // of their own in any window
+      w0[0] = f4{0.f, 0.f, 0.f, 0.f};
+      if (t < T - 1) bp_mma<1, NJC, OC0A, false, true>(wr, nullptr, (const f4*)(a.OP0 + (long)(t + 1) * OPS) + lane, wave, 0, 96, w0);
+      f4 acc[1] = {w1[0]};
       wait_phase(pA - 1);
       if (fail) break;
       BPT(1);
@@ -508,12 +510,9 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
         gt = ((const f4*)a.GT0)[(long)t * sH + (long)eb * H + U];
         hp = a.H0[(long)(t - 1) * sH + (long)eb * H + U];
       }
-      if (t < T - 1) {      // window: carry0 += second half of W_hh0^T (.) of step t+1
-        f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
-        bp_mma<1, NJC, OC0B, false, true>(wr, nullptr, (const f4*)(a.OP0 + (long)(t + 1) * OPS) + lane, wave, 96, 96, acct);
-        c0 += window_total(acct[0]);
-      }
-      f4 acc[1] = {f4{0.f, 0.f, 0.f, 0.f}};
+      // window: carry0 += second half of W_hh0^T (.) of step t+1
+      if (t < T - 1) bp_mma<1, NJC, OC0B, false, true>(wr, nullptr, (const f4*)(a.OP0 + (long)(t + 1) * OPS) + lane, wave, 96, 96, w0);
+      f4 acc[1] = {w0[0]};
       wait_phase(pB - 1);
       if (fail) break;
       BPT(5);
@@ -555,11 +554,9 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       refresh();
       float hid = 0.f;
       if (er >= 4 && er < 8 && bact) hid = a.Gin[(long)t * sG + (long)eb * GL + U];
-      {     // window: carry1 += first half of W_hh1^T (DI1_t r,z | dn_h1) -- the operand is one phase old
-        f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
-        bp_mma<1, NJC, OC1A, false, true>(wr, nullptr, op1, wave, 0, 96, acct);
-        c1 += window_total(acct[0]);
-      }
+      // window: carry1 += first half of W_hh1^T (DI1_t r,z | dn_h1) -- the operand is one phase old
+      w1[0] = f4{0.f, 0.f, 0.f, 0.f};
+      bp_mma<1, NJC, OC1A, false, true>(wr, nullptr, op1, wave, 0, 96, w1);
       if (ract && t > 1) {      // root thread: the gradient-independent half of the root backward of frame t-1 (in place)
         RootIn ri;
         ri.gather([&](int item) { return rin[item][eb]; });
@@ -605,11 +602,8 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       refresh();
       float dpo = 0.f;
       if (t > 1 && bact && row4 >= 6 && row4 < PO) dpo = a.dpose[((long)eb * T + t - 1) * PO + row4];
-      {     // window: carry1 += second half of W_hh1^T (DI1_t r,z | dn_h1)
-        f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
-        bp_mma<1, NJC, OC1B, false, true>(wr, nullptr, op1, wave, 96, 96, acct);
-        c1 += window_total(acct[0]);
-      }
+      // window: carry1 += second half of W_hh1^T (DI1_t r,z | dn_h1)
+      bp_mma<1, NJC, OC1B, false, true>(wr, nullptr, op1, wave, 96, 96, w1);
       f4 acc[3] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
       wait_phase(pD - 1);
       if (fail) break;
@@ -683,11 +677,13 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       BPT(16);
     }
   }
-  if (!fail) {          // the carry0 pieces of step 1 (their windows would have been in a step 0)
+  if (!fail) {          // the carry0 pieces of step 1 (their windows would have been in a step 0), the carry1 windows of step 1
     f4 acct[1] = {f4{0.f, 0.f, 0.f, 0.f}};
     bp_mma<1, NJC, OC0A, false, true>(wr, nullptr, (const f4*)(a.OP0 + OPS) + lane, wave, 0, 96, acct);
     bp_mma<1, NJC, OC0B, false, true>(wr, nullptr, (const f4*)(a.OP0 + OPS) + lane, wave, 96, 96, acct);
     c0 += window_total(acct[0]);
+    __syncthreads();
+    c1 += window_total(w1[0]);
   }
   if (!fail && er < 4 && bact) {     // gradients wrt the initial hidden states (CellStateEncoder backward)
     a.dH1c[(long)eb * H + U] = c1;

@@ -250,7 +250,8 @@ class TrainEngine:
         self._status_ring = []
         self._history = collections.deque(maxlen=8)
         self.recovered_steps = 0
-        if torch.device(dev).type == "cuda":
+        import os
+        if torch.device(dev).type == "cuda" and not os.environ.get("ZEGGS_NO_GUARD"):     # (env: A/B measurement of its cost)
             self.status = ops.new_status(dev)
             self.opt.attach_guard(self.status, self._gflag if (world_size > 1 or force_allreduce) else None)
         self.iteration = 0

@@ -477,6 +477,7 @@ def decoder_param_list(dec):
 
 
 _PREPARED = None
+prepared_hits = 0       # decoder forwards that picked up a workspace prepared on the side stream (tests / bench)
 
 
 def _drop_prepared():
@@ -493,6 +494,7 @@ def decoder_prepare(dec, B, T, SP, ST, in_mean, in_std, out_mean, out_std, dt, s
     """Weight-only preparation of the NEXT training-mode decoder_core call with these dimensions (zeggs_decoder_prepare) on
     `stream`, beside whatever the current stream does meanwhile (the encoders' forward); that call picks the prepared
     workspace up and waits for it.  The weights must not change in between."""
+    global _PREPARED
     _drop_prepared()
     params = [_f32c(t) for t in decoder_param_list(dec)]
     stats = [_f32c(t) for t in (in_mean, in_std, out_mean, out_std)]
@@ -540,6 +542,8 @@ class _DecoderFn(torch.autograd.Function):
                                                          tuple(t.data_ptr() for t in params)):
             _PREPARED = None
             _, ws, ev, mask = prep                          # packs of this step's weights, made on a second stream
+            global prepared_hits
+            prepared_hits += 1
             torch.cuda.current_stream().wait_event(ev)
         else:
             _drop_prepared()                                # (waits for the side stream before the block is released)
