@@ -231,7 +231,9 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   // GRU epilogue item of this thread: unit eu, batch row eb; the previous hidden values stay in registers for the rollout
   // (re-derived from an opaque copy of the thread index at the top of every step: the per-thread addresses they feed are not
   //  worth a register pair each for the whole rollout)
-  int eu = tid / BP, eb = tid % BP;
+  // (thread <-> item mapping = the one of the reduction below: thread nb * 64 + l owns float4 l of batch tile nb, which holds
+  //  the four gate sums (r, z, n_input, n_hidden) of unit l >> 4 for batch row 16 nb + (l & 15))
+  int eu = (tid & 63) >> 4, eb = (tid >> 6) * 16 + (tid & 15);
   bool gact = tid < 4 * BP && eb < B;
   int EU = 4 * c + (eu & 3);
   float hp0 = 0.f, hp1 = 0.f;
@@ -267,6 +269,21 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     }
     __syncthreads();
   };
+  // GRU phases: the thread that adds up float4 (nb, l) of the eight waves IS the gate thread of that unit / batch row, so the
+  // sums go from its registers straight into the gate math (no second barrier, no trip through `fin`)
+  auto reduce_gate = [&](f4 (&acc)[NB]) -> f4 {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) red[wave][nb][lane] = acc[nb];
+    __syncthreads();
+    f4 sfv = f4{0.f, 0.f, 0.f, 0.f};
+    if (tid < NB * 64) {
+      const int nb = tid >> 6, l = tid & 63;
+      sfv = red[0][nb][l];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) sfv += red[w][nb][l];
+    }
+    return sfv;
+  };
 #ifdef ZEGGS_TPSTAT
   unsigned long long wsum[3] = {0, 0, 0};      // 100 MHz ticks this workgroup spent polling, per phase kind
 #endif
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     {
       int tx = tid;
       asm volatile("" : "+v"(tx));
-      eu = tx / BP; eb = tx % BP;
+      eu = (tx & 63) >> 4; eb = (tx >> 6) * 16 + (tx & 15);
       gact = tx < 4 * BP && eb < B;
       EU = 4 * c + (eu & 3);
       rb = TTHR - 1 - tx;
@@ -340,7 +357,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       tp_mma<NB, TJ0 - TL0, TNO0 - TL0, TNF0, false>(wr0, nullptr, x0, wave, TFR0, acc);  // fresh part
     }
     TPT(2);
-    reduce(*(SPREAD ? &acc1 : &acc));
+    const f4 fv0 = reduce_gate(*(SPREAD ? &acc1 : &acc));
     TPT(3);
     if (gact) {
       const float* k_ = cA[eu];
@@ -348,10 +365,10 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       float xr, xz, xn;
       if (t == 1) { const float* q = a.p1x + (long)eb * 3 * H + EU; xr = q[0]; xz = q[H]; xn = q[2 * H]; }
       else { xr = cV[eu][0]; xz = cV[eu][1]; xn = cV[eu][2]; }
-      const float r = d_sigmoid(FV(4 * eu, eb) + k_[0] + xr + k_[3]);
-      const float z = d_sigmoid(FV(4 * eu + 1, eb) + k_[1] + xz + k_[4]);
-      const float nh = FV(4 * eu + 3, eb) + k_[5];
-      const float nn = tanhf(FV(4 * eu + 2, eb) + k_[2] + xn + r * nh);
+      const float r = d_sigmoid(fv0[0] + k_[0] + xr + k_[3]);
+      const float z = d_sigmoid(fv0[1] + k_[1] + xz + k_[4]);
+      const float nh = fv0[3] + k_[5];
+      const float nn = tanhf(fv0[2] + k_[2] + xn + r * nh);
       const float h = (1.f - z) * nn + z * hp0;
       hp0 = h;
       const long i = (long)t * sH + (long)eb * H + EU;
@@ -388,14 +405,14 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       tp_mma<NB, TJ1, TNO1, TNF1, false>(wr1, nullptr, x1, wave, 64, acc);                // h0_t
     }
     TPT(7);
-    reduce(*(SPREAD ? &acc2 : &acc));
+    const f4 fv1 = reduce_gate(*(SPREAD ? &acc2 : &acc));
     TPT(8);
     if (gact) {
       const float* k_ = cA[eu];
-      const float r = d_sigmoid(FV(4 * eu, eb) + k_[6] + k_[9]);
-      const float z = d_sigmoid(FV(4 * eu + 1, eb) + k_[7] + k_[10]);
-      const float nh = FV(4 * eu + 3, eb) + k_[11];
-      const float nn = tanhf(FV(4 * eu + 2, eb) + k_[8] + r * nh);
+      const float r = d_sigmoid(fv1[0] + k_[6] + k_[9]);
+      const float z = d_sigmoid(fv1[1] + k_[7] + k_[10]);
+      const float nh = fv1[3] + k_[11];
+      const float nn = tanhf(fv1[2] + k_[8] + r * nh);
       const float h = (1.f - z) * nn + z * hp1;
       hp1 = h;
       const long i = (long)t * sH + (long)eb * H + EU;
