@@ -42,6 +42,7 @@ BATCH, WINDOW, EXAMPLE_LEN, CLIP_FRAMES = 32, 256, 384, 7200
 H, SP, ST = 1024, 64, 64
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
+FP64_VECTOR_PEAK_TFLOPS = 78.6          # MI355X datasheet (fp64 vector = fp64 matrix)
 
 
 def step_weight_bytes(style=ST):
@@ -311,7 +312,13 @@ def decode_30min(se, de, dev, minutes=30.0, reps=3):
         finite = bool(torch.isfinite(out[0]).all() and torch.isfinite(feats).all())
     se.train(), de.train()
     t_dec = min(ts)
+    n_stft = audio.stft_frame_count(n)
+    mel_flop = 2.0 * 2 * 401 * 800 * n_stft          # direct DFT: 401 bins x 800 samples x (re, im) fp64 FMAs per STFT frame
     return {"frames": T, "mel_ms": round(t_mel * 1e3, 2), "speech_encoder_ms": round(t_se * 1e3, 2),
+            "mel_roofline": {"bound": "fp64 vector", "kernel": "mel_stft_k (direct 800-point DFT + mel + log chain per STFT frame)",
+                             "achieved": round(mel_flop / t_mel / 1e12, 2), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(mel_flop / t_mel / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4), "stft_frames": int(n_stft),
+                             "note": "2 % of the 30-minute pipeline; an fp64-MFMA DFT would cut it ~5x (DESIGN.md section 8)"},
             "decode_s": round(t_dec, 3), "decode_s_all": [round(v, 3) for v in ts],
             "value": round((T - 1) / t_dec, 1), "unit": "frames/s",
             "x_realtime": round(minutes * 60.0 / (t_mel + t_se + t_dec), 1), "finite": finite,

@@ -11,6 +11,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "ubisoft-laforge-zeroeggs_amd"), str(ROOT / "tests")]
 import bench  # noqa: E402
 import helpers  # noqa: E402
+from zeggs import ops as _ops_diag  # noqa: E402
+_ops_diag._CHAIN_DIAGNOSTICS = True      # keep the last decoder workspace for the read-back below
 from zeggs import ops, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
