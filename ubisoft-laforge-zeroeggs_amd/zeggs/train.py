@@ -170,9 +170,15 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
         eng.opt.load_state_dict(ck["optimizer_state_dict"])
         eng.opt.attach_flat(eng.flat_p, eng.flat_g, keep_state=True)
         eng.iteration = iteration
+        # the noise stream (dropout masks, VAE eps) continues as a function of the ITERATION, not from its iteration-0 state
+        # (a resumed run would otherwise replay the noise of the start of training)
+        ops.manual_seed(train_options["seed"] + 7919 * rank + 104729 * iteration)
     (logs_dir / "samples").mkdir(parents=True, exist_ok=True)
     scalars = ScalarLog(logs_dir / "tb") if (train_options.get("use_tensorboard") and rank == 0) else None
     example_len = st_opt["example_length"]
+    if resume and iteration > 0:     # the length the interrupted run had drawn for this iteration (seeded per iteration below)
+        example_len = 2 * random.Random(train_options["seed"] * 1000003 + iteration - 1).randint(
+            st_opt["example_length"] // 2, st_opt["example_length"])
     gb = batchsize * world
     labels_onehot = None
     if style_type == "label":       # one-hot row per training range (dataset.py:150-151), gathered per window by a HIP kernel
@@ -184,7 +190,11 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
         start = datetime.datetime.now()
         perm = perm_rng.permutation(len(ds))
         nb = len(ds) // gb                                            # drop_last
-        for bi in range(nb):
+        # resume: the batches of this epoch's permutation that the interrupted run had already consumed are skipped (the
+        # checkpointed iteration itself is re-run, as the reference does: train.py:166-172)
+        first = iteration - epoch * nb if (resume and 0 < iteration - epoch * nb < nb) else 0
+        resume = False
+        for bi in range(first, nb):
             se.train(), de.train()
             if st is not None:
                 st.train()
