@@ -17,14 +17,23 @@
 
 namespace {
 
+// ---- matrix-core DFT (mel_stft_mfma_k): 32 STFT frames per workgroup, the DFT as a [frames, n_fft] x [n_fft, 2 bins] fp64
+// product on v_mfma_f64_16x16x4_f64 against a cos / -sin table built once per call
+constexpr int MF = 32, MWAVES = 8, MTPW = 7, MCOLP = MWAVES * MTPW * 16;      // frames, waves, column tiles per wave, 896 columns
+constexpr int MFB_CAP = 2048;                                                  // filterbank non-zeros staged in LDS
+
 struct MelWs {
   double* logmel;   // [M, n_mels]
   double* energy;   // [M]
+  double* table;    // [n_fft, MCOLP]: column 2k = cos(2 pi j k / n_fft), 2k+1 = -sin(.), zero beyond bin n_fft/2
+  double* win;      // [n_fft] symmetric Hann
 };
 MelWs carve_mel(const ZeggsMelDims& d, long M, Arena& a) {
   MelWs w;
   w.logmel = (double*)a.raw(sizeof(double) * M * d.n_mels);
   w.energy = (double*)a.raw(sizeof(double) * M);
+  w.table = (double*)a.raw(sizeof(double) * (size_t)d.n_fft * MCOLP);
+  w.win = (double*)a.raw(sizeof(double) * (size_t)d.n_fft);
   return w;
 }
 
@@ -92,6 +101,153 @@ __global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* w
   }
 }
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// DFT basis + window, once per call (the angle is reduced exactly: (j k) mod n_fft -- the same table entries the direct
+// kernel above walks)
+__global__ void mel_table_k(double* T, double* win, int NF, int NBIN) {
+  const long n = (long)NF * MCOLP;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i / MCOLP), c = (int)(i % MCOLP), k = c >> 1;
+    double v = 0.0;
+    if (k < NBIN) {
+      const double ang = 2.0 * M_PI * (double)(((long)j * k) % NF) / (double)NF;
+      v = (c & 1) ? -sin(ang) : cos(ang);
+    }
+    T[i] = v;
+    if (i < NF) win[i] = 0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)(NF - 1));   // scipy hann(sym=True)
+  }
+}
+
+// LDS of mel_stft_mfma_k (bytes): raw samples of the 32 overlapping frames | window | amplitudes [32][NBIN] | staged filterbank
+// non-zeros | band tables.  The log-mel values of the workgroup's frames reuse the sample area after the products.
+__host__ __device__ inline size_t mel_fast_lds(int NF, int hop, int n_mels) {
+  const size_t ns = (size_t)(MF - 1) * hop + NF;
+  size_t xs = ns * sizeof(float), mv = (size_t)MF * n_mels * sizeof(double);
+  if (mv > xs) xs = mv;
+  xs = (xs + 15) / 16 * 16;
+  return xs + sizeof(double) * ((size_t)NF + (size_t)MF * (NF / 2 + 1) + MFB_CAP) + sizeof(int) * 3 * (size_t)n_mels + 64;
+}
+
+// STFT frames m0 + 32 blockIdx.x ... (nfr frames in all): same results as mel_stft_k -- identical table entries, window, clip /
+// log chain and summation order of the mel and energy sums; only the 800-term DFT sums are accumulated by the matrix cores
+// (fp64, k in steps of 4) instead of one fma chain per bin.
+__global__ __launch_bounds__(MWAVES * 64) void mel_stft_mfma_k(ZeggsMelDims d, const float* wav, long n, long n_avail,
+                                                                const double* fb, const double* table, const double* wintab,
+                                                                double* logmel, double* energy, long m0, long nfr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int NF = d.n_fft, NBIN = NF / 2 + 1, hop = d.hop, NM = d.n_mels;
+  const int ns = (MF - 1) * hop + NF;
+  size_t xs_bytes = (size_t)ns * sizeof(float), mv_bytes = (size_t)MF * NM * sizeof(double);
+  if (mv_bytes > xs_bytes) xs_bytes = mv_bytes;
+  xs_bytes = (xs_bytes + 15) / 16 * 16;
+  float* xs = (float*)smem;                         // [ns] samples (reflect rule applied)
+  double* melv = (double*)smem;                     // [MF][NM] after the products
+  double* win = (double*)(smem + xs_bytes);         // [NF]
+  double* amp = win + NF;                           // [MF][NBIN]
+  double* fbs = amp + (size_t)MF * NBIN;            // [MFB_CAP] non-zero bands of the filterbank, mel after mel
+  int* blo = (int*)(fbs + MFB_CAP);                 // [NM] first bin of the band
+  int* bhi = blo + NM;                              // [NM] one past its last bin
+  int* bof = bhi + NM;                              // [NM] offset of the band in fbs (-1: not staged, read from fb)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long fr0 = m0 + (long)blockIdx.x * MF, slot0 = (long)blockIdx.x * MF;
+  const long neff = n > NF ? n : NF;
+  for (int i = tid; i < ns; i += blockDim.x) {
+    const long p = fr0 * hop + i - NF / 2;
+    const long src = p < 0 ? -p : (p >= neff ? 2 * (neff - 1) - p : p);
+    xs[i] = (src >= 0 && src < n && src < n_avail) ? wav[src] : 0.f;
+  }
+  for (int j = tid; j < NF; j += blockDim.x) win[j] = wintab[j];
+  if (tid < NM) {                                   // band of mel filter tid
+    const double* f = fb + (long)tid * NBIN;
+    int lo = 0, hi = 0;
+    for (int k = 0; k < NBIN; ++k)
+      if (f[k] != 0.0) { if (hi == 0) lo = k; hi = k + 1; }
+    blo[tid] = lo; bhi[tid] = hi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+    for (int m = 0; m < NM; ++m) {
+      const int w = bhi[m] - blo[m];
+      if (o + w <= MFB_CAP) { bof[m] = o; o += w; } else bof[m] = -1;
+    }
+  }
+  // ---- DFT: P[frame][col] = sum_j xw[frame][j] T[j][col]; this wave: column tiles wave * MTPW .. + MTPW - 1, both row tiles
+  d4 acc[2][MTPW];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int t = 0; t < MTPW; ++t) acc[rt][t] = d4{0.0, 0.0, 0.0, 0.0};
+  const int r16 = lane & 15, kk = lane >> 4;
+  const double* tb = table + (long)kk * MCOLP + 16 * (wave * MTPW) + r16;
+  double bq[MTPW];
+#pragma unroll
+  for (int t = 0; t < MTPW; ++t) bq[t] = tb[16 * t];
+  for (int s4 = 0; s4 < NF; s4 += 4) {
+    const int j = s4 + kk;
+    const double wj = win[j];
+    const double a0 = (double)xs[r16 * hop + j] * wj, a1 = (double)xs[(16 + r16) * hop + j] * wj;
+    double bc[MTPW];
+#pragma unroll
+    for (int t = 0; t < MTPW; ++t) bc[t] = bq[t];
+    if (s4 + 4 < NF) {
+      const double* tn = tb + (long)(s4 + 4) * MCOLP;
+#pragma unroll
+      for (int t = 0; t < MTPW; ++t) bq[t] = tn[16 * t];
+    }
+#pragma unroll
+    for (int t = 0; t < MTPW; ++t) {
+      acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bc[t], acc[0][t], 0, 0, 0);
+      acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bc[t], acc[1][t], 0, 0, 0);
+    }
+  }
+  // accumulator layout of the f64 form: col = lane & 15, row = (lane >> 4) + 4 i.  Even column = Re, odd = Im of bin col / 2
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int t = 0; t < MTPW; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double v = acc[rt][t][i];
+        const double o = __shfl_xor(v, 1, 64);
+        const int col = 16 * (wave * MTPW + t) + r16, bin = col >> 1, fr = rt * 16 + kk + 4 * i;
+        if (!(col & 1) && bin < NBIN) amp[(size_t)fr * NBIN + bin] = sqrt(v * v + o * o) / (double)NF;   // real_amplitude
+      }
+  __syncthreads();
+  for (int m = tid; m < NM; m += blockDim.x) {       // filterbank bands -> LDS (the 742 non-zeros of the shipped filterbank)
+    if (bof[m] >= 0)
+      for (int k = blo[m]; k < bhi[m]; ++k) fbs[bof[m] + k - blo[m]] = fb[(long)m * NBIN + k];
+  }
+  __syncthreads();
+  const double amin = (double)d.min_clip / (double)NF;
+  const double rng = -20.0 * log10(amin);
+  for (int it = tid; it < MF * NM; it += blockDim.x) {
+    const int f = it / NM, m = it % NM;
+    const double* av = amp + (size_t)f * NBIN;
+    double s = 0.0;
+    if (bof[m] >= 0) {
+      const double* fv = fbs + bof[m] - blo[m];
+      for (int k = blo[m]; k < bhi[m]; ++k) s = fma(fv[k], av[k], s);
+    } else {
+      const double* fv = fb + (long)m * NBIN;
+      for (int k = blo[m]; k < bhi[m]; ++k) s = fma(fv[k], av[k], s);
+    }
+    s = fabs(s);
+    if (s < amin) s = amin;
+    const double v = (20.0 * log10(s) + rng) / rng;
+    const double y = log(pow(10.0, v / 20.0));
+    melv[it] = y;                                   // (the sample area: the products are done)
+    if (slot0 + f < nfr) logmel[(slot0 + f) * NM + m] = y;
+  }
+  __syncthreads();
+  if (tid < MF && slot0 + tid < nfr) {
+    double e = 0.0;
+    for (int m = 0; m < NM; ++m) { const double z = exp(melv[tid * NM + m]); e += z * z; }
+    energy[slot0 + tid] = sqrt(e);
+  }
+}
+
 // linear resampling at t_k = ((fs/hop)/fps) k : mel -> NaN outside the hull (griddata), energy extrapolates
 // animation frames k0 .. k0 + n_frames - 1; logmel / energy hold the STFT frames m0 .. (indices relative to m0)
 __global__ void mel_resample_k(ZeggsMelDims d, const double* logmel, const double* energy, long M, long m0, long k0,
@@ -122,6 +278,32 @@ __global__ void mel_resample_k(ZeggsMelDims d, const double* logmel, const doubl
 
 }  // namespace
 
+int g_mel_mfma = 1;      // zeggs_set_option("mel_mfma", 0/1): matrix-core DFT (default) / one workgroup per frame, direct DFT
+
+// STFT frames m0 .. m0 + nfr - 1 -> logmel / energy slots 0 .. nfr - 1
+static int launch_stft(const ZeggsMelDims& d, const MelWs& w, const float* wav, long n, long n_avail, const double* fb, long m0,
+                       long nfr, hipStream_t s) {
+  const int NBIN = d.n_fft / 2 + 1;
+  const size_t fast_lds = mel_fast_lds(d.n_fft, d.hop, d.n_mels);
+  if (g_mel_mfma && d.n_fft % 4 == 0 && 2 * NBIN <= MCOLP && fast_lds <= 160 * 1024 && nfr >= 1) {
+    static bool attr_set = false;
+    if (!attr_set) {       // more than 64 KB of dynamic LDS needs the opt-in
+      hipFuncSetAttribute((const void*)mel_stft_mfma_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(mel_table_k, dim3(1024), dim3(256), 0, s, w.table, w.win, d.n_fft, NBIN);
+    ZLAUNCH_CHECK("mel_table");
+    hipLaunchKernelGGL(mel_stft_mfma_k, dim3((unsigned)((nfr + MF - 1) / MF)), dim3(MWAVES * 64), fast_lds, s, d, wav, n, n_avail,
+                       fb, w.table, w.win, w.logmel, w.energy, m0, nfr);
+    ZLAUNCH_CHECK("mel_stft_mfma");
+    return 0;
+  }
+  const size_t lds = sizeof(double) * (3 * (size_t)d.n_fft + d.n_fft / 2 + 1 + d.n_mels);
+  hipLaunchKernelGGL(mel_stft_k, dim3((unsigned)nfr), dim3(256), lds, s, d, wav, n, n_avail, fb, w.logmel, w.energy, m0);
+  ZLAUNCH_CHECK("mel_stft");
+  return 0;
+}
+
 extern "C" long zeggs_mel_stft_frames(const ZeggsMelDims* d, long n_samples) {
   return stft_frames(n_samples, d->n_fft, d->hop);
 }
@@ -142,10 +324,7 @@ extern "C" int zeggs_mel_features(const ZeggsMelDims* dp, const float* wav, long
   Arena a(ws, ws_bytes);
   MelWs w = carve_mel(d, M, a);
   ZCHECK(a.ok(), "mel: workspace too small (%zu < %zu)", ws_bytes, a.off);
-  const size_t lds = sizeof(double) * (3 * (size_t)d.n_fft + d.n_fft / 2 + 1 + d.n_mels);
-  hipLaunchKernelGGL(mel_stft_k, dim3((unsigned)M), dim3(256), lds, s, d, wav, n_samples, n_samples, filterbank, w.logmel,
-                     w.energy, 0L);
-  ZLAUNCH_CHECK("mel_stft");
+  ZTRY(launch_stft(d, w, wav, n_samples, n_samples, filterbank, 0L, M, s));
   if (n_frames > 0) {
     long n = (long)n_frames * (d.n_mels + 1), g = (n + 255) / 256;
     hipLaunchKernelGGL(mel_resample_k, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, d, w.logmel, w.energy, M,
@@ -193,10 +372,7 @@ extern "C" int zeggs_mel_features_range(const ZeggsMelDims* dp, const float* wav
   Arena a(ws, ws_bytes);
   MelWs w = carve_mel(d, m1 - m0, a);
   ZCHECK(a.ok(), "mel range: workspace too small (%zu < %zu)", ws_bytes, a.off);
-  const size_t lds = sizeof(double) * (3 * (size_t)d.n_fft + d.n_fft / 2 + 1 + d.n_mels);
-  hipLaunchKernelGGL(mel_stft_k, dim3((unsigned)(m1 - m0)), dim3(256), lds, s, d, wav, final ? n_samples : (1L << 50),
-                     n_samples, filterbank, w.logmel, w.energy, m0);
-  ZLAUNCH_CHECK("mel_stft");
+  ZTRY(launch_stft(d, w, wav, final ? n_samples : (1L << 50), n_samples, filterbank, m0, m1 - m0, s));
   const long n = (k1 - k0) * (d.n_mels + 1), g = (n + 255) / 256;
   hipLaunchKernelGGL(mel_resample_k, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, d, w.logmel, w.energy, M, m0, k0,
                      (int)(k1 - k0), out);

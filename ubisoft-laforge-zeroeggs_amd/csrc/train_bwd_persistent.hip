@@ -483,7 +483,9 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       // (w0: P2 of this step, w1: P1 of the next one): its reduction adds them up -- no reduction (LDS round trip + barrier)
       // of their own in any window
       w0[0] = f4{0.f, 0.f, 0.f, 0.f};
+#ifndef ZEGGS_BP_NOWIN      // (timing experiment: the hand-off latency with empty windows; results are wrong)
       if (t < T - 1) bp_mma<1, NJC, OC0A, false, true>(wr, nullptr, (const f4*)(a.OP0 + (long)(t + 1) * OPS) + lane, wave, 0, 96, w0);
+#endif
       f4 acc[1] = {w1[0]};
       wait_phase(pA - 1);
       if (fail) break;
@@ -511,7 +513,9 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
         hp = a.H0[(long)(t - 1) * sH + (long)eb * H + U];
       }
       // window: carry0 += second half of W_hh0^T (.) of step t+1
+#ifndef ZEGGS_BP_NOWIN      // (timing experiment: the hand-off latency with empty windows; results are wrong)
       if (t < T - 1) bp_mma<1, NJC, OC0B, false, true>(wr, nullptr, (const f4*)(a.OP0 + (long)(t + 1) * OPS) + lane, wave, 96, 96, w0);
+#endif
       f4 acc[1] = {w0[0]};
       wait_phase(pB - 1);
       if (fail) break;
@@ -556,7 +560,9 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       if (er >= 4 && er < 8 && bact) hid = a.Gin[(long)t * sG + (long)eb * GL + U];
       // window: carry1 += first half of W_hh1^T (DI1_t r,z | dn_h1) -- the operand is one phase old
       w1[0] = f4{0.f, 0.f, 0.f, 0.f};
+#ifndef ZEGGS_BP_NOWIN      // (timing experiment: the hand-off latency with empty windows; results are wrong)
       bp_mma<1, NJC, OC1A, false, true>(wr, nullptr, op1, wave, 0, 96, w1);
+#endif
       if (ract && t > 1) {      // root thread: the gradient-independent half of the root backward of frame t-1 (in place)
         RootIn ri;
         ri.gather([&](int item) { return rin[item][eb]; });
@@ -603,7 +609,9 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       float dpo = 0.f;
       if (t > 1 && bact && row4 >= 6 && row4 < PO) dpo = a.dpose[((long)eb * T + t - 1) * PO + row4];
       // window: carry1 += second half of W_hh1^T (DI1_t r,z | dn_h1)
+#ifndef ZEGGS_BP_NOWIN      // (timing experiment: the hand-off latency with empty windows; results are wrong)
       bp_mma<1, NJC, OC1B, false, true>(wr, nullptr, op1, wave, 96, 96, w1);
+#endif
       f4 acc[3] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
       wait_phase(pD - 1);
       if (fail) break;
