@@ -27,6 +27,7 @@ extern int g_bwd_persistent;
 extern int g_fused_attention;
 extern int g_gemm_streamk;
 extern int g_gemm_mid_split;
+extern int g_gemm_streamk_wgs;
 extern int g_mel_mfma;
 extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "decoder_fast") == 0) { g_decoder_fast = value; return 0; }
@@ -51,6 +52,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
     return 0;
   }
   if (strcmp(name, "mel_mfma") == 0) { g_mel_mfma = value != 0; return 0; }
+  if (strcmp(name, "gemm_streamk_wgs") == 0) { g_gemm_streamk_wgs = value; return 0; }
   if (strcmp(name, "gemm_mid_split") == 0) { g_gemm_mid_split = value != 0; return 0; }
   if (strcmp(name, "gemm_streamk") == 0) { g_gemm_streamk = value != 0; return 0; }
   if (strcmp(name, "fused_attention") == 0) { g_fused_attention = value != 0; return 0; }

@@ -16,12 +16,16 @@
 #include "gemm.h"
 #include "kernels.h"
 
+int g_gemm_streamk_wgs = 0;     // zeggs_set_option("gemm_streamk_wgs", n): stream-K workgroups per CU (0: as many as are resident)
 int g_gemm_wg_target = 6144;   // split-K aims at this many workgroups (24 per CU = 6 rounds of 4 resident ones; sweep 1536..12288 in
                                // tools/gemm_bench.py: 3072 -> 6144 is 10-14 % on the weight-gradient shapes, flat beyond)
 
 namespace {
 
-constexpr int BK = 16;
+#ifndef ZEGGS_GEMM_BK
+#define ZEGGS_GEMM_BK 16
+#endif
+constexpr int BK = ZEGGS_GEMM_BK;      // k-extent of a tile (A/B loaders move BM * BK / threads floats per thread: 16 or 32 at 128 x 128)
 
 template <int E>
 __device__ __forceinline__ void load_contig(float (&r)[E], const float* p, int nvalid) {
@@ -307,7 +311,7 @@ int launch_streamk(GemmArgs g, hipStream_t s) {
   g.splitk = kt;
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  long nwg = (long)ncu * ZEGGS_GEMM_MINB;
+  long nwg = (long)ncu * (g_gemm_streamk_wgs > 0 ? g_gemm_streamk_wgs : ZEGGS_GEMM_MINB);
   const long total = (long)tx * ty * kt;
   if (nwg > total / 8) nwg = total / 8 > 0 ? total / 8 : 1;     // at least 8 k-tiles per workgroup
   dim3 grid((unsigned)nwg), block(256);
