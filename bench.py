@@ -426,6 +426,29 @@ def v2_label_b64(ds, dev, steps=10, warmup=3, batch=64, nlabels=9):
             "config": "configs_v2.json shape: label conditioning (9 one-hot labels), no style encoder, batch 64 x 256"}
 
 
+def variants_b32(ds, dev, steps=3, warmup=1):
+    """The option surface beyond the shipped configs: rnn_cond = "film" (RecurrentDecoderFiLM, ZEGGS/modules.py:188-227) and
+    style_encoder.type = "gru" (StyleEncoderGRU, :307-343) at the headline shape.  Both run the GENERIC path (per-step GEMM
+    launches, no fragment-packed / persistent kernels): correct and reference-pinned (tests/golden/variants.npz), not tuned."""
+    torch.manual_seed(1234)
+    se = modules.SpeechEncoder(synth.N_AUDIO, 64, SP).to(dev).train()
+    de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, SP, ST, H, 2, rnn_cond="film").to(dev).train()
+    st = modules.StyleEncoder(synth.POSE_IN, 512, ST, type="gru", use_vae=True).to(dev).train()
+    eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT)
+    perm = np.random.default_rng(42).permutation(len(ds))
+    for it in range(warmup):
+        eng.step(engine.shard_indices(perm, it, BATCH, 1, 0), EXAMPLE_LEN)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(warmup, warmup + steps):
+        loss = eng.step(engine.shard_indices(perm, it, BATCH, 1, 0), EXAMPLE_LEN)
+    torch.cuda.synchronize()
+    dt_ = (time.perf_counter() - t0) / steps
+    return {"value": round(BATCH * WINDOW / dt_, 1), "unit": "frames/s", "ms_per_step": round(dt_ * 1e3, 2), "steps": steps,
+            "finite": bool(torch.isfinite(loss)),
+            "config": "FiLM decoder + GRU style encoder (VAE), batch 32 x 256, example 384: generic per-step GEMM path"}
+
+
 # ----------------------------------------------------------------------------- launcher
 def launch_command(argv, gpus, port):
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
@@ -667,6 +690,7 @@ def main():
                 out["generate_30min"] = generate_30min(dev)
             del eng
             out["v2_label_b64"] = v2_label_b64(ds, dev)
+            out["variants_film_gru_b32"] = variants_b32(ds, dev)
         if world == 1 and not a.no_cpu_baseline:
             import contextlib
             with contextlib.redirect_stdout(sys.stderr):      # the reference's train() writes its progress bar to stdout
