@@ -274,6 +274,17 @@ int zeggs_loss_fwd_bwd(const ZeggsLossDims*, const int* parents, const float* o_
                        float* dpose, float* drpos, float* drrot, float* dmu, float* dlogvar, float gscale,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* The ground-truth half of the loss's feature pass (transposed truth rows + forward kinematics of the truth side) depends on
+ * the batch only: zeggs_loss_prepare_truth runs it ahead of the step (any stream, e.g. with the batch prefetch) into the
+ * workspace that the loss call of that batch is then given with truth_prepared = 1 (zeggs_loss_fwd_bwd = truth_prepared 0). */
+int zeggs_loss_prepare_truth(const ZeggsLossDims*, const int* parents, const float* w_pose, const float* w_rpos,
+                             const float* w_rrot, const float* gaze, void* ws, size_t ws_bytes, void* stream);
+int zeggs_loss_fwd_bwd_ex(const ZeggsLossDims*, const int* parents, const float* o_pose, const float* o_rpos,
+                          const float* o_rrot, const float* w_pose, const float* w_rpos, const float* w_rrot,
+                          const float* gaze, const float* mu, const float* logvar, float kl_weight, float* terms,
+                          float* dpose, float* drpos, float* drrot, float* dmu, float* dlogvar, float gscale,
+                          void* ws, size_t ws_bytes, void* stream, int truth_prepared);
+
 /* ---------------------------------------------------------------- RAdam
  * replaces RAdam.step, ZEGGS/optimizers.py:31-99, fused over one flat fp32 buffer.
  * rectified != 0: p -= step_scale * m / (sqrt(v) + eps), else p -= step_scale * m (host scalars of

@@ -177,15 +177,17 @@ __device__ void build_levels(Levels& L, const int* parents, int J) {
 
 // forward per frame; side 0 = prediction (also stores local matrices LM), side 1 = ground truth.
 // One workgroup = 64 consecutive frames (lanes) x 8 waves sharing the joints of each tree level.
+// items gid0 .. gid_end - 1 of the 2 NF (side, frame) pairs: [0, NF) = prediction, [NF, 2 NF) = ground truth (the truth half
+// depends on the batch only: zeggs_loss_prepare_truth runs it ahead of the step)
 __global__ __launch_bounds__(512) void loss_frame_fwd_k(ZeggsLossDims d, const int* parents, FrameIO io0, FrameIO io1,
                                                         const float* PT0, const float* PT1, const float* gaze, float* F0,
-                                                        float* F1, float* LM) {
+                                                        float* F1, float* LM, long gid0, long gid_end) {
   __shared__ Levels lv;
   const long NF = (long)d.B * d.T;
   build_levels(lv, parents, d.J);
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const long gid = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-  const bool live = gid < 2 * NF;                 // dead lanes keep walking (barriers), on a clamped frame, storing nothing
+  const long gid = gid0 + (long)blockIdx.x * 64 + (threadIdx.x & 63);
+  const bool live = gid < gid_end;                // dead lanes keep walking (barriers), on a clamped frame, storing nothing
   const int side = live ? gid >= NF : 0;
   const long f = live ? (side ? gid - NF : gid) : 0;
   const FrameIO io = side ? io1 : io0;
@@ -566,11 +568,40 @@ extern "C" size_t zeggs_loss_workspace_bytes(const ZeggsLossDims* d) {
   return a.off + 256;
 }
 
+// The ground-truth half of the feature pass (pose rows transposed, forward kinematics of the truth side) depends on the batch
+// only: a training loop may run it ahead of the step, on any stream, into the workspace the loss call of that batch will be
+// given, and pass truth_prepared = 1 there.
+extern "C" int zeggs_loss_prepare_truth(const ZeggsLossDims* dp, const int* parents, const float* w_pose, const float* w_rpos,
+                                        const float* w_rrot, const float* gaze, void* ws, size_t ws_bytes, void* stream) {
+  const ZeggsLossDims& d = *dp;
+  hipStream_t s = (hipStream_t)stream;
+  Arena a(ws, ws_bytes);
+  LossWs w = carve_loss(d, a);
+  ZCHECK(a.ok(), "loss: workspace too small (%zu < %zu)", ws_bytes, a.off);
+  ZCHECK(d.J >= 1 && d.J <= MAXJ && d.T >= 1 && d.B >= 1, "loss: bad dims");
+  const long NF = (long)d.B * d.T;
+  const int PO = 6 + 15 * d.J;
+  FrameIO ioW{w_pose, w_rpos, w_rrot};
+  hipLaunchKernelGGL(transpose_k, dim3((unsigned)cdiv(NF, 64), (unsigned)cdiv(PO, 64)), dim3(256), 0, s, w.PT1, w_pose, NF, PO);
+  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(NF, 64)), dim3(512), 0, s, d, parents, ioW, ioW, w.PT1, w.PT1, gaze, w.FW, w.FW,
+                     w.LM, NF, 2 * NF);
+  ZLAUNCH_CHECK("loss_prepare_truth");
+  return 0;
+}
+
 extern "C" int zeggs_loss_fwd_bwd(const ZeggsLossDims* dp, const int* parents, const float* o_pose, const float* o_rpos,
                                   const float* o_rrot, const float* w_pose, const float* w_rpos, const float* w_rrot,
                                   const float* gaze, const float* mu, const float* logvar, float kl_weight, float* terms,
                                   float* dpose, float* drpos, float* drrot, float* dmu, float* dlogvar, float gscale,
                                   void* ws, size_t ws_bytes, void* stream) {
+  return zeggs_loss_fwd_bwd_ex(dp, parents, o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze, mu, logvar, kl_weight, terms,
+                               dpose, drpos, drrot, dmu, dlogvar, gscale, ws, ws_bytes, stream, 0);
+}
+extern "C" int zeggs_loss_fwd_bwd_ex(const ZeggsLossDims* dp, const int* parents, const float* o_pose, const float* o_rpos,
+                                     const float* o_rrot, const float* w_pose, const float* w_rpos, const float* w_rrot,
+                                     const float* gaze, const float* mu, const float* logvar, float kl_weight, float* terms,
+                                     float* dpose, float* drpos, float* drrot, float* dmu, float* dlogvar, float gscale,
+                                     void* ws, size_t ws_bytes, void* stream, int truth_prepared) {
   const ZeggsLossDims& d = *dp;
   hipStream_t s = (hipStream_t)stream;
   Arena a(ws, ws_bytes);
@@ -584,10 +615,12 @@ extern "C" int zeggs_loss_fwd_bwd(const ZeggsLossDims* dp, const int* parents, c
   const int PO = 6 + 15 * d.J;
   const dim3 tg((unsigned)cdiv(NF, 64), (unsigned)cdiv(PO, 64));
   hipLaunchKernelGGL(transpose_k, tg, dim3(256), 0, s, w.PT0, o_pose, NF, PO);
-  hipLaunchKernelGGL(transpose_k, tg, dim3(256), 0, s, w.PT1, w_pose, NF, PO);
+  if (!truth_prepared) hipLaunchKernelGGL(transpose_k, tg, dim3(256), 0, s, w.PT1, w_pose, NF, PO);
   ZCHECK(d.J <= MAXJ, "loss: more than %d joints", MAXJ);
-  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(2 * NF, 64)), dim3(512), 0, s, d, parents, ioO, ioW, w.PT0, w.PT1, gaze, w.FO,
-                     w.FW, w.LM);
+  // (truth_prepared: zeggs_loss_prepare_truth has filled PT1 / FW of THIS workspace; only the prediction side is left)
+  const long gend = truth_prepared ? NF : 2 * NF;
+  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(gend, 64)), dim3(512), 0, s, d, parents, ioO, ioW, w.PT0, w.PT1, gaze, w.FO,
+                     w.FW, w.LM, 0L, gend);
   ZLAUNCH_CHECK("loss_frame_fwd");
   hipLaunchKernelGGL(loss_terms_k, dim3(o.n), dim3(256), 0, s, d, w.FO, w.FW, w.G, terms, gscale);
   ZLAUNCH_CHECK("loss_terms");

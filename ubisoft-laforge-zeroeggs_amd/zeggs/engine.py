@@ -281,6 +281,9 @@ class TrainEngine:
         ex_len = example_len if self.style_type == "example" else None
         with torch.cuda.stream(self.aux_stream):
             b = self.ds.batch(idx, ex_len)
+            # ... and the half of the loss's feature pass that depends on the batch only (ground-truth rows transposed, their
+            # forward kinematics): off the serial section between the two sweeps
+            b["loss_ws"] = ops.loss_prepare_truth(b["pose"], b["rpos"], b["rrot"], b["gaze"], self.parents, self.dt)
             ev = torch.cuda.Event()
             ev.record(self.aux_stream)
         self._prefetched = ((np.asarray(idx).tobytes(), ex_len), b, ev)
@@ -396,7 +399,7 @@ class TrainEngine:
             klw = kl_div_weight(self.iteration) if mu is not None else 0.0
             loss, terms = ops.training_loss(pose, orp, orr, b["pose"], b["rpos"], b["rrot"], b["gaze"], self.parents,
                                             self.dt, mu, logvar, kl_weight=klw, gscale=1.0 / self.world,
-                                            unit_grad=True)
+                                            unit_grad=True, truth_ws=b.get("loss_ws"))
             if self.decoder_bwd_events is not None:
                 e2 = ev()
                 e2.record()

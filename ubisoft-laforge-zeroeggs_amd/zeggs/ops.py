@@ -675,7 +675,7 @@ def decoder_rollout(dec, Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos,
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, o_pose, o_rpos, o_rrot, mu, logvar, w_pose, w_rpos, w_rrot, gaze, parents, kl_weight, dt, gscale,
-                unit_grad):
+                unit_grad, truth_ws):
         o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze = (
             _f32c(t) for t in (o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze))
         B, T, PO = o_pose.shape
@@ -685,17 +685,19 @@ class _LossFn(torch.autograd.Function):
         d = LossDims(B, T, J, S, float(dt))
         L = lib()
         dev = o_pose.device
-        ws = _ws(L.zeggs_loss_workspace_bytes(C.byref(d)), dev)
+        need = L.zeggs_loss_workspace_bytes(C.byref(d))
+        prepared = truth_ws is not None and truth_ws.numel() >= need       # (loss_prepare_truth filled its truth half)
+        ws = truth_ws if prepared else _ws(need, dev)
         terms = torch.empty(19, device=dev, dtype=torch.float32)
         dpose, drpos, drrot = torch.empty_like(o_pose), torch.empty_like(o_rpos), torch.empty_like(o_rrot)
         dmu = torch.empty(B, S, device=dev) if mu is not None else None
         dlv = torch.empty(B, S, device=dev) if mu is not None else None
-        _check(L.zeggs_loss_fwd_bwd(C.byref(d), _p(parents), _p(o_pose), _p(o_rpos), _p(o_rrot), _p(w_pose),
-                                    _p(w_rpos), _p(w_rrot), _p(gaze), _p(_f32c(mu)) if mu is not None else None,
-                                    _p(_f32c(logvar)) if mu is not None else None,
-                                    C.c_float(kl_weight if has_kl else 0.0), _p(terms), _p(dpose), _p(drpos),
-                                    _p(drrot), _p(dmu), _p(dlv), C.c_float(gscale), _p(ws), C.c_size_t(ws.numel()),
-                                    _stream()), "loss_fwd_bwd")
+        _check(L.zeggs_loss_fwd_bwd_ex(C.byref(d), _p(parents), _p(o_pose), _p(o_rpos), _p(o_rrot), _p(w_pose),
+                                       _p(w_rpos), _p(w_rrot), _p(gaze), _p(_f32c(mu)) if mu is not None else None,
+                                       _p(_f32c(logvar)) if mu is not None else None,
+                                       C.c_float(kl_weight if has_kl else 0.0), _p(terms), _p(dpose), _p(drpos),
+                                       _p(drrot), _p(dmu), _p(dlv), C.c_float(gscale), _p(ws), C.c_size_t(ws.numel()),
+                                       _stream(), int(prepared)), "loss_fwd_bwd")
         ctx.save_for_backward(dpose, drpos, drrot, dmu, dlv)
         ctx.unit_grad = bool(unit_grad)
         ctx.mark_non_differentiable(terms)
@@ -708,22 +710,35 @@ class _LossFn(torch.autograd.Function):
     def backward(ctx, g, _gterms):
         dpose, drpos, drrot, dmu, dlv = ctx.saved_tensors
         if g is None:
-            return (None,) * 14
+            return (None,) * 15
         if not ctx.unit_grad:        # general case: scale by the upstream scalar (device side, no host sync)
             g = _f32c(g).reshape(1)
             dpose, drpos, drrot = scale_copy(dpose, g), scale_copy(drpos, g), scale_copy(drrot, g)
             if dmu is not None:
                 dmu, dlv = scale_copy(dmu, g), scale_copy(dlv, g)
-        return (dpose, drpos, drrot, dmu, dlv, None, None, None, None, None, None, None, None, None)
+        return (dpose, drpos, drrot, dmu, dlv, None, None, None, None, None, None, None, None, None, None)
+
+
+def loss_prepare_truth(w_pose, w_rpos, w_rrot, gaze, parents, dt):
+    """The ground-truth half of the loss's feature pass on the current stream (zeggs_loss_prepare_truth) -> the workspace to
+    hand to training_loss(truth_ws=...) for the same batch."""
+    w_pose, w_rpos, w_rrot, gaze = (_f32c(t) for t in (w_pose, w_rpos, w_rrot, gaze))
+    B, T, PO = w_pose.shape
+    d = LossDims(B, T, (PO - 6) // 15, 0, float(dt))
+    L = lib()
+    ws = _ws(L.zeggs_loss_workspace_bytes(C.byref(d)), w_pose.device)
+    _check(L.zeggs_loss_prepare_truth(C.byref(d), _p(parents), _p(w_pose), _p(w_rpos), _p(w_rrot), _p(gaze), _p(ws),
+                                      C.c_size_t(ws.numel()), _stream()), "loss_prepare_truth")
+    return ws
 
 
 def training_loss(o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze, parents, dt, mu=None, logvar=None,
-                  kl_weight=0.0, gscale=1.0, unit_grad=False):
+                  kl_weight=0.0, gscale=1.0, unit_grad=False, truth_ws=None):
     """-> (loss scalar tensor, terms[19]); terms[0:18] are the reference's weighted loss terms.
     unit_grad=True: the caller promises to call backward() on the returned loss itself (upstream gradient 1), so
     the gradients computed in the fused forward+backward kernel are handed on without a scaling pass."""
     return _LossFn.apply(o_pose, o_rpos, o_rrot, mu, logvar, w_pose, w_rpos, w_rrot, gaze, parents,
-                         float(kl_weight), float(dt), float(gscale), bool(unit_grad))
+                         float(kl_weight), float(dt), float(gscale), bool(unit_grad), truth_ws)
 
 
 # ----------------------------------------------------------------------------- optimizer / data
