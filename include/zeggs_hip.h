@@ -74,6 +74,10 @@ int zeggs_speech_encoder_fwd(const ZeggsSpeechDims*, const ZeggsSpeechParams*, c
 int zeggs_speech_encoder_bwd(const ZeggsSpeechDims*, const ZeggsSpeechParams*, const float* x,
                              const float* out, const float* dout, const ZeggsSpeechGrads*, void* ws,
                              size_t ws_bytes, void* stream);
+/* grads_zeroed != 0: every gradient output is zero on entry (see ZeggsDecCall.grads_zeroed) */
+int zeggs_speech_encoder_bwd_ex(const ZeggsSpeechDims*, const ZeggsSpeechParams*, const float* x,
+                                const float* out, const float* dout, const ZeggsSpeechGrads*, void* ws,
+                                size_t ws_bytes, void* stream, int grads_zeroed);
 
 /* ---------------------------------------------------------------- StyleEncoderAttn trunk
  * replaces StyleEncoderAttn.forward, ZEGGS/modules.py:391-420 (convs :359-384, FFTBlock :484-612).
@@ -104,6 +108,8 @@ int zeggs_style_encoder_fwd(const ZeggsStyleDims*, const ZeggsStyleParams*, cons
                             float* out, void* ws, size_t ws_bytes, void* stream);
 int zeggs_style_encoder_bwd(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* dout,
                             const ZeggsStyleGrads*, void* ws, size_t ws_bytes, void* stream);
+int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* dout,
+                               const ZeggsStyleGrads*, void* ws, size_t ws_bytes, void* stream, int grads_zeroed);
 /* style_encoder.type "gru": replaces StyleEncoderGRU.forward, ZEGGS/modules.py:307-343 (conv3+ReLU x2, one
  * bidirectional GRU layer, projection of the last time step) and its backward.  x [B,L,C] -> out [B,O]. */
 typedef struct {
@@ -236,6 +242,8 @@ typedef struct {
   int defer_wgrads;
   void* wgrad_stream;
   unsigned* status;
+  int grads_zeroed;     /* bwd: every gradient output is zero on entry (a loop that zeroes its flat gradient buffer once per step):
+                           weight / bias gradients are accumulated by the split GEMMs / column sums, no zero-fill launch each */
 } ZeggsDecCall;
 int zeggs_decoder_fwd_ex(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDecStats*, const float* pose0,
                          const float* rpos0, const float* rrot0, const float* gaze, const float* speech,
@@ -245,7 +253,8 @@ int zeggs_decoder_bwd_ex(const ZeggsDecDims*, const ZeggsDecParams*, const Zeggs
                          const float* pose, const float* rpos, const float* rrot, const float* dpose,
                          const float* drpos, const float* drrot, const ZeggsDecGrads*, float* dspeech,
                          float* dstyle, void* ws, size_t ws_bytes, void* stream, const ZeggsDecCall* call);
-/* second half of the deferred weight gradients (ZeggsDecCall.defer_wgrads = 2): what = 4 -> GRU layer 0 and layer0 */
+/* second half of the deferred weight gradients (ZeggsDecCall.defer_wgrads = 2): what = 4 -> GRU layer 0 and layer0;
+ * what | 8: the gradient outputs are zero on entry (as ZeggsDecCall.grads_zeroed of the backward it completes) */
 int zeggs_decoder_wgrads(const ZeggsDecDims*, const ZeggsDecGrads*, void* ws, size_t ws_bytes, int what, void* stream);
 /* The weight-only preparation of a training step on `ws` (merged / folded matrices and the fragment packs of the two
  * persistent sweeps; the reference has no counterpart, its GEMMs read nn.Parameter storage directly): may run on a second

@@ -674,7 +674,8 @@ extern "C" int zeggs_decoder_wgrads(const ZeggsDecDims* dp, const ZeggsDecGrads*
   ZCHECK(a.ok(), "decoder wgrads: workspace too small (was the forward run with training=1?)");
   ZCHECK(d.T > 1, "decoder wgrads: T must be > 1");
   const bool fast_path = g_decoder_fast && dec_fast_supported(d);
-  return dec_recurrent_wgrads(d, w, G, 1, d.T - 1, 0.f, fast_path ? 1 : 0, (hipStream_t)stream, what & 5);
+  // what & 8: the gradient outputs are zero on entry (ZeggsDecCall.grads_zeroed of the backward this call completes)
+  return dec_recurrent_wgrads(d, w, G, 1, d.T - 1, (what & 8) ? 1.f : 0.f, fast_path ? 1 : 0, (hipStream_t)stream, what & 5);
 }
 // Everything the two persistent sweeps of a training step need that depends on the WEIGHTS only (the merged / folded
 // matrices, the per-workgroup fragment packs of both kernels): the caller may run it on a second stream beside the encoders'
@@ -731,6 +732,7 @@ extern "C" int zeggs_decoder_bwd_ex(const ZeggsDecDims* dp, const ZeggsDecParams
   const bool bwd_prepared = call && (call->prepared & 2);
   const int defer_wgrads = call ? call->defer_wgrads : 0;
   unsigned* status = call ? call->status : nullptr;
+  const float gb = (call && call->grads_zeroed) ? 1.f : 0.f;      // gradient outputs are zero on entry: accumulate, no fills
   ZCHECK(defer_wgrads == 0 || call->wgrad_stream != nullptr, "decoder bwd: defer_wgrads needs ZeggsDecCall.wgrad_stream");
   Arena a(ws, ws_bytes);
   DecWs w = carve_dec(d, 1, a);
@@ -784,7 +786,7 @@ extern "C" int zeggs_decoder_bwd_ex(const ZeggsDecDims* dp, const ZeggsDecParams
       if (nch > 1) {
         ZCHECK(hipEventRecord(ss->chunk, s) == hipSuccess, "hipEventRecord failed");
         ZCHECK(hipStreamWaitEvent(ss->s, ss->chunk, 0) == hipSuccess, "hipStreamWaitEvent failed");
-        ZTRY(dec_recurrent_wgrads(d, w, G, t_lo, t_hi, c == 0 ? 0.f : 1.f, 1, ss->s));
+        ZTRY(dec_recurrent_wgrads(d, w, G, t_lo, t_hi, c == 0 ? gb : 1.f, 1, ss->s));
       }
     }
     if (nch > 1) {
@@ -850,28 +852,28 @@ extern "C" int zeggs_decoder_bwd_ex(const ZeggsDecDims* dp, const ZeggsDecParams
     //  computes the second half)
     // The bias sums (a dozen column sums over the same saves) go with them: since the split-K retune the GEMMs are the shorter
     // of the two queues.
-    ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, gs, (defer_wgrads == 2 ? 1 : 5) | 2));
+    ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, gb, fast_path ? 1 : 0, gs, (defer_wgrads == 2 ? 1 : 5) | 2));
   } else if (!wgrads_done) {
-    ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, 0.f, fast_path ? 1 : 0, s));
+    ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, gb, fast_path ? 1 : 0, s));
   }
   // ---- CellStateEncoder backward: dH0c / dH1c are the grads wrt its two output halves
   {
     // out = [H0_init | H1_init] = cse_b W2^T + b2
-    ZTRY(gemm_tn(w.dH0c, H, w.cse_b, H, G->c2_w, H, B, H, H, 0.f, s));
-    ZTRY(gemm_tn(w.dH1c, H, w.cse_b, H, G->c2_w + (long)H * H, H, B, H, H, 0.f, s));
-    ZTRY(k_colsum(G->c2_b, w.dH0c, B, H, H, 0.f, s));
-    ZTRY(k_colsum(G->c2_b + H, w.dH1c, B, H, H, 0.f, s));
+    ZTRY(gemm_tn(w.dH0c, H, w.cse_b, H, G->c2_w, H, B, H, H, gb, s));
+    ZTRY(gemm_tn(w.dH1c, H, w.cse_b, H, G->c2_w + (long)H * H, H, B, H, H, gb, s));
+    ZTRY(k_colsum(G->c2_b, w.dH0c, B, H, H, gb, s));
+    ZTRY(k_colsum(G->c2_b + H, w.dH1c, B, H, H, gb, s));
     float* db = w.t0;                       // [B,H] grad wrt cse_b
     ZTRY(gemm_nn(w.dH0c, H, P->c2_w, H, db, H, B, H, H, 0.f, s));
     ZTRY(gemm_nn(w.dH1c, H, P->c2_w + (long)H * H, H, db, H, B, H, H, 1.f, s));
     ZTRY(k_act_bwd(db, db, w.cse_b, sH, ACT_ELU, 1.f, s));
-    ZTRY(gemm_tn(db, H, w.cse_a, H, G->c1_w, H, B, H, H, 0.f, s));
-    ZTRY(k_colsum(G->c1_b, db, B, H, H, 0.f, s));
+    ZTRY(gemm_tn(db, H, w.cse_a, H, G->c1_w, H, B, H, H, gb, s));
+    ZTRY(k_colsum(G->c1_b, db, B, H, H, gb, s));
     float* da = w.t0 + sH;                  // [B,H] grad wrt cse_a
     ZTRY(gemm_nn(db, H, P->c1_w, H, da, H, B, H, H, 0.f, s));
     ZTRY(k_act_bwd(da, da, w.cse_a, sH, ACT_ELU, 1.f, s));
-    ZTRY(gemm_tn(da, H, w.cse_in, CI, G->c0_w, CI, B, H, CI, 0.f, s));
-    ZTRY(k_colsum(G->c0_b, da, B, H, H, 0.f, s));
+    ZTRY(gemm_tn(da, H, w.cse_in, CI, G->c0_w, CI, B, H, CI, gb, s));
+    ZTRY(k_colsum(G->c0_b, da, B, H, H, gb, s));
     ZTRY(gemm_nn(da, H, P->c0_w, CI, w.t1, CI, B, H, CI, 0.f, s));   // t1 = d cse_in [B, PI+ST]
   }
   hipLaunchKernelGGL(dec_scatter_cond_grad_k, g1((long)T * B * (d.SP + d.ST)), dim3(256), 0, s, d, w.DX, XD, dspeech,

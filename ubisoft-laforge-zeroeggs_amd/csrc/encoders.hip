@@ -92,7 +92,15 @@ extern "C" int zeggs_speech_encoder_fwd(const ZeggsSpeechDims* dp, const ZeggsSp
 extern "C" int zeggs_speech_encoder_bwd(const ZeggsSpeechDims* dp, const ZeggsSpeechParams* P, const float* x,
                                         const float* out, const float* dout, const ZeggsSpeechGrads* G, void* ws,
                                         size_t ws_bytes, void* stream) {
+  return zeggs_speech_encoder_bwd_ex(dp, P, x, out, dout, G, ws, ws_bytes, stream, 0);
+}
+// grads_zeroed != 0: the caller vouches that every gradient output is zero on entry (a training loop that zeroes its flat gradient
+// buffer once per step): weight / bias gradients are then ACCUMULATED by the split GEMMs / column sums without a zero-fill launch each
+extern "C" int zeggs_speech_encoder_bwd_ex(const ZeggsSpeechDims* dp, const ZeggsSpeechParams* P, const float* x,
+                                           const float* out, const float* dout, const ZeggsSpeechGrads* G, void* ws,
+                                           size_t ws_bytes, void* stream, int grads_zeroed) {
   const ZeggsSpeechDims& d = *dp;
+  const float gb = grads_zeroed ? 1.f : 0.f;
   hipStream_t s = (hipStream_t)stream;
   Arena a(ws, ws_bytes);
   SpeechWs w = carve_speech(d, a);
@@ -102,8 +110,8 @@ extern "C" int zeggs_speech_encoder_bwd(const ZeggsSpeechDims* dp, const ZeggsSp
   const float keep = 1.f - d.dropout_p;
   // layer2
   ZTRY(k_act_bwd(w.d2, dout, out, BT * d.O, ACT_ELU, 1.f, s));
-  ZTRY(gemm_tn(w.d2, d.O, w.h1, d.O, G->w2, d.O, (int)BT, d.O, d.O, 0.f, s));
-  ZTRY(k_colsum(G->b2, w.d2, BT, d.O, d.O, 0.f, s));
+  ZTRY(gemm_tn(w.d2, d.O, w.h1, d.O, G->w2, d.O, (int)BT, d.O, d.O, gb, s));
+  ZTRY(k_colsum(G->b2, w.d2, BT, d.O, d.O, gb, s));
   // dh1 (into the interior of the doubly zero-padded buffer), through dropout and ELU
   float* dh1 = w.dh1pp + (long)pad * d.O;
   {
@@ -120,7 +128,7 @@ extern "C" int zeggs_speech_encoder_bwd(const ZeggsSpeechDims* dp, const ZeggsSp
   }
   ZTRY(k_pad_edges(w.dh1pp, B, T, d.O, pad, pad, 0, s));
   // bias / weight grads of the conv
-  ZTRY(k_colsum_v(G->b1, rv(dh1, T, (long)TPP * d.O), BT, d.O, 0.f, s));
+  ZTRY(k_colsum_v(G->b1, rv(dh1, T, (long)TPP * d.O), BT, d.O, gb, s));
   ZTRY(conv_dw_gemm(w.h0p, (long)TP * d.H, d.H, dh1, d.O, (long)TPP * d.O, w.dwf1, d.KW * d.H, d.O, B, T, s));
   ZTRY(k_unpack_conv_dw(G->w1, w.dwf1, d.O, d.H, d.KW, s));
   // input grad w.r.t. the padded conv input: correlation of zero-padded dh1 with flipped taps
@@ -130,8 +138,8 @@ extern "C" int zeggs_speech_encoder_bwd(const ZeggsSpeechDims* dp, const ZeggsSp
   // through dropout0 and ELU0 (saved h0p interior is post-dropout)
   ZTRY(k_dropout(w.dh0, BT * d.H, d.dropout_p, d.seed + 1, s));
   ZTRY(k_act_bwd_v(rv(w.dh0), rv(w.dh0), rv(w.h0p + (long)half * d.H, T, (long)TP * d.H), BT, d.H, ACT_ELU, keep, s));
-  ZTRY(gemm_tn(w.dh0, d.H, x, d.F, G->w0, d.F, (int)BT, d.H, d.F, 0.f, s));
-  ZTRY(k_colsum(G->b0, w.dh0, BT, d.H, d.H, 0.f, s));
+  ZTRY(gemm_tn(w.dh0, d.H, x, d.F, G->w0, d.F, (int)BT, d.H, d.F, gb, s));
+  ZTRY(k_colsum(G->b0, w.dh0, BT, d.H, d.H, gb, s));
   return 0;
 }
 
@@ -273,7 +281,12 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
 
 extern "C" int zeggs_style_encoder_bwd(const ZeggsStyleDims* dp, const ZeggsStyleParams* P, const float* dout,
                                        const ZeggsStyleGrads* G, void* ws, size_t ws_bytes, void* stream) {
+  return zeggs_style_encoder_bwd_ex(dp, P, dout, G, ws, ws_bytes, stream, 0);
+}
+extern "C" int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims* dp, const ZeggsStyleParams* P, const float* dout,
+                                          const ZeggsStyleGrads* G, void* ws, size_t ws_bytes, void* stream, int grads_zeroed) {
   const ZeggsStyleDims& d = *dp;
+  const float gb = grads_zeroed ? 1.f : 0.f;      // (see zeggs_speech_encoder_bwd_ex)
   hipStream_t s = (hipStream_t)stream;
   Arena a(ws, ws_bytes);
   StyleWs w = carve_style(d, a);
@@ -284,33 +297,33 @@ extern "C" int zeggs_style_encoder_bwd(const ZeggsStyleDims* dp, const ZeggsStyl
   float *t0 = w.t0, *t1 = w.t1, *t2 = w.t2, *t3 = w.t3;
   // ---- mean pool, final LN (f = LN(f2 + a))
   ZTRY(k_meanpool_bwd(t1, dout, B, L, E, s));                                   // t1 = df [BL,E]
-  ZTRY(k_fill(G->lnf_g, E, 0.f, s)); ZTRY(k_fill(G->lnf_b, E, 0.f, s));
+  if (!grads_zeroed) { ZTRY(k_fill(G->lnf_g, E, 0.f, s)); ZTRY(k_fill(G->lnf_b, E, 0.f, s)); }
   ZTRY(k_layernorm_bwd_v(rv(t2), rv(t1), rv(w.f2), rv(w.ap + E, L, (long)LP * E), P->lnf_g, w.mf, w.rf, G->lnf_g,
                           G->lnf_b, (int)BL, E, s));                              // t2 = d(f2 + a) [BL,E]
   // residual branch: da_res = t2 (kept in t2); conv branch: df2 = t2 * mask
   ZTRY(k_copy(t1, t2, BL * E, s));
   ZTRY(k_dropout(t1, BL * E, p1, d.seed + 5, s));                               // t1 = df2
-  ZTRY(k_colsum(G->ff2_b, t1, BL, E, E, 0.f, s));
+  ZTRY(k_colsum(G->ff2_b, t1, BL, E, E, gb, s));
   ZTRY(conv_dw_gemm(w.f1p, (long)LP * E, E, t1, E, (long)L * E, w.dwf, 3 * E, E, B, L, s));
   ZTRY(k_unpack_conv_dw(G->ff2_w, w.dwf, E, E, 3, s));
   // d f1 = conv_bwd(df2): zero-pad df2 by 1 and correlate with flipped taps
   ZTRY(k_pad_rows(t0, t1, B, L, E, 1, 1, 0, s));                                // t0 = df2 padded [B,LP,E]
   ZTRY(conv_gemm(t0, (long)LP * E, E, w.wfb2, 3 * E, E, t1, E, (long)L * E, nullptr, B, L, ACT_NONE, s));
   ZTRY(k_act_bwd_v(rv(t1), rv(t1), rv(w.f1p + E, L, (long)LP * E), BL, E, ACT_RELU, 1.f, s));  // ReLU' (saved f1)
-  ZTRY(k_colsum(G->ff0_b, t1, BL, E, E, 0.f, s));
+  ZTRY(k_colsum(G->ff0_b, t1, BL, E, E, gb, s));
   ZTRY(conv_dw_gemm(w.ap, (long)LP * E, E, t1, E, (long)L * E, w.dwf, 3 * E, E, B, L, s));
   ZTRY(k_unpack_conv_dw(G->ff0_w, w.dwf, E, E, 3, s));
   ZTRY(k_pad_rows(t0, t1, B, L, E, 1, 1, 0, s));
   ZTRY(conv_gemm(t0, (long)LP * E, E, w.wfb0, 3 * E, E, t1, E, (long)L * E, nullptr, B, L, ACT_NONE, s));
   ZTRY(k_add_inplace(t2, t1, BL * E, s));                                       // t2 = da  (conv path + residual)
   // ---- attention LN: a = LN(ao + h)
-  ZTRY(k_fill(G->lna_g, E, 0.f, s)); ZTRY(k_fill(G->lna_b, E, 0.f, s));
+  if (!grads_zeroed) { ZTRY(k_fill(G->lna_g, E, 0.f, s)); ZTRY(k_fill(G->lna_b, E, 0.f, s)); }
   ZTRY(k_layernorm_bwd(t1, t2, w.ao, w.h, P->lna_g, w.ma, w.ra, G->lna_g, G->lna_b, (int)BL, E, s));
   // t1 = d(ao + h): residual grad to h kept in t3; out-proj branch through dropout
   ZTRY(k_copy(t3, t1, BL * E, s));                                              // t3 = dh (residual part)
   ZTRY(k_dropout(t1, BL * E, p1, d.seed + 4, s));                               // t1 = dao
-  ZTRY(gemm_tn(t1, E, w.O, E, G->out_w, E, (int)BL, E, E, 0.f, s));
-  ZTRY(k_colsum(G->out_b, t1, BL, E, E, 0.f, s));
+  ZTRY(gemm_tn(t1, E, w.O, E, G->out_w, E, (int)BL, E, E, gb, s));
+  ZTRY(k_colsum(G->out_b, t1, BL, E, E, gb, s));
   ZTRY(gemm_nn(t1, E, P->out_w, E, t2, E, (int)BL, E, E, 0.f, s));              // t2 = dO [BL,E]
   if (w.fused) {      // dQ, dK, dV with the probabilities recomputed from the saved row log-sum-exp (attention.hip)
     ZTRY(k_attn_bwd(w.qkv, w.O, w.lse, t2, w.dqkv, w.dsum, B, L, E, NH, p1, d.seed + 3, s));
@@ -347,25 +360,25 @@ extern "C" int zeggs_style_encoder_bwd(const ZeggsStyleDims* dp, const ZeggsStyl
     ZTRY(launch_gemm(g, B * NH, s));
   }
   }
-  ZTRY(gemm_tn(w.dqkv, 3 * E, w.h, E, G->in_w, E, (int)BL, 3 * E, E, 0.f, s));
-  ZTRY(k_colsum(G->in_b, w.dqkv, BL, 3 * E, 3 * E, 0.f, s));
+  ZTRY(gemm_tn(w.dqkv, 3 * E, w.h, E, G->in_w, E, (int)BL, 3 * E, E, gb, s));
+  ZTRY(k_colsum(G->in_b, w.dqkv, BL, 3 * E, 3 * E, gb, s));
   ZTRY(gemm_nn(w.dqkv, 3 * E, P->in_w, E, t1, E, (int)BL, 3 * E, E, 0.f, s));   // t1 = dh (attention part)
   ZTRY(k_add_inplace(t1, t3, BL * E, s));                                       // t1 = dh total (pos table: no grad)
   // ---- conv stack: h = dropout(LN(c2)) + pos
   ZTRY(k_dropout(t1, BL * E, p2, d.seed + 2, s));
-  ZTRY(k_fill(G->ln1_g, E, 0.f, s)); ZTRY(k_fill(G->ln1_b, E, 0.f, s));
+  if (!grads_zeroed) { ZTRY(k_fill(G->ln1_g, E, 0.f, s)); ZTRY(k_fill(G->ln1_b, E, 0.f, s)); }
   ZTRY(k_layernorm_bwd(t2, t1, w.c2, nullptr, P->ln1_g, w.m2, w.r2, G->ln1_g, G->ln1_b, (int)BL, E, s));
   ZTRY(k_act_bwd(t2, t2, w.c2, BL * E, ACT_RELU, 1.f, s));                      // t2 = dc2 (pre-activation)
-  ZTRY(k_colsum(G->c4_b, t2, BL, E, E, 0.f, s));
+  ZTRY(k_colsum(G->c4_b, t2, BL, E, E, gb, s));
   ZTRY(conv_dw_gemm(w.a1p, (long)LP * H, H, t2, E, (long)L * E, w.dwf, 3 * H, E, B, L, s));
   ZTRY(k_unpack_conv_dw(G->c4_w, w.dwf, E, H, 3, s));
   ZTRY(k_pad_rows(t0, t2, B, L, E, 1, 1, 0, s));
   ZTRY(conv_gemm(t0, (long)LP * E, E, w.wb4, 3 * E, H, t1, H, (long)L * H, nullptr, B, L, ACT_NONE, s));  // t1 = da1 [BL,H]
   ZTRY(k_dropout(t1, BL * H, p2, d.seed + 1, s));
-  ZTRY(k_fill(G->ln0_g, H, 0.f, s)); ZTRY(k_fill(G->ln0_b, H, 0.f, s));
+  if (!grads_zeroed) { ZTRY(k_fill(G->ln0_g, H, 0.f, s)); ZTRY(k_fill(G->ln0_b, H, 0.f, s)); }
   ZTRY(k_layernorm_bwd(t2, t1, w.c1, nullptr, P->ln0_g, w.m1, w.r1, G->ln0_g, G->ln0_b, (int)BL, H, s));
   ZTRY(k_act_bwd(t2, t2, w.c1, BL * H, ACT_RELU, 1.f, s));                      // t2 = dc1
-  ZTRY(k_colsum(G->c0_b, t2, BL, H, H, 0.f, s));
+  ZTRY(k_colsum(G->c0_b, t2, BL, H, H, gb, s));
   ZTRY(conv_dw_gemm(w.xp, (long)LP * C, C, t2, H, (long)L * H, w.dwf, 3 * C, H, B, L, s));
   ZTRY(k_unpack_conv_dw(G->c0_w, w.dwf, H, C, 3, s));
   return 0;

@@ -58,7 +58,8 @@ DecStats = _ptr_struct("DecStats", ("in_mean", "in_std", "out_mean", "out_std"))
 
 
 class DecCall(C.Structure):       # mirrors ZeggsDecCall: the per-call controls of zeggs_decoder_fwd_ex / _bwd_ex
-    _fields_ = [("prepared", C.c_int), ("defer_wgrads", C.c_int), ("wgrad_stream", C.c_void_p), ("status", C.c_void_p)]
+    _fields_ = [("prepared", C.c_int), ("defer_wgrads", C.c_int), ("wgrad_stream", C.c_void_p), ("status", C.c_void_p),
+                ("grads_zeroed", C.c_int)]
 
 
 STATUS_WORDS = 4                                   # ZEGGS_STATUS_WORDS
@@ -137,7 +138,9 @@ def direct_param_grads(on):
     """Training-engine mode: the *_bwd entry points write parameter gradients STRAIGHT into the parameters'
     existing `.grad` tensors (views of the engine's flat gradient buffer) and the autograd Functions return None
     for them, so no AccumulateGrad add runs.  Semantics are OVERWRITE (every parameter is used by exactly one
-    op per iteration), not accumulate -- only engine.TrainEngine turns this on."""
+    op per iteration), not accumulate -- only engine.TrainEngine turns this on.  The `.grad` tensors MUST be zero when the
+    backward starts (the engine zeroes its flat buffer once per step): the kernels are told so (`grads_zeroed`) and accumulate
+    onto them instead of zero-filling each one first."""
     global _DIRECT_GRADS
     _DIRECT_GRADS = bool(on)
 
@@ -308,8 +311,9 @@ class _SpeechFn(torch.autograd.Function):
         grads, rets = _grad_targets(ctx.orig, params)
         P = _ptrs(SpeechPtrs, SPEECH_FIELDS, params)
         G = _ptrs(SpeechPtrs, SPEECH_FIELDS, grads)
-        _check(L.zeggs_speech_encoder_bwd(C.byref(ctx.d), C.byref(P), _p(x), _p(out), _p(_f32c(dout)), C.byref(G),
-                                          _p(ctx.ws), C.c_size_t(ctx.ws.numel()), _stream()), "speech_encoder_bwd")
+        zeroed = int(_DIRECT_GRADS and all(r is None for r in rets))     # the engine zeroes its flat gradient buffer per step
+        _check(L.zeggs_speech_encoder_bwd_ex(C.byref(ctx.d), C.byref(P), _p(x), _p(out), _p(_f32c(dout)), C.byref(G),
+                                             _p(ctx.ws), C.c_size_t(ctx.ws.numel()), _stream(), zeroed), "speech_encoder_bwd")
         return (None, *rets, None, None)
 
 
@@ -376,8 +380,9 @@ class _StyleFn(torch.autograd.Function):
         grads, rets = _grad_targets(ctx.orig, params)
         P = _ptrs(StylePtrs, STYLE_FIELDS, params)
         G = _ptrs(StylePtrs, STYLE_FIELDS, grads)
-        _check(L.zeggs_style_encoder_bwd(C.byref(ctx.d), C.byref(P), _p(_f32c(dout)), C.byref(G), _p(ctx.ws),
-                                         C.c_size_t(ctx.ws.numel()), _stream()), "style_encoder_bwd")
+        zeroed = int(_DIRECT_GRADS and all(r is None for r in rets))
+        _check(L.zeggs_style_encoder_bwd_ex(C.byref(ctx.d), C.byref(P), _p(_f32c(dout)), C.byref(G), _p(ctx.ws),
+                                            C.c_size_t(ctx.ws.numel()), _stream(), zeroed), "style_encoder_bwd")
         return (None, None, None, None, None, *rets)
 
 
@@ -560,7 +565,7 @@ class _DecoderFn(torch.autograd.Function):
             status = _INFER_STATUS.get(dev.index)
             if status is None and not capturing:
                 status = _INFER_STATUS[dev.index] = new_status(dev)
-        call = DecCall(int(mask) & 1, 0, None, status.data_ptr() if status is not None else None)
+        call = DecCall(int(mask) & 1, 0, None, status.data_ptr() if status is not None else None, 0)
 
         def run():
             _check(L.zeggs_decoder_fwd_ex(C.byref(d), C.byref(P), C.byref(S), _p(pose0), _p(rpos0), _p(rrot0), _p(gaze),
@@ -613,7 +618,7 @@ class _DecoderFn(torch.autograd.Function):
         chunked = side is not None and _AFTER_DECODER_BWD is not None
         call = DecCall(2 if ctx.bwd_prepared else 0, 0 if side is None else (2 if chunked else 1),
                        side.cuda_stream if side is not None else None,
-                       ctx.status.data_ptr() if ctx.status is not None else None)
+                       ctx.status.data_ptr() if ctx.status is not None else None, int(direct))
         _check(L.zeggs_decoder_bwd_ex(C.byref(d), C.byref(P), C.byref(S), _p(gaze), _p(pose), _p(rpos), _p(rrot),
                                       _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
                                       C.c_size_t(ctx.ws.numel()), _stream(), C.byref(call)), "decoder_bwd")
@@ -625,7 +630,7 @@ class _DecoderFn(torch.autograd.Function):
                 side.wait_stream(torch.cuda.current_stream())       # the CellStateEncoder gradients come from this stream
                 with torch.cuda.stream(side):
                     _AFTER_DECODER_BWD(0)         # layer2, GRU layer 1, CellStateEncoder: final behind the GEMMs already on `side`
-                    _check(L.zeggs_decoder_wgrads(C.byref(d), C.byref(G), _p(ctx.ws), C.c_size_t(ctx.ws.numel()), 4,
+                    _check(L.zeggs_decoder_wgrads(C.byref(d), C.byref(G), _p(ctx.ws), C.c_size_t(ctx.ws.numel()), 4 | 8,
                                                   C.c_void_p(side.cuda_stream)), "decoder_wgrads")
                     _AFTER_DECODER_BWD(1)         # layer0, GRU layer 0
         elif _AFTER_DECODER_BWD is not None and direct:
