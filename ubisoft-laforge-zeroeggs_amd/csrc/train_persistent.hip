@@ -336,7 +336,9 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       const f4* x1 = (const f4*)(a.G1 + (long)t * 128 * XB) + lane;
       // window: the rest of this phase's old part, h1_{t-1} through the fold (cond and h0_{t-1} ran in the window of the previous
       // output stage)
+#ifndef ZEGGS_TP_NOWIN      // (timing experiment: the hand-off latency with empty windows; results are wrong)
       tp_mma<NB, TJ0 - TL0, TS0 - TL0, TNO0 - TS0, false>(wr0, nullptr, x0, TFR0 + wave + 8 * TS0, a.KB0, acc1);
+#endif
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc2[nb] = f4{0.f, 0.f, 0.f, 0.f};
       if constexpr (TS1 > 0) tp_mma<NB, TJ1, 0, TS1, false>(wr1, nullptr, x1, 64 + wave, 128, acc2);
@@ -389,7 +391,9 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     // ================================================================ GRU layer 1 : [h0_t | h1_{t-1}]
     if constexpr (SPREAD) {
       const f4* x1 = (const f4*)(a.G1 + (long)t * 128 * XB) + lane;
+#ifndef ZEGGS_TP_NOWIN
       tp_mma<NB, TJ1, TS1, TNO1 - TS1, false>(wr1, nullptr, x1, 64 + wave + 8 * TS1, 128, acc2);   // window: rest of the old part
+#endif
       wait_phase(p2 - 1);
       if (fail) break;
       TPT(6);
@@ -441,9 +445,12 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     {
       const f4* x3 = (const f4*)(a.G3 + (long)t * a.KB3 * XB) + lane;
       const f4* wl3 = w3 + wave * TJ3 * 64 + lane;
+#ifndef ZEGGS_TP_NOWIN
       tp_mma<NB, TJ0 - TL0, 0, TNO3, true>(wr0, wl3, x3, 64 + wave, a.KB3, acc);          // cond_{t+1}: before the hand-off
+#endif
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc1[nb] = f4{0.f, 0.f, 0.f, 0.f};
+#ifndef ZEGGS_TP_NOWIN
       if constexpr (SPREAD) {
         if (next) {     // window: cond and h0_t blocks of the NEXT step's GRU layer 0 (h0_t was published two hand-offs ago)
           const f4* x0n = (const f4*)(a.G0 + (long)(t + 1) * a.KB0 * XB) + lane;
@@ -451,6 +458,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
           tp_mma<NB, TJ0 - TL0, 0, TS0 - TL0, false>(wr0, nullptr, x0n, TFR0 + wave + 8 * TL0, a.KB0, acc1);
         }
       }
+#endif
       wait_phase(p3 - 1);
       if (fail) break;
       TPT(11);
