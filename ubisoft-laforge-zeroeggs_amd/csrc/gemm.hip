@@ -31,7 +31,13 @@ template <int E>
 __device__ __forceinline__ void load_contig(float (&r)[E], const float* p, int nvalid) {
   // p is only 4-byte aligned in general
   if (nvalid >= E) {
-    if constexpr (E == 8) {
+    if constexpr (E == 16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f4u a = *(const f4u*)(p + 4 * q);
+        r[4 * q] = a.x; r[4 * q + 1] = a.y; r[4 * q + 2] = a.z; r[4 * q + 3] = a.w;
+      }
+    } else if constexpr (E == 8) {
       f4u a = *(const f4u*)p, b = *(const f4u*)(p + 4);
       r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
     } else if constexpr (E == 4) {
@@ -52,7 +58,13 @@ __device__ __forceinline__ void load_contig(float (&r)[E], const float* p, int n
 
 template <int E>
 __device__ __forceinline__ void load_full(float (&r)[E], const float* p) {
-  if constexpr (E == 8) {
+  if constexpr (E == 16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f4u a = *(const f4u*)(p + 4 * q);
+      r[4 * q] = a.x; r[4 * q + 1] = a.y; r[4 * q + 2] = a.z; r[4 * q + 3] = a.w;
+    }
+  } else if constexpr (E == 8) {
     f4u a = *(const f4u*)p, b = *(const f4u*)(p + 4);
     r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
   } else if constexpr (E == 4) {
@@ -88,7 +100,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const float* A, con
   constexpr int MT = TM / 32, NTL = TN / 32;
   constexpr int EA = BM * BK / NT, EB = BN * BK / NT;
   constexpr int LDA = BM + 4, LDB = BN + 4;
-  static_assert(EA >= 1 && EB >= 1 && (EA == 1 || EA == 2 || EA == 4 || EA == 8), "tile/threads");
+  static_assert(EA >= 1 && EB >= 1 && (EA == 1 || EA == 2 || EA == 4 || EA == 8 || EA == 16), "tile/threads");
   float (*As2)[BK * LDA] = (float (*)[BK * LDA])As2base;
   float (*Bs2)[BK * LDB] = (float (*)[BK * LDB])Bs2base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
