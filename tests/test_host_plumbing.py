@@ -85,3 +85,40 @@ def test_state_dict_checkpoint_round_trip(tmp_path):
             assert all(torch.equal(sa[k], sb[k]) for k in sa)
     se2, de2, st2, _ = (lambda d: (compat.save_state(d, se, de, None), compat.load_state(d))[1])(tmp_path / "label")
     assert st2 is None
+
+
+def test_cli_option_surface_and_csv_batch_mode(tmp_path, monkeypatch):
+    """`python -m zeggs.cli` keeps the reference scripts' options (main.py -o/-n; generate.py -o -p -se -s -a -n -fp -t -r -g -f -c)
+    and the CSV batch columns; the entry points it calls are the drop-in train() / generate_gesture() (stubbed here: no GPU)."""
+    import json
+    from zeggs import cli
+    import zeggs.generate as zg
+    import zeggs.train as zt
+    calls = []
+    monkeypatch.setattr(zt, "train", lambda **k: calls.append(("train", k)))
+    monkeypatch.setattr(zg, "generate_gesture", lambda **k: calls.append(("gen", k)))
+    opts = {"train_opt": {"resume": False}, "net_opt": {"x": 1},
+            "paths": {"base_path": str(tmp_path), "path_processed_data": "data/processed_v1", "output_dir": None, "models_dir": None}}
+    of = tmp_path / "o.json"
+    of.write_text(json.dumps(opts))
+    assert cli.main(["train", "-o", str(of), "-n", "run1"]) == 0
+    kind, k = calls[-1]
+    assert kind == "train" and k["path_processed_data"].name == "processed_data.npz" and k["models_dir"].name == "saved_models"
+    written = json.loads((k["logs_dir"].parent / "options.json").read_text())
+    assert written["name"] == "run1" and written["paths"]["models_dir"] == str(k["models_dir"])
+    gen_opts = k["logs_dir"].parent / "options.json"
+    assert cli.main(["generate", "-o", str(gen_opts), "-s", "ex.bvh", "-a", "a.wav", "-f", "10", "200", "-t", "0.5", "-r", "7",
+                     "-n", "out", "-fp", "fp.bvh", "-g"]) == 0
+    kind, k = calls[-1]
+    assert kind == "gen" and k["styles"] == [(cli.Path("ex.bvh"), [10, 200])] and k["temperature"] == 0.5 and k["seed"] == 7
+    assert k["file_name"] == "out" and k["first_pose"] == cli.Path("fp.bvh") and k["results_path"].name == "results"
+    csvf = tmp_path / "p.csv"
+    csvf.write_text("base_path,audio,style,file_name,temperature,seed,use_gpu,frames,first_pose,generate\n"
+                    f"{tmp_path},a1.wav,s1.bvh,o1,1.0,1234,True,5 50,s1.bvh,True\n"
+                    f"{tmp_path},a2.wav,s2.bvh,o2,0.8,99,True,,s2.bvh,False\n"
+                    f"{tmp_path},a3.wav,s3.bvh,o3,0.8,99,True,,,True\n")
+    n0 = len(calls)
+    assert cli.main(["generate", "-o", str(gen_opts), "-c", str(csvf)]) == 0
+    new = [k for kind, k in calls[n0:]]
+    assert [k["file_name"] for k in new] == ["o1", "o3"] and new[0]["styles"][0][1] == [5, 50] and new[1]["styles"][0][1] is None
+    assert new[1]["first_pose"] is None and new[1]["temperature"] == 0.8 and new[1]["seed"] == 99
