@@ -305,6 +305,12 @@ int zeggs_radam_step(float* p, const float* g, float* m, float* v, long n, float
  * all-reduce: zeggs_status_flag writes this rank's 0 / 1 into the float that travels with the gradients) */
 int zeggs_radam_step_guarded(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
                              float step_scale, int rectified, unsigned* status, const float* gflag, void* stream);
+/* a step applied in PIECES (slices of the flat buffers, each as soon as its gradients are final -- zeggs/engine.py runs the
+ * decoder's slice on the weight-gradient stream underneath the encoders' backward): every piece is guarded alike, exactly one of
+ * them passes count_skip != 0 so that status[1] still counts skipped STEPS */
+int zeggs_radam_step_guarded_part(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
+                                  float step_scale, int rectified, unsigned* status, const float* gflag, int count_skip,
+                                  void* stream);
 int zeggs_status_flag(const unsigned* status, float* dst /* device float */, void* stream);
 
 /* ---------------------------------------------------------------- batch gather

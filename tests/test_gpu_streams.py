@@ -29,6 +29,8 @@ def _run(overlap, steps=4, B=8, T=24, L=32, clip=None):
             eng.prefetch(engine.shard_indices(perm, k + 1, B, 1, 0), L)      # picked up by the next step
             assert eng._prefetched is not None
     torch.cuda.synchronize()
+    # with the side streams the decoder's slice of every optimizer step runs early, on the weight-gradient stream
+    assert eng.opt.early_pieces == (steps if overlap else 0), eng.opt.early_pieces
     return eng.flat_p.detach().cpu().numpy().copy(), [float(x.detach()) for x in losses]
 
 

@@ -22,11 +22,11 @@ namespace {
 // 16-byte vector accesses: 16 B read x4 + 12 B written per parameter = the algorithmic 28 B/param.
 __global__ __launch_bounds__(256) void radam_k(float* p, const float* g, float* m, float* v, long n4, long n,
                                                 float b1, float b2, float eps, float scale, int rect,
-                                                unsigned* status, const float* gflag) {
+                                                unsigned* status, const float* gflag, int count_skip) {
   // guarded step (zeggs_radam_step_guarded): a persistent sweep of this iteration gave up on this rank (sticky status word) or
   // on another one (gflag: the all-reduced flag) -> the gradients are invalid, the whole step is a no-op and is counted
   if (status && (status[0] != 0u || (gflag && gflag[0] != 0.f))) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(status + 1, 1u);
+    if (count_skip && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(status + 1, 1u);
     return;
   }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -159,21 +159,26 @@ extern "C" int zeggs_radam_step(float* p, const float* g, float* m, float* v, lo
   if (n <= 0) return 0;
   long n4 = n / 4;
   hipLaunchKernelGGL(radam_k, dim3(g1(n4 > 0 ? n4 : 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
-                     beta2, eps, step_scale, rectified, (unsigned*)nullptr, (const float*)nullptr);
+                     beta2, eps, step_scale, rectified, (unsigned*)nullptr, (const float*)nullptr, 0);
+  ZLAUNCH_CHECK("radam");
+  return 0;
+}
+extern "C" int zeggs_radam_step_guarded_part(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2,
+                                             float eps, float step_scale, int rectified, unsigned* status,
+                                             const float* gflag, int count_skip, void* stream) {
+  ZCHECK(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "radam: buffers must be 16-byte aligned");
+  ZCHECK(status != nullptr, "radam (guarded): the status words are required");
+  if (n <= 0) return 0;
+  long n4 = n / 4;
+  hipLaunchKernelGGL(radam_k, dim3(g1(n4 > 0 ? n4 : 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
+                     beta2, eps, step_scale, rectified, status, gflag, count_skip);
   ZLAUNCH_CHECK("radam");
   return 0;
 }
 extern "C" int zeggs_radam_step_guarded(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2,
                                         float eps, float step_scale, int rectified, unsigned* status, const float* gflag,
                                         void* stream) {
-  ZCHECK(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "radam: buffers must be 16-byte aligned");
-  ZCHECK(status != nullptr, "radam (guarded): the status words are required");
-  if (n <= 0) return 0;
-  long n4 = n / 4;
-  hipLaunchKernelGGL(radam_k, dim3(g1(n4 > 0 ? n4 : 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
-                     beta2, eps, step_scale, rectified, status, gflag);
-  ZLAUNCH_CHECK("radam");
-  return 0;
+  return zeggs_radam_step_guarded_part(p, g, m, v, n, beta1, beta2, eps, step_scale, rectified, status, gflag, 1, stream);
 }
 extern "C" int zeggs_status_flag(const unsigned* status, float* dst, void* stream) {
   hipLaunchKernelGGL(status_flag_k, dim3(1), dim3(64), 0, (hipStream_t)stream, status, dst);

@@ -158,6 +158,18 @@ def set_after_decoder_backward(fn):
     _AFTER_DECODER_BWD = fn
 
 
+_DECODER_GRADS_FINAL = None
+
+
+def set_decoder_grads_final(fn):
+    """Engine hook for the single-rank schedule with the weight-gradient GEMMs on the side stream: `fn()` runs with that stream
+    current, ordered behind ALL of the decoder's parameter gradients of the iteration (the deferred GEMMs and the
+    CellStateEncoder gradients of the caller's stream) -- engine.TrainEngine applies the decoder's slice of the optimizer step
+    there, underneath the encoders' backward."""
+    global _DECODER_GRADS_FINAL
+    _DECODER_GRADS_FINAL = fn
+
+
 _WGRAD_STREAM = None
 _SIDE_STREAMS = {}
 
@@ -633,6 +645,10 @@ class _DecoderFn(torch.autograd.Function):
                     _check(L.zeggs_decoder_wgrads(C.byref(d), C.byref(G), _p(ctx.ws), C.c_size_t(ctx.ws.numel()), 4 | 8,
                                                   C.c_void_p(side.cuda_stream)), "decoder_wgrads")
                     _AFTER_DECODER_BWD(1)         # layer0, GRU layer 0
+            elif _DECODER_GRADS_FINAL is not None:
+                side.wait_stream(torch.cuda.current_stream())       # the CellStateEncoder gradients come from this stream
+                with torch.cuda.stream(side):
+                    _DECODER_GRADS_FINAL()
         elif _AFTER_DECODER_BWD is not None and direct:
             _AFTER_DECODER_BWD(None)
         return (None, None, None, None, dspeech, dstyle, None, None, None, None, None, None, None, *rets)
@@ -747,18 +763,19 @@ def training_loss(o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze, parents,
 
 
 # ----------------------------------------------------------------------------- optimizer / data
-def radam_step(p, g, m, v, beta1, beta2, eps, step_scale, rectified, status=None, gflag=None):
+def radam_step(p, g, m, v, beta1, beta2, eps, step_scale, rectified, status=None, gflag=None, count=True):
     """status (int32[STATUS_WORDS], device): the guarded step -- a no-op on the device, counted in status[1], when a
-    persistent sweep of the iteration gave up here (status[0]) or on another rank (gflag, a device float)."""
+    persistent sweep of the iteration gave up here (status[0]) or on another rank (gflag, a device float).  A step applied in
+    pieces (slices of the flat buffers) counts its skip in ONE of them: count=False for the others."""
     if status is None:
         _check(lib().zeggs_radam_step(_p(p), _p(g), _p(m), _p(v), C.c_long(p.numel()), C.c_float(beta1),
                                       C.c_float(beta2), C.c_float(eps), C.c_float(step_scale), int(rectified),
                                       _stream()), "radam_step")
     else:
-        _check(lib().zeggs_radam_step_guarded(_p(p), _p(g), _p(m), _p(v), C.c_long(p.numel()), C.c_float(beta1),
-                                              C.c_float(beta2), C.c_float(eps), C.c_float(step_scale), int(rectified),
-                                              C.c_void_p(status.data_ptr()), _p(gflag) if gflag is not None else None,
-                                              _stream()), "radam_step_guarded")
+        _check(lib().zeggs_radam_step_guarded_part(_p(p), _p(g), _p(m), _p(v), C.c_long(p.numel()), C.c_float(beta1),
+                                                   C.c_float(beta2), C.c_float(eps), C.c_float(step_scale), int(rectified),
+                                                   C.c_void_p(status.data_ptr()), _p(gflag) if gflag is not None else None,
+                                                   int(bool(count)), _stream()), "radam_step_guarded")
 
 
 def status_flag(status, dst):

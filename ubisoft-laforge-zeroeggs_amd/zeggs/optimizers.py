@@ -44,6 +44,8 @@ class RAdam(Optimizer):
         self._flat = None      # (p, g, m, v) flat buffers when attached
         self._step = 0
         self._guard = None     # (status words, all-reduced flag or None): the flat step is skipped ON THE DEVICE on a give-up
+        self.early_pieces = 0
+        self._early = []       # [lo, hi) slices of the flat buffers the coming step() has already been applied to (early())
 
     def attach_guard(self, status, gflag=None):
         """zeggs_radam_step_guarded for the flat step: `status` = the engine's sticky give-up words, `gflag` = the device
@@ -77,6 +79,24 @@ class RAdam(Optimizer):
                 off += n
         assert off == flat_p.numel()
 
+    def _flat_piece(self, group, step, lo, hi, count):
+        beta1, beta2 = group["betas"]
+        rect, scale, active = radam_scalars(step, group["lr"], beta1, beta2, self.degenerated_to_sgd)
+        p, g, m, v = (t[lo:hi] for t in self._flat)
+        st, gf = self._guard if self._guard is not None else (None, None)
+        ops.radam_step(p, g, m, v, beta1, beta2, group["eps"], scale if active else 0.0, rect, st, gf, count=count)
+
+    @torch.no_grad()
+    def early(self, lo, hi):
+        """Flat mode: apply the COMING step() to elements [lo, hi) now, on the current stream -- their gradients are final there
+        while others are still being computed (zeggs.engine: the decoder's slice, on the weight-gradient stream underneath the
+        encoders' backward).  step() then covers the rest.  lo, hi multiples of 4 (16-byte accesses)."""
+        assert self._flat is not None and len(self.param_groups) == 1 and lo % 4 == 0 and hi % 4 == 0 and lo < hi
+        assert all(hi <= a or b <= lo for a, b in self._early), "early(): overlapping slices"
+        self._flat_piece(self.param_groups[0], self._step + 1, lo, hi, count=False)
+        self._early.append((lo, hi))
+        self.early_pieces += 1
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
@@ -85,10 +105,16 @@ class RAdam(Optimizer):
             beta1, beta2 = group["betas"]
             if self._flat is not None:
                 step = self._step
-                rect, scale, active = radam_scalars(step, group["lr"], beta1, beta2, self.degenerated_to_sgd)
-                p, g, m, v = self._flat
-                st, gf = self._guard if self._guard is not None else (None, None)
-                ops.radam_step(p, g, m, v, beta1, beta2, group["eps"], scale if active else 0.0, rect, st, gf)
+                n, at, rest = self._flat[0].numel(), 0, []
+                for a, b in sorted(self._early):          # what early() has not done yet
+                    if a > at:
+                        rest.append((at, a))
+                    at = b
+                if at < n:
+                    rest.append((at, n))
+                self._early = []
+                for k, (a, b) in enumerate(rest):         # (a skipped step is counted once: by the first piece here)
+                    self._flat_piece(group, step, a, b, count=k == 0)
                 for q in group["params"]:
                     self.state[q]["step"] = step
                 continue
