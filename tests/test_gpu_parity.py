@@ -49,6 +49,35 @@ def test_gemm_layouts(M, N, K):
     assert relerr(C, 2.0 * ref + 0.5 * C0.double()) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(32, 1024, 1198), (32, 3072, 1131), (64, 1024, 1024), (33, 1000, 67), (17, 70, 64),
+                                   (1, 2262, 1262), (48, 64, 4097)])
+def test_gemm_skinny_nt_one_launch(M, N, K):
+    """batch-sized y = act(x W^T + b) (skinny_nt_k: one launch instead of zero fill + split-K atomics + bias pass), with row
+    strides / bases that are not 16-byte aligned (W_ih0[:, H:] of the decoder, the CellStateEncoder's 1198-wide input)"""
+    torch.manual_seed(M + N + K)
+    ldx, ldw, ldy = K + 3, K + 1022, N + 5
+    xb, wb = torch.randn(M, ldx), torch.randn(N, ldw)
+    bias = torch.randn(N)
+    X, Wm = g(xb), g(wb)
+    x, w = X[:, 1:1 + K], Wm[:, 1021:1021 + K]                       # odd element offsets
+    ref = x.double().cpu() @ w.double().cpu().t() + bias.double()
+    for act, fn in ((0, lambda t: t), (1, torch.nn.functional.elu)):
+        Y = torch.full((M, ldy), 7.0, device=DEV)
+        ops.gemm(x, w, Y, M, N, K, (ldx, 1), (1, ldw), (ldy, 1), bias=g(bias), act=act)
+        assert relerr(Y[:, :N], fn(ref)) < 2e-6
+        assert bool((Y[:, N:] == 7.0).all())                          # nothing written past the N columns
+        ops.set_option("gemm_skinny", 0)                              # the split-K recipe gives the same
+        Y0 = torch.zeros(M, ldy, device=DEV)
+        ops.gemm(x, w, Y0, M, N, K, (ldx, 1), (1, ldw), (ldy, 1), bias=g(bias), act=act)
+        ops.set_option("gemm_skinny", 1)
+        assert relerr(Y[:, :N], Y0[:, :N]) < 2e-6
+    # NN (input gradients dx = dy W: W[k][n], four 4-byte loads down a column), accumulating onto an existing result
+    wt = g(wb[:, 1021:1021 + K].t().contiguous())                     # [K, N]
+    Y = torch.full((M, ldy), 0.5, device=DEV)
+    ops.gemm(x, wt, Y, M, N, K, (ldx, 1), (N, 1), (ldy, 1), beta=1.0)
+    assert relerr(Y[:, :N], ref - bias.double() + 0.5) < 2e-6 and bool((Y[:, N:] == 0.5).all())
+
+
 def test_gemm_batched_and_overlapping_rows():
     torch.manual_seed(1)
     nb, T, Cc, Co, kw = 3, 37, 10, 7, 5

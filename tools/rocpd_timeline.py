@@ -14,6 +14,9 @@ st, en = pick("start", "start_timestamp"), pick("end", "end_timestamp")
 qid = pick("queue_id", "stream_id", "queue", "stream")
 rows = list(db.execute(f"select {name}, {gx}, {st}, {en}, {qid if qid else 0} from kernels order by {st}"))
 rad = [i for i, r in enumerate(rows) if "radam_k" in r[0]]
+# the optimizer step is applied in pieces (the decoder's slice early, on the weight-gradient stream): an iteration ends with the
+# LAST radam_k of a cluster (no other one starts within the next 2 ms)
+rad = [i for k, i in enumerate(rad) if k + 1 == len(rad) or rows[rad[k + 1]][2] - rows[i][2] > 2_000_000]
 if len(rad) < 2:
     sys.exit("need two radam_k dispatches")
 # the shortest of the last few iterations (the bench's trailing iterations are separated by host-side event reads)

@@ -28,6 +28,7 @@ struct AttnArgs {
   float* lse;            // [B*NH, L]  row log-sum-exp of the scaled scores
   const float* dO;       // backward
   float* dqkv;           // [B*L, 3E]
+  float* dbias;          // != null: [3E] += column sums of dqkv (the in-projection's bias gradient), atomics
   float* dsum;           // [B*NH, L]  rowsum(dO . O)
   int L, E, NH;
   float scale, p;
@@ -171,6 +172,15 @@ __global__ __launch_bounds__(256) void attn_bwd_q_k(AttnArgs a) {
     for (int r = 0; r < 16; ++r) dq[mrow(r, kh)] = dqT[r] * a.scale;
     if (kh == 0) a.dsum[(long)bh * L + myq] = Dq;
   }
+  if (a.dbias) {      // column sums over this wave's 32 queries (lanes of one half-wave hold one d each)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = myq < L ? dqT[r] * a.scale : 0.f;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (l31 == 0) atomicAdd(a.dbias + h * HD + mrow(r, kh), v);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
@@ -234,6 +244,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_k(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[mrow(r, kh)] = dkT[r]; dv[mrow(r, kh)] = dvT[r]; }
   }
+  if (a.dbias) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float vk = mykey < L ? dkT[r] : 0.f, vv = mykey < L ? dvT[r] : 0.f;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) { vk += __shfl_xor(vk, o, 64); vv += __shfl_xor(vv, o, 64); }
+      if (l31 == 0) {
+        atomicAdd(a.dbias + a.E + h * HD + mrow(r, kh), vk);
+        atomicAdd(a.dbias + 2 * a.E + h * HD + mrow(r, kh), vv);
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -250,11 +272,11 @@ int k_attn_fwd(const float* qkv, float* O, float* lse, int B, int L, int E, int 
   ZLAUNCH_CHECK("attn_fwd");
   return 0;
 }
-int k_attn_bwd(const float* qkv, const float* O, const float* lse, const float* dO, float* dqkv, float* dsum, int B, int L,
-               int E, int NH, float p, uint64_t seed, hipStream_t s) {
+int k_attn_bwd(const float* qkv, const float* O, const float* lse, const float* dO, float* dqkv, float* dsum, float* dbias,
+               int B, int L, int E, int NH, float p, uint64_t seed, hipStream_t s) {
   AttnArgs a;
   memset(&a, 0, sizeof(a));
-  a.qkv = qkv; a.O = (float*)O; a.lse = (float*)lse; a.dO = dO; a.dqkv = dqkv; a.dsum = dsum;
+  a.qkv = qkv; a.O = (float*)O; a.lse = (float*)lse; a.dO = dO; a.dqkv = dqkv; a.dsum = dsum; a.dbias = dbias;
   a.L = L; a.E = E; a.NH = NH; a.scale = 1.0f / sqrtf((float)HD); a.p = p; a.seed = seed;
   hipLaunchKernelGGL(attn_bwd_q_k, dim3(cdiv(L, WQ), B * NH), dim3(256), 0, s, a);
   ZLAUNCH_CHECK("attn_bwd_q");

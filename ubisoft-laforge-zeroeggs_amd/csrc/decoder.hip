@@ -26,6 +26,7 @@ extern int g_train_persistent;
 extern int g_bwd_persistent;
 extern int g_fused_attention;
 extern int g_gemm_streamk;
+extern int g_gemm_skinny;
 extern int g_gemm_mid_split;
 extern int g_gemm_streamk_wgs;
 extern int g_mel_mfma;
@@ -54,6 +55,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "mel_mfma") == 0) { g_mel_mfma = value != 0; return 0; }
   if (strcmp(name, "gemm_streamk_wgs") == 0) { g_gemm_streamk_wgs = value; return 0; }
   if (strcmp(name, "gemm_mid_split") == 0) { g_gemm_mid_split = value != 0; return 0; }
+  if (strcmp(name, "gemm_skinny") == 0) { g_gemm_skinny = value != 0; return 0; }
   if (strcmp(name, "gemm_streamk") == 0) { g_gemm_streamk = value != 0; return 0; }
   if (strcmp(name, "fused_attention") == 0) { g_fused_attention = value != 0; return 0; }
   if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
@@ -419,17 +421,17 @@ int side_stream(SideStream** out) {
 }
 
 // fork event of a deferred-GEMM hand-over: stream-ordered use only (record on one stream, wait on another, both enqueued
-// before this returns), so one event per device is enough; events carry no data and are created once
-int fork_event(hipEvent_t* out) {
-  static hipEvent_t pool[16];
-  static bool ready[16] = {};
+// before this returns), so one event per device and hand-over point (`which`) is enough; events carry no data and are created once
+int fork_event(hipEvent_t* out, int which = 0) {
+  static hipEvent_t pool[16][2];
+  static bool ready[16][2] = {};
   int dev = 0;
   ZCHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "decoder bwd: unsupported device index");
-  if (!ready[dev]) {
-    ZCHECK(hipEventCreateWithFlags(&pool[dev], hipEventDisableTiming) == hipSuccess, "event creation failed");
-    ready[dev] = true;
+  if (!ready[dev][which]) {
+    ZCHECK(hipEventCreateWithFlags(&pool[dev][which], hipEventDisableTiming) == hipSuccess, "event creation failed");
+    ready[dev][which] = true;
   }
-  *out = pool[dev];
+  *out = pool[dev][which];
   return 0;
 }
 
@@ -856,25 +858,34 @@ extern "C" int zeggs_decoder_bwd_ex(const ZeggsDecDims* dp, const ZeggsDecParams
   } else if (!wgrads_done) {
     ZTRY(dec_recurrent_wgrads(d, w, G, 1, T - 1, gb, fast_path ? 1 : 0, s));
   }
-  // ---- CellStateEncoder backward: dH0c / dH1c are the grads wrt its two output halves
+  // ---- CellStateEncoder backward: dH0c / dH1c are the grads wrt its two output halves.  The input-gradient chain (four
+  // batch-sized products, the ELU' factors in their epilogues) is what the caller's next kernels wait for (dstyle -> the style
+  // encoder's backward): it goes first; the weight / bias gradients need only its intermediates and, with deferred GEMMs, join
+  // the recurrent layers' on the weight-gradient stream.
   {
     // out = [H0_init | H1_init] = cse_b W2^T + b2
-    ZTRY(gemm_tn(w.dH0c, H, w.cse_b, H, G->c2_w, H, B, H, H, gb, s));
-    ZTRY(gemm_tn(w.dH1c, H, w.cse_b, H, G->c2_w + (long)H * H, H, B, H, H, gb, s));
-    ZTRY(k_colsum(G->c2_b, w.dH0c, B, H, H, gb, s));
-    ZTRY(k_colsum(G->c2_b + H, w.dH1c, B, H, H, gb, s));
     float* db = w.t0;                       // [B,H] grad wrt cse_b
-    ZTRY(gemm_nn(w.dH0c, H, P->c2_w, H, db, H, B, H, H, 0.f, s));
-    ZTRY(gemm_nn(w.dH1c, H, P->c2_w + (long)H * H, H, db, H, B, H, H, 1.f, s));
-    ZTRY(k_act_bwd(db, db, w.cse_b, sH, ACT_ELU, 1.f, s));
-    ZTRY(gemm_tn(db, H, w.cse_a, H, G->c1_w, H, B, H, H, gb, s));
-    ZTRY(k_colsum(G->c1_b, db, B, H, H, gb, s));
     float* da = w.t0 + sH;                  // [B,H] grad wrt cse_a
-    ZTRY(gemm_nn(db, H, P->c1_w, H, da, H, B, H, H, 0.f, s));
-    ZTRY(k_act_bwd(da, da, w.cse_a, sH, ACT_ELU, 1.f, s));
-    ZTRY(gemm_tn(da, H, w.cse_in, CI, G->c0_w, CI, B, H, CI, gb, s));
-    ZTRY(k_colsum(G->c0_b, da, B, H, H, gb, s));
+    ZTRY(gemm_nn(w.dH0c, H, P->c2_w, H, db, H, B, H, H, 0.f, s));
+    ZTRY(gemm_nn_actbwd(w.dH1c, H, P->c2_w + (long)H * H, H, db, H, B, H, H, 1.f, w.cse_b, H, ACT_ELU, s));
+    ZTRY(gemm_nn_actbwd(db, H, P->c1_w, H, da, H, B, H, H, 0.f, w.cse_a, H, ACT_ELU, s));
     ZTRY(gemm_nn(da, H, P->c0_w, CI, w.t1, CI, B, H, CI, 0.f, s));   // t1 = d cse_in [B, PI+ST]
+    hipStream_t ws_ = s;
+    if (!wgrads_done && defer_wgrads && cap == hipStreamCaptureStatusNone) {
+      ws_ = (hipStream_t)call->wgrad_stream;
+      hipEvent_t fork = nullptr;
+      ZTRY(fork_event(&fork, 1));
+      ZCHECK(hipEventRecord(fork, s) == hipSuccess, "hipEventRecord failed");
+      ZCHECK(hipStreamWaitEvent(ws_, fork, 0) == hipSuccess, "hipStreamWaitEvent failed");
+    }
+    ZTRY(gemm_tn(w.dH0c, H, w.cse_b, H, G->c2_w, H, B, H, H, gb, ws_));
+    ZTRY(gemm_tn(w.dH1c, H, w.cse_b, H, G->c2_w + (long)H * H, H, B, H, H, gb, ws_));
+    ZTRY(k_colsum(G->c2_b, w.dH0c, B, H, H, gb, ws_));
+    ZTRY(k_colsum(G->c2_b + H, w.dH1c, B, H, H, gb, ws_));
+    ZTRY(gemm_tn(db, H, w.cse_a, H, G->c1_w, H, B, H, H, gb, ws_));
+    ZTRY(k_colsum(G->c1_b, db, B, H, H, gb, ws_));
+    ZTRY(gemm_tn(da, H, w.cse_in, CI, G->c0_w, CI, B, H, CI, gb, ws_));
+    ZTRY(k_colsum(G->c0_b, da, B, H, H, gb, ws_));
   }
   hipLaunchKernelGGL(dec_scatter_cond_grad_k, g1((long)T * B * (d.SP + d.ST)), dim3(256), 0, s, d, w.DX, XD, dspeech,
                      dstyle);

@@ -295,38 +295,53 @@ extern "C" int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims* dp, const ZeggsS
   const long BL = (long)B * L;
   const float p2 = d.dropout ? 0.2f : 0.f, p1 = d.dropout ? 0.1f : 0.f;
   float *t0 = w.t0, *t1 = w.t1, *t2 = w.t2, *t3 = w.t3;
-  // ---- mean pool, final LN (f = LN(f2 + a))
-  ZTRY(k_meanpool_bwd(t1, dout, B, L, E, s));                                   // t1 = df [BL,E]
-  if (!grads_zeroed) { ZTRY(k_fill(G->lnf_g, E, 0.f, s)); ZTRY(k_fill(G->lnf_b, E, 0.f, s)); }
-  ZTRY(k_layernorm_bwd_v(rv(t2), rv(t1), rv(w.f2), rv(w.ap + E, L, (long)LP * E), P->lnf_g, w.mf, w.rf, G->lnf_g,
-                          G->lnf_b, (int)BL, E, s));                              // t2 = d(f2 + a) [BL,E]
-  // residual branch: da_res = t2 (kept in t2); conv branch: df2 = t2 * mask
-  ZTRY(k_copy(t1, t2, BL * E, s));
-  ZTRY(k_dropout(t1, BL * E, p1, d.seed + 5, s));                               // t1 = df2
-  ZTRY(k_colsum(G->ff2_b, t1, BL, E, E, gb, s));
-  ZTRY(conv_dw_gemm(w.f1p, (long)LP * E, E, t1, E, (long)L * E, w.dwf, 3 * E, E, B, L, s));
+  // The elementwise work between the products is four passes, each fused around a LayerNorm backward (k_ln_bwd_fused): the
+  // chain is the critical path of the iteration's tail, beside the decoder's weight-gradient GEMMs on the other stream, and every
+  // separate small pass (pool, copy, mask, ReLU', bias sum, pad) waited for CU slots there.
+  if (!grads_zeroed) {
+    ZTRY(k_fill(G->lnf_g, E, 0.f, s)); ZTRY(k_fill(G->lnf_b, E, 0.f, s)); ZTRY(k_fill(G->ff2_b, E, 0.f, s));
+    ZTRY(k_fill(G->ff0_b, E, 0.f, s)); ZTRY(k_fill(G->lna_g, E, 0.f, s)); ZTRY(k_fill(G->lna_b, E, 0.f, s));
+    ZTRY(k_fill(G->out_b, E, 0.f, s)); ZTRY(k_fill(G->ln1_g, E, 0.f, s)); ZTRY(k_fill(G->ln1_b, E, 0.f, s));
+    ZTRY(k_fill(G->c4_b, E, 0.f, s)); ZTRY(k_fill(G->ln0_g, H, 0.f, s)); ZTRY(k_fill(G->ln0_b, H, 0.f, s));
+    ZTRY(k_fill(G->c0_b, H, 0.f, s));
+    if (w.fused) ZTRY(k_fill(G->in_b, 3 * E, 0.f, s));
+  }
+  const RowView t0in = rv(t0 + E, L, (long)LP * E);      // interior of the padded [B, LP, E] buffer the input-gradient convs read
+  // ---- mean pool, final LN (f = LN(f2 + a)), the mask of ff2's output: t2 = d(f2 + a) (the residual branch keeps it),
+  //      t0 interior = df2 = t2 * mask, ff2_b += column sums
+  {
+    LnBwdFused q = ln_bwd_fused_args((int)BL, E);
+    q.dy_pool = dout; q.pool_L = L;
+    q.x = rv(w.f2); q.res = rv(w.ap + E, L, (long)LP * E); q.gamma = P->lnf_g; q.mean = w.mf; q.rstd = w.rf;
+    q.dgamma = G->lnf_g; q.dbeta = G->lnf_b;
+    q.dx_raw = rv(t2); q.out = t0in; q.pad_L = L; q.p_post = p1; q.seed_post = d.seed + 5; q.dbias = G->ff2_b;
+    ZTRY(k_ln_bwd_fused(q, s));
+  }
+  ZTRY(conv_dw_gemm(w.f1p, (long)LP * E, E, t0 + E, E, (long)LP * E, w.dwf, 3 * E, E, B, L, s));
   ZTRY(k_unpack_conv_dw(G->ff2_w, w.dwf, E, E, 3, s));
-  // d f1 = conv_bwd(df2): zero-pad df2 by 1 and correlate with flipped taps
-  ZTRY(k_pad_rows(t0, t1, B, L, E, 1, 1, 0, s));                                // t0 = df2 padded [B,LP,E]
+  // d f1 = conv_bwd(df2): the zero-padded df2 correlated with the flipped taps, then ReLU' (saved f1), ff0_b, padded again
   ZTRY(conv_gemm(t0, (long)LP * E, E, w.wfb2, 3 * E, E, t1, E, (long)L * E, nullptr, B, L, ACT_NONE, s));
-  ZTRY(k_act_bwd_v(rv(t1), rv(t1), rv(w.f1p + E, L, (long)LP * E), BL, E, ACT_RELU, 1.f, s));  // ReLU' (saved f1)
-  ZTRY(k_colsum(G->ff0_b, t1, BL, E, E, gb, s));
-  ZTRY(conv_dw_gemm(w.ap, (long)LP * E, E, t1, E, (long)L * E, w.dwf, 3 * E, E, B, L, s));
+  {
+    LnBwdFused q = ln_bwd_fused_args((int)BL, E);
+    q.dyA = rv(t1); q.out = t0in; q.pad_L = L; q.ysave = rv(w.f1p + E, L, (long)LP * E); q.act = ACT_RELU; q.dbias = G->ff0_b;
+    ZTRY(k_ln_bwd_fused(q, s));
+  }
+  ZTRY(conv_dw_gemm(w.ap, (long)LP * E, E, t0 + E, E, (long)LP * E, w.dwf, 3 * E, E, B, L, s));
   ZTRY(k_unpack_conv_dw(G->ff0_w, w.dwf, E, E, 3, s));
-  ZTRY(k_pad_rows(t0, t1, B, L, E, 1, 1, 0, s));
   ZTRY(conv_gemm(t0, (long)LP * E, E, w.wfb0, 3 * E, E, t1, E, (long)L * E, nullptr, B, L, ACT_NONE, s));
-  ZTRY(k_add_inplace(t2, t1, BL * E, s));                                       // t2 = da  (conv path + residual)
-  // ---- attention LN: a = LN(ao + h)
-  if (!grads_zeroed) { ZTRY(k_fill(G->lna_g, E, 0.f, s)); ZTRY(k_fill(G->lna_b, E, 0.f, s)); }
-  ZTRY(k_layernorm_bwd(t1, t2, w.ao, w.h, P->lna_g, w.ma, w.ra, G->lna_g, G->lna_b, (int)BL, E, s));
-  // t1 = d(ao + h): residual grad to h kept in t3; out-proj branch through dropout
-  ZTRY(k_copy(t3, t1, BL * E, s));                                              // t3 = dh (residual part)
-  ZTRY(k_dropout(t1, BL * E, p1, d.seed + 4, s));                               // t1 = dao
+  // ---- attention LN: a = LN(ao + h), da = t2 (residual) + t1 (conv path): t3 = d(ao + h) (h's residual share),
+  //      t1 = dao = t3 * mask, out_b += column sums
+  {
+    LnBwdFused q = ln_bwd_fused_args((int)BL, E);
+    q.dyA = rv(t2); q.dyB = rv(t1);
+    q.x = rv(w.ao); q.res = rv(w.h); q.gamma = P->lna_g; q.mean = w.ma; q.rstd = w.ra; q.dgamma = G->lna_g; q.dbeta = G->lna_b;
+    q.dx_raw = rv(t3); q.out = rv(t1); q.p_post = p1; q.seed_post = d.seed + 4; q.dbias = G->out_b;
+    ZTRY(k_ln_bwd_fused(q, s));
+  }
   ZTRY(gemm_tn(t1, E, w.O, E, G->out_w, E, (int)BL, E, E, gb, s));
-  ZTRY(k_colsum(G->out_b, t1, BL, E, E, gb, s));
   ZTRY(gemm_nn(t1, E, P->out_w, E, t2, E, (int)BL, E, E, 0.f, s));              // t2 = dO [BL,E]
   if (w.fused) {      // dQ, dK, dV with the probabilities recomputed from the saved row log-sum-exp (attention.hip)
-    ZTRY(k_attn_bwd(w.qkv, w.O, w.lse, t2, w.dqkv, w.dsum, B, L, E, NH, p1, d.seed + 3, s));
+    ZTRY(k_attn_bwd(w.qkv, w.O, w.lse, t2, w.dqkv, w.dsum, G->in_b, B, L, E, NH, p1, d.seed + 3, s));
   } else {
   const float* Pm = w.Pd ? w.Pd : w.P;
   {
@@ -361,24 +376,28 @@ extern "C" int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims* dp, const ZeggsS
   }
   }
   ZTRY(gemm_tn(w.dqkv, 3 * E, w.h, E, G->in_w, E, (int)BL, 3 * E, E, gb, s));
-  ZTRY(k_colsum(G->in_b, w.dqkv, BL, 3 * E, 3 * E, gb, s));
-  ZTRY(gemm_nn(w.dqkv, 3 * E, P->in_w, E, t1, E, (int)BL, 3 * E, E, 0.f, s));   // t1 = dh (attention part)
-  ZTRY(k_add_inplace(t1, t3, BL * E, s));                                       // t1 = dh total (pos table: no grad)
-  // ---- conv stack: h = dropout(LN(c2)) + pos
-  ZTRY(k_dropout(t1, BL * E, p2, d.seed + 2, s));
-  if (!grads_zeroed) { ZTRY(k_fill(G->ln1_g, E, 0.f, s)); ZTRY(k_fill(G->ln1_b, E, 0.f, s)); }
-  ZTRY(k_layernorm_bwd(t2, t1, w.c2, nullptr, P->ln1_g, w.m2, w.r2, G->ln1_g, G->ln1_b, (int)BL, E, s));
-  ZTRY(k_act_bwd(t2, t2, w.c2, BL * E, ACT_RELU, 1.f, s));                      // t2 = dc2 (pre-activation)
-  ZTRY(k_colsum(G->c4_b, t2, BL, E, E, gb, s));
-  ZTRY(conv_dw_gemm(w.a1p, (long)LP * H, H, t2, E, (long)L * E, w.dwf, 3 * H, E, B, L, s));
+  if (!w.fused) ZTRY(k_colsum(G->in_b, w.dqkv, BL, 3 * E, 3 * E, gb, s));          // (fused attention: summed by its kernels)
+  ZTRY(gemm_nn(w.dqkv, 3 * E, P->in_w, E, t1, E, (int)BL, 3 * E, E, 0.f, s));   // t1 = dh (attention part; pos table: no grad)
+  // ---- conv stack: h = dropout(LN(c2)) + pos, c2 = ReLU(conv): dh = (t1 + t3) * mask -> LN backward -> ReLU' -> t0 interior
+  //      (padded for the conv's input gradient), c4_b += column sums
+  {
+    LnBwdFused q = ln_bwd_fused_args((int)BL, E);
+    q.dyA = rv(t1); q.dyB = rv(t3); q.p_pre = p2; q.seed_pre = d.seed + 2;
+    q.x = rv(w.c2); q.gamma = P->ln1_g; q.mean = w.m2; q.rstd = w.r2; q.dgamma = G->ln1_g; q.dbeta = G->ln1_b;
+    q.out = t0in; q.pad_L = L; q.ysave = rv(w.c2); q.act = ACT_RELU; q.dbias = G->c4_b;
+    ZTRY(k_ln_bwd_fused(q, s));
+  }
+  ZTRY(conv_dw_gemm(w.a1p, (long)LP * H, H, t0 + E, E, (long)LP * E, w.dwf, 3 * H, E, B, L, s));
   ZTRY(k_unpack_conv_dw(G->c4_w, w.dwf, E, H, 3, s));
-  ZTRY(k_pad_rows(t0, t2, B, L, E, 1, 1, 0, s));
   ZTRY(conv_gemm(t0, (long)LP * E, E, w.wb4, 3 * E, H, t1, H, (long)L * H, nullptr, B, L, ACT_NONE, s));  // t1 = da1 [BL,H]
-  ZTRY(k_dropout(t1, BL * H, p2, d.seed + 1, s));
-  if (!grads_zeroed) { ZTRY(k_fill(G->ln0_g, H, 0.f, s)); ZTRY(k_fill(G->ln0_b, H, 0.f, s)); }
-  ZTRY(k_layernorm_bwd(t2, t1, w.c1, nullptr, P->ln0_g, w.m1, w.r1, G->ln0_g, G->ln0_b, (int)BL, H, s));
-  ZTRY(k_act_bwd(t2, t2, w.c1, BL * H, ACT_RELU, 1.f, s));                      // t2 = dc1
-  ZTRY(k_colsum(G->c0_b, t2, BL, H, H, gb, s));
+  // ---- a1 = dropout(LN(c1)), c1 = ReLU(conv): the same pass at width H, t2 = dc1
+  {
+    LnBwdFused q = ln_bwd_fused_args((int)BL, H);
+    q.dyA = rv(t1); q.p_pre = p2; q.seed_pre = d.seed + 1;
+    q.x = rv(w.c1); q.gamma = P->ln0_g; q.mean = w.m1; q.rstd = w.r1; q.dgamma = G->ln0_g; q.dbeta = G->ln0_b;
+    q.out = rv(t2); q.ysave = rv(w.c1); q.act = ACT_RELU; q.dbias = G->c0_b;
+    ZTRY(k_ln_bwd_fused(q, s));
+  }
   ZTRY(conv_dw_gemm(w.xp, (long)LP * C, C, t2, H, (long)L * H, w.dwf, 3 * C, H, B, L, s));
   ZTRY(k_unpack_conv_dw(G->c0_w, w.dwf, H, C, 3, s));
   return 0;

@@ -24,5 +24,7 @@ int gemm_nt(const float* x, long ldx, const float* W, long ldw, float* y, long l
             int N, int K, int act, float beta, hipStream_t s);
 int gemm_nn(const float* dy, long lddy, const float* W, long ldw, float* dx, long lddx, int M, int N_contract,
             int K_out, float beta, hipStream_t s);
+int gemm_nn_actbwd(const float* dy, long lddy, const float* W, long ldw, float* dx, long lddx, int M, int N_contract,
+                   int K_out, float beta, const float* ysave, long ldys, int act, hipStream_t s);
 int gemm_tn(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M_contract, int N,
             int K, float beta, hipStream_t s);

@@ -338,8 +338,132 @@ int launch_streamk(GemmArgs g, hipStream_t s) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Batch-sized products y[M <= 64, N] = act(x W + bias) in ONE launch (the CellStateEncoder forward and backward, hid_1, the
+// step-1 pose product in front of the training rollout, the per-step products of the generic decoder path): the split-K recipe
+// below costs three dependent launches (zero fill, atomics, bias + activation) on chains that are nothing but launch latency.
+// A workgroup owns 16 output columns, its 8 waves split K in 16-wide blocks (block = wave + 8 i), every lane loads 4 consecutive
+// k of one x row (16 bytes) and the matching 4 weights -- WKC: W[n][k], 16 bytes of one row (nn.Linear forward, y = x W^T);
+// else W[k][n], four 4-byte loads down a column (input gradients, dx = dy W) -- and feeds 4 v_mfma_f32_16x16x4 with them (the
+// contraction order inside a block is a permutation that both operands share); the waves' partial tiles meet in LDS; bias,
+// beta * y, the activation or the factor act'(saved output) of a backward chain are applied by the reducing threads.
+// All workgroups read the same x (L2 hits); W is read exactly once.
+struct SkinnyArgs {
+  const float *x, *W, *bias;
+  float* y;
+  const float* ysave;      // != null: y *= act'(ysave) (ysave = the forward's activation output, row stride ldys)
+  long ldx, ldw, ldy, ldys;
+  int M, N, K, act;
+  float beta;
+};
+template <int NBM, bool WKC>
+__global__ __launch_bounds__(512) void skinny_k(SkinnyArgs a) {
+  __shared__ f4 red[8][NBM][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int M = a.M, N = a.N, K = a.K;
+  const int n0 = blockIdx.x * 16, nblk = (K + 15) >> 4;
+  const int wcol = n0 + r < N ? n0 + r : N - 1;                 // (clamped columns compute garbage nobody stores)
+  const float* wp = WKC ? a.W + (long)wcol * a.ldw + 4 * g : a.W + (long)(4 * g) * a.ldw + wcol;
+  const float* xp[NBM];
+#pragma unroll
+  for (int nb = 0; nb < NBM; ++nb) { const int row = nb * 16 + r; xp[nb] = a.x + (long)(row < M ? row : M - 1) * a.ldx + 4 * g; }
+  f4 acc[NBM];
+#pragma unroll
+  for (int nb = 0; nb < NBM; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+  constexpr int GR = 4;                                        // blocks per group: the next group's loads fly under this one's products
+  float wa[GR][4], xa[GR][NBM][4], wq[GR][4], xq[GR][NBM][4];
+  auto load = [&](float (&w)[GR][4], float (&xv)[GR][NBM][4], int i0) {
+#pragma unroll
+    for (int u = 0; u < GR; ++u) {
+      const int kb = wave + 8 * (i0 + u);
+      const int nv = kb < nblk ? K - (kb * 16 + 4 * g) : 0;     // valid k of this lane's quad (<= 0: all zero)
+      if constexpr (WKC) load_contig<4>(w[u], wp + kb * 16, nv);
+      else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[u][j] = j < nv ? wp[(long)(kb * 16 + j) * a.ldw] : 0.f;
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBM; ++nb) load_contig<4>(xv[u][nb], xp[nb] + kb * 16, nv);
+    }
+  };
+  auto comp = [&](const float (&w)[GR][4], const float (&xv)[GR][NBM][4]) {
+#pragma unroll
+    for (int u = 0; u < GR; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NBM; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][nb][j], w[u][j], acc[nb], 0, 0, 0);
+  };
+  const int ni = (nblk - wave + 7) / 8;                         // blocks of this wave
+  load(wa, xa, 0);
+  for (int i = 0; i < ni; i += 2 * GR) {
+    if (i + GR < ni) load(wq, xq, i + GR);
+    comp(wa, xa);
+    if (i + 2 * GR < ni) load(wa, xa, i + 2 * GR);
+    if (i + GR < ni) comp(wq, xq);
+  }
+#pragma unroll
+  for (int nb = 0; nb < NBM; ++nb) red[wave][nb][lane] = acc[nb];
+  __syncthreads();
+  if (tid < NBM * 64) {
+    const int nb = tid >> 6, l = tid & 63;
+    f4 sum = red[0][nb][l];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) sum += red[w][nb][l];
+    const int col = n0 + (l & 15);
+    if (col < N) {
+      const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = nb * 16 + 4 * (l >> 4) + q;             // D layout: lane holds rows 4 (lane / 16) + q of column lane % 16
+        if (row < M) {
+          float* yp = a.y + (long)row * a.ldy + col;
+          float v = sum[q] + bv;
+          if (a.beta != 0.f) v += a.beta * *yp;
+          if (a.ysave) {
+            const float ys = a.ysave[(long)row * a.ldys + col];
+            v = a.act == ACT_ELU ? v * d_elu_grad_from_out(ys) : a.act == ACT_RELU ? (ys > 0.f ? v : 0.f) : v;
+          } else v = d_act(v, a.act);
+          *yp = v;
+        }
+      }
+    }
+  }
+}
+
+int launch_skinny(const SkinnyArgs& a, bool wkc, hipStream_t s) {
+  const int nbm = cdiv(a.M, 16);
+  dim3 grid(cdiv(a.N, 16)), block(512);
+#define ZEGGS_SKINNY(NB)                                                             \
+  do {                                                                               \
+    if (wkc) hipLaunchKernelGGL((skinny_k<NB, true>), grid, block, 0, s, a);         \
+    else hipLaunchKernelGGL((skinny_k<NB, false>), grid, block, 0, s, a);            \
+  } while (0)
+  if (nbm == 1) ZEGGS_SKINNY(1);
+  else if (nbm == 2) ZEGGS_SKINNY(2);
+  else if (nbm == 3) ZEGGS_SKINNY(3);
+  else ZEGGS_SKINNY(4);
+#undef ZEGGS_SKINNY
+  ZLAUNCH_CHECK("gemm_skinny");
+  return 0;
+}
+// the shapes / layouts the one-launch kernel takes: C row-major, A k-contiguous, B k- or n-contiguous, no batching
+bool skinny_ok(const GemmArgs& g, int nbatch) {
+  return g.M <= 64 && nbatch == 1 && g.kbatch == 1 && g.sak == 1 && g.scn == 1 && g.alpha == 1.f && g.N >= 64 && g.K >= 64 &&
+         ((g.sbk == 1 && g.sbn != 1) || g.sbn == 1) && (g.beta == 0.f || (g.bias == nullptr && g.act == ACT_NONE));
+}
+SkinnyArgs skinny_args(const GemmArgs& g) {
+  SkinnyArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = g.A; a.ldx = g.sam; a.W = g.B; a.y = g.C; a.ldy = g.scm; a.bias = g.bias; a.M = g.M; a.N = g.N; a.K = g.K;
+  a.act = g.act; a.beta = g.beta;
+  a.ldw = (g.sbk == 1 && g.sbn != 1) ? g.sbn : g.sbk;
+  return a;
+}
+
 }  // namespace
 
+int g_gemm_skinny = 1;          // zeggs_set_option("gemm_skinny", 0/1): batch-sized NT products in one launch
 int g_gemm_streamk = 1;        // zeggs_set_option("gemm_streamk", 0/1): stream-K instead of the many-workgroup split-K
 int g_gemm_mid_split = 1;      // zeggs_set_option("gemm_mid_split", 0/1): split K of the latency-bound narrow-output products
 
@@ -348,6 +472,7 @@ int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   if (g.nb1 <= 0) g.nb1 = 1;
   if (g.kbatch <= 0) g.kbatch = 1;
   g.splitk = 1;
+  if (g_gemm_skinny && skinny_ok(g, nbatch)) return launch_skinny(skinny_args(g), g.sbk == 1 && g.sbn != 1, s);
   if (g.M <= 32) {
     // batch-sized products (M = B rows against a whole weight matrix: CellStateEncoder, the per-step GEMMs of the
     // generic decoder path): N / 128 workgroups would leave most of the chip idle -> split K over workgroups
@@ -462,6 +587,21 @@ int gemm_nn(const float* dy, long lddy, const float* W, long ldw, float* dx, lon
   GemmArgs g = gemm_args(dy, W, dx, M, K_out, N_contract);
   g.sam = lddy; g.sak = 1; g.sbk = ldw; g.sbn = 1; g.scm = lddx; g.scn = 1; g.beta = beta;
   return launch_gemm(g, 1, s);
+}
+// dx[M,K] = (beta*dx + dy[M,N] W[N,K]) * act'(ysave)   (input gradient of nn.Linear through the preceding activation, whose
+// output the forward saved): one launch for batch-sized M, else the product followed by the elementwise pass
+int gemm_nn_actbwd(const float* dy, long lddy, const float* W, long ldw, float* dx, long lddx, int M, int N_contract,
+                   int K_out, float beta, const float* ysave, long ldys, int act, hipStream_t s) {
+  GemmArgs g = gemm_args(dy, W, dx, M, K_out, N_contract);
+  g.sam = lddy; g.sak = 1; g.sbk = ldw; g.sbn = 1; g.scm = lddx; g.scn = 1; g.beta = beta;
+  if (g_gemm_skinny && skinny_ok(g, 1)) {
+    SkinnyArgs a = skinny_args(g);
+    a.ysave = ysave; a.ldys = ldys; a.act = act;
+    return launch_skinny(a, false, s);
+  }
+  ZTRY(launch_gemm(g, 1, s));
+  if (lddx != K_out || ldys != K_out) { zeggs_set_error("gemm_nn_actbwd: strided rows need the one-launch kernel (M <= 64)"); return -1; }
+  return k_act_bwd(dx, dx, ysave, (long)M * K_out, act, 1.f, s);
 }
 // dW[N,K] = beta*dW + dy[M,N]^T x[M,K]        (weight gradient of nn.Linear)
 int gemm_tn(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M_contract, int N,

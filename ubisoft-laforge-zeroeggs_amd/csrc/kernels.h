@@ -15,6 +15,28 @@ int k_layernorm_fwd_v(RowView y, RowView x, RowView res, const float* gamma, con
 int k_layernorm_bwd_v(RowView dx, RowView dy, RowView x, RowView res, const float* gamma, const float* mean,
                       const float* rstd, float* dgamma, float* dbeta, int R, int C, hipStream_t s);
 int k_act_bwd_v(RowView dx, RowView dy, RowView y, long R, int C, int act, float y_scale, hipStream_t s);
+// One pass over the rows of a backward chain around a LayerNorm (the style encoder's backward is four such chains):
+//   dy   = (dyA + dyB) * mask(seed_pre)                     [dy_pool != null: the mean-pool backward dy_pool[row / pool_L] / pool_L]
+//   dx   = LayerNorm backward of dy (gamma == null: dx = dy), dgamma / dbeta accumulated (atomics)
+//   dx_raw (optional) = dx                                   (the residual branch's share)
+//   out  = dx * mask(seed_post) * act'(ysave);  dbias[c] += sum_rows out   (atomics; the gradient of the bias that produced the
+//          LayerNorm's input);  pad_L > 0: `out` is the interior of a [B, pad_L + 2, C] buffer whose edge rows are zeroed here
+// Element index of the masks: row * C + c (k_dropout over the contiguous [R, C] array).  In-place use is fine row by row.
+struct LnBwdFused {
+  RowView dyA, dyB;
+  const float* dy_pool;
+  int pool_L;
+  float p_pre, p_post;
+  uint64_t seed_pre, seed_post;
+  RowView x, res;
+  const float *gamma, *mean, *rstd;
+  RowView dx_raw, out, ysave;
+  int act, pad_L;
+  float *dgamma, *dbeta, *dbias;
+  int R, C;
+};
+LnBwdFused ln_bwd_fused_args(int R, int C);
+int k_ln_bwd_fused(const LnBwdFused& a, hipStream_t s);
 int k_colsum_v(float* out, RowView x, long R, int C, float beta, hipStream_t s);
 
 // y = x (optional), fill
@@ -61,5 +83,6 @@ int k_meanpool_bwd(float* df, const float* dout, int B, int L, int C, hipStream_
 // fused multi-head attention of the style encoder (attention.hip); head dimension 32 only (attn_fused_supported)
 int attn_fused_supported(int E, int NH);
 int k_attn_fwd(const float* qkv, float* O, float* lse, int B, int L, int E, int NH, float p, uint64_t seed, hipStream_t s);
-int k_attn_bwd(const float* qkv, const float* O, const float* lse, const float* dO, float* dqkv, float* dsum, int B, int L,
-               int E, int NH, float p, uint64_t seed, hipStream_t s);
+// dbias != null: [3E] += column sums of dqkv (atomics onto a zeroed / accumulating bias gradient)
+int k_attn_bwd(const float* qkv, const float* O, const float* lse, const float* dO, float* dqkv, float* dsum, float* dbias,
+               int B, int L, int E, int NH, float p, uint64_t seed, hipStream_t s);

@@ -133,6 +133,84 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(RowView dxv, RowView dyv,
   }
 }
 
+// see kernels.h (LnBwdFused).  One wave per row, 16 rows per block (as layernorm_bwd_k)
+template <int MAXJ>
+__global__ __launch_bounds__(256) void ln_bwd_fused_k(LnBwdFused a, int rows_per_block) {
+  __shared__ float sg[4][64 * MAXJ], sb[4][64 * MAXJ], sc[4][64 * MAXJ];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, C = a.C, R = a.R;
+  const bool ln = a.gamma != nullptr;
+  float pg[MAXJ], pb[MAXJ], pc[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) pg[j] = pb[j] = pc[j] = 0.f;
+  const int r0 = blockIdx.x * rows_per_block;
+  for (int row = r0 + wave; row < r0 + rows_per_block && row < R; row += 4) {
+    const float mu = ln ? a.mean[row] : 0.f, rs = ln ? a.rstd[row] : 1.f;
+    const float* x = ln ? rv_row(a.x, row, C) : nullptr;
+    const float* res = (ln && a.res.p) ? rv_row(a.res, row, C) : nullptr;
+    const float* dyA = a.dy_pool ? a.dy_pool + (long)(row / a.pool_L) * C : rv_row(a.dyA, row, C);
+    const float* dyB = a.dyB.p ? rv_row(a.dyB, row, C) : nullptr;
+    const float dscale = a.dy_pool ? 1.f / a.pool_L : 1.f;
+    float xh[MAXJ], g[MAXJ], d[MAXJ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = lane + 64 * j;
+      xh[j] = 0.f; g[j] = 0.f; d[j] = 0.f;
+      if (c < C) {
+        float dv = dyA[c] * dscale + (dyB ? dyB[c] : 0.f);
+        dv *= dropout_scale(a.seed_pre, (uint64_t)((long)row * C + c), a.p_pre);
+        d[j] = dv;
+        if (ln) {
+          const float xval = x[c] + (res ? res[c] : 0.f);
+          xh[j] = (xval - mu) * rs;
+          g[j] = dv * a.gamma[c];
+          pg[j] += dv * xh[j];
+          pb[j] += dv;
+          s1 += g[j];
+          s2 += g[j] * xh[j];
+        }
+      }
+    }
+    if (ln) {
+      s1 = wave_sum(s1) / C;
+      s2 = wave_sum(s2) / C;
+    }
+    float* outr = rv_row(a.out, row, C);
+    float* rawr = a.dx_raw.p ? rv_row(a.dx_raw, row, C) : nullptr;
+    const float* ys = a.ysave.p ? rv_row(a.ysave, row, C) : nullptr;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C) {
+        const float dx = ln ? rs * (g[j] - s1 - xh[j] * s2) : d[j];
+        if (rawr) rawr[c] = dx;
+        float o = dx * dropout_scale(a.seed_post, (uint64_t)((long)row * C + c), a.p_post);
+        if (ys) {
+          const float yv = ys[c];
+          o = a.act == ACT_ELU ? o * d_elu_grad_from_out(yv) : a.act == ACT_RELU ? (yv > 0.f ? o : 0.f) : o;
+        }
+        outr[c] = o;
+        pc[j] += o;
+        if (a.pad_L > 0) {       // edge rows of the padded buffer this row sits in
+          const int l = row % a.pad_L;
+          if (l == 0) outr[c - C] = 0.f;
+          if (l == a.pad_L - 1) outr[c + C] = 0.f;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) { sg[wave][lane + 64 * j] = pg[j]; sb[wave][lane + 64 * j] = pb[j]; sc[wave][lane + 64 * j] = pc[j]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    if (ln) {
+      atomicAdd(a.dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+      atomicAdd(a.dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+    }
+    if (a.dbias) atomicAdd(a.dbias + c, sc[0][c] + sc[1][c] + sc[2][c] + sc[3][c]);
+  }
+}
+
 __global__ __launch_bounds__(256) void softmax_fwd_k(float* P, float* Pd, const float* S, long R, int L, float p,
                                                       uint64_t seed) {
   long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -371,6 +449,21 @@ int k_layernorm_bwd_v(RowView dx, RowView dy, RowView x, RowView res, const floa
     hipLaunchKernelGGL((layernorm_bwd_k<8>), dim3(cdiv(R, rpb)), dim3(256), 0, s, dx, dy, x, res, gamma, mean, rstd,
                        dgamma, dbeta, R, C, rpb);
   ZLAUNCH_CHECK("layernorm_bwd");
+  return 0;
+}
+LnBwdFused ln_bwd_fused_args(int R, int C) {
+  LnBwdFused a;
+  memset(&a, 0, sizeof(a));
+  a.R = R; a.C = C; a.pool_L = 1;
+  return a;
+}
+int k_ln_bwd_fused(const LnBwdFused& a, hipStream_t s) {
+  const int rpb = 16;
+  ZCHECK(a.C <= 512, "ln_bwd_fused: C=%d > 512 unsupported", a.C);
+  ZCHECK(a.out.p != nullptr && (a.dy_pool != nullptr || a.dyA.p != nullptr), "ln_bwd_fused: missing operand");
+  if (a.C <= 128) hipLaunchKernelGGL((ln_bwd_fused_k<2>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb);
+  else hipLaunchKernelGGL((ln_bwd_fused_k<8>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb);
+  ZLAUNCH_CHECK("ln_bwd_fused");
   return 0;
 }
 int k_layernorm_bwd(float* dx, const float* dy, const float* x, const float* res, const float* gamma,
