@@ -60,21 +60,29 @@ def test_gemm_skinny_nt_one_launch(M, N, K):
     bias = torch.randn(N)
     X, Wm = g(xb), g(wb)
     x, w = X[:, 1:1 + K], Wm[:, 1021:1021 + K]                       # odd element offsets
+
+    class Raw:      # a strided view handed over as its first element's address (ops.gemm takes the strides separately)
+        def __init__(self, t):
+            self.t, self.is_cuda, self.dtype = t, True, t.dtype
+        def is_contiguous(self):
+            return True
+        def data_ptr(self):
+            return self.t.data_ptr()
     ref = x.double().cpu() @ w.double().cpu().t() + bias.double()
     for act, fn in ((0, lambda t: t), (1, torch.nn.functional.elu)):
         Y = torch.full((M, ldy), 7.0, device=DEV)
-        ops.gemm(x, w, Y, M, N, K, (ldx, 1), (1, ldw), (ldy, 1), bias=g(bias), act=act)
+        ops.gemm(Raw(x), Raw(w), Y, M, N, K, (ldx, 1), (1, ldw), (ldy, 1), bias=g(bias), act=act)
         assert relerr(Y[:, :N], fn(ref)) < 2e-6
         assert bool((Y[:, N:] == 7.0).all())                          # nothing written past the N columns
         ops.set_option("gemm_skinny", 0)                              # the split-K recipe gives the same
         Y0 = torch.zeros(M, ldy, device=DEV)
-        ops.gemm(x, w, Y0, M, N, K, (ldx, 1), (1, ldw), (ldy, 1), bias=g(bias), act=act)
+        ops.gemm(Raw(x), Raw(w), Y0, M, N, K, (ldx, 1), (1, ldw), (ldy, 1), bias=g(bias), act=act)
         ops.set_option("gemm_skinny", 1)
         assert relerr(Y[:, :N], Y0[:, :N]) < 2e-6
     # NN (input gradients dx = dy W: W[k][n], four 4-byte loads down a column), accumulating onto an existing result
     wt = g(wb[:, 1021:1021 + K].t().contiguous())                     # [K, N]
     Y = torch.full((M, ldy), 0.5, device=DEV)
-    ops.gemm(x, wt, Y, M, N, K, (ldx, 1), (N, 1), (ldy, 1), beta=1.0)
+    ops.gemm(Raw(x), wt, Y, M, N, K, (ldx, 1), (N, 1), (ldy, 1), beta=1.0)
     assert relerr(Y[:, :N], ref - bias.double() + 0.5) < 2e-6 and bool((Y[:, N:] == 0.5).all())
 
 

@@ -27,6 +27,7 @@ extern int g_bwd_persistent;
 extern int g_fused_attention;
 extern int g_gemm_streamk;
 extern int g_gemm_skinny;
+void zeggs_gemm_set_dma(int on);
 extern int g_gemm_mid_split;
 extern int g_gemm_streamk_wgs;
 extern int g_mel_mfma;
@@ -55,6 +56,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "mel_mfma") == 0) { g_mel_mfma = value != 0; return 0; }
   if (strcmp(name, "gemm_streamk_wgs") == 0) { g_gemm_streamk_wgs = value; return 0; }
   if (strcmp(name, "gemm_mid_split") == 0) { g_gemm_mid_split = value != 0; return 0; }
+  if (strcmp(name, "gemm_dma") == 0) { zeggs_gemm_set_dma(value != 0); return 0; }
   if (strcmp(name, "gemm_skinny") == 0) { g_gemm_skinny = value != 0; return 0; }
   if (strcmp(name, "gemm_streamk") == 0) { g_gemm_streamk = value != 0; return 0; }
   if (strcmp(name, "fused_attention") == 0) { g_fused_attention = value != 0; return 0; }

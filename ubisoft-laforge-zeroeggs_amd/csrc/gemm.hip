@@ -87,6 +87,15 @@ __device__ __forceinline__ void load_full(float (&r)[E], const float* p) {
 #ifndef ZEGGS_GEMM_HALF_TILES
 #define ZEGGS_GEMM_HALF_TILES 1
 #endif
+#ifndef ZEGGS_GEMM_SWP
+#define ZEGGS_GEMM_SWP 0
+#endif
+#ifndef ZEGGS_GEMM_MIDSTORE
+#define ZEGGS_GEMM_MIDSTORE 0      // (with ZEGGS_GEMM_SWP) k-pair in front of which the next tile is stored to LDS; 0: after the products
+#endif
+#ifndef ZEGGS_GEMM_ABL
+#define ZEGGS_GEMM_ABL 0           // timing experiments (wrong results): 1 no per-k LDS fetch, 2 no loads / stores, 3 = 2 + no barrier, 4 = 1 + 3
+#endif
 #ifndef ZEGGS_GEMM_SWIZZLE
 #define ZEGGS_GEMM_SWIZZLE 1
 #endif
@@ -117,7 +126,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const float* A, con
 
   // interior blocks take a branch-free path (unguarded vector loads); edge blocks / the K tail use guarded loads
   const bool interior = (m_base + BM <= g.M) && (n_base + BN <= g.N);
-  auto gload = [&](int tile) {
+  auto gload_r = [&](float (&ra)[EA], float (&rb)[EB], int tile) {
     const int kb = tile / nkt, k_base = (tile % nkt) * BK;
     const float* Ab = A + (long)kb * g.kbsA;
     const float* Bb = B + (long)kb * g.kbsB;
@@ -147,7 +156,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const float* A, con
       load_contig<EB>(rb, Bb + (long)k * g.sbk + n, nv < 0 ? 0 : nv);
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore_r = [&](const float (&ra)[EA], const float (&rb)[EB], int buf) {
     float* As = As2[buf];
     float* Bs = Bs2[buf];
     if constexpr (AKC) {
@@ -165,6 +174,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const float* A, con
       for (int i = 0; i < EB; ++i) Bs[b_r * LDB + b_c + i] = rb[i];
     }
   };
+
+  auto gload = [&](int tile) { gload_r(ra, rb, tile); };
+  auto sstore = [&](int buf) { sstore_r(ra, rb, buf); };
 
   f16v acc[MT][NTL];
 #pragma unroll
@@ -184,22 +196,79 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const float* A, con
     const int cur = (t - t_begin) & 1;
     const float* As = As2[cur];
     const float* Bs = Bs2[cur];
+#if ZEGGS_GEMM_ABL == 2 || ZEGGS_GEMM_ABL == 3 || ZEGGS_GEMM_ABL == 4 || ZEGGS_GEMM_ABL == 6   // (timing experiment: no global loads / LDS stores after the first tile)
+    if (t + 1 < ntiles && t == t_begin) gload(t + 1);
+#else
     if (t + 1 < ntiles) gload(t + 1);
+#endif
+#if ZEGGS_GEMM_SWP
+    // operand fetch of k-pair kp + 1 in flight under the products of k-pair kp
+    float a[2][MT], b[2][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a[0][i] = As[kh * LDA + wm * TM + i * 32 + l31];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) b[0][j] = Bs[kh * LDB + wn * TN + j * 32 + l31];
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+#if ZEGGS_GEMM_MIDSTORE > 0
+      // the next tile goes to the other LDS buffer in the MIDDLE of this tile's products (its global loads were issued at the
+      // top; the buffer's last readers passed the barrier at the end of the previous tile): the end of a tile is then only
+      // the barrier, not drain + store + barrier -- which all co-resident workgroups reach together (they share the matrix
+      // pipe round-robin and run in lockstep), so nobody covers it
+      if (kp == ZEGGS_GEMM_MIDSTORE && t + 1 < ntiles) { sstore(cur ^ 1); __builtin_amdgcn_sched_barrier(0); }
+#endif
+      if (kp + 1 < BK / 2) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[(kp + 1) & 1][i] = As[(2 * kp + 2 + kh) * LDA + wm * TM + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) b[(kp + 1) & 1][j] = Bs[(2 * kp + 2 + kh) * LDB + wn * TN + j * 32 + l31];
+      }
+      __builtin_amdgcn_sched_barrier(0);      // (left alone, the compiler sinks the fetch back next to its first use)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][i], b[kp & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int kp = 0; kp < BK / 2; ++kp) {
       float a[MT], b[NTL];
+#if ZEGGS_GEMM_ABL == 1 || ZEGGS_GEMM_ABL == 4      // (timing experiment, results wrong: operands fetched once per tile)
+      const int kq = 0;
+#else
+      const int kq = kp;
+#endif
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = As[(2 * kp + kh) * LDA + wm * TM + i * 32 + l31];
+      for (int i = 0; i < MT; ++i) a[i] = As[(2 * kq + kh) * LDA + wm * TM + i * 32 + l31];
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) b[j] = Bs[(2 * kp + kh) * LDB + wn * TN + j * 32 + l31];
+      for (int j = 0; j < NTL; ++j) b[j] = Bs[(2 * kq + kh) * LDB + wn * TN + j * 32 + l31];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTL; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+#endif
+#if ZEGGS_GEMM_ABL == 2 || ZEGGS_GEMM_ABL == 3 || ZEGGS_GEMM_ABL == 4
+    if (t + 1 < ntiles && t == t_begin) { sstore(0); sstore(1); }
+#elif ZEGGS_GEMM_ABL == 5      // loads kept (and waited for), no LDS stores after the first tile
+    if (t + 1 < ntiles) {
+      if (t == t_begin) { sstore(0); sstore(1); }
+#pragma unroll
+      for (int i = 0; i < EA; ++i) asm volatile("" ::"v"(ra[i]));
+#pragma unroll
+      for (int i = 0; i < EB; ++i) asm volatile("" ::"v"(rb[i]));
+    }
+#elif !(ZEGGS_GEMM_SWP && ZEGGS_GEMM_MIDSTORE > 0)
     if (t + 1 < ntiles) sstore(cur ^ 1);
+#endif
+#if ZEGGS_GEMM_ABL == 3 || ZEGGS_GEMM_ABL == 4
+    if (t == t_begin) __syncthreads();
+#else
     __syncthreads();
+#endif
   }
 
   // epilogue: D layout of 32x32x2: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -263,7 +332,7 @@ __global__ __launch_bounds__(WM* WN * 64, ZEGGS_GEMM_MINB) void gemm_kernel(Gemm
 // work).  A range that crosses a tile boundary finishes the first tile's share and starts the next: at most two epilogues,
 // always atomics onto the zeroed C.  g.splitk carries the number of k-tiles per output tile here.
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
-__global__ __launch_bounds__(WM* WN * 64, ZEGGS_GEMM_MINB) void gemm_streamk_kernel(GemmArgs g, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN > 4 ? 2 : ZEGGS_GEMM_MINB)) void gemm_streamk_kernel(GemmArgs g, int tiles_x, int tiles_y) {
   constexpr int LDA = BM + 4, LDB = BN + 4;
   __shared__ __attribute__((aligned(16))) float As2[2][BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs2[2][BK * LDB];
@@ -316,26 +385,169 @@ int launch_cfg(const GemmArgs& g, int nbatch, hipStream_t s) {
   return 0;
 }
 
-int launch_streamk(GemmArgs g, hipStream_t s) {
-  constexpr int BM = 128, BN = 128;
+#ifndef ZEGGS_GEMM_DMA_DEFAULT
+#define ZEGGS_GEMM_DMA_DEFAULT 0
+#endif
+// ---------------------------------------------------------------------------------------------------------------------------
+// Stream-K weight-gradient product (TN: A(m,k) = dy[k][m], B(k,n) = x[k][n], both rows contiguous) with the tiles brought in by
+// LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no staging registers, no ds_write pass) through a ring
+// of THREE LDS buffers, so that two tiles are in flight while one is multiplied.  Measured on the register-staged kernel above
+// (tools/gemm_probe.py, ablation builds): without its global loads the matrix pipe is busy 0.85 instead of 0.75 of the time,
+// without the LDS store pass another 0.04 -- with one tile of prefetch distance and four co-resident workgroups that share the
+// pipe oldest-first, a wave reaches its store pass ~1 us after it issued the loads, sooner than the fabric answers.
+//   * a wave moves rows 4w .. 4w+3 of the [16 x 128] A and B tiles: two instructions per operand (lanes 0-31 one row, 32-63 the
+//     next), the LDS image is the plain [k][128] row-major tile (the operand fetch reads 32 consecutive floats: conflict-free
+//     without padding, which LDS-DMA could not produce anyway -- its destination is base + lane * 16);
+//   * per tile: s_waitcnt vmcnt(4) (this wave's share of tile t has landed, tile t+1's four DMAs stay in flight), ONE raw
+//     s_barrier (everybody's share has; everybody is done reading tile t-1), DMA of tile t+2 into the buffer tile t-1 used,
+//     products of tile t;
+//   * edge tiles: the source column of a lane is clamped into the row (duplicates feed output rows / columns >= M / N, which the
+//     epilogue does not store); K must be a multiple of 16 and the rows 16-byte aligned (launch_gemm checks).
+constexpr int DK = 16;
+__device__ __forceinline__ unsigned lds_off(const float* p) { return (unsigned)(size_t)p; }     // low half of a flat LDS address
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__global__ __launch_bounds__(256, 3) void gemm_tn_dma_kernel(GemmArgs g, int tiles_x, int tiles_y) {
+  constexpr int BM = 128, BN = 128, TS = DK * 128;
+  __shared__ __attribute__((aligned(16))) float As3[3 * TS];
+  __shared__ __attribute__((aligned(16))) float Bs3[3 * TS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+  const int kh = lane >> 5, l31 = lane & 31;
+  const int kt = g.splitk, nkt = g.K / DK;
+  const long total = (long)tiles_x * tiles_y * kt;
+  const unsigned nwg = gridDim.x, w = blockIdx.x, xcd = w & 7, idx = w >> 3, q = nwg >> 3, r = nwg & 7;
+  const unsigned wl = xcd * q + (xcd < r ? xcd : r) + idx;
+  long it = total * wl / nwg;
+  const long it_end = total * (wl + 1) / nwg;
+  const int mmax = (g.M - 1) & ~3, nmax = (g.N - 1) & ~3;
+  const unsigned la0 = lds_off(As3 + 4 * wave * 128), lb0 = lds_off(Bs3 + 4 * wave * 128);
+  while (it < it_end) {
+    const int tile = (int)(it / kt), t_begin = (int)(it % kt);
+    const long left = it_end - it;
+    const int ntiles = (long)(kt - t_begin) < left ? kt : t_begin + (int)left;
+    constexpr int GM = 4;
+    const int width = GM * tiles_x, group = tile / width, first = group * GM, gsz = tiles_y - first < GM ? tiles_y - first : GM;
+    const int m_base = (first + (tile % width) % gsz) * BM, n_base = ((tile % width) / gsz) * BN;
+    int mcol = m_base + 4 * l31, ncol = n_base + 4 * l31;
+    mcol = mcol < mmax ? mcol : mmax;
+    ncol = ncol < nmax ? ncol : nmax;
+    const float* Al = g.A + (long)(4 * wave + kh) * g.sak + mcol;
+    const float* Bl = g.B + (long)(4 * wave + kh) * g.sbk + ncol;
+    auto issue = [&](int t, int buf) {
+      const int kb = t / nkt, k_base = (t - kb * nkt) * DK;
+      const float* ap = Al + (long)kb * g.kbsA + (long)k_base * g.sak;
+      const float* bp = Bl + (long)kb * g.kbsB + (long)k_base * g.sbk;
+      const unsigned la = la0 + buf * (TS * 4), lb = lb0 + buf * (TS * 4);
+      glds16(ap, la);
+      glds16(ap + 2 * g.sak, la + 2 * 128 * 4);
+      glds16(bp, lb);
+      glds16(bp + 2 * g.sbk, lb + 2 * 128 * 4);
+    };
+    f16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    issue(t_begin, 0);
+    if (t_begin + 1 < ntiles) issue(t_begin + 1, 1);
+    int buf = 0;
+    for (int t = t_begin; t < ntiles; ++t) {
+      if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t + 2 < ntiles) issue(t + 2, buf >= 1 ? buf - 1 : 2);       // (buf + 2) % 3: the buffer tile t - 1 was read from
+      const float* As = As3 + buf * TS;
+      const float* Bs = Bs3 + buf * TS;
+#pragma unroll
+      for (int kp = 0; kp < DK / 2; ++kp) {
+        float a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = As[(2 * kp + kh) * 128 + wm * 64 + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = Bs[(2 * kp + kh) * 128 + wn * 64 + j * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+    // partial sums -> fp32 atomics onto C (D layout of 32x32x2: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5))
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n_base + wn * 64 + j * 32 + l31;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m_base + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+          if (m < g.M) atomicAdd(g.C + (long)m * g.scm + n, g.alpha * acc[i][j][e]);
+        }
+      }
+    __syncthreads();                                           // the LDS ring starts over
+    it += ntiles - t_begin;
+  }
+}
+
+int g_gemm_dma = ZEGGS_GEMM_DMA_DEFAULT;      // zeggs_set_option("gemm_dma", 0/1)
+bool dma_ok(const GemmArgs& g) {
+  auto a16 = [](const void* p) { return ((size_t)p & 15) == 0; };
+  return g_gemm_dma && g.sam == 1 && g.sbn == 1 && g.scn == 1 && g.K % DK == 0 && g.sak % 4 == 0 && g.sbk % 4 == 0 &&
+         g.kbsA % 4 == 0 && g.kbsB % 4 == 0 && a16(g.A) && a16(g.B) && g.M >= 4 && g.N >= 4 &&
+         (g.M % 4 == 0 || g.sak >= ((g.M + 3) & ~3)) && (g.N % 4 == 0 || g.sbk >= ((g.N + 3) & ~3));
+}
+int launch_tn_dma(GemmArgs g, hipStream_t s) {
+  const int tx = cdiv(g.N, 128), ty = cdiv(g.M, 128);
+  const int kt = (g.K / DK) * g.kbatch;
+  g.splitk = kt;
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  long nwg = (long)ncu * 3;
+  const long total = (long)tx * ty * kt;
+  if (nwg > total / 8) nwg = total / 8 > 0 ? total / 8 : 1;
+  hipLaunchKernelGGL(gemm_tn_dma_kernel, dim3((unsigned)nwg), dim3(256), 0, s, g, tx, ty);
+  ZLAUNCH_CHECK("gemm_tn_dma");
+  return 0;
+}
+
+#ifndef ZEGGS_GEMM_SK256
+#define ZEGGS_GEMM_SK256 0
+#endif
+template <int BM, int BN, int WM, int WN>
+int launch_streamk_cfg(GemmArgs g, hipStream_t s) {
   const int tx = cdiv(g.N, BN), ty = cdiv(g.M, BM);
   const int kt = cdiv(g.K, BK) * g.kbatch;
   g.splitk = kt;
   int dev = 0, ncu = 256;
-  if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  long nwg = (long)ncu * (g_gemm_streamk_wgs > 0 ? g_gemm_streamk_wgs : ZEGGS_GEMM_MINB);
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  constexpr int resident = WM * WN > 4 ? 2 : ZEGGS_GEMM_MINB;
+  long nwg = (long)ncu * (g_gemm_streamk_wgs > 0 ? g_gemm_streamk_wgs : resident);
   const long total = (long)tx * ty * kt;
   if (nwg > total / 8) nwg = total / 8 > 0 ? total / 8 : 1;     // at least 8 k-tiles per workgroup
-  dim3 grid((unsigned)nwg), block(256);
+  dim3 grid((unsigned)nwg), block(WM * WN * 64);
   const bool akc = (g.sak == 1), bkc = (g.sbk == 1) && (g.sbn != 1 || g.N == 1);
   if (!akc && g.sam != 1) { zeggs_set_error("gemm: A has no unit stride (sam=%ld sak=%ld)", g.sam, g.sak); return -1; }
   if (!bkc && g.sbn != 1) { zeggs_set_error("gemm: B has no unit stride (sbk=%ld sbn=%ld)", g.sbk, g.sbn); return -1; }
-  if (akc && bkc) hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, 2, 2, true, true>), grid, block, 0, s, g, tx, ty);
-  else if (akc && !bkc) hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, 2, 2, true, false>), grid, block, 0, s, g, tx, ty);
-  else if (!akc && bkc) hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, 2, 2, false, true>), grid, block, 0, s, g, tx, ty);
-  else hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, 2, 2, false, false>), grid, block, 0, s, g, tx, ty);
+  if (akc && bkc) hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, g, tx, ty);
+  else if (akc && !bkc) hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, g, tx, ty);
+  else if (!akc && bkc) hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, g, tx, ty);
+  else hipLaunchKernelGGL((gemm_streamk_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, g, tx, ty);
   ZLAUNCH_CHECK("gemm_streamk");
   return 0;
+}
+int launch_streamk(GemmArgs g, hipStream_t s) {
+  if (dma_ok(g)) return launch_tn_dma(g, s);
+#if ZEGGS_GEMM_SK256
+  if (g.M >= 512) return launch_streamk_cfg<256, 128, 4, 2>(g, s);
+#endif
+  return launch_streamk_cfg<128, 128, 2, 2>(g, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -463,6 +675,7 @@ SkinnyArgs skinny_args(const GemmArgs& g) {
 
 }  // namespace
 
+void zeggs_gemm_set_dma(int on) { g_gemm_dma = on; }
 int g_gemm_skinny = 1;          // zeggs_set_option("gemm_skinny", 0/1): batch-sized NT products in one launch
 int g_gemm_streamk = 1;        // zeggs_set_option("gemm_streamk", 0/1): stream-K instead of the many-workgroup split-K
 int g_gemm_mid_split = 1;      // zeggs_set_option("gemm_mid_split", 0/1): split K of the latency-bound narrow-output products
