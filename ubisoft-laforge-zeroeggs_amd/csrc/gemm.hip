@@ -518,7 +518,7 @@ int launch_tn_dma(GemmArgs g, hipStream_t s) {
 }
 
 #ifndef ZEGGS_GEMM_SK256
-#define ZEGGS_GEMM_SK256 0
+#define ZEGGS_GEMM_SK256 2      // 2: by output size (default)
 #endif
 template <int BM, int BN, int WM, int WN>
 int launch_streamk_cfg(GemmArgs g, hipStream_t s) {
@@ -544,8 +544,13 @@ int launch_streamk_cfg(GemmArgs g, hipStream_t s) {
 }
 int launch_streamk(GemmArgs g, hipStream_t s) {
   if (dma_ok(g)) return launch_tn_dma(g, s);
-#if ZEGGS_GEMM_SK256
+  // 256 x 128 tiles (8 waves, 2 workgroups per CU: 3/4 of the operand bytes per product) pay on the big outputs only: +5 .. +8 %
+  // on dW_ih0 (432 tiles of 128 x 128), -4 .. -6 % at 72 .. 200 tiles where the coarser grain costs balance
+  // (profiles/r03_gemm_ablation.txt); -DZEGGS_GEMM_SK256=0 / 1 forces never / from 512 rows on
+#if ZEGGS_GEMM_SK256 == 1
   if (g.M >= 512) return launch_streamk_cfg<256, 128, 4, 2>(g, s);
+#elif ZEGGS_GEMM_SK256 != 0
+  if ((long)cdiv(g.M, 128) * cdiv(g.N, 128) >= 384 && g.M >= 512) return launch_streamk_cfg<256, 128, 4, 2>(g, s);
 #endif
   return launch_streamk_cfg<128, 128, 2, 2>(g, s);
 }
