@@ -62,7 +62,23 @@ typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ float d_elu(float x) { return x > 0.f ? x : expm1f(x); }
 // derivative of ELU expressed with the OUTPUT y: y>0 -> 1, else y+1 (= e^x)
 __device__ __forceinline__ float d_elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
+// GRU gates on the hardware transcendentals (v_exp_f32 = 2^x and v_rcp_f32, 1 ulp each): ~7 instructions per gate instead of the
+// ~35 of expf + IEEE division / ~45 of tanhf -- they sit in the epilogue of every hand-off of the persistent rollouts.  Absolute
+// error <= 2e-7 (sigmoid) / 4e-7 (tanh), the rounding level of the fp32 sums they are applied to.  -DZEGGS_EXACT_GATES=1: library calls.
+#ifndef ZEGGS_EXACT_GATES
+#define ZEGGS_EXACT_GATES 0
+#endif
+#if ZEGGS_EXACT_GATES
 __device__ __forceinline__ float d_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float d_tanh(float x) { return tanhf(x); }
+#else
+__device__ __forceinline__ float d_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float d_tanh(float x) {
+  return 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.f;
+}
+#endif
 
 enum { ACT_NONE = 0, ACT_ELU = 1, ACT_RELU = 2 };
 __device__ __forceinline__ float d_act(float x, int act) {

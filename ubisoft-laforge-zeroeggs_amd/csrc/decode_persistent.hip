@@ -218,7 +218,7 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
       const float r = d_sigmoid(part[2 * tq][0] + part[2 * tq + 1][0] + k_[0] + k_[3]);
       const float z = d_sigmoid(part[2 * tq][1] + part[2 * tq + 1][1] + k_[1] + k_[4]);
       const float nh = part[2 * tq][3] + part[2 * tq + 1][3] + k_[5];
-      const float nn = tanhf(part[2 * tq][2] + part[2 * tq + 1][2] + k_[2] + r * nh);
+      const float nn = d_tanh(part[2 * tq][2] + part[2 * tq + 1][2] + k_[2] + r * nh);
       publish(a.g_h0 + Uu, (unsigned)t, (1.f - z) * nn + z * h0s[Uu]);
     }
     __syncthreads();      // the old h0 has been read everywhere before the sweep overwrites it
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
       const float r = d_sigmoid(part[2 * tq][0] + part[2 * tq + 1][0] + k_[6] + k_[9]);
       const float z = d_sigmoid(part[2 * tq][1] + part[2 * tq + 1][1] + k_[7] + k_[10]);
       const float nh = part[2 * tq][3] + part[2 * tq + 1][3] + k_[11];
-      const float nn = tanhf(part[2 * tq][2] + part[2 * tq + 1][2] + k_[8] + r * nh);
+      const float nn = d_tanh(part[2 * tq][2] + part[2 * tq + 1][2] + k_[8] + r * nh);
       publish(a.g_h1 + Uu, (unsigned)t, (1.f - z) * nn + z * h1s[Uu]);
     }
     __syncthreads();

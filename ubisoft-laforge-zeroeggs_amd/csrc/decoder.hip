@@ -142,7 +142,7 @@ __global__ void gru_gate_fwd_k(const float* gi, const float* gh, const float* hp
     float r = d_sigmoid(gib[u] + ghb[u]);
     float z = d_sigmoid(gib[H + u] + ghb[H + u]);
     float nh = ghb[2 * H + u];
-    float nn = tanhf(gib[2 * H + u] + r * nh);
+    float nn = d_tanh(gib[2 * H + u] + r * nh);
     float hp = hprev[i];
     hout[i] = (1.f - z) * nn + z * hp;
     if (GT) GT[i] = f4{r, z, nn, nh};

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageA
         const float r = d_sigmoid(FV(0, u, b) + pre[0] + (FV(1, u, b) + pre[1]));
         const float z = d_sigmoid(FV(0, 5 + u, b) + pre[2] + (FV(1, 5 + u, b) + pre[3]));
         const float nh = FV(1, 10 + u, b) + pre[5];
-        const float nn = tanhf(FV(0, 10 + u, b) + pre[4] + r * nh);
+        const float nn = d_tanh(FV(0, 10 + u, b) + pre[4] + r * nh);
         const long i = (long)b * H + U;
         const float h = (1.f - z) * nn + z * pre[6];
         st_out<CH>(&G.o0[i], h);

@@ -26,7 +26,7 @@ __global__ void sg_gate_fwd_k(const float* gi, const float* gh, const float* hpr
     float r = d_sigmoid(gib[u] + ghb[u]);
     float z = d_sigmoid(gib[H + u] + ghb[H + u]);
     float nh = ghb[2 * H + u];
-    float nn = tanhf(gib[2 * H + u] + r * nh);
+    float nn = d_tanh(gib[2 * H + u] + r * nh);
     hout[i] = (1.f - z) * nn + z * hprev[i];
     R[i] = r; Z[i] = z; N[i] = nn; NH[i] = nh;
   }

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       const float r = d_sigmoid(fv0[0] + k_[0] + xr + k_[3]);
       const float z = d_sigmoid(fv0[1] + k_[1] + xz + k_[4]);
       const float nh = fv0[3] + k_[5];
-      const float nn = tanhf(fv0[2] + k_[2] + xn + r * nh);
+      const float nn = d_tanh(fv0[2] + k_[2] + xn + r * nh);
       const float h = (1.f - z) * nn + z * hp0;
       hp0 = h;
       const long i = (long)t * sH + (long)eb * H + EU;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       const float r = d_sigmoid(fv1[0] + k_[6] + k_[9]);
       const float z = d_sigmoid(fv1[1] + k_[7] + k_[10]);
       const float nh = fv1[3] + k_[11];
-      const float nn = tanhf(fv1[2] + k_[8] + r * nh);
+      const float nn = d_tanh(fv1[2] + k_[8] + r * nh);
       const float h = (1.f - z) * nn + z * hp1;
       hp1 = h;
       const long i = (long)t * sH + (long)eb * H + EU;
