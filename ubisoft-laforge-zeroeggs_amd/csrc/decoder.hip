@@ -63,6 +63,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
   // bound of every device-side wait of the persistent kernels (polls); 0 makes the first unsatisfied wait give up: the
   // tests use it to drive the give-up path (tests/test_gpu_giveup.py)
+  if (strcmp(name, "poll_sleep") == 0) { g_poll_sleep = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "persistent_spin") == 0) { g_persistent_spin = value < 0 ? 0 : value; return 0; }
   zeggs_set_error("unknown option %s", name);
   return -1;

@@ -71,6 +71,7 @@ struct BArgs {
   unsigned *cnt, *err;
   unsigned* status;                          // caller-owned sticky give-up flags (ZeggsDecCall.status), may be null
   unsigned spin;                             // bound of every wait (option "persistent_spin")
+  unsigned nap;                              // s_sleep units between two polls (option "poll_sleep")
 };
 
 __device__ __forceinline__ void stp(float* p, float v) {       // published: write-through
@@ -90,7 +91,7 @@ __host__ __device__ inline long op_idx(int b, int k) {
   return ((((long)(k >> 4) * 2 + ((k >> 2) & 1)) * 64 + ((((k >> 3) & 1) << 5) | b)) << 2) | (k & 3);
 }
 
-__device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect, unsigned limit) {
+__device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect, unsigned limit, unsigned nap = 0) {
   const int lane = threadIdx.x & 63;
   const gu64t* q = (const gu64t*)(slots + 4 * lane);
   for (unsigned spins = 0;; ++spins) {
@@ -99,6 +100,7 @@ __device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect, 
     const bool ok = (unsigned)a >= expect && (unsigned)(a >> 32) >= expect && (unsigned)b >= expect && (unsigned)(b >> 32) >= expect;
     if (__all(ok)) return true;
     if (spins >= limit) return false;
+    for (unsigned i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
 #ifdef ZEGGS_BPSTAT
       const unsigned long long w0 = wall_clock64();
 #endif
-      if (wave == 1 && !bp_wait(a.cnt, (unsigned)(p + 1), a.spin)) fail = 1;     // (wave 0 of workgroup 0 prepares the root frame meanwhile)
+      if (wave == 1 && !bp_wait(a.cnt, (unsigned)(p + 1), a.spin, a.nap)) fail = 1;     // (wave 0 of workgroup 0 prepares the root frame meanwhile)
 #ifdef ZEGGS_BPSTAT
       wsum[(p + 1) & 3] += wall_clock64() - w0;
 #endif
@@ -863,7 +865,7 @@ int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
     a.pose = pose + o * T * d.PO; a.rpos = rpos + o * T * 3; a.rrot = rrot + o * T * 4;
     a.carry = w.carry + o * 8;
     a.cnt = w.bp_cnt; a.err = w.bp_cnt + 1024;
-    a.status = status; a.spin = (unsigned)g_persistent_spin;
+    a.status = status; a.spin = (unsigned)g_persistent_spin; a.nap = (unsigned)g_poll_sleep;
     hipLaunchKernelGGL(train_bwd_persistent_k, dim3(BNCU), dim3(BTHR), 0, s, a);
     ZLAUNCH_CHECK("train_bwd_persistent");
   }

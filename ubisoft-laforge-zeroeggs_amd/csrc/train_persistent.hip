@@ -34,7 +34,7 @@ constexpr int TH = 1024, TTHR = 512, TNCU = 256;
 // k-blocks of a wave per phase: first the OLD part of the operand (known one phase earlier: previous hidden state,
 // speech / style columns), then the FRESH part (produced by the preceding phase).  Block j of a part is k-block
 // lo + wave + 8 j: the parts are interleaved over the 8 waves so that every wave owns old work to do before the hand-off.
-constexpr int TNO0 = 17, TNF0 = 9, TNO1 = 8, TNF1 = 8, TNO3 = 1, TNF3 = 8;
+constexpr int TNO0 = 17, TNF0 = 8, TNO1 = 8, TNF1 = 8, TNO3 = 1, TNF3 = 8;
 constexpr int TJ0 = TNO0 + TNF0, TJ1 = TNO1 + TNF1, TJ3 = TNO3 + TNF3;
 // GRU layer 0 operand of a step, in k-blocks: [hid_t (64) | gaze direction of x_t (1) | speech / style of x_t (TKC, zero
 // padded) | h0_{t-1} (64) | h1_{t-1} (64)].  The POSE columns of x_t are not an operand: between the output stage of step t-1
@@ -45,6 +45,11 @@ constexpr int TJ0 = TNO0 + TNF0, TJ1 = TNO1 + TNF1, TJ3 = TNO3 + TNF3;
 // Only k-blocks [0, TFR0) are fresh; the old ones are ordered [cond | h0 | h1]: h0_{t-1} is two hand-offs old when the previous
 // output stage waits, h1_{t-1} one.
 constexpr int TKC = 8, TFR0 = 65, TKH0 = TFR0 + TKC, TKH1 = TKH0 + 64, TKB0 = TKH1 + 64;      // 65, 73, 137, 201
+// ... of which only the 64 blocks of hid_t are walked: the gaze block would give ONE wave a ninth fresh block (every workgroup
+// waits for it: +1/8 on the matrix-core time of the phase's critical part) for three columns -- the gate threads add them instead
+// (9 FMAs each; every workgroup has the normalised gaze direction in LDS anyway, from its own root integration).  The block keeps
+// its place in the operand layout (unread).
+constexpr int TFRW = 64;
 // old blocks of GRU layer 0 done one window early (cond + h0_{t-1}: in front of the previous output stage) / of GRU layer 1 done
 // in layer 0's window (batch <= 32; the wider variants have no registers to spare for a second live accumulator)
 constexpr int ts0(int nb) { return nb <= 2 ? 9 : 0; }
@@ -66,12 +71,14 @@ struct TArgs {
   float *G0, *G1, *G3;                       // operand fragments, time-major [T][KB*][NB][64][4]
   float *Gin, *H0, *H1, *GT0, *GT1;          // canonical saves (time-major)
   const float *b_ih0, *b_hh0, *b_ih1, *b_hh1, *cvec, *l0_w, *l2_b;
+  const float* w_ih0;                        // [3H][H + XD]: its three gaze columns (H + PO ..) are applied by the gate threads
   const float *cv0, *p1x;                    // folded pose term of GRU layer 0: constant [3H], step-1 product [B][3H]
   const float* gaze;
   float *pose, *rpos, *rrot;
   unsigned *cnt, *err;
   unsigned* status;                          // caller-owned sticky give-up flags (ZeggsDecCall.status), may be null
   unsigned spin;                             // bound of every wait (option "persistent_spin")
+  unsigned nap;                              // s_sleep units between two polls (option "poll_sleep")
 };
 
 __device__ __forceinline__ void stp(float* p, float v) {       // published: write-through
@@ -92,15 +99,19 @@ __device__ __forceinline__ long xfi(int b, int k, int NB) {   // B-fragment posi
 // waits until every slot has reached p + 1.  Epochs are monotonic and a workgroup can run at most one phase ahead of the
 // slowest one, so one 1 KB array serves every phase.  Returns false on give-up.
 typedef __attribute__((address_space(1))) unsigned long long gu64t;
-__device__ __forceinline__ bool tp_wait(const unsigned* slots, unsigned expect, unsigned limit) {
+// `mine` (per lane): this lane's four slots = the four workgroups that produce k-block `lane` of every exchanged vector (workgroup c
+// owns hidden units 4c .. 4c+3 = a quarter of block c / 4) matter to the calling wave; a wave waits for the producers of ITS
+// k-blocks only (wave + 8 j: the lanes with lane % 8 == wave), the eight waves of a workgroup together for everybody.
+__device__ __forceinline__ bool tp_wait(const unsigned* slots, unsigned expect, unsigned limit, bool mine = true, unsigned nap = 0) {
   const int lane = threadIdx.x & 63;
   const gu64t* q = (const gu64t*)(slots + 4 * lane);
   for (unsigned spins = 0;; ++spins) {
     const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool ok = (unsigned)a >= expect && (unsigned)(a >> 32) >= expect && (unsigned)b >= expect && (unsigned)(b >> 32) >= expect;
+    const bool ok = !mine || ((unsigned)a >= expect && (unsigned)(a >> 32) >= expect && (unsigned)b >= expect && (unsigned)(b >> 32) >= expect);
     if (__all(ok)) return true;
     if (spins >= limit) return false;
+    for (unsigned i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -172,6 +183,16 @@ __device__ __forceinline__ void tp_mma(const f4 (&wr)[NJT], const f4* wl, const 
 #define TPT(i)
 #endif
 
+#ifndef ZEGGS_TP_WAVEWAIT
+#define ZEGGS_TP_WAVEWAIT 0      // (measured: every wave polling for its own producers = 8x the polls: 22.5 -> 24.1 us per step)
+#endif
+#if ZEGGS_TP_WAVEWAIT
+#define TP_FAIL_AT_WAIT
+#define TP_FAIL_AT_REDUCE if (fail) break
+#else
+#define TP_FAIL_AT_WAIT if (fail) break
+#define TP_FAIL_AT_REDUCE
+#endif
 template <int NB>
 __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   constexpr int BP = 16 * NB;
@@ -186,6 +207,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   __shared__ f4 ex[BP];                       // epilogue exchange: the 4 units of a batch row -> one 16-byte store
   __shared__ float cG[6];                     // gaze columns of x: in_mean[PO..PO+2], 1 / in_std[PO..PO+2]
   __shared__ float cV[4][3];                  // constant of the folded pose columns of GRU layer 0 (r, z, n), steps t > 1
+  __shared__ float cW[4][3][3];               // W_ih0[gate rows of the 4 units][gaze columns]
   __shared__ float cB[16][8];                 // output-stage row constants
   __shared__ int fail;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = blockIdx.x;
@@ -214,6 +236,8 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       cA[tid][g] = a.b_ih0[g * H + U]; cA[tid][3 + g] = a.b_hh0[g * H + U];
       cA[tid][6 + g] = a.b_ih1[g * H + U]; cA[tid][9 + g] = a.b_hh1[g * H + U];
       cV[tid][g] = a.cv0[g * H + U];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) cW[tid][g][q] = a.w_ih0[(long)(g * H + U) * (H + a.XD) + H + PO + q];
     }
     cB[tid][0] = a.cvec[U];
 #pragma unroll
@@ -228,6 +252,10 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   }
   if (tid >= 32 && tid < 38) cG[tid - 32] = tid < 35 ? a.st.in_mean[PO + tid - 32] : 1.f / a.st.in_std[PO + tid - 35];
   if (tid == 0) fail = 0;
+  if (tid >= 64 && tid < 64 + 3 * BP) {          // normalised gaze direction of x_1 (canonical row of step 1); later steps: root integration
+    const int i = tid - 64, b = i / 3;
+    gsh[i] = b < B ? a.Gin[sG + (long)b * GL + H + PO + i % 3] : 0.f;
+  }
   // GRU epilogue item of this thread: unit eu, batch row eb; the previous hidden values stay in registers for the rollout
   // (re-derived from an opaque copy of the thread index at the top of every step: the per-thread addresses they feed are not
   //  worth a register pair each for the whole rollout)
@@ -292,12 +320,20 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
 #ifdef ZEGGS_TPSTAT
       const unsigned long long w0 = wall_clock64();
 #endif
-      if (wave == 0 && !tp_wait(a.cnt, (unsigned)(p + 1), a.spin)) fail = 1;
+#if ZEGGS_TP_WAVEWAIT
+      // every wave for the producers of its own k-blocks: no barrier, no broadcast; a give-up is noticed by everybody behind the
+      // phase's reduction barrier (`fail` is checked there: all waves of a workgroup must meet the same barriers)
+      if (!tp_wait(a.cnt, (unsigned)(p + 1), a.spin, (lane & 7) == wave)) fail = 1;
+#else
+      if (wave == 0 && !tp_wait(a.cnt, (unsigned)(p + 1), a.spin, true, a.nap)) fail = 1;
+#endif
 #ifdef ZEGGS_TPSTAT
       wsum[(p + 1) % 3] += wall_clock64() - w0;
 #endif
     }
+#if !ZEGGS_TP_WAVEWAIT
     __syncthreads();
+#endif
   };
   auto arrive = [&](long p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -343,9 +379,9 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       for (int nb = 0; nb < NB; ++nb) acc2[nb] = f4{0.f, 0.f, 0.f, 0.f};
       if constexpr (TS1 > 0) tp_mma<NB, TJ1, 0, TS1, false>(wr1, nullptr, x1, 64 + wave, 128, acc2);
       wait_phase(p1 - 1);
-      if (fail) break;
+      TP_FAIL_AT_WAIT;
       TPT(1);
-      tp_mma<NB, TJ0 - TL0, TNO0 - TL0, TNF0, false>(wr0, nullptr, x0, wave, TFR0, acc1);  // fresh part
+      tp_mma<NB, TJ0 - TL0, TNO0 - TL0, TNF0, false>(wr0, nullptr, x0, wave, TFRW, acc1);  // fresh part
     } else {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
@@ -354,12 +390,13 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       tp_mma<NB, TJ0 - TL0, 0, TL0, true>(wr0, w0l + wave * TL0 * 64 + lane, x0, TFR0 + wave, a.KB0, acc);
       tp_mma<NB, TJ0 - TL0, 0, TNO0 - TL0, false>(wr0, nullptr, x0, TFR0 + wave + 8 * TL0, a.KB0, acc);
       wait_phase(p1 - 1);
-      if (fail) break;
+      TP_FAIL_AT_WAIT;
       TPT(1);
-      tp_mma<NB, TJ0 - TL0, TNO0 - TL0, TNF0, false>(wr0, nullptr, x0, wave, TFR0, acc);  // fresh part
+      tp_mma<NB, TJ0 - TL0, TNO0 - TL0, TNF0, false>(wr0, nullptr, x0, wave, TFRW, acc);  // fresh part
     }
     TPT(2);
     const f4 fv0 = reduce_gate(*(SPREAD ? &acc1 : &acc));
+    TP_FAIL_AT_REDUCE;
     TPT(3);
     if (gact) {
       const float* k_ = cA[eu];
@@ -367,6 +404,13 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       float xr, xz, xn;
       if (t == 1) { const float* q = a.p1x + (long)eb * 3 * H + EU; xr = q[0]; xz = q[H]; xn = q[2 * H]; }
       else { xr = cV[eu][0]; xz = cV[eu][1]; xn = cV[eu][2]; }
+      {     // gaze columns of x_t
+        const float g0 = gsh[eb * 3], g1 = gsh[eb * 3 + 1], g2 = gsh[eb * 3 + 2];
+        const float (*wq)[3] = cW[eu];
+        xr += wq[0][0] * g0 + wq[0][1] * g1 + wq[0][2] * g2;
+        xz += wq[1][0] * g0 + wq[1][1] * g1 + wq[1][2] * g2;
+        xn += wq[2][0] * g0 + wq[2][1] * g1 + wq[2][2] * g2;
+      }
       const float r = d_sigmoid(fv0[0] + k_[0] + xr + k_[3]);
       const float z = d_sigmoid(fv0[1] + k_[1] + xz + k_[4]);
       const float nh = fv0[3] + k_[5];
@@ -395,7 +439,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       tp_mma<NB, TJ1, TS1, TNO1 - TS1, false>(wr1, nullptr, x1, 64 + wave + 8 * TS1, 128, acc2);   // window: rest of the old part
 #endif
       wait_phase(p2 - 1);
-      if (fail) break;
+      TP_FAIL_AT_WAIT;
       TPT(6);
       tp_mma<NB, TJ1, TNO1, TNF1, false>(wr1, nullptr, x1, wave, 64, acc2);               // h0_t
     } else {
@@ -404,12 +448,13 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       const f4* x1 = (const f4*)(a.G1 + (long)t * 128 * XB) + lane;
       tp_mma<NB, TJ1, 0, TNO1, false>(wr1, nullptr, x1, 64 + wave, 128, acc);             // h1_{t-1}: before the hand-off
       wait_phase(p2 - 1);
-      if (fail) break;
+      TP_FAIL_AT_WAIT;
       TPT(6);
       tp_mma<NB, TJ1, TNO1, TNF1, false>(wr1, nullptr, x1, wave, 64, acc);                // h0_t
     }
     TPT(7);
     const f4 fv1 = reduce_gate(*(SPREAD ? &acc2 : &acc));
+    TP_FAIL_AT_REDUCE;
     TPT(8);
     if (gact) {
       const float* k_ = cA[eu];
@@ -460,12 +505,13 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       }
 #endif
       wait_phase(p3 - 1);
-      if (fail) break;
+      TP_FAIL_AT_WAIT;
       TPT(11);
       tp_mma<NB, TJ0 - TL0, TNO3, TNF3, true>(wr0, wl3, x3, wave, 64, acc);               // h1_t
     }
     TPT(12);
     reduce(acc);
+    TP_FAIL_AT_REDUCE;
     TPT(13);
     {
       float* gnext = a.Gin + (long)(t + 1) * sG;                       // canonical [hid | x] row of step t+1
@@ -594,7 +640,7 @@ __global__ void tp_pack_k(TPackArgs p) {
     const int lane = (int)(r & 63);
     const long cwi = r >> 6;
     const int i = (int)(cwi % J), wave = (int)((cwi / J) & 7), c = (int)(cwi / (8L * J));
-    const int kb = ph == 0 ? tp_kb(i, wave, TNO0, TFR0, p.KB0, TFR0)
+    const int kb = ph == 0 ? tp_kb(i, wave, TNO0, TFR0, p.KB0, TFRW)
                  : ph == 1 ? tp_kb(i, wave, TNO1, 64, 128, 64) : tp_kb(i, wave, TNO3, 64, p.KB3, 64);
     const int row = lane & 15, kk = 16 * kb + 4 * (lane >> 4);
     f4 v = f4{0.f, 0.f, 0.f, 0.f};
@@ -721,9 +767,9 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   a.G0 = w.G0xf; a.G1 = w.G1xf; a.G3 = w.G3xf;
   a.Gin = w.Gin; a.H0 = w.H0; a.H1 = w.H1; a.GT0 = w.GT0; a.GT1 = w.GT1;
   a.b_ih0 = P->b_ih0; a.b_hh0 = P->b_hh0; a.b_ih1 = P->b_ih1; a.b_hh1 = P->b_hh1; a.cvec = w.cvec; a.l0_w = P->l0_w;
-  a.l2_b = P->l2_b; a.cv0 = w.tp_cv0; a.p1x = w.tp_p1x; a.gaze = gaze; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
+  a.l2_b = P->l2_b; a.w_ih0 = P->w_ih0; a.cv0 = w.tp_cv0; a.p1x = w.tp_p1x; a.gaze = gaze; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
   a.cnt = w.tp_cnt; a.err = w.tp_cnt + TRING * TSH * TSTR;
-  a.status = status; a.spin = (unsigned)g_persistent_spin;
+  a.status = status; a.spin = (unsigned)g_persistent_spin; a.nap = (unsigned)g_poll_sleep;
   switch (NB) {
     case 1: hipLaunchKernelGGL((train_fwd_persistent_k<1>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
     case 2: hipLaunchKernelGGL((train_fwd_persistent_k<2>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
