@@ -489,6 +489,8 @@ def main():
                     help="ONE blocking all-reduce after the backward instead of the overlapped decoder-slice exchange")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
                     help="decoder weight-gradient GEMMs on the main stream instead of beside the encoders' backward")
+    ap.add_argument("--no-early-step", action="store_true",
+                    help="the whole optimizer step at the end of the iteration (default: the decoder's slice on the weight-gradient stream)")
     ap.add_argument("--no-prefetch", action="store_true", help="gather every batch at the start of its own step")
     ap.add_argument("--no-extras", action="store_true", help="skip decode / decode_30min / v2_label_b64 (N = 1 only)")
     ap.add_argument("--no-generate", action="store_true", help="skip generate_30min (configs[4] through generate_gesture())")
@@ -551,7 +553,7 @@ def main():
     se, de, st = build_nets(dev)
     eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, world_size=world, rank=rank,
                              force_allreduce=a.force_process_group, overlap_allreduce=not a.no_overlap,
-                             overlap_wgrads=not a.no_wgrad_overlap)
+                             overlap_wgrads=not a.no_wgrad_overlap, early_decoder_step=not a.no_early_step)
     ops.manual_seed(1000 + rank)                            # per-rank noise streams (dropout masks, VAE eps)
     perm = np.random.default_rng(42).permutation(len(ds))   # same permutation on every rank
     gb = BATCH * world
