@@ -1087,3 +1087,39 @@ def test_streaming_with_film_decoder_matches_offline():
     outs = [gs.push(wav[:7000]), gs.push(wav[7000:15000]), gs.push(wav[15000:]), gs.finish()]
     pose = torch.cat([o["pose"] for o in outs if o], dim=0)
     assert pose.shape[0] == n_frames and float((pose - ref[0][0]).abs().max()) < 5e-5
+
+
+def test_cli_train_then_generate_end_to_end(tmp_path):
+    """`python -m zeggs.cli train -o ...` then `generate -o <run>/options.json ...` (the reference's main.py / generate.py command
+    lines) on a tiny synthetic data set: a run directory in the reference's layout, then a BVH + WAV pair from its checkpoints."""
+    import json
+    import scipy.io.wavfile as wavfile
+    from zeggs import anim, cli
+    synth.write_dataset(tmp_path / "data" / "processed_v1", n_train=2, n_valid=1, nframes=40, seed=3)
+    conf = dict(audio_conf=dict(pre_emphasis=False, pre_emph_coeff=0.97, centered=True, real_amplitude=True,
+                                normalize_mel_bins=True, normalize_range=True, min_clipping=1e-5, sampling_rate=16000,
+                                mel_fmin=20, mel_fmax=7600, n_mel_channels=80, filter_length=800, hop_length=200,
+                                resample_method="linear", normalize_loudness=False),
+                audio_feature_type=["mel_spec", "energy"])
+    json.dump(conf, open(tmp_path / "data" / "processed_v1" / "data_pipeline_conf.json", "w"))
+    options = {"paths": {"base_path": str(tmp_path), "path_processed_data": "data/processed_v1", "output_dir": None,
+                         "models_dir": None},
+               "net_opt": {"decoder": {"nhidden": 1024, "num_rnn_layers": 2, "rnn_cond": "normal"},
+                           "speech_encoder": {"nhidden": 64, "speech_encoding_size": 64},
+                           "style_encoder": {"nhidden": 512, "style_encoding_size": 64, "example_length": 16, "type": "attn",
+                                             "use_vae": True}},
+               "train_opt": dict(niterations=0.002, batchsize=4, window=8, change_pace=True, learning_rate=1e-4,
+                                 learning_rate_decay=0.995, eps=1e-5, resume=False, use_gpu=True, thread_count=1, seed=1234,
+                                 use_tensorboard=False, style_encoding_type="example", generate_samples_step=1000, use_script=False)}
+    json.dump(options, open(tmp_path / "options.json", "w"))
+    assert cli.main(["train", "-o", str(tmp_path / "options.json"), "-n", "tiny"]) == 0
+    runs = list((tmp_path / "outputs").iterdir())
+    assert len(runs) == 1 and (runs[0] / "saved_models" / "decoder.pt").exists() and (runs[0] / "logs").is_dir()
+    assert json.load(open(runs[0] / "options.json"))["name"] == "tiny"
+    anim.bvh_save(tmp_path / "ex.bvh", synth.make_bvh_clip(48, seed=5))
+    wavfile.write(tmp_path / "a.wav", 16000, synth.synth_wav(16000, seed=2))
+    assert cli.main(["generate", "-o", str(runs[0] / "options.json"), "-s", str(tmp_path / "ex.bvh"), "-a", str(tmp_path / "a.wav"),
+                     "-n", "clip", "-fp", str(tmp_path / "ex.bvh"), "-t", "0.5", "-r", "3", "-f", "4", "40", "-g"]) == 0
+    out = anim.bvh_load(runs[0] / "results" / "clip.bvh")
+    assert out["rotations"].shape[1:] == (75, 3) and out["rotations"].shape[0] >= 50 and np.isfinite(out["rotations"]).all()
+    assert (runs[0] / "results" / "clip.wav").exists()

@@ -96,6 +96,9 @@ __device__ __forceinline__ void load_full(float (&r)[E], const float* p) {
 #ifndef ZEGGS_GEMM_ABL
 #define ZEGGS_GEMM_ABL 0           // timing experiments (wrong results): 1 no per-k LDS fetch, 2 no loads / stores, 3 = 2 + no barrier, 4 = 1 + 3
 #endif
+#ifndef ZEGGS_GEMM_BUMP
+#define ZEGGS_GEMM_BUMP 0      // carried source addresses: +3 .. 4 % on the GEMM alone, -0.6 % on the training iteration (three alternating A/B pairs)
+#endif
 #ifndef ZEGGS_GEMM_SWIZZLE
 #define ZEGGS_GEMM_SWIZZLE 1
 #endif
@@ -126,7 +129,33 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const float* A, con
 
   // interior blocks take a branch-free path (unguarded vector loads); edge blocks / the K tail use guarded loads
   const bool interior = (m_base + BM <= g.M) && (n_base + BN <= g.N);
+#if ZEGGS_GEMM_BUMP
+  // Tiles are loaded in order (t_begin, t_begin + 1, ...): this thread's source addresses advance by a constant per tile, so they
+  // are carried instead of being rebuilt from the tile index (an integer division and four 64-bit multiply-adds, ~70 scalar
+  // instructions in front of every tile's loads -- all co-resident workgroups reach them together, nobody issues products
+  // meanwhile).  nx_*: state of the NEXT tile to be loaded.
+  int nx_kb = t_begin / nkt, nx_k = (t_begin - nx_kb * nkt) * BK;
+  const float* nx_a = A + (long)nx_kb * g.kbsA + (AKC ? (long)(m_base + a_r) * g.sam + (nx_k + a_c) : (long)(nx_k + a_r) * g.sak + (m_base + a_c));
+  const float* nx_b = B + (long)nx_kb * g.kbsB + (BKC ? (long)(n_base + b_r) * g.sbn + (nx_k + b_c) : (long)(nx_k + b_r) * g.sbk + (n_base + b_c));
+  const long a_step = AKC ? (long)BK : (long)BK * g.sak, b_step = BKC ? (long)BK : (long)BK * g.sbk;
+  const long a_wrap = g.kbsA - (long)nkt * a_step, b_wrap = g.kbsB - (long)nkt * b_step;      // from the last k-tile of a segment to the next segment
+#endif
   auto gload_r = [&](float (&ra)[EA], float (&rb)[EB], int tile) {
+#if ZEGGS_GEMM_BUMP
+    (void)tile;
+    const int k_base = nx_k;
+    const float* pa = nx_a;
+    const float* pb = nx_b;
+    nx_k += BK; nx_a += a_step; nx_b += b_step;
+    if (nx_k >= nkt * BK) { nx_k = 0; nx_a += a_wrap; nx_b += b_wrap; }
+    if (interior && k_base + BK <= g.K) {
+      load_full<EA>(ra, pa);
+      load_full<EB>(rb, pb);
+      return;
+    }
+    const float* Ab = pa - (AKC ? (long)(m_base + a_r) * g.sam + (k_base + a_c) : (long)(k_base + a_r) * g.sak + (m_base + a_c));
+    const float* Bb = pb - (BKC ? (long)(n_base + b_r) * g.sbn + (k_base + b_c) : (long)(k_base + b_r) * g.sbk + (n_base + b_c));
+#else
     const int kb = tile / nkt, k_base = (tile % nkt) * BK;
     const float* Ab = A + (long)kb * g.kbsA;
     const float* Bb = B + (long)kb * g.kbsB;
@@ -137,6 +166,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const float* A, con
       else load_full<EB>(rb, Bb + (long)(k_base + b_r) * g.sbk + (n_base + b_c));
       return;
     }
+#endif
     if constexpr (AKC) {
       int m = m_base + a_r, k = k_base + a_c;
       int nv = (m < g.M) ? (g.K - k) : 0;
