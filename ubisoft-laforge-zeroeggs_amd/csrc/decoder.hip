@@ -27,6 +27,7 @@ extern int g_bwd_persistent;
 extern int g_fused_attention;
 extern int g_gemm_streamk;
 extern int g_gemm_skinny;
+extern int g_tp_tiles4;
 void zeggs_gemm_set_dma(int on);
 extern int g_gemm_mid_split;
 extern int g_gemm_streamk_wgs;
@@ -63,6 +64,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "bwd_chunks") == 0) { g_bwd_chunks = value < 1 ? 1 : value; return 0; }
   // bound of every device-side wait of the persistent kernels (polls); 0 makes the first unsatisfied wait give up: the
   // tests use it to drive the give-up path (tests/test_gpu_giveup.py)
+  if (strcmp(name, "tp_tiles4") == 0) { g_tp_tiles4 = value != 0; return 0; }
   if (strcmp(name, "poll_sleep") == 0) { g_poll_sleep = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "persistent_spin") == 0) { g_persistent_spin = value < 0 ? 0 : value; return 0; }
   zeggs_set_error("unknown option %s", name);

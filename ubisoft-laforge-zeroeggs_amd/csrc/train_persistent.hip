@@ -25,6 +25,7 @@
 #include "kernels.h"
 
 int g_train_persistent = 1;      // zeggs_set_option("train_persistent", 0/1)
+int g_tp_tiles4 = 1;             // zeggs_set_option("tp_tiles4", 0/1): the GRU phases of the training rollout on 4-row tiles (even batch-tile counts)
 static int g_tp_ok = -1;
 
 namespace {
@@ -166,6 +167,76 @@ __device__ __forceinline__ void tp_mma(const f4 (&wr)[NJT], const f4* wl, const 
   }
 }
 
+// ---- 4-row tiles for the two GRU phases (option "tp_tiles4", batch tiles in pairs: 17..32 and 49..64 rows).  A 16-row tile of
+// v_mfma_f32_16x16x4 holds (r, z, n_input, n_hidden) x 4 units, and every k-block multiplies one all-zero n row group (input-side
+// blocks have no hidden-side n weights and vice versa): a quarter of the GRU phases' matrix-core time.  v_mfma_f32_4x4x1 with
+// cbsz = 3 is a [4 rows x 2 k x 32 batch] product per instruction (train_bwd_persistent.hip): three row groups (r, z, n of the 4
+// units) per k-block, 24 x 8 cycles instead of 8 x 32 per 32 batch rows, one VGPR per [4 rows x 16 k] weight tile (3 per block
+// instead of 4).  The n group of a block accumulates into the input- or the hidden-side n sum, by block.
+// Operand position of (batch row, k) for that instruction form: lane 32 * ((k >> 3) & 1) + (b & 31) reads float4 q = (k >> 2) & 1
+// of block k >> 4 (batch tile b >> 5), element k & 3 = abid & 3.  A block is 512 floats per 32 batch rows: the same size as two
+// 16-row tiles of the 16x16x4 layout, so the block offsets of the operand buffers do not change.
+__host__ __device__ inline long xf4(int b, int k, int NT) {
+  return (((((long)(k >> 4) * NT + (b >> 5)) * 2 + ((k >> 2) & 1)) * 64 + ((((k >> 3) & 1) << 5) | (b & 31))) << 2) | (k & 3);
+}
+// block i (position in the wave's list: old part first) of phase ph has hidden-side n rows: layer 0 = [cond | 8 x h0_{t-1} |
+// 8 x h1_{t-1} through the fold (input side: pose columns) | 8 x hid_t], layer 1 = [8 x h1_{t-1} | 8 x h0_t]
+__host__ __device__ constexpr bool tp4_hidden_side(int ph, int i) { return ph == 0 ? (i >= 1 && i <= 8) : (i < TNO1); }
+template <int NT, int NW, int OFF, int NJ, bool WLDS, int PH, int IABS>
+__device__ __forceinline__ void tp_mma4(const float (&wq)[NW], const float* wl, const f4* __restrict__ xb, int kb0, int hi,
+                                        f4 (&acc)[4][NT]) {
+  if constexpr (NJ <= 0) return;
+  constexpr int GU = NT >= 2 ? 1 : 2;
+  constexpr int NG = (NJ + GU - 1) / GU;
+  asm volatile("" : "+s"(kb0));
+  f4 xa[GU][2][NT], xq[GU][2][NT];
+  auto load = [&](f4 (&x)[GU][2][NT], int g) {
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      int kb = kb0 + 8 * (GU * g + u);
+      kb = kb < hi ? kb : hi - 1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) x[u][q][nt] = xb[(((long)kb * NT + nt) * 2 + q) * 64];
+    }
+  };
+  auto comp = [&](const f4 (&x)[GU][2][NT], int g) {
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const int i = GU * g + u;
+      if (i < NJ) {
+        const int nd = tp4_hidden_side(PH, IABS + i) ? 3 : 2;
+        const int wi = 3 * (OFF + i);
+        const float w0 = WLDS ? wl[(wi + 0) * 64] : wq[wi + 0 < NW ? wi + 0 : 0];
+        const float w1 = WLDS ? wl[(wi + 1) * 64] : wq[wi + 1 < NW ? wi + 1 : 0];
+        const float w2 = WLDS ? wl[(wi + 2) * 64] : wq[wi + 2 < NW ? wi + 2 : 0];
+#define TP4_STEP(A)                                                                                    \
+  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                  \
+    const float xv = x[u][(A) >> 2][nt][(A) & 3];                                                      \
+    acc[0][nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0, xv, acc[0][nt], 3, A, 0);                      \
+    acc[1][nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1, xv, acc[1][nt], 3, A, 0);                      \
+    acc[nd][nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(w2, xv, acc[nd][nt], 3, A, 0);                    \
+  }
+        TP4_STEP(0) TP4_STEP(1) TP4_STEP(2) TP4_STEP(3) TP4_STEP(4) TP4_STEP(5) TP4_STEP(6) TP4_STEP(7)
+#undef TP4_STEP
+      }
+    }
+  };
+  load(xa, 0);
+#pragma unroll
+  for (int g = 0; g < NG; g += 2) {
+    if (g + 1 < NG) load(xq, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    comp(xa, g);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 2 < NG) load(xa, g + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < NG) comp(xq, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // -DZEGGS_TPTIME: wall-clock (100 MHz) stamps of the phases of the LAST step, workgroups 0 and 255 (tools/tp_time.py)
 #ifdef ZEGGS_TPTIME
 #define TPT(i)                                                                                              \
@@ -193,9 +264,13 @@ __device__ __forceinline__ void tp_mma(const f4 (&wr)[NJT], const f4* wl, const 
 #define TP_FAIL_AT_WAIT if (fail) break
 #define TP_FAIL_AT_REDUCE
 #endif
-template <int NB>
+template <bool C, typename A, typename B> struct tp_pick { typedef A type; };
+template <typename A, typename B> struct tp_pick<false, A, B> { typedef B type; };
+template <int NB, bool T4 = false>
 __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   constexpr int BP = 16 * NB;
+  constexpr int NT = NB >= 2 ? NB / 2 : 1;     // 32-row batch tiles of the 4-row form (T4: NB is even)
+  typedef typename tp_pick<T4, f4[4][NT], f4[NB]>::type GAcc;      // accumulators of a GRU phase: (r, z, n_in, n_hid) x units, or 16-row tiles
   __shared__ f4 red[8][NB][64];
   __shared__ f4 fin[NB][64];
   __shared__ f4 w3[8 * TJ3 * 64];             // output-stage weights of this workgroup (72 KB)
@@ -216,7 +291,18 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   const long sG = (long)B * GL, sH = (long)B * H, XB = 256L * NB;
   // ---------------------------------------------------------------- weights -> registers / LDS (once per rollout)
   f4 wr0[TJ0 - TL0], wr1[TJ1];
-  {
+  float wq0[3 * (TJ0 - TL0)], wq1[3 * TJ1];      // T4: one register per [4 rows x 16 k] tile, three (r, z, n) per k-block
+  float* const w0lf = (float*)w0l;                // T4: the LDS-parked blocks as floats, [wave][3 TL0][64]
+  if constexpr (T4) {
+    const float* p0 = (const float*)a.PW0 + ((long)(c * 8 + wave) * TJ0) * 3 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 3 * TL0; ++i) w0lf[(wave * 3 * TL0 + i) * 64 + lane] = p0[(long)i * 64];
+#pragma unroll
+    for (int i = 3 * TL0; i < 3 * TJ0; ++i) wq0[i - 3 * TL0] = p0[(long)i * 64];
+    const float* p1 = (const float*)a.PW1 + ((long)(c * 8 + wave) * TJ1) * 3 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 3 * TJ1; ++i) wq1[i] = p1[(long)i * 64];
+  } else {
     const f4* p0 = a.PW0 + ((long)(c * 8 + wave) * TJ0) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < TL0; ++i) w0l[(wave * TL0 + i) * 64 + lane] = p0[(long)i * 64];
@@ -225,6 +311,8 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     const f4* p1 = a.PW1 + ((long)(c * 8 + wave) * TJ1) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < TJ1; ++i) wr1[i] = p1[(long)i * 64];
+  }
+  {
     const f4* p3 = a.PW3 + ((long)(c * 8 + wave) * TJ3) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < TJ3; ++i) w3[(wave * TJ3 + i) * 64 + lane] = p3[(long)i * 64];
@@ -265,7 +353,16 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   bool gact = tid < 4 * BP && eb < B;
   int EU = 4 * c + (eu & 3);
   float hp0 = 0.f, hp1 = 0.f;
-  if (gact) { hp0 = a.H0[(long)eb * H + EU]; hp1 = a.H1[(long)eb * H + EU]; }      // state before the first generated frame
+  if (!T4 && gact) { hp0 = a.H0[(long)eb * H + EU]; hp1 = a.H1[(long)eb * H + EU]; }      // state before the first generated frame
+  // T4: the gate thread of batch row gb carries all four units (lanes 0..31 of wave nt = batch tile nt)
+  int gb = (tid >> 6) * 32 + (tid & 31);
+  bool gact4 = T4 && tid < 64 * NT && gb < B;      // both half-waves: lanes < 32 units 0, 1, lanes >= 32 units 2, 3 of row gb
+  f4 hq0 = f4{0.f, 0.f, 0.f, 0.f}, hq1 = f4{0.f, 0.f, 0.f, 0.f};
+  if (gact4) {      // (elements 0, 1 = this lane's two units)
+    const int u0 = (tid & 32) ? 2 : 0;
+    hq0[0] = a.H0[(long)gb * H + 4 * c + u0]; hq0[1] = a.H0[(long)gb * H + 4 * c + u0 + 1];
+    hq1[0] = a.H1[(long)gb * H + 4 * c + u0]; hq1[1] = a.H1[(long)gb * H + 4 * c + u0 + 1];
+  }
   // root thread of batch row rb (the LAST B threads: the first ones carry the GRU items): the root state of its row stays
   // in registers for the rollout
   int rb = TTHR - 1 - tid;
@@ -312,6 +409,80 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     }
     return sfv;
   };
+  // T4: the accumulators of a wave hold, per gate, the four units of batch row 4 (blk % 8) + j for k-half blk / 8 (lane = 4 blk + j):
+  // add the two k-halves (lanes l, l + 32), lanes < 32 park [gate][batch row] float4s (the four units) in LDS (the storage of
+  // `red`), 64 threads per batch tile add up two gates each over the eight waves, the upper half hands its pair down: lanes < 32
+  // of wave nt end up with (r, z, n_in, n_hid) x 4 units of batch row 32 nt + lane -- the gate thread, no further exchange
+  f4 (*red4)[4][NT][32] = (f4 (*)[4][NT][32])red;
+  auto swap_down = [&](f4 v) -> f4 {          // lanes < 32 receive lane + 32's value
+    f4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned x = __float_as_uint(v[e]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+      o[e] = __uint_as_float(sw[1]);
+    }
+    return o;
+  };
+  auto swap_halves = [&](f4 v) -> f4 {        // every lane receives the value of lane ^ 32
+    f4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned x = __float_as_uint(v[e]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+      o[e] = __uint_as_float(lane < 32 ? sw[1] : sw[0]);
+    }
+    return o;
+  };
+  auto reduce_gate4 = [&](f4 (&acc)[4][NT], f4 (&out)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f4 v = acc[g][nt] + swap_down(acc[g][nt]);
+        if (lane < 32) red4[wave][g][nt][lane] = v;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) out[g] = f4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 64 * NT) {
+      const int nt = tid >> 6, h2 = (tid >> 5) & 1, b = tid & 31;
+      f4 s0 = red4[0][2 * h2][nt][b], s1 = red4[0][2 * h2 + 1][nt][b];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) { s0 += red4[w][2 * h2][nt][b]; s1 += red4[w][2 * h2 + 1][nt][b]; }
+      // both halves end up with all four gates: the lower lanes do units 0, 1 of the batch row, the upper ones units 2, 3
+      const f4 t0 = swap_halves(s0), t1 = swap_halves(s1);
+      out[0] = h2 ? t0 : s0; out[1] = h2 ? t1 : s1; out[2] = h2 ? s0 : t0; out[3] = h2 ? s1 : t1;
+    }
+  };
+  auto zero_g = [&](GAcc& g) {
+    if constexpr (T4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) g[q][nt] = f4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) g[nb] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // products of the two GRU phases in either tile form.  I0 = position of the first block in the wave's list (old part first);
+  // layer 0's first TL0 blocks live in LDS (LDS0 forms)
+#define TP_MMA0(I0, NJ, X, KB0, HI, ACC)                                                                            \
+  do {                                                                                                              \
+    if constexpr (T4) tp_mma4<NT, 3 * (TJ0 - TL0), (I0) - TL0, NJ, false, 0, I0>(wq0, nullptr, X, KB0, HI, ACC);    \
+    else tp_mma<NB, TJ0 - TL0, (I0) - TL0, NJ, false>(wr0, nullptr, X, KB0, HI, ACC);                              \
+  } while (0)
+#define TP_MMA0_LDS(NJ, X, KB0, HI, ACC)                                                                            \
+  do {                                                                                                              \
+    if constexpr (T4) tp_mma4<NT, 3 * (TJ0 - TL0), 0, NJ, true, 0, 0>(wq0, w0lf + wave * 3 * TL0 * 64 + lane, X, KB0, HI, ACC); \
+    else tp_mma<NB, TJ0 - TL0, 0, NJ, true>(wr0, w0l + wave * TL0 * 64 + lane, X, KB0, HI, ACC);                   \
+  } while (0)
+#define TP_MMA1(I0, NJ, X, KB0, HI, ACC)                                                                            \
+  do {                                                                                                              \
+    if constexpr (T4) tp_mma4<NT, 3 * TJ1, I0, NJ, false, 1, I0>(wq1, nullptr, X, KB0, HI, ACC);                    \
+    else tp_mma<NB, TJ1, I0, NJ, false>(wr1, nullptr, X, KB0, HI, ACC);                                            \
+  } while (0)
 #ifdef ZEGGS_TPSTAT
   unsigned long long wsum[3] = {0, 0, 0};      // 100 MHz ticks this workgroup spent polling, per phase kind
 #endif
@@ -341,13 +512,12 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     if (tid == 0) __hip_atomic_store((gu32*)(a.cnt + c), (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
-  f4 acc1[NB], acc2[NB];        // accumulators of GRU layer 0 / 1: started in the windows of earlier phases
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc1[nb] = f4{0.f, 0.f, 0.f, 0.f};
+  GAcc acc1, acc2;              // accumulators of GRU layer 0 / 1: started in the windows of earlier phases
+  zero_g(acc1);
   if constexpr (SPREAD) {     // step 1 has no previous output stage to hide these behind
     const f4* x01 = (const f4*)(a.G0 + (long)a.KB0 * XB) + lane;
-    tp_mma<NB, TJ0 - TL0, 0, TL0, true>(wr0, w0l + wave * TL0 * 64 + lane, x01, TFR0 + wave, a.KB0, acc1);
-    tp_mma<NB, TJ0 - TL0, 0, TS0 - TL0, false>(wr0, nullptr, x01, TFR0 + wave + 8 * TL0, a.KB0, acc1);
+    TP_MMA0_LDS(TL0, x01, TFR0 + wave, a.KB0, acc1);
+    TP_MMA0(TL0, TS0 - TL0, x01, TFR0 + wave + 8 * TL0, a.KB0, acc1);
   }
   for (int t = 1; t < T; ++t) {
     {
@@ -359,10 +529,13 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       rb = TTHR - 1 - tx;
       ract = rb < B;
       tb = tx;
+      gb = (tx >> 6) * 32 + (tx & 31);
+      gact4 = T4 && tx < 64 * NT && gb < B;
     }
     const bool next = t + 1 < T;
     const long p1 = 3L * (t - 1), p2 = p1 + 1, p3 = p1 + 2;
     f4 acc[NB];
+    GAcc accg;                  // (non-SPREAD variants: the GRU phases' accumulator)
     // ================================================================ GRU layer 0 : [hid_t | x_t | h0_{t-1}]
     // The old parts of the three phases (18 blocks per wave) are spread over the three hand-off windows, ~6 blocks each: a
     // hand-off (store drain, flag, poll) takes about as long as 7 blocks of products.
@@ -373,31 +546,68 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       // window: the rest of this phase's old part, h1_{t-1} through the fold (cond and h0_{t-1} ran in the window of the previous
       // output stage)
 #ifndef ZEGGS_TP_NOWIN      // (timing experiment: the hand-off latency with empty windows; results are wrong)
-      tp_mma<NB, TJ0 - TL0, TS0 - TL0, TNO0 - TS0, false>(wr0, nullptr, x0, TFR0 + wave + 8 * TS0, a.KB0, acc1);
+      TP_MMA0(TS0, TNO0 - TS0, x0, TFR0 + wave + 8 * TS0, a.KB0, acc1);
 #endif
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc2[nb] = f4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (TS1 > 0) tp_mma<NB, TJ1, 0, TS1, false>(wr1, nullptr, x1, 64 + wave, 128, acc2);
+      zero_g(acc2);
+      if constexpr (TS1 > 0) TP_MMA1(0, TS1, x1, 64 + wave, 128, acc2);
       wait_phase(p1 - 1);
       TP_FAIL_AT_WAIT;
       TPT(1);
-      tp_mma<NB, TJ0 - TL0, TNO0 - TL0, TNF0, false>(wr0, nullptr, x0, wave, TFRW, acc1);  // fresh part
+      TP_MMA0(TNO0, TNF0, x0, wave, TFRW, acc1);  // fresh part
     } else {
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+      zero_g(accg);
       const f4* x0 = (const f4*)(a.G0 + (long)t * a.KB0 * XB) + lane;
       // old part (before the hand-off): its first TL0 blocks come from LDS
-      tp_mma<NB, TJ0 - TL0, 0, TL0, true>(wr0, w0l + wave * TL0 * 64 + lane, x0, TFR0 + wave, a.KB0, acc);
-      tp_mma<NB, TJ0 - TL0, 0, TNO0 - TL0, false>(wr0, nullptr, x0, TFR0 + wave + 8 * TL0, a.KB0, acc);
+      TP_MMA0_LDS(TL0, x0, TFR0 + wave, a.KB0, accg);
+      TP_MMA0(TL0, TNO0 - TL0, x0, TFR0 + wave + 8 * TL0, a.KB0, accg);
       wait_phase(p1 - 1);
       TP_FAIL_AT_WAIT;
       TPT(1);
-      tp_mma<NB, TJ0 - TL0, TNO0 - TL0, TNF0, false>(wr0, nullptr, x0, wave, TFRW, acc);  // fresh part
+      TP_MMA0(TNO0, TNF0, x0, wave, TFRW, accg);  // fresh part
     }
     TPT(2);
-    const f4 fv0 = reduce_gate(*(SPREAD ? &acc1 : &acc));
+    f4 fv0 = f4{0.f, 0.f, 0.f, 0.f}, gq[4];
+    if constexpr (T4) reduce_gate4(*(SPREAD ? &acc1 : &accg), gq);
+    else fv0 = reduce_gate(*(SPREAD ? &acc1 : &accg));
     TP_FAIL_AT_REDUCE;
     TPT(3);
+    if constexpr (T4) {
+      if (gact4) {      // two units (u0, u0 + 1) of batch row gb per lane; the lower lane assembles and publishes the four
+        const int u0 = (tid & 32) ? 2 : 0;
+        float hh[2];
+        f4 gt[2];
+        const float g0 = gsh[gb * 3], g1 = gsh[gb * 3 + 1], g2 = gsh[gb * 3 + 2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int u = u0 + j;
+          const float* k_ = cA[u];
+          const float (*wq)[3] = cW[u];
+          float xr, xz, xn;
+          if (t == 1) { const float* q = a.p1x + (long)gb * 3 * H + 4 * c + u; xr = q[0]; xz = q[H]; xn = q[2 * H]; }
+          else { xr = cV[u][0]; xz = cV[u][1]; xn = cV[u][2]; }
+          xr += wq[0][0] * g0 + wq[0][1] * g1 + wq[0][2] * g2;
+          xz += wq[1][0] * g0 + wq[1][1] * g1 + wq[1][2] * g2;
+          xn += wq[2][0] * g0 + wq[2][1] * g1 + wq[2][2] * g2;
+          const float r = d_sigmoid(gq[0][u] + k_[0] + xr + k_[3]);
+          const float z = d_sigmoid(gq[1][u] + k_[1] + xz + k_[4]);
+          const float nh = gq[3][u] + k_[5];
+          const float nn = d_tanh(gq[2][u] + k_[2] + xn + r * nh);
+          hh[j] = (1.f - z) * nn + z * hq0[j];
+          gt[j] = f4{r, z, nn, nh};
+        }
+        hq0[0] = hh[0]; hq0[1] = hh[1];
+        const f4 mine = f4{hh[0], hh[1], 0.f, 0.f}, oth = swap_halves(mine);
+        if (!(tid & 32)) {
+          const f4 hv = f4{hh[0], hh[1], oth[0], oth[1]};
+          const long o = xf4(gb, 4 * c, NT);
+          stp4(a.G1 + (long)t * 128 * XB + o, hv);                                                // [h0_t | .] of layer 1
+          if (next) stp4(a.G0 + (long)(t + 1) * a.KB0 * XB + (long)TKH0 * XB + o, hv);            // h0 slot of layer 0, step t+1
+          *(f4*)(a.H0 + (long)t * sH + (long)gb * H + 4 * c) = hv;
+        }
+        f4* gts = (f4*)a.GT0 + (long)t * sH + (long)gb * H + 4 * c + u0;
+        gts[0] = gt[0]; gts[1] = gt[1];
+      }
+    } else {
     if (gact) {
       const float* k_ = cA[eu];
       // pose columns of x_t: N0 h1_{t-1} (in the products) + cv0; step 1: the product with the given first pose
@@ -429,6 +639,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       if (next) stp4(a.G0 + (long)(t + 1) * a.KB0 * XB + (long)TKH0 * XB + o, v);            // h0 slot of layer 0, step t+1
       *(f4*)(a.H0 + (long)t * sH + (long)tb * H + 4 * c) = v;
     }
+    }
     TPT(4);
     arrive(p1);
     TPT(5);
@@ -436,26 +647,59 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     if constexpr (SPREAD) {
       const f4* x1 = (const f4*)(a.G1 + (long)t * 128 * XB) + lane;
 #ifndef ZEGGS_TP_NOWIN
-      tp_mma<NB, TJ1, TS1, TNO1 - TS1, false>(wr1, nullptr, x1, 64 + wave + 8 * TS1, 128, acc2);   // window: rest of the old part
+      TP_MMA1(TS1, TNO1 - TS1, x1, 64 + wave + 8 * TS1, 128, acc2);   // window: rest of the old part
 #endif
       wait_phase(p2 - 1);
       TP_FAIL_AT_WAIT;
       TPT(6);
-      tp_mma<NB, TJ1, TNO1, TNF1, false>(wr1, nullptr, x1, wave, 64, acc2);               // h0_t
+      TP_MMA1(TNO1, TNF1, x1, wave, 64, acc2);               // h0_t
     } else {
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+      zero_g(accg);
       const f4* x1 = (const f4*)(a.G1 + (long)t * 128 * XB) + lane;
-      tp_mma<NB, TJ1, 0, TNO1, false>(wr1, nullptr, x1, 64 + wave, 128, acc);             // h1_{t-1}: before the hand-off
+      TP_MMA1(0, TNO1, x1, 64 + wave, 128, accg);             // h1_{t-1}: before the hand-off
       wait_phase(p2 - 1);
       TP_FAIL_AT_WAIT;
       TPT(6);
-      tp_mma<NB, TJ1, TNO1, TNF1, false>(wr1, nullptr, x1, wave, 64, acc);                // h0_t
+      TP_MMA1(TNO1, TNF1, x1, wave, 64, accg);                // h0_t
     }
     TPT(7);
-    const f4 fv1 = reduce_gate(*(SPREAD ? &acc2 : &acc));
+    f4 fv1 = f4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (T4) reduce_gate4(*(SPREAD ? &acc2 : &accg), gq);
+    else fv1 = reduce_gate(*(SPREAD ? &acc2 : &accg));
     TP_FAIL_AT_REDUCE;
     TPT(8);
+    if constexpr (T4) {
+      if (gact4) {
+        const int u0 = (tid & 32) ? 2 : 0;
+        float hh[2];
+        f4 gt[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int u = u0 + j;
+          const float* k_ = cA[u];
+          const float r = d_sigmoid(gq[0][u] + k_[6] + k_[9]);
+          const float z = d_sigmoid(gq[1][u] + k_[7] + k_[10]);
+          const float nh = gq[3][u] + k_[11];
+          const float nn = d_tanh(gq[2][u] + k_[8] + r * nh);
+          hh[j] = (1.f - z) * nn + z * hq1[j];
+          gt[j] = f4{r, z, nn, nh};
+        }
+        hq1[0] = hh[0]; hq1[1] = hh[1];
+        const f4 mine = f4{hh[0], hh[1], 0.f, 0.f}, oth = swap_halves(mine);
+        if (!(tid & 32)) {
+          const f4 hv = f4{hh[0], hh[1], oth[0], oth[1]};
+          const long o = xf4(gb, 4 * c, NT);
+          stp4(a.G3 + (long)t * a.KB3 * XB + xfi(gb, 4 * c, NB), hv);                              // [h1_t | .] of the output stage (16-row tiles)
+          if (next) {
+            stp4(a.G1 + (long)(t + 1) * 128 * XB + 64 * XB + o, hv);                              // [. | h1_t] of t+1
+            stp4(a.G0 + (long)(t + 1) * a.KB0 * XB + (long)TKH1 * XB + o, hv);                    // h1 slot of layer 0, step t+1 (fold)
+          }
+          *(f4*)(a.H1 + (long)t * sH + (long)gb * H + 4 * c) = hv;
+        }
+        f4* gts = (f4*)a.GT1 + (long)t * sH + (long)gb * H + 4 * c + u0;
+        gts[0] = gt[0]; gts[1] = gt[1];
+      }
+    } else {
     if (gact) {
       const float* k_ = cA[eu];
       const float r = d_sigmoid(fv1[0] + k_[6] + k_[9]);
@@ -479,6 +723,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       }
       *(f4*)(a.H1 + (long)t * sH + (long)tb * H + 4 * c) = v;
     }
+    }
     TPT(9);
     arrive(p2);
     TPT(10);
@@ -493,14 +738,13 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
 #ifndef ZEGGS_TP_NOWIN
       tp_mma<NB, TJ0 - TL0, 0, TNO3, true>(wr0, wl3, x3, 64 + wave, a.KB3, acc);          // cond_{t+1}: before the hand-off
 #endif
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc1[nb] = f4{0.f, 0.f, 0.f, 0.f};
+      zero_g(acc1);
 #ifndef ZEGGS_TP_NOWIN
       if constexpr (SPREAD) {
         if (next) {     // window: cond and h0_t blocks of the NEXT step's GRU layer 0 (h0_t was published two hand-offs ago)
           const f4* x0n = (const f4*)(a.G0 + (long)(t + 1) * a.KB0 * XB) + lane;
-          tp_mma<NB, TJ0 - TL0, 0, TL0, true>(wr0, w0l + wave * TL0 * 64 + lane, x0n, TFR0 + wave, a.KB0, acc1);
-          tp_mma<NB, TJ0 - TL0, 0, TS0 - TL0, false>(wr0, nullptr, x0n, TFR0 + wave + 8 * TL0, a.KB0, acc1);
+          TP_MMA0_LDS(TL0, x0n, TFR0 + wave, a.KB0, acc1);
+          TP_MMA0(TL0, TS0 - TL0, x0n, TFR0 + wave + 8 * TL0, a.KB0, acc1);
         }
       }
 #endif
@@ -572,7 +816,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       __syncthreads();
       if (next && tb < B) {
         const f4 v = ex[tb];
-        stp4(xnext + xfi(tb, 4 * c, NB), v);
+        stp4(xnext + (T4 ? xf4(tb, 4 * c, NT) : xfi(tb, 4 * c, NB)), v);
         *(f4*)(gnext + (long)tb * GL + 4 * c) = v;
       }
     }
@@ -599,6 +843,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
 
 // value of virtual row i, contraction index k of workgroup c's tile for phase ph (0: GRU l0, 1: GRU l1, 3: output stage)
 struct TPackArgs {
+  int t4;                                    // != 0: PW0 / PW1 as 4-row tiles (three floats per lane and k-block), see tp_mma4
   f4 *PW0, *PW1, *PW3;
   const float *w_ih0, *w_hh0, *w_ih1, *w_hh1, *l2_w, *l0_w, *Mc, *n0;
   int XD, KBX, KBC, KB0, KB3, PO, PI, NC;
@@ -642,8 +887,21 @@ __global__ void tp_pack_k(TPackArgs p) {
     const int i = (int)(cwi % J), wave = (int)((cwi / J) & 7), c = (int)(cwi / (8L * J));
     const int kb = ph == 0 ? tp_kb(i, wave, TNO0, TFR0, p.KB0, TFRW)
                  : ph == 1 ? tp_kb(i, wave, TNO1, 64, 128, 64) : tp_kb(i, wave, TNO3, 64, p.KB3, 64);
-    const int row = lane & 15, kk = 16 * kb + 4 * (lane >> 4);
     f4 v = f4{0.f, 0.f, 0.f, 0.f};
+    if (p.t4 && ph <= 1) {
+      // lane = 32 * k-half + 4 * a + unit holds, for row group rg (r, z, n), the weight of (unit, gate rg) at k = 16 kb + 8 half + a;
+      // the n group is the block's input- or hidden-side n row (the other one is zero for every k of the block)
+      if (kb >= 0) {
+        const int u = lane & 3, k = 16 * kb + 8 * (lane >> 5) + ((lane >> 2) & 7);
+        v[0] = tp_value(p, ph, c, 4 * u + 0, k);
+        v[1] = tp_value(p, ph, c, 4 * u + 1, k);
+        v[2] = tp_value(p, ph, c, 4 * u + 2, k) + tp_value(p, ph, c, 4 * u + 3, k);
+      }
+      float* d3 = (float*)dst + (cwi * 3) * 64 + lane;      // [workgroup][wave][block][rg][64]
+      d3[0] = v[0]; d3[64] = v[1]; d3[128] = v[2];
+      continue;
+    }
+    const int row = lane & 15, kk = 16 * kb + 4 * (lane >> 4);
     if (kb >= 0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = tp_value(p, ph, c, row, kk + q);
@@ -660,16 +918,16 @@ __global__ void tp_zero_blocks_k(float* G, long KB, long XB, int kb0, int nkb, i
     G[((long)t0 + i / per) * KB * XB + (long)kb0 * XB + i % per] = 0.f;
 }
 // canonical [B, ld] (columns off .. off+K) -> fragments at k offset kofs of an operand buffer
-__global__ void tp_xfrag_k(float* xf, const float* src, long ld, int off, int K, int B, int NB, int kofs) {
+__global__ void tp_xfrag_k(float* xf, const float* src, long ld, int off, int K, int B, int NB, int kofs, int t4) {
   long n = (long)B * K;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int k = (int)(i % K), b = (int)(i / K);
-    xf[xfi(b, kofs + k, NB)] = src[(long)b * ld + off + k];
+    xf[t4 ? xf4(b, kofs + k, NB / 2) : xfi(b, kofs + k, NB)] = src[(long)b * ld + off + k];
   }
 }
 // speech / style columns of every step: x part of G0[t] (t >= 1) and the cond part of G3[t] (cond_{t+1})
 __global__ void tp_cond_k(ZeggsDecDims d, const float* speech, const float* style, float* G0, float* G3, int KB0, int KB3,
-                          int NB) {
+                          int NB, int t4) {
   const int XC = d.SP + d.ST;
   const long XB = 256L * NB, n = (long)(d.T - 1) * d.B * XC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -677,7 +935,7 @@ __global__ void tp_cond_k(ZeggsDecDims d, const float* speech, const float* styl
     const long r = i / XC;
     const int b = (int)(r % d.B), t = 1 + (int)(r / d.B);
     const float v = cc < d.SP ? speech[((long)b * d.T + t) * d.SP + cc] : style[((long)b * d.T + t) * d.ST + (cc - d.SP)];
-    G0[(long)t * KB0 * XB + (long)TFR0 * XB + xfi(b, cc, NB)] = v;
+    G0[(long)t * KB0 * XB + (long)TFR0 * XB + (t4 ? xf4(b, cc, NB / 2) : xfi(b, cc, NB))] = v;      // (G3 keeps the 16-row form)
     if (t >= 2) G3[(long)(t - 1) * KB3 * XB + 64 * XB + xfi(b, cc, NB)] = v;
   }
 }
@@ -699,6 +957,7 @@ int dec_tp_supported(const ZeggsDecDims& d, const DecWs& w) {
   return !d.film && d.H == TH && d.B <= 64 && d.T >= 4 && d.PI == d.PO + 3 && d.SP + d.ST <= 16 * TKC && w.KBC >= 1 &&
          w.KBC <= 8 * TNO3 && d.PO <= 5 * TNCU && d.PO >= 16 && w.G0xf != nullptr;
 }
+static bool tp_use_t4(const DecWs& w) { return g_tp_tiles4 && w.NB % 2 == 0; }
 int dec_tp_state() { return g_tp_ok; }
 void dec_tp_set_state(int v) { g_tp_ok = v; }
 
@@ -715,7 +974,7 @@ int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSt
     ZTRY(gemm_nn(w.tp_n0s, w.POL, P->l2_w, H, w.tp_n0, H, 3 * H, d.PO, H, 0.f, s));
     ZTRY(gemm_nt(w.vvec, w.POL, P->w_ih0 + H, KIN, w.tp_cv0, 3 * H, nullptr, 1, 3 * H, d.PO, ACT_NONE, 0.f, s));
   }
-  TPackArgs p{(f4*)w.tp_w0, (f4*)w.tp_w1, (f4*)w.tp_w3, P->w_ih0, P->w_hh0, P->w_ih1, P->w_hh1, P->l2_w, P->l0_w, w.Mc, w.tp_n0,
+  TPackArgs p{tp_use_t4(w) ? 1 : 0, (f4*)w.tp_w0, (f4*)w.tp_w1, (f4*)w.tp_w3, P->w_ih0, P->w_hh0, P->w_ih1, P->w_hh1, P->l2_w, P->l0_w, w.Mc, w.tp_n0,
               w.XD, w.KBX, w.KBC, TKB0, 64 + w.KBC, d.PO, d.PI, d.SP + d.ST};
   hipLaunchKernelGGL(tp_pack_k, dim3(8192), dim3(256), 0, s, p);
   ZLAUNCH_CHECK("tp_pack");
@@ -747,10 +1006,11 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   // operand buffers: zero (pad rows / pad columns must be finite), then the inputs that do not depend on the rollout
   // (only the blocks with pad columns: the gaze + speech / style blocks of G0, the cond blocks of G3, the h1 slot of step 1)
   if (!zeroed) ZTRY(dec_tp_zero(d, w, s));
-  hipLaunchKernelGGL(tp_cond_k, dim3(1024), dim3(256), 0, s, d, speech, style, w.G0xf, w.G3xf, KB0, KB3, NB);
+  const int t4 = tp_use_t4(w) ? 1 : 0;
+  hipLaunchKernelGGL(tp_cond_k, dim3(1024), dim3(256), 0, s, d, speech, style, w.G0xf, w.G3xf, KB0, KB3, NB, t4);
   auto conv = [&](float* xf, const float* src, long ld, int off, int K, int kofs) {
     long n = (long)B * K, g = (n + 255) / 256;
-    hipLaunchKernelGGL(tp_xfrag_k, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, s, xf, src, ld, off, K, B, NB, kofs);
+    hipLaunchKernelGGL(tp_xfrag_k, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, s, xf, src, ld, off, K, B, NB, kofs, t4);
   };
   const float* gin1 = w.Gin + sG;
   conv(w.G0xf + (long)KB0 * XB, gin1, w.GL, 0, H, 0);                         // hid_1
@@ -772,9 +1032,15 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   a.status = status; a.spin = (unsigned)g_persistent_spin; a.nap = (unsigned)g_poll_sleep;
   switch (NB) {
     case 1: hipLaunchKernelGGL((train_fwd_persistent_k<1>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((train_fwd_persistent_k<2>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
+    case 2:
+      if (t4) hipLaunchKernelGGL((train_fwd_persistent_k<2, true>), dim3(TNCU), dim3(TTHR), 0, s, a);
+      else hipLaunchKernelGGL((train_fwd_persistent_k<2>), dim3(TNCU), dim3(TTHR), 0, s, a);
+      break;
     case 3: hipLaunchKernelGGL((train_fwd_persistent_k<3>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
-    default: hipLaunchKernelGGL((train_fwd_persistent_k<4>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
+    default:
+      if (t4) hipLaunchKernelGGL((train_fwd_persistent_k<4, true>), dim3(TNCU), dim3(TTHR), 0, s, a);
+      else hipLaunchKernelGGL((train_fwd_persistent_k<4>), dim3(TNCU), dim3(TTHR), 0, s, a);
+      break;
   }
   ZLAUNCH_CHECK("train_fwd_persistent");
   return 0;
