@@ -528,10 +528,10 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       const bool rfetch = c == 0 && t > 1;
       if (rfetch) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int idx = tid + q * BTHR;
-          if (idx < 33 * 32 && (idx & 31) < a.Bact)
-            rv[q] = root_item(a.drpos, a.drrot, a.rrot, a.rpos, a.gaze, a.pose, a.dpose, T, PO, idx & 31, t - 1, true, idx >> 5);
+        for (int q = 0; q < 3; ++q) {       // item er + 16 q of batch row eb: from the per-step (opaque) copy of the thread index, so that
+          const int item = er + 16 * q;     // the compiler does not keep 3 x 7 source addresses per thread live across the whole sweep
+          if (item < 33 && bact)
+            rv[q] = root_item(a.drpos, a.drrot, a.rrot, a.rpos, a.gaze, a.pose, a.dpose, T, PO, eb, t - 1, true, item);
         }
       }
       bp_mma<1, NJ2A, 0, true>(wr, wl + L3A * 64, op1, wave, 0, 128, acc);
@@ -539,8 +539,8 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       if (rfetch) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          const int idx = tid + q * BTHR;
-          if (idx < 33 * 32) rin[idx >> 5][idx & 31] = rv[q];
+          const int item = er + 16 * q;
+          if (item < 33) rin[item][eb] = rv[q];
         }
       }
       BPT(6);
@@ -647,8 +647,8 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
         float* dyc = a.DY + ((long)(t - 1) * B + eb) * POL;
         float* opy = a.OPY + (long)(t - 1) * a.KBY * 512;
         if (c != 0) {
-          const int g = tid >> 5, rb = 8 * c + 4 * g;          // groups 0, 1 of this workgroup's rows
-          if (tid < 64 && bact && rb < PO) {
+          const int g = er, rb = 8 * c + 4 * g;                // groups 0, 1 of this workgroup's rows (er: the per-step thread index)
+          if (er < 2 && bact && rb < PO) {
             const f4 v = ex[g][eb];
             stp4(opy + op_idx(eb, rb), v);
             *(f4*)(dyc + rb) = v;

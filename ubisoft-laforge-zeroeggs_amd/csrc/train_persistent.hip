@@ -167,6 +167,12 @@ __device__ __forceinline__ void tp_mma(const f4 (&wr)[NJT], const f4* wl, const 
   }
 }
 
+#ifndef ZEGGS_T4_TL0
+#define ZEGGS_T4_TL0 8      // LDS-parked k-blocks of GRU layer 0 in the 4-row form (B <= 32; 4 / 0 parked blocks or 3 / 4 blocks per group spill 6 .. 24 registers)
+#endif
+#ifndef ZEGGS_T4_GU
+#define ZEGGS_T4_GU 2       // k-blocks per operand-prefetch group in the 4-row form (B <= 32; 4 / 0 parked blocks or 3 / 4 blocks per group spill 6 .. 24 registers)
+#endif
 // ---- 4-row tiles for the two GRU phases (option "tp_tiles4", batch tiles in pairs: 17..32 and 49..64 rows).  A 16-row tile of
 // v_mfma_f32_16x16x4 holds (r, z, n_input, n_hidden) x 4 units, and every k-block multiplies one all-zero n row group (input-side
 // blocks have no hidden-side n weights and vice versa): a quarter of the GRU phases' matrix-core time.  v_mfma_f32_4x4x1 with
@@ -186,7 +192,7 @@ template <int NT, int NW, int OFF, int NJ, bool WLDS, int PH, int IABS>
 __device__ __forceinline__ void tp_mma4(const float (&wq)[NW], const float* wl, const f4* __restrict__ xb, int kb0, int hi,
                                         f4 (&acc)[4][NT]) {
   if constexpr (NJ <= 0) return;
-  constexpr int GU = NT >= 2 ? 1 : 2;
+  constexpr int GU = NT >= 2 ? 1 : ZEGGS_T4_GU;
   constexpr int NG = (NJ + GU - 1) / GU;
   asm volatile("" : "+s"(kb0));
   f4 xa[GU][2][NT], xq[GU][2][NT];
@@ -274,9 +280,9 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
   __shared__ f4 red[8][NB][64];
   __shared__ f4 fin[NB][64];
   __shared__ f4 w3[8 * TJ3 * 64];             // output-stage weights of this workgroup (72 KB)
-  constexpr int TL0 = tl0(NB), TS0 = ts0(NB), TS1 = ts1(NB);
+  constexpr int TL0 = (T4 && NB == 2) ? ZEGGS_T4_TL0 : tl0(NB), TS0 = ts0(NB), TS1 = ts1(NB);
   constexpr bool SPREAD = TS0 > 0;       // old parts spread over all three hand-off windows
-  __shared__ f4 w0l[8 * TL0 * 64];            // the first TL0 (old-part) k-blocks of GRU layer 0: relieves the register file
+  __shared__ f4 w0l[8 * (TL0 > 0 ? TL0 : 1) * 64];   // the first TL0 (old-part) k-blocks of GRU layer 0: relieves the register file
   __shared__ float gsh[BP * 3];               // normalised gaze direction of x_{t+1} per batch row
   __shared__ float cA[4][12];                 // biases of the 4 units: b_ih0, b_hh0, b_ih1, b_hh1 (r, z, n)
   __shared__ f4 ex[BP];                       // epilogue exchange: the 4 units of a batch row -> one 16-byte store
@@ -791,7 +797,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
             }
         }
       }
-      for (int item = tid; item < 5 * BP; item += TTHR) {       // layer2 rows: pose_t and the pose columns of x_{t+1}
+      for (int item = tb; item < 5 * BP; item += TTHR) {        // layer2 rows: pose_t and the pose columns of x_{t+1} (tb: per-step thread index)
         const int vc = 4 + item / BP, b = item % BP;
         if (b < B && cB[vc][5] != 0.f) {
           const float* k_ = cB[vc];
@@ -805,8 +811,8 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
         }
       }
       __syncthreads();
-      if (next && tid < 4 * BP && tid % BP < B) {                 // folded layer0 rows: hid_{t+1}
-        const int vc = tid / BP, b = tid % BP;
+      if (next && tb < 4 * BP && tb % BP < B) {                   // folded layer0 rows: hid_{t+1}
+        const int vc = tb / BP, b = tb % BP;
         const float* k_ = cB[vc];
         const int col = 4 * c + vc;
         const float val = d_elu(FV(vc, b) + k_[0] + k_[1] * gsh[b * 3] + k_[2] * gsh[b * 3 + 1] + k_[3] * gsh[b * 3 + 2]);
