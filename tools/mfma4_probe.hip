@@ -30,6 +30,9 @@ __global__ __launch_bounds__(512, 2) void rate_k(const float* a, const float* b,
     for (int i = 0; i < 12; ++i) {
       if (KIND == 0) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[i], 0, 0, 0);
       else if (KIND == 2) acc[i % 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[i % 3], 3, 5, 0);   // 3 accumulators, broadcast A
+      else if (KIND == 3) acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[0], 3, 5, 0);            // ONE dependent chain per wave
+      else if (KIND == 4) acc[i % 2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[i % 2], 3, 5, 0);    // two chains
+      else if (KIND == 5) acc[i % 6] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[i % 6], 3, 5, 0);    // six chains
       else acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
     }
   }
@@ -69,17 +72,20 @@ int main() {
   }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int n = 20000;
-  for (int kind = 0; kind < 3; ++kind) {
+  for (int kind = 0; kind < 6; ++kind) {
     for (int rep = 0; rep < 2; ++rep) {
       hipEventRecord(e0);
       if (kind == 0) hipLaunchKernelGGL((rate_k<0>), dim3(256), dim3(512), 0, 0, a, b, d, n);
       else if (kind == 1) hipLaunchKernelGGL((rate_k<1>), dim3(256), dim3(512), 0, 0, a, b, d, n);
-      else hipLaunchKernelGGL((rate_k<2>), dim3(256), dim3(512), 0, 0, a, b, d, n);
+      else if (kind == 2) hipLaunchKernelGGL((rate_k<2>), dim3(256), dim3(512), 0, 0, a, b, d, n);
+      else if (kind == 3) hipLaunchKernelGGL((rate_k<3>), dim3(256), dim3(512), 0, 0, a, b, d, n);
+      else if (kind == 4) hipLaunchKernelGGL((rate_k<4>), dim3(256), dim3(512), 0, 0, a, b, d, n);
+      else hipLaunchKernelGGL((rate_k<5>), dim3(256), dim3(512), 0, 0, a, b, d, n);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       const double per = kind == 1 ? 2048.0 : 512.0;     // flops per instruction
       const double flops = per * 12.0 * n * 8 * 256;     // 8 waves x 256 workgroups
-      if (rep) printf("%s: %.3f ms, %.1f TFLOP/s, %.1f ns per instruction per SIMD\n", kind == 0 ? "4x4x1_16b " : kind == 1 ? "16x16x4    " : "4x4x1 cbsz3, 3 acc",
+      if (rep) printf("%s: %.3f ms, %.1f TFLOP/s, %.1f ns per instruction per SIMD\n", kind == 0 ? "4x4x1_16b, 12 acc" : kind == 1 ? "16x16x4, 12 acc" : kind == 2 ? "4x4x1 cbsz3, 3 acc" : kind == 3 ? "4x4x1 cbsz3, 1 acc (one chain per wave, 2 waves per SIMD)" : kind == 4 ? "4x4x1 cbsz3, 2 acc" : "4x4x1 cbsz3, 6 acc",
                       ms, flops / ms * 1e-9, ms * 1e6 / (12.0 * n * 2));
     }
   }

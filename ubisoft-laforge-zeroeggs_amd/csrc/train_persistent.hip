@@ -441,12 +441,19 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     return o;
   };
   auto reduce_gate4 = [&](f4 (&acc)[4][NT], f4 (&out)[4]) {
+    // one v_permlane32_swap folds the k-halves of TWO values: swap(a, b) = ([a_lo | b_lo], [a_hi | b_hi]), whose sum holds the folded a
+    // in lanes < 32 and the folded b in lanes >= 32 -- gates (0, 2) and (1, 3) pair up, every lane has something to store
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const f4 v = acc[g][nt] + swap_down(acc[g][nt]);
-        if (lane < 32) red4[wave][g][nt][lane] = v;
+        f4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[g][nt][e]), __float_as_uint(acc[g + 2][nt][e]), false, false);
+          v[e] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        red4[wave][lane < 32 ? g : g + 2][nt][lane & 31] = v;
       }
     __syncthreads();
 #pragma unroll
