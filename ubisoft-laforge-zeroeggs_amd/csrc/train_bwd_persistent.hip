@@ -421,11 +421,12 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   };
   // wave partial sums -> red[wave][row0 + 4 rg + i][batch]  (the two k-halves of the accumulator lanes are added first)
   auto put = [&](const f4& v, int row0) {
+    // swap(a, b) = ([a_lo | b_lo], [a_hi | b_hi]): the sum of the pair is the folded a in lanes < 32 and the folded b in lanes >= 32,
+    // so one swap serves two rows (i, i + 2) and every lane has a value to park
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned x = __float_as_uint(v[i]);
-      const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);     // [1]: lanes < 32 get lane + 32's value
-      if (lane < 32) red[wave][row0 + i][lane] = v[i] + __uint_as_float(sw[1]);
+    for (int i = 0; i < 2; ++i) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2]), false, false);
+      red[wave][row0 + i + (lane < 32 ? 0 : 2)][lane & 31] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
   };
   auto total = [&](int row) -> float {       // sum over the 8 waves of (row, eb)
