@@ -12,6 +12,11 @@
 #include "common.h"
 #include "kernels.h"
 
+// waves of a frame workgroup (64 frames = the lanes; the waves share the joints of a tree level)
+#ifndef ZEGGS_LOSS_WAVES
+#define ZEGGS_LOSS_WAVES 8
+#endif
+
 namespace {
 
 struct Off {
@@ -179,7 +184,7 @@ __device__ void build_levels(Levels& L, const int* parents, int J) {
 // One workgroup = 64 consecutive frames (lanes) x 8 waves sharing the joints of each tree level.
 // items gid0 .. gid_end - 1 of the 2 NF (side, frame) pairs: [0, NF) = prediction, [NF, 2 NF) = ground truth (the truth half
 // depends on the batch only: zeggs_loss_prepare_truth runs it ahead of the step)
-__global__ __launch_bounds__(512) void loss_frame_fwd_k(ZeggsLossDims d, const int* parents, FrameIO io0, FrameIO io1,
+__global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_fwd_k(ZeggsLossDims d, const int* parents, FrameIO io0, FrameIO io1,
                                                         const float* PT0, const float* PT1, const float* gaze, float* F0,
                                                         float* F1, float* LM, long gid0, long gid_end) {
   __shared__ Levels lv;
@@ -353,7 +358,7 @@ __device__ void build_children(Children& Cn, const int* parents, int J) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(512) void loss_frame_bwd_k(ZeggsLossDims d, const int* parents, FrameIO io, const float* gaze,
+__global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_bwd_k(ZeggsLossDims d, const int* parents, FrameIO io, const float* gaze,
                                                          const float* PT, const float* F, const float* LM, float* G,
                                                          float* DPT, float* drpos, float* DQ) {
   __shared__ Levels lv;
@@ -583,7 +588,7 @@ extern "C" int zeggs_loss_prepare_truth(const ZeggsLossDims* dp, const int* pare
   const int PO = 6 + 15 * d.J;
   FrameIO ioW{w_pose, w_rpos, w_rrot};
   hipLaunchKernelGGL(transpose_k, dim3((unsigned)cdiv(NF, 64), (unsigned)cdiv(PO, 64)), dim3(256), 0, s, w.PT1, w_pose, NF, PO);
-  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(NF, 64)), dim3(512), 0, s, d, parents, ioW, ioW, w.PT1, w.PT1, gaze, w.FW, w.FW,
+  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(NF, 64)), dim3(64 * ZEGGS_LOSS_WAVES), 0, s, d, parents, ioW, ioW, w.PT1, w.PT1, gaze, w.FW, w.FW,
                      w.LM, NF, 2 * NF);
   ZLAUNCH_CHECK("loss_prepare_truth");
   return 0;
@@ -619,7 +624,7 @@ extern "C" int zeggs_loss_fwd_bwd_ex(const ZeggsLossDims* dp, const int* parents
   ZCHECK(d.J <= MAXJ, "loss: more than %d joints", MAXJ);
   // (truth_prepared: zeggs_loss_prepare_truth has filled PT1 / FW of THIS workspace; only the prediction side is left)
   const long gend = truth_prepared ? NF : 2 * NF;
-  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(gend, 64)), dim3(512), 0, s, d, parents, ioO, ioW, w.PT0, w.PT1, gaze, w.FO,
+  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(gend, 64)), dim3(64 * ZEGGS_LOSS_WAVES), 0, s, d, parents, ioO, ioW, w.PT0, w.PT1, gaze, w.FO,
                      w.FW, w.LM, 0L, gend);
   ZLAUNCH_CHECK("loss_frame_fwd");
   hipLaunchKernelGGL(loss_terms_k, dim3(o.n), dim3(256), 0, s, d, w.FO, w.FW, w.G, terms, gscale);
@@ -628,7 +633,7 @@ extern "C" int zeggs_loss_fwd_bwd_ex(const ZeggsLossDims* dp, const int* parents
                      gscale);
   ZLAUNCH_CHECK("loss_kl_final");
   if (dpose) {
-    hipLaunchKernelGGL(loss_frame_bwd_k, dim3(cdiv(NF, 64)), dim3(512), 0, s, d, parents, ioO, gaze, w.PT0, w.FO, w.LM, w.G,
+    hipLaunchKernelGGL(loss_frame_bwd_k, dim3(cdiv(NF, 64)), dim3(64 * ZEGGS_LOSS_WAVES), 0, s, d, parents, ioO, gaze, w.PT0, w.FO, w.LM, w.G,
                        w.DPT, drpos, w.DQ);
     ZLAUNCH_CHECK("loss_frame_bwd");
     // back to [frame][PO] (columns 0..5 hold nothing yet: the root-velocity kernel below writes them)
