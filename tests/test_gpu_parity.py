@@ -567,14 +567,16 @@ def test_chained_decode_launches_match_plain_launches(B):
         assert float((a - b).abs().max()) < 2e-5
 
 
-@pytest.mark.parametrize("B,T", [(32, 12), (17, 6), (5, 9), (32, 4), (64, 6), (40, 5)])
-def test_persistent_training_forward_matches_stage_launches(B, T):
+@pytest.mark.parametrize("B,T,tiles4", [(32, 12, 1), (17, 6, 1), (5, 9, 1), (32, 4, 1), (64, 6, 1), (40, 5, 1), (32, 12, 0), (64, 6, 0)])
+def test_persistent_training_forward_matches_stage_launches(B, T, tiles4):
     """option "train_persistent" (default on for batch <= 64): the forward rollout of a training step as one
     weight-stationary launch.  Outputs and, through the unchanged BPTT that consumes what the forward saved, every
-    gradient must agree with the stage-launch forward."""
+    gradient must agree with the stage-launch forward.  tiles4: the GRU phases on 4-row v_mfma_f32_4x4x1 tiles (batch 17..32 and
+    49..64; default) or on the 16-row tiles every batch size can use."""
     _, de, _ = helpers.build_nets()
     de = de.to(DEV).train()
     try:
+        ops.set_option("tp_tiles4", tiles4)
         ops.set_option("train_persistent", 0)
         out0, g0, ds0, dy0 = _rollout_with_grads(de, B, T, 21)
         ops.set_option("train_persistent", 1)
@@ -582,6 +584,7 @@ def test_persistent_training_forward_matches_stage_launches(B, T):
         assert ops.lib().zeggs_persistent_state(1) == 1            # it really ran (validated, not fallen back)
     finally:
         ops.set_option("train_persistent", 1)
+        ops.set_option("tp_tiles4", 1)
     for a, b in zip(out0, out1):
         assert float((a - b).abs().max()) < 2e-5
     assert relerr(ds1, ds0) < 1e-4 and relerr(dy1, dy0) < 1e-4
