@@ -229,15 +229,30 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
   ZTRY(k_pack_conv_w(w.wf0, nullptr, P->c0_w, H, C, 3, s));
   ZTRY(conv_gemm(w.xp, (long)LP * C, C, w.wf0, 3 * C, H, w.c1, H, (long)L * H, P->c0_b, B, L, ACT_RELU, s));
   // LN1 -> interior of padded a1p, dropout, zero edges
+  if (H <= 512) {     // LayerNorm + dropout + the zero edge rows of the next conv's input in one row pass
+    LnFwdFused q = ln_fwd_fused_args((int)BL, H, eps);
+    q.x = rv(w.c1); q.y = rv(w.a1p + H, L, (long)LP * H); q.gamma = P->ln0_g; q.beta = P->ln0_b; q.mean = w.m1; q.rstd = w.r1;
+    q.p_post = p2; q.seed_post = d.seed + 1; q.pad_L = L;
+    ZTRY(k_ln_fwd_fused(q, s));
+  } else {
   ZTRY(k_layernorm_fwd_v(rv(w.a1p + H, L, (long)LP * H), rv(w.c1), rv(nullptr), P->ln0_g, P->ln0_b, w.m1, w.r1,
                           (int)BL, H, eps, s));
   ZTRY(k_dropout_rows(w.a1p + H, (int)BL, H, H, L, (long)LP * H, p2, d.seed + 1, s));
   ZTRY(k_pad_edges(w.a1p, B, L, H, 1, 1, 0, s));
+  }
   ZTRY(k_pack_conv_w(w.wf4, w.wb4, P->c4_w, E, H, 3, s));
   ZTRY(conv_gemm(w.a1p, (long)LP * H, H, w.wf4, 3 * H, E, w.c2, E, (long)L * E, P->c4_b, B, L, ACT_RELU, s));
+  const bool fuse = E <= 512;
+  if (fuse) {         // h = dropout(LayerNorm(c2)) + positional table
+    LnFwdFused q = ln_fwd_fused_args((int)BL, E, eps);
+    q.x = rv(w.c2); q.y = rv(w.h); q.gamma = P->ln1_g; q.beta = P->ln1_b; q.mean = w.m2; q.rstd = w.r2;
+    q.p_post = p2; q.seed_post = d.seed + 2; q.table = pos; q.table_L = L;
+    ZTRY(k_ln_fwd_fused(q, s));
+  } else {
   ZTRY(k_layernorm_fwd(w.h, w.c2, nullptr, P->ln1_g, P->ln1_b, w.m2, w.r2, (int)BL, E, eps, s));
   ZTRY(k_dropout(w.h, BL * E, p2, d.seed + 2, s));
   ZTRY(k_add_rows_bcast(w.h, pos, B, L, E, s));
+  }
   // multi-head self attention
   ZTRY(gemm_nt(w.h, E, P->in_w, E, w.qkv, 3 * E, P->in_b, (int)BL, 3 * E, E, ACT_NONE, 0.f, s));
   if (w.fused) {      // softmax(Q K^T / sqrt(hd)) -> dropout -> . V in one kernel (attention.hip)
@@ -261,20 +276,34 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
   }
   }
   ZTRY(gemm_nt(w.O, E, P->out_w, E, w.ao, E, P->out_b, (int)BL, E, E, ACT_NONE, 0.f, s));
+  if (fuse) {         // ao = dropout(ao) (kept: the backward's LayerNorm input), a = LN(ao + h) -> interior of padded ap, edge rows zero
+    LnFwdFused q = ln_fwd_fused_args((int)BL, E, eps);
+    q.x = rv(w.ao); q.res = rv(w.h); q.y = rv(w.ap + E, L, (long)LP * E); q.gamma = P->lna_g; q.beta = P->lna_b;
+    q.mean = w.ma; q.rstd = w.ra; q.p_pre = p1; q.seed_pre = d.seed + 4; q.pad_L = L;
+    ZTRY(k_ln_fwd_fused(q, s));
+  } else {
   ZTRY(k_dropout(w.ao, BL * E, p1, d.seed + 4, s));
   // a = LN(ao + h) -> interior of padded ap
   ZTRY(k_layernorm_fwd_v(rv(w.ap + E, L, (long)LP * E), rv(w.ao), rv(w.h), P->lna_g, P->lna_b, w.ma, w.ra, (int)BL, E,
                           eps, s));
   ZTRY(k_pad_edges(w.ap, B, L, E, 1, 1, 0, s));
+  }
   // position-wise conv feed-forward
   ZTRY(k_pack_conv_w(w.wff0, w.wfb0, P->ff0_w, E, E, 3, s));
   ZTRY(k_pack_conv_w(w.wff2, w.wfb2, P->ff2_w, E, E, 3, s));
   ZTRY(conv_gemm(w.ap, (long)LP * E, E, w.wff0, 3 * E, E, w.f1p + E, E, (long)LP * E, P->ff0_b, B, L, ACT_RELU, s));
   ZTRY(k_pad_edges(w.f1p, B, L, E, 1, 1, 0, s));
   ZTRY(conv_gemm(w.f1p, (long)LP * E, E, w.wff2, 3 * E, E, w.f2, E, (long)L * E, P->ff2_b, B, L, ACT_NONE, s));
+  if (fuse) {         // f2 = dropout(f2), f = LN(f2 + a)
+    LnFwdFused q = ln_fwd_fused_args((int)BL, E, eps);
+    q.x = rv(w.f2); q.res = rv(w.ap + E, L, (long)LP * E); q.y = rv(w.f); q.gamma = P->lnf_g; q.beta = P->lnf_b;
+    q.mean = w.mf; q.rstd = w.rf; q.p_pre = p1; q.seed_pre = d.seed + 5;
+    ZTRY(k_ln_fwd_fused(q, s));
+  } else {
   ZTRY(k_dropout(w.f2, BL * E, p1, d.seed + 5, s));
   ZTRY(k_layernorm_fwd_v(rv(w.f), rv(w.f2), rv(w.ap + E, L, (long)LP * E), P->lnf_g, P->lnf_b, w.mf, w.rf, (int)BL, E,
                           eps, s));
+  }
   ZTRY(k_meanpool_fwd(out, w.f, B, L, E, s));
   return 0;
 }

@@ -36,6 +36,19 @@ struct LnBwdFused {
   int R, C;
 };
 LnBwdFused ln_bwd_fused_args(int R, int C);
+// ... and the forward twin: y = (LayerNorm(x * mask(seed_pre) + res) * gamma + beta) * mask(seed_post) + table[row % table_L]
+// in one pass (the masked x is written back when p_pre > 0: the backward's LayerNorm input is the post-dropout tensor);
+// pad_L > 0: y is the interior of a [B, pad_L + 2, C] buffer whose edge rows are zeroed here.  C <= 512.
+struct LnFwdFused {
+  RowView x, res, y;
+  const float *gamma, *beta, *table;
+  float *mean, *rstd;
+  float p_pre, p_post, eps;
+  uint64_t seed_pre, seed_post;
+  int table_L, pad_L, R, C;
+};
+LnFwdFused ln_fwd_fused_args(int R, int C, float eps);
+int k_ln_fwd_fused(const LnFwdFused& a, hipStream_t s);
 int k_ln_bwd_fused(const LnBwdFused& a, hipStream_t s);
 int k_colsum_v(float* out, RowView x, long R, int C, float beta, hipStream_t s);
 

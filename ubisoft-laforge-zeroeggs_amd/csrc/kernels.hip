@@ -133,6 +133,54 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(RowView dxv, RowView dyv,
   }
 }
 
+// see kernels.h (LnFwdFused): one wave per row, the row in registers
+template <int MAXJ>
+__global__ __launch_bounds__(256) void ln_fwd_fused_k(LnFwdFused a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, C = a.C;
+  if (row >= a.R) return;
+  float* xr = rv_row(a.x, row, C);
+  const float* rr = a.res.p ? rv_row(a.res, row, C) : nullptr;
+  float* yr = rv_row(a.y, row, C);
+  float v[MAXJ];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int c = lane + 64 * j;
+    v[j] = 0.f;
+    if (c < C) {
+      float xv = xr[c];
+      if (a.p_pre > 0.f) { xv *= dropout_scale(a.seed_pre, (uint64_t)((long)row * C + c), a.p_pre); xr[c] = xv; }
+      v[j] = xv + (rr ? rr[c] : 0.f);
+      s += v[j];
+    }
+  }
+  const float mu = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int c = lane + 64 * j;
+    if (c < C) { const float d = v[j] - mu; q += d * d; }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / C + a.eps);   // biased variance, as torch
+  const float* tb = a.table ? a.table + (long)(row % a.table_L) * C : nullptr;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int c = lane + 64 * j;
+    if (c < C) {
+      float o = (v[j] - mu) * rs * a.gamma[c] + a.beta[c];
+      o *= dropout_scale(a.seed_post, (uint64_t)((long)row * C + c), a.p_post);
+      if (tb) o += tb[c];
+      yr[c] = o;
+      if (a.pad_L > 0) {
+        const int l = row % a.pad_L;
+        if (l == 0) yr[c - C] = 0.f;
+        if (l == a.pad_L - 1) yr[c + C] = 0.f;
+      }
+    }
+  }
+  if (lane == 0) { a.mean[row] = mu; a.rstd[row] = rs; }
+}
+
 // see kernels.h (LnBwdFused).  One wave per row, 16 rows per block (as layernorm_bwd_k)
 template <int MAXJ>
 __global__ __launch_bounds__(256) void ln_bwd_fused_k(LnBwdFused a, int rows_per_block) {
@@ -449,6 +497,19 @@ int k_layernorm_bwd_v(RowView dx, RowView dy, RowView x, RowView res, const floa
     hipLaunchKernelGGL((layernorm_bwd_k<8>), dim3(cdiv(R, rpb)), dim3(256), 0, s, dx, dy, x, res, gamma, mean, rstd,
                        dgamma, dbeta, R, C, rpb);
   ZLAUNCH_CHECK("layernorm_bwd");
+  return 0;
+}
+LnFwdFused ln_fwd_fused_args(int R, int C, float eps) {
+  LnFwdFused a;
+  memset(&a, 0, sizeof(a));
+  a.R = R; a.C = C; a.eps = eps; a.table_L = 1;
+  return a;
+}
+int k_ln_fwd_fused(const LnFwdFused& a, hipStream_t s) {
+  ZCHECK(a.C <= 512, "ln_fwd_fused: C=%d > 512 unsupported", a.C);
+  if (a.C <= 128) hipLaunchKernelGGL((ln_fwd_fused_k<2>), dim3(cdiv(a.R, 4)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((ln_fwd_fused_k<8>), dim3(cdiv(a.R, 4)), dim3(256), 0, s, a);
+  ZLAUNCH_CHECK("ln_fwd_fused");
   return 0;
 }
 LnBwdFused ln_bwd_fused_args(int R, int C) {

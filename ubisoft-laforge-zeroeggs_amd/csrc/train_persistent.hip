@@ -930,12 +930,16 @@ __global__ void tp_zero_blocks_k(float* G, long KB, long XB, int kb0, int nkb, i
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     G[((long)t0 + i / per) * KB * XB + (long)kb0 * XB + i % per] = 0.f;
 }
-// canonical [B, ld] (columns off .. off+K) -> fragments at k offset kofs of an operand buffer
-__global__ void tp_xfrag_k(float* xf, const float* src, long ld, int off, int K, int B, int NB, int kofs, int t4) {
-  long n = (long)B * K;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % K), b = (int)(i / K);
-    xf[t4 ? xf4(b, kofs + k, NB / 2) : xfi(b, kofs + k, NB)] = src[(long)b * ld + off + k];
+// canonical [B, ld] (columns 0 .. K) -> fragments at k offset kofs of an operand buffer; the three vectors the rollout starts
+// from (hid_1, h0_0, h1_0: K = H each) in one launch
+struct TXfrag { float* xf[3]; const float* src[3]; long ld[3]; int kofs[3]; };
+__global__ void tp_xfrag_k(TXfrag x, int K, int B, int NB, int t4) {
+  const long n = (long)B * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i / n);
+    const long r = i - j * n;
+    const int k = (int)(r % K), b = (int)(r / K);
+    x.xf[j][t4 ? xf4(b, x.kofs[j] + k, NB / 2) : xfi(b, x.kofs[j] + k, NB)] = x.src[j][(long)b * x.ld[j] + k];
   }
 }
 // speech / style columns of every step: x part of G0[t] (t >= 1) and the cond part of G3[t] (cond_{t+1})
@@ -1021,15 +1025,16 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   if (!zeroed) ZTRY(dec_tp_zero(d, w, s));
   const int t4 = tp_use_t4(w) ? 1 : 0;
   hipLaunchKernelGGL(tp_cond_k, dim3(1024), dim3(256), 0, s, d, speech, style, w.G0xf, w.G3xf, KB0, KB3, NB, t4);
-  auto conv = [&](float* xf, const float* src, long ld, int off, int K, int kofs) {
-    long n = (long)B * K, g = (n + 255) / 256;
-    hipLaunchKernelGGL(tp_xfrag_k, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, s, xf, src, ld, off, K, B, NB, kofs, t4);
-  };
   const float* gin1 = w.Gin + sG;
-  conv(w.G0xf + (long)KB0 * XB, gin1, w.GL, 0, H, 0);                         // hid_1
-  conv(w.G0xf + (long)KB0 * XB, gin1, w.GL, H + d.PO, 3, 16 * 64);            // gaze direction of x_1
-  conv(w.G0xf + (long)KB0 * XB, w.H0, H, 0, H, 16 * TKH0);                    // h0_0 (the h1 slot of step 1 stays zero:
-  conv(w.G1xf + 128 * XB, w.H1, H, 0, H, 16 * 64);                            // h1_0  its pose columns are the given first pose)
+  {   // hid_1, h0_0 -> operand of GRU layer 0, step 1 (its h1 slot stays zero: the pose columns of x_1 are the given first pose; its
+      // gaze block is not an operand any more: the gate threads read the gaze direction of x_1 from the canonical row); h1_0 -> layer 1
+    TXfrag x;
+    x.xf[0] = w.G0xf + (long)KB0 * XB; x.src[0] = gin1; x.ld[0] = w.GL; x.kofs[0] = 0;
+    x.xf[1] = w.G0xf + (long)KB0 * XB; x.src[1] = w.H0; x.ld[1] = H;    x.kofs[1] = 16 * TKH0;
+    x.xf[2] = w.G1xf + 128 * XB;       x.src[2] = w.H1; x.ld[2] = H;    x.kofs[2] = 16 * 64;
+    const long g = (3L * B * H + 255) / 256;
+    hipLaunchKernelGGL(tp_xfrag_k, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, s, x, H, B, NB, t4);
+  }
   // ... whose product with W_ih0 is one small GEMM: p1x[b][3H] = x_1[b][pose] W_ih0[:, pose]^T
   ZTRY(gemm_nt(gin1 + H, w.GL, P->w_ih0 + H, H + w.XD, w.tp_p1x, 3 * H, nullptr, B, 3 * H, d.PO, ACT_NONE, 0.f, s));
   ZLAUNCH_CHECK("tp_prologue");
