@@ -31,6 +31,7 @@
 
 int g_persistent = 1;           // zeggs_set_option("persistent", 0/1)
 int g_poll_sleep = 0;
+int g_poll_stagger = 0;
 int g_persistent_spin = 1 << 21;   // bound of every device-side wait of the three persistent kernels ("persistent_spin")
 static int g_persistent_ok = -1;   // -1 not validated yet, 0 failed once (disabled), 1 validated on this process
 

@@ -65,6 +65,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   // bound of every device-side wait of the persistent kernels (polls); 0 makes the first unsatisfied wait give up: the
   // tests use it to drive the give-up path (tests/test_gpu_giveup.py)
   if (strcmp(name, "tp_tiles4") == 0) { g_tp_tiles4 = value != 0; return 0; }
+  if (strcmp(name, "poll_stagger") == 0) { g_poll_stagger = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "poll_sleep") == 0) { g_poll_sleep = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "persistent_spin") == 0) { g_persistent_spin = value < 0 ? 0 : value; return 0; }
   zeggs_set_error("unknown option %s", name);

@@ -146,6 +146,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
 }
 
 extern int g_poll_sleep;           // s_sleep units (64 clocks) between two polls of the arrival slots (option "poll_sleep")
+extern int g_poll_stagger;         // != 0: two polls of the arrival slots in flight, this many s_sleep units apart (option "poll_stagger")
 extern int g_persistent_spin;      // bound of the device-side waits of the persistent kernels (option "persistent_spin")
 // persistent weight-stationary decode (decode_persistent.hip)
 int dec_persistent_supported(const ZeggsDecDims& d, const DecWs& w);

@@ -72,6 +72,7 @@ struct BArgs {
   unsigned* status;                          // caller-owned sticky give-up flags (ZeggsDecCall.status), may be null
   unsigned spin;                             // bound of every wait (option "persistent_spin")
   unsigned nap;                              // s_sleep units between two polls (option "poll_sleep")
+  unsigned stag;                             // != 0: two staggered polls in flight (option "poll_stagger")
 };
 
 __device__ __forceinline__ void stp(float* p, float v) {       // published: write-through
@@ -101,6 +102,26 @@ __device__ __forceinline__ bool bp_wait(const unsigned* slots, unsigned expect, 
     if (__all(ok)) return true;
     if (spins >= limit) return false;
     for (unsigned i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+}
+// two staggered samples in flight (train_persistent.hip: tp_wait2)
+__device__ __forceinline__ bool bp_wait2(const unsigned* slots, unsigned expect, unsigned limit, unsigned stagger) {
+  const int lane = threadIdx.x & 63;
+  const gu64t* q = (const gu64t*)(slots + 4 * lane);
+  auto all_in = [&](unsigned long long a, unsigned long long b) {
+    return __all((unsigned)a >= expect && (unsigned)(a >> 32) >= expect && (unsigned)b >= expect && (unsigned)(b >> 32) >= expect);
+  };
+  unsigned long long a0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long b0 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (unsigned i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  for (unsigned spins = 0;; spins += 2) {
+    const unsigned long long a1 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (all_in(a0, b0)) return true;
+    a0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b0 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (all_in(a1, b1)) return true;
+    if (spins >= limit) return false;
   }
 }
 
@@ -407,7 +428,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
 #ifdef ZEGGS_BPSTAT
       const unsigned long long w0 = wall_clock64();
 #endif
-      if (wave == 1 && !bp_wait(a.cnt, (unsigned)(p + 1), a.spin, a.nap)) fail = 1;     // (wave 0 of workgroup 0 prepares the root frame meanwhile)
+      if (wave == 1 && !(a.stag ? bp_wait2(a.cnt, (unsigned)(p + 1), a.spin, a.stag) : bp_wait(a.cnt, (unsigned)(p + 1), a.spin, a.nap))) fail = 1;     // (wave 0 of workgroup 0 prepares the root frame meanwhile)
 #ifdef ZEGGS_BPSTAT
       wsum[(p + 1) & 3] += wall_clock64() - w0;
 #endif
@@ -866,7 +887,7 @@ int dec_bp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
     a.pose = pose + o * T * d.PO; a.rpos = rpos + o * T * 3; a.rrot = rrot + o * T * 4;
     a.carry = w.carry + o * 8;
     a.cnt = w.bp_cnt; a.err = w.bp_cnt + 1024;
-    a.status = status; a.spin = (unsigned)g_persistent_spin; a.nap = (unsigned)g_poll_sleep;
+    a.status = status; a.spin = (unsigned)g_persistent_spin; a.nap = (unsigned)g_poll_sleep; a.stag = (unsigned)g_poll_stagger;
     hipLaunchKernelGGL(train_bwd_persistent_k, dim3(BNCU), dim3(BTHR), 0, s, a);
     ZLAUNCH_CHECK("train_bwd_persistent");
   }

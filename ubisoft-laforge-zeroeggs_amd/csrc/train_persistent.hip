@@ -80,6 +80,7 @@ struct TArgs {
   unsigned* status;                          // caller-owned sticky give-up flags (ZeggsDecCall.status), may be null
   unsigned spin;                             // bound of every wait (option "persistent_spin")
   unsigned nap;                              // s_sleep units between two polls (option "poll_sleep")
+  unsigned stag;                             // != 0: two staggered polls in flight (option "poll_stagger")
 };
 
 __device__ __forceinline__ void stp(float* p, float v) {       // published: write-through
@@ -113,6 +114,28 @@ __device__ __forceinline__ bool tp_wait(const unsigned* slots, unsigned expect, 
     if (__all(ok)) return true;
     if (spins >= limit) return false;
     for (unsigned i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+}
+// Two samples of the slots in flight, half a round trip apart (option "poll_stagger" = that half in s_sleep units, 0 = off): a
+// producer's flag is seen by the first sample issued after it landed, i.e. after a quarter of a round trip on average instead of
+// half of one (the round trip of a load that misses every cache is ~0.9 us: the dominant term of a hand-off).
+__device__ __forceinline__ bool tp_wait2(const unsigned* slots, unsigned expect, unsigned limit, unsigned stagger) {
+  const int lane = threadIdx.x & 63;
+  const gu64t* q = (const gu64t*)(slots + 4 * lane);
+  auto all_in = [&](unsigned long long a, unsigned long long b) {
+    return __all((unsigned)a >= expect && (unsigned)(a >> 32) >= expect && (unsigned)b >= expect && (unsigned)(b >> 32) >= expect);
+  };
+  unsigned long long a0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long b0 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (unsigned i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  for (unsigned spins = 0;; spins += 2) {
+    const unsigned long long a1 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (all_in(a0, b0)) return true;
+    a0 = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b0 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (all_in(a1, b1)) return true;
+    if (spins >= limit) return false;
   }
 }
 
@@ -509,7 +532,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       // phase's reduction barrier (`fail` is checked there: all waves of a workgroup must meet the same barriers)
       if (!tp_wait(a.cnt, (unsigned)(p + 1), a.spin, (lane & 7) == wave)) fail = 1;
 #else
-      if (wave == 0 && !tp_wait(a.cnt, (unsigned)(p + 1), a.spin, true, a.nap)) fail = 1;
+      if (wave == 0 && !(a.stag ? tp_wait2(a.cnt, (unsigned)(p + 1), a.spin, a.stag) : tp_wait(a.cnt, (unsigned)(p + 1), a.spin, true, a.nap))) fail = 1;
 #endif
 #ifdef ZEGGS_TPSTAT
       wsum[(p + 1) % 3] += wall_clock64() - w0;
@@ -1047,7 +1070,7 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   a.b_ih0 = P->b_ih0; a.b_hh0 = P->b_hh0; a.b_ih1 = P->b_ih1; a.b_hh1 = P->b_hh1; a.cvec = w.cvec; a.l0_w = P->l0_w;
   a.l2_b = P->l2_b; a.w_ih0 = P->w_ih0; a.cv0 = w.tp_cv0; a.p1x = w.tp_p1x; a.gaze = gaze; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
   a.cnt = w.tp_cnt; a.err = w.tp_cnt + TRING * TSH * TSTR;
-  a.status = status; a.spin = (unsigned)g_persistent_spin; a.nap = (unsigned)g_poll_sleep;
+  a.status = status; a.spin = (unsigned)g_persistent_spin; a.nap = (unsigned)g_poll_sleep; a.stag = (unsigned)g_poll_stagger;
   switch (NB) {
     case 1: hipLaunchKernelGGL((train_fwd_persistent_k<1>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
     case 2:
