@@ -253,6 +253,16 @@ int zeggs_decoder_bwd_ex(const ZeggsDecDims*, const ZeggsDecParams*, const Zeggs
                          const float* pose, const float* rpos, const float* rrot, const float* dpose,
                          const float* drpos, const float* drrot, const ZeggsDecGrads*, float* dspeech,
                          float* dstyle, void* ws, size_t ws_bytes, void* stream, const ZeggsDecCall* call);
+/* zeggs_decoder_fwd_state + ZeggsDecCall (only `status` is used): a caller that feeds the returned state into its NEXT chunk
+ * must be able to tell a rollout that gave up -- without a status word the only trace is NaN in the chunk's LAST frame, which
+ * such a caller would carry forward for ever.  zeggs/stream.py owns one word per stream, looks at it after every chunk and
+ * redoes the chunk on the stage launches.  (The plain entry points without a ZeggsDecCall -- zeggs_decoder_fwd,
+ * zeggs_decoder_fwd_state, zeggs_decoder_bwd -- have nowhere to report a give-up of a validated persistent kernel: callers
+ * that cannot rule out a co-tenant on the GPU use the *_ex forms or switch the persistent kernels off.) */
+int zeggs_decoder_fwd_state_ex(const ZeggsDecDims*, const ZeggsDecParams*, const ZeggsDecStats*, const float* pose0,
+                               const float* rpos0, const float* rrot0, const float* gaze, const float* speech,
+                               const float* style, float* pose, float* rpos, float* rrot, const float* h_in,
+                               float* h_out, void* ws, size_t ws_bytes, void* stream, const ZeggsDecCall* call);
 /* second half of the deferred weight gradients (ZeggsDecCall.defer_wgrads = 2): what = 4 -> GRU layer 0 and layer0;
  * what | 8: the gradient outputs are zero on entry (as ZeggsDecCall.grads_zeroed of the backward it completes) */
 int zeggs_decoder_wgrads(const ZeggsDecDims*, const ZeggsDecGrads*, void* ws, size_t ws_bytes, int what, void* stream);
@@ -375,6 +385,45 @@ int zeggs_randn(float* out, long n, uint64_t seed, void* stream);
 int zeggs_dropout(float* x, long n, float p, uint64_t seed, void* stream);
 int zeggs_broadcast_time(float* out /* [B,T,S] */, const float* z /* [B,S] */, int B, int T, int S, void* stream);
 int zeggs_sum_time(float* dz /* [B,S] */, const float* dout /* [B,T,S] */, int B, int T, int S, void* stream);
+
+/* ---------------------------------------------------------------- free functions of the Networks layer
+ * The module-level functions ZEGGS/train.py:20-24 and ZEGGS/generate.py import next to the classes
+ * (`from modules import compute_KL_div, normalize`) and the two pose (de)vectorisers Decoder.forward is built from, forward and
+ * backward, so that the reference's OWN training loop (its inline ATen loss differentiates through them) runs against the
+ * drop-in `modules` (INTEGRATION.md route 2).  Inside zeggs_decoder_* / zeggs_loss_* the same arithmetic is fused.
+ *
+ * normalize, ZEGGS/modules.py:673-675: y = x / (||x||_2 + eps) over the last dimension of [rows, width]. */
+int zeggs_normalize_vec_fwd(const float* x, float* y, long rows, int width, float eps, void* stream);
+int zeggs_normalize_vec_bwd(const float* x, const float* dy, float* dx, long rows, int width, float eps, void* stream);
+/* vectorize_input, ZEGGS/modules.py:677-713: out [B, 9+15J] = (cat[root_vel, root_vrt, lpos, ltxy, lvel, lvrt,
+ * quat_inv_mul_vec(root_rot, gaze_pos - root_pos)] - in_mean) / in_std; inputs [B,3] [B,4] [B,3] [B,3] [B,J,3] [B,J,2,3]
+ * [B,J,3] [B,J,3] [B,3].  The backward writes every input gradient (shapes of the inputs). */
+int zeggs_vectorize_input_fwd(int B, int J, const float* root_pos, const float* root_rot, const float* root_vel,
+                              const float* root_vrt, const float* lpos, const float* ltxy, const float* lvel,
+                              const float* lvrt, const float* gaze_pos, const float* in_mean, const float* in_std,
+                              float* out, void* stream);
+int zeggs_vectorize_input_bwd(int B, int J, const float* root_pos, const float* root_rot, const float* gaze_pos,
+                              const float* in_std, const float* dout, float* d_root_pos, float* d_root_rot,
+                              float* d_root_vel, float* d_root_vrt, float* d_lpos, float* d_ltxy, float* d_lvel,
+                              float* d_lvrt, float* d_gaze_pos, void* stream);
+/* devectorize_output, ZEGGS/modules.py:716-742: pose [B, 6+15J] = predicted * out_std + out_mean (its slices 0:3, 3:6, lpos,
+ * ltxy, lvel, lvrt are the six pose outputs); new_root_pos = quat_mul_vec(root_rot, vel dt) + root_pos; new_root_rot =
+ * quat_mul(quat_from_helical(quat_mul_vec(root_rot, vrt dt)), root_rot).  Backward: any of the three upstream gradients may be
+ * NULL (= zero). */
+int zeggs_devectorize_output_fwd(int B, int J, float dt, const float* predicted, const float* root_pos,
+                                 const float* root_rot, const float* out_mean, const float* out_std, float* pose,
+                                 float* new_root_pos, float* new_root_rot, void* stream);
+int zeggs_devectorize_output_bwd(int B, int J, float dt, const float* predicted, const float* root_pos,
+                                 const float* root_rot, const float* out_mean, const float* out_std, const float* d_pose,
+                                 const float* d_new_root_pos, const float* d_new_root_rot, float* d_predicted,
+                                 float* d_root_pos, float* d_root_rot, void* stream);
+/* compute_KL_div, ZEGGS/modules.py:764-789 (the divergence; its annealing weight is host arithmetic):
+ * out[0] = mean_b(-0.5 mean_s(1 + logvar - mu^2 - exp(logvar))), mu / logvar [B,S]; dout = device scalar. */
+int zeggs_kl_div_fwd(const float* mu, const float* logvar, int B, int S, float* out, void* stream);
+int zeggs_kl_div_bwd(const float* mu, const float* logvar, int B, int S, const float* dout, float* dmu, float* dlogvar,
+                     void* stream);
+/* get_mask_from_lengths, ZEGGS/modules.py:802-813: mask[b][i] = i < lengths[b] (bytes 0/1), lengths int64 [B] */
+int zeggs_mask_from_lengths(const int64_t* lengths, int B, int max_len, uint8_t* mask, void* stream);
 
 /* ---------------------------------------------------------------- animation pre-/post-processing (float64)
  * zeggs_anim_features replaces preprocess_animation, ZEGGS/data_pipeline.py:90-228 (with quat.py from_euler /

@@ -349,12 +349,163 @@ def gold_generate(ref):
     print("generate.npz frames", out["rotations"].shape)
 
 
+def gold_generate_branches(ref):
+    """The branches of the reference's generate_gesture() that generate.npz does not reach (generate.py:84,158,264-354):
+    two styles "stitch" (integer frame splits, helpers.py:26-37) and "add" with blend_ratio [0.3, 0.7], label strings
+    (label-conditioned decoder, style width = nlabels), a pre-computed ndarray embedding, first_pose=None (the first pose is
+    the LAST style exemplar's frame 0, here a (start, end)-trimmed one), audio_file=None (encodings only).  Same files, seeds
+    and temperature = 1e8 convention as gold_generate()."""
+    import scipy.io.wavfile as wavfile
+    tmp = Path(tempfile.mkdtemp(prefix="zeggs_gold_genb_"))
+    net, netl, data, res = tmp / "net", tmp / "net_label", tmp / "data", tmp / "res"
+    net.mkdir(), netl.mkdir(), data.mkdir()
+    se, de, st = build_ref_nets(ref)
+    torch.save(se, net / "speech_encoder.pt"), torch.save(de, net / "decoder.pt"), torch.save(st, net / "style_encoder.pt")
+    nlabels = len(synth.data_definition()["label_names"])
+    torch.manual_seed(SEED)                      # label mode: no style encoder, decoder style width = nlabels (train.py:99-131)
+    sel = ref.modules.SpeechEncoder(synth.N_AUDIO, 64, 64)
+    del_ = ref.modules.Decoder(pose_input_size=synth.POSE_IN, pose_output_size=synth.POSE_OUT, speech_encoding_size=64,
+                               style_encoding_size=nlabels, hidden_size=1024, num_rnn_layers=2)
+    torch.save(sel, netl / "speech_encoder.pt"), torch.save(del_, netl / "decoder.pt")
+    np.savez(data / "stats.npz", **synth.make_stats())
+    json.dump(synth.data_definition(), open(data / "data_definition.json", "w"))
+    conf = json.load(open("/root/reference/data/processed_v1/data_pipeline_conf.json"))
+    conf["audio_conf"]["normalize_loudness"] = False
+    json.dump(conf, open(data / "data_pipeline_conf.json", "w"))
+    wav = synth.synth_wav(32000 + 4000, seed=19)           # 2.25 s -> 135 frames: 0.3 * 135 = 40.5 truncates to 40
+    wavfile.write(tmp / "a.wav", 16000, wav)
+    ref.bvh.save(str(tmp / "exa.bvh"), synth.make_bvh_clip(40, seed=4))
+    ref.bvh.save(str(tmp / "exb.bvh"), synth.make_bvh_clip(52, seed=6))
+    A, Bx, WAV = tmp / "exa.bvh", tmp / "exb.bvh", tmp / "a.wav"
+    emb = np.random.default_rng(23).standard_normal(64).astype(np.float32) * 0.5
+    label = synth.data_definition()["label_names"][5]
+    orig_load = torch.load
+    torch.load = ref.torch_load
+    g = dict(wav=wav, exa_bvh=np.frombuffer(open(A, "rb").read(), dtype=np.uint8),
+             exb_bvh=np.frombuffer(open(Bx, "rb").read(), dtype=np.uint8), embedding=emb, label=np.array(label),
+             blend_ratio=np.array([0.3, 0.7]), trim=np.array([7, 45], dtype=np.int64))
+    common = dict(temperature=1e8, seed=1234, use_gpu=False, use_script=False)
+
+    def run(tag, audio, styles, netdir, **kw):
+        enc = ref.generate.generate_gesture(audio, styles, netdir, data, res if audio is not None else None,
+                                            file_name=tag if audio is not None else None, **kw, **common)
+        if isinstance(enc, list):
+            for i, e in enumerate(enc):
+                g[f"{tag}_encoding{i}"] = e.numpy()
+        else:
+            g[f"{tag}_encoding"] = enc.numpy()
+        if audio is not None:
+            out = ref.bvh.load(str(res / (tag + ".bvh")))
+            g[f"{tag}_rotations"] = out["rotations"].astype(np.float32)
+            g[f"{tag}_root_positions"] = out["positions"][:, 0].astype(np.float32)
+
+    try:
+        two = [(A, None), (Bx, None)]
+        run("stitch", WAV, two, net, style_encoding_type="example", blend_type="stitch", blend_ratio=[0.3, 0.7],
+            first_pose=A)
+        run("add", WAV, two, net, style_encoding_type="example", blend_type="add", blend_ratio=[0.3, 0.7], first_pose=A)
+        run("label", WAV, [label], netl, style_encoding_type="label", blend_type="add", blend_ratio=[1.0], first_pose=Bx)
+        run("ndarray", WAV, [(emb, "given")], net, style_encoding_type="example", blend_type="add", blend_ratio=[1.0],
+            first_pose=Bx)
+        # first_pose=None: pose 0 = frame 0 of the LAST exemplar after its (start, end) trim (generate.py:196-203,313-354)
+        run("nofirst", WAV, [(A, None), (Bx, (7, 45))], net, style_encoding_type="example", blend_type="add",
+            blend_ratio=[0.6, 0.4], first_pose=None)
+        # audio_file=None: embeddings only; "stitch" returns the LIST of per-style encodings (generate.py:282-284)
+        run("noaudio_stitch", None, two, net, style_encoding_type="example", blend_type="stitch", blend_ratio=[0.3, 0.7])
+        run("noaudio_add", None, two, net, style_encoding_type="example", blend_type="add", blend_ratio=[0.3, 0.7])
+        run("noaudio_trim", None, [(Bx, (7, 45))], net, style_encoding_type="example", blend_type="add", blend_ratio=[1.0])
+    finally:
+        torch.load = orig_load
+    g["split_135"] = np.array(ref.helpers.split_by_ratio(135, [0.3, 0.7]))
+    np.savez_compressed(GOLD / "generate_branches.npz", **g)
+    print("generate_branches.npz", {k: v.shape for k, v in g.items() if k.endswith("encoding") or "encoding" in k})
+
+
+def gold_train_iter_fp64(ref):
+    """The two iterations of train_iter.npz once more through the UNMODIFIED reference train(), in float64 (modules built
+    from the same fp32 seed, then .double(); the recorded batches and VAE noise replayed): the arbiter for gradient
+    comparisons.  Needed because iteration 1 of that fixture is ill-conditioned: the reference's own fp32 gradients are
+    0.5-0.8 % away from its fp64 gradients there (2.5e-5 at iteration 0) -- recorded as `it*_ref32_vs_ref64`."""
+    import torch.nn.functional as F
+    gd = np.load(GOLD / "train_iter.npz")
+    window, B, n_it = int(gd["window"]), int(gd["batch"]), len(gd["loss"])
+    tmp = Path(tempfile.mkdtemp(prefix="zeggs_gold64_"))
+    (tmp / "data").mkdir(), (tmp / "models").mkdir(), (tmp / "logs").mkdir()
+    npz, jsn = tmp / "data" / "processed_data.npz", tmp / "data" / "data_definition.json"
+    np.savez(npz, **{k[5:]: gd[k] for k in gd.files if k.startswith("data_")})
+    json.dump(synth.data_definition(), open(jsn, "w"))
+    rec = dict(grads=[], loss=[])
+    state = dict(it=0)
+
+    class ReplayDL:
+        def __init__(self, ds, **kw):
+            pass
+
+        def __iter__(self):
+            for it in range(n_it):
+                yield [torch.as_tensor(gd[f"it{it}_batch{j}"]).double() for j in range(11)]
+
+    def fake_randn_like(x, *a, **k):
+        if tuple(x.shape) == (B, 64):
+            return torch.as_tensor(gd[f"it{min(state['it'], n_it - 1)}_eps"]).to(x.dtype)
+        return torch.zeros_like(x)
+
+    def double_module(cls):
+        def make(*a, **k):
+            m = cls(*a, **k).double()
+            m.register_forward_pre_hook(lambda mod, args: tuple(x.double() if torch.is_tensor(x) and x.is_floating_point()
+                                                                else x for x in args))
+            return m
+        return make
+
+    orig_step = ref.optimizers.RAdam.step
+
+    def rec_step(self, closure=None):
+        ps = [p for g in self.param_groups for p in g["params"]]
+        rec["grads"].append(np.concatenate([p.grad.flatten()[sample_idx(p.numel())].numpy() for p in ps]))
+        state["it"] += 1
+        return orig_step(self, closure)
+
+    orig_backward = torch.Tensor.backward
+
+    def rec_backward(self, *a, **k):
+        rec["loss"].append(float(self.detach()))
+        return orig_backward(self, *a, **k)
+
+    rt = ref.train
+    saved = (rt.DataLoader, torch.randn_like, F.dropout, rt.SpeechEncoder, rt.Decoder, rt.StyleEncoder, torch.save)
+    rt.DataLoader, torch.randn_like = ReplayDL, fake_randn_like
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x
+    rt.SpeechEncoder, rt.Decoder, rt.StyleEncoder = (double_module(c) for c in saved[3:6])
+    torch.save = lambda *a, **k: None                  # (the pre-hooks are not picklable; no checkpoint is needed here)
+    ref.optimizers.RAdam.step = rt.RAdam.step = rec_step
+    torch.Tensor.backward = rec_backward
+    random.seed(0)
+    train_opt = dict(niterations=0.001, batchsize=B, window=window, change_pace=True, learning_rate=1e-4,
+                     learning_rate_decay=0.995, eps=1e-5, resume=False, use_gpu=False, thread_count=1, seed=SEED,
+                     use_tensorboard=False, style_encoding_type="example", generate_samples_step=10 ** 9, use_script=False)
+    try:
+        rt.train(tmp / "models", tmp / "logs", npz, jsn, train_opt, NET_OPT)
+    finally:
+        (rt.DataLoader, torch.randn_like, F.dropout, rt.SpeechEncoder, rt.Decoder, rt.StyleEncoder, torch.save) = saved
+        ref.optimizers.RAdam.step = rt.RAdam.step = orig_step
+        torch.Tensor.backward = orig_backward
+    out = dict(loss64=np.array(rec["loss"]))
+    for it in range(n_it):
+        g64, g32 = rec["grads"][it], gd[f"it{it}_grad_samples"].astype(np.float64)
+        out[f"it{it}_grad_samples64"] = g64
+        out[f"it{it}_ref32_vs_ref64"] = np.float64(np.abs(g32 - g64).max() / np.abs(g64).max())
+        print(f"train_iter_fp64: iteration {it}: loss {rec['loss'][it]:.8f} (fp32 {gd['loss'][it]:.8f}), reference fp32 vs fp64 "
+              f"gradients {out[f'it{it}_ref32_vs_ref64']:.2e} of the largest entry")
+    np.savez_compressed(GOLD / "train_iter_fp64.npz", **out)
+
+
 def main():
     assert ref_shims.available(), "/root/reference is required to (re)generate golden vectors"
     GOLD.mkdir(parents=True, exist_ok=True)
     ref = ref_shims.load()
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["nets", "train", "mel", "dataset", "radam", "generate", "variants"]
+    which = sys.argv[1:] or ["nets", "train", "mel", "dataset", "radam", "generate", "variants", "generate_branches"]
     if "variants" in which:
         gold_variants(ref)
     if "nets" in which:
@@ -367,8 +518,12 @@ def main():
         gold_radam(ref)
     if "generate" in which:
         gold_generate(ref)
+    if "generate_branches" in which:
+        gold_generate_branches(ref)
     if "train" in which:
         gold_train_iter(ref)
+    if "train" in which or "train_fp64" in which:
+        gold_train_iter_fp64(ref)
 
 
 if __name__ == "__main__":

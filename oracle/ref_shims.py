@@ -115,6 +115,30 @@ def load():
     return ns
 
 
+def load_dropin(dropin_modules):
+    """The reference's OWN `train.py` and `generate.py` (unmodified files, imported under private names) with the top-level
+    name `modules` bound to `dropin_modules` while they are imported -- i.e. `from modules import Decoder, SpeechEncoder,
+    StyleEncoder, compute_KL_div, normalize` (train.py:20-24) resolves to the drop-in, everything else (dataset, optimizers,
+    anim, helpers, utils, data_pipeline) stays the reference's.  INTEGRATION.md route 2; used by
+    tests/test_gpu_reference_side.py.  Returns a namespace with .train / .generate (modules) and .ref (load())."""
+    ref = load()                         # third-party stubs, sys.path, the reference's helper modules
+    ns = types.SimpleNamespace(ref=ref)
+    mine = sys.modules.get("modules")
+    sys.modules["modules"] = dropin_modules
+    try:
+        for name in ("train", "generate"):
+            spec = importlib.util.spec_from_file_location("zeggs_ref_dropin_" + name, root() / "ZEGGS" / f"{name}.py")
+            m = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(m)
+            setattr(ns, name, m)
+    finally:
+        if mine is None:
+            sys.modules.pop("modules", None)
+        else:
+            sys.modules["modules"] = mine
+    return ns
+
+
 _saved = {}
 
 

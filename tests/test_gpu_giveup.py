@@ -157,3 +157,105 @@ def test_two_decoders_interleave_in_one_process(restore_options):
         for got, want in zip(grads(m), ref):
             scale = max(1e-12, float(want.abs().max()))
             assert float((got - want).abs().max()) <= 2e-5 * scale
+
+
+def test_flush_replays_a_giveup_in_the_last_iterations(restore_options):
+    """a sweep that gives up within the last STATUS_LAG iterations (or right before a checkpoint) is only known to
+    the device -- TrainEngine.flush() drains it: the skipped step is re-run on the stage kernels, the optimizer's step count
+    and the weights are those of an undisturbed run on the stage kernels, and the replayed loss is handed to the caller."""
+    steps = 5
+    ref = _train(steps, -1, persistent=False)
+    w_ref = ref.flat_p.detach().cpu().numpy().copy()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        eng = _train(steps, steps - 1, persistent=True)              # the LAST step gives up: no later step() would notice
+        assert eng.recovered_steps == 0 and int(eng.status.cpu()[1]) == 1
+        assert eng.flush() == 1
+    assert any("gave up" in str(w.message) for w in rec)
+    assert eng.recovered_steps == 1 and eng.iteration == steps == eng.opt._step
+    assert [it for it, _, _ in eng.replayed] == [steps - 1] and np.isfinite(float(eng.replayed[0][1]))
+    assert int(eng.status.cpu()[0]) == 0 and int(eng.status.cpu()[1]) == 0 and eng.flush() == 0
+    w = eng.flat_p.detach().cpu().numpy()
+    assert np.isfinite(w).all() and np.abs(w - w_ref).max() <= 5e-6, np.abs(w - w_ref).max()
+
+
+def test_plain_autograd_training_giveup_is_redone(restore_options):
+    """Training-mode decoder calls OUTSIDE an engine (plain autograd: the tests, the reference's own loop of INTEGRATION.md
+    route 2) have nobody who looks at a status word later: the binding inspects its own word right after the rollout and
+    after the BPTT sweep and redoes them on the stage kernels, so neither outputs nor gradients of a give-up reach the caller."""
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).train()
+    B, T = 32, 40
+    W, speech, style = helpers.full_decoder_inputs(helpers.real_stats("v1"), B, T, 911)
+    s = helpers.real_stats_tensors("v1", device=DEV)
+    g = lambda t: t.to(DEV)  # noqa: E731
+    fp = [g(W[k][:, 0].contiguous()) for k in ("Y_root_pos", "Y_root_rot", "Y_root_vel", "Y_root_vrt", "Y_lpos", "Y_ltxy",
+                                               "Y_lvel", "Y_lvrt")]
+
+    def run():
+        de.zero_grad()
+        sp = g(speech).requires_grad_(True)
+        O = de(*fp, g(W["Y_gaze_pos"]), sp, g(style), None, s["in_mean"], s["in_std"], s["out_mean"], s["out_std"], synth.DT)
+        sum((o * o).mean() for o in O).backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in O], [p.grad.detach().clone() for p in de.parameters()] + [sp.grad.clone()]
+
+    for k in ("train_persistent", "bwd_persistent"):
+        ops.set_option(k, 0)
+    out_s, grad_s = run()                                       # stage kernels
+    for k in ("train_persistent", "bwd_persistent"):
+        ops.set_option(k, 1)
+    run()                                                       # validates both sweeps on this process
+    assert ops.lib().zeggs_persistent_state(1) == 1 and ops.lib().zeggs_persistent_state(2) == 1
+    ops.set_option("persistent_spin", 0)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        out_g, grad_g = run()
+    assert any("gave up" in str(w.message) for w in rec)
+    for a, b in zip(out_g, out_s):     # (run to run the stage path differs by the split-K atomics of its prologue GEMMs)
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) < 1e-6 * max(1.0, float(b.abs().max()))
+    for a, b in zip(grad_g, grad_s):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 2e-5 * max(1e-12, float(b.abs().max()))
+
+
+def test_streaming_giveup_redoes_the_chunk(restore_options):
+    """GestureStream feeds a chunk's last frame and GRU state into the next chunk -- a persistent decode kernel that
+    gives up mid-stream must not be carried forward: the stream owns a status word, checks it per chunk and redoes the
+    chunk on the stage launches; the streamed frames equal an undisturbed stream's."""
+    from zeggs import anim, stream
+    se, de, _ = helpers.build_nets()
+    se, de = se.to(DEV).eval(), de.to(DEV).eval()
+    stats = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32, device=DEV) for k, v in synth.make_stats().items()}
+    conf = dict(pre_emphasis=False, pre_emph_coeff=0.97, centered=True, real_amplitude=True, normalize_mel_bins=True,
+                normalize_range=True, min_clipping=1e-5, sampling_rate=16000, mel_fmin=20, mel_fmax=7600,
+                n_mel_channels=80, filter_length=800, hop_length=200, resample_method="linear", normalize_loudness=False)
+    wav = synth.synth_wav(40000, seed=5).astype(np.float32) / 32768.0
+    first = anim.preprocess_animation(synth.make_bvh_clip(8, seed=3), DEV)
+    torch.manual_seed(5)
+    style = torch.randn(1, 64, device=DEV) * 0.5
+    cuts = [0, 9000, 21000, 30000, 40000]
+
+    def run(fail_chunk):
+        gs = stream.GestureStream(se, de, first, style, stats, conf, synth.DT)
+        outs = []
+        for i in range(len(cuts) - 1):
+            if i == fail_chunk:
+                assert ops.lib().zeggs_persistent_state(0) == 1
+                ops.set_option("persistent_spin", 0)
+            outs.append(gs.push(wav[cuts[i]:cuts[i + 1]]))
+            ops.set_option("persistent_spin", SPIN)
+        outs.append(gs.finish())
+        return gs, {k: torch.cat([o[k] for o in outs if o], dim=0) for k in ("pose", "rpos", "rrot")}
+
+    ops.set_option("persistent", 1)
+    _, good = run(-1)
+    if ops.lib().zeggs_persistent_state(0) != 1:
+        pytest.skip("the B = 1 persistent decode kernel is not available on this device")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        gs, got = run(2)
+    assert any("gave up" in str(w.message) for w in rec) and gs.redone_chunks == 1
+    for k in good:
+        assert got[k].shape == good[k].shape and torch.isfinite(got[k]).all()
+        assert float((got[k] - good[k]).abs().max()) < 5e-5, k

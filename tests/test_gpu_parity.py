@@ -456,6 +456,97 @@ def test_generate_gesture_vs_reference(golden_dir, tmp_path):
     np.testing.assert_allclose(out["positions"][:, 0], gd["out_positions"][:, 0], atol=2e-3)
 
 
+def _bvh_angle_deg(rot_a, rot_b):
+    """largest angle (degrees) between two sets of zyx Euler channels, compared as rotations (no +-180 wrap artefacts)"""
+    qa = oanim.q_from_euler(np.radians(np.asarray(rot_a, np.float64)))
+    qb = oanim.q_from_euler(np.radians(np.asarray(rot_b, np.float64)))
+    return float((2 * np.degrees(np.arccos(np.clip(np.abs(np.sum(qa * qb, axis=-1)), 0, 1)))).max())
+
+
+def test_generate_gesture_branches_vs_reference(golden_dir, tmp_path):
+    """The generate_gesture() branches beyond single-style / "add" / first_pose given, each against the REFERENCE's own
+    run on the same files (tests/golden/generate_branches.npz, oracle/make_golden.py:gold_generate_branches): two styles
+    "stitch" with blend_ratio [0.3, 0.7] (integer frame splits bit-exact, generate.py:280-298, helpers.py:26-37), two styles
+    "add" (:299-308), label strings (:270-276), a pre-computed ndarray embedding (:264-269), first_pose=None with a
+    (start, end)-trimmed last exemplar (:196-203, 313-354), audio_file=None (:84, 158, 282-284).
+    Bounds: integers exact, encodings 1e-4, joint rotations of the BVH < 0.02 degrees, root positions 2e-3."""
+    import json
+    import scipy.io.wavfile as wavfile
+    from zeggs import anim, generate
+    gd = np.load(golden_dir / "generate_branches.npz")
+    net, netl, data, res = tmp_path / "net", tmp_path / "net_label", tmp_path / "data", tmp_path / "res"
+    net.mkdir(), netl.mkdir(), data.mkdir()
+    se, de, st = helpers.build_nets()
+    torch.save(se, net / "speech_encoder.pt"), torch.save(de, net / "decoder.pt"), torch.save(st, net / "style_encoder.pt")
+    nlabels = len(synth.data_definition()["label_names"])
+    sel, del_, _ = helpers.build_nets(style_size=nlabels)
+    torch.save(sel, netl / "speech_encoder.pt"), torch.save(del_, netl / "decoder.pt")
+    np.savez(data / "stats.npz", **synth.make_stats())
+    json.dump(synth.data_definition(), open(data / "data_definition.json", "w"))
+    conf = dict(audio_conf=dict(pre_emphasis=False, pre_emph_coeff=0.97, centered=True, real_amplitude=True,
+                                normalize_mel_bins=True, normalize_range=True, min_clipping=1e-5, sampling_rate=16000,
+                                mel_fmin=20, mel_fmax=7600, n_mel_channels=80, filter_length=800, hop_length=200,
+                                resample_method="linear", normalize_loudness=False),
+                audio_feature_type=["mel_spec", "energy"])
+    json.dump(conf, open(data / "data_pipeline_conf.json", "w"))
+    WAV, A, Bx = tmp_path / "a.wav", tmp_path / "exa.bvh", tmp_path / "exb.bvh"
+    wavfile.write(WAV, 16000, gd["wav"])
+    A.write_bytes(gd["exa_bvh"].tobytes()), Bx.write_bytes(gd["exb_bvh"].tobytes())
+    ratio = [float(r) for r in gd["blend_ratio"]]
+    trim = tuple(int(v) for v in gd["trim"])
+    label, emb = str(gd["label"]), gd["embedding"]
+    # integer frame splits of "stitch": bit-exact
+    assert generate.split_by_ratio(135, ratio) == gd["split_135"].tolist()
+    common = dict(temperature=1e8, seed=1234)
+    two = [(A, None), (Bx, None)]
+
+    def run(tag, audio, styles, netdir, **kw):
+        enc = generate.generate_gesture(audio, styles, netdir, data, res if audio is not None else None,
+                                        file_name=tag if audio is not None else None, **kw, **common)
+        if isinstance(enc, list):
+            assert len(enc) == sum(k.startswith(f"{tag}_encoding") for k in gd.files)
+            for i, e in enumerate(enc):
+                assert tuple(e.shape) == gd[f"{tag}_encoding{i}"].shape
+                assert float((e.cpu() - torch.as_tensor(gd[f"{tag}_encoding{i}"])).abs().max()) < 1e-4, tag
+        else:
+            assert tuple(enc.shape) == gd[f"{tag}_encoding"].shape, tag
+            assert float((enc.cpu() - torch.as_tensor(gd[f"{tag}_encoding"])).abs().max()) < 1e-4, tag
+        if audio is not None:
+            out = anim.bvh_load(res / (tag + ".bvh"))
+            assert out["rotations"].shape == gd[f"{tag}_rotations"].shape, tag          # frame count: bit-exact
+            ang = _bvh_angle_deg(out["rotations"], gd[f"{tag}_rotations"])
+            assert ang < 2e-2, (tag, ang)
+            np.testing.assert_allclose(out["positions"][:, 0], gd[f"{tag}_root_positions"], atol=2e-3, err_msg=tag)
+            assert (res / (tag + ".wav")).exists()
+        return enc
+
+    enc = run("stitch", WAV, two, net, style_encoding_type="example", blend_type="stitch", blend_ratio=ratio, first_pose=A)
+    # the per-frame encoding switches styles exactly at the reference's split frame
+    s0 = int(gd["split_135"][0][1])
+    ref_enc = torch.as_tensor(gd["stitch_encoding"])
+    assert float((ref_enc[0, s0 - 1] - ref_enc[0, s0]).abs().max()) > 1e-3         # (the fixture does switch there)
+    assert float((enc[0, s0 - 1] - enc[0, 0]).abs().max()) == 0.0 and float((enc[0, s0] - enc[0, -1]).abs().max()) == 0.0
+    run("add", WAV, two, net, style_encoding_type="example", blend_type="add", blend_ratio=ratio, first_pose=A)
+    run("label", WAV, [label], netl, style_encoding_type="label", blend_type="add", blend_ratio=[1.0], first_pose=Bx)
+    run("ndarray", WAV, [(emb, "given")], net, style_encoding_type="example", blend_type="add", blend_ratio=[1.0],
+        first_pose=Bx)
+    run("nofirst", WAV, [(A, None), (Bx, trim)], net, style_encoding_type="example", blend_type="add",
+        blend_ratio=[0.6, 0.4], first_pose=None)
+    run("noaudio_stitch", None, two, net, style_encoding_type="example", blend_type="stitch", blend_ratio=ratio)
+    run("noaudio_add", None, two, net, style_encoding_type="example", blend_type="add", blend_ratio=ratio)
+    run("noaudio_trim", None, [(Bx, trim)], net, style_encoding_type="example", blend_type="add", blend_ratio=[1.0])
+    # first_pose as an already-parsed clip dictionary (generate.py:316-317) = the same file given as a path
+    enc_d = generate.generate_gesture(WAV, [(emb, "given")], net, data, res, style_encoding_type="example", blend_type="add",
+                                      blend_ratio=[1.0], file_name="ndarray_dict", first_pose=anim.bvh_load(Bx), **common)
+    assert float((enc_d.cpu() - torch.as_tensor(gd["ndarray_encoding"])).abs().max()) < 1e-6
+    o = anim.bvh_load(res / "ndarray_dict.bvh")
+    assert _bvh_angle_deg(o["rotations"], gd["ndarray_rotations"]) < 2e-2
+    # default file name (generate.py:391-392): audio_<wav stem>_label_<style name>
+    generate.generate_gesture(WAV, [(emb, "given")], net, data, res, style_encoding_type="example", blend_type="add",
+                              blend_ratio=[1.0], first_pose=Bx, **common)
+    assert (res / "audio_a_label_given.bvh").exists() and (res / "audio_a_label_given.wav").exists()
+
+
 def test_train_api_runs_and_checkpoints(tmp_path):
     """train() with the reference's option dictionaries on a tiny synthetic dataset: runs, loss finite, writes
     the reference's checkpoint layout (incl. iteration 0), and the checkpoints load back into generate-able nets."""

@@ -482,6 +482,16 @@ extern "C" int zeggs_decoder_fwd_state(const ZeggsDecDims* dp, const ZeggsDecPar
   return decoder_fwd_impl(dp, P, st, pose0, rpos0, rrot0, gaze, speech, style, pose, rpos, rrot, 0, h_in, h_out, ws,
                           ws_bytes, stream, nullptr);
 }
+// the same with per-call controls: ZeggsDecCall.status receives the give-up bit of the B = 1 persistent kernel, so that a caller
+// that feeds the returned state into the NEXT chunk (zeggs/stream.py) can notice a rollout that did not complete and redo it
+extern "C" int zeggs_decoder_fwd_state_ex(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
+                                          const float* pose0, const float* rpos0, const float* rrot0, const float* gaze,
+                                          const float* speech, const float* style, float* pose, float* rpos, float* rrot,
+                                          const float* h_in, float* h_out, void* ws, size_t ws_bytes, void* stream,
+                                          const ZeggsDecCall* call) {
+  return decoder_fwd_impl(dp, P, st, pose0, rpos0, rrot0, gaze, speech, style, pose, rpos, rrot, 0, h_in, h_out, ws,
+                          ws_bytes, stream, call);
+}
 
 static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, const ZeggsDecStats* st,
                             const float* pose0, const float* rpos0, const float* rrot0, const float* gaze,
@@ -538,7 +548,7 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
   // ---- batch-1 inference: the weight-stationary persistent kernel (one launch for all frames, decode_persistent.hip)
   if (fast && !training && g_persistent && dec_persistent_state() != 0 && dec_persistent_supported(d, w)) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    hipStreamIsCapturing(s, &cap);
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;   // a failed query must not read as "not capturing"
     // the first use on a process is validated (device sync + error word); never inside a stream capture
     if (cap == hipStreamCaptureStatusNone || dec_persistent_state() == 1) {
       float* gin1 = w.Gin + slot(1) * sG;
@@ -564,7 +574,7 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
   // ---- training, batch <= 32: the forward rollout as one persistent launch (train_persistent.hip)
   if (fast && training && g_train_persistent && dec_tp_state() != 0 && dec_tp_supported(d, w)) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    hipStreamIsCapturing(s, &cap);
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;   // a failed query must not read as "not capturing"
     if (cap == hipStreamCaptureStatusNone || dec_tp_state() == 1) {
       float* gin1 = w.Gin + sG;
       ZTRY(gemm_nt(gin1 + H, GL, P->l0_w, XD, gin1, GL, P->l0_b, B, H, XD, ACT_ELU, 0.f, s));   // hid_1 = ELU(W0 x_1 + b0)
@@ -760,7 +770,7 @@ extern "C" int zeggs_decoder_bwd_ex(const ZeggsDecDims* dp, const ZeggsDecParams
   // ---- batch <= 32: the whole sweep as one persistent launch (train_bwd_persistent.hip)
   bool swept = false;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  hipStreamIsCapturing(s, &cap);
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;   // a failed query must not read as "not capturing"
   if (fast_path && g_bwd_persistent && dec_bp_state() != 0 && dec_bp_supported(d, w) &&
       (cap == hipStreamCaptureStatusNone || dec_bp_state() == 1)) {
     ZTRY(dec_bp_run(d, P, st, w, gaze, pose, rpos, rrot, dpose, drpos, drrot, s, bwd_prepared,

@@ -1118,7 +1118,7 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   ch.s[0] = ch.s[1] = s;
   {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    hipStreamIsCapturing(s, &cap);
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;   // a failed query must not read as "not capturing"
     const int per_wave = (w.KBH + w.KBX + w.KBH + 7) / 8;            // the widest stage (GRU layer 0)
     if (g_chain && gemv && T > 2 && cap == hipStreamCaptureStatusNone && per_wave <= CH_GPRE &&
         !(g_stage_variant & (16384 | V_NOW | V_NOEPI))) {

@@ -207,8 +207,14 @@ def flatten_parameters(modules):
 class TrainEngine:
     def __init__(self, speech_encoder, decoder, style_encoder, dataset, parents, dt, lr=1e-4, eps=1e-5,
                  style_encoding_type="example", world_size=1, rank=0, process_group=None, force_allreduce=False,
-                 overlap_allreduce=True, overlap_wgrads=True, early_decoder_step=True):
+                 overlap_allreduce=True, overlap_wgrads=True, early_decoder_step=True, noise_seed=None):
         self.se, self.de, self.st = speech_encoder, decoder, style_encoder
+        # everything the binding needs beyond the arguments of a call (gradient targets, side stream, status words, hooks,
+        # the prepared decoder workspace, optionally an own noise-seed stream) travels in THIS engine's context object --
+        # two engines stepping from two threads do not see each other's (ops.EngineContext)
+        self.ctx = ops.EngineContext()
+        if noise_seed is not None:
+            self.ctx.seed_rng = np.random.default_rng(int(noise_seed))
         self.early_decoder_step = early_decoder_step
         self.ds = dataset
         self.dt = float(dt)
@@ -251,6 +257,7 @@ class TrainEngine:
         self._status_ring = []
         self._history = collections.deque(maxlen=8)
         self.recovered_steps = 0
+        self.replayed = []                  # (iteration, loss, terms) of steps re-run by _recover(): for the caller's log
         import os
         if torch.device(dev).type == "cuda" and not os.environ.get("ZEGGS_NO_GUARD"):     # (env: A/B measurement of its cost)
             self.status = ops.new_status(dev)
@@ -334,16 +341,36 @@ class TrainEngine:
         self.opt.rewind(n)
         self._prefetched = None
         self.recovered_steps += n
+        rng = self.ctx.rng()
+        after = copy.deepcopy(rng.bit_generator.state)       # the stream continues where the (skipped) steps left it
         for h in redo:
-            ops._seed_rng.bit_generator.state = copy.deepcopy(h["seed_state"])
-            self.step(h["idx"], h["example_len"], eps=h["eps"], labels=h["labels"], _replay=True)
+            rng.bit_generator.state = copy.deepcopy(h["seed_state"])
+            loss = self.step(h["idx"], h["example_len"], eps=h["eps"], labels=h["labels"], _replay=True)
+            self.replayed.append((self.iteration - 1, loss, self.last_terms))
+        rng.bit_generator.state = after
+
+    def flush(self):
+        """Drain the give-up protocol NOW (a device synchronisation): _check_status() looks at an optimizer step STATUS_LAG
+        iterations after it ran, so steps skipped within the last STATUS_LAG iterations are still unknown to the host.  Call
+        before anything reads the weights for keeps -- a checkpoint, rendered samples, the end of training (zeggs.train does);
+        on every rank at the same iteration in data-parallel runs (all ranks skip the same steps).  Returns the number of steps
+        that were re-run."""
+        if self.status is None:
+            return 0
+        torch.cuda.synchronize()
+        n = int(self.status.cpu()[1])
+        if n > 0:
+            self._recover()
+        for slot in self._status_ring:
+            slot[1] = None
+        return n
 
     def step(self, idx, example_len, eps=None, labels=None, _replay=False):
         """One training iteration on window indices `idx` (this rank's slice). Returns the loss tensor (device)."""
         if self.status is not None and not _replay:
             self._check_status()
             self._history.append(dict(idx=np.array(idx, copy=True), example_len=example_len, eps=eps, labels=labels,
-                                      seed_state=copy.deepcopy(ops._seed_rng.bit_generator.state)))
+                                      seed_state=copy.deepcopy(self.ctx.rng().bit_generator.state)))
         ds, T = self.ds, self.ds.window
         ex_len = example_len if self.style_type == "example" else None
         pre, self._prefetched = self._prefetched, None
@@ -356,73 +383,80 @@ class TrainEngine:
         else:
             b = ds.batch(idx, ex_len)
         ops.fill_(self.flat_gx)
-        ops.direct_param_grads(True)        # *_bwd kernels write straight into the flat gradient buffer
-        ops.set_status(self.status)
+        ctx = self.ctx
+        ctx.direct_grads = True             # *_bwd kernels write straight into the flat gradient buffer
+        ctx.status = self.status
         overlap = self.overlap_allreduce and (self.world > 1 or self.force_allreduce)
         self._dec_work = None
-        if overlap:
-            ops.set_after_decoder_backward(self._reduce_decoder_grads)
-        ops.set_wgrad_stream(self.wgrad_stream)
+        ctx.after_decoder_backward = self._reduce_decoder_grads if overlap else None
+        ctx.wgrad_stream = self.wgrad_stream
+        ctx.decoder_grads_final = None
         if self.early_decoder_step and not overlap and self.world == 1 and not self.force_allreduce:
             # no exchange to wait for: the decoder's 88 % of the optimizer step (HBM-bound) runs on the weight-gradient stream as
             # soon as its gradients are final, underneath the encoders' backward (matrix-core-bound) instead of after it
             lo, hi = self._dec_range
-            ops.set_decoder_grads_final(lambda: self.opt.early((lo + 3) // 4 * 4, hi // 4 * 4))
+            ctx.decoder_grads_final = lambda: self.opt.early((lo + 3) // 4 * 4, hi // 4 * 4)
+        done = False
         try:
-            cur = torch.cuda.current_stream() if self.aux_stream is not None else None
-            if self.wgrad_stream is not None and self._dec_shape is not None and self._dec_shape[0] == len(idx):
-                # the weight-only packs of the decoder sweeps, beside the encoders' forward
-                Bd, SP, ST = self._dec_shape
-                ops.decoder_prepare(self.de, Bd, T, SP, ST, ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, self.dt,
-                                    self.wgrad_stream)
-            if self.aux_stream is not None:
-                self.aux_stream.wait_stream(cur)            # the batch was gathered on the current stream
-                b["audio"].record_stream(self.aux_stream)
-                with torch.cuda.stream(self.aux_stream):
+            with ops.use(ctx):
+                cur = torch.cuda.current_stream() if self.aux_stream is not None else None
+                if self.wgrad_stream is not None and self._dec_shape is not None and self._dec_shape[0] == len(idx):
+                    # the weight-only packs of the decoder sweeps, beside the encoders' forward
+                    Bd, SP, ST = self._dec_shape
+                    ops.decoder_prepare(self.de, Bd, T, SP, ST, ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, self.dt,
+                                        self.wgrad_stream)
+                if self.aux_stream is not None:
+                    self.aux_stream.wait_stream(cur)            # the batch was gathered on the current stream
+                    b["audio"].record_stream(self.aux_stream)
+                    with torch.cuda.stream(self.aux_stream):
+                        speech = self.se(b["audio"])
+                else:
                     speech = self.se(b["audio"])
-            else:
-                speech = self.se(b["audio"])
-            mu = logvar = None
-            if self.style_type == "example":
-                z, mu, logvar = self.st(b["example"], 1.0, eps=eps)
-            else:
-                z = labels
-            style = ops.broadcast_time(z, T)
-            if self.aux_stream is not None:
-                cur.wait_stream(self.aux_stream)
-                speech.record_stream(cur)
-            ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-            if self.decoder_fwd_events is not None:
-                e0 = ev()
-                e0.record()
-            self._dec_shape = (speech.shape[0], speech.shape[2], style.shape[2])
-            pose, orp, orr = ops.decoder_core(self.de, b["pose0"], b["rpos0"], b["rrot0"], b["gaze"], speech, style,
-                                              ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, self.dt)
-            if self.decoder_fwd_events is not None:
-                e1 = ev()
-                e1.record()
-                self.decoder_fwd_events.append((e0, e1))
-            klw = kl_div_weight(self.iteration) if mu is not None else 0.0
-            loss, terms = ops.training_loss(pose, orp, orr, b["pose"], b["rpos"], b["rrot"], b["gaze"], self.parents,
-                                            self.dt, mu, logvar, kl_weight=klw, gscale=1.0 / self.world,
-                                            unit_grad=True, truth_ws=b.get("loss_ws"))
-            if self.decoder_bwd_events is not None:
-                e2 = ev()
-                e2.record()
-            loss.backward(self._one)
-            if self.decoder_bwd_events is not None:
-                e3 = ev()
-                e3.record()
-                self.decoder_bwd_events.append((e2, e3))
+                mu = logvar = None
+                if self.style_type == "example":
+                    z, mu, logvar = self.st(b["example"], 1.0, eps=eps)
+                else:
+                    z = labels
+                style = ops.broadcast_time(z, T)
+                if self.aux_stream is not None:
+                    cur.wait_stream(self.aux_stream)
+                    speech.record_stream(cur)
+                ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+                if self.decoder_fwd_events is not None:
+                    e0 = ev()
+                    e0.record()
+                self._dec_shape = (speech.shape[0], speech.shape[2], style.shape[2])
+                pose, orp, orr = ops.decoder_core(self.de, b["pose0"], b["rpos0"], b["rrot0"], b["gaze"], speech, style,
+                                                  ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, self.dt)
+                if self.decoder_fwd_events is not None:
+                    e1 = ev()
+                    e1.record()
+                    self.decoder_fwd_events.append((e0, e1))
+                klw = kl_div_weight(self.iteration) if mu is not None else 0.0
+                loss, terms = ops.training_loss(pose, orp, orr, b["pose"], b["rpos"], b["rrot"], b["gaze"], self.parents,
+                                                self.dt, mu, logvar, kl_weight=klw, gscale=1.0 / self.world,
+                                                unit_grad=True, truth_ws=b.get("loss_ws"))
+                if self.decoder_bwd_events is not None:
+                    e2 = ev()
+                    e2.record()
+                loss.backward(self._one)
+                if self.decoder_bwd_events is not None:
+                    e3 = ev()
+                    e3.record()
+                    self.decoder_bwd_events.append((e2, e3))
+            done = True
         finally:
-            ops.direct_param_grads(False)
-            ops.set_after_decoder_backward(None)
-            ops.set_wgrad_stream(None)
-            ops.set_decoder_grads_final(None)
-            ops.set_status(None)
+            if not done:
+                # the step did not complete (OOM, an error in a backward, KeyboardInterrupt): forget the slices the optimizer
+                # may already have applied early -- a stale list would make the NEXT step() skip the decoder slice -- and give
+                # the decoder workspaces back once the side stream is done with them
+                self.opt._early = []
+                if self.wgrad_stream is not None:
+                    torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+                ctx.release_wgrad_workspaces()
         if self.wgrad_stream is not None:      # join: every decoder gradient is final from here on in stream order
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
-            ops.release_wgrad_workspaces()
+            ctx.release_wgrad_workspaces()
         if self.aux_stream is not None:        # ... and the speech encoder's
             torch.cuda.current_stream().wait_stream(self.aux_stream)
         if self.allreduce_events is not None:       # with the overlap on: the EXPOSED part of the exchange

@@ -235,8 +235,34 @@ class LinearNorm(nn.Module):
 
 
 # ----------------------------------------------------------------------------
-# free functions of the reference module namespace
+# free functions of the reference module namespace (ZEGGS/modules.py:673-813) -- what `from modules import ...` in the
+# reference's train.py:20-24 / generate.py resolves to when this module stands in for it (INTEGRATION.md route 2).
+# Same names, argument order and return values; the arithmetic runs in csrc/funcs.hip (forward + backward).
 # ----------------------------------------------------------------------------
+def normalize(x, eps: float = 1e-8):
+    """x / (||x|| + eps) over the last dimension (reference modules.py:673-675)"""
+    return ops.normalize_vec(x, eps)
+
+
+def vectorize_input(Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos, Z_ltxy, Z_lvel, Z_lvrt, Z_gaze_pos, parents,
+                    anim_input_mean, anim_input_std):
+    """The decoder's normalised autoregressive input [B, 1134] (reference modules.py:677-713; `parents` is unused there too)"""
+    return ops.vectorize_input(Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos, Z_ltxy, Z_lvel, Z_lvrt, Z_gaze_pos,
+                               anim_input_mean, anim_input_std)
+
+
+def devectorize_output(predicted, Z_root_pos, Z_root_rot, batchsize: int, njoints: int, dt: float, anim_output_mean,
+                       anim_output_std):
+    """De-normalise one decoder output and integrate the root (reference modules.py:716-742) ->
+    (P_root_pos, P_root_rot, P_root_vel, P_root_vrt, P_lpos, P_ltxy, P_lvel, P_lvrt)"""
+    pose, rpos, rrot = ops.devectorize_output(predicted, Z_root_pos, Z_root_rot, njoints, dt, anim_output_mean,
+                                              anim_output_std)
+    J, B = njoints, batchsize
+    return (rpos, rrot, pose[:, 0:3], pose[:, 3:6], pose[:, 6:6 + 3 * J].reshape(B, J, 3),
+            pose[:, 6 + 3 * J:6 + 9 * J].reshape(B, J, 2, 3), pose[:, 6 + 9 * J:6 + 12 * J].reshape(B, J, 3),
+            pose[:, 6 + 12 * J:6 + 15 * J].reshape(B, J, 3))
+
+
 def generalized_logistic_function(x, center=0.0, B=1.0, A=0.0, K=1.0, C=1.0, Q=1.0, nu=1.0):
     return A + (K - A) / (C + Q * math.exp(-B * (x - center))) ** (1 / nu)
 
@@ -244,3 +270,13 @@ def generalized_logistic_function(x, center=0.0, B=1.0, A=0.0, K=1.0, C=1.0, Q=1
 def kl_div_weight(iteration):
     """KL annealing weight of reference compute_KL_div (modules.py:773-788)."""
     return min(generalized_logistic_function(iteration, center=7500, B=0.005), 2e-1)
+
+
+def compute_KL_div(mu, logvar, iteration):
+    """-> (kl_div device scalar, kl_div_weight float) (reference modules.py:764-789)"""
+    return ops.kl_div(mu, logvar), kl_div_weight(iteration)
+
+
+def get_mask_from_lengths(lengths):
+    """bool mask [B, max(lengths)] (reference modules.py:802-813)"""
+    return ops.mask_from_lengths(lengths)

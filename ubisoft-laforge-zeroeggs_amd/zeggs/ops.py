@@ -86,6 +86,7 @@ def lib():
         k, v = kv.split("=")
         if L.zeggs_set_option(k.strip().encode(), int(v)) != 0:
             raise RuntimeError(f"ZEGGS_OPTIONS: {L.zeggs_last_error().decode()}")
+        _OPTIONS[k.strip()] = int(v)
     return L
 
 
@@ -122,55 +123,70 @@ _seed_rng = np.random.default_rng(0x5EED)
 
 
 def next_seed():
-    return int(_seed_rng.integers(1, 2 ** 62))
+    rng = current().seed_rng
+    return int((rng if rng is not None else _seed_rng).integers(1, 2 ** 62))
 
 
 def manual_seed(s):
-    """Seed of the dropout-mask stream (counter-based hash inside the kernels)."""
+    """Seed of the dropout-mask / VAE-noise stream (counter-based hash inside the kernels).  Process-wide default stream; an
+    EngineContext with its own `seed_rng` (TrainEngine(noise_seed=...)) draws from that instead."""
     global _seed_rng
     _seed_rng = np.random.default_rng(int(s))
 
 
-_DIRECT_GRADS = False
+# ----------------------------------------------------------------------------- per-engine call context
+# What a training loop needs beyond the arguments of a call -- where gradients are written, the stream of the deferred
+# weight-gradient GEMMs, the status words, hooks, a prepared workspace -- lives in an EngineContext OBJECT, not in module
+# globals: `with ops.use(ctx):` makes it the context of the calling THREAD, every autograd Function captures the context of its
+# forward and its backward (which autograd runs on another thread) uses that one.  Two engines stepping from two threads
+# therefore never see each other's switches (tests/test_gpu_streams.py::test_two_engines_on_two_threads).
+import threading  # noqa: E402
 
 
-def direct_param_grads(on):
-    """Training-engine mode: the *_bwd entry points write parameter gradients STRAIGHT into the parameters'
-    existing `.grad` tensors (views of the engine's flat gradient buffer) and the autograd Functions return None
-    for them, so no AccumulateGrad add runs.  Semantics are OVERWRITE (every parameter is used by exactly one
-    op per iteration), not accumulate -- only engine.TrainEngine turns this on.  The `.grad` tensors MUST be zero when the
-    backward starts (the engine zeroes its flat buffer once per step): the kernels are told so (`grads_zeroed`) and accumulate
-    onto them instead of zero-filling each one first."""
-    global _DIRECT_GRADS
-    _DIRECT_GRADS = bool(on)
+class EngineContext:
+    def __init__(self):
+        self.direct_grads = False          # *_bwd kernels write parameter gradients straight into the parameters' .grad
+        self.wgrad_stream = None           # torch stream of the decoder's deferred weight-gradient GEMMs (ZeggsDecCall)
+        self.status = None                 # device status words of the training-mode decoder calls (ZeggsDecCall.status)
+        self.after_decoder_backward = None # hook fn(part): decoder gradients final in stream order (data-parallel exchange)
+        self.decoder_grads_final = None    # hook fn(): runs on wgrad_stream behind ALL decoder gradients (early RAdam slice)
+        self.prepared = None               # (key, workspace, event, mask) of decoder_prepare, until a forward picks it up
+        self.prepared_hits = 0
+        self.wgrad_keepalive = []          # workspaces the deferred GEMMs still read, until the caller joined wgrad_stream
+        self.seed_rng = None               # own noise-seed generator (None: the process-wide stream of ops.manual_seed)
+
+    def release_wgrad_workspaces(self):
+        """After the caller has made its stream wait for wgrad_stream: the decoder workspaces the deferred weight-gradient
+        GEMMs were reading may go back to the allocator (kept alive here instead of `record_stream`-ed, see decoder_prepare)."""
+        self.wgrad_keepalive.clear()
+
+    def rng(self):
+        return self.seed_rng if self.seed_rng is not None else _seed_rng
 
 
-_AFTER_DECODER_BWD = None
+_DEFAULT_CTX = EngineContext()          # plain autograd use (tests, the reference's own loop): nothing special
+_tls = threading.local()
 
 
-def set_after_decoder_backward(fn):
-    """Engine hook: `fn(part)` runs when decoder parameter gradients of the iteration are final in stream order (the encoders'
-    backward follows) and engine.TrainEngine starts their all-reduce: part None = all of them (single-stream schedule, right
-    after zeggs_decoder_bwd); with the weight-gradient GEMMs on the side stream, part 0 = the parameters from GRU layer 1 on
-    in module order (layer2, CellStateEncoder), then part 1 = layer0 and GRU layer 0, whose GEMMs run underneath part 0's
-    exchange."""
-    global _AFTER_DECODER_BWD
-    _AFTER_DECODER_BWD = fn
+def current():
+    return getattr(_tls, "ctx", None) or _DEFAULT_CTX
 
 
-_DECODER_GRADS_FINAL = None
+class use:
+    """`with ops.use(ctx):` -- ctx is the EngineContext of this thread inside the block."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "ctx", None)
+        _tls.ctx = self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _tls.ctx = self.prev
 
 
-def set_decoder_grads_final(fn):
-    """Engine hook for the single-rank schedule with the weight-gradient GEMMs on the side stream: `fn()` runs with that stream
-    current, ordered behind ALL of the decoder's parameter gradients of the iteration (the deferred GEMMs and the
-    CellStateEncoder gradients of the caller's stream) -- engine.TrainEngine applies the decoder's slice of the optimizer step
-    there, underneath the encoders' backward."""
-    global _DECODER_GRADS_FINAL
-    _DECODER_GRADS_FINAL = fn
-
-
-_WGRAD_STREAM = None
 _SIDE_STREAMS = {}
 
 
@@ -186,25 +202,7 @@ def side_stream(device=None):
     return _SIDE_STREAMS[idx]
 
 
-_WGRAD_KEEPALIVE = []
-
-
-def release_wgrad_workspaces():
-    """After the caller has made its stream wait for side_stream(): the decoder workspaces the deferred weight-gradient GEMMs
-    were reading may go back to the allocator (they were kept alive here instead of `record_stream`-ed, see decoder_prepare)."""
-    _WGRAD_KEEPALIVE.clear()
-
-
-def set_wgrad_stream(stream):
-    """Engine hook (direct-gradient mode only): the decoder backward lets the library enqueue the weight-gradient GEMMs of
-    its recurrent layers on `stream` (ZeggsDecCall.defer_wgrads / .wgrad_stream), beside the encoders' backward; the CALLER
-    joins (`wait_stream`) before it reads a decoder gradient.  None: everything on the current stream."""
-    global _WGRAD_STREAM
-    _WGRAD_STREAM = stream
-
-
-_STATUS = None
-_INFER_STATUS = {}
+_PLAIN_STATUS = {}       # per device: status words of decoder calls made outside an engine context (inspected right away)
 
 
 def new_status(device):
@@ -214,17 +212,24 @@ def new_status(device):
     return t
 
 
-def set_status(status):
-    """Engine hook: the device status words the training-mode decoder calls report give-ups into (None: none)."""
-    global _STATUS
-    _STATUS = status
+def _plain_status(dev):
+    key = (dev.index, threading.get_ident())       # one word per device AND host thread: concurrent rollouts do not share it
+    st = _PLAIN_STATUS.get(key)
+    if st is None:
+        st = _PLAIN_STATUS[key] = new_status(dev)
+    return st
 
 
-def _grad_targets(orig_params, params):
-    """-> (tensors the backward kernel writes, values returned to autograd)"""
+def _grad_targets(orig_params, params, ectx):
+    """-> (tensors the backward kernel writes, values returned to autograd).  Direct mode (EngineContext.direct_grads, only
+    engine.TrainEngine turns it on): the *_bwd entry points write parameter gradients STRAIGHT into the parameters' existing
+    `.grad` tensors (views of the engine's flat gradient buffer) and the autograd Functions return None for them, so no
+    AccumulateGrad add runs.  Semantics are OVERWRITE (every parameter is used by exactly one op per iteration); the `.grad`
+    tensors MUST be zero when the backward starts (the engine zeroes its flat buffer once per step): the kernels are told so
+    (`grads_zeroed`) and accumulate onto them instead of zero-filling each one first."""
     outs, rets = [], []
     for o, t in zip(orig_params, params):
-        g = getattr(o, "grad", None) if _DIRECT_GRADS else None
+        g = getattr(o, "grad", None) if ectx.direct_grads else None
         if g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.shape == t.shape:
             outs.append(g)
             rets.append(None)
@@ -302,6 +307,7 @@ class _SpeechFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w0, b0, w1, b1, w2, b2, p, seed):
         x = _f32c(x)
+        ctx.ectx = current()
         ctx.orig = (w0, b0, w1, b1, w2, b2)
         params = [_f32c(t) for t in (w0, b0, w1, b1, w2, b2)]
         B, T, F = x.shape
@@ -320,10 +326,10 @@ class _SpeechFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, out, *params = ctx.saved_tensors
         L = lib()
-        grads, rets = _grad_targets(ctx.orig, params)
+        grads, rets = _grad_targets(ctx.orig, params, ctx.ectx)
         P = _ptrs(SpeechPtrs, SPEECH_FIELDS, params)
         G = _ptrs(SpeechPtrs, SPEECH_FIELDS, grads)
-        zeroed = int(_DIRECT_GRADS and all(r is None for r in rets))     # the engine zeroes its flat gradient buffer per step
+        zeroed = int(ctx.ectx.direct_grads and all(r is None for r in rets))     # the engine zeroes its flat gradient buffer per step
         _check(L.zeggs_speech_encoder_bwd_ex(C.byref(ctx.d), C.byref(P), _p(x), _p(out), _p(_f32c(dout)), C.byref(G),
                                              _p(ctx.ws), C.c_size_t(ctx.ws.numel()), _stream(), zeroed), "speech_encoder_bwd")
         return (None, *rets, None, None)
@@ -370,6 +376,7 @@ class _StyleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos, dropout, seed, nheads, *params):
         x = _f32c(x)
+        ctx.ectx = current()
         ctx.orig = params
         params = [_f32c(t) for t in params]
         B, Lx, Cx = x.shape
@@ -389,10 +396,10 @@ class _StyleFn(torch.autograd.Function):
     def backward(ctx, dout):
         params = list(ctx.saved_tensors)
         L = lib()
-        grads, rets = _grad_targets(ctx.orig, params)
+        grads, rets = _grad_targets(ctx.orig, params, ctx.ectx)
         P = _ptrs(StylePtrs, STYLE_FIELDS, params)
         G = _ptrs(StylePtrs, STYLE_FIELDS, grads)
-        zeroed = int(_DIRECT_GRADS and all(r is None for r in rets))
+        zeroed = int(ctx.ectx.direct_grads and all(r is None for r in rets))
         _check(L.zeggs_style_encoder_bwd_ex(C.byref(ctx.d), C.byref(P), _p(_f32c(dout)), C.byref(G), _p(ctx.ws),
                                             C.c_size_t(ctx.ws.numel()), _stream(), zeroed), "style_encoder_bwd")
         return (None, None, None, None, None, *rets)
@@ -411,6 +418,7 @@ class _StyleGruFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, *params):
         x = _f32c(x)
+        ctx.ectx = current()
         ctx.orig = params
         params = [_f32c(t) for t in params]
         B, Lx, Cx = x.shape
@@ -429,7 +437,7 @@ class _StyleGruFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         params = list(ctx.saved_tensors)
-        grads, rets = _grad_targets(ctx.orig, params)
+        grads, rets = _grad_targets(ctx.orig, params, ctx.ectx)
         P = _ptrs(StyleGruPtrs, STYLE_GRU_FIELDS, params)
         G = _ptrs(StyleGruPtrs, STYLE_GRU_FIELDS, grads)
         _check(lib().zeggs_style_encoder_gru_bwd(C.byref(ctx.d), C.byref(P), _p(_f32c(dout)), C.byref(G), _p(ctx.ws),
@@ -493,26 +501,21 @@ def decoder_param_list(dec):
     return ps
 
 
-_PREPARED = None
-prepared_hits = 0       # decoder forwards that picked up a workspace prepared on the side stream (tests / bench)
-
-
-def _drop_prepared():
+def _drop_prepared(ectx):
     """Forget a preparation nobody picked up (an eval / no_grad call, another batch size, an exception in between): the
     prepare kernels may still be WRITING the workspace on the side stream, and the block goes back to the current stream's
     pool -- so the current stream waits for them first."""
-    global _PREPARED
-    prep, _PREPARED = _PREPARED, None
+    prep, ectx.prepared = ectx.prepared, None
     if prep is not None:
         torch.cuda.current_stream().wait_event(prep[2])
 
 
 def decoder_prepare(dec, B, T, SP, ST, in_mean, in_std, out_mean, out_std, dt, stream):
-    """Weight-only preparation of the NEXT training-mode decoder_core call with these dimensions (zeggs_decoder_prepare) on
-    `stream`, beside whatever the current stream does meanwhile (the encoders' forward); that call picks the prepared
-    workspace up and waits for it.  The weights must not change in between."""
-    global _PREPARED
-    _drop_prepared()
+    """Weight-only preparation of the NEXT training-mode decoder_core call of THIS context (ops.use) with these dimensions
+    (zeggs_decoder_prepare) on `stream`, beside whatever the current stream does meanwhile (the encoders' forward); that
+    call picks the prepared workspace up and waits for it.  The weights must not change in between."""
+    ectx = current()
+    _drop_prepared(ectx)
     params = [_f32c(t) for t in decoder_param_list(dec)]
     stats = [_f32c(t) for t in (in_mean, in_std, out_mean, out_std)]
     PO, H = int(stats[2].numel()), dec.recurrent_decoder.layer1.hidden_size
@@ -533,8 +536,15 @@ def decoder_prepare(dec, B, T, SP, ST, in_mean, in_std, out_mean, out_std, dt, s
         ev.record(stream)
     if mask > 0:
         key = (d.B, d.T, d.PI, d.PO, d.SP, d.ST, d.H, d.film, tuple(t.data_ptr() for t in params))
-        _PREPARED = (key, ws, ev, int(mask))
+        ectx.prepared = (key, ws, ev, int(mask))
     return int(mask)
+
+
+def _warn_gave_up(bits, what):
+    import warnings
+    warnings.warn("zeggs: a persistent kernel gave up (" + ", ".join(n for b, n in GAVE_UP.items() if bits & b) +
+                  "; another tenant on the GPU?); it is disabled for this process and " + what +
+                  " is redone on the stage kernels")
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -543,6 +553,7 @@ class _DecoderFn(torch.autograd.Function):
                 *params):
         pose0, rpos0, rrot0, gaze, speech, style = (_f32c(t) for t in (pose0, rpos0, rrot0, gaze, speech, style))
         stats = [_f32c(t) for t in (in_mean, in_std, out_mean, out_std)]
+        ectx = ctx.ectx = current()
         ctx.orig = params
         params = [_f32c(t) for t in params]
         B, T, SP = speech.shape
@@ -552,18 +563,16 @@ class _DecoderFn(torch.autograd.Function):
         d = DecDims(B, T, PO + 3, PO, SP, ST, H, float(dt), 1 if len(params) == len(DEC_FIELDS) else 0)
         L = lib()
         dev = pose0.device
-        global _PREPARED
-        prep = _PREPARED
+        prep = ectx.prepared
         mask = 0
         if prep is not None and training and prep[0] == (d.B, d.T, d.PI, d.PO, d.SP, d.ST, d.H, d.film,
                                                          tuple(t.data_ptr() for t in params)):
-            _PREPARED = None
+            ectx.prepared = None
             _, ws, ev, mask = prep                          # packs of this step's weights, made on a second stream
-            global prepared_hits
-            prepared_hits += 1
+            ectx.prepared_hits += 1
             torch.cuda.current_stream().wait_event(ev)
         else:
-            _drop_prepared()                                # (waits for the side stream before the block is released)
+            _drop_prepared(ectx)                            # (waits for the side stream before the block is released)
             ws = _ws(L.zeggs_decoder_workspace_bytes(C.byref(d), int(training)), pose0.device)
         pose = torch.empty(B, T, PO, device=dev, dtype=torch.float32)
         rpos = torch.empty(B, T, 3, device=dev, dtype=torch.float32)
@@ -571,12 +580,21 @@ class _DecoderFn(torch.autograd.Function):
         P = _ptrs(DecPtrs, DEC_FIELDS, params)
         S = _ptrs(DecStats, ("in_mean", "in_std", "out_mean", "out_std"), stats)
         capturing = torch.cuda.is_current_stream_capturing()
+        # Give-up detection (ZeggsDecCall.status).  An engine passes ITS status words and looks at them itself (device-guarded
+        # optimizer step, lagged read-back: engine.TrainEngine).  Every other caller gets a per-thread word that is inspected
+        # right here, where a validated persistent kernel may have run: the outputs are consumed next (BVH export, sample
+        # rendering, the reference's own loss / optimizer) and nothing else would notice.  No read-back -- and no host
+        # synchronisation -- when no persistent kernel can have been involved, or inside a stream capture (there the NaN
+        # poisoning of the outputs is what is left).
+        own = None
         if training:
-            status = _STATUS
-        else:           # inference: a per-device status word, inspected right after the rollout (below)
-            status = _INFER_STATUS.get(dev.index)
-            if status is None and not capturing:
-                status = _INFER_STATUS[dev.index] = new_status(dev)
+            status = ectx.status
+            if status is None and not capturing and (_persistent_live(1) or _persistent_live(2)):
+                status = own = _plain_status(dev)
+        else:
+            status = None
+            if not capturing and B == 1 and _persistent_live(0):
+                status = own = _plain_status(dev)
         call = DecCall(int(mask) & 1, 0, None, status.data_ptr() if status is not None else None, 0)
 
         def run():
@@ -584,26 +602,22 @@ class _DecoderFn(torch.autograd.Function):
                                           _p(speech), _p(style), _p(pose), _p(rpos), _p(rrot), int(training), _p(ws),
                                           C.c_size_t(ws.numel()), _stream(), C.byref(call)), "decoder_fwd")
         run()
-        if not training and status is not None and not capturing:
-            # an inference rollout's outputs are consumed right away (BVH export, sample rendering): look at the sticky
-            # give-up word first.  (One 16-byte read-back per rollout; inside a capture the NaN poisoning is what is left.)
-            bits = int(status[0].item())
+        if own is not None:
+            bits = int(own[0].item())                      # one 4-byte read-back per rollout
             if bits:
-                import warnings
-                warnings.warn("zeggs: a persistent decode kernel gave up (" +
-                              ", ".join(n for b, n in GAVE_UP.items() if bits & b) +
-                              "; another tenant on the GPU?); it is disabled for this process and the rollout is redone "
-                              "on the stage kernels")
-                set_option("persistent", 0)
-                fill_(status.view(torch.float32))
+                _warn_gave_up(bits, "the rollout")
+                for name in ("persistent", "train_persistent", "bwd_persistent"):
+                    set_option(name, 0)
+                fill_(own.view(torch.float32))
+                call.prepared = 0
                 run()
         global _LAST_DECODER_WS
         if _CHAIN_DIAGNOSTICS:          # (diagnostic of the off-by-default "chain" option only: pins the workspace)
             _LAST_DECODER_WS = (d, int(training), ws)
         if training:
             ctx.d, ctx.ws = d, ws
-            ctx.status = status
-            ctx.bwd_prepared = bool(mask & 2)
+            ctx.status, ctx.own_status = status, own is not None
+            ctx.bwd_prepared = bool(mask & 2) and call.prepared != 0
             ctx.save_for_backward(gaze, pose, rpos, rrot, *stats, *params)
             ctx.set_materialize_grads(False)      # missing output gradients are zero-filled by our own kernel in backward
         return pose, rpos, rrot
@@ -613,44 +627,59 @@ class _DecoderFn(torch.autograd.Function):
         gaze, pose, rpos, rrot, *rest = ctx.saved_tensors
         stats, params = rest[:4], rest[4:]
         d = ctx.d
+        ectx = ctx.ectx
         L = lib()
         dev = pose.device
         z = lambda g, ref: fill_(torch.empty_like(ref)) if g is None else _f32c(g)  # noqa: E731
         dpose, drpos, drrot = z(dpose, pose), z(drpos, rpos), z(drrot, rrot)
-        grads, rets = _grad_targets(ctx.orig, params)
+        grads, rets = _grad_targets(ctx.orig, params, ectx)
         dspeech = torch.empty(d.B, d.T, d.SP, device=dev, dtype=torch.float32)
         dstyle = torch.empty(d.B, d.T, d.ST, device=dev, dtype=torch.float32)
         P = _ptrs(DecPtrs, DEC_FIELDS, params)
         G = _ptrs(DecPtrs, DEC_FIELDS, grads)
         S = _ptrs(DecStats, ("in_mean", "in_std", "out_mean", "out_std"), stats)
-        direct = _DIRECT_GRADS and all(r is None for r in rets)
-        side = _WGRAD_STREAM if direct and not torch.cuda.is_current_stream_capturing() else None
+        direct = ectx.direct_grads and all(r is None for r in rets)
+        side = ectx.wgrad_stream if direct and not torch.cuda.is_current_stream_capturing() else None
         # with a gradient exchange waiting (engine hook) the deferred GEMMs come in two halves of the parameter order, so that
         # the all-reduce of one runs underneath the GEMMs of the other
-        chunked = side is not None and _AFTER_DECODER_BWD is not None
+        after = ectx.after_decoder_backward
+        chunked = side is not None and after is not None
         call = DecCall(2 if ctx.bwd_prepared else 0, 0 if side is None else (2 if chunked else 1),
                        side.cuda_stream if side is not None else None,
                        ctx.status.data_ptr() if ctx.status is not None else None, int(direct))
-        _check(L.zeggs_decoder_bwd_ex(C.byref(d), C.byref(P), C.byref(S), _p(gaze), _p(pose), _p(rpos), _p(rrot),
-                                      _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
-                                      C.c_size_t(ctx.ws.numel()), _stream(), C.byref(call)), "decoder_bwd")
+
+        def run():
+            _check(L.zeggs_decoder_bwd_ex(C.byref(d), C.byref(P), C.byref(S), _p(gaze), _p(pose), _p(rpos), _p(rrot),
+                                          _p(dpose), _p(drpos), _p(drrot), C.byref(G), _p(dspeech), _p(dstyle), _p(ctx.ws),
+                                          C.c_size_t(ctx.ws.numel()), _stream(), C.byref(call)), "decoder_bwd")
+        run()
+        if ctx.own_status and not torch.cuda.is_current_stream_capturing():
+            # plain autograd use (no engine looking at the word later): the gradients go to the caller's optimizer next
+            bits = int(ctx.status[0].item())
+            if bits:
+                _warn_gave_up(bits, "the BPTT sweep")
+                for name in ("train_persistent", "bwd_persistent"):
+                    set_option(name, 0)
+                fill_(ctx.status.view(torch.float32))
+                call.prepared = 0
+                run()                   # the forward's saved activations are intact: only the sweep is repeated
         if side is not None:
             # the library has put the recurrent layers' weight-gradient GEMMs on its second stream (they read only what the
             # sweep left in the workspace), beside the CellStateEncoder / encoder backward on this one
-            _WGRAD_KEEPALIVE.append(ctx.ws)      # read by `side` until the caller joins it (release_wgrad_workspaces)
+            ectx.wgrad_keepalive.append(ctx.ws)      # read by `side` until the caller joins it (release_wgrad_workspaces)
             if chunked:
                 side.wait_stream(torch.cuda.current_stream())       # the CellStateEncoder gradients come from this stream
                 with torch.cuda.stream(side):
-                    _AFTER_DECODER_BWD(0)         # layer2, GRU layer 1, CellStateEncoder: final behind the GEMMs already on `side`
+                    after(0)         # layer2, GRU layer 1, CellStateEncoder: final behind the GEMMs already on `side`
                     _check(L.zeggs_decoder_wgrads(C.byref(d), C.byref(G), _p(ctx.ws), C.c_size_t(ctx.ws.numel()), 4 | 8,
                                                   C.c_void_p(side.cuda_stream)), "decoder_wgrads")
-                    _AFTER_DECODER_BWD(1)         # layer0, GRU layer 0
-            elif _DECODER_GRADS_FINAL is not None:
+                    after(1)         # layer0, GRU layer 0
+            elif ectx.decoder_grads_final is not None:
                 side.wait_stream(torch.cuda.current_stream())       # the CellStateEncoder gradients come from this stream
                 with torch.cuda.stream(side):
-                    _DECODER_GRADS_FINAL()
-        elif _AFTER_DECODER_BWD is not None and direct:
-            _AFTER_DECODER_BWD(None)
+                    ectx.decoder_grads_final()
+        elif after is not None and direct:
+            after(None)
         return (None, None, None, None, dspeech, dstyle, None, None, None, None, None, None, None, *rets)
 
 
@@ -690,6 +719,135 @@ def decoder_rollout(dec, Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos,
             pose[..., 6 + 3 * J:6 + 9 * J].reshape(B, T, J, 2, 3),
             pose[..., 6 + 9 * J:6 + 12 * J].reshape(B, T, J, 3),
             pose[..., 6 + 12 * J:6 + 15 * J].reshape(B, T, J, 3))
+
+
+# ----------------------------------------------------------------------------- free functions of the Networks layer
+# (reference ZEGGS/modules.py:673-813; csrc/funcs.hip).  Differentiable: the reference's own training loop (INTEGRATION.md
+# route 2) calls normalize / compute_KL_div inside its inline loss and back-propagates through them.
+class _NormalizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = _f32c(x)
+        W = x.shape[-1]
+        y = torch.empty_like(x)
+        _check(lib().zeggs_normalize_vec_fwd(_p(x), _p(y), C.c_long(x.numel() // max(W, 1)), W, C.c_float(eps), _stream()),
+               "normalize_vec_fwd")
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        W = x.shape[-1]
+        dx = torch.empty_like(x)
+        _check(lib().zeggs_normalize_vec_bwd(_p(x), _p(_f32c(dy)), _p(dx), C.c_long(x.numel() // max(W, 1)), W,
+                                             C.c_float(ctx.eps), _stream()), "normalize_vec_bwd")
+        return dx, None
+
+
+def normalize_vec(x, eps=1e-8):
+    """x / (||x||_2 + eps) over the last dimension (reference modules.py:673-675)"""
+    return _NormalizeFn.apply(x, float(eps))
+
+
+class _VectorizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, root_pos, root_rot, root_vel, root_vrt, lpos, ltxy, lvel, lvrt, gaze_pos, in_mean, in_std):
+        a = [_f32c(t) for t in (root_pos, root_rot, root_vel, root_vrt, lpos, ltxy, lvel, lvrt, gaze_pos)]
+        in_mean, in_std = _f32c(in_mean), _f32c(in_std)
+        B, J = a[4].shape[0], a[4].shape[1]
+        out = torch.empty(B, 9 + 15 * J, device=a[0].device, dtype=torch.float32)
+        _check(lib().zeggs_vectorize_input_fwd(B, J, *[_p(t) for t in a], _p(in_mean), _p(in_std), _p(out), _stream()),
+               "vectorize_input_fwd")
+        ctx.save_for_backward(a[0], a[1], a[8], in_std)
+        ctx.shapes = [t.shape for t in a]
+        ctx.dims = (B, J)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        root_pos, root_rot, gaze_pos, in_std = ctx.saved_tensors
+        B, J = ctx.dims
+        g = [torch.empty(sh, device=root_pos.device, dtype=torch.float32) for sh in ctx.shapes]
+        _check(lib().zeggs_vectorize_input_bwd(B, J, _p(root_pos), _p(root_rot), _p(gaze_pos), _p(in_std), _p(_f32c(dout)),
+                                               *[_p(t) for t in g], _stream()), "vectorize_input_bwd")
+        return (*g, None, None)
+
+
+def vectorize_input(root_pos, root_rot, root_vel, root_vrt, lpos, ltxy, lvel, lvrt, gaze_pos, in_mean, in_std):
+    """-> [B, 9 + 15 J] normalised autoregressive input (reference modules.py:677-713)"""
+    return _VectorizeFn.apply(root_pos, root_rot, root_vel, root_vrt, lpos, ltxy, lvel, lvrt, gaze_pos, in_mean, in_std)
+
+
+class _DevectorizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, predicted, root_pos, root_rot, J, dt, out_mean, out_std):
+        predicted, root_pos, root_rot, out_mean, out_std = (_f32c(t) for t in (predicted, root_pos, root_rot, out_mean,
+                                                                                 out_std))
+        B = predicted.shape[0]
+        dev = predicted.device
+        pose = torch.empty(B, 6 + 15 * J, device=dev, dtype=torch.float32)
+        nrp = torch.empty(B, 3, device=dev, dtype=torch.float32)
+        nrr = torch.empty(B, 4, device=dev, dtype=torch.float32)
+        _check(lib().zeggs_devectorize_output_fwd(B, J, C.c_float(dt), _p(predicted), _p(root_pos), _p(root_rot),
+                                                  _p(out_mean), _p(out_std), _p(pose), _p(nrp), _p(nrr), _stream()),
+               "devectorize_output_fwd")
+        ctx.save_for_backward(predicted, root_pos, root_rot, out_mean, out_std)
+        ctx.dims = (B, J, dt)
+        ctx.set_materialize_grads(False)
+        return pose, nrp, nrr
+
+    @staticmethod
+    def backward(ctx, dpose, dnrp, dnrr):
+        predicted, root_pos, root_rot, out_mean, out_std = ctx.saved_tensors
+        B, J, dt = ctx.dims
+        c = lambda g: _p(_f32c(g)) if g is not None else None  # noqa: E731
+        dpred, drp, drr = torch.empty_like(predicted), torch.empty_like(root_pos), torch.empty_like(root_rot)
+        _check(lib().zeggs_devectorize_output_bwd(B, J, C.c_float(dt), _p(predicted), _p(root_pos), _p(root_rot),
+                                                  _p(out_mean), _p(out_std), c(dpose), c(dnrp), c(dnrr), _p(dpred), _p(drp),
+                                                  _p(drr), _stream()), "devectorize_output_bwd")
+        return dpred, drp, drr, None, None, None, None
+
+
+def devectorize_output(predicted, root_pos, root_rot, njoints, dt, out_mean, out_std):
+    """-> pose [B, 6 + 15 J] (de-normalised output vector), new root_pos [B,3], new root_rot [B,4] (reference modules.py:716-742)"""
+    return _DevectorizeFn.apply(predicted, root_pos, root_rot, int(njoints), float(dt), out_mean, out_std)
+
+
+class _KLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        mu, logvar = _f32c(mu), _f32c(logvar)
+        out = torch.empty((), device=mu.device, dtype=torch.float32)
+        _check(lib().zeggs_kl_div_fwd(_p(mu), _p(logvar), mu.shape[0], mu.numel() // mu.shape[0], _p(out), _stream()),
+               "kl_div_fwd")
+        ctx.save_for_backward(mu, logvar)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mu, logvar = ctx.saved_tensors
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(logvar)
+        _check(lib().zeggs_kl_div_bwd(_p(mu), _p(logvar), mu.shape[0], mu.numel() // mu.shape[0], _p(_f32c(dout).reshape(1)),
+                                      _p(dmu), _p(dlv), _stream()), "kl_div_bwd")
+        return dmu, dlv
+
+
+def kl_div(mu, logvar):
+    """mean_b(-0.5 mean_s(1 + logvar - mu^2 - exp(logvar))) as a device scalar (reference modules.py:778-779)"""
+    return _KLFn.apply(mu, logvar)
+
+
+def mask_from_lengths(lengths):
+    """bool [B, max(lengths)]: position < length (reference modules.py:802-813; like the reference's `torch.arange(0,
+    max_len)` on a device scalar, sizing the result reads max(lengths) back to the host)"""
+    lengths = lengths.to(torch.int64).contiguous()
+    B = lengths.shape[0]
+    max_len = int(lengths.max().item())
+    mask = torch.empty(B, max_len, device=lengths.device, dtype=torch.uint8)
+    _check(lib().zeggs_mask_from_lengths(_p(lengths), B, max_len, _p(mask), _stream()), "mask_from_lengths")
+    return mask.view(torch.bool)
 
 
 # ----------------------------------------------------------------------------- loss
@@ -814,10 +972,22 @@ def normalize_rows_(x, mean, std):
     return x
 
 
+_OPTIONS = {}            # switches set through set_option / ZEGGS_OPTIONS (the library's defaults otherwise)
+_PERSISTENT_OPTION = ("persistent", "train_persistent", "bwd_persistent")
+
+
+def _persistent_live(which):
+    """True if persistent kernel `which` (0 B=1 decode, 1 training rollout, 2 BPTT sweep) is switched on and validated on this
+    process -- only then can a call have ended in an undetected give-up (an unvalidated kernel is checked, with a stream
+    synchronisation, by the library itself)."""
+    return _OPTIONS.get(_PERSISTENT_OPTION[which], 1) != 0 and lib().zeggs_persistent_state(which) == 1
+
+
 def set_option(name, value):
     """Runtime switches of the library (e.g. "decoder_fast": 1 packed stage kernels / 0 generic GEMM path)."""
     global _CHAIN_DIAGNOSTICS, _LAST_DECODER_WS
     _check(lib().zeggs_set_option(name.encode(), int(value)), "set_option")
+    _OPTIONS[name] = int(value)
     if name == "chain":
         _CHAIN_DIAGNOSTICS = bool(value)
         if not value:

@@ -59,6 +59,10 @@ class GestureStream:
         self.feats = torch.zeros(0, self.mel.n_mels + 1, device=self.dev)  # audio features of frames [0, n_feat)
         self.n_emitted = 0                                                # pose frames handed out so far (incl. frame 0)
         self.finished = False
+        # give-up word of THIS stream's decoder calls (ZeggsDecCall.status): the state a chunk returns is the input of the next
+        # one, so a rollout that did not complete must be noticed before it is carried forward (checked after every chunk)
+        self.status = ops.new_status(self.dev)
+        self.redone_chunks = 0
         self._L = ops.lib()
         self._L.zeggs_mel_frames_ready.restype = C.c_long
         self._L.zeggs_mel_range_workspace_bytes.restype = C.c_size_t
@@ -117,11 +121,24 @@ class GestureStream:
         rpos, rrot = torch.empty(1, N1, 3, device=self.dev), torch.empty(1, N1, 4, device=self.dev)
         h_out = torch.empty(2, 1, d.H, device=self.dev)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-        rc = L.zeggs_decoder_fwd_state(C.byref(d), C.byref(P), C.byref(S), p(self.pose), p(self.rpos), p(self.rrot), p(gaze),
-                                       p(sp), p(style), p(pose), p(rpos), p(rrot), p(self.h), p(h_out), p(ws),
-                                       C.c_size_t(ws.numel()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        if rc != 0:
-            raise RuntimeError("zeggs_decoder_fwd_state: " + L.zeggs_last_error().decode())
+        call = ops.DecCall(0, 0, None, self.status.data_ptr(), 0)
+
+        def run():
+            rc = L.zeggs_decoder_fwd_state_ex(C.byref(d), C.byref(P), C.byref(S), p(self.pose), p(self.rpos), p(self.rrot),
+                                              p(gaze), p(sp), p(style), p(pose), p(rpos), p(rrot), p(self.h), p(h_out), p(ws),
+                                              C.c_size_t(ws.numel()), C.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                              C.byref(call))
+            if rc != 0:
+                raise RuntimeError("zeggs_decoder_fwd_state_ex: " + L.zeggs_last_error().decode())
+        run()
+        if ops._persistent_live(0):       # a validated persistent kernel may have run: look at the word before the chunk's
+            bits = int(self.status[0].item())     # state becomes the next chunk's input (the frames go to the host anyway)
+            if bits:
+                ops._warn_gave_up(bits, "the chunk")
+                ops.set_option("persistent", 0)
+                ops.fill_(self.status.view(torch.float32))
+                self.redone_chunks += 1
+                run()                     # same inputs (self.pose / self.h are untouched so far), stage launches
         self.h = h_out
         self.pose, self.rpos, self.rrot = pose[:, -1].contiguous(), rpos[:, -1].contiguous(), rrot[:, -1].contiguous()
         out.setdefault("pose", []).append(pose[0, 1:])

@@ -210,12 +210,26 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
             if (iteration + 1) % 1000 == 0:
                 for g in eng.opt.param_groups:
                     g["lr"] *= train_options["learning_rate_decay"]
+            checkpoint = iteration % train_options["generate_samples_step"] == 0
+            if checkpoint:
+                # the weights are about to be read for keeps: drain the give-up protocol first (steps a persistent sweep lost
+                # within the last few iterations are re-run on the stage kernels NOW; every rank, same iteration)
+                eng.flush()
+            if eng.replayed:                 # steps the engine re-ran: their losses replace the NaN ones logged at the time
+                for it_r, loss_r, terms_r in eng.replayed:
+                    if scalars is not None:
+                        scalars.add(it_r, loss_r, terms_r)
+                    if rank == 0:
+                        print(f"\n| it {it_r} re-run on the stage kernels | loss {float(loss_r):.4f} |")
+                if eng.replayed[-1][0] == iteration:
+                    loss = eng.replayed[-1][1]
+                eng.replayed.clear()
             if scalars is not None:
                 scalars.add(iteration, loss, eng.last_terms)
             if rank == 0 and iteration % 50 == 0:
                 sys.stdout.write(f"\r| epoch {epoch} | it {iteration} | batch {bi}/{nb} | loss {float(loss):.4f} "
                                  f"| {datetime.datetime.now() - start} |")
-            if rank == 0 and iteration % train_options["generate_samples_step"] == 0:
+            if rank == 0 and checkpoint:
                 snap = [compact_copy(m) if m is not None else None for m in (se, de, st)]
                 osd = eng.opt.state_dict()                 # moments are views of the flat buffers: store them compact
                 osd["state"] = {k: {kk: (vv.detach().clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
@@ -235,6 +249,13 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
                 render_samples(logs_dir / "samples", iteration, ds, se, de, st, details, st_opt["example_length"])
             iteration += 1
         epoch += 1
+    eng.flush()                               # nothing skipped on the device may be left behind when train() returns
+    for it_r, loss_r, terms_r in eng.replayed:
+        if scalars is not None:
+            scalars.add(it_r, loss_r, terms_r)
+        if rank == 0:
+            print(f"\n| it {it_r} re-run on the stage kernels | loss {float(loss_r):.4f} |")
+    eng.replayed.clear()
     if scalars is not None:
         scalars.close()
     if rank == 0:
