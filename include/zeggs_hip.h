@@ -458,9 +458,21 @@ typedef struct {
 int zeggs_pose_to_bvh(const ZeggsBvhDims*, const float* root_pos, const float* root_rot, const float* lpos,
                       const float* ltxy, double* positions, double* euler_deg, void* stream);
 
+/* The same conversion for a CHUNK of a longer clip, written straight into the rows of the BVH motion block: table [T, 3 + 3J]
+ * float64 = [root position | euler angles of joint seq[0], seq[1], ...] with seq int32 [J] (device) = the file's hierarchy
+ * order (ZEGGS/anim/bvh.py save()); ref_root_pos [3] / ref_root_rot [4] (device, may be NULL = this chunk's frame 0) = frame 0
+ * of the WHOLE clip, which the re-basing of utils.py:60-66 refers to.  generate_gesture() converts, downloads and formats a
+ * chunk while the next one is being decoded. */
+int zeggs_pose_to_bvh_table(const ZeggsBvhDims*, const float* root_pos, const float* root_rot, const float* lpos,
+                            const float* ltxy, const float* ref_root_pos, const float* ref_root_rot, const int* seq,
+                            double* table, void* stream);
+
 /* HOST helper of write_bvh / bvh.save (ZEGGS/anim/bvh.py: one text row per frame, "%f" per channel, a space after every
  * number): appends (append != 0) or writes `rows` x `cols` HOST doubles to `path`.  No device work. */
 int zeggs_write_table_text(const char* path, int append, const double* table /* host */, long rows, int cols);
+/* the formatting half alone, into the caller's buffer (single-threaded, re-entrant: called from several host threads on row
+ * blocks, the caller writes the blocks in order); *written = bytes produced.  cap >= rows * (cols * 24 + 1) suffices. */
+int zeggs_format_table_text(const double* table /* host */, long rows, int cols, char* out, size_t cap, size_t* written);
 
 #ifdef __cplusplus
 }

@@ -89,3 +89,78 @@ def test_overlapped_allreduce_equals_the_single_collective():
         d = np.abs(a[r][0] - b[r][0]).max()
         assert d <= 1e-7, d          # split-K atomics in the prologue GEMMs: not bitwise run to run
         assert np.array_equal(a[r][0], a[0][0]) and np.array_equal(b[r][0], b[0][0])
+
+
+def _worker_full(rank, world, port, out):
+    """One rank of the 8-way split of the reference's recorded B = 32 x 256 iteration (full_train32.npz)."""
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path[:0] = [str(root), str(root / "ubisoft-laforge-zeroeggs_amd"), str(root / "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import helpers
+    from zeggs import engine, ops, synth
+    for k in ("train_persistent", "bwd_persistent", "persistent"):     # eight co-tenants of ONE GPU: stage launches
+        ops.set_option(k, 0)
+    dev = torch.device("cuda:0")
+    gd = np.load(helpers.GOLDEN / "full_train32.npz")
+    data = helpers.full_dataset(gd, "v1")
+    B, T, Lx = int(gd["B"]), int(gd["window"]), int(gd["example_length"])
+    per = B // world
+    se, de, st = helpers.build_nets()
+    se, de, st = se.to(dev).eval(), de.to(dev).train(), st.to(dev).eval()     # dropout was patched to identity in the fixture
+    ds = engine.DeviceDataset(data, T, dev)
+    eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, lr=1e-4, eps=1e-5, world_size=world, rank=rank)
+    idx = engine.shard_indices(np.asarray(gd["idx"]), 0, per, world, rank)     # rank r: the r-th contiguous slice (SURVEY 8(e))
+    eps = torch.as_tensor(gd["eps"][rank * per:(rank + 1) * per]).to(dev).contiguous()
+    loss = eng.step(idx, Lx, eps=eps)
+    eng.flush()
+    torch.cuda.synchronize()
+    take = lambda t: np.concatenate([x.detach().flatten()[torch.as_tensor(helpers.sample_idx(x.numel()), device=dev)]  # noqa: E731
+                                     .cpu().numpy() for x in t])
+    samples = take(eng.params)
+    grads = take([p.grad for p in eng.params])           # the flat gradient buffer after the exchange: the global-batch mean
+    fp = helpers.fingerprint(eng.flat_p)
+    out[rank] = (samples, float(loss), fp, grads)
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_reproduce_the_reference_b32_iteration():
+    """SURVEY 8(e)'s verification on the fixture that exists: EIGHT ranks (one GPU here, gloo over device tensors, per-rank
+    batch 4) whose global batch is exactly the 32 windows of full_train32.npz -- the reference's own recorded train()
+    iteration at B = 32 x 256, example length 384.  Every rank takes its contiguous slice, gradients are pre-scaled by 1/8 in
+    the loss kernel and exchanged by the engine's all-reduce schedule, the fused RAdam step runs everywhere: the weights of
+    every rank after the step must be bit-identical to each other and equal the REFERENCE's `weight_samples` (3e-7, the bound
+    of the single-process test), the mean of the rank losses the reference's loss."""
+    import helpers
+    world = 8
+    gd = np.load(helpers.GOLDEN / "full_train32.npz")
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_full, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert sorted(out.keys()) == list(range(world))
+    for r in range(1, world):
+        assert np.array_equal(out[r][0], out[0][0]) and np.array_equal(out[r][2], out[0][2])     # identical replicas
+    np.testing.assert_allclose(np.mean([out[r][1] for r in range(world)]), gd["loss"][0], rtol=2e-5)
+    np.testing.assert_allclose(out[0][0], gd["weight_samples"], atol=3e-7)
+    # the exchanged gradient (mean over the 8 shards) against the reference's B = 32 gradient, tensor by tensor: every sampled
+    # entry within 5e-4 of the tensor's largest sampled entry of the fp64 reference, or within 3x the reference's own fp32
+    # deviation from it
+    sizes = [len(helpers.sample_idx(p.numel())) for m in helpers.build_nets() for p in m.parameters()]
+    g8, g32, g64 = out[0][3], gd["grad_samples"].astype(np.float64), gd["grad_samples_fp64"]
+    assert g8.shape == g64.shape == (sum(sizes),)
+    off = 0
+    for i, n in enumerate(sizes):
+        sl = slice(off, off + n)
+        scale = max(1e-7, float(np.abs(g64[sl]).max()))
+        err, own = float(np.abs(g8[sl] - g64[sl]).max()) / scale, float(np.abs(g32[sl] - g64[sl]).max()) / scale
+        assert err < max(5e-4, 3 * own), (i, err, own)
+        off += n
+    # ... and the update itself (lr 1e-4 x the first, un-rectified RAdam step of a B = 32 mean gradient: ~1e-6, a few hundred
+    # ulps of the weights): the 8-rank update against the reference's update
+    init = np.concatenate([p.detach().flatten()[torch.as_tensor(helpers.sample_idx(p.numel()))].numpy()
+                           for m in helpers.build_nets() for p in m.parameters()])
+    moved = float(np.abs(gd["weight_samples"] - init).max())
+    assert moved > 3e-7, moved
+    assert np.abs((out[0][0] - init) - (gd["weight_samples"] - init)).max() <= 0.03 * moved + 8e-9

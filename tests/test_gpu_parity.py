@@ -547,6 +547,52 @@ def test_generate_gesture_branches_vs_reference(golden_dir, tmp_path):
     assert (res / "audio_a_label_given.bvh").exists() and (res / "audio_a_label_given.wav").exists()
 
 
+def test_generate_gesture_streaming_writer_equals_one_launch(golden_dir, tmp_path, monkeypatch):
+    """Long clips go through generate._decode_to_bvh_streaming (chunked persistent decode, BVH rows converted on the device per
+    chunk and formatted by host threads underneath the next chunks): the file it writes equals the one-launch path's -- same
+    header bytes, same frame count, joint rotations < 0.02 degrees, root positions 2e-3 -- for chunk sizes that do and do not
+    divide the clip, including a single chunk, and the first-pose exemplar is parsed once."""
+    import json
+    import scipy.io.wavfile as wavfile
+    from zeggs import anim, generate
+    gd = np.load(golden_dir / "generate.npz")
+    net, data, res = tmp_path / "net", tmp_path / "data", tmp_path / "res"
+    net.mkdir(), data.mkdir()
+    se, de, st = helpers.build_nets()
+    torch.save(se, net / "speech_encoder.pt"), torch.save(de, net / "decoder.pt"), torch.save(st, net / "style_encoder.pt")
+    np.savez(data / "stats.npz", **synth.make_stats())
+    json.dump(synth.data_definition(), open(data / "data_definition.json", "w"))
+    conf = dict(audio_conf=dict(pre_emphasis=False, pre_emph_coeff=0.97, centered=True, real_amplitude=True,
+                                normalize_mel_bins=True, normalize_range=True, min_clipping=1e-5, sampling_rate=16000,
+                                mel_fmin=20, mel_fmax=7600, n_mel_channels=80, filter_length=800, hop_length=200,
+                                resample_method="linear", normalize_loudness=False),
+                audio_feature_type=["mel_spec", "energy"])
+    json.dump(conf, open(data / "data_pipeline_conf.json", "w"))
+    wavfile.write(tmp_path / "a.wav", 16000, synth.synth_wav(16000 * 12 + 777, seed=31))        # 12 s -> 723 frames
+    (tmp_path / "ex.bvh").write_bytes(gd["exemplar_bvh"].tobytes())
+    kw = dict(style_encoding_type="example", blend_type="add", blend_ratio=[1.0], first_pose=tmp_path / "ex.bvh",
+              temperature=1e8, seed=1234)
+    loads = []
+    orig_load = anim.bvh_load
+    monkeypatch.setattr(anim, "bvh_load", lambda f: (loads.append(str(f)), orig_load(f))[1])
+    enc0 = generate.generate_gesture(tmp_path / "a.wav", [(tmp_path / "ex.bvh", None)], net, data, res, file_name="one", **kw)
+    assert len(loads) == 1, loads                 # style exemplar == first pose: parsed once
+    ref = anim.bvh_load(res / "one.bvh")
+    head_ref = open(res / "one.bvh").read().split("MOTION")[0]
+    for tag, chunk, block in (("c250", 250, 64), ("c361", 361, 1024), ("c1", 100000, 100)):
+        monkeypatch.setattr(generate, "STREAM_MIN_FRAMES", 100)
+        monkeypatch.setattr(generate, "STREAM_CHUNK", chunk)
+        monkeypatch.setattr(generate, "STREAM_BLOCK", block)
+        enc = generate.generate_gesture(tmp_path / "a.wav", [(tmp_path / "ex.bvh", None)], net, data, res, file_name=tag, **kw)
+        assert float((enc - enc0).abs().max()) < 1e-5
+        assert open(res / f"{tag}.bvh").read().split("MOTION")[0] == head_ref                  # hierarchy + offsets: same bytes
+        out = anim.bvh_load(res / f"{tag}.bvh")
+        assert out["rotations"].shape == ref["rotations"].shape == (723, 75, 3), out["rotations"].shape
+        assert _bvh_angle_deg(out["rotations"], ref["rotations"]) < 2e-2, tag
+        np.testing.assert_allclose(out["positions"][:, 0], ref["positions"][:, 0], atol=2e-3, err_msg=tag)
+        assert (res / f"{tag}.wav").read_bytes() == (tmp_path / "a.wav").read_bytes()
+
+
 def test_train_api_runs_and_checkpoints(tmp_path):
     """train() with the reference's option dictionaries on a tiny synthetic dataset: runs, loss finite, writes
     the reference's checkpoint layout (incl. iteration 0), and the checkpoints load back into generate-able nets."""

@@ -336,6 +336,41 @@ __global__ void pose_to_bvh_k(ZeggsBvhDims d, const float* root_pos, const float
   }
 }
 
+// The same conversion written straight into the BVH motion block's row layout: table[f] = [root position 3 | euler angles of
+// joint seq[0], seq[1], ... (hierarchy order of the file)], for a CHUNK of frames of a longer clip: the re-basing frame (frame 0
+// of the whole clip) is passed explicitly.  Lets generate_gesture() convert / download / format a chunk while the next one is
+// still being decoded.
+__global__ void pose_to_bvh_table_k(ZeggsBvhDims d, const float* root_pos, const float* root_rot, const float* lpos,
+                                    const float* ltxy, const float* ref_pos, const float* ref_rot, const int* seq,
+                                    double* table) {
+  const long n = (long)d.T * d.J;
+  const int cols = 3 + 3 * d.J;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % d.J);            // position in the file's joint order
+    const long f = i / d.J;
+    const int j = seq[k];
+    const long src = f * d.J + j;
+    const float* t = ltxy + src * 6;
+    DQ q = dq_from_xy(D3{(double)t[0], (double)t[1], (double)t[2]}, D3{(double)t[3], (double)t[4], (double)t[5]});
+    if (j == 0) {
+      D3 p = D3{(double)lpos[src * 3], (double)lpos[src * 3 + 1], (double)lpos[src * 3 + 2]};
+      DQ rr = DQ{(double)root_rot[f * 4], (double)root_rot[f * 4 + 1], (double)root_rot[f * 4 + 2], (double)root_rot[f * 4 + 3]};
+      D3 rp = D3{(double)root_pos[f * 3], (double)root_pos[f * 3 + 1], (double)root_pos[f * 3 + 2]};
+      if (d.rebase) {
+        const DQ r0 = dq_inv(DQ{(double)ref_rot[0], (double)ref_rot[1], (double)ref_rot[2], (double)ref_rot[3]});
+        const D3 p0 = D3{(double)ref_pos[0], (double)ref_pos[1], (double)ref_pos[2]};
+        const DQ sr = DQ{d.start_rot[0], d.start_rot[1], d.start_rot[2], d.start_rot[3]};
+        rp = dq_mul_vec(sr, dq_mul_vec(r0, rp - p0)) + D3{d.start_pos[0], d.start_pos[1], d.start_pos[2]};
+        rr = dq_mul(sr, dq_mul(r0, rr));
+      }
+      p = dq_mul_vec(rr, p) + rp;
+      q = dq_mul(rr, q);
+      st3(table + f * cols, p);
+    }
+    dq_to_euler_zyx_deg(q, table + f * cols + 3 + 3 * k);
+  }
+}
+
 struct AnimWs { double *lrot_raw, *dprev, *sign, *gz; SelState* sel; };
 AnimWs carve_anim(const ZeggsAnimDims& d, Arena& a) {
   AnimWs w;
@@ -394,5 +429,18 @@ extern "C" int zeggs_pose_to_bvh(const ZeggsBvhDims* dp, const float* root_pos, 
   hipLaunchKernelGGL(pose_to_bvh_k, grid_for((long)d.T * d.J, 256), dim3(256), 0, (hipStream_t)stream, d, root_pos,
                      root_rot, lpos, ltxy, positions, euler_deg);
   ZLAUNCH_CHECK("pose_to_bvh");
+  return 0;
+}
+
+extern "C" int zeggs_pose_to_bvh_table(const ZeggsBvhDims* dp, const float* root_pos, const float* root_rot, const float* lpos,
+                                       const float* ltxy, const float* ref_root_pos, const float* ref_root_rot, const int* seq,
+                                       double* table, void* stream) {
+  const ZeggsBvhDims& d = *dp;
+  ZCHECK(d.T >= 1 && d.J >= 1, "pose_to_bvh_table: empty clip");
+  ZCHECK(seq != nullptr && table != nullptr, "pose_to_bvh_table: seq / table missing");
+  hipLaunchKernelGGL(pose_to_bvh_table_k, grid_for((long)d.T * d.J, 256), dim3(256), 0, (hipStream_t)stream, d, root_pos,
+                     root_rot, lpos, ltxy, ref_root_pos ? ref_root_pos : root_pos, ref_root_rot ? ref_root_rot : root_rot, seq,
+                     table);
+  ZLAUNCH_CHECK("pose_to_bvh_table");
   return 0;
 }

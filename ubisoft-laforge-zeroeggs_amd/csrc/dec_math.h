@@ -7,8 +7,12 @@
 // that occurs in practice: two even polynomials in h^2 (truncation error 2.5e-8 / 2e-9 at h = 1, below fp32 rounding) instead of
 // sinf + cosf + a division (~200 instructions with their range reduction) in the epilogue of every output stage of the
 // persistent rollouts.  h >= 1: the library functions.
+// -DZEGGS_EXACT_SINCOS=1: always the library functions (A/B builds of tools/drift_ab.py).
+#ifndef ZEGGS_EXACT_SINCOS
+#define ZEGGS_EXACT_SINCOS 0
+#endif
 static __device__ __forceinline__ void d_sinc_cos(float h, float& sinc, float& c) {
-  if (h < 1.f) {
+  if (!ZEGGS_EXACT_SINCOS && h < 1.f) {
     const float u = h * h;
     sinc = 1.f + u * (-1.f / 6.f + u * (1.f / 120.f + u * (-1.f / 5040.f + u * (1.f / 362880.f + u * (-1.f / 39916800.f)))));
     c = 1.f + u * (-0.5f + u * (1.f / 24.f + u * (-1.f / 720.f + u * (1.f / 40320.f + u * (-1.f / 3628800.f + u * (1.f / 479001600.f))))));
@@ -27,6 +31,39 @@ static __device__ __forceinline__ Q4 quat_exp(V3 x) {
   float s, c;
   d_sinc_cos(h, s, c);
   return Q4{c, x.x * s, x.y * s, x.z * s};
+}
+
+// The root update  q' = quat_mul(quat_from_helical(u), q) = quat_mul(quat_exp(u / 2), q)  (ZEGGS/modules.py:739) as q + DELTA.
+// Written as a product, the scalar part of exp(x) -- cos|x| = 1 - |x|^2 / 2 + ..., |x| ~ 1e-3 per frame -- is rounded to the
+// fp32 grid around 1 (spacing 6e-8) BEFORE it multiplies q: an error of up to 3e-8 per frame that keeps its sign while the
+// root turns at a steady rate, i.e. the norm of the (never re-normalised) root quaternion drifts linearly, 1e-3 over the
+// 108 000 frames of a 30-minute decode, and every later root step is scaled by it -- the whole long-run drift of round 3
+// (tools/drift_ab.py: with the root update in float64 the deviation from the reference's fp64 run falls from 5e-2 to 2e-4;
+// exact gates / exact sin, cos / no algebraic folds change nothing).  The reference's own fp32 run has the same defect with
+// other rounding luck (3e-3).  Here cos|x| - 1 = -|x|^2 (1/2 - |x|^2 / 24 + ...) is formed at full relative precision and the
+// small correction DELTA = (cos|x| - 1) q + [ -e.qv, q.w e + e x qv ] is added to q with ONE (data-dependent, zero-mean)
+// rounding.  Same function as quat_mul(quat_exp(x), q) in exact arithmetic, both branches of quat_exp (tquat.py:94-99).
+static __device__ __forceinline__ Q4 quat_exp_mul(V3 x, Q4 q) {
+  const float u = x.x * x.x + x.y * x.y + x.z * x.z;
+  const float h = sqrtf(u);
+  float cm1, s;          // scalar part of exp(x) minus one; factor of the vector part
+  if (h < 1e-5f) {       // quat_normalize([1, x], eps = 1e-5) = [1, x] / (sqrt(1 + |x|^2) + 1e-5)
+    const float nm1 = 0.5f * u;                    // sqrt(1 + u) - 1 for u < 1e-10
+    const float ne = 1.f + (nm1 + 1e-5f);
+    s = 1.f / ne;
+    cm1 = -(nm1 + 1e-5f) * s;
+  } else if (!ZEGGS_EXACT_SINCOS && h < 1.f) {
+    s = 1.f + u * (-1.f / 6.f + u * (1.f / 120.f + u * (-1.f / 5040.f + u * (1.f / 362880.f + u * (-1.f / 39916800.f)))));
+    cm1 = u * (-0.5f + u * (1.f / 24.f + u * (-1.f / 720.f + u * (1.f / 40320.f + u * (-1.f / 3628800.f + u * (1.f / 479001600.f))))));
+  } else {
+    const float sh = sinf(0.5f * h);
+    s = sinf(h) / h;
+    cm1 = -2.f * sh * sh;
+  }
+  const V3 e = s * x, qv = v3(q.x, q.y, q.z);
+  const V3 c = cross(e, qv);
+  return Q4{q.w + (cm1 * q.w - dot(e, qv)), q.x + (cm1 * q.x + q.w * e.x + c.x), q.y + (cm1 * q.y + q.w * e.y + c.y),
+            q.z + (cm1 * q.z + q.w * e.z + c.z)};
 }
 
 // quat_exp and its backward for the SAME argument share the norm and its sine / cosine (the root-integration backward

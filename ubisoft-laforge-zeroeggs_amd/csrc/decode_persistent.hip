@@ -284,7 +284,7 @@ __global__ __launch_bounds__(PTHR, 2) void decode_persistent_k(PArgs a) {
         const V3 pos = v3(rt[4], rt[5], rt[6]);
         npos = quat_mul_vec(q, d.dt * v3(p[0], p[1], p[2])) + pos;
         const V3 uu = quat_mul_vec(q, d.dt * v3(p[3], p[4], p[5]));
-        nq = quat_mul(quat_exp(0.5f * uu), q);
+        nq = quat_exp_mul(0.5f * uu, q);
         if (next) {
           const V3 gd = quat_mul_vec(quat_inv(nq), v3(rt[7], rt[8], rt[9]) - npos);
           genc[0] = (gd.x - cg[0]) * cg[3];

@@ -194,9 +194,40 @@ __global__ void dec_devec_k(ZeggsDecDims d, ZeggsDecStats st, const float* y, in
     const float* rp = rpos + ((long)b * d.T + t - 1) * 3;
     Q4 q = Q4{rq[0], rq[1], rq[2], rq[3]};
     V3 pos = v3(rp[0], rp[1], rp[2]);
+#if defined(ZEGGS_ROOT_FP64) && ZEGGS_ROOT_FP64
+    // DIAGNOSTIC build (tools/drift_ab.py): the root integration of the generic path evaluated in float64 from the same fp32
+    // inputs, rounded once at the end -- separates "rounding inside the root integration" from everything else
+    V3 npos; Q4 nq;
+    {
+      auto qmv = [](const double* q4, const double* v, double* o) {
+        const double tx = 2.0 * (q4[2] * v[2] - q4[3] * v[1]), ty = 2.0 * (q4[3] * v[0] - q4[1] * v[2]),
+                     tz = 2.0 * (q4[1] * v[1] - q4[2] * v[0]);
+        o[0] = v[0] + q4[0] * tx + (q4[2] * tz - q4[3] * ty);
+        o[1] = v[1] + q4[0] * ty + (q4[3] * tx - q4[1] * tz);
+        o[2] = v[2] + q4[0] * tz + (q4[1] * ty - q4[2] * tx);
+      };
+      const double qd[4] = {q.w, q.x, q.y, q.z}, dtd = (double)d.dt;
+      const double v[3] = {dtd * p[0], dtd * p[1], dtd * p[2]}, w3[3] = {dtd * p[3], dtd * p[4], dtd * p[5]};
+      double o[3], u3[3];
+      qmv(qd, v, o);
+      npos = v3((float)(o[0] + pos.x), (float)(o[1] + pos.y), (float)(o[2] + pos.z));
+      qmv(qd, w3, u3);
+      const double hx = 0.5 * u3[0], hy = 0.5 * u3[1], hz = 0.5 * u3[2], h = sqrt(hx * hx + hy * hy + hz * hz);
+      double e[4];
+      if (h < 1e-5) { const double n = sqrt(1.0 + h * h) + 1e-5; e[0] = 1.0 / n; e[1] = hx / n; e[2] = hy / n; e[3] = hz / n; }
+      else { const double sc = sin(h) / h; e[0] = cos(h); e[1] = hx * sc; e[2] = hy * sc; e[3] = hz * sc; }
+      // quat_mul(e, q)
+      nq = Q4{(float)(qd[0] * e[0] - qd[1] * e[1] - qd[2] * e[2] - qd[3] * e[3]),
+              (float)(qd[0] * e[1] + qd[1] * e[0] - qd[2] * e[3] + qd[3] * e[2]),
+              (float)(qd[0] * e[2] + qd[1] * e[3] + qd[2] * e[0] - qd[3] * e[1]),
+              (float)(qd[0] * e[3] - qd[1] * e[2] + qd[2] * e[1] + qd[3] * e[0])};
+    }
+    V3 u = v3(0.f, 0.f, 0.f); (void)u;
+#else
     V3 npos = quat_mul_vec(q, d.dt * v3(p[0], p[1], p[2])) + pos;
     V3 u = quat_mul_vec(q, d.dt * v3(p[3], p[4], p[5]));
-    Q4 nq = quat_mul(quat_exp(0.5f * u), q);
+    Q4 nq = quat_exp_mul(0.5f * u, q);
+#endif
     float* op = rpos + ((long)b * d.T + t) * 3; op[0] = npos.x; op[1] = npos.y; op[2] = npos.z;
     float* oq = rrot + ((long)b * d.T + t) * 4; oq[0] = nq.w; oq[1] = nq.x; oq[2] = nq.y; oq[3] = nq.z;
     if (gin_next) {

@@ -118,7 +118,7 @@ __global__ void devectorize_fwd_k(int B, int PO, float dt, const float* pred, co
     V3 pos = v3(root_pos[b * 3], root_pos[b * 3 + 1], root_pos[b * 3 + 2]);
     V3 np = quat_mul_vec(q, dt * v3(p[0], p[1], p[2])) + pos;
     V3 u = quat_mul_vec(q, dt * v3(p[3], p[4], p[5]));
-    Q4 nq = quat_mul(quat_exp(0.5f * u), q);
+    Q4 nq = quat_exp_mul(0.5f * u, q);
     nrpos[b * 3] = np.x; nrpos[b * 3 + 1] = np.y; nrpos[b * 3 + 2] = np.z;
     nrrot[b * 4] = nq.w; nrrot[b * 4 + 1] = nq.x; nrrot[b * 4 + 2] = nq.y; nrrot[b * 4 + 3] = nq.z;
   }

@@ -64,3 +64,24 @@ extern "C" int zeggs_write_table_text(const char* path, int append, const double
   ZCHECK(fclose(f) == 0, "write_table_text: close failed for %s", path);
   return 0;
 }
+
+// The formatting half alone: rows x cols HOST doubles -> text in the caller's buffer (same "%f " per number, '\n' per row).
+// Single-threaded and re-entrant: generate_gesture() calls it from several host threads on row blocks of the chunks a running
+// decode has already delivered, and writes the blocks in order itself.  *written = bytes produced; -1 if `cap` is too small
+// (cap >= rows * (cols * 24 + 1) always suffices for |values| < 1e15).
+extern "C" int zeggs_format_table_text(const double* table, long rows, int cols, char* out, size_t cap, size_t* written) {
+  ZCHECK(table && out && written && rows >= 0 && cols > 0, "format_table_text: bad arguments");
+  char* p = out;
+  char* const end = out + cap;
+  for (long r = 0; r < rows; ++r) {
+    const double* row = table + r * cols;
+    for (int c = 0; c < cols; ++c) {
+      ZCHECK(end - p > 330, "format_table_text: buffer too small (%zu bytes for %ld x %d)", cap, rows, cols);
+      p += snprintf(p, 328, "%f", row[c]);
+      *p++ = ' ';
+    }
+    *p++ = '\n';
+  }
+  *written = (size_t)(p - out);
+  return 0;
+}

@@ -805,7 +805,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
         const V3 pos = rp_;
         const V3 npos = quat_mul_vec(q, d.dt * v3(p[0], p[1], p[2])) + pos;
         const V3 uu = quat_mul_vec(q, d.dt * v3(p[3], p[4], p[5]));
-        const Q4 nq = quat_mul(quat_exp(0.5f * uu), q);
+        const Q4 nq = quat_exp_mul(0.5f * uu, q);
         rq_ = nq; rp_ = npos;
         float genc[3] = {0.f, 0.f, 0.f};
         if (next) {

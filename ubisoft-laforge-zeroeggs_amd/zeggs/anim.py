@@ -74,12 +74,12 @@ def bvh_load(filename):
                 names=names, order=order or "zyx", frametime=frametime)
 
 
-def bvh_save(filename, data):
-    """Writes root with 6 channels and every other joint with 3 (reference bvh.save, translations=False)."""
-    rots, poss, offsets = np.asarray(data["rotations"]), np.asarray(data["positions"]), np.asarray(data["offsets"])
-    parents = list(data["parents"])
-    names = data.get("names") or [f"joint_{i}" for i in range(len(parents))]
-    order = data.get("order", "zyx")
+def bvh_header(offsets, parents, names=None, order="zyx", nframes=0, frametime=1.0 / 60.0):
+    """-> (text of the HIERARCHY block + the MOTION head, joint order of the motion rows) as reference bvh.save writes them
+    (root with 6 channels, every other joint with 3, translations=False)."""
+    offsets = np.asarray(offsets)
+    parents = list(parents)
+    names = names or [f"joint_{i}" for i in range(len(parents))]
     rot_ch = " ".join(_CHAN_INV[c] for c in order)
     children = {i: [j for j, p in enumerate(parents) if p == i] for i in range(len(parents))}
     seq, out = [], ["HIERARCHY"]
@@ -102,19 +102,41 @@ def bvh_save(filename, data):
         out.append(ind + "}")
 
     emit(0, 0)
-    out += ["MOTION", "Frames: %i" % len(rots), "Frame Time: %f" % data.get("frametime", 1.0 / 60.0)]
-    # motion block: one row per frame = root position + the rotations in hierarchy order (formatted in C by savetxt)
+    out += ["MOTION", "Frames: %i" % nframes, "Frame Time: %f" % frametime]
+    return "\n".join(out) + "\n", seq
+
+
+def bvh_save(filename, data):
+    """Writes root with 6 channels and every other joint with 3 (reference bvh.save, translations=False)."""
+    rots, poss = np.asarray(data["rotations"]), np.asarray(data["positions"])
+    head, seq = bvh_header(data["offsets"], data["parents"], data.get("names"), data.get("order", "zyx"), len(rots),
+                           data.get("frametime", 1.0 / 60.0))
+    # motion block: one row per frame = root position + the rotations in hierarchy order
     table = np.concatenate([np.asarray(poss[:, 0], np.float64).reshape(len(rots), 3)] +
                            [np.asarray(rots[:, j], np.float64).reshape(len(rots), 3) for j in seq], axis=1)
     with open(filename, "w") as fh:
-        fh.write("\n".join(out) + "\n")
-    # the motion block is formatted by the library's host helper (same correctly-rounded "%f" as the line above would give
-    # through numpy.savetxt, ten times faster: a 30-minute clip is 24.6 M numbers)
+        fh.write(head)
+    # the motion block is formatted by the library's host helper (same correctly-rounded "%f" as numpy.savetxt gives, ten
+    # times faster: a 30-minute clip is 24.6 M numbers)
     table = np.ascontiguousarray(table, dtype=np.float64)
     rc = ops.lib().zeggs_write_table_text(str(filename).encode(), 1, table.ctypes.data_as(C.c_void_p), C.c_long(table.shape[0]),
                                           int(table.shape[1]))
+    if rc != 0:      # as np.savetxt / open() would: an OSError, which generate_gesture() reports and survives (generate.py:407)
+        raise OSError("zeggs_write_table_text: " + ops.lib().zeggs_last_error().decode())
+
+
+def format_rows(table):
+    """host float64 [rows, cols] (C-contiguous; e.g. a view of a pinned staging buffer) -> bytes of the BVH motion rows
+    (zeggs_format_table_text: releases the GIL, so several host threads format row blocks side by side)"""
+    rows, cols = table.shape
+    cap = rows * (cols * 24 + 1) + 400
+    buf = C.create_string_buffer(cap)
+    n = C.c_size_t(0)
+    ptr = table.ctypes.data_as(C.c_void_p) if isinstance(table, np.ndarray) else C.c_void_p(table.data_ptr())
+    rc = ops.lib().zeggs_format_table_text(ptr, C.c_long(rows), int(cols), buf, C.c_size_t(cap), C.byref(n))
     if rc != 0:
-        raise RuntimeError("zeggs_write_table_text: " + ops.lib().zeggs_last_error().decode())
+        raise RuntimeError("zeggs_format_table_text: " + ops.lib().zeggs_last_error().decode())
+    return buf.raw[:n.value]
 
 
 # ----------------------------------------------------------------------------- device kernels (csrc/anim.hip)

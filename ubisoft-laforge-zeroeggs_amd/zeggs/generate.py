@@ -70,6 +70,115 @@ def _example_features(p):
                      [torch.zeros(n, 3, dtype=torch.float32, device=root_vel.device)], dim=1)
 
 
+STREAM_MIN_FRAMES = 20000     # clips longer than this are decoded chunk by chunk with the BVH text written meanwhile
+STREAM_CHUNK = 8192
+STREAM_BLOCK = 1024           # rows per formatting task (host threads)
+
+
+def _decode_to_bvh_streaming(decoder, pose0, rpos0, rrot0, gaze_row, speech, style, stats, dt, path, parents, names,
+                             chunk=None, block=None, threads=None):
+    """Long clips (configs[4]: 108 000 frames): the B = 1 rollout runs as a sequence of persistent launches of `chunk` frames,
+    each resumed from the state of the one before (zeggs_decoder_fwd_state_ex); behind every chunk its frames are converted to
+    the rows of the BVH motion block ON THE DEVICE (zeggs_pose_to_bvh_table), downloaded on a copy stream into pinned memory
+    and formatted by host threads (zeggs_format_table_text) WHILE the next chunks are being decoded; this thread writes the
+    text blocks in order.  Same file as the one-launch path (decoder -> bvh_channels -> write_bvh_channels) up to the fp32
+    re-association at the chunk boundaries (joint rotations < 0.02 degrees apart, as any chunking of zeggs/stream.py):
+    tests/test_gpu_parity.py::test_generate_gesture_streaming_writer_equals_one_launch.  The decoder's frames are not kept
+    (488 MB for 30 minutes).  Give-ups of the persistent kernel are collected in one status word that is looked at ONCE, after
+    the last chunk: then everything is redone on the stage launches."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from . import ops
+    chunk, block = chunk or STREAM_CHUNK, block or STREAM_BLOCK
+    dev = speech.device
+    T = speech.shape[1]
+    J = len(parents)
+    in_mean, in_std, out_mean, out_std = stats
+    L = ops.lib()
+    cols = 3 + 3 * J
+    # frame 0 is the given first pose: its joint positions are the OFFSETs of the file (utils.write_bvh: offsets = positions[0])
+    sl = lambda a, b: pose0[:, a:b]  # noqa: E731
+    pos0, _ = anim.bvh_channels(rpos0, rrot0, sl(6, 6 + 3 * J).reshape(1, J, 3), sl(6 + 3 * J, 6 + 9 * J).reshape(1, J, 2, 3),
+                                np.array([0, 0, 0]), np.array([1, 0, 0, 0]))
+    head, seq = anim.bvh_header(pos0[0].cpu().numpy(), parents, names, "zyx", T, dt)
+    seq_dev = torch.as_tensor(np.asarray(seq, np.int32), device=dev)
+    d = anim.BvhDims(0, J, 1)
+    d.start_pos[:] = [0.0, 0.0, 0.0]
+    d.start_rot[:] = [1.0, 0.0, 0.0, 0.0]
+    ref_pos, ref_rot = rpos0.to(torch.float32).contiguous(), rrot0.to(torch.float32).contiguous()
+    copy_stream = torch.cuda.Stream(device=dev)
+    status = ops.new_status(dev)
+    main = torch.cuda.current_stream()
+
+    def run(pool):
+        """enqueue everything; -> list of (pinned table, event) per chunk"""
+        staged = []
+        state = (pose0, rpos0, rrot0, None)
+        k = 0                                            # last frame produced so far
+        while k < T - 1 or not staged:
+            n = min(chunk, T - 1 - k)                    # new frames of this chunk
+            sp, sty = speech[:, k:k + n + 1], style[:, k:k + n + 1]
+            gz = gaze_row.expand(n + 1, 3)[None]
+            if n > 0:
+                pose, rpos, rrot, h = ops.decoder_chunk(decoder, state[0], state[1], state[2], gz, sp, sty, in_mean, in_std,
+                                                        out_mean, out_std, dt, h_in=state[3], status=status)
+                state = (pose[:, -1], rpos[:, -1], rrot[:, -1], h)
+            else:                                        # a one-frame clip
+                pose, rpos, rrot = pose0[:, None], rpos0[:, None], rrot0[:, None]
+            lo = 0 if k == 0 else 1                      # (frame 0 of a later chunk was written with the chunk before)
+            rows = n + 1 - lo
+            table = torch.empty(rows, cols, dtype=torch.float64, device=dev)
+            d.T = rows
+            # (named, not temporaries: a tensor freed between two argument expressions hands its block to the next one)
+            P = pose[0, lo:]
+            a_rpos, a_rrot = rpos[0, lo:].contiguous(), rrot[0, lo:].contiguous()
+            a_lpos, a_ltxy = P[:, 6:6 + 3 * J].contiguous(), P[:, 6 + 3 * J:6 + 9 * J].contiguous()
+            rc = L.zeggs_pose_to_bvh_table(C.byref(d), C.c_void_p(a_rpos.data_ptr()), C.c_void_p(a_rrot.data_ptr()),
+                                           C.c_void_p(a_lpos.data_ptr()), C.c_void_p(a_ltxy.data_ptr()),
+                                           C.c_void_p(ref_pos.data_ptr()), C.c_void_p(ref_rot.data_ptr()),
+                                           C.c_void_p(seq_dev.data_ptr()), C.c_void_p(table.data_ptr()),
+                                           C.c_void_p(main.cuda_stream))
+            del a_rpos, a_rrot, a_lpos, a_ltxy
+            if rc != 0:
+                raise RuntimeError("zeggs_pose_to_bvh_table: " + L.zeggs_last_error().decode())
+            done = torch.cuda.Event()
+            done.record(main)
+            host = torch.empty(rows, cols, dtype=torch.float64).pin_memory()
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done)
+                host.copy_(table, non_blocking=True)
+                table.record_stream(copy_stream)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+
+            def fmt(host=host, ev=ev, r0=0, r1=0):
+                ev.synchronize()
+                return anim.format_rows(host[r0:r1].numpy())
+            staged.append([pool.submit(fmt, r0=r0, r1=min(r0 + block, rows)) for r0 in range(0, rows, block)])
+            k += n
+            if n == 0:
+                break
+        return staged
+
+    with ThreadPoolExecutor(max_workers=threads or min(16, (__import__("os").cpu_count() or 4))) as pool:
+        staged = run(pool)
+        with open(path, "wb") as fh:
+            fh.write(head.encode())
+            for futs in staged:
+                for f in futs:
+                    fh.write(f.result())
+        if ops._persistent_live(0) and int(status[0].item()):     # (every chunk has been downloaded by now: no extra wait)
+            ops._warn_gave_up(int(status[0].item()), "the whole rollout")
+            ops.set_option("persistent", 0)
+            ops.fill_(status.view(torch.float32))
+            staged = run(pool)
+            with open(path, "wb") as fh:
+                fh.write(head.encode())
+                for futs in staged:
+                    for f in futs:
+                        fh.write(f.result())
+
+
 def generate_gesture(audio_file, styles, network_path, data_path, results_path, style_encoding_type="example",
                      blend_type="add", blend_ratio=[0.5, 0.5], file_name=None, first_pose=None, temperature=1.0,
                      seed=1234, use_gpu=True, use_script=False):
@@ -120,6 +229,7 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
 
         encodings, feat = [], None
         anim_name = "style"
+        parsed = {}                     # exemplar files already parsed in this call: (path, trim) -> feature arrays
         for style in styles:
             if style_encoding_type == "example":
                 if isinstance(style[0], (pathlib.PurePath, str)):
@@ -132,6 +242,7 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
                     assert int(np.ceil(1 / clip["frametime"])) == 60
                     with _stage("exemplar_features_device"):
                         feat = anim.preprocess_animation(clip, device)
+                        parsed[(str(Path(style[0]).resolve()), None if style[1] is None else tuple(style[1]))] = feat
                         ex = (_example_features(feat) - in_mean) / in_std
                     with _stage("style_encoder_device"):
                         z, _, _ = style_net(ex[None].contiguous(), temperature)
@@ -164,22 +275,46 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
 
         if audio_file is not None:
             if first_pose is not None:
-                with _stage("first_pose_bvh_parse_host"):
-                    clip = anim.bvh_load(first_pose) if isinstance(first_pose, (pathlib.PurePath, str)) else dict(first_pose)
-                with _stage("first_pose_features_device"):
-                    feat = anim.preprocess_animation(clip, device)
+                key = (str(Path(first_pose).resolve()), None) if isinstance(first_pose, (pathlib.PurePath, str)) else None
+                if key in parsed:       # the first pose is an (untrimmed) style exemplar of this call: parsed already
+                    feat = parsed[key]
+                else:
+                    with _stage("first_pose_bvh_parse_host"):
+                        clip = anim.bvh_load(first_pose) if key is not None else dict(first_pose)
+                    with _stage("first_pose_features_device"):
+                        feat = anim.preprocess_animation(clip, device)
             g = lambda a: a[0:1].to(torch.float32).contiguous()  # noqa: E731
             root_pos, root_rot, root_vel, root_vrt, lpos, lrot, ltxy, lvel, lvrt = feat[:9]
             gaze_pos = feat[14]
             if final.dim() == 2:
                 final = final.unsqueeze(1).repeat(1, speech.shape[1], 1)
-            gaze = g(gaze_pos).repeat(speech.shape[1], 1)[None]
+            if file_name is None:
+                file_name = f"audio_{Path(audio_file).stem}_label_{anim_name}"
+            T = speech.shape[1]
+            film = hasattr(decoder.recurrent_decoder, "gammas_predictor")
+            if T > STREAM_MIN_FRAMES and not film:
+                # long clip: chunked persistent decode with the BVH text formatted and written underneath it
+                pose0 = torch.cat([g(x).reshape(1, -1) for x in (root_vel, root_vrt, lpos, ltxy, lvel, lvrt)], dim=1)
+                copier = None
+                try:
+                    import threading
+                    copier = threading.Thread(target=copyfile, args=(audio_file, str(results_path / (file_name + ".wav"))))
+                    copier.start()
+                    with _stage("decode_device+bvh_text_write_host(overlapped)"):
+                        _decode_to_bvh_streaming(decoder, pose0, g(root_pos), g(root_rot), g(gaze_pos), speech,
+                                                 final.contiguous(), (in_mean, in_std, out_mean, out_std), dt,
+                                                 str(results_path / (file_name + ".bvh")), parents, bone_names)
+                except (PermissionError, OSError) as e:
+                    print(e)
+                finally:
+                    if copier is not None:
+                        copier.join()
+                return final
+            gaze = g(gaze_pos).repeat(T, 1)[None]
             with _stage("decode_device"):
                 out = decoder(g(root_pos), g(root_rot), g(root_vel), g(root_vrt), g(lpos), g(ltxy), g(lvel), g(lvrt),
                               gaze.contiguous(), speech, final.contiguous(), None, in_mean, in_std, out_mean, out_std, dt)
             V_root_pos, V_root_rot, _, _, V_lpos, V_ltxy = out[0], out[1], out[2], out[3], out[4], out[5]
-            if file_name is None:
-                file_name = f"audio_{Path(audio_file).stem}_label_{anim_name}"
             try:
                 with _stage("pose_to_bvh_device"):
                     channels = anim.bvh_channels(V_root_pos[0], V_root_rot[0], V_lpos[0], V_ltxy[0], np.array([0, 0, 0]),

@@ -721,6 +721,35 @@ def decoder_rollout(dec, Z_root_pos, Z_root_rot, Z_root_vel, Z_root_vrt, Z_lpos,
             pose[..., 6 + 12 * J:6 + 15 * J].reshape(B, T, J, 3))
 
 
+def decoder_chunk(dec, pose0, rpos0, rrot0, gaze, speech, style, in_mean, in_std, out_mean, out_std, dt, h_in=None,
+                  status=None):
+    """Inference rollout resumed from a given state (zeggs_decoder_fwd_state_ex): frame 0 of the chunk is the last frame already
+    produced (pose0 / rpos0 / rrot0; index 0 of gaze / speech / style belongs to it), h_in [2,B,H] the GRU state after it (None:
+    first chunk, CellStateEncoder).  -> pose [B,N,PO], rpos, rrot, h_out [2,B,H].  Nothing is read back: `status` (device
+    words, ops.new_status) collects a give-up bit of the persistent kernel for the CALLER to look at when it chooses to."""
+    pose0, rpos0, rrot0, gaze, speech, style = (_f32c(t) for t in (pose0, rpos0, rrot0, gaze, speech, style))
+    stats = [_f32c(t) for t in (in_mean, in_std, out_mean, out_std)]
+    params = [_f32c(t) for t in decoder_param_list(dec)]
+    B, N, SP = speech.shape
+    PO, H = pose0.shape[1], dec.recurrent_decoder.layer1.hidden_size
+    d = DecDims(B, N, PO + 3, PO, SP, style.shape[2], H, float(dt), 1 if len(params) == len(DEC_FIELDS) else 0)
+    L = lib()
+    dev = pose0.device
+    ws = _ws(L.zeggs_decoder_workspace_bytes(C.byref(d), 0), dev)
+    pose = torch.empty(B, N, PO, device=dev, dtype=torch.float32)
+    rpos = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+    rrot = torch.empty(B, N, 4, device=dev, dtype=torch.float32)
+    h_out = torch.empty(2, B, H, device=dev, dtype=torch.float32)
+    P = _ptrs(DecPtrs, DEC_FIELDS, params)
+    S = _ptrs(DecStats, ("in_mean", "in_std", "out_mean", "out_std"), stats)
+    call = DecCall(0, 0, None, status.data_ptr() if status is not None else None, 0)
+    _check(L.zeggs_decoder_fwd_state_ex(C.byref(d), C.byref(P), C.byref(S), _p(pose0), _p(rpos0), _p(rrot0), _p(gaze),
+                                        _p(speech), _p(style), _p(pose), _p(rpos), _p(rrot),
+                                        _p(_f32c(h_in)) if h_in is not None else None, _p(h_out), _p(ws),
+                                        C.c_size_t(ws.numel()), _stream(), C.byref(call)), "decoder_fwd_state_ex")
+    return pose, rpos, rrot, h_out
+
+
 # ----------------------------------------------------------------------------- free functions of the Networks layer
 # (reference ZEGGS/modules.py:673-813; csrc/funcs.hip).  Differentiable: the reference's own training loop (INTEGRATION.md
 # route 2) calls normalize / compute_KL_div inside its inline loss and back-propagates through them.
