@@ -140,6 +140,9 @@ def _check_engine_iteration(gd, v):
         ref32 = gd["grad_samples"][off:off + len(idx)]
         ref64 = gd["grad_samples_fp64"][off:off + len(idx)]
         scale = max(1e-7, float(np.abs(ref64).max()))          # largest SAMPLED entry (for the printed figures)
+        # the tensor's |g| SUM is pinned to the reference's first: an inflated gradient cannot widen the tolerance that its own
+        # max |g| sets below
+        np.testing.assert_allclose(helpers.fingerprint(p.grad)[1], gd["grad_fp"][i][1], rtol=2e-3, err_msg=f"param {i} |g| sum")
         gmax = max(scale, float(p.grad.abs().max()))            # the tensor's max |g|
         e64, e32 = float(np.abs(got - ref64).max()) / scale, float(np.abs(got - ref32).max()) / scale
         worst64, worst32 = max(worst64, e64), max(worst32, e32)
@@ -222,17 +225,62 @@ def test_free_running_decode_108000_frames_vs_fp64_reference(golden_dir):
     print(f"  root_rot {e_rot:.2e} (reference {floor['root_rot']:.2e}); root_pos {e_pos[100]:.2e} at frame 10 000, "
           f"{e_pos[-1]:.2e} at the end = {e_pos[-1] / T:.2e} per frame (reference {ref_pos[100]:.2e} / {ref_pos[-1]:.2e} = "
           f"{ref_pos[-1] / T:.2e} per frame)")
-    # A free-running rollout of the random-init network amplifies rounding differences (the root drift feeds back through the
-    # gaze direction): the reference's own fp32 run leaves its fp64 run by 4e-5 after 2 000 frames, 4e-4 after 30 000 and 3e-3
-    # after 108 000; another fp32 summation order (this kernel) separates at its own, equally arbitrary, rate.  What is
-    # asserted: the north-star bound on every channel over the first 2 000 frames and on the joint rotations over the first
-    # 10 000; after that the run must stay finite, bounded (root drift per frame) and within a generous multiple of the
-    # reference's own deviation -- a sanity bound against gross errors, not a parity claim; the profile is printed above.
-    assert e_pose[:5].max() < 1e-4
-    assert e_grp["ltxy"][:21].max() < 1e-4
-    assert (e_pose <= np.maximum(1e-3, 50 * ref_pose)).all(), float((e_pose / np.maximum(1e-3, 50 * ref_pose)).max())
-    assert e_rot < max(1e-3, 50 * floor["root_rot"])
-    assert (e_pos <= np.maximum(1e-2, 50 * ref_pos)).all() and float((e_pos / fr).max()) < 2e-4
+    # Round 4: the long-run drift was attributed (tools/drift_ab.py) -- not the hardware-exp gates, not the
+    # polynomial sin / cos, not the algebraic folds, not the summation order (all of them leave the deviation unchanged to three
+    # digits), but the ROOT UPDATE: cos of the per-frame half angle rounds to the fp32 grid around 1 with an error that keeps
+    # its sign while the root turns steadily, so the never-renormalised root quaternion's norm drifts linearly and scales every
+    # later root step (the reference's own fp32 run has the same defect: 1.4 units / 3e-3 after 108 000 frames).  With the
+    # update evaluated as q + delta (dec_math.h: quat_exp_mul) the persistent kernel measures 3.7e-6 / 5.4e-6 / 3.6e-5 / 5.2e-4 /
+    # 1.5e-3 over frames <= 2 000 / 10 000 / 30 000 / 60 000 / 108 000 (round 3: 2e-5 / 1.6e-4 / 1.7e-3 / 1.7e-2 / 5.3e-2), root
+    # position 0.23 units at the end (round 3: 5.5; the reference's fp32 run: 1.40).  Asserted: the north-star bound 1e-4 on
+    # EVERY channel over the first 30 000 frames and on the joint rotations over the first 60 000; everywhere no further from the
+    # fp64 run than the reference's own fp32 run is (running maximum); root drift per frame below the reference's.
+    assert e_pose[:61].max() < 1e-4, e_pose[:61].max()
+    assert e_grp["ltxy"][:121].max() < 1e-4 and e_grp["ltxy"].max() < 2e-4, (e_grp["ltxy"][:121].max(), e_grp["ltxy"].max())
+    assert (e_pose <= np.maximum(1e-4, ref_pose)).all(), float((e_pose / np.maximum(1e-4, ref_pose)).max())
+    assert e_rot < max(1e-3, floor["root_rot"])
+    assert (e_pos <= np.maximum(1e-2, ref_pos)).all(), float((e_pos / np.maximum(1e-2, ref_pos)).max())
+    assert float((e_pos / fr).max()) < 5e-6 and e_pos[-1] / T < ref_pos[-1] / T
+
+
+def test_fast_gate_build_equals_exact_gate_build(tmp_path):
+    """the shipped library evaluates the GRU gates with the hardware exp2 / rcp (common.h: d_sigmoid, d_tanh) and
+    the root's half-angle sine / cosine with two short polynomials (dec_math.h) -- this pins it against the build with libm
+    calls throughout (libzeggs_exact.so: -DZEGGS_EXACT_GATES=1 -DZEGGS_EXACT_SINCOS=1, built by __graft_entry__.build()), on
+    the persistent kernels: a B = 32 x 64 training rollout + BPTT and a 2 000-frame B = 1 decode (tools/ab_rollout.py, one
+    process per build).  Outputs 2e-5, gradients 2e-4 of each tensor's largest entry."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exact = root / "ubisoft-laforge-zeroeggs_amd" / "zeggs" / "libzeggs_exact.so"
+    if not exact.exists():
+        pytest.skip("libzeggs_exact.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    res = {}
+    for tag, lib in (("fast", None), ("exact", exact)):
+        env = dict(os.environ)
+        env.pop("ZEGGS_LIB", None)
+        if lib is not None:
+            env["ZEGGS_LIB"] = str(lib)
+        r = subprocess.run([sys.executable, str(root / "tools" / "ab_rollout.py"), str(tmp_path / f"{tag}.npz")], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(tmp_path / f"{tag}.npz")
+    a, b = res["fast"], res["exact"]
+    assert (a["persistent"] == 1).all() and (b["persistent"] == 1).all(), (a["persistent"], b["persistent"])
+    for k in ("train_pose", "decode_pose"):
+        assert np.isfinite(a[k]).all() and np.abs(a[k] - b[k]).max() < 2e-5, (k, np.abs(a[k] - b[k]).max())
+    for k in ("train_root", "decode_root"):
+        assert np.abs(a[k] - b[k]).max() < 2e-5 * max(1.0, np.abs(b[k]).max()), (k, np.abs(a[k] - b[k]).max())
+    sizes = [len(helpers.sample_idx(p.numel())) for p in helpers.build_nets()[1].parameters()]
+    off = 0
+    for i, n in enumerate(sizes):
+        err = np.abs(a["train_grads"][off:off + n] - b["train_grads"][off:off + n]).max()
+        assert err < 2e-4 * b["train_gmax"][i] + 1e-9, (i, err, b["train_gmax"][i])
+        off += n
+    tail = slice(off, None)
+    assert np.abs(a["train_grads"][tail] - b["train_grads"][tail]).max() < 2e-4 * np.abs(b["train_grads"][tail]).max() + 1e-9
 
 
 def test_style_encoder_7200_frame_exemplar_vs_reference(golden_dir):

@@ -143,6 +143,9 @@ def _check_iteration(gd, v):
         ref = gd["grad_samples"][off:off + len(idx)]
         # 5e-4 of the TENSOR's largest gradient entry (as the GPU test does): after 255 BPTT steps fp32 accumulation noise is
         # relative to the large entries of a tensor, not to each sampled one
+        # (the tensor's own max |g| enters the scale only after its |g| SUM has been pinned to the reference's: an inflated
+        #  gradient cannot widen its own tolerance)
+        np.testing.assert_allclose(helpers.fingerprint(p.grad)[1], gd["grad_fp"][i][1], rtol=2e-3, err_msg=f"param {i} |g| sum")
         scale = max(1e-7, float(np.abs(ref).max()), float(p.grad.abs().max()))
         np.testing.assert_allclose(p.grad.flatten()[idx].numpy(), ref, atol=5e-4 * scale + 1e-9, err_msg=f"param {i}")
         off += len(idx)

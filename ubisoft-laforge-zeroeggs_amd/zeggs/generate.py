@@ -300,7 +300,7 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
                     import threading
                     copier = threading.Thread(target=copyfile, args=(audio_file, str(results_path / (file_name + ".wav"))))
                     copier.start()
-                    with _stage("decode_device+bvh_text_write_host(overlapped)"):
+                    with _stage("decode+pose_to_bvh_device_with_bvh_text_write_host_underneath"):
                         _decode_to_bvh_streaming(decoder, pose0, g(root_pos), g(root_rot), g(gaze_pos), speech,
                                                  final.contiguous(), (in_mean, in_std, out_mean, out_std), dt,
                                                  str(results_path / (file_name + ".bvh")), parents, bone_names)
