@@ -461,6 +461,47 @@ def variants_b32(ds, dev, steps=3, warmup=1):
             "config": "FiLM decoder + GRU style encoder (VAE), batch 32 x 256, example 384: generic per-step GEMM path"}
 
 
+def nhidden_512_b32(ds, dev, steps=5, warmup=2):
+    """configs_v1.json with decoder.nhidden = 512 (ZEGGS/train.py:129 honours the option): the persistent sweeps are built for
+    H = 1024 and decline, the fragment-packed stage kernels serve it (3 launches per step and direction) -- the fall-back
+    path, measured (parity at this width: tests/test_gpu_parity.py::test_decoder_other_hidden_width_vs_oracle)."""
+    torch.manual_seed(1234)
+    H2 = 512
+    se = modules.SpeechEncoder(synth.N_AUDIO, 64, SP).to(dev).train()
+    de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, SP, ST, H2, 2).to(dev).train()
+    st = modules.StyleEncoder(synth.POSE_IN, 512, ST, type="attn", use_vae=True).to(dev).train()
+    eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT)
+    perm = np.random.default_rng(42).permutation(len(ds))
+    ops.set_option("timing", 1)
+    for it in range(warmup):
+        eng.step(engine.shard_indices(perm, it, BATCH, 1, 0), EXAMPLE_LEN)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(warmup, warmup + steps):
+        loss = eng.step(engine.shard_indices(perm, it, BATCH, 1, 0), EXAMPLE_LEN)
+    torch.cuda.synchronize()
+    dt_ = (time.perf_counter() - t0) / steps
+    ms = ctypes.c_float(0.0)
+    fwd_us = bwd_us = None
+    if ops.lib().zeggs_timing_ms(0, ctypes.byref(ms)) == 0:
+        fwd_us = ms.value * 1e3 / (WINDOW - 1)
+    if ops.lib().zeggs_timing_ms(1, ctypes.byref(ms)) == 0:
+        bwd_us = ms.value * 1e3 / (WINDOW - 1)
+    ops.set_option("timing", 0)
+    xd = synth.POSE_IN + SP + ST
+    wbytes = 4 * (H2 * xd + 3 * H2 * (H2 + xd) + 3 * 3 * H2 * H2 + synth.POSE_OUT * H2 + H2 + 12 * H2 + synth.POSE_OUT)
+    out = {"value": round(BATCH * WINDOW / dt_, 1), "unit": "frames/s", "ms_per_step": round(dt_ * 1e3, 2), "steps": steps,
+           "finite": bool(torch.isfinite(loss)), "algorithmic_bytes_per_step": wbytes,
+           "config": "configs_v1 nets with decoder.nhidden = 512, batch 32 x 256, example 384: fragment-packed stage kernels "
+                     "(the persistent sweeps serve H = 1024 only)"}
+    if fwd_us:
+        out["roofline"] = {"bound": "hbm", "kernel": "stage_k (3 launches per step)", "us_per_step": round(fwd_us, 2),
+                           "achieved": round(wbytes / fwd_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(wbytes / fwd_us / 1e3 / HBM_PEAK_GBS, 4),
+                           "backward_us_per_step": round(bwd_us, 2) if bwd_us else None}
+    return out
+
+
 # ----------------------------------------------------------------------------- launcher
 def launch_command(argv, gpus, port):
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
@@ -705,6 +746,7 @@ def main():
             del eng
             out["v2_label_b64"] = v2_label_b64(ds, dev)
             out["variants_film_gru_b32"] = variants_b32(ds, dev)
+            out["nhidden_512_b32"] = nhidden_512_b32(ds, dev)
         if world == 1 and not a.no_cpu_baseline:
             import contextlib
             with contextlib.redirect_stdout(sys.stderr):      # the reference's train() writes its progress bar to stdout

@@ -224,6 +224,50 @@ def test_decoder_backward_vs_oracle(golden_dir):
         assert relerr(p.grad, w64[k].grad) < 3e-4, k
 
 
+@pytest.mark.parametrize("H", [512, 768])
+def test_decoder_other_hidden_width_vs_oracle(golden_dir, H):
+    """`decoder.nhidden` other than the shipped 1024 (ZEGGS/train.py:129 honours the option): the persistent kernels are
+    built for H = 1024 and decline, the fragment-packed stage kernels serve any H % 16 == 0 -- forward 1e-4 and every gradient
+    3e-4 against the oracle in float64 at H = 512 / 768, and the stage path really was the one that ran (bench.py times the
+    same width: `nhidden_512_b32`)."""
+    from zeggs import modules
+    gd, _, s = _golden_nets(golden_dir)
+    torch.manual_seed(77)
+    de_g = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, 64, 64, H, 2).to(DEV).train()
+    B, T = 2, 9
+    speech, style = torch.randn(B, T, 64) * 0.5, torch.randn(B, T, 64) * 0.5
+    gaze = torch.as_tensor(gd["in_Y_gaze_pos"])[:, :1].repeat(1, T, 1)
+    fp = _first_pose(gd)
+    wts = [torch.randn(B, T, *o.shape[1:]) for o in fp]
+    s64 = {k: v.double() for k, v in s.items()}
+    w64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in de_g.state_dict().items()}
+    sp64, sy64 = speech.double().requires_grad_(True), style.double().requires_grad_(True)
+    O = onets.decoder_rollout(w64, *[t.double() for t in fp], gaze.double(), sp64, sy64, s64["in_mean"], s64["in_std"],
+                              s64["out_mean"], s64["out_std"], synth.DT)
+    sum((o * w.double()).sum() for o, w in zip(O, wts)).backward()
+    spg, syg = g(speech).requires_grad_(True), g(style).requires_grad_(True)
+    before = [ops.lib().zeggs_persistent_state(k) for k in (1, 2)]
+    out = de_g(*[g(t) for t in fp], g(gaze), spg, syg, None, g(s["in_mean"]), g(s["in_std"]), g(s["out_mean"]),
+               g(s["out_std"]), synth.DT)
+    for n, o, r in zip(NAMES, out, O):
+        assert float((o.detach().cpu().double() - r.detach()).abs().max()) < 1e-4, n
+    sum((o * g(w)).sum() for o, w in zip(out, wts)).backward()
+    assert [ops.lib().zeggs_persistent_state(k) for k in (1, 2)] == before       # not the H = 1024 persistent kernels
+    assert relerr(spg.grad, sp64.grad) < 3e-4 and relerr(syg.grad, sy64.grad) < 3e-4
+    for k, p in de_g.named_parameters():
+        assert relerr(p.grad, w64[k].grad) < 3e-4, k
+    # ... and the fragment-packed stage path agrees with the generic per-step GEMM path at this width
+    try:
+        ops.set_option("decoder_fast", 0)
+        with torch.no_grad():
+            ref = de_g(*[g(t) for t in fp], g(gaze), g(speech), g(style), None, g(s["in_mean"]), g(s["in_std"]),
+                       g(s["out_mean"]), g(s["out_std"]), synth.DT)
+    finally:
+        ops.set_option("decoder_fast", 1)
+    for n, o, r in zip(NAMES, out, ref):
+        assert float((o.detach() - r).abs().max()) < 1e-4, n
+
+
 # ----------------------------------------------------------------------------- loss
 def _pack_pose(vel, vrt, lpos, ltxy, lvel, lvrt):
     B, T = vel.shape[:2]

@@ -243,6 +243,8 @@ class TrainEngine:
         cut = names.index("recurrent_decoder.layer1.weight_ih_l1") if "recurrent_decoder.layer1.weight_ih_l1" in names else 0
         self._dec_split = lo + sum(p.numel() for p in list(decoder.parameters())[:cut])
         self._dec_work = None
+        self._early_dp = False              # this step applies the decoder's optimizer slices behind their own exchange
+        self._flag_sent = False
         self._dec_shape = None              # (B, speech width, style width) of the last decoder call: what to prepare for
         self._prefetched = None             # (key, batch, event): the next step's batch, gathered on the third stream
         self.prefetch_hits = 0
@@ -276,9 +278,31 @@ class TrainEngine:
         backward.  Same collective sequence on every rank: decoder slice(s), then the encoder slices."""
         lo, hi = self._dec_range
         a, b = (lo, hi) if part is None else (self._dec_split, hi) if part == 0 else (lo, self._dec_split)
+        early = self._early_dp and part is not None
+        if early and part == 0:
+            # the decoder's slices of the optimizer step are applied as soon as THEIR exchange is complete (below), underneath
+            # the encoders' backward -- so the give-up flag of all ranks has to be known first: it is final here (both sweeps
+            # of this iteration are behind this point in stream order) and travels ahead of the gradients, 16 bytes
+            ops.status_flag(self.status, self._gflag)
+            self._dec_work = (self._dec_work or []) + [torch.distributed.all_reduce(
+                self.flat_gx[self.flat_gx.numel() - 4:], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)]
+            self._flag_sent = True
+            self._early_ranges = []
         if b > a:
             self._dec_work = (self._dec_work or []) + [torch.distributed.all_reduce(
                 self.flat_g[a:b], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)]
+            if early:
+                self._early_ranges.append(((a + 3) // 4 * 4, b // 4 * 4, len(self._dec_work)))
+        if early and part == 1:
+            # both halves are in flight (the second one's GEMMs ran underneath the first one's exchange): now the CURRENT
+            # (weight-gradient) stream -- not the host -- waits for each exchange and updates that slice behind it
+            done = 0
+            for a4, b4, upto in self._early_ranges:
+                for w in self._dec_work[done:upto]:
+                    w.wait()
+                done = upto
+                if b4 > a4:
+                    self.opt.early(a4, b4)
 
     def prefetch(self, idx, example_len):
         """Gather the batch of a LATER step now, on the third stream (beside whatever the chip is doing: the gather is a
@@ -390,6 +414,10 @@ class TrainEngine:
         self._dec_work = None
         ctx.after_decoder_backward = self._reduce_decoder_grads if overlap else None
         ctx.wgrad_stream = self.wgrad_stream
+        # data-parallel twin of the early decoder step below: needs the two-halves exchange on the weight-gradient stream
+        # (the slices are then updated there, behind their own all-reduce) and the device-side guard (flag first)
+        self._early_dp = bool(self.early_decoder_step and overlap and self.wgrad_stream is not None and self.status is not None)
+        self._flag_sent = False
         ctx.decoder_grads_final = None
         if self.early_decoder_step and not overlap and self.world == 1 and not self.force_allreduce:
             # no exchange to wait for: the decoder's 88 % of the optimizer step (HBM-bound) runs on the weight-gradient stream as
@@ -463,13 +491,14 @@ class TrainEngine:
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a0.record()
         guarded_dp = self.status is not None and (self.world > 1 or self.force_allreduce)
-        if guarded_dp:      # this rank's give-up flag joins the last slice of the exchange (summed over the ranks)
+        if guarded_dp and not self._flag_sent:      # this rank's give-up flag joins the last slice of the exchange (summed over the ranks)
             ops.status_flag(self.status, self._gflag)
         if self._dec_work is not None:
             # the decoder slice has been in flight since the decoder backward returned; now the encoders' slices
             lo, hi = self._dec_range
             works = list(self._dec_work)
-            for part in (self.flat_g[:lo], self.flat_gx[hi:]):
+            tail = self.flat_g[hi:] if self._flag_sent else self.flat_gx[hi:]      # (flag already exchanged: not summed twice)
+            for part in (self.flat_g[:lo], tail):
                 if part.numel():
                     works.append(torch.distributed.all_reduce(part, op=torch.distributed.ReduceOp.SUM, group=self.pg,
                                                               async_op=True))
