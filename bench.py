@@ -688,7 +688,7 @@ def main():
         nst = WINDOW - 1
         f_us, b_us = float(np.mean(fw)) * 1e3 / nst, float(np.mean(bw)) * 1e3 / nst
         pmc = None
-        for name in ("r03_decoder_step_pmc.json", "r02_decoder_step_pmc.json", "r01_decoder_step_pmc.json"):
+        for name in ("r04_decoder_step_pmc.json", "r03_decoder_step_pmc.json", "r02_decoder_step_pmc.json", "r01_decoder_step_pmc.json"):
             if (ROOT / "profiles" / name).exists():
                 pmc = json.load(open(ROOT / "profiles" / name))
                 pmc["file"] = "profiles/" + name
@@ -713,6 +713,8 @@ def main():
                          "us_per_step_in_timed_region": round(bwd_in * 1e3 / nst, 2),
                          "traffic": pmc.get("traffic_bytes_per_step_backward") if pmc else None},
             "mfma_frac_at_b32": round(step_flops(BATCH) / (f_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            "dominant_kernel": "train_bwd_persistent_k (27 % of kernel time, profiles/r04_train_only_kernel_stats_12steps.csv): "
+                               "its figures are roofline.backward; train_fwd_persistent_k (21 %) is the top-level entry",
             "note": "HIP events (library hook zeggs_timing_ms, recorded on the stream the kernels run on) around the "
                     "255-step stage sweeps: the last timed iteration + 3 more; traffic = FETCH_SIZE(x2)+WRITE_SIZE "
                     f"from {pmc['file'] if pmc else 'n/a'}; at B=32 the step is also at the fp32 MFMA ridge"}

@@ -122,3 +122,44 @@ def test_cli_option_surface_and_csv_batch_mode(tmp_path, monkeypatch):
     new = [k for kind, k in calls[n0:]]
     assert [k["file_name"] for k in new] == ["o1", "o3"] and new[0]["styles"][0][1] == [5, 50] and new[1]["styles"][0][1] is None
     assert new[1]["first_pose"] is None and new[1]["temperature"] == 0.8 and new[1]["seed"] == 99
+
+
+def test_generate_branch_fixture_integer_rules(golden_dir):
+    """The integer rules of the generate_gesture() branches recorded in generate_branches.npz (round 4): "stitch" split frames
+    (helpers.split_by_ratio: truncation, last end = length) bit-exact, and the shapes the reference returns for every branch."""
+    g = np.load(golden_dir / "generate_branches.npz")
+    ratio = [float(r) for r in g["blend_ratio"]]
+    assert generate.split_by_ratio(135, ratio) == g["split_135"].tolist() == [[0, 40], [40, 135]]
+    assert generate.split_by_ratio(10, [0.5, 0.25, 0.25]) == [[0, 5], [5, 7], [7, 10]]
+    enc = g["stitch_encoding"]
+    assert enc.shape == (1, 135, 64)
+    s0 = int(g["split_135"][0][1])
+    assert np.array_equal(enc[0, 0], enc[0, s0 - 1]) and np.array_equal(enc[0, s0], enc[0, -1]) and not np.array_equal(enc[0, 0], enc[0, s0])
+    assert g["add_encoding"].shape == (1, 135, 64) and g["label_encoding"].shape == (1, 135, 19)
+    assert g["label_encoding"][0, 0].sum() == 1.0 and g["label_encoding"][0, 0, synth.LABEL_NAMES.index(str(g["label"]))] == 1.0
+    assert g["noaudio_stitch_encoding0"].shape == g["noaudio_stitch_encoding1"].shape == g["noaudio_add_encoding"].shape == (1, 64)
+    # "add" without audio = the blend of the two per-style encodings "stitch" returns as a list (generate.py:299-308)
+    blend = ratio[0] * g["noaudio_stitch_encoding0"] + ratio[1] * g["noaudio_stitch_encoding1"]
+    np.testing.assert_allclose(g["noaudio_add_encoding"], blend, atol=1e-6)
+    np.testing.assert_allclose(g["ndarray_encoding"][0, 7], g["embedding"], atol=0)
+    for tag in ("stitch", "add", "label", "ndarray", "nofirst"):
+        assert g[f"{tag}_rotations"].shape == (135, 75, 3) and g[f"{tag}_root_positions"].shape == (135, 3)
+
+
+def test_format_table_text_equals_the_file_writer(tmp_path):
+    """the host helper behind the streaming BVH writer (zeggs_format_table_text, single-threaded, row blocks) produces the bytes
+    zeggs_write_table_text writes (= the reference's "%f " rows), for any split of the table into blocks"""
+    import ctypes as C
+    from zeggs import ops
+    rng = np.random.default_rng(3)
+    table = np.ascontiguousarray(rng.standard_normal((257, 228)) * np.array([1e3, 1.0, 1e-4] * 76), dtype=np.float64)
+    table[5, 7] = -0.0
+    table[6, 8] = 123456789.125
+    path = tmp_path / "t.txt"
+    assert ops.lib().zeggs_write_table_text(str(path).encode(), 0, table.ctypes.data_as(C.c_void_p), C.c_long(257), 228) == 0
+    whole = path.read_bytes()
+    assert whole.decode().splitlines()[0] == "".join("%f " % v for v in table[0])
+    pieces = b"".join(anim.format_rows(table[a:b]) for a, b in ((0, 1), (1, 100), (100, 100), (100, 257)))
+    assert pieces == whole
+    head, seq = anim.bvh_header(np.zeros((75, 3)), synth.PARENTS, synth.BONE_NAMES, "zyx", 257, synth.DT)
+    assert sorted(seq) == list(range(75)) and seq[0] == 0 and head.endswith("Frames: 257\nFrame Time: %f\n" % synth.DT)

@@ -99,6 +99,26 @@ def test_oracle_train_iteration_vs_reference(golden_dir):
     assert off == len(gs)
 
 
+def test_oracle_fp64_vs_reference_fp64_both_iterations(golden_dir):
+    """The oracle in float64 against the UNMODIFIED reference run in float64 (train_iter_fp64.npz, round 4) on iteration 0: loss
+    to 1e-11, the gradient samples of all 44 tensors to 1e-9 of the largest entry -- the tightest pin the restatement has.
+    (Iteration 1 needs the weights after the reference's first RAdam step, of which the fixture holds samples only.)"""
+    g, g64 = np.load(golden_dir / "train_iter.npz"), np.load(golden_dir / "train_iter_fp64.npz")
+    nets = helpers.build_nets()
+    s = helpers.stats_tensors()
+    loss, terms, ws = _oracle_iteration(g, 0, nets, s, torch.float64)
+    np.testing.assert_allclose(float(loss), g64["loss64"][0], rtol=1e-11)
+    plist = [v for w in ws for k, v in w.items()]
+    got = np.concatenate([p.grad.flatten()[helpers.sample_idx(p.numel())].numpy() for p in plist])
+    ref = g64["it0_grad_samples64"]
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
+    # the fixture's own record of how far the reference's fp32 run is from its fp64 run (the arbiter of
+    # tests/test_gpu_reference_side.py): 2.5e-5 at iteration 0, 5e-3 at the ill-conditioned iteration 1
+    assert float(g64["it0_ref32_vs_ref64"]) < 1e-4 < float(g64["it1_ref32_vs_ref64"]) < 2e-2
+    np.testing.assert_allclose(g["loss"], g64["loss64"], rtol=2e-6)
+
+
 def test_oracle_radam_vs_reference(golden_dir):
     g = np.load(golden_dir / "radam.npz")
     p = g["params"][0].copy()
