@@ -195,13 +195,13 @@ def cpu_baselines(data):
     if ref_shims.available():
         # the reference ITSELF on this box's host cores (on the GPU box: the byte-for-byte snapshot oracle/build_ref.py left in
         # oracle/_ref/): train() with every core (the headline baseline) and with thread_count = 1 (the shipped config value,
-        # configs_v1.json:37); bounded samples (2 + 1 steady iterations; iteration 0 = checkpoint + sample rendering is skipped)
+        # configs_v1.json:37); bounded samples (4 + 1 steady iterations; iteration 0 = checkpoint + sample rendering is skipped)
         from oracle import ref_timing
         ncpu = os.cpu_count() or 1
         # "all cores" = the physical cores, capped at 32 threads: torch's intra-op pool gets SLOWER beyond that on this
         # workload (hundreds of sub-millisecond ops per decoder step, each a fork-join over the pool)
         nthr = max(1, min(physical_cores(), 32))
-        r = ref_timing.measure(iters=2, frames=600, train_threads=(nthr,), legs=("train", "decode", "mel"))
+        r = ref_timing.measure(iters=4, frames=600, train_threads=(nthr,), legs=("train", "decode", "mel"))      # ~25 s of CPU work
         tr = next(iter(r["train"].values()))
         train = {"value": tr["frames_per_s"], "unit": "frames/s", "cores": tr["threads"], "kind": "reference",
                  "sample": f"{tr['iterations_timed']} steady iterations of the unmodified reference train() "

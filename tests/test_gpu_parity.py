@@ -1084,6 +1084,40 @@ def test_streaming_matches_offline_generation(seed, nsamp):
         assert float((cat(k) - r[0]).abs().max()) < 5e-5, k
 
 
+def test_streaming_vs_the_reference_generate_gesture(golden_dir):
+    """zeggs.stream.GestureStream against the REFERENCE directly (round 3 compared it with the offline HIP path only): the 2 s
+    clip of generate.npz -- the reference's own generate_gesture() run, whose decoder outputs were captured on their way into
+    the BVH conversion (oracle/make_golden.py:gold_generate) -- pushed through the stream in irregular chunks with the
+    reference's style encoding, first pose and nets: joint rotations / positions / root trajectory of every frame 1e-4."""
+    from zeggs import anim, stream
+    gd = np.load(golden_dir / "generate.npz")
+    se, de, _ = helpers.build_nets()
+    se, de = se.to(DEV).eval(), de.to(DEV).eval()
+    stats = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32, device=DEV) for k, v in synth.make_stats().items()}
+    conf = dict(pre_emphasis=False, pre_emph_coeff=0.97, centered=True, real_amplitude=True, normalize_mel_bins=True,
+                normalize_range=True, min_clipping=1e-5, sampling_rate=16000, mel_fmin=20, mel_fmax=7600,
+                n_mel_channels=80, filter_length=800, hop_length=200, resample_method="linear", normalize_loudness=False)
+    wav = gd["wav"].astype(np.float32) / 32768.0
+    clip = dict(rotations=gd["ex_rotations"], positions=gd["ex_positions"], offsets=gd["ex_offsets"], parents=gd["ex_parents"],
+                names=synth.BONE_NAMES, order="zyx", frametime=synth.DT)
+    first = anim.preprocess_animation(clip, DEV)
+    style = torch.as_tensor(gd["encoding"][:, 0], device=DEV)            # the reference's own (per-frame constant) encoding
+    gs = stream.GestureStream(se, de, first, style, stats, conf, synth.DT)
+    outs, pos = [], 0
+    for n in (700, 5000, 123, 9000, 16000, 1177):
+        outs.append(gs.push(wav[pos:pos + n]))
+        pos += n
+    assert pos == len(wav)
+    outs.append(gs.finish())
+    cat = lambda k: torch.cat([o[k] for o in outs if o], dim=0).cpu().numpy()  # noqa: E731
+    pose, rpos, rrot = cat("pose"), cat("rpos"), cat("rrot")
+    T, J = gd["dec_ltxy"].shape[0], synth.NJ
+    assert pose.shape[0] == T                                             # integer frame count: bit-exact
+    assert np.abs(pose[:, 6 + 3 * J:6 + 9 * J].reshape(T, J, 2, 3) - gd["dec_ltxy"]).max() < 1e-4
+    assert np.abs(pose[:, 6:6 + 3 * J].reshape(T, J, 3) - gd["dec_lpos"]).max() < 1e-4
+    assert np.abs(rpos - gd["dec_root_pos"]).max() < 1e-4 and np.abs(rrot - gd["dec_root_rot"]).max() < 1e-4
+
+
 # ----------------------------------------------------------------------------- BASELINE.json full size
 def test_full_size_rollout_fast_equals_generic_and_is_linear_in_loss_weights():
     """configs[1] shape (B=32, T=256): the fragment-packed stage kernels (merged stages, batch split) and the generic
