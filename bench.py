@@ -314,25 +314,19 @@ def decode_30min(se, de, dev, minutes=30.0, reps=3):
     se.train(), de.train()
     t_dec = min(ts)
     n_stft = audio.stft_frame_count(n)
-    mel_flop = 2.0 * 2 * 401 * 800 * n_stft          # direct DFT: 401 bins x 800 samples x (re, im) fp64 FMAs per STFT frame
+    mel_bytes = n * 4 + T * 81 * 4                   # 200 new samples in per STFT frame, (80 + 1) x 60/80 floats out
     return {"frames": T, "mel_ms": round(t_mel * 1e3, 2), "speech_encoder_ms": round(t_se * 1e3, 2),
             "wav_upload_ms": round(t_up * 1e3, 2),
-            "mel_roofline": {"bound": "mfma", "kernel": "mel_stft_mfma_k: the 800-point DFT of 32 STFT frames per workgroup as a "
-                                                        "[32, 800] x [800, 802] fp64 product on v_mfma_f64_16x16x4_f64 (+ mel bands "
-                                                        "from LDS + log chain), mel_resample_k",
-                             "achieved": round(mel_flop / t_mel / 1e12, 2), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(mel_flop / t_mel / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4), "stft_frames": int(n_stft),
-                             "algorithmic_flop": "2 x 2 x 401 x 800 fp64 per STFT frame (Re and Im of 401 bins)",
-                             # the same launch against what the ALGORITHM needs (an 800-point real FFT is ~19
-                             # kFLOP per STFT frame; 200 new samples in, 81 x 60/80 floats out): the DFT-as-GEMM does 67x the
-                             # FFT's arithmetic, so the honest yardstick for the front-end is the HBM one
-                             "hbm": {"bound": "hbm", "algorithmic_bytes": int(n * 4 + T * 81 * 4),
-                                     "achieved": round((n * 4 + T * 81 * 4) / t_mel / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                     "unit": "GB/s", "frac": round((n * 4 + T * 81 * 4) / t_mel / 1e9 / HBM_PEAK_GBS, 5),
-                                     "us_at_hbm_peak": round((n * 4 + T * 81 * 4) / (HBM_PEAK_GBS * 1e9) * 1e6, 1),
-                                     "fft_flop_per_stft_frame": 19000,
-                                     "note": "0.4 % of configs[4]'s 1.1 s: an FFT kernel would take the front-end from ~4 ms to "
-                                             "well under 1 ms and move nothing else"}},
+            "mel_roofline": {"bound": "hbm", "kernel": "mel_stft_fft_k (round 4): the 800-point real STFT of 4 frames per workgroup as a "
+                                                       "half-length complex FFT (mixed-radix Stockham 4 4 5 5 in LDS, float64) + split + mel "
+                                                       "bands from LDS + log chain; mel_resample_k",
+                             "achieved": round(mel_bytes / t_mel / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(mel_bytes / t_mel / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(mel_bytes),
+                             "us_at_hbm_peak": round(mel_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 1), "stft_frames": int(n_stft),
+                             "fft_flop_per_stft_frame": 19000,
+                             "note": "an FFT now, as the reference's np.fft.rfft (round 3: the DFT as an fp64 matrix-core product, 67x "
+                                     "the arithmetic, 6.5 ms; option mel_fft = 0); the launch is bound by the float64 log10 / pow / log / "
+                                     "exp chain of 80 mel values per frame and LDS traffic, not by HBM; 0.1 % of configs[4]"},
             "decode_s": round(t_dec, 3), "decode_s_all": [round(v, 3) for v in ts],
             "value": round((T - 1) / t_dec, 1), "unit": "frames/s",
             "x_realtime": round(minutes * 60.0 / (t_mel + t_se + t_dec), 1), "finite": finite,

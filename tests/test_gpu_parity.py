@@ -454,6 +454,36 @@ def test_mel_features_vs_reference(golden_dir):
         np.testing.assert_allclose(feat, ref, atol=2e-6, equal_nan=True)
 
 
+def test_mel_fft_form_equals_the_dft_forms(golden_dir):
+    """Round 4: the STFT as a real FFT (half-length complex mixed-radix Stockham transform in LDS + split, what the reference's
+    np.fft.rfft computes) is the default; the fp64 matrix-core DFT (round 3) and the direct DFT stay behind options.  All three
+    against the reference fixtures (2e-6) and against each other (1e-6: float64 spectra a few ulp apart, float32 features), on
+    lengths that are / are not multiples of the hop, and on a clip shorter than one window."""
+    from zeggs import audio
+    gd = np.load(golden_dir / "mel.npz")
+    wavs = {tag: (gd[f"{tag}_wav"], int(gd[f"{tag}_nframes"]), gd[f"{tag}_feat"]) for tag in "abc"}
+    short = synth.synth_wav(700, seed=3).astype(np.float32) / 32768.0
+    try:
+        for tag, (wav, nfr, ref) in wavs.items():
+            feats = {}
+            for name, fft, mfma in (("fft", 1, 1), ("mfma", 0, 1), ("direct", 0, 0)):
+                ops.set_option("mel_fft", fft)
+                ops.set_option("mel_mfma", mfma)
+                feats[name] = audio.mel_features(wav, nfr).cpu().numpy()
+                np.testing.assert_array_equal(np.isnan(feats[name]), np.isnan(ref))
+                np.testing.assert_allclose(feats[name], ref, atol=2e-6, equal_nan=True, err_msg=f"{tag} {name}")
+            for name in ("mfma", "direct"):
+                np.testing.assert_allclose(feats["fft"], feats[name], atol=1e-6, equal_nan=True, err_msg=f"{tag} fft vs {name}")
+        outs = []
+        for fft in (1, 0):
+            ops.set_option("mel_fft", fft)
+            outs.append(audio.mel_features(short, audio.n_anim_frames(len(short))).cpu().numpy())
+        np.testing.assert_allclose(outs[0], outs[1], atol=1e-6, equal_nan=True)
+    finally:
+        ops.set_option("mel_fft", 1)
+        ops.set_option("mel_mfma", 1)
+
+
 # ----------------------------------------------------------------------------- drop-in API end to end
 def test_generate_gesture_vs_reference(golden_dir, tmp_path):
     """generate_gesture() (wav + exemplar BVH -> BVH) against the reference's own output for the same files."""

@@ -1,19 +1,35 @@
-import sys, time
-sys.path[:0] = ["/root/repo", "/root/repo/ubisoft-laforge-zeroeggs_amd"]
-import numpy as np, torch
-from zeggs import audio, ops
+"""mel front-end A/B: the FFT form (round 4, default) against the fp64-MFMA DFT (round 3) and the direct-DFT kernel -- time for 30
+minutes of audio (wav resident on the device) and agreement of the features."""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "ubisoft-laforge-zeroeggs_amd")]
+from zeggs import audio, ops  # noqa: E402
+
 n = 30 * 60 * 16000
-wav = (0.1 * np.random.default_rng(0).standard_normal(n)).astype(np.float32)
+wav = torch.as_tensor((0.1 * np.random.default_rng(0).standard_normal(n)).astype(np.float32)).cuda()
 T = audio.n_anim_frames(n)
 outs = {}
-for v in (0, 1):
-    ops.set_option("mel_mfma", v)
+for name, fft, mfma in (("direct", 0, 0), ("mfma", 0, 1), ("fft", 1, 1)):
+    ops.set_option("mel_fft", fft)
+    ops.set_option("mel_mfma", mfma)
     audio.mel_features(wav[:16000], 60)
     torch.cuda.synchronize()
     ts = []
     for _ in range(3):
-        t0 = time.perf_counter(); o = audio.mel_features(wav, T); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-    outs[v] = o.cpu()
-    print(f"mel_mfma={v}: {min(ts)*1e3:.2f} ms (incl. H2D of the wav)", flush=True)
-d = (outs[0] - outs[1]).abs()
-print("max |direct - mfma|:", float(d[torch.isfinite(d)].max()), "nan pattern equal:", bool((torch.isnan(outs[0]) == torch.isnan(outs[1])).all()))
+        t0 = time.perf_counter()
+        o = audio.mel_features(wav, T)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    outs[name] = o.cpu()
+    print(f"{name:7s}: {min(ts) * 1e3:8.3f} ms for {T} frames (wav on the device)", flush=True)
+ops.set_option("mel_fft", 1)
+for a, b in (("direct", "mfma"), ("direct", "fft"), ("mfma", "fft")):
+    d = (outs[a] - outs[b]).abs()
+    print(f"max |{a} - {b}|: {float(d[torch.isfinite(d)].max()):.3e}   NaN pattern equal: "
+          f"{bool((torch.isnan(outs[a]) == torch.isnan(outs[b])).all())}")

@@ -32,6 +32,7 @@ void zeggs_gemm_set_dma(int on);
 extern int g_gemm_mid_split;
 extern int g_gemm_streamk_wgs;
 extern int g_mel_mfma;
+extern int g_mel_fft;
 extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "decoder_fast") == 0) { g_decoder_fast = value; return 0; }
   if (strcmp(name, "stage_variant") == 0) { g_stage_variant = value; return 0; }
@@ -55,6 +56,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
     return 0;
   }
   if (strcmp(name, "mel_mfma") == 0) { g_mel_mfma = value != 0; return 0; }
+  if (strcmp(name, "mel_fft") == 0) { g_mel_fft = value != 0; return 0; }
   if (strcmp(name, "gemm_streamk_wgs") == 0) { g_gemm_streamk_wgs = value; return 0; }
   if (strcmp(name, "gemm_mid_split") == 0) { g_gemm_mid_split = value != 0; return 0; }
   if (strcmp(name, "gemm_dma") == 0) { zeggs_gemm_set_dma(value != 0); return 0; }

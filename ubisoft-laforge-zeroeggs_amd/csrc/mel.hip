@@ -5,6 +5,9 @@
 // [0,1]); ZEGGS/data_pipeline.py:62-80 (10**(x/20) -> ln, linear resampling to the animation rate,
 // energy = ||exp(mel)||_2 resampled with extrapolation).
 //
+// Three forms of the STFT, same results (float32 features bit-identical, tools/mel_ab.py): the FFT form mel_stft_fft_k (round 4,
+// default: a half-length complex mixed-radix FFT + split, what the reference's np.fft.rfft computes), the DFT as a float64
+// matrix-core product mel_stft_mfma_k (round 3, option mel_fft = 0) and the direct DFT below (other n_fft).
 // The reference's spectrogram is float64, so this kernel computes in float64 as well (MI355X runs f64
 // FMAs at full vector rate): one workgroup per STFT frame, the windowed frame and an n_fft-entry
 // cos/sin table are staged in LDS, each thread evaluates a direct DFT for its bins (index k*n mod n_fft
@@ -27,6 +30,9 @@ struct MelWs {
   double* energy;   // [M]
   double* table;    // [n_fft, MCOLP]: column 2k = cos(2 pi j k / n_fft), 2k+1 = -sin(.), zero beyond bin n_fft/2
   double* win;      // [n_fft] symmetric Hann
+  double* ftw;      // FFT form: [n_fft / 2 + n_fft / 2 + 1 + n_fft] complex (twiddles of the half-length transform, of the split, window)
+  double* fbp;      // FFT form: the filterbank's non-zeros, band after band [MFB_CAP]
+  int* bands;       // FFT form: [3 n_mels] first bin | one past the last bin | offset in fbp
 };
 MelWs carve_mel(const ZeggsMelDims& d, long M, Arena& a) {
   MelWs w;
@@ -34,6 +40,9 @@ MelWs carve_mel(const ZeggsMelDims& d, long M, Arena& a) {
   w.energy = (double*)a.raw(sizeof(double) * M);
   w.table = (double*)a.raw(sizeof(double) * (size_t)d.n_fft * MCOLP);
   w.win = (double*)a.raw(sizeof(double) * (size_t)d.n_fft);
+  w.ftw = (double*)a.raw(sizeof(double) * 2 * ((size_t)2 * d.n_fft + 1));
+  w.fbp = (double*)a.raw(sizeof(double) * MFB_CAP);
+  w.bands = (int*)a.raw(sizeof(int) * 3 * (size_t)d.n_mels);
   return w;
 }
 
@@ -248,6 +257,180 @@ __global__ __launch_bounds__(MWAVES * 64) void mel_stft_mfma_k(ZeggsMelDims d, c
   }
 }
 
+
+// ---- FFT form (mel_stft_fft_k, round 4): what the reference's np.fft.rfft does (spectrograms.py:251-263) instead of the
+// O(N^2) DFT as a matrix product -- an n_fft-point real transform as ONE complex FFT of half the length (even samples real part,
+// odd samples imaginary part), mixed-radix Stockham autosort in LDS (radices 4 / 5 / 2: 400 = 4 4 5 5 for the shipped
+// n_fft = 800), then the usual split X[k] = (Z[k] + conj Z[M-k]) / 2 - i / 2 e^{-2 pi i k / N} (Z[k] - conj Z[M-k]).
+// 19 kFLOP per STFT frame instead of 1.28 MFLOP; the launch is bound by the log / exp chain of the 80 mel values and by LDS
+// traffic, not by the transform.  Twiddles come from two tables built once per call in float64 (exact angle reduction), so
+// the spectrum agrees with the matrix form to a few ulp; mel / clip / log chain and summation orders are the same code.
+constexpr int FFB = 4;            // STFT frames per workgroup
+#ifndef ZEGGS_MEL_FFT_THREADS
+#define ZEGGS_MEL_FFT_THREADS 320 // 5 waves: the radix-5 stages (4 x 80 butterflies) and the mel / log chain (4 x 80 values) are ONE pass each
+#endif
+constexpr int FTHR = ZEGGS_MEL_FFT_THREADS;
+constexpr int FMAXST = 8;         // stages
+struct FftPlan { int nst; int radix[FMAXST]; };
+typedef double c2 __attribute__((ext_vector_type(2)));     // (re, im)
+__device__ __forceinline__ c2 cmul(c2 a, c2 b) { return c2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ c2 cmul_mi(c2 a) { return c2{a.y, -a.x}; }      // a * (-i)
+
+// TW[n] = exp(-2 pi i n / M), n < M;  TW[M + k] = exp(-2 pi i k / (2 M)), k <= M;  TW[2 M + 1 + j] = (hann window j, 0), j < 2 M.
+// Block 0 also packs the filterbank ONCE per call: bands[m] = first bin, bands[NM + m] = one past the last bin, bands[2 NM + m] =
+// offset of the band's non-zeros in fbp (-1: does not fit, read from the dense matrix) -- every STFT workgroup copies these few
+// KB into LDS instead of scanning the dense [n_mels, n_bins] matrix itself (that scan was 2/3 of the first version's time).
+__global__ void mel_fft_table_k(c2* TW, int M, const double* fb, int NM, int* bands, double* fbp) {
+  const int NF = 2 * M, n = 2 * M + 1 + NF, NBIN = M + 1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (i < M) { const double a = 2.0 * M_PI * (double)i / (double)M; TW[i] = c2{cos(a), -sin(a)}; }
+    else if (i <= 2 * M) { const double a = 2.0 * M_PI * (double)(i - M) / (double)NF; TW[i] = c2{cos(a), -sin(a)}; }
+    else { const int j = i - 2 * M - 1; TW[i] = c2{0.5 - 0.5 * cos(2.0 * M_PI * (double)j / (double)(NF - 1)), 0.0}; }
+  }
+  if (blockIdx.x == 0) {
+    // first / last non-zero bin of every mel filter: all threads walk the dense matrix together (min / max through global atomics
+    // on the band table itself: a serial scan per filter was 0.13 ms of a 1.7 ms front-end)
+    for (int m = threadIdx.x; m < NM; m += blockDim.x) { bands[m] = NBIN; bands[NM + m] = 0; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NM * NBIN; i += blockDim.x) {
+      const int m = i / NBIN, k = i - m * NBIN;
+      if (fb[i] != 0.0) { atomicMin(bands + m, k); atomicMax(bands + NM + m, k + 1); }
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < NM; m += blockDim.x)
+      if (bands[NM + m] == 0) bands[m] = 0;            // an all-zero filter: empty band [0, 0)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int o = 0;
+      for (int m = 0; m < NM; ++m) {
+        const int w = bands[NM + m] - bands[m];
+        if (o + w <= MFB_CAP) { bands[2 * NM + m] = o; o += w; } else bands[2 * NM + m] = -1;
+      }
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < NM; m += blockDim.x)
+      if (bands[2 * NM + m] >= 0)
+        for (int k = bands[m]; k < bands[NM + m]; ++k) fbp[bands[2 * NM + m] + k - bands[m]] = fb[(long)m * NBIN + k];
+  }
+}
+
+__host__ __device__ inline size_t mel_fft_lds(int NF, int n_mels) {
+  return sizeof(double) * 2 * ((size_t)2 * FFB * (NF / 2)) + sizeof(double) * MFB_CAP + sizeof(int) * 3 * (size_t)n_mels + 64;
+}
+
+__global__ __launch_bounds__(FTHR) void mel_stft_fft_k(ZeggsMelDims d, FftPlan plan, const float* wav, long n, long n_avail,
+                                                      const double* fb, const c2* __restrict__ TW, const int* bands,
+                                                      const double* fbp, double* logmel, double* energy, long m0, long nfr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int NF = d.n_fft, M = NF / 2, NBIN = M + 1, hop = d.hop, NM = d.n_mels;
+  c2* bufA = (c2*)smem;                               // [FFB][M]
+  c2* bufB = bufA + (size_t)FFB * M;                  // [FFB][M]
+  double* fbs = (double*)(bufB + (size_t)FFB * M);    // [MFB_CAP]
+  int* blo = (int*)(fbs + MFB_CAP);
+  int* bhi = blo + NM;
+  int* bof = bhi + NM;
+  const int tid = threadIdx.x;
+  const long fr0 = m0 + (long)blockIdx.x * FFB, slot0 = (long)blockIdx.x * FFB;
+  const long neff = n > NF ? n : NF;
+  const c2* WIN = TW + 2 * M + 1;
+  // windowed samples, packed: z[m] = xw[2 m] + i xw[2 m + 1]
+  for (int i = tid; i < FFB * M; i += blockDim.x) {
+    const int f = i / M, m = i - f * M;
+    double v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = 2 * m + h;
+      const long p = (fr0 + f) * hop + j - NF / 2;
+      const long src = p < 0 ? -p : (p >= neff ? 2 * (neff - 1) - p : p);
+      const double x = (src >= 0 && src < n && src < n_avail) ? (double)wav[src] : 0.0;
+      v[h] = x * WIN[j].x;
+    }
+    bufA[i] = c2{v[0], v[1]};
+  }
+  for (int i = tid; i < 3 * NM; i += blockDim.x) blo[i] = bands[i];          // blo | bhi | bof are contiguous
+  for (int i = tid; i < MFB_CAP; i += blockDim.x) fbs[i] = fbp[i];
+  __syncthreads();
+  // ---- Stockham stages: x -> y, natural order in, natural order out
+  c2* x = bufA;
+  c2* y = bufB;
+  int Ns = 1;
+  for (int st = 0; st < plan.nst; ++st) {
+    const int r = plan.radix[st], t = M / r, tws = M / (Ns * r);      // tws: table stride of this stage's twiddle
+    for (int it = tid; it < FFB * t; it += blockDim.x) {
+      const int f = it / t, i = it - f * t;
+      const int k = i % Ns, j = (i - k) * r + k;
+      const c2* xi = x + (size_t)f * M + i;
+      c2* yo = y + (size_t)f * M + j;
+      if (r == 4) {
+        c2 u0 = xi[0], u1 = xi[t], u2 = xi[2 * t], u3 = xi[3 * t];
+        if (k) { const int a = k * tws; u1 = cmul(u1, TW[a]); u2 = cmul(u2, TW[2 * a]); u3 = cmul(u3, TW[3 * a]); }
+        const c2 s0 = u0 + u2, s1 = u0 - u2, s2 = u1 + u3, s3 = cmul_mi(u1 - u3);
+        yo[0] = s0 + s2; yo[Ns] = s1 + s3; yo[2 * Ns] = s0 - s2; yo[3 * Ns] = s1 - s3;
+      } else if (r == 5) {
+        c2 u0 = xi[0], u1 = xi[t], u2 = xi[2 * t], u3 = xi[3 * t], u4 = xi[4 * t];
+        if (k) {
+          const int a = k * tws;
+          u1 = cmul(u1, TW[a]); u2 = cmul(u2, TW[2 * a]); u3 = cmul(u3, TW[3 * a]); u4 = cmul(u4, TW[4 * a]);
+        }
+        const double c1 = 0.30901699437494742, c2_ = -0.80901699437494742;      // cos(2 pi / 5), cos(4 pi / 5)
+        const double s1 = 0.95105651629515357, s2 = 0.58778525229247313;        // sin(2 pi / 5), sin(4 pi / 5)
+        const c2 a1 = u1 + u4, a2 = u2 + u3, b1 = u1 - u4, b2 = u2 - u3;
+        const c2 m1 = u0 + c1 * a1 + c2_ * a2, m2 = u0 + c2_ * a1 + c1 * a2;
+        const c2 n1 = cmul_mi(s1 * b1 + s2 * b2), n2 = cmul_mi(s2 * b1 - s1 * b2);       // -i (...)
+        yo[0] = u0 + a1 + a2; yo[Ns] = m1 + n1; yo[2 * Ns] = m2 + n2; yo[3 * Ns] = m2 - n2; yo[4 * Ns] = m1 - n1;
+      } else {      // r == 2
+        c2 u0 = xi[0], u1 = xi[t];
+        if (k) u1 = cmul(u1, TW[k * tws]);
+        yo[0] = u0 + u1; yo[Ns] = u0 - u1;
+      }
+    }
+    __syncthreads();
+    c2* tmp = x; x = y; y = tmp;
+    Ns *= r;
+  }
+  // ---- split: amplitude of bin k of the real transform (real_amplitude: |X[k]| / n_fft) -> the other buffer
+  double* amp = (double*)y;                           // [FFB][NBIN] doubles <= [FFB][M] complex
+  for (int it = tid; it < FFB * NBIN; it += blockDim.x) {
+    const int f = it / NBIN, k = it - f * NBIN;
+    const c2* Z = x + (size_t)f * M;
+    const c2 zk = Z[k == M ? 0 : k], zm = Z[k == 0 ? 0 : M - k];
+    const c2 zc = c2{zm.x, -zm.y};
+    const c2 xe = 0.5 * (zk + zc), dd = 0.5 * (zk - zc);
+    const c2 xo = c2{dd.y, -dd.x};                    // (zk - conj zm) / (2 i)
+    const c2 X = xe + cmul(TW[M + k], xo);
+    amp[(size_t)f * NBIN + k] = sqrt(X.x * X.x + X.y * X.y) / (double)NF;
+  }
+  __syncthreads();
+  double* melv = (double*)x;                          // [FFB][NM] squares of exp(log-mel): the spectrum buffer is free now
+  const double amin = (double)d.min_clip / (double)NF;
+  const double rng = -20.0 * log10(amin);
+  for (int it = tid; it < FFB * NM; it += blockDim.x) {
+    const int f = it / NM, m = it % NM;
+    const double* av = amp + (size_t)f * NBIN;
+    double sacc = 0.0;
+    if (bof[m] >= 0) {
+      const double* fv = fbs + bof[m] - blo[m];
+      for (int k = blo[m]; k < bhi[m]; ++k) sacc = fma(fv[k], av[k], sacc);
+    } else {
+      const double* fv = fb + (long)m * NBIN;
+      for (int k = blo[m]; k < bhi[m]; ++k) sacc = fma(fv[k], av[k], sacc);
+    }
+    sacc = fabs(sacc);
+    if (sacc < amin) sacc = amin;
+    const double v = (20.0 * log10(sacc) + rng) / rng;
+    const double yv = log(pow(10.0, v / 20.0));
+    const double z = exp(yv);
+    melv[it] = z * z;                                 // (every thread its own exp; the frame's thread only adds, in mel order)
+    if (slot0 + f < nfr) logmel[(slot0 + f) * NM + m] = yv;
+  }
+  __syncthreads();
+  if (tid < FFB && slot0 + tid < nfr) {
+    double e = 0.0;
+    for (int m = 0; m < NM; ++m) e += melv[tid * NM + m];
+    energy[slot0 + tid] = sqrt(e);
+  }
+}
+
 // linear resampling at t_k = ((fs/hop)/fps) k : mel -> NaN outside the hull (griddata), energy extrapolates
 // animation frames k0 .. k0 + n_frames - 1; logmel / energy hold the STFT frames m0 .. (indices relative to m0)
 __global__ void mel_resample_k(ZeggsMelDims d, const double* logmel, const double* energy, long M, long m0, long k0,
@@ -278,12 +461,46 @@ __global__ void mel_resample_k(ZeggsMelDims d, const double* logmel, const doubl
 
 }  // namespace
 
-int g_mel_mfma = 1;      // zeggs_set_option("mel_mfma", 0/1): matrix-core DFT (default) / one workgroup per frame, direct DFT
+int g_mel_mfma = 1;      // zeggs_set_option("mel_mfma", 0/1): matrix-core DFT / one workgroup per frame, direct DFT (when the FFT form is off)
+int g_mel_fft = 1;       // zeggs_set_option("mel_fft", 0/1): the FFT form (default; n_fft / 2 must factor into 4, 5, 2)
+
+// radices of the half-length transform: 4s first, then 5s, then a 2 (400 = 4 4 5 5); nst = 0: not this path
+static FftPlan fft_plan(int M) {
+  FftPlan p{};
+  int m = M, n4 = 0, n5 = 0, n2 = 0;
+  while (m % 4 == 0) { m /= 4; ++n4; }
+  while (m % 5 == 0) { m /= 5; ++n5; }
+  while (m % 2 == 0) { m /= 2; ++n2; }
+  if (m != 1 || n4 + n5 + n2 > FMAXST || n4 + n5 + n2 == 0) return p;
+  for (int i = 0; i < n4; ++i) p.radix[p.nst++] = 4;
+  for (int i = 0; i < n5; ++i) p.radix[p.nst++] = 5;
+  for (int i = 0; i < n2; ++i) p.radix[p.nst++] = 2;
+  return p;
+}
 
 // STFT frames m0 .. m0 + nfr - 1 -> logmel / energy slots 0 .. nfr - 1
 static int launch_stft(const ZeggsMelDims& d, const MelWs& w, const float* wav, long n, long n_avail, const double* fb, long m0,
                        long nfr, hipStream_t s) {
   const int NBIN = d.n_fft / 2 + 1;
+  const FftPlan plan = fft_plan(d.n_fft / 2);
+  const size_t fft_lds = mel_fft_lds(d.n_fft, d.n_mels);
+  if (g_mel_fft && plan.nst > 0 && d.n_fft % 2 == 0 && fft_lds <= 160 * 1024 && (size_t)FFB * d.n_mels <= (size_t)2 * FFB * (d.n_fft / 2) &&
+      nfr >= 1) {
+    static bool fft_attr_set = false;
+    if (!fft_attr_set) {
+      if (hipFuncSetAttribute((const void*)mel_stft_fft_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        zeggs_set_error("mel: cannot raise the LDS limit of the FFT kernel");
+        return -1;
+      }
+      fft_attr_set = true;
+    }
+    hipLaunchKernelGGL(mel_fft_table_k, dim3(16), dim3(256), 0, s, (c2*)w.ftw, d.n_fft / 2, fb, d.n_mels, w.bands, w.fbp);
+    ZLAUNCH_CHECK("mel_fft_table");
+    hipLaunchKernelGGL(mel_stft_fft_k, dim3((unsigned)((nfr + FFB - 1) / FFB)), dim3(FTHR), fft_lds, s, d, plan, wav, n, n_avail, fb,
+                       (const c2*)w.ftw, w.bands, w.fbp, w.logmel, w.energy, m0, nfr);
+    ZLAUNCH_CHECK("mel_stft_fft");
+    return 0;
+  }
   const size_t fast_lds = mel_fast_lds(d.n_fft, d.hop, d.n_mels);
   if (g_mel_mfma && d.n_fft % 4 == 0 && 2 * NBIN <= MCOLP && fast_lds <= 160 * 1024 && nfr >= 1) {
     static bool attr_set = false;
