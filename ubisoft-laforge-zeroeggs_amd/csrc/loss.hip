@@ -30,9 +30,11 @@ __host__ __device__ inline Off offsets(int J) {
   return o;
 }
 
+constexpr int LOSS_TSPLIT = 2;      // workgroups per feature row of loss_terms4_k
 struct LossWs {
   float *FO, *FW, *LM, *G, *DQ;
   float *PT0, *PT1, *DPT;   // pose rows of both sides / their gradient, transposed to [PO][frames]
+  float* PS;                // per-workgroup partial sums of loss_terms4_k [rows][LOSS_TSPLIT][2]
 };
 LossWs carve_loss(const ZeggsLossDims& d, Arena& a) {
   LossWs w;
@@ -41,6 +43,7 @@ LossWs carve_loss(const ZeggsLossDims& d, Arena& a) {
   w.FO = a.f(NF * o.n); w.FW = a.f(NF * o.n); w.LM = a.f(NF * 9 * d.J); w.G = a.f(NF * o.n); w.DQ = a.f(NF * 4);
   const long PO = 6 + 15 * d.J;
   w.PT0 = a.f(NF * PO); w.PT1 = a.f(NF * PO); w.DPT = a.f(NF * PO);
+  w.PS = a.f((long)o.n * LOSS_TSPLIT * 2);
   return w;
 }
 
@@ -331,6 +334,65 @@ __global__ __launch_bounds__(256) void loss_terms_k(ZeggsLossDims d, const float
   }
 }
 
+// The same, four consecutive frames per thread (16-byte loads / stores; T % 4 == 0, so a thread's frames lie in one window) and
+// LOSS_TSPLIT workgroups per feature row: the scalar form moved 245 MB in 110 us (2.2x its HBM bound: 2 496 workgroups are 1.2
+// rounds of the chip, 4-byte accesses); identical G (same expression per element).  The workgroups' term sums go to a partials
+// table that loss_kl_final_k adds up in LDS: 5 000 float atomics onto the 18 words of ONE cache line were what the first version
+// of this kernel spent its time on (122 us, no faster than the scalar form).
+__global__ __launch_bounds__(256) void loss_terms4_k(ZeggsLossDims d, const float* FO, const float* FW, float* G,
+                                                      float* partial, float gscale) {
+  __shared__ float red[16];
+  const long NF = (long)d.B * d.T, NQ = NF / 4;
+  const int e = blockIdx.x;
+  int id, id2, size; float w, w2;
+  term_of(e, d.J, id, w, id2, w2, size);
+  const float n1 = (float)d.B * d.T * size, n2 = (float)d.B * (d.T - 1) * size;
+  const float* fo = FO + (long)e * NF;
+  const float* fw = FW + (long)e * NF;
+  const bool diff = id2 >= 0 && d.T > 1;
+  float s1 = 0.f, s2 = 0.f;
+  const long q0 = NQ * blockIdx.y / LOSS_TSPLIT, q1 = NQ * (blockIdx.y + 1) / LOSS_TSPLIT;
+  for (long q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
+    const long f0 = 4 * q;
+    const int t0 = (int)(f0 % d.T);
+    const f4 o = *(const f4*)(fo + f0), wv = *(const f4*)(fw + f0);
+    float op = 0.f, wp = 0.f, on = 0.f, wn = 0.f;        // neighbours across the thread's edges (inside the window)
+    if (diff && t0 > 0) { op = fo[f0 - 1]; wp = fw[f0 - 1]; }
+    if (diff && t0 + 4 < d.T) { on = fo[f0 + 4]; wn = fw[f0 + 4]; }
+    f4 g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + i;
+      const float o0 = o[i], w0 = wv[i];
+      const float v = w * (o0 - w0);
+      s1 += fabsf(v);
+      float gi = w * sgn(v) / n1;
+      if (diff) {
+        if (t + 1 < d.T) {
+          const float o1 = i < 3 ? o[i < 3 ? i + 1 : 3] : on, w1 = i < 3 ? wv[i < 3 ? i + 1 : 3] : wn;
+          const float dd = w2 * ((o1 - o0) / d.dt - (w1 - w0) / d.dt);
+          s2 += fabsf(dd);
+          gi -= w2 * sgn(dd) / (d.dt * n2);
+        }
+        if (t > 0) {
+          const float om = i > 0 ? o[i > 0 ? i - 1 : 0] : op, wm = i > 0 ? wv[i > 0 ? i - 1 : 0] : wp;
+          const float dd = w2 * ((o0 - om) / d.dt - (w0 - wm) / d.dt);
+          gi += w2 * sgn(dd) / (d.dt * n2);
+        }
+      }
+      g[i] = gi * gscale / 18.0f;
+    }
+    *(f4*)(G + (long)e * NF + f0) = g;
+  }
+  s1 = block_sum(s1, red);
+  if (id2 >= 0) s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    float* ps = partial + ((long)e * LOSS_TSPLIT + blockIdx.y) * 2;
+    ps[0] = s1 / n1;
+    ps[1] = diff ? s2 / n2 : 0.f;
+  }
+}
+
 // backward through FK / first-joint transform / orthogonalisation (prediction side), thread per frame.
 // Consumes G in place.  Level-parallel like the forward kernel, deepest level first; a joint never writes another
 // joint's rows: it GATHERS the totals of its character-space gradients (its own rows + its children's messages, in
@@ -541,9 +603,24 @@ __global__ void loss_rootvel_bwd_k(ZeggsLossDims d, FrameIO io, const float* G, 
 }
 
 // KL term (modules.py:778-779) + final sum/18 (train.py:402-421); one block
-__global__ __launch_bounds__(256) void loss_kl_final_k(const float* mu, const float* logvar, int n, int B, float klw,
-                                                        float* terms, float* dmu, float* dlogvar, float gscale) {
+__global__ __launch_bounds__(1024) void loss_kl_final_k(const float* mu, const float* logvar, int n, int B, float klw,
+                                                        float* terms, float* dmu, float* dlogvar, float gscale,
+                                                        const float* partial, int nrows, int J) {
   __shared__ float red[16];
+  __shared__ float tsum[18];
+  if (partial) {        // term sums of loss_terms4_k's workgroups (LDS atomics: 18 words, one workgroup)
+    if (threadIdx.x < 18) tsum[threadIdx.x] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nrows * LOSS_TSPLIT; i += blockDim.x) {
+      int id, id2, size; float w, w2;
+      term_of(i / LOSS_TSPLIT, J, id, w, id2, w2, size);
+      atomicAdd(&tsum[id], partial[2 * i]);
+      if (id2 >= 0) atomicAdd(&tsum[id2], partial[2 * i + 1]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 17) terms[threadIdx.x] += tsum[threadIdx.x];
+    __syncthreads();
+  }
   float s = 0.f;
   if (mu && klw > 0.f) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -627,10 +704,14 @@ extern "C" int zeggs_loss_fwd_bwd_ex(const ZeggsLossDims* dp, const int* parents
   hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(gend, 64)), dim3(64 * ZEGGS_LOSS_WAVES), 0, s, d, parents, ioO, ioW, w.PT0, w.PT1, gaze, w.FO,
                      w.FW, w.LM, 0L, gend);
   ZLAUNCH_CHECK("loss_frame_fwd");
-  hipLaunchKernelGGL(loss_terms_k, dim3(o.n), dim3(256), 0, s, d, w.FO, w.FW, w.G, terms, gscale);
+  if (d.T % 4 == 0 && ((uintptr_t)w.FO % 16 == 0) && ((uintptr_t)w.FW % 16 == 0) && ((uintptr_t)w.G % 16 == 0))      // (= vec4 below)
+    hipLaunchKernelGGL(loss_terms4_k, dim3(o.n, LOSS_TSPLIT), dim3(256), 0, s, d, w.FO, w.FW, w.G, w.PS, gscale);
+  else
+    hipLaunchKernelGGL(loss_terms_k, dim3(o.n), dim3(256), 0, s, d, w.FO, w.FW, w.G, terms, gscale);
   ZLAUNCH_CHECK("loss_terms");
-  hipLaunchKernelGGL(loss_kl_final_k, dim3(1), dim3(256), 0, s, mu, logvar, d.B * d.S, d.B, kl_weight, terms, dmu, dlogvar,
-                     gscale);
+  const bool vec4 = d.T % 4 == 0 && ((uintptr_t)w.FO % 16 == 0) && ((uintptr_t)w.FW % 16 == 0) && ((uintptr_t)w.G % 16 == 0);
+  hipLaunchKernelGGL(loss_kl_final_k, dim3(1), dim3(1024), 0, s, mu, logvar, d.B * d.S, d.B, kl_weight, terms, dmu, dlogvar,
+                     gscale, vec4 ? w.PS : (const float*)nullptr, o.n, d.J);
   ZLAUNCH_CHECK("loss_kl_final");
   if (dpose) {
     hipLaunchKernelGGL(loss_frame_bwd_k, dim3(cdiv(NF, 64)), dim3(64 * ZEGGS_LOSS_WAVES), 0, s, d, parents, ioO, gaze, w.PT0, w.FO, w.LM, w.G,
