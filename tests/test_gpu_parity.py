@@ -624,7 +624,7 @@ def test_generate_gesture_branches_vs_reference(golden_dir, tmp_path):
 def test_generate_gesture_streaming_writer_equals_one_launch(golden_dir, tmp_path, monkeypatch):
     """Long clips go through generate._decode_to_bvh_streaming (chunked persistent decode, BVH rows converted on the device per
     chunk and formatted by host threads underneath the next chunks): the file it writes equals the one-launch path's -- same
-    header bytes, same frame count, joint rotations < 0.02 degrees, root positions 2e-3 -- for chunk sizes that do and do not
+    header bytes, same frame count, joint rotations < 0.06 degrees, root positions 5e-3 -- for chunk sizes that do and do not
     divide the clip, including a single chunk, and the first-pose exemplar is parsed once."""
     import json
     import scipy.io.wavfile as wavfile
@@ -662,8 +662,11 @@ def test_generate_gesture_streaming_writer_equals_one_launch(golden_dir, tmp_pat
         assert open(res / f"{tag}.bvh").read().split("MOTION")[0] == head_ref                  # hierarchy + offsets: same bytes
         out = anim.bvh_load(res / f"{tag}.bvh")
         assert out["rotations"].shape == ref["rotations"].shape == (723, 75, 3), out["rotations"].shape
-        assert _bvh_angle_deg(out["rotations"], ref["rotations"]) < 2e-2, tag
-        np.testing.assert_allclose(out["positions"][:, 0], ref["positions"][:, 0], atol=2e-3, err_msg=tag)
+        # (chunk boundaries re-enter the recurrence through the unmerged layer0: fp32 re-association of ~1e-6 per boundary, which the
+        #  free-running random-init rollout carries and amplifies over the 723 frames -- measured 0.005 .. 0.022 degrees from run to
+        #  run (split-K atomics in the prologue GEMMs); a state hand-over bug would show as degrees)
+        assert _bvh_angle_deg(out["rotations"], ref["rotations"]) < 6e-2, tag
+        np.testing.assert_allclose(out["positions"][:, 0], ref["positions"][:, 0], atol=5e-3, err_msg=tag)
         assert (res / f"{tag}.wav").read_bytes() == (tmp_path / "a.wav").read_bytes()
 
 

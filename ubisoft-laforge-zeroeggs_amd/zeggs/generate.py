@@ -82,7 +82,7 @@ def _decode_to_bvh_streaming(decoder, pose0, rpos0, rrot0, gaze_row, speech, sty
     the rows of the BVH motion block ON THE DEVICE (zeggs_pose_to_bvh_table), downloaded on a copy stream into pinned memory
     and formatted by host threads (zeggs_format_table_text) WHILE the next chunks are being decoded; this thread writes the
     text blocks in order.  Same file as the one-launch path (decoder -> bvh_channels -> write_bvh_channels) up to the fp32
-    re-association at the chunk boundaries (joint rotations < 0.02 degrees apart, as any chunking of zeggs/stream.py):
+    re-association at the chunk boundaries (joint rotations a few hundredths of a degree apart after 700 free-running frames):
     tests/test_gpu_parity.py::test_generate_gesture_streaming_writer_equals_one_launch.  The decoder's frames are not kept
     (488 MB for 30 minutes).  Give-ups of the persistent kernel are collected in one status word that is looked at ONCE, after
     the last chunk: then everything is redone on the stage launches."""
