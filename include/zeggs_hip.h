@@ -470,6 +470,10 @@ int zeggs_pose_to_bvh_table(const ZeggsBvhDims*, const float* root_pos, const fl
 /* HOST helper of write_bvh / bvh.save (ZEGGS/anim/bvh.py: one text row per frame, "%f" per channel, a space after every
  * number): appends (append != 0) or writes `rows` x `cols` HOST doubles to `path`.  No device work. */
 int zeggs_write_table_text(const char* path, int append, const double* table /* host */, long rows, int cols);
+/* HOST helper of bvh.load (ZEGGS/anim/bvh.py: the MOTION block): `text` [len] bytes, NUL-terminated behind them, holding `rows`
+ * non-empty lines of `cols` whitespace-separated numbers each -> HOST doubles [rows, cols] (strtod: correctly rounded, as float()).
+ * -1 when the text does not have that shape.  No device work. */
+int zeggs_parse_table_text(const char* text, size_t len, double* table /* host */, long rows, int cols);
 /* the formatting half alone, into the caller's buffer (single-threaded, re-entrant: called from several host threads on row
  * blocks, the caller writes the blocks in order); *written = bytes produced.  cap >= rows * (cols * 24 + 1) suffices. */
 int zeggs_format_table_text(const double* table /* host */, long rows, int cols, char* out, size_t cap, size_t* written);

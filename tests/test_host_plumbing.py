@@ -163,3 +163,38 @@ def test_format_table_text_equals_the_file_writer(tmp_path):
     assert pieces == whole
     head, seq = anim.bvh_header(np.zeros((75, 3)), synth.PARENTS, synth.BONE_NAMES, "zyx", 257, synth.DT)
     assert sorted(seq) == list(range(75)) and seq[0] == 0 and head.endswith("Frames: 257\nFrame Time: %f\n" % synth.DT)
+
+
+def test_parse_table_text_is_exact_and_declines_malformed_tables(tmp_path):
+    """the host helper behind bvh_load's MOTION block (zeggs_parse_table_text: plain decimals through one exact division,
+    everything else through strtod, rows dealt to threads): every value == float(token); blank lines are skipped; a ragged or
+    short table is DECLINED (-1) so that bvh_load falls back to numpy.loadtxt and its error"""
+    import ctypes as C
+    from zeggs import ops
+    rng = np.random.default_rng(5)
+    toks = ["0.1", "-0.000001", "123456.654321", "9007199254740991", "9007199254740993", "1e-7", "-3.5e3",
+            "0.3333333333333333333", "179.999999", "-0", "42", "+7.25", "1e400", "0.000000", "-179.123456789012345678"]
+    toks += ["%f" % v for v in rng.standard_normal(3000 - len(toks)) * 10.0 ** rng.integers(-3, 4, 3000 - len(toks))]
+    rows, cols = 300, 10
+    lines = [" ".join(toks[r * cols:(r + 1) * cols]) + " " for r in range(rows)]
+    text = ("\n".join(lines[:100]) + "\n\n  \n" + "\n".join(lines[100:]) + "\n").encode()
+
+    def parse(buf, r, c):
+        out = np.full((r, c), np.nan)
+        rc = ops.lib().zeggs_parse_table_text(buf + b"\0", C.c_size_t(len(buf)), out.ctypes.data_as(C.c_void_p), C.c_long(r), int(c))
+        return rc, out
+
+    rc, out = parse(text, rows, cols)
+    assert rc == 0
+    want = np.array([float(t) for t in toks]).reshape(rows, cols)
+    assert np.array_equal(out, want) and np.array_equal(np.signbit(out), np.signbit(want))
+    assert parse(text, rows + 1, cols)[0] == -1 and parse(text, rows, cols + 1)[0] == -1          # wrong shape
+    assert parse(text.replace(b"42", b"4x2"), rows, cols)[0] == -1                                 # not a number
+    # end to end: a BVH with blank lines inside the MOTION block loads as before
+    clip = synth.make_bvh_clip(9, seed=2)
+    anim.bvh_save(tmp_path / "a.bvh", clip)
+    raw = (tmp_path / "a.bvh").read_text().split("\n")
+    raw.insert(len(raw) - 4, "")
+    (tmp_path / "b.bvh").write_text("\n".join(raw))
+    a, b = anim.bvh_load(tmp_path / "a.bvh"), anim.bvh_load(tmp_path / "b.bvh")
+    assert np.array_equal(a["rotations"], b["rotations"]) and np.array_equal(a["positions"], b["positions"])

@@ -216,6 +216,26 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
         style_net = style_net.eval() if style_net is not None else None
         assert style_net is not None or style_encoding_type != "example", "checkpoint has no style encoder"
 
+    # exemplar / first-pose BVH files are parsed on a host thread (the C parser releases the GIL) while this thread reads the WAV
+    # and enqueues the audio front-end: every distinct file once
+    from concurrent.futures import ThreadPoolExecutor
+    bvh_paths = [str(Path(s_[0])) for s_ in styles
+                 if style_encoding_type == "example" and isinstance(s_, (tuple, list)) and isinstance(s_[0], (pathlib.PurePath, str))]
+    if audio_file is not None and isinstance(first_pose, (pathlib.PurePath, str)):
+        bvh_paths.append(str(Path(first_pose)))
+    loader = ThreadPoolExecutor(max_workers=1) if (audio_file is not None and bvh_paths and PROFILE is None) else None
+    loading = {}
+    if loader is not None:
+        for pth in dict.fromkeys(bvh_paths):
+            loading[pth] = loader.submit(anim.bvh_load, pth)
+        loader.shutdown(wait=False)
+
+    def load_bvh(pth):
+        """parsed clip of a BVH path (a private copy: callers trim / modify it)"""
+        fut = loading.get(str(Path(pth)))
+        clip = fut.result() if fut is not None else anim.bvh_load(pth)
+        return {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in clip.items()}
+
     with torch.no_grad():
         if audio_file is not None:
             with _stage("wav_read_host"):
@@ -235,7 +255,7 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
                 if isinstance(style[0], (pathlib.PurePath, str)):
                     anim_name = Path(style[0]).stem
                     with _stage("exemplar_bvh_parse_host"):
-                        clip = anim.bvh_load(style[0])
+                        clip = load_bvh(style[0])
                     if style[1] is not None:
                         clip["rotations"] = clip["rotations"][style[1][0]:style[1][1]]
                         clip["positions"] = clip["positions"][style[1][0]:style[1][1]]
@@ -280,7 +300,7 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
                     feat = parsed[key]
                 else:
                     with _stage("first_pose_bvh_parse_host"):
-                        clip = anim.bvh_load(first_pose) if key is not None else dict(first_pose)
+                        clip = load_bvh(first_pose) if key is not None else dict(first_pose)
                     with _stage("first_pose_features_device"):
                         feat = anim.preprocess_animation(clip, device)
             g = lambda a: a[0:1].to(torch.float32).contiguous()  # noqa: E731
