@@ -615,6 +615,13 @@ def test_generate_gesture_branches_vs_reference(golden_dir, tmp_path):
     assert float((enc_d.cpu() - torch.as_tensor(gd["ndarray_encoding"])).abs().max()) < 1e-6
     o = anim.bvh_load(res / "ndarray_dict.bvh")
     assert _bvh_angle_deg(o["rotations"], gd["ndarray_rotations"]) < 2e-2
+    # the seed fixes the VAE noise (generate.py:86-87): the same call twice at temperature 1 gives the same encoding, another seed
+    # another one
+    kw = dict(style_encoding_type="example", blend_type="add", blend_ratio=[1.0], temperature=1.0)
+    e1 = generate.generate_gesture(None, [(A, None)], net, data, None, seed=77, **kw)
+    e2 = generate.generate_gesture(None, [(A, None)], net, data, None, seed=77, **kw)
+    e3 = generate.generate_gesture(None, [(A, None)], net, data, None, seed=78, **kw)
+    assert torch.equal(e1, e2) and float((e1 - e3).abs().max()) > 1e-3
     # default file name (generate.py:391-392): audio_<wav stem>_label_<style name>
     generate.generate_gesture(WAV, [(emb, "given")], net, data, res, style_encoding_type="example", blend_type="add",
                               blend_ratio=[1.0], first_pose=Bx, **common)

@@ -72,7 +72,7 @@ def _example_features(p):
 
 STREAM_MIN_FRAMES = 20000     # clips longer than this are decoded chunk by chunk with the BVH text written meanwhile
 STREAM_CHUNK = 8192
-STREAM_BLOCK = 1024           # rows per formatting task (host threads)
+STREAM_BLOCK = 512            # rows per formatting task (host threads)
 
 
 def _decode_to_bvh_streaming(decoder, pose0, rpos0, rrot0, gaze_row, speech, style, stats, dt, path, parents, names,
@@ -110,13 +110,24 @@ def _decode_to_bvh_streaming(decoder, pose0, rpos0, rrot0, gaze_row, speech, sty
     status = ops.new_status(dev)
     main = torch.cuda.current_stream()
 
-    def run(pool):
-        """enqueue everything; -> list of (pinned table, event) per chunk"""
-        staged = []
+    tail_rows = max(1, min(chunk // 4, 2048))
+    RING = 4                                             # pinned staging buffers in flight (page-locking 15 MB costs ~5 ms: not per chunk)
+    ring = _pinned_ring(RING, min(chunk, T) + 1, cols)
+
+    def run(pool, fh):
+        """decode chunk by chunk; chunk c's text is written while chunks c + 1 .. c + RING - 1 are queued on the device"""
+        pending = []                                     # per chunk in flight: its formatting futures, in row order
         state = (pose0, rpos0, rrot0, None)
-        k = 0                                            # last frame produced so far
-        while k < T - 1 or not staged:
+        k, c = 0, 0                                      # last frame produced so far, chunk index
+
+        def drain(keep):
+            while len(pending) > keep:
+                for f in pending.pop(0):
+                    fh.write(f.result())
+        while True:
             n = min(chunk, T - 1 - k)                    # new frames of this chunk
+            if n == T - 1 - k and n > tail_rows:         # the LAST chunk is short: what follows the end of the decode is only its
+                n -= tail_rows                           # conversion, download and formatting (the pipeline's tail)
             sp, sty = speech[:, k:k + n + 1], style[:, k:k + n + 1]
             gz = gaze_row.expand(n + 1, 3)[None]
             if n > 0:
@@ -143,7 +154,8 @@ def _decode_to_bvh_streaming(decoder, pose0, rpos0, rrot0, gaze_row, speech, sty
                 raise RuntimeError("zeggs_pose_to_bvh_table: " + L.zeggs_last_error().decode())
             done = torch.cuda.Event()
             done.record(main)
-            host = torch.empty(rows, cols, dtype=torch.float64).pin_memory()
+            drain(RING - 1)                              # the staging buffer of chunk c - RING has been formatted and written
+            host = ring[c % RING][:rows]
             with torch.cuda.stream(copy_stream):
                 copy_stream.wait_event(done)
                 host.copy_(table, non_blocking=True)
@@ -154,29 +166,37 @@ def _decode_to_bvh_streaming(decoder, pose0, rpos0, rrot0, gaze_row, speech, sty
             def fmt(host=host, ev=ev, r0=0, r1=0):
                 ev.synchronize()
                 return anim.format_rows(host[r0:r1].numpy())
-            staged.append([pool.submit(fmt, r0=r0, r1=min(r0 + block, rows)) for r0 in range(0, rows, block)])
+            pending.append([pool.submit(fmt, r0=r0, r1=min(r0 + block, rows)) for r0 in range(0, rows, block)])
             k += n
-            if n == 0:
+            c += 1
+            if n == 0 or k >= T - 1:
                 break
-        return staged
+        drain(0)
 
     with ThreadPoolExecutor(max_workers=threads or min(16, (__import__("os").cpu_count() or 4))) as pool:
-        staged = run(pool)
         with open(path, "wb") as fh:
             fh.write(head.encode())
-            for futs in staged:
-                for f in futs:
-                    fh.write(f.result())
+            run(pool, fh)
         if ops._persistent_live(0) and int(status[0].item()):     # (every chunk has been downloaded by now: no extra wait)
             ops._warn_gave_up(int(status[0].item()), "the whole rollout")
             ops.set_option("persistent", 0)
             ops.fill_(status.view(torch.float32))
-            staged = run(pool)
             with open(path, "wb") as fh:
                 fh.write(head.encode())
-                for futs in staged:
-                    for f in futs:
-                        fh.write(f.result())
+                run(pool, fh)
+
+
+_PINNED = {}
+
+
+def _pinned_ring(count, rows, cols):
+    """`count` page-locked float64 staging buffers [rows, cols], kept for the life of the process (page-locking is the expensive
+    part; 4 x 15 MB for the default chunk)"""
+    key = (count, cols)
+    ring = _PINNED.get(key)
+    if ring is None or ring[0].shape[0] < rows:
+        ring = _PINNED[key] = [torch.empty(rows, cols, dtype=torch.float64).pin_memory() for _ in range(count)]
+    return ring
 
 
 def generate_gesture(audio_file, styles, network_path, data_path, results_path, style_encoding_type="example",
@@ -191,6 +211,9 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
         raise RuntimeError("the ZeroEGGS MI355X engine has no CPU path (use_gpu=False / no GPU visible)")
     np.random.seed(seed)
     torch.manual_seed(seed)
+    from . import ops
+    ops.manual_seed(seed)       # the VAE noise comes from the library's counter-hash stream: the same seed gives the same clip,
+                                # as `torch.manual_seed(seed)` does for the reference's randn_like (generate.py:86-87)
     device = torch.device("cuda")
 
     with open(data_path / "data_pipeline_conf.json") as f:
@@ -223,7 +246,7 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
                  if style_encoding_type == "example" and isinstance(s_, (tuple, list)) and isinstance(s_[0], (pathlib.PurePath, str))]
     if audio_file is not None and isinstance(first_pose, (pathlib.PurePath, str)):
         bvh_paths.append(str(Path(first_pose)))
-    loader = ThreadPoolExecutor(max_workers=1) if (audio_file is not None and bvh_paths and PROFILE is None) else None
+    loader = ThreadPoolExecutor(max_workers=1) if (audio_file is not None and bvh_paths) else None
     loading = {}
     if loader is not None:
         for pth in dict.fromkeys(bvh_paths):
