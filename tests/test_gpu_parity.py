@@ -621,7 +621,7 @@ def test_generate_gesture_branches_vs_reference(golden_dir, tmp_path):
     e1 = generate.generate_gesture(None, [(A, None)], net, data, None, seed=77, **kw)
     e2 = generate.generate_gesture(None, [(A, None)], net, data, None, seed=77, **kw)
     e3 = generate.generate_gesture(None, [(A, None)], net, data, None, seed=78, **kw)
-    assert torch.equal(e1, e2) and float((e1 - e3).abs().max()) > 1e-3
+    assert float((e1 - e2).abs().max()) < 1e-5 and float((e1 - e3).abs().max()) > 1e-3       # (split-K atomics: not bitwise)
     # default file name (generate.py:391-392): audio_<wav stem>_label_<style name>
     generate.generate_gesture(WAV, [(emb, "given")], net, data, res, style_encoding_type="example", blend_type="add",
                               blend_ratio=[1.0], first_pose=Bx, **common)
