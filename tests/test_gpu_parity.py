@@ -1044,6 +1044,59 @@ def test_film_decoder_forward_backward(golden_dir):
         assert relerr(p.grad, w64[k].grad) < 3e-4, k
 
 
+@pytest.mark.parametrize("B,T", [(5, 6), (33, 4)])
+def test_film_decoder_stage_path_batches(golden_dir, B, T):
+    """RecurrentDecoderFiLM on the fragment-packed stage kernels at batches the variants fixture (B = 2) does not reach: the
+    matrix-core inference path (B >= 3), two and three batch blocks, a style that changes every frame (the modulation vectors
+    are per step: ZEGGS/modules.py:213-225 inside the frame loop :107-137).  Forward 1e-4 / gradients 3e-4 against the oracle in
+    float64, and against the generic per-step GEMM path (option decoder_fast = 0)."""
+    gd, _, s = _golden_nets(golden_dir)
+    de, _ = _variant_nets()
+    de_g = de.to(DEV).train()
+    torch.manual_seed(100 + B)
+    speech, style = torch.randn(B, T, 64) * 0.5, torch.randn(B, T, 64) * 0.5
+    rep = lambda x: x.repeat((B + 1) // 2, *([1] * (x.dim() - 1)))[:B].clone()  # noqa: E731
+    fp = [rep(x) for x in _first_pose(gd)]
+    for x in fp:
+        x += 0.01 * torch.randn_like(x)
+    fp[1] = fp[1] / fp[1].norm(dim=-1, keepdim=True)
+    gaze = rep(torch.as_tensor(gd["in_Y_gaze_pos"])[:, :1]).repeat(1, T, 1) + 0.05 * torch.randn(B, T, 3)
+    wts = [torch.randn(B, T, *o.shape[1:]) for o in fp]
+    s64 = {k: v.double() for k, v in s.items()}
+    w64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in de_g.state_dict().items()}
+    sp64, sy64 = speech.double().requires_grad_(True), style.double().requires_grad_(True)
+    O = onets.decoder_rollout(w64, *[t.double() for t in fp], gaze.double(), sp64, sy64, s64["in_mean"], s64["in_std"],
+                              s64["out_mean"], s64["out_std"], synth.DT)
+    sum((o * w.double()).sum() for o, w in zip(O, wts)).backward()
+    stat = [g(s[k]) for k in ("in_mean", "in_std", "out_mean", "out_std")]
+    with torch.no_grad():      # ring path
+        out = de_g(*[g(x) for x in fp], g(gaze), g(speech), g(style), None, *stat, synth.DT)
+    for n, o, r in zip(NAMES, out, O):
+        assert float((o.cpu().double() - r.detach()).abs().max()) < 1e-4, n
+    spg, syg = g(speech).requires_grad_(True), g(style).requires_grad_(True)
+    out = de_g(*[g(x) for x in fp], g(gaze), spg, syg, None, *stat, synth.DT)
+    for n, o, r in zip(NAMES, out, O):
+        assert float((o.detach().cpu().double() - r.detach()).abs().max()) < 1e-4, n
+    sum((o * g(w)).sum() for o, w in zip(out, wts)).backward()
+    assert relerr(spg.grad, sp64.grad) < 3e-4 and relerr(syg.grad, sy64.grad) < 3e-4
+    for k, p in de_g.named_parameters():
+        assert relerr(p.grad, w64[k].grad) < 3e-4, k
+    fast_grads = {k: p.grad.clone() for k, p in de_g.named_parameters()}
+    try:       # the generic path on the same inputs
+        ops.set_option("decoder_fast", 0)
+        de_g.zero_grad()
+        sp2, sy2 = g(speech).requires_grad_(True), g(style).requires_grad_(True)
+        ref = de_g(*[g(x) for x in fp], g(gaze), sp2, sy2, None, *stat, synth.DT)
+        sum((o * g(w)).sum() for o, w in zip(ref, wts)).backward()
+    finally:
+        ops.set_option("decoder_fast", 1)
+    for n, o, r in zip(NAMES, out, ref):
+        assert float((o.detach() - r.detach()).abs().max()) < 1e-4, n
+    assert relerr(spg.grad, sp2.grad) < 1e-4 and relerr(syg.grad, sy2.grad) < 1e-4
+    for k, p in de_g.named_parameters():
+        assert relerr(fast_grads[k], p.grad) < 1e-4, k
+
+
 def test_gru_style_encoder_forward_backward(golden_dir):
     """StyleEncoderGRU (+VAE): forward vs the reference, gradients vs the float64 oracle"""
     gd = np.load(golden_dir / "variants.npz")
@@ -1066,6 +1119,41 @@ def test_gru_style_encoder_forward_backward(golden_dir):
     ((z * g(wz.float())).sum() + (mu * g(wm.float())).sum() + (lv * g(wl.float())).sum()).backward()
     for k, p in st_g.named_parameters():
         assert relerr(p.grad, w64[k].grad) < 3e-4, k
+
+
+@pytest.mark.parametrize("B,L", [(32, 24), (35, 7)])
+def test_gru_style_encoder_stage_path_batch(B, L):
+    """StyleEncoderGRU with the forward-direction recurrence on the stage kernels (one launch per frame and direction) at
+    batches of two / three 16-row blocks: outputs and every gradient against the oracle in float64 and against the generic
+    per-step GEMM path (option decoder_fast = 0)"""
+    _, st = _variant_nets()
+    st_g = st.to(DEV).train()
+    torch.manual_seed(L)
+    ex, eps = torch.randn(B, L, synth.POSE_IN), torch.randn(B, 64)
+    w64 = {k: v.detach().cpu().double().requires_grad_(True) for k, v in st_g.state_dict().items()}
+    z64, mu64, lv64 = onets.style_encoder(w64, ex.double(), eps.double(), 1.0)
+    wz, wm, wl = torch.randn_like(z64), torch.randn_like(z64), torch.randn_like(z64)
+    ((z64 * wz).sum() + (mu64 * wm).sum() + (lv64 * wl).sum()).backward()
+
+    def run():
+        st_g.zero_grad()
+        z, mu, lv = st_g(g(ex), 1.0, eps=g(eps))      # (the exemplar is data: the binding returns no gradient for it)
+        ((z * g(wz.float())).sum() + (mu * g(wm.float())).sum() + (lv * g(wl.float())).sum()).backward()
+        return z.detach(), mu.detach(), lv.detach(), {k: p.grad.clone() for k, p in st_g.named_parameters()}
+
+    z, mu, lv, gr = run()
+    for a, r in ((z, z64), (mu, mu64), (lv, lv64)):
+        assert float((a.cpu().double() - r.detach()).abs().max()) < 5e-5
+    for k in gr:
+        assert relerr(gr[k], w64[k].grad) < 3e-4, k
+    try:
+        ops.set_option("decoder_fast", 0)
+        z2, mu2, lv2, gr2 = run()
+    finally:
+        ops.set_option("decoder_fast", 1)
+    assert float((z - z2).abs().max()) < 2e-5 and float((lv - lv2).abs().max()) < 2e-5
+    for k in gr:
+        assert relerr(gr[k], gr2[k]) < 1e-4, k
 
 
 @pytest.mark.parametrize("L", [1, 2, 37])

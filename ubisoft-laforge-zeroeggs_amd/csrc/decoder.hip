@@ -15,7 +15,7 @@
 #include "dec_math.h"
 #include "decoder_ws.h"
 
-static int g_decoder_fast = 1;
+int g_decoder_fast = 1;      // option "decoder_fast": 0 = generic per-step GEMM path everywhere (A/B reference of the stage kernels)
 static int g_bwd_chunks = 1;   // BPTT sweep chunks whose weight-gradient GEMMs overlap the rest of the sweep (1: serial)
 extern int g_stage_variant;
 extern int g_gemm_wg_target;

@@ -36,10 +36,10 @@ static bool g_tev_ok = false;
 static void timing_mark(int i, hipStream_t s) {
   if (!g_timing) return;
   if (!g_tev_ok) {
-    for (int k = 0; k < 4; ++k) hipEventCreate(&g_tev[k]);
+    for (int k = 0; k < 4; ++k) (void)hipEventCreate(&g_tev[k]);
     g_tev_ok = true;
   }
-  hipEventRecord(g_tev[i], s);
+  (void)hipEventRecord(g_tev[i], s);
 }
 extern "C" int zeggs_timing_ms(int which, float* ms) {
   ZCHECK(which == 0 || which == 1, "timing: which = 0 (forward sweep) or 1 (backward sweep)");
@@ -57,7 +57,9 @@ namespace {
 //   16384 every forward stage launched twice (cold vs L2-warm weights, tools/warm_probe.sh)
 enum { V_NOW = 2, V_NOEPI = 4 };
 
-enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_HID_MERGED, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX, EPI_GRU_BWD_M };
+// (forward epilogues first: launch_stage tells the two kernel families apart by `epi >= EPI_GRU_BWD`)
+enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_HID_MERGED, EPI_ELU_FILM, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX,
+       EPI_GRU_BWD_M, EPI_FILM_BWD };
 
 struct Seg {
   const float* w;   // packed weights  [tile][kb][64][4]
@@ -77,6 +79,7 @@ struct Grp {
   int tkbcat, kacc;
   const float *p0, *p1, *p2, *p3, *p4;
   float *o0, *o1, *o2, *o3, *o4, *o5;
+  int ld0;   // row stride of o0 in the ELU epilogues (0: a.GL, the [hid | x] rows of Gin)
 };
 struct StageArgs {
   Grp g[2];
@@ -338,12 +341,21 @@ __global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageA
       eact = tid < 16 * BP && eb < B && col < H;
       if (eact) pre[0] = G.p0[col];
     } break;
+    case EPI_ELU_FILM: if constexpr (FAM == 0) {   // p1 / p2: gamma / beta rows of this step, [B][2H] (pre-offset to the layer's half)
+      const int col = tile * 16 + ev;
+      eact = tid < 16 * BP && eb < B && col < H;
+      if (eact) { pre[0] = G.p0[col]; pre[1] = G.p1[(long)eb * 2 * H + col]; pre[2] = G.p2[(long)eb * 2 * H + col]; }
+    } break;
     case EPI_GRU_FWD: if constexpr (FAM == 0) {
       const int U = tile * 5 + ev;
       eact = tid < 5 * BP && eb < B && U < H;
       if (eact) {
         pre[0] = G.p0[U]; pre[1] = G.p1[U]; pre[2] = G.p0[H + U]; pre[3] = G.p1[H + U];
         pre[4] = G.p0[2 * H + U]; pre[5] = G.p1[2 * H + U]; pre[6] = G.p2[(long)eb * H + U];
+        if (G.p3) {   // input-side pre-activations of this step from memory ([B][3H], bias included: time-batched GEMM)
+          const float* gi = G.p3 + (long)eb * 3 * H;
+          pre[0] = gi[U]; pre[2] = gi[H + U]; pre[4] = gi[2 * H + U];
+        }
       }
     } break;
     case EPI_OUT_FWD: if constexpr (FAM == 0) {
@@ -406,7 +418,15 @@ __global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageA
     case EPI_DGIN: if constexpr (FAM == 1) {
       const int j = tile * 16 + ev;
       eact = tid < 16 * BP && eb < B && j < H + a.XD;
-      if (eact && j < H) pre[0] = G.p0[(long)eb * a.GL + j];
+      if (eact && j < H) {
+        if (G.p1) { pre[0] = G.p1[(long)eb * H + j]; pre[1] = G.p2[(long)eb * 2 * H + j]; }   // film: ELU output A0, gamma
+        else pre[0] = G.p0[(long)eb * a.GL + j];
+      }
+    } break;
+    case EPI_FILM_BWD: if constexpr (FAM == 1) {   // p0: ELU output A2 [B][H]; p1: gamma rows [B][2H] (pre-offset)
+      const int U = tile * 16 + ev;
+      eact = tid < 16 * BP && eb < B && U < H;
+      if (eact) { pre[0] = G.p0[(long)eb * H + U]; pre[1] = G.p1[(long)eb * 2 * H + U]; }
     } break;
     case EPI_DX: if constexpr (FAM == 1) {
       const int q = tile * 16 + ev;
@@ -620,10 +640,20 @@ __global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageA
         if (G.o1) st_out<CH>(&G.o1[xf_index(eb, col, LNB)], val);
       }
     } break;
+    case EPI_ELU_FILM: if constexpr (FAM == 0) {  // a = ELU(W x + b); out = a (1 + gamma) + beta (reference modules.py:213-225)
+      if (eact) {
+        const int col = tile * 16 + ev;
+        const float av = d_elu(FV(0, ev, eb) + pre[0]);
+        const float val = av * (1.f + pre[1]) + pre[2];
+        st_out<CH>(&G.o0[(long)eb * (G.ld0 ? G.ld0 : a.GL) + col], val);
+        if (G.o1) st_out<CH>(&G.o1[xf_index(eb, col, LNB)], val);
+        if (G.o2) G.o2[(long)eb * H + col] = av;      // pre-modulation activation, read by the backward pass only
+      }
+    } break;
     case EPI_GRU_FWD: if constexpr (FAM == 0) {   // tile = 5 hidden units x (r, z, n); acc0 = input side, acc1 = hidden side
       if (eact) {
         const int u = ev, b = eb, U = tile * 5 + u;
-        const float r = d_sigmoid(FV(0, u, b) + pre[0] + (FV(1, u, b) + pre[1]));
+        const float r = d_sigmoid(FV(0, u, b) + pre[0] + (FV(1, u, b) + pre[1]));   // (p3: pre[0,2,4] = stored input side)
         const float z = d_sigmoid(FV(0, 5 + u, b) + pre[2] + (FV(1, 5 + u, b) + pre[3]));
         const float nh = FV(1, 10 + u, b) + pre[5];
         const float nn = d_tanh(FV(0, 10 + u, b) + pre[4] + r * nh);
@@ -634,7 +664,7 @@ __global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageA
         if (G.o2) ((f4*)G.o2)[i] = f4{r, z, nn, nh};   // saved gates, one 16-byte store (read by the backward pass only)
       }
       if (a.cf_gin || a.cf_x || a.cf_cond) {   // speech / style columns of x_{t+1} (inputs: independent of this step)
-        const int XC = d.SP + d.ST;
+        const int XC = d.SP + (d.film ? 0 : d.ST);
         for (int e = blockIdx.x * NTHR + tid; e < B * XC; e += gridDim.x * NTHR) {
           const int b = e / XC, c = e % XC;
           const float val = c < d.SP ? a.speech[((long)b * d.T + t + 1) * d.SP + c]
@@ -757,7 +787,12 @@ __global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageA
         const int b = eb, j = tile * 16 + ev;
         const float g = FV(0, ev, b);
         if (j < H) {
-          const float d0 = g * d_elu_grad_from_out(pre[0]);
+          float d0 = g * d_elu_grad_from_out(pre[0]);
+          if (G.p1) {     // film: g is the gradient of the modulated value
+            d0 *= 1.f + pre[1];
+            G.o3[(long)b * 2 * H + j] = g * pre[0];
+            G.o4[(long)b * 2 * H + j] = g;
+          }
           G.o0[(long)b * H + j] = d0;
           G.o1[xf_index(b, j, LNB)] = d0;
         } else {
@@ -766,6 +801,17 @@ __global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageA
           if (a.rxf && c >= 6 && c < PO)     // operand of the merged W2^T product of the next launch
             a.rxf[xf_index(b, c, LNB)] = a.st.out_std[c] * (a.dpose[((long)b * d.T + t - 1) * PO + c] + g / a.st.in_std[c]);
         }
+      }
+    } break;
+    case EPI_FILM_BWD: if constexpr (FAM == 1) {  // dF2 = W3^T dy -> D2 = dF2 (1 + gamma) ELU'(A2), dgamma = dF2 A2, dbeta = dF2
+      if (eact) {
+        const int b = eb, U = tile * 16 + ev;
+        const float g = FV(0, ev, b);
+        const float d2 = g * (1.f + pre[1]) * d_elu_grad_from_out(pre[0]);
+        G.o0[(long)b * H + U] = d2;
+        G.o1[xf_index(b, U, LNB)] = d2;
+        G.o2[(long)b * 2 * H + U] = g * pre[0];
+        G.o3[(long)b * 2 * H + U] = g;
       }
     } break;
     case EPI_DX: if constexpr (FAM == 1) {        // dx_t = dXa + W0^T D0 ; pose part -> dy_{t-1} (devectorize/vectorize backward)
@@ -1023,7 +1069,9 @@ StageArgs base_args(const ZeggsDecDims& d, const ZeggsDecStats* st, const DecWs&
 
 }  // namespace
 
-int dec_fast_supported(const ZeggsDecDims& d) { return !d.film && d.H % 16 == 0 && d.B <= 64 && d.PI == d.PO + 3 && d.PO >= 16; }
+// rnn_cond "film" (RecurrentDecoderFiLM, ZEGGS/modules.py:188-227) runs the same stage kernels, five launches per step and
+// direction (the two modulated ELU layers cannot be folded into their neighbours); the persistent kernels decline it
+int dec_fast_supported(const ZeggsDecDims& d) { return d.H % 16 == 0 && d.B <= 64 && d.PI == d.PO + 3 && d.PO >= 16; }
 
 int dec_fast_pack_fwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s) {
   const int H = d.H, XD = w.XD;
@@ -1033,6 +1081,12 @@ int dec_fast_pack_fwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, 
   ZTRY(pack(w.pw_hh0, P->w_hh0, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s, w.TG0));
   ZTRY(pack(w.pw_ih1, P->w_ih1, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s, w.TG1));
   ZTRY(pack(w.pw_hh1, P->w_hh1, w.nT5, w.KBH, 1, H, 3 * H, H, d.PO, H, 0, s, w.TG1));
+  if (d.film) {
+    ZCHECK(P->l3_w && P->l3_b && P->g_w && P->g_b && P->be_w && P->be_b, "decoder: film parameters missing");
+    ZTRY(pack(w.pw_l2, P->l2_w, w.nTH, w.KBH, 0, H, H, H, d.PO, H, 0, s));
+    ZTRY(pack(w.pw_l3, P->l3_w, w.nTPO, w.KBH, 0, H, d.PO, H, d.PO, H, 0, s));
+    return 0;
+  }
   ZTRY(pack(w.pw_l2, P->l2_w, w.nTPO, w.KBH, 0, H, d.PO, H, d.PO, H, 0, s));
   return 0;
 }
@@ -1066,6 +1120,10 @@ int dec_fast_pack_merged(const ZeggsDecDims& d, const ZeggsDecParams* P, const Z
 
 int dec_fast_pack_bwd(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s) {
   const int H = d.H, XD = w.XD;
+  if (d.film) {
+    ZTRY(pack(w.pb_l3, P->l3_w, w.nTH, w.KBPO, 2, d.PO, H, H, d.PO, H, 0, s));         // V[U][c] = W3[c][U]
+    ZTRY(pack(w.pb_l2, P->l2_w, w.nTH, w.KBH, 2, H, H, H, d.PO, H, 0, s));             // V[U][k] = W2[k][U]
+  } else
   if (!(g_stage_variant & 8192) && d.T > 2) {
     // merged stage (dx of step t + layer-1 gates of step t-1): M' = W0[:, 6:PO] diag(sigma_o/sigma_i) W2[6:PO, :],
     // packed transposed (V[U][k] = M'[k][U]); the six root columns take the non-linear root-integration path.
@@ -1077,7 +1135,7 @@ int dec_fast_pack_bwd(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zegg
     ZTRY(gemm_nn(w.W0s, w.POL, P->l2_w, H, w.Mc, H, H, d.PO, H, 0.f, s));
     ZTRY(pack(w.pb_mt, w.Mc, w.nTH, w.KBH, 2, H, H, H, d.PO, H, 0, s));
   }
-  ZTRY(pack(w.pb_l2, P->l2_w, w.nTH, w.KBPO, 2, d.PO, H, H, d.PO, H, 0, s));          // V[U][c] = W2[c][U]
+  if (!d.film) ZTRY(pack(w.pb_l2, P->l2_w, w.nTH, w.KBPO, 2, d.PO, H, H, d.PO, H, 0, s));          // V[U][c] = W2[c][U]
   ZTRY(pack(w.pb_ih1, P->w_ih1, w.nTH, w.KB3H, 2, 3 * H, H, H, d.PO, H, 0, s));        // V[U][k] = W_ih1[k][U]
   ZTRY(pack(w.pb_hh1, P->w_hh1, w.nTH, w.KB3H, 2, 3 * H, H, H, d.PO, H, 0, s));
   ZTRY(pack(w.pb_ih0, P->w_ih0, w.nTGI, w.KB3H, 2, 3 * H, H + XD, H, d.PO, H + XD, 0, s));
@@ -1112,7 +1170,7 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   // weights and must be finite)
   const bool gemv = !training && B <= 2 && !(g_stage_variant & 1024);
   // 3 launches per step: layer2 of step t and layer0 of step t+1 run in ONE launch (variant 4096: 4 launches)
-  const bool merged = !(g_stage_variant & 4096);
+  const bool merged = !(g_stage_variant & 4096) && !d.film;
   if (merged && T > 2) ZTRY(dec_fast_pack_merged(d, P, st, w, s));
   Chain ch;
   ch.s[0] = ch.s[1] = s;
@@ -1120,7 +1178,7 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;   // a failed query must not read as "not capturing"
     const int per_wave = (w.KBH + w.KBX + w.KBH + 7) / 8;            // the widest stage (GRU layer 0)
-    if (g_chain && gemv && T > 2 && cap == hipStreamCaptureStatusNone && per_wave <= CH_GPRE &&
+    if (g_chain && gemv && !d.film && T > 2 && cap == hipStreamCaptureStatusNone && per_wave <= CH_GPRE &&
         !(g_stage_variant & (16384 | V_NOW | V_NOEPI))) {
       ZTRY(chain_stream(&ch.cs));
       ch.on = true;
@@ -1143,13 +1201,23 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     float* gin_n = w.Gin + cs(t + 1) * sG;
     const float *h0p = w.H0 + cs(t - 1) * sH, *h1p = w.H1 + cs(t - 1) * sH;
     float *h0c = w.H0 + cs(t) * sH, *h1c = w.H1 + cs(t) * sH;
+    const float *gam = nullptr, *bet = nullptr;
+    if (d.film) {
+      if (!training) {   // ring path: this step's modulation vectors from style[:, t] (training: every step's, decoder.hip)
+        ZTRY(gemm_nt(style + (long)t * d.ST, (long)T * d.ST, P->g_w, d.ST, w.GAM, 2 * H, P->g_b, B, 2 * H, d.ST, ACT_NONE, 0.f, s));
+        ZTRY(gemm_nt(style + (long)t * d.ST, (long)T * d.ST, P->be_w, d.ST, w.BET, 2 * H, P->be_b, B, 2 * H, d.ST, ACT_NONE, 0.f, s));
+      }
+      gam = w.GAM + (training ? (long)t * B * 2 * H : 0);
+      bet = w.BET + (training ? (long)t * B * 2 * H : 0);
+    }
     if (t == 1 || !merged) {
-      // S1: hid = ELU(W0 x + b0)
+      // S1: hid = ELU(W0 x + b0)   [film: modulated]
       a.g[0] = Grp{}; a.g[1] = Grp{};
       a.g[0].seg[0] = seg(w.pw_l0, Xxf[c], w.KBX, 0, gin_c + H, w.GL); a.g[0].nseg = 1; a.g[0].tiles = w.nTH;
       a.g[0].wcat = w.pw_l0; a.g[0].tkbcat = w.KBX; a.g[0].kacc = w.KBX;
-      a.g[0].epi = EPI_ELU_HID;
+      a.g[0].epi = d.film ? EPI_ELU_FILM : EPI_ELU_HID;
       a.g[0].p0 = P->l0_b; a.g[0].o0 = w.Gin + cs(t) * sG; a.g[0].o1 = gemv ? nullptr : w.HIDxf;
+      if (d.film) { a.g[0].p1 = gam; a.g[0].p2 = bet; a.g[0].o2 = training ? w.A0 + o : nullptr; }
       ZTRY(launch_stage(a, ch.next(a, stage_wgs(a))));
     }
     // S2: GRU layer 0
@@ -1179,6 +1247,24 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     }
     ZTRY(launch_stage(a, ch.next(a, stage_wgs(a))));
     a.cf_gin = a.cf_x = a.cf_cond = nullptr;
+    if (d.film) {
+      // S4a: F2 = FiLM(ELU(W2 h1 + b2))
+      float* f2 = w.F2 + cs(t) * sH;
+      a.g[0] = Grp{}; a.g[1] = Grp{};
+      a.g[0].seg[0] = seg(w.pw_l2, H1xf[c], w.KBH, 0, h1c, H); a.g[0].nseg = 1; a.g[0].tiles = w.nTH;
+      a.g[0].epi = EPI_ELU_FILM; a.g[0].ld0 = H;
+      a.g[0].p0 = P->l2_b; a.g[0].p1 = gam + H; a.g[0].p2 = bet + H;
+      a.g[0].o0 = f2; a.g[0].o1 = gemv ? nullptr : w.F2xf; a.g[0].o2 = training ? w.A2 + o : nullptr;
+      ZTRY(launch_stage(a, s));
+      // S4b: y = W3 F2 + b3 -> pose[t], root integration, pose/gaze columns of x_{t+1}
+      a.g[0] = Grp{};
+      a.g[0].seg[0] = seg(w.pw_l3, w.F2xf, w.KBH, 0, f2, H); a.g[0].nseg = 1; a.g[0].tiles = w.nTPO;
+      a.g[0].epi = EPI_OUT_FWD;
+      a.g[0].p0 = P->l3_b; a.g[0].o0 = next ? gin_n : nullptr;
+      a.g[0].o1 = gemv ? nullptr : Xxf[(t + 1) & 1];
+      ZTRY(launch_stage(a, s));
+      continue;
+    }
     // S4: y = W2 h1 + b2 -> pose[t], root integration, pose/gaze columns of x_{t+1}
     //     [merged: + hid_{t+1} = ELU(M h1 + Wc cond_{t+1} + W0[:, gaze] g_{t+1} + cvec) in the same launch]
     a.g[0] = Grp{}; a.g[1] = Grp{};
@@ -1214,7 +1300,7 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   if (T < 2) return 0;
   if (t_hi == T - 1) {   // first chunk of the sweep
     ZTRY(k_fill(w.xf_base_bwd, (long)(w.xf_bytes_bwd / 4), 0.f, s));
-    const bool merged0 = !(g_stage_variant & 8192) && T > 2;   // carry slot read by the first dx stage (see below)
+    const bool merged0 = !(g_stage_variant & 8192) && T > 2 && !d.film;   // carry slot read by the first dx stage (see below)
     hipLaunchKernelGGL(dy_last_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, gaze, pose, rpos, rrot,
                        w.carry + (merged0 ? (long)((T - 1) & 1) * B * 8 : 0), w.DY + (long)(T - 1) * B * w.POL, w.POL,
                        w.DYxf, NB);
@@ -1222,7 +1308,7 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   }
   // 3 launches per step: the dx stage of step t also evaluates the layer-1 gate gradients of step t-1 (variant 8192:
   // separate launches).  The root-state carry is double-buffered: slot (t & 1) is read, slot ((t - 1) & 1) written.
-  const bool merged = !(g_stage_variant & 8192) && T > 2;
+  const bool merged = !(g_stage_variant & 8192) && T > 2 && !d.film;
   if (t_hi == T - 1) timing_mark(2, s);
   for (int t = t_hi; t >= t_lo; --t) {
     const long o = (long)t * sH;
@@ -1232,10 +1318,20 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     float* c_in = w.carry + (merged ? (long)(t & 1) * B * 8 : 0);
     float* c_out = w.carry + (merged ? (long)((t - 1) & 1) * B * 8 : 0);
     a.carry = c_in; a.carry_out = c_out;
-    if (t == T - 1 || !merged) {
-      // B1: dH1 = W2^T dy + carry -> layer-1 gate gradients
+    if (d.film) {
+      // B0: dF2 = W3^T dy -> D2 (through the modulation and layer2's ELU), dgamma / dbeta of layer2's half
+      const long og = (long)t * B * 2 * H;
       a.g[0] = Grp{}; a.g[1] = Grp{};
-      a.g[0].seg[0] = seg(w.pb_l2, w.DYxf, w.KBPO, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
+      a.g[0].seg[0] = seg(w.pb_l3, w.DYxf, w.KBPO, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_FILM_BWD;
+      a.g[0].p0 = w.A2 + o; a.g[0].p1 = w.GAM + og + H;
+      a.g[0].o0 = w.D2 + o; a.g[0].o1 = w.D2xf; a.g[0].o2 = w.DGAM + og + H; a.g[0].o3 = w.DBET + og + H;
+      ZTRY(launch_stage(a, s));
+    }
+    if (t == T - 1 || !merged) {
+      // B1: dH1 = W2^T dy + carry -> layer-1 gate gradients   [film: W2^T D2]
+      a.g[0] = Grp{}; a.g[1] = Grp{};
+      a.g[0].seg[0] = d.film ? seg(w.pb_l2, w.D2xf, w.KBH, 0) : seg(w.pb_l2, w.DYxf, w.KBPO, 0);
+      a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
       a.g[0].p0 = w.GT1 + 4 * o; a.g[0].p4 = w.H1 + o - sH;
       a.g[0].o0 = w.dH1c; a.g[0].o1 = w.DI1 + t * s3; a.g[0].o2 = w.DH1 + o; a.g[0].o3 = w.DI1xf; a.g[0].o4 = w.DH1xf;
       ZTRY(launch_stage(a, s));
@@ -1255,6 +1351,10 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     a.g[0] = Grp{}; a.g[1] = Grp{};
     a.g[0].seg[0] = seg(w.pb_ih0, w.DI0xf, w.KB3H, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTGI; a.g[0].epi = EPI_DGIN;
     a.g[0].p0 = w.Gin + t * sG; a.g[0].o0 = w.D0 + o; a.g[0].o1 = w.D0xf; a.g[0].o2 = w.dXa;
+    if (d.film) {   // layer0's modulation: D0 through (1 + gamma) ELU'(A0), dgamma / dbeta of layer0's half
+      const long og = (long)t * B * 2 * H;
+      a.g[0].p1 = w.A0 + o; a.g[0].p2 = w.GAM + og; a.g[0].o3 = w.DGAM + og; a.g[0].o4 = w.DBET + og;
+    }
     a.g[1].seg[0] = subseg(w.pb_hh0, w.DI0xf, 0, 2 * w.KBH, w.KB3H, 0);
     a.g[1].seg[1] = subseg(w.pb_hh0, w.DH0xf, 2 * w.KBH, w.KBH, w.KB3H, 0);
     a.g[1].nseg = 2; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_ADD;
@@ -1282,5 +1382,73 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     ZTRY(launch_stage(a, s));
   }
   if (t_lo <= 1) timing_mark(3, s);
+  return 0;
+}
+
+// ---- style encoder "gru" (style_gru.hip; reference StyleEncoderGRU, ZEGGS/modules.py:307-343): the forward-direction
+// recurrence h_{t+1} = GRU(x_t, h_t) and its BPTT on the same stage kernels -- ONE launch per frame and direction instead of a
+// skinny GEMM + gate kernel (+ copy) each.  The input-side pre-activations GI [L][B][3H] come from one time-batched GEMM
+// (EPI_GRU_FWD reads them through Grp.p3); W_hh (3 MB at H = 512) stays L2-resident across the frames: the sweep is
+// launch-bound.  Saved gates are float4 (r, z, n, W_hn h + b_hn) per unit; the hidden-side gate gradients are kept compact
+// (their r, z rows are those of DI) as in the decoder's sweep.
+extern int g_decoder_fast;
+int sg_fast_supported(int B, int H) { return g_decoder_fast && H % 16 == 0 && H >= 16 && B >= 1 && B <= 64; }
+SgFast sg_fast_carve(int B, int H, int L, Arena& a) {
+  SgFast f;
+  memset(&f, 0, sizeof(f));
+  f.NB = (B + 15) / 16; f.nT5 = (H + 4) / 5; f.nTH = H / 16; f.KBH = H / 16; f.KB3H = 3 * H / 16;
+  const long XB = 256L * f.NB;
+  f.pw = a.f((long)f.nT5 * f.KBH * 256);
+  f.pb = a.f((long)f.nTH * f.KB3H * 256);
+  f.xf = a.f(2 * f.KBH * XB + 2 * f.KB3H * XB + 2 * f.KBH * XB);
+  f.xf_floats = 2 * f.KBH * XB + 2 * f.KB3H * XB + 2 * f.KBH * XB;
+  f.Hxf = f.xf; f.DIxf = f.xf + 2 * f.KBH * XB; f.DHxf = f.DIxf + 2 * f.KB3H * XB;
+  f.GT = a.f((long)L * B * H * 4);
+  f.DHn = a.f((long)L * B * H);
+  return f;
+}
+static StageArgs sg_args(int B, int H, const SgFast& f) {
+  StageArgs a;
+  memset(&a, 0, sizeof(a));
+  a.d.B = B; a.d.H = H; a.d.T = 1; a.NB = f.NB; a.variant = 0;
+  return a;
+}
+// Hs [(L+1)][B][H] with slot 0 = the initial state (zero), GI [L][B][3H] incl. b_ih
+int sg_fast_fwd(int B, int H, int L, const float* w_hh, const float* b_hh, const float* GI, float* Hs, const SgFast& f,
+                hipStream_t s) {
+  const long sH = (long)B * H, XB = 256L * f.NB;
+  ZTRY(pack(f.pw, w_hh, f.nT5, f.KBH, 1, H, 3 * H, H, 0, H, 0, s));
+  ZTRY(k_fill(f.xf, f.xf_floats, 0.f, s));
+  for (int t = 0; t < L; ++t) {
+    StageArgs a = sg_args(B, H, f);
+    float *hx_in = f.Hxf + (long)(t & 1) * f.KBH * XB, *hx_out = f.Hxf + (long)((t + 1) & 1) * f.KBH * XB;
+    a.g[0].seg[0] = seg(f.pw, hx_in, f.KBH, 1, Hs + t * sH, H); a.g[0].nseg = 1; a.g[0].tiles = f.nT5;
+    a.g[0].epi = EPI_GRU_FWD;
+    a.g[0].p0 = b_hh; a.g[0].p1 = b_hh; a.g[0].p2 = Hs + t * sH; a.g[0].p3 = GI + (long)t * 3 * sH;
+    a.g[0].o0 = Hs + (t + 1) * sH; a.g[0].o1 = hx_out; a.g[0].o2 = f.GT + 4 * t * sH;
+    ZTRY(launch_stage(a, s));
+  }
+  return 0;
+}
+// dhc [B][H]: in = gradient wrt h_L (the last state), out = gradient wrt h_0; DI [L][B][3H] (grad wrt the input-side
+// pre-activations) and f.DHn [L][B][H] (n rows of the hidden side) are left for the weight-gradient GEMMs
+int sg_fast_bwd(int B, int H, int L, const float* w_hh, const float* Hs, float* DI, float* dhc, const SgFast& f, hipStream_t s) {
+  const long sH = (long)B * H, XB = 256L * f.NB;
+  ZTRY(pack(f.pb, w_hh, f.nTH, f.KB3H, 2, 3 * H, H, H, 0, H, 0, s));      // V[U][k] = W_hh[k][U]
+  ZTRY(k_fill(f.DIxf, 2 * f.KB3H * XB + 2 * f.KBH * XB, 0.f, s));
+  for (int t = L - 1; t >= 0; --t) {
+    StageArgs a = sg_args(B, H, f);
+    float *di_in = f.DIxf + (long)((t + 1) & 1) * f.KB3H * XB, *di_out = f.DIxf + (long)(t & 1) * f.KB3H * XB;
+    float *dh_in = f.DHxf + (long)((t + 1) & 1) * f.KBH * XB, *dh_out = f.DHxf + (long)(t & 1) * f.KBH * XB;
+    if (t < L - 1) {     // dh_t = W_hh^T dhh_{t+1} + dh_{t+1} z_{t+1}
+      a.g[0].seg[0] = subseg(f.pb, di_in, 0, 2 * f.KBH, f.KB3H, 0);
+      a.g[0].seg[1] = subseg(f.pb, dh_in, 2 * f.KBH, f.KBH, f.KB3H, 0);
+      a.g[0].nseg = 2;
+    }
+    a.g[0].tiles = f.nTH; a.g[0].epi = EPI_GRU_BWD;
+    a.g[0].p0 = f.GT + 4 * t * sH; a.g[0].p4 = Hs + t * sH;
+    a.g[0].o0 = dhc; a.g[0].o1 = DI + (long)t * 3 * sH; a.g[0].o2 = f.DHn + t * sH; a.g[0].o3 = di_out; a.g[0].o4 = dh_out;
+    ZTRY(launch_stage(a, s));
+  }
   return 0;
 }

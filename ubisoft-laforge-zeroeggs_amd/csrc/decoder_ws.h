@@ -22,6 +22,9 @@ struct DecWs {
   // pw_g1 = [ih1 | hh1], pw_mc = [M | Wc | copy of layer2's tile 0]) so that a wave's share of the concatenated
   // contraction is one address range (chained GEMV launches); the named pointers are sub-ranges (Seg.tkb = TG*)
   float *pw_l0, *pw_ih0h, *pw_ih0x, *pw_hh0, *pw_ih1, *pw_hh1, *pw_l2;
+  // FiLM decoder on the stage kernels: layer2 is [H,H] (pw_l2: nTH tiles), layer3 [PO,H] (pw_l3); transposed packs pb_l2
+  // (V[U][k] = W2[k][U]) and pb_l3 (V[U][c] = W3[c][U]); fragments of F2 = FiLM(ELU(layer2)) and of D2 = grad wrt layer2's output
+  float *pw_l3, *pb_l3, *F2xf, *D2xf;
   float *pw_g0, *pw_g1, *pw_mc, *pw_l2c;
   int TG0, TG1, TMC;
   float *pb_l2, *pb_ih1, *pb_hh1, *pb_ih0, *pb_hh0, *pb_l0, *pb_mt;      // backward (transposed) packs
@@ -83,7 +86,6 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
       w.DGAM = a.f(T * B * 2 * H); w.DBET = a.f(T * B * 2 * H); w.D2 = a.f(T * B * H); w.dF2 = a.f(B * H);
       w.STm = a.f(T * B * (long)d.ST); w.dSTm = a.f(T * B * (long)d.ST);
     }
-    return w;   // the fragment-packed fast path covers rnn_cond "normal" only
   }
   // ---- fast path
   w.NB = (d.B + 15) / 16;
@@ -98,7 +100,8 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
   w.pw_ih0h = w.pw_g0; w.pw_ih0x = w.pw_g0 + w.KBH * BLK; w.pw_hh0 = w.pw_g0 + (w.KBH + w.KBX) * BLK;
   w.pw_g1 = a.f((long)w.nT5 * w.TG1 * BLK);
   w.pw_ih1 = w.pw_g1; w.pw_hh1 = w.pw_g1 + w.KBH * BLK;
-  w.pw_l2 = a.f((long)w.nTPO * w.KBH * BLK);
+  w.pw_l2 = a.f((long)(d.film ? w.nTH : w.nTPO) * w.KBH * BLK);
+  if (d.film) w.pw_l3 = a.f((long)w.nTPO * w.KBH * BLK);
   w.pw_mc = a.f((long)w.nTH * w.TMC * BLK);
   w.pw_m = w.pw_mc; w.pw_c = w.pw_mc + w.KBH * BLK; w.pw_l2c = w.pw_mc + (w.KBH + w.KBC) * BLK;
   w.W0s = a.f(H * (long)w.POL); w.Mc = a.f(H * H); w.vvec = a.f(w.POL); w.cvec = a.f(H);
@@ -107,6 +110,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
     size_t o0 = a.off;
     w.Xxf = a.f(2 * w.KBX * XB); w.HIDxf = a.f(w.KBH * XB); w.H0xf = a.f(2 * w.KBH * XB); w.H1xf = a.f(2 * w.KBH * XB);
     w.CONDxf = a.f(w.KBC * XB);
+    if (d.film) w.F2xf = a.f(w.KBH * XB);
     w.chain = (unsigned*)a.f(4096);
     w.pgran_bytes = 36864;
     w.pgran = a.raw(w.pgran_bytes);
@@ -114,7 +118,8 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
     w.xf_bytes_fwd = a.off - align_up(o0, 256);
   }
   if (training) {
-    w.pb_l2 = a.f((long)w.nTH * w.KBPO * BLK);
+    w.pb_l2 = a.f((long)w.nTH * (d.film ? w.KBH : w.KBPO) * BLK);
+    if (d.film) w.pb_l3 = a.f((long)w.nTH * w.KBPO * BLK);
     w.pb_ih1 = a.f((long)w.nTH * w.KB3H * BLK);
     w.pb_hh1 = a.f((long)w.nTH * w.KB3H * BLK);
     w.pb_ih0 = a.f((long)w.nTGI * w.KB3H * BLK);
@@ -124,17 +129,18 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
     size_t o0 = a.off;
     w.DYxf = a.f(w.KBPO * XB); w.DI1xf = a.f(w.KB3H * XB); w.DH1xf = a.f(w.KB3H * XB);
     w.DI0xf = a.f(w.KB3H * XB); w.DH0xf = a.f(w.KB3H * XB); w.D0xf = a.f(w.KBH * XB); w.Rxf = a.f(w.KBPO * XB);
+    if (d.film) w.D2xf = a.f(w.KBH * XB);
     w.xf_base_bwd = w.DYxf;
     w.xf_bytes_bwd = a.off - align_up(o0, 256);
     w.dXa = a.f(B * (long)w.XD);
-    if (d.H == 1024 && d.B <= 64) {
+    if (d.H == 1024 && d.B <= 64 && !d.film) {
       const long KB0 = 64 + w.KBX + 64, KB3 = 64 + w.KBC;
       w.tp_w0 = a.f(256L * 8 * 26 * BLK); w.tp_w1 = a.f(256L * 8 * 16 * BLK); w.tp_w3 = a.f(256L * 8 * 9 * BLK);   // [wg][wave][block]
       w.G0xf = a.f(T * KB0 * XB); w.G1xf = a.f(T * 128 * XB); w.G3xf = a.f(T * KB3 * XB);
       w.tp_n0s = a.f(3 * H * (long)w.POL); w.tp_n0 = a.f(3 * H * H); w.tp_cv0 = a.f(3 * H); w.tp_p1x = a.f(B * 3 * H);
       w.tp_cnt = (unsigned*)a.f(8192);      // arrival slots | error word (+1024) | stamps | wait statistics (+1536)
     }
-    if (d.H == 1024 && d.B <= 64) {
+    if (d.H == 1024 && d.B <= 64 && !d.film) {
       w.bp_wr = a.f(256L * 8 * 113 * 64); w.bp_wl = a.f(256L * 8 * 64 * 64);
       w.bp_opy = a.f(T * (long)((d.PO + 15) / 16) * 512);
       w.bp_op1 = a.f(T * 4 * H * 32); w.bp_op0 = a.f(T * 4 * H * 32); w.bp_opd = a.f(T * H * 32);

@@ -99,3 +99,16 @@ int k_attn_fwd(const float* qkv, float* O, float* lse, int B, int L, int E, int 
 // dbias != null: [3E] += column sums of dqkv (atomics onto a zeroed / accumulating bias gradient)
 int k_attn_bwd(const float* qkv, const float* O, const float* lse, const float* dO, float* dqkv, float* dsum, float* dbias,
                int B, int L, int E, int NH, float p, uint64_t seed, hipStream_t s);
+
+// style encoder "gru": forward-direction recurrence and BPTT on the decoder's stage kernels (decoder_fast.hip)
+struct Arena;
+struct SgFast {
+  float *pw, *pb, *xf, *Hxf, *DIxf, *DHxf, *GT, *DHn;
+  long xf_floats;
+  int NB, nT5, nTH, KBH, KB3H;
+};
+int sg_fast_supported(int B, int H);
+SgFast sg_fast_carve(int B, int H, int L, Arena& a);
+int sg_fast_fwd(int B, int H, int L, const float* w_hh, const float* b_hh, const float* GI, float* Hs, const SgFast& f,
+                hipStream_t s);
+int sg_fast_bwd(int B, int H, int L, const float* w_hh, const float* Hs, float* DI, float* dhc, const SgFast& f, hipStream_t s);

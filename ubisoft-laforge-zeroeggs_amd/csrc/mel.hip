@@ -505,7 +505,7 @@ static int launch_stft(const ZeggsMelDims& d, const MelWs& w, const float* wav, 
   if (g_mel_mfma && d.n_fft % 4 == 0 && 2 * NBIN <= MCOLP && fast_lds <= 160 * 1024 && nfr >= 1) {
     static bool attr_set = false;
     if (!attr_set) {       // more than 64 KB of dynamic LDS needs the opt-in
-      hipFuncSetAttribute((const void*)mel_stft_mfma_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)mel_stft_mfma_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
     hipLaunchKernelGGL(mel_table_k, dim3(1024), dim3(256), 0, s, w.table, w.win, d.n_fft, NBIN);

@@ -59,12 +59,19 @@ __global__ void sg_concat_k(float* cat, const float* a, const float* b, int B, i
     cat[i] = c < H ? a[r * H + c] : b[r * H + (c - H)];
   }
 }
+__global__ void sg_copy_cols_k(float* dst, const float* src, long lds, int w, int B) {
+  long n = (long)B * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = src[(i / w) * lds + (i % w)];
+}
 inline dim3 sg1(long n) { long g = (n + 255) / 256; return dim3((unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g))); }
 
 struct SgWs {
   float *wf0, *wf2, *wb2;                       // packed conv weights
   float *xp, *a1p, *c2, *GI, *gh, *Hs, *R, *Z, *N, *NH, *gir, *ghr, *Rr, *Zr, *Nr, *NHr, *hb, *cat;   // saved
   float *dcat, *DI, *DH, *dh, *dhc, *dir, *dhr, *dC, *t0, *t1, *dwf;                                  // backward
+  bool use_fast;      // the forward-direction recurrence runs on the decoder's stage kernels (decoder_fast.hip: sg_fast_*)
+  SgFast fast;
 };
 SgWs carve_sg(const ZeggsStyleGruDims& d, Arena& a) {
   SgWs w;
@@ -79,6 +86,8 @@ SgWs carve_sg(const ZeggsStyleGruDims& d, Arena& a) {
   w.dir = a.f(B * 3 * H); w.dhr = a.f(B * 3 * H); w.dC = a.f(B * L * H);
   w.t0 = a.f(B * LP * H); w.t1 = a.f(B * L * H);
   w.dwf = a.f(3 * (C > H ? C : H) * H);
+  w.use_fast = sg_fast_supported(d.B, d.H) != 0;
+  if (w.use_fast) w.fast = sg_fast_carve(d.B, d.H, d.L, a);
   return w;
 }
 // conv-as-GEMM helpers (same contracts as encoders.hip)
@@ -130,6 +139,8 @@ extern "C" int zeggs_style_encoder_gru_fwd(const ZeggsStyleGruDims* dp, const Ze
     ZTRY(launch_gemm(g, B, s));
   }
   ZTRY(k_fill(w.Hs, sH, 0.f, s));
+  if (w.use_fast) ZTRY(sg_fast_fwd(B, H, L, P->w_hh, P->b_hh, w.GI, w.Hs, w.fast, s));
+  else
   for (int t = 0; t < L; ++t) {
     ZTRY(gemm_nt(w.Hs + t * sH, H, P->w_hh, H, w.gh, 3 * H, P->b_hh, B, 3 * H, H, ACT_NONE, 0.f, s));
     hipLaunchKernelGGL(sg_gate_fwd_k, sg1(sH), dim3(256), 0, s, w.GI + t * s3, w.gh, w.Hs + t * sH, w.Hs + (t + 1) * sH,
@@ -166,6 +177,10 @@ extern "C" int zeggs_style_encoder_gru_bwd(const ZeggsStyleGruDims* dp, const Ze
   ZTRY(k_colsum(G->b_hh_r, w.dhr, B, 3 * H, 3 * H, 0.f, s));
   ZTRY(k_fill(G->w_hh_r, 3L * H * H, 0.f, s));
   // forward direction: BPTT over the L frames
+  if (w.use_fast) {
+    hipLaunchKernelGGL(sg_copy_cols_k, sg1(sH), dim3(256), 0, s, w.dhc, w.dcat, (long)2 * H, H, B);
+    ZTRY(sg_fast_bwd(B, H, L, P->w_hh, w.Hs, w.DI, w.dhc, w.fast, s));
+  } else
   for (int t = L - 1; t >= 0; --t) {
     const float* dh = (t == L - 1) ? w.dcat : w.dh;
     const long lddh = (t == L - 1) ? 2 * H : H;
@@ -177,8 +192,15 @@ extern "C" int zeggs_style_encoder_gru_bwd(const ZeggsStyleGruDims* dp, const Ze
     }
   }
   ZLAUNCH_CHECK("style_gru_bwd");
-  ZTRY(gemm_tn(w.DH, 3 * H, w.Hs, H, G->w_hh, H, (int)((long)L * B), 3 * H, H, 0.f, s));
-  ZTRY(k_colsum(G->b_hh, w.DH, (long)L * B, 3 * H, 3 * H, 0.f, s));
+  if (w.use_fast) {      // compact hidden-side gradients: r, z rows = those of DI, n rows in fast.DHn
+    ZTRY(gemm_tn(w.DI, 3 * H, w.Hs, H, G->w_hh, H, (int)((long)L * B), 2 * H, H, 0.f, s));
+    ZTRY(gemm_tn(w.fast.DHn, H, w.Hs, H, G->w_hh + 2L * H * H, H, (int)((long)L * B), H, H, 0.f, s));
+    ZTRY(k_colsum(G->b_hh, w.DI, (long)L * B, 2 * H, 3 * H, 0.f, s));
+    ZTRY(k_colsum(G->b_hh + 2 * H, w.fast.DHn, (long)L * B, H, H, 0.f, s));
+  } else {
+    ZTRY(gemm_tn(w.DH, 3 * H, w.Hs, H, G->w_hh, H, (int)((long)L * B), 3 * H, H, 0.f, s));
+    ZTRY(k_colsum(G->b_hh, w.DH, (long)L * B, 3 * H, 3 * H, 0.f, s));
+  }
   ZTRY(k_colsum(G->b_ih, w.DI, (long)L * B, 3 * H, 3 * H, 0.f, s));
   {   // dW_ih = sum_b DI_b^T c2_b   (DI time-major, c2 batch-major: batch-reduce over b)
     GemmArgs g = gemm_args(w.DI, w.c2, G->w_ih, 3 * H, H, L);
