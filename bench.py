@@ -432,16 +432,19 @@ def v2_label_b64(ds, dev, steps=10, warmup=3, batch=64, nlabels=9):
             "config": "configs_v2.json shape: label conditioning (9 one-hot labels), no style encoder, batch 64 x 256"}
 
 
-def variants_b32(ds, dev, steps=3, warmup=1):
+def variants_b32(ds, dev, steps=5, warmup=2):
     """The option surface beyond the shipped configs: rnn_cond = "film" (RecurrentDecoderFiLM, ZEGGS/modules.py:188-227) and
-    style_encoder.type = "gru" (StyleEncoderGRU, :307-343) at the headline shape.  Both run the GENERIC path (per-step GEMM
-    launches, no fragment-packed / persistent kernels): correct and reference-pinned (tests/golden/variants.npz), not tuned."""
+    style_encoder.type = "gru" (StyleEncoderGRU, :307-343) at the headline shape.  Since round 4 both run on the fragment-packed
+    stage kernels: the FiLM step is 4 launches per direction (its two modulated ELU layers add a dependent stage to the normal
+    decoder's 3), the style recurrence one launch per exemplar frame and direction, replayed as a hipGraph.  Reference-pinned
+    (tests/golden/variants.npz); the persistent H = 1024 sweeps decline rnn_cond = "film"."""
     torch.manual_seed(1234)
     se = modules.SpeechEncoder(synth.N_AUDIO, 64, SP).to(dev).train()
     de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, SP, ST, H, 2, rnn_cond="film").to(dev).train()
     st = modules.StyleEncoder(synth.POSE_IN, 512, ST, type="gru", use_vae=True).to(dev).train()
     eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT)
     perm = np.random.default_rng(42).permutation(len(ds))
+    ops.set_option("timing", 1)
     for it in range(warmup):
         eng.step(engine.shard_indices(perm, it, BATCH, 1, 0), EXAMPLE_LEN)
     torch.cuda.synchronize()
@@ -450,9 +453,26 @@ def variants_b32(ds, dev, steps=3, warmup=1):
         loss = eng.step(engine.shard_indices(perm, it, BATCH, 1, 0), EXAMPLE_LEN)
     torch.cuda.synchronize()
     dt_ = (time.perf_counter() - t0) / steps
-    return {"value": round(BATCH * WINDOW / dt_, 1), "unit": "frames/s", "ms_per_step": round(dt_ * 1e3, 2), "steps": steps,
-            "finite": bool(torch.isfinite(loss)),
-            "config": "FiLM decoder + GRU style encoder (VAE), batch 32 x 256, example 384: generic per-step GEMM path"}
+    ms = ctypes.c_float(0.0)
+    fwd_us = bwd_us = None
+    if ops.lib().zeggs_timing_ms(0, ctypes.byref(ms)) == 0:
+        fwd_us = ms.value * 1e3 / (WINDOW - 1)
+    if ops.lib().zeggs_timing_ms(1, ctypes.byref(ms)) == 0:
+        bwd_us = ms.value * 1e3 / (WINDOW - 1)
+    ops.set_option("timing", 0)
+    xd = synth.POSE_IN + SP       # film: the style is not a step input, it modulates (gamma / beta [B, 2H] per step)
+    wbytes = 4 * (H * xd + 3 * H * (H + xd) + 3 * 3 * H * H + H * H + synth.POSE_OUT * H + 2 * H + 12 * H + synth.POSE_OUT)
+    abytes = wbytes + BATCH * 4 * (xd + 2 * 2 * H + 2 * H + synth.POSE_OUT + 2 * H)
+    out = {"value": round(BATCH * WINDOW / dt_, 1), "unit": "frames/s", "ms_per_step": round(dt_ * 1e3, 2), "steps": steps,
+           "finite": bool(torch.isfinite(loss)), "algorithmic_bytes_per_step": abytes,
+           "config": "FiLM decoder + GRU style encoder (VAE), batch 32 x 256, example 384: fragment-packed stage kernels"}
+    if fwd_us:
+        out["roofline"] = {"bound": "hbm", "kernel": "stage_k (4 launches per FiLM decoder step and direction)",
+                           "us_per_step": round(fwd_us, 2), "achieved": round(abytes / fwd_us / 1e3, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(abytes / fwd_us / 1e3 / HBM_PEAK_GBS, 4),
+                           "backward_us_per_step": round(bwd_us, 2) if bwd_us else None,
+                           "backward_frac": round(abytes / bwd_us / 1e3 / HBM_PEAK_GBS, 4) if bwd_us else None, "traffic": None}
+    return out
 
 
 def nhidden_512_b32(ds, dev, steps=5, warmup=2):

@@ -478,6 +478,10 @@ int zeggs_parse_table_text(const char* text, size_t len, double* table /* host *
  * blocks, the caller writes the blocks in order); *written = bytes produced.  cap >= rows * (cols * 24 + 1) suffices. */
 int zeggs_format_table_text(const double* table /* host */, long rows, int cols, char* out, size_t cap, size_t* written);
 
+/* Launch sequences that are replayed as hipGraphs (the frame sweeps of the "gru" style encoder with option "sweep_graphs" = 1; default off):
+ * how many were captured and how many replays hit the cache on this process.  No reference counterpart (diagnostics). */
+int zeggs_sweep_graph_stats(long* captures, long* replays);
+
 #ifdef __cplusplus
 }
 #endif

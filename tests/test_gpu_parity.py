@@ -1082,6 +1082,19 @@ def test_film_decoder_stage_path_batches(golden_dir, B, T):
     for k, p in de_g.named_parameters():
         assert relerr(p.grad, w64[k].grad) < 3e-4, k
     fast_grads = {k: p.grad.clone() for k, p in de_g.named_parameters()}
+    try:       # unfolded stage launches (5 per step and direction instead of 4) on the same inputs
+        ops.set_option("stage_variant", 4096 + 8192)
+        de_g.zero_grad()
+        sp3 = g(speech).requires_grad_(True)
+        unf = de_g(*[g(x) for x in fp], g(gaze), sp3, g(style), None, *stat, synth.DT)
+        sum((o * g(w)).sum() for o, w in zip(unf, wts)).backward()
+    finally:
+        ops.set_option("stage_variant", 0)
+    for n, o, r in zip(NAMES, out, unf):
+        assert float((o.detach() - r.detach()).abs().max()) < 1e-4, n
+    assert relerr(spg.grad, sp3.grad) < 1e-4
+    for k, p in de_g.named_parameters():
+        assert relerr(fast_grads[k], p.grad) < 1e-4, k
     try:       # the generic path on the same inputs
         ops.set_option("decoder_fast", 0)
         de_g.zero_grad()
@@ -1154,6 +1167,20 @@ def test_gru_style_encoder_stage_path_batch(B, L):
     assert float((z - z2).abs().max()) < 2e-5 and float((lv - lv2).abs().max()) < 2e-5
     for k in gr:
         assert relerr(gr[k], gr2[k]) < 1e-4, k
+    # the same two frame sweeps captured into hipGraphs and replayed (option "sweep_graphs"): same launches, same results
+    import ctypes
+    c0, r0, c1, r1 = (ctypes.c_long(0) for _ in range(4))
+    ops.lib().zeggs_sweep_graph_stats(ctypes.byref(c0), ctypes.byref(r0))
+    try:
+        ops.set_option("sweep_graphs", 1)
+        z3, mu3, lv3, gr3 = run()
+    finally:
+        ops.set_option("sweep_graphs", 0)
+    ops.lib().zeggs_sweep_graph_stats(ctypes.byref(c1), ctypes.byref(r1))
+    assert (c1.value + r1.value) - (c0.value + r0.value) == 2
+    assert float((z - z3).abs().max()) < 2e-6 and float((lv - lv3).abs().max()) < 2e-6
+    for k in gr:
+        assert relerr(gr[k], gr3[k]) < 1e-5, k
 
 
 @pytest.mark.parametrize("L", [1, 2, 37])

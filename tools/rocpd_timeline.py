@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Timeline of ONE training iteration from a rocprofv3 kernel trace (rocpd sqlite): every dispatch between the last two
 radam_k launches with start offset, duration and queue, plus how much of the iteration the chip ran nothing / one / several
-kernels at once.  usage: tools/rocpd_timeline.py <results.db> [out.csv]"""
+kernels at once.  usage: tools/rocpd_timeline.py <results.db> [out.csv] [cluster_gap_ms = 2]"""
 import csv
 import sqlite3
 import sys
@@ -13,14 +13,15 @@ name, gx = pick("name", "kernel_name"), pick("grid_x", "grid_size_x", "grid_size
 st, en = pick("start", "start_timestamp"), pick("end", "end_timestamp")
 qid = pick("queue_id", "stream_id", "queue", "stream")
 rows = list(db.execute(f"select {name}, {gx}, {st}, {en}, {qid if qid else 0} from kernels order by {st}"))
+GAP = int(float(sys.argv[3]) * 1e6) if len(sys.argv) > 3 else 2_000_000
 rad = [i for i, r in enumerate(rows) if "radam_k" in r[0]]
 # the optimizer step is applied in pieces (the decoder's slice early, on the weight-gradient stream): an iteration ends with the
 # LAST radam_k of a cluster (no other one starts within the next 2 ms)
-rad = [i for k, i in enumerate(rad) if k + 1 == len(rad) or rows[rad[k + 1]][2] - rows[i][2] > 2_000_000]
+rad = [i for k, i in enumerate(rad) if k + 1 == len(rad) or rows[rad[k + 1]][2] - rows[i][2] > GAP]
 if len(rad) < 2:
     sys.exit("need two radam_k dispatches")
 # the shortest of the last few iterations (the bench's trailing iterations are separated by host-side event reads)
-pairs = list(zip(rad[-6:-1], rad[-5:]))
+pairs = list(zip(rad[:-1], rad[1:]))[-5:]
 lo, hi = min(pairs, key=lambda ab: rows[ab[1]][3] - rows[ab[0]][3])
 it = rows[lo + 1: hi + 1]
 t0 = rows[lo][3]

@@ -30,5 +30,11 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 for it in range(1, 1 + steps):
     eng.step(engine.shard_indices(perm, it, bench.BATCH, 1, 0), bench.EXAMPLE_LEN)
+th = time.perf_counter() - t0
 torch.cuda.synchronize()
-print(f"{cond} + {sty}: {(time.perf_counter() - t0) / steps * 1e3:.2f} ms per iteration")
+print(f"{cond} + {sty}: {(time.perf_counter() - t0) / steps * 1e3:.2f} ms per iteration (host returned after {th / steps * 1e3:.2f} ms)")
+import ctypes  # noqa: E402
+from zeggs import ops  # noqa: E402
+c, r = ctypes.c_long(0), ctypes.c_long(0)
+ops.lib().zeggs_sweep_graph_stats(ctypes.byref(c), ctypes.byref(r))
+print(f"sweep graphs: {c.value} captured, {r.value} replays")

@@ -21,6 +21,8 @@ extern int g_stage_variant;
 extern int g_gemm_wg_target;
 extern int g_timing;
 extern int g_chain;
+extern int g_sweep_graphs;
+extern int g_launch_window;
 extern int g_persistent;
 extern int g_train_persistent;
 extern int g_bwd_persistent;
@@ -39,6 +41,8 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "gemm_wg_target") == 0) { g_gemm_wg_target = value; return 0; }
   if (strcmp(name, "timing") == 0) { g_timing = value; return 0; }
   if (strcmp(name, "chain") == 0) { g_chain = value; return 0; }
+  if (strcmp(name, "sweep_graphs") == 0) { g_sweep_graphs = value != 0; return 0; }
+  if (strcmp(name, "launch_window") == 0) { g_launch_window = value < 0 ? 0 : value; return 0; }
   // (re-)enabling gives a kernel that was disabled after a failed validation another chance
   if (strcmp(name, "train_persistent") == 0) {
     g_train_persistent = value;

@@ -24,9 +24,11 @@
 #include "dec_math.h"
 #include "gemm.h"
 #include "kernels.h"
+#include <mutex>
 
 int g_stage_variant = 0;
 int g_chain = 0;   // zeggs_set_option("chain", 1): chained (run-ahead) stage launches, see struct Chain
+int g_launch_window = 8;   // zeggs_set_option("launch_window", steps): see struct LaunchWindow (measured: 8 -> sweeps 6-9 % faster than unbounded)
 
 // zeggs_set_option("timing", 1): HIP events on the caller's stream around the steady-state stage sweeps (the 3-launch
 // steps only, not the per-call packs), read back by zeggs_timing_ms -- bench.py's roofline figures
@@ -59,7 +61,7 @@ enum { V_NOW = 2, V_NOEPI = 4 };
 
 // (forward epilogues first: launch_stage tells the two kernel families apart by `epi >= EPI_GRU_BWD`)
 enum { EPI_ELU_HID = 0, EPI_GRU_FWD, EPI_OUT_FWD, EPI_HID_MERGED, EPI_ELU_FILM, EPI_GRU_BWD, EPI_ADD, EPI_DGIN, EPI_DX,
-       EPI_GRU_BWD_M, EPI_FILM_BWD };
+       EPI_GRU_BWD_M, EPI_FILM_BWD, EPI_FILM_BWD_M };
 
 struct Seg {
   const float* w;   // packed weights  [tile][kb][64][4]
@@ -381,6 +383,7 @@ __global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageA
       if (eact) {
         const float* wgz = G.p1 + (long)col * a.XD + PO;     // gaze columns of layer0
         pre[0] = G.p0[col]; pre[1] = wgz[0]; pre[2] = wgz[1]; pre[3] = wgz[2];
+        if (G.p3) { pre[4] = G.p3[(long)eb * 2 * H + col]; pre[5] = G.p4[(long)eb * 2 * H + col]; }   // film: gamma / beta of step t+1
       }
       if (tid < BP && eb < B) {
         const float* rq = a.rrot + ((long)eb * d.T + t - 1) * 4;
@@ -427,6 +430,15 @@ __global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageA
       const int U = tile * 16 + ev;
       eact = tid < 16 * BP && eb < B && U < H;
       if (eact) { pre[0] = G.p0[(long)eb * H + U]; pre[1] = G.p1[(long)eb * 2 * H + U]; }
+    } break;
+    case EPI_FILM_BWD_M: if constexpr (FAM == 1) {
+      const int U = tile * 16 + ev;
+      eact = tid < 16 * BP && eb < B && U < H;
+      if (eact) {
+        pre[0] = G.p0[(long)eb * H + U]; pre[1] = G.p1[(long)eb * 2 * H + U];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) rt[c] = a.aux1[(long)c * H + U];     // layer3 rows of the 6 root columns
+      }
     } break;
     case EPI_DX: if constexpr (FAM == 1) {
       const int q = tile * 16 + ev;
@@ -721,7 +733,11 @@ __global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageA
       if (eact) {
         const int col = tile * 16 + ev;
         const float pa = FV(0, ev, eb) + pre[0] + pre[1] * gsh[ebl * 3] + pre[2] * gsh[ebl * 3 + 1] + pre[3] * gsh[ebl * 3 + 2];
-        const float val = d_elu(pa);
+        float val = d_elu(pa);
+        if (G.p3) {     // film: the modulation of layer0's output (and its pre-modulation value for the backward pass)
+          if (G.o2) G.o2[(long)eb * H + col] = val;
+          val = val * (1.f + pre[4]) + pre[5];
+        }
         st_out<CH>(&G.o0[(long)eb * a.GL + col], val);
         if (G.o1) st_out<CH>(&G.o1[xf_index(eb, col, LNB)], val);
       }
@@ -807,6 +823,32 @@ __global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageA
       if (eact) {
         const int b = eb, U = tile * 16 + ev;
         const float g = FV(0, ev, b);
+        const float d2 = g * (1.f + pre[1]) * d_elu_grad_from_out(pre[0]);
+        G.o0[(long)b * H + U] = d2;
+        G.o1[xf_index(b, U, LNB)] = d2;
+        G.o2[(long)b * 2 * H + U] = g * pre[0];
+        G.o3[(long)b * 2 * H + U] = g;
+      }
+    } break;
+    case EPI_FILM_BWD_M: if constexpr (FAM == 1) {   // film twin of EPI_GRU_BWD_M: dF2_{t-1} in the launch that produces dy_{t-1}:
+      // dF2 = M'^T D0 + W3^T r (acc 0) + W3[0:6]^T dy6, dy6 from the root-integration backward of the root columns of W0^T D0
+      // (acc 1); then the modulation / ELU backward of layer2 (EPI_FILM_BWD).  The DX group of this launch owns the carry update.
+      float* dsh = (float*)red;                      // [BP][6]
+      if (tid < BP && eb < B) {
+        const int b = eb;
+        float g6[6], dgd[3];
+        for (int c = 0; c < 6; ++c)
+          g6[c] = a.dpose[((long)b * d.T + t - 1) * PO + c] + (FV(1, c, b) + a.aux0[(long)b * a.XD + c]) / a.st.in_std[c];
+        for (int k = 0; k < 3; ++k) dgd[k] = FV(1, 6 + k, b) + a.aux0[(long)b * a.XD + PO + k];
+        root_bwd(d, a.st, b, t - 1, true, dgd, a.gaze, a.cpose, a.crpos, a.crrot, a.drpos, a.drrot, a.carry, nullptr, g6);
+        for (int c = 0; c < 6; ++c) dsh[ebl * 6 + c] = g6[c] * a.st.out_std[c];
+      }
+      __syncthreads();
+      if (eact) {
+        const int b = eb, U = tile * 16 + ev;
+        float g = FV(0, ev, b);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) g = fmaf(rt[c], dsh[ebl * 6 + c], g);
         const float d2 = g * (1.f + pre[1]) * d_elu_grad_from_out(pre[0]);
         G.o0[(long)b * H + U] = d2;
         G.o1[xf_index(b, U, LNB)] = d2;
@@ -1060,6 +1102,37 @@ struct Chain {
   }
 };
 
+// ---- bound on how far the host runs ahead of the device inside a sweep (option "launch_window" = steps between two marks, 0 = off):
+// every `g_launch_window` steps an event is recorded, and the host waits for the mark before the previous one -- at most about
+// 2 x window x (launches per step) launches are outstanding.  The host enqueues a stage launch in ~3.4 us (tools/launch_cost.hip),
+// the device takes 6-15 us for one, so an unbounded loop fills the hardware queue within a sweep; with a full queue the same
+// launches run slower (H = 512, B = 32: forward / BPTT step 26.2 / 33.1 us unbounded, 24.8 / 29.8 us with a window of 8 steps;
+// FiLM: 45.6 / 54.4 -> 44.5 / 49.2 us) and, on some boxes of the pool, a sweep that follows another engine's in the same process
+// dropped to a third of its speed (bench extras: 19.5 -> 45 ms per iteration).
+struct LaunchWindow {
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  int n = 0, steps = 0;
+  bool on = false;
+  int begin(hipStream_t s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
+    on = g_launch_window > 0 && cap == hipStreamCaptureStatusNone;
+    n = steps = 0;
+    if (on && !ev[0])
+      for (hipEvent_t& e : ev) ZCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "event creation failed");
+    return 0;
+  }
+  int tick(hipStream_t s, int mult = 1) {     // mult: launches per step relative to a decoder step's three or four
+    if (!on || ++steps < g_launch_window * mult) return 0;
+    steps = 0;
+    ZCHECK(hipEventRecord(ev[n % 3], s) == hipSuccess, "hipEventRecord failed");
+    if (n >= 2) ZCHECK(hipEventSynchronize(ev[(n - 2) % 3]) == hipSuccess, "hipEventSynchronize failed");
+    ++n;
+    return 0;
+  }
+};
+thread_local LaunchWindow t_window;
+
 StageArgs base_args(const ZeggsDecDims& d, const ZeggsDecStats* st, const DecWs& w) {
   StageArgs a;
   memset(&a, 0, sizeof(a));
@@ -1069,8 +1142,12 @@ StageArgs base_args(const ZeggsDecDims& d, const ZeggsDecStats* st, const DecWs&
 
 }  // namespace
 
-// rnn_cond "film" (RecurrentDecoderFiLM, ZEGGS/modules.py:188-227) runs the same stage kernels, five launches per step and
-// direction (the two modulated ELU layers cannot be folded into their neighbours); the persistent kernels decline it
+// rnn_cond "film" (RecurrentDecoderFiLM, ZEGGS/modules.py:188-227) runs the same stage kernels, four launches per step and
+// direction: S1* layer0 + modulation (folded into the previous step's output launch: M = W0[:, :PO] D W3), S2 / S3 the GRU
+// layers, S4a F2 = FiLM(ELU(layer2)), S4b layer3 + root integration; backward B1 (W2^T D2), B2, B3 (+ layer0's modulation
+// backward), B4 dx + dF2 of the previous step through the same fold.  The modulation sits between two matrix products as an
+// elementwise factor that depends on (batch row, frame), so each modulated layer stays a dependent stage; the persistent
+// H = 1024 kernels decline it.
 int dec_fast_supported(const ZeggsDecDims& d) { return d.H % 16 == 0 && d.B <= 64 && d.PI == d.PO + 3 && d.PO >= 16; }
 
 int dec_fast_pack_fwd(const ZeggsDecDims& d, const ZeggsDecParams* P, DecWs& w, hipStream_t s) {
@@ -1101,10 +1178,11 @@ void dec_timing_mark(int i, hipStream_t s) { timing_mark(i, s); }
 int dec_fast_merge_prep(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, hipStream_t s) {
   const int H = d.H, XD = w.XD;
   const long n = (long)H * w.POL;
+  const float *ow = d.film ? P->l3_w : P->l2_w, *ob = d.film ? P->l3_b : P->l2_b;     // the output layer [PO,H]
   hipLaunchKernelGGL(merge_prep_k, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, w.W0s,
-                     w.vvec, P->l0_w, P->l2_b, *st, H, d.PO, w.POL, XD, 0);
+                     w.vvec, P->l0_w, ob, *st, H, d.PO, w.POL, XD, 0);
   ZLAUNCH_CHECK("merge_prep");
-  ZTRY(gemm_nn(w.W0s, w.POL, P->l2_w, H, w.Mc, H, H, d.PO, H, 0.f, s));
+  ZTRY(gemm_nn(w.W0s, w.POL, ow, H, w.Mc, H, H, d.PO, H, 0.f, s));
   ZTRY(gemm_nt(w.vvec, w.POL, P->l0_w, XD, w.cvec, H, P->l0_b, 1, H, d.PO, ACT_NONE, 0.f, s));
   return 0;
 }
@@ -1113,8 +1191,8 @@ int dec_fast_pack_merged(const ZeggsDecDims& d, const ZeggsDecParams* P, const Z
   const int H = d.H, XD = w.XD;
   ZTRY(dec_fast_merge_prep(d, P, st, w, s));
   ZTRY(pack(w.pw_m, w.Mc, w.nTH, w.KBH, 0, H, H, H, d.PO, H, 0, s, w.TMC));
-  ZTRY(pack(w.pw_c, P->l0_w, w.nTH, w.KBC, 0, d.SP + d.ST, H, H, d.PO, XD, d.PI, s, w.TMC));
-  ZTRY(pack(w.pw_l2c, P->l2_w, w.nTH, w.KBH, 4, H, 16, H, d.PO, H, 0, s, w.TMC));   // layer2's root tile, per tile
+  ZTRY(pack(w.pw_c, P->l0_w, w.nTH, w.KBC, 0, d.SP + (d.film ? 0 : d.ST), H, H, d.PO, XD, d.PI, s, w.TMC));
+  ZTRY(pack(w.pw_l2c, d.film ? P->l3_w : P->l2_w, w.nTH, w.KBH, 4, H, 16, H, d.PO, H, 0, s, w.TMC));   // the output layer's root tile, per tile
   return 0;
 }
 
@@ -1123,7 +1201,7 @@ int dec_fast_pack_bwd(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zegg
   if (d.film) {
     ZTRY(pack(w.pb_l3, P->l3_w, w.nTH, w.KBPO, 2, d.PO, H, H, d.PO, H, 0, s));         // V[U][c] = W3[c][U]
     ZTRY(pack(w.pb_l2, P->l2_w, w.nTH, w.KBH, 2, H, H, H, d.PO, H, 0, s));             // V[U][k] = W2[k][U]
-  } else
+  }
   if (!(g_stage_variant & 8192) && d.T > 2) {
     // merged stage (dx of step t + layer-1 gates of step t-1): M' = W0[:, 6:PO] diag(sigma_o/sigma_i) W2[6:PO, :],
     // packed transposed (V[U][k] = M'[k][U]); the six root columns take the non-linear root-integration path.
@@ -1132,7 +1210,7 @@ int dec_fast_pack_bwd(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zegg
     hipLaunchKernelGGL(merge_prep_k, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, s, w.W0s,
                        (float*)nullptr, P->l0_w, P->l2_b, *st, H, d.PO, w.POL, XD, 6);
     ZLAUNCH_CHECK("merge_prep");
-    ZTRY(gemm_nn(w.W0s, w.POL, P->l2_w, H, w.Mc, H, H, d.PO, H, 0.f, s));
+    ZTRY(gemm_nn(w.W0s, w.POL, d.film ? P->l3_w : P->l2_w, H, w.Mc, H, H, d.PO, H, 0.f, s));   // (film: the output layer is layer3)
     ZTRY(pack(w.pb_mt, w.Mc, w.nTH, w.KBH, 2, H, H, H, d.PO, H, 0, s));
   }
   if (!d.film) ZTRY(pack(w.pb_l2, P->l2_w, w.nTH, w.KBPO, 2, d.PO, H, H, d.PO, H, 0, s));          // V[U][c] = W2[c][U]
@@ -1170,7 +1248,7 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   // weights and must be finite)
   const bool gemv = !training && B <= 2 && !(g_stage_variant & 1024);
   // 3 launches per step: layer2 of step t and layer0 of step t+1 run in ONE launch (variant 4096: 4 launches)
-  const bool merged = !(g_stage_variant & 4096) && !d.film;
+  const bool merged = !(g_stage_variant & 4096);
   if (merged && T > 2) ZTRY(dec_fast_pack_merged(d, P, st, w, s));
   Chain ch;
   ch.s[0] = ch.s[1] = s;
@@ -1190,7 +1268,9 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     }
   }
   timing_mark(0, s);
+  ZTRY(t_window.begin(s));
   for (int t = 1; t < T; ++t) {
+    ZTRY(t_window.tick(s));
     const int c = t & 1, p = (t - 1) & 1;
     const long o = (long)t * sH;
     const bool next = t + 1 < T;
@@ -1202,13 +1282,17 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     const float *h0p = w.H0 + cs(t - 1) * sH, *h1p = w.H1 + cs(t - 1) * sH;
     float *h0c = w.H0 + cs(t) * sH, *h1c = w.H1 + cs(t) * sH;
     const float *gam = nullptr, *bet = nullptr;
+    const float *gam_n = nullptr, *bet_n = nullptr;   // ... and those of step t + 1 (merged launch: layer0 of the next step)
     if (d.film) {
-      if (!training) {   // ring path: this step's modulation vectors from style[:, t] (training: every step's, decoder.hip)
-        ZTRY(gemm_nt(style + (long)t * d.ST, (long)T * d.ST, P->g_w, d.ST, w.GAM, 2 * H, P->g_b, B, 2 * H, d.ST, ACT_NONE, 0.f, s));
-        ZTRY(gemm_nt(style + (long)t * d.ST, (long)T * d.ST, P->be_w, d.ST, w.BET, 2 * H, P->be_b, B, 2 * H, d.ST, ACT_NONE, 0.f, s));
+      const long sg = (long)B * 2 * H;
+      if (!training) {   // ring path: the modulation vectors of step u from style[:, u] into slot u & 1 (training: every step's, decoder.hip)
+        for (int u = (t == 1 ? 1 : t + 1); u <= t + 1 && u < T; ++u) {
+          ZTRY(gemm_nt(style + (long)u * d.ST, (long)T * d.ST, P->g_w, d.ST, w.GAM + (u & 1) * sg, 2 * H, P->g_b, B, 2 * H, d.ST, ACT_NONE, 0.f, s));
+          ZTRY(gemm_nt(style + (long)u * d.ST, (long)T * d.ST, P->be_w, d.ST, w.BET + (u & 1) * sg, 2 * H, P->be_b, B, 2 * H, d.ST, ACT_NONE, 0.f, s));
+        }
       }
-      gam = w.GAM + (training ? (long)t * B * 2 * H : 0);
-      bet = w.BET + (training ? (long)t * B * 2 * H : 0);
+      gam = w.GAM + cs(t) * sg; bet = w.BET + cs(t) * sg;
+      gam_n = w.GAM + cs(t + 1) * sg; bet_n = w.BET + cs(t + 1) * sg;
     }
     if (t == 1 || !merged) {
       // S1: hid = ELU(W0 x + b0)   [film: modulated]
@@ -1257,11 +1341,20 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
       a.g[0].o0 = f2; a.g[0].o1 = gemv ? nullptr : w.F2xf; a.g[0].o2 = training ? w.A2 + o : nullptr;
       ZTRY(launch_stage(a, s));
       // S4b: y = W3 F2 + b3 -> pose[t], root integration, pose/gaze columns of x_{t+1}
+      //      [merged: + hid_{t+1} = FiLM(ELU(M F2 + Wc speech_{t+1} + W0[:, gaze] g_{t+1} + cvec)), M = W0[:, :PO] D W3]
       a.g[0] = Grp{};
       a.g[0].seg[0] = seg(w.pw_l3, w.F2xf, w.KBH, 0, f2, H); a.g[0].nseg = 1; a.g[0].tiles = w.nTPO;
       a.g[0].epi = EPI_OUT_FWD;
       a.g[0].p0 = P->l3_b; a.g[0].o0 = next ? gin_n : nullptr;
       a.g[0].o1 = gemv ? nullptr : Xxf[(t + 1) & 1];
+      if (merged && next) {
+        a.g[1].seg[0] = seg(w.pw_m, w.F2xf, w.KBH, 0, f2, H, 0, w.TMC);
+        a.g[1].seg[1] = seg(w.pw_c, w.CONDxf, w.KBC, 0, gin_n + H + d.PI, w.GL, 0, w.TMC);
+        a.g[1].seg[2] = seg(w.pw_l3, w.F2xf, w.KBH, 1, f2, H, 1);          // every workgroup: layer3's tile 0 (L2-resident)
+        a.g[1].nseg = 3; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_HID_MERGED;
+        a.g[1].p0 = w.cvec; a.g[1].p1 = P->l0_w; a.g[1].p2 = P->l3_b; a.g[1].p3 = gam_n; a.g[1].p4 = bet_n;
+        a.g[1].o0 = gin_n; a.g[1].o1 = gemv ? nullptr : w.HIDxf; a.g[1].o2 = training ? w.A0 + o + sH : nullptr;
+      }
       ZTRY(launch_stage(a, s));
       continue;
     }
@@ -1300,7 +1393,7 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   if (T < 2) return 0;
   if (t_hi == T - 1) {   // first chunk of the sweep
     ZTRY(k_fill(w.xf_base_bwd, (long)(w.xf_bytes_bwd / 4), 0.f, s));
-    const bool merged0 = !(g_stage_variant & 8192) && T > 2 && !d.film;   // carry slot read by the first dx stage (see below)
+    const bool merged0 = !(g_stage_variant & 8192) && T > 2;   // carry slot read by the first dx stage (see below)
     hipLaunchKernelGGL(dy_last_k, dim3(B), dim3(256), 0, s, d, *st, dpose, drpos, drrot, gaze, pose, rpos, rrot,
                        w.carry + (merged0 ? (long)((T - 1) & 1) * B * 8 : 0), w.DY + (long)(T - 1) * B * w.POL, w.POL,
                        w.DYxf, NB);
@@ -1308,9 +1401,11 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
   }
   // 3 launches per step: the dx stage of step t also evaluates the layer-1 gate gradients of step t-1 (variant 8192:
   // separate launches).  The root-state carry is double-buffered: slot (t & 1) is read, slot ((t - 1) & 1) written.
-  const bool merged = !(g_stage_variant & 8192) && T > 2 && !d.film;
+  const bool merged = !(g_stage_variant & 8192) && T > 2;
   if (t_hi == T - 1) timing_mark(2, s);
+  ZTRY(t_window.begin(s));
   for (int t = t_hi; t >= t_lo; --t) {
+    ZTRY(t_window.tick(s));
     const long o = (long)t * sH;
     StageArgs a = base_args(d, st, w);
     a.t = t; a.gaze = gaze; a.cpose = pose; a.crpos = rpos; a.crrot = rrot; a.dpose = dpose; a.drpos = drpos;
@@ -1318,7 +1413,7 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     float* c_in = w.carry + (merged ? (long)(t & 1) * B * 8 : 0);
     float* c_out = w.carry + (merged ? (long)((t - 1) & 1) * B * 8 : 0);
     a.carry = c_in; a.carry_out = c_out;
-    if (d.film) {
+    if (d.film && (t == T - 1 || !merged)) {
       // B0: dF2 = W3^T dy -> D2 (through the modulation and layer2's ELU), dgamma / dbeta of layer2's half
       const long og = (long)t * B * 2 * H;
       a.g[0] = Grp{}; a.g[1] = Grp{};
@@ -1327,8 +1422,8 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
       a.g[0].o0 = w.D2 + o; a.g[0].o1 = w.D2xf; a.g[0].o2 = w.DGAM + og + H; a.g[0].o3 = w.DBET + og + H;
       ZTRY(launch_stage(a, s));
     }
-    if (t == T - 1 || !merged) {
-      // B1: dH1 = W2^T dy + carry -> layer-1 gate gradients   [film: W2^T D2]
+    if (t == T - 1 || !merged || d.film) {
+      // B1: dH1 = W2^T dy + carry -> layer-1 gate gradients   [film: W2^T D2, D2 from B0 or from the merged launch of step t+1]
       a.g[0] = Grp{}; a.g[1] = Grp{};
       a.g[0].seg[0] = d.film ? seg(w.pb_l2, w.D2xf, w.KBH, 0) : seg(w.pb_l2, w.DYxf, w.KBPO, 0);
       a.g[0].nseg = 1; a.g[0].tiles = w.nTH; a.g[0].epi = EPI_GRU_BWD;
@@ -1368,6 +1463,16 @@ int dec_fast_bwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     a.g[0].seg[0] = seg(w.pb_l0, w.D0xf, w.KBH, 0); a.g[0].nseg = 1; a.g[0].tiles = w.nTX; a.g[0].epi = EPI_DX;
     a.g[0].p0 = w.dXa; a.g[0].o0 = w.DX + (long)t * B * w.XD;
     a.g[0].o1 = t > 1 ? w.DY + (long)(t - 1) * B * w.POL : nullptr; a.g[0].o2 = w.DYxf;
+    if (merged && t > 1 && d.film) {   // + dF2 of step t-1 and layer2's modulation / ELU backward (EPI_FILM_BWD_M)
+      const long o1 = o - sH, og1 = (long)(t - 1) * B * 2 * H;
+      a.g[1].seg[0] = seg(w.pb_mt, w.D0xf, w.KBH, 0);
+      a.g[1].seg[1] = seg(w.pb_l3, w.Rxf, w.KBPO, 0);
+      a.g[1].seg[2] = seg(w.pb_l0, w.D0xf, w.KBH, 1, nullptr, 0, 1);
+      a.g[1].nseg = 3; a.g[1].tiles = w.nTH; a.g[1].epi = EPI_FILM_BWD_M;
+      a.g[1].p0 = w.A2 + o1; a.g[1].p1 = w.GAM + og1 + H;
+      a.g[1].o0 = w.D2 + o1; a.g[1].o1 = w.D2xf; a.g[1].o2 = w.DGAM + og1 + H; a.g[1].o3 = w.DBET + og1 + H;
+      a.aux0 = w.dXa; a.aux1 = P->l3_w;
+    } else
     if (merged && t > 1) {
       const long o1 = o - sH;
       a.g[1].seg[0] = seg(w.pb_mt, w.D0xf, w.KBH, 0);
@@ -1407,6 +1512,68 @@ SgFast sg_fast_carve(int B, int H, int L, Arena& a) {
   f.DHn = a.f((long)L * B * H);
   return f;
 }
+// ---- replayed launch sequences (option "sweep_graphs" = 1; default off).  The frame sweeps of the style recurrence are static for
+// given buffers, so they can be captured once into a hipGraph and replayed (key = every pointer / size the launches depend on; the
+// workspace comes from a caching allocator, so the key repeats from iteration to iteration).  Measured (tools/launch_cost.hip,
+// tools/order_probe.py): a replay costs the host nothing and 1.7 us per trivial node against 3.4 us per stream launch, but the
+// nodes of OUR sweep take 5.5 us each either way (the dependent-dispatch latency is the device's), and the windowed stream
+// launches (LaunchWindow below) finish the FiLM + GRU iteration 0.6-0.9 ms sooner than the replay (36.2 vs 36.9 ms): a replay
+// puts all 384 nodes into the queue at once.  Kept for hosts that cannot issue a launch every ~5 us.
+int g_sweep_graphs = 0;
+namespace {
+struct SweepGraph { uint64_t key[16]; hipGraphExec_t exec; unsigned long long used; };
+std::mutex g_sweep_mu;
+SweepGraph g_sweeps[8];
+unsigned long long g_sweep_clock = 0;
+long g_sweep_captures = 0, g_sweep_replays = 0;
+template <class F>
+int run_graphed(const uint64_t (&key)[16], hipStream_t s, F&& enqueue) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
+  if (!g_sweep_graphs || cap != hipStreamCaptureStatusNone) return enqueue(s);
+  std::lock_guard<std::mutex> lk(g_sweep_mu);
+  SweepGraph* slot = &g_sweeps[0];
+  for (SweepGraph& e : g_sweeps) {
+    if (e.exec && memcmp(e.key, key, sizeof(key)) == 0) {
+      e.used = ++g_sweep_clock;
+      ++g_sweep_replays;
+      ZCHECK(hipGraphLaunch(e.exec, s) == hipSuccess, "sweep graph: launch failed");
+      return 0;
+    }
+    if (e.used < slot->used) slot = &e;      // least recently used (empty slots have used == 0)
+  }
+  // captured on a library-owned stream (the caller's may be the legacy default stream, which cannot capture), replayed on `s`
+  static hipStream_t cs[16] = {};
+  int dev = 0;
+  ZCHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "sweep graph: unsupported device index");
+  if (!cs[dev]) ZCHECK(hipStreamCreateWithFlags(&cs[dev], hipStreamNonBlocking) == hipSuccess, "sweep graph: stream creation failed");
+  ZCHECK(hipStreamBeginCapture(cs[dev], hipStreamCaptureModeThreadLocal) == hipSuccess, "sweep graph: begin capture failed");
+  const int r = enqueue(cs[dev]);
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(cs[dev], &graph);      // always: the stream must leave capture mode
+  if (r != 0) { if (graph) (void)hipGraphDestroy(graph); return r; }
+  ZCHECK(e == hipSuccess && graph, "sweep graph: capture failed");
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  ZCHECK(ei == hipSuccess && exec, "sweep graph: instantiate failed");
+  if (slot->exec) (void)hipGraphExecDestroy(slot->exec);
+  memcpy(slot->key, key, sizeof(key));
+  slot->exec = exec;
+  slot->used = ++g_sweep_clock;
+  ++g_sweep_captures;
+  ZCHECK(hipGraphLaunch(exec, s) == hipSuccess, "sweep graph: launch failed");
+  return 0;
+}
+}  // namespace
+// how often a launch sequence was captured / replayed from the cache on this process (a capture per iteration would mean the
+// buffers move between iterations and the cache never hits)
+extern "C" int zeggs_sweep_graph_stats(long* captures, long* replays) {
+  std::lock_guard<std::mutex> lk(g_sweep_mu);
+  *captures = g_sweep_captures; *replays = g_sweep_replays;
+  return 0;
+}
+
 static StageArgs sg_args(int B, int H, const SgFast& f) {
   StageArgs a;
   memset(&a, 0, sizeof(a));
@@ -1415,11 +1582,16 @@ static StageArgs sg_args(int B, int H, const SgFast& f) {
 }
 // Hs [(L+1)][B][H] with slot 0 = the initial state (zero), GI [L][B][3H] incl. b_ih
 int sg_fast_fwd(int B, int H, int L, const float* w_hh, const float* b_hh, const float* GI, float* Hs, const SgFast& f,
-                hipStream_t s) {
+                hipStream_t s_) {
   const long sH = (long)B * H, XB = 256L * f.NB;
+  const uint64_t key[16] = {1, (uint64_t)B, (uint64_t)H, (uint64_t)L, (uint64_t)w_hh, (uint64_t)b_hh, (uint64_t)GI, (uint64_t)Hs,
+                            (uint64_t)f.pw, (uint64_t)f.xf, (uint64_t)f.GT, 0, 0, 0, 0, 0};
+  return run_graphed(key, s_, [&](hipStream_t s) -> int {
   ZTRY(pack(f.pw, w_hh, f.nT5, f.KBH, 1, H, 3 * H, H, 0, H, 0, s));
   ZTRY(k_fill(f.xf, f.xf_floats, 0.f, s));
+  ZTRY(t_window.begin(s));
   for (int t = 0; t < L; ++t) {
+    ZTRY(t_window.tick(s, 3));
     StageArgs a = sg_args(B, H, f);
     float *hx_in = f.Hxf + (long)(t & 1) * f.KBH * XB, *hx_out = f.Hxf + (long)((t + 1) & 1) * f.KBH * XB;
     a.g[0].seg[0] = seg(f.pw, hx_in, f.KBH, 1, Hs + t * sH, H); a.g[0].nseg = 1; a.g[0].tiles = f.nT5;
@@ -1429,14 +1601,20 @@ int sg_fast_fwd(int B, int H, int L, const float* w_hh, const float* b_hh, const
     ZTRY(launch_stage(a, s));
   }
   return 0;
+  });
 }
 // dhc [B][H]: in = gradient wrt h_L (the last state), out = gradient wrt h_0; DI [L][B][3H] (grad wrt the input-side
 // pre-activations) and f.DHn [L][B][H] (n rows of the hidden side) are left for the weight-gradient GEMMs
-int sg_fast_bwd(int B, int H, int L, const float* w_hh, const float* Hs, float* DI, float* dhc, const SgFast& f, hipStream_t s) {
+int sg_fast_bwd(int B, int H, int L, const float* w_hh, const float* Hs, float* DI, float* dhc, const SgFast& f, hipStream_t s_) {
   const long sH = (long)B * H, XB = 256L * f.NB;
+  const uint64_t key[16] = {2, (uint64_t)B, (uint64_t)H, (uint64_t)L, (uint64_t)w_hh, (uint64_t)Hs, (uint64_t)DI, (uint64_t)dhc,
+                            (uint64_t)f.pb, (uint64_t)f.xf, (uint64_t)f.GT, (uint64_t)f.DHn, 0, 0, 0, 0};
+  return run_graphed(key, s_, [&](hipStream_t s) -> int {
   ZTRY(pack(f.pb, w_hh, f.nTH, f.KB3H, 2, 3 * H, H, H, 0, H, 0, s));      // V[U][k] = W_hh[k][U]
   ZTRY(k_fill(f.DIxf, 2 * f.KB3H * XB + 2 * f.KBH * XB, 0.f, s));
+  ZTRY(t_window.begin(s));
   for (int t = L - 1; t >= 0; --t) {
+    ZTRY(t_window.tick(s, 3));
     StageArgs a = sg_args(B, H, f);
     float *di_in = f.DIxf + (long)((t + 1) & 1) * f.KB3H * XB, *di_out = f.DIxf + (long)(t & 1) * f.KB3H * XB;
     float *dh_in = f.DHxf + (long)((t + 1) & 1) * f.KBH * XB, *dh_out = f.DHxf + (long)(t & 1) * f.KBH * XB;
@@ -1451,4 +1629,5 @@ int sg_fast_bwd(int B, int H, int L, const float* w_hh, const float* Hs, float* 
     ZTRY(launch_stage(a, s));
   }
   return 0;
+  });
 }

@@ -93,7 +93,7 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
   w.nTGI = w.nTH + w.nTX;
   w.KBH = d.H / 16; w.KBX = w.nTX; w.KBPO = w.nTPO; w.KB3H = 3 * d.H / 16;
   const long BLK = 256;   // floats per (tile, k-block) weight fragment = 64 lanes x 4
-  w.KBC = (d.SP + d.ST + 15) / 16;
+  w.KBC = (d.SP + (d.film ? 0 : d.ST) + 15) / 16;   // conditioning columns of x (film: speech only)
   w.TG0 = w.KBH + w.KBX + w.KBH; w.TG1 = 2 * w.KBH; w.TMC = w.KBH + w.KBC + w.KBH;
   w.pw_l0 = a.f((long)w.nTH * w.KBX * BLK);
   w.pw_g0 = a.f((long)w.nT5 * w.TG0 * BLK);

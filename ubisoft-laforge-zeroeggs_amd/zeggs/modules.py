@@ -191,7 +191,7 @@ class Decoder(nn.Module):
             raise NotImplementedError("the reference hard-codes 2 GRU layers (train.py:130)")
         if rnn_cond == "normal":
             cls = _RecurrentDecoderNormal
-        elif rnn_cond == "film":          # generic per-step GEMM path (the fragment-packed fast path is "normal" only)
+        elif rnn_cond == "film":          # fragment-packed stage kernels, 4 launches per step (the persistent sweeps are "normal" only)
             cls = _RecurrentDecoderFiLM
         else:
             raise ValueError(f"unknown rnn_cond {rnn_cond!r}")
