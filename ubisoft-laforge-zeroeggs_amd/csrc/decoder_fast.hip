@@ -1111,15 +1111,23 @@ struct Chain {
 // dropped to a third of its speed (bench extras: 19.5 -> 45 ms per iteration).
 struct LaunchWindow {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  int n = 0, steps = 0;
+  int n = 0, steps = 0, dev = -1;
   bool on = false;
   int begin(hipStream_t s) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
     on = g_launch_window > 0 && cap == hipStreamCaptureStatusNone;
     n = steps = 0;
-    if (on && !ev[0])
+    if (!on) return 0;
+    int cur = 0;
+    ZCHECK(hipGetDevice(&cur) == hipSuccess, "hipGetDevice failed");
+    if (ev[0] && cur != dev) {        // this host thread moved to another device: events belong to the device they were created on
+      for (hipEvent_t& e : ev) { (void)hipEventDestroy(e); e = nullptr; }
+    }
+    if (!ev[0]) {
       for (hipEvent_t& e : ev) ZCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "event creation failed");
+      dev = cur;
+    }
     return 0;
   }
   int tick(hipStream_t s, int mult = 1) {     // mult: launches per step relative to a decoder step's three or four
