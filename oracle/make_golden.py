@@ -500,6 +500,67 @@ def gold_train_iter_fp64(ref):
     np.savez_compressed(GOLD / "train_iter_fp64.npz", **out)
 
 
+def gold_variants_batch(ref):
+    """The same two nets (seed 4321) at a batch the stage kernels split into two 16-row blocks, with a style that changes every
+    frame: reference forward outputs AND the reference's own autograd gradients (fp32, as the reference trains) of a seeded
+    weighted sum -- input gradients in full, every parameter gradient as 512 evenly spaced samples + its max |g|.
+    Pins the round-4 stage-kernel path of rnn_cond="film" / type="gru" to the reference beyond the tiny variants.npz case."""
+    torch.manual_seed(4321)
+    de = ref.modules.Decoder(pose_input_size=synth.POSE_IN, pose_output_size=synth.POSE_OUT, speech_encoding_size=64,
+                             style_encoding_size=64, hidden_size=1024, num_rnn_layers=2, rnn_cond="film")
+    st = ref.modules.StyleEncoder(synth.POSE_IN, 512, 64, type="gru", use_vae=True)
+    de.train(), st.train()          # (neither net has dropout: train() only matters for autograd bookkeeping)
+    stats = synth.make_stats()
+    B, T, L = 19, 12, 33
+    clips = [synth.make_clip(T + L, seed=170 + b, stats=stats) for b in range(B)]
+    W = {k: torch.as_tensor(np.stack([c[k][:T] for c in clips])) for k in clips[0]}
+    in_mean, in_std = torch.as_tensor(stats["anim_input_mean"]), torch.as_tensor(stats["anim_input_std"])
+    out_mean, out_std = torch.as_tensor(stats["anim_output_mean"]), torch.as_tensor(stats["anim_output_std"])
+    ex = []
+    for c in clips:
+        ex.append(np.concatenate([c["Y_root_vel"][T:T + L], c["Y_root_vrt"][T:T + L],
+                                  c["Y_lpos"][T:T + L].reshape(L, -1), c["Y_ltxy"][T:T + L].reshape(L, -1),
+                                  c["Y_lvel"][T:T + L].reshape(L, -1), c["Y_lvrt"][T:T + L].reshape(L, -1),
+                                  np.zeros((L, 3), np.float32)], axis=1))
+    example = torch.as_tensor(np.stack(ex))
+    rng = np.random.default_rng(18)
+    eps = torch.as_tensor(rng.standard_normal((B, 64)).astype(np.float32))
+    speech = torch.as_tensor(rng.standard_normal((B, T, 64)).astype(np.float32) * 0.5).requires_grad_(True)
+    style = torch.as_tensor(rng.standard_normal((B, T, 64)).astype(np.float32) * 0.5).requires_grad_(True)
+    names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
+    orig = torch.randn_like
+    torch.randn_like = lambda x, *a, **k: eps.to(x.dtype)
+    try:
+        z, mu, logvar = st((example - in_mean) / in_std, 1.0)
+    finally:
+        torch.randn_like = orig
+    O = de(W["Y_root_pos"][:, 0], W["Y_root_rot"][:, 0], W["Y_root_vel"][:, 0], W["Y_root_vrt"][:, 0],
+           W["Y_lpos"][:, 0], W["Y_ltxy"][:, 0], W["Y_lvel"][:, 0], W["Y_lvrt"][:, 0], W["Y_gaze_pos"], speech,
+           style, torch.LongTensor(synth.PARENTS), in_mean, in_std, out_mean, out_std, synth.DT)
+    # the weights of the scalar that is differentiated are re-created from this seed by the tests (not stored: 2 MB)
+    gen = torch.Generator().manual_seed(1804)
+    wts = [torch.randn(tuple(o.shape), generator=gen) for o in O]
+    wz, wm, wl = (torch.randn(B, 64, generator=gen) for _ in range(3))
+    (sum((o * w).sum() for o, w in zip(O, wts)) + (z * wz).sum() + (mu * wm).sum() + (logvar * wl).sum()).backward()
+    # (first pose, gaze targets and the exemplar are NOT stored: the tests rebuild them from synth.make_clip(T + L, seed=170 + b),
+    #  the same deterministic NumPy generator; their checksums are)
+    out = {"clip_T_L": np.array([T, L]), "sum_example": fingerprint(example), "sum_gaze": fingerprint(W["Y_gaze_pos"])}
+    out.update(in_eps=eps.numpy(),
+               in_speech=speech.detach().numpy(), in_style=style.detach().numpy(), gru_z=z.detach().numpy(),
+               gru_mu=mu.detach().numpy(), gru_logvar=logvar.detach().numpy(), weight_seed=np.int64(1804),
+               d_speech=speech.grad.numpy(), d_style=style.grad.numpy())
+    out.update({"O_" + n: o.detach().numpy() for n, o in zip(names, O)})
+    for tag, net in (("decoder", de), ("style", st)):
+        for k, p in net.named_parameters():
+            g = p.grad.detach().flatten()
+            idx = np.unique(np.linspace(0, g.numel() - 1, 512).astype(np.int64))
+            out[f"gidx_{tag}.{k}"] = idx
+            out[f"gsamp_{tag}.{k}"] = g[torch.as_tensor(idx)].numpy()
+            out[f"gmax_{tag}.{k}"] = np.float32(g.abs().max())
+    np.savez_compressed(GOLD / "variants_batch.npz", **out)
+    print("variants_batch.npz", out["O_lpos"].shape, (GOLD / "variants_batch.npz").stat().st_size)
+
+
 def main():
     assert ref_shims.available(), "/root/reference is required to (re)generate golden vectors"
     GOLD.mkdir(parents=True, exist_ok=True)
@@ -508,6 +569,8 @@ def main():
     which = sys.argv[1:] or ["nets", "train", "mel", "dataset", "radam", "generate", "variants", "generate_branches"]
     if "variants" in which:
         gold_variants(ref)
+    if "variants" in which or "variants_batch" in which:
+        gold_variants_batch(ref)
     if "nets" in which:
         gold_nets(ref)
     if "mel" in which:

@@ -109,3 +109,40 @@ def exemplar_rows(st, L, seed):
     c = synth.make_clip_stats(L, seed=seed, stats=st)
     return np.concatenate([c["Y_root_vel"], c["Y_root_vrt"], c["Y_lpos"].reshape(L, -1), c["Y_ltxy"].reshape(L, -1),
                            c["Y_lvel"].reshape(L, -1), c["Y_lvrt"].reshape(L, -1), np.zeros((L, 3), np.float32)], axis=1)
+
+
+def variants_batch_inputs(gd):
+    """Inputs of tests/golden/variants_batch.npz that the fixture does not store (oracle/make_golden.py gold_variants_batch):
+    first pose, gaze targets and exemplar rebuilt from the same deterministic synth clips, checked against the stored checksums;
+    the weights of the differentiated scalar from the stored seed."""
+    T, L = (int(v) for v in gd["clip_T_L"])
+    B = gd["in_speech"].shape[0]
+    stats = synth.make_stats()
+    clips = [synth.make_clip(T + L, seed=170 + b, stats=stats) for b in range(B)]
+    W = {k: torch.as_tensor(np.stack([c[k][:T] for c in clips])) for k in clips[0]}
+    ex = []
+    for c in clips:
+        ex.append(np.concatenate([c["Y_root_vel"][T:T + L], c["Y_root_vrt"][T:T + L],
+                                  c["Y_lpos"][T:T + L].reshape(L, -1), c["Y_ltxy"][T:T + L].reshape(L, -1),
+                                  c["Y_lvel"][T:T + L].reshape(L, -1), c["Y_lvrt"][T:T + L].reshape(L, -1),
+                                  np.zeros((L, 3), np.float32)], axis=1))
+    example = torch.as_tensor(np.stack(ex))
+    np.testing.assert_allclose(fingerprint(example), gd["sum_example"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(fingerprint(W["Y_gaze_pos"]), gd["sum_gaze"], rtol=1e-12, atol=0)
+    first = [W[k][:, 0] for k in ("Y_root_pos", "Y_root_rot", "Y_root_vel", "Y_root_vrt", "Y_lpos", "Y_ltxy", "Y_lvel", "Y_lvrt")]
+    names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
+    gen = torch.Generator().manual_seed(int(gd["weight_seed"]))
+    wts = [torch.randn(tuple(gd["O_" + n].shape), generator=gen) for n in names]
+    wz, wm, wl = (torch.randn(B, 64, generator=gen) for _ in range(3))
+    return first, W["Y_gaze_pos"], example, wts, (wz, wm, wl)
+
+
+def assert_grad_samples(gd, tag, named_grads, tol):
+    """parameter gradients against the reference's stored samples: |g - g_ref| <= tol * max |g_ref| at the sampled indices"""
+    for k, gr in named_grads:
+        idx = torch.as_tensor(gd[f"gidx_{tag}.{k}"])
+        ref = torch.as_tensor(gd[f"gsamp_{tag}.{k}"]).double()
+        got = gr.detach().cpu().flatten()[idx].double()
+        scale = max(float(gd[f"gmax_{tag}.{k}"]), 1e-12)
+        err = float((got - ref).abs().max()) / scale
+        assert err < tol, (tag, k, err)

@@ -182,3 +182,33 @@ def test_oracle_variants_vs_reference(golden_dir):
     names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
     for n, o in zip(names, O):
         np.testing.assert_allclose(o.numpy(), g["O_" + n], atol=1e-5, rtol=1e-5, err_msg=n)
+
+
+def test_oracle_variants_batch_vs_reference(golden_dir):
+    """the same two variants at B = 19, T = 12, exemplar 33 with a style that changes every frame: forward AND the autograd
+    gradients of the oracle against the reference's own (variants_batch.npz: outputs in full, input gradients in full, 512
+    samples of every parameter gradient)"""
+    from zeggs import modules
+    g = np.load(golden_dir / "variants_batch.npz")
+    torch.manual_seed(4321)
+    de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, 64, 64, 1024, 2, rnn_cond="film")
+    st = modules.StyleEncoder(synth.POSE_IN, 512, 64, type="gru", use_vae=True)
+    first, gaze, example, wts, (wz, wm, wl) = helpers.variants_batch_inputs(g)
+    s = helpers.stats_tensors()
+    t = lambda k: torch.as_tensor(g[k])  # noqa: E731
+    wd = {k: v.detach().clone().requires_grad_(True) for k, v in helpers.sd(de).items()}
+    ws = {k: v.detach().clone().requires_grad_(True) for k, v in helpers.sd(st).items()}
+    speech, style = t("in_speech").requires_grad_(True), t("in_style").requires_grad_(True)
+    z, mu, logvar = onets.style_encoder(ws, (example - s["in_mean"]) / s["in_std"], t("in_eps"), 1.0)
+    for a, k in ((z, "gru_z"), (mu, "gru_mu"), (logvar, "gru_logvar")):
+        np.testing.assert_allclose(a.detach().numpy(), g[k], atol=1e-5, err_msg=k)
+    O = onets.decoder_rollout(wd, *first, gaze, speech, style, s["in_mean"], s["in_std"], s["out_mean"], s["out_std"], synth.DT)
+    names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
+    for n, o in zip(names, O):
+        np.testing.assert_allclose(o.detach().numpy(), g["O_" + n], atol=2e-5, rtol=1e-5, err_msg=n)
+    (sum((o * w).sum() for o, w in zip(O, wts)) + (z * wz).sum() + (mu * wm).sum() + (logvar * wl).sum()).backward()
+    for got, k in ((speech.grad, "d_speech"), (style.grad, "d_style")):
+        ref = torch.as_tensor(g[k])
+        assert float((got - ref).abs().max()) < 1e-4 * float(ref.abs().max()), k
+    helpers.assert_grad_samples(g, "decoder", [(k, v.grad) for k, v in wd.items() if v.grad is not None], 1e-4)
+    helpers.assert_grad_samples(g, "style", [(k, v.grad) for k, v in ws.items() if v.grad is not None], 1e-4)
