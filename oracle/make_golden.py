@@ -561,6 +561,46 @@ def gold_variants_batch(ref):
     print("variants_batch.npz", out["O_lpos"].shape, (GOLD / "variants_batch.npz").stat().st_size)
 
 
+def gold_width512(ref):
+    """decoder.nhidden = 512 (ZEGGS/train.py:129 honours the option; the shipped configs use 1024): the reference's
+    RecurrentDecoderNormal at the other width, B = 18, T = 8 -- outputs in full, input gradients in full, 512 samples of every
+    parameter gradient of the reference's autograd (weights of the scalar from the stored seed).  Seed 5512."""
+    torch.manual_seed(5512)
+    de = ref.modules.Decoder(pose_input_size=synth.POSE_IN, pose_output_size=synth.POSE_OUT, speech_encoding_size=64,
+                             style_encoding_size=64, hidden_size=512, num_rnn_layers=2)
+    de.train()
+    stats = synth.make_stats()
+    B, T = 18, 8
+    clips = [synth.make_clip(T, seed=270 + b, stats=stats) for b in range(B)]
+    W = {k: torch.as_tensor(np.stack([c[k][:T] for c in clips])) for k in clips[0]}
+    in_mean, in_std = torch.as_tensor(stats["anim_input_mean"]), torch.as_tensor(stats["anim_input_std"])
+    out_mean, out_std = torch.as_tensor(stats["anim_output_mean"]), torch.as_tensor(stats["anim_output_std"])
+    rng = np.random.default_rng(28)
+    speech = torch.as_tensor(rng.standard_normal((B, T, 64)).astype(np.float32) * 0.5).requires_grad_(True)
+    style = torch.as_tensor(rng.standard_normal((B, T, 64)).astype(np.float32) * 0.5).requires_grad_(True)
+    names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
+    O = de(W["Y_root_pos"][:, 0], W["Y_root_rot"][:, 0], W["Y_root_vel"][:, 0], W["Y_root_vrt"][:, 0],
+           W["Y_lpos"][:, 0], W["Y_ltxy"][:, 0], W["Y_lvel"][:, 0], W["Y_lvrt"][:, 0], W["Y_gaze_pos"], speech,
+           style, torch.LongTensor(synth.PARENTS), in_mean, in_std, out_mean, out_std, synth.DT)
+    gen = torch.Generator().manual_seed(1805)
+    wts = [torch.randn(tuple(o.shape), generator=gen) for o in O]
+    sum((o * w).sum() for o, w in zip(O, wts)).backward()
+    out = {"clip_T": np.int64(T), "sum_gaze": fingerprint(W["Y_gaze_pos"]), "weight_seed": np.int64(1805),
+           "in_speech": speech.detach().numpy(), "in_style": style.detach().numpy(),
+           "d_speech": speech.grad.numpy(), "d_style": style.grad.numpy()}
+    out.update({"O_" + n: o.detach().numpy() for n, o in zip(names, O)})
+    for k, v in de.state_dict().items():
+        out[f"fp_decoder.{k}"] = fingerprint(v)
+    for k, p in de.named_parameters():
+        g = p.grad.detach().flatten()
+        idx = np.unique(np.linspace(0, g.numel() - 1, 512).astype(np.int64))
+        out[f"gidx_decoder.{k}"] = idx
+        out[f"gsamp_decoder.{k}"] = g[torch.as_tensor(idx)].numpy()
+        out[f"gmax_decoder.{k}"] = np.float32(g.abs().max())
+    np.savez_compressed(GOLD / "width512.npz", **out)
+    print("width512.npz", out["O_lpos"].shape, (GOLD / "width512.npz").stat().st_size)
+
+
 def main():
     assert ref_shims.available(), "/root/reference is required to (re)generate golden vectors"
     GOLD.mkdir(parents=True, exist_ok=True)
@@ -571,6 +611,8 @@ def main():
         gold_variants(ref)
     if "variants" in which or "variants_batch" in which:
         gold_variants_batch(ref)
+    if "nets" in which or "width512" in which:
+        gold_width512(ref)
     if "nets" in which:
         gold_nets(ref)
     if "mel" in which:

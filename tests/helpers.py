@@ -146,3 +146,18 @@ def assert_grad_samples(gd, tag, named_grads, tol):
         scale = max(float(gd[f"gmax_{tag}.{k}"]), 1e-12)
         err = float((got - ref).abs().max()) / scale
         assert err < tol, (tag, k, err)
+
+
+def width512_inputs(gd):
+    """inputs of tests/golden/width512.npz (oracle/make_golden.py gold_width512) rebuilt from the deterministic synth clips"""
+    T = int(gd["clip_T"])
+    B = gd["in_speech"].shape[0]
+    stats = synth.make_stats()
+    clips = [synth.make_clip(T, seed=270 + b, stats=stats) for b in range(B)]
+    W = {k: torch.as_tensor(np.stack([c[k][:T] for c in clips])) for k in clips[0]}
+    np.testing.assert_allclose(fingerprint(W["Y_gaze_pos"]), gd["sum_gaze"], rtol=1e-12, atol=0)
+    first = [W[k][:, 0] for k in ("Y_root_pos", "Y_root_rot", "Y_root_vel", "Y_root_vrt", "Y_lpos", "Y_ltxy", "Y_lvel", "Y_lvrt")]
+    names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
+    gen = torch.Generator().manual_seed(int(gd["weight_seed"]))
+    wts = [torch.randn(tuple(gd["O_" + n].shape), generator=gen) for n in names]
+    return first, W["Y_gaze_pos"], wts

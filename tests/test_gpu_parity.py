@@ -268,6 +268,33 @@ def test_decoder_other_hidden_width_vs_oracle(golden_dir, H):
         assert float((o.detach() - r).abs().max()) < 1e-4, n
 
 
+def test_decoder_width512_vs_reference(golden_dir):
+    """decoder.nhidden = 512 on the fragment-packed stage kernels against the REFERENCE at that width (width512.npz, B = 18,
+    T = 8: outputs, input gradients in full, 512 samples of every parameter gradient of the reference's autograd)"""
+    from zeggs import modules
+    gd = np.load(golden_dir / "width512.npz")
+    torch.manual_seed(5512)
+    de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, 64, 64, 512, 2)
+    for k, v in de.state_dict().items():
+        np.testing.assert_allclose(helpers.fingerprint(v), gd[f"fp_decoder.{k}"], rtol=1e-12, atol=0, err_msg=k)
+    first, gaze, wts = helpers.width512_inputs(gd)
+    s = helpers.stats_tensors()
+    de_g = de.to(DEV).train()
+    stat = [g(s[k]) for k in ("in_mean", "in_std", "out_mean", "out_std")]
+    t = lambda k: torch.as_tensor(gd[k])  # noqa: E731
+    spg, syg = g(t("in_speech")).requires_grad_(True), g(t("in_style")).requires_grad_(True)
+    out = de_g(*[g(x) for x in first], g(gaze), spg, syg, None, *stat, synth.DT)
+    for n, o in zip(NAMES, out):
+        assert float((o.detach().cpu() - t("O_" + n)).abs().max()) < 1e-4, n
+    sum((o * g(w)).sum() for o, w in zip(out, wts)).backward()
+    assert relerr(spg.grad, t("d_speech")) < 3e-4 and relerr(syg.grad, t("d_style")) < 3e-4
+    helpers.assert_grad_samples(gd, "decoder", [(k, p.grad) for k, p in de_g.named_parameters()], 3e-4)
+    with torch.no_grad():
+        out = de_g(*[g(x) for x in first], g(gaze), g(t("in_speech")), g(t("in_style")), None, *stat, synth.DT)
+    for n, o in zip(NAMES, out):
+        assert float((o.cpu() - t("O_" + n)).abs().max()) < 1e-4, n
+
+
 # ----------------------------------------------------------------------------- loss
 def _pack_pose(vel, vrt, lpos, ltxy, lvel, lvrt):
     B, T = vel.shape[:2]

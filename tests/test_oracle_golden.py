@@ -212,3 +212,27 @@ def test_oracle_variants_batch_vs_reference(golden_dir):
         assert float((got - ref).abs().max()) < 1e-4 * float(ref.abs().max()), k
     helpers.assert_grad_samples(g, "decoder", [(k, v.grad) for k, v in wd.items() if v.grad is not None], 1e-4)
     helpers.assert_grad_samples(g, "style", [(k, v.grad) for k, v in ws.items() if v.grad is not None], 1e-4)
+
+
+def test_oracle_width512_vs_reference(golden_dir):
+    """decoder.nhidden = 512: the oracle's rollout and autograd against the reference's (width512.npz)"""
+    from zeggs import modules
+    g = np.load(golden_dir / "width512.npz")
+    torch.manual_seed(5512)
+    de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, 64, 64, 512, 2)
+    for k, v in de.state_dict().items():
+        np.testing.assert_allclose(helpers.fingerprint(v), g[f"fp_decoder.{k}"], rtol=1e-12, atol=0, err_msg=k)
+    first, gaze, wts = helpers.width512_inputs(g)
+    s = helpers.stats_tensors()
+    wd = {k: v.detach().clone().requires_grad_(True) for k, v in helpers.sd(de).items()}
+    speech = torch.as_tensor(g["in_speech"]).requires_grad_(True)
+    style = torch.as_tensor(g["in_style"]).requires_grad_(True)
+    O = onets.decoder_rollout(wd, *first, gaze, speech, style, s["in_mean"], s["in_std"], s["out_mean"], s["out_std"], synth.DT)
+    names = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "ltxy", "lvel", "lvrt")
+    for n, o in zip(names, O):
+        np.testing.assert_allclose(o.detach().numpy(), g["O_" + n], atol=2e-5, rtol=1e-5, err_msg=n)
+    sum((o * w).sum() for o, w in zip(O, wts)).backward()
+    for got, k in ((speech.grad, "d_speech"), (style.grad, "d_style")):
+        ref = torch.as_tensor(g[k])
+        assert float((got - ref).abs().max()) < 1e-4 * float(ref.abs().max()), k
+    helpers.assert_grad_samples(g, "decoder", [(k, v.grad) for k, v in wd.items() if v.grad is not None], 1e-4)
