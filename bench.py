@@ -522,6 +522,26 @@ def nhidden_512_b32(ds, dev, steps=5, warmup=2):
     return out
 
 
+EXTRA_ENGINES = {"v2_label_b64": v2_label_b64, "variants_film_gru_b32": variants_b32, "nhidden_512_b32": nhidden_512_b32}
+
+
+def extra_in_fresh_process(key, timeout=240):
+    """`python bench.py --extra <key>` in a child process: the extra's engine is then the FIRST of its process, like the headline's
+    (a later engine of one process gets its streams from further down PyTorch's pool; measured up to 2.3 x slower on some boxes).
+    Returns the child's JSON, or None (the caller then runs the extra in-process)."""
+    try:
+        r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--extra", key], capture_output=True, text=True,
+                           timeout=timeout, env=launch_env())
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            res = json.loads(lines[-1])
+            res["process"] = "own (python bench.py --extra %s)" % key
+            return res
+    except (subprocess.SubprocessError, OSError, ValueError):
+        pass
+    return None
+
+
 # ----------------------------------------------------------------------------- launcher
 def launch_command(argv, gpus, port):
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
@@ -571,9 +591,27 @@ def main():
                     help="initialise the RCCL process group and run the gradient all-reduce even at --gpus 1")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="only rendezvous (gloo on CPU when no GPU is visible) and print the rank census")
+    ap.add_argument("--extra", choices=sorted(EXTRA_ENGINES), default=None,
+                    help="run ONE of the extra training configurations alone and print its JSON (what the default run does in a "
+                         "fresh process per extra: a second or third engine in one process maps its streams onto hardware queues "
+                         "less luckily than the first, tools/prio_probe.py)")
     a = ap.parse_args()
+    if a.extra:
+        dev = rank_device(0)
+        torch.cuda.set_device(dev)
+        ops.set_option("timing", 1)
+        ds = engine.DeviceDataset(build_dataset(), WINDOW, dev)
+        print(json.dumps(EXTRA_ENGINES[a.extra](ds, dev)))
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))
+    # The extra training configurations run FIRST, each in a process of its own, before this process has touched the GPU: a
+    # second engine in one process runs slower than the first on some boxes (stream -> hardware-queue mapping), and a child
+    # that starts while its parent holds queues on the same GPU is scheduled against them (FiLM: 42 instead of 36 ms).
+    pre_extras = {}
+    if a.gpus == 1 and "WORLD_SIZE" not in os.environ and not a.no_extras and not a.launch_selftest:
+        for key in EXTRA_ENGINES:
+            pre_extras[key] = extra_in_fresh_process(key)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -766,9 +804,8 @@ def main():
             if not a.no_generate:
                 out["generate_30min"] = generate_30min(dev)
             del eng
-            out["v2_label_b64"] = v2_label_b64(ds, dev)
-            out["variants_film_gru_b32"] = variants_b32(ds, dev)
-            out["nhidden_512_b32"] = nhidden_512_b32(ds, dev)
+            for key, fn in EXTRA_ENGINES.items():
+                out[key] = pre_extras.get(key) or fn(ds, dev)
         if world == 1 and not a.no_cpu_baseline:
             import contextlib
             with contextlib.redirect_stdout(sys.stderr):      # the reference's train() writes its progress bar to stdout
