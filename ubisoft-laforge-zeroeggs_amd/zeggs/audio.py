@@ -182,9 +182,11 @@ def normalize_loudness_device(wav, rate, target=-20.0, device="cuda", chunk=4096
         raise ValueError("Audio must have length greater than the block size.")       # pyloudnorm.util.valid_audio
     T_g, step = 0.4, 1.0 - 0.75
     nblocks = int(np.round(((n / rate - T_g) / (T_g * step))) + 1)
+    # pyloudnorm's bounds int(T_g * (j * step) * rate) / int(T_g * (j * step + 1) * rate): the same float64 operations in the same
+    # order on the whole index vector (18 000 blocks for 30 minutes: 34 ms as a Python loop, 0.3 ms so), truncated like int()
     j = np.arange(nblocks)
-    lo = np.array([int(T_g * (jj * step) * rate) for jj in j], dtype=np.int64)
-    hi = np.minimum(np.array([int(T_g * (jj * step + 1) * rate) for jj in j], dtype=np.int64), n)
+    lo = np.trunc(T_g * (j * step) * rate).astype(np.int64)
+    hi = np.minimum(np.trunc(T_g * (j * step + 1) * rate).astype(np.int64), n)
     coef, trans = [], []
     for b, a in _kweighting(rate):
         coef += [b[0], b[1], b[2], a[1], a[2]]

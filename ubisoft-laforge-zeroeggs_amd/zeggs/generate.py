@@ -57,8 +57,10 @@ def read_wav_mono16k(path):
     if x.ndim > 1:
         x = x.mean(axis=1)
     if np.issubdtype(x.dtype, np.integer):
-        x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
-    return fs, x.astype(np.float32)
+        scale = float(np.iinfo(x.dtype).max + 1)          # a power of two: multiplying by its reciprocal is the same division, exactly
+        x = x.astype(np.float32)
+        np.multiply(x, np.float32(1.0 / scale), out=x)    # (one pass over the 115 MB of a 30-minute clip instead of three)
+    return fs, x if x.dtype == np.float32 else x.astype(np.float32)
 
 
 def _example_features(p):
