@@ -383,10 +383,10 @@ def generate_30min(dev, minutes=30.0, exemplar_frames=CLIP_FRAMES):
                     break
         # (round 4: long clips decode in chunks with the BVH rows converted / downloaded / formatted / written underneath the
         #  next chunks -- that one stage is device-bound with the host work hidden in it: counted with the device stages)
-        dev_ms = sum(v for k, v in prof.items() if k.endswith("_device") or "_device_with_" in k)
+        dev_ms = sum(v for k, v in prof.items() if (k.endswith("_device") or "_device_with_" in k) and isinstance(v, (int, float)))
         host_ms = sum(v for k, v in prof.items() if k.endswith("_host"))
         return {"frames": frames, "total_s": round(total, 2), "device_stages_ms": round(dev_ms, 1),
-                "host_stages_ms": round(host_ms, 1), "stages_ms": {k: round(v, 2) for k, v in prof.items()},
+                "host_stages_ms": round(host_ms, 1), "stages_ms": {k: (round(v, 2) if isinstance(v, (int, float)) else v) for k, v in prof.items()},
                 "x_realtime_device_stages": round(minutes * 60e3 / dev_ms, 1), "x_realtime_total": round(minutes * 60 / total, 1),
                 "bvh_bytes": (res / "out.bvh").stat().st_size, "style_encoding_finite": bool(torch.isfinite(enc).all()),
                 "config": f"generate_gesture(): {minutes:g} min 16 kHz WAV, {exemplar_frames}-frame exemplar BVH (= first pose), "

@@ -89,8 +89,10 @@ def _decode_to_bvh_streaming(decoder, pose0, rpos0, rrot0, gaze_row, speech, sty
     (488 MB for 30 minutes).  Give-ups of the persistent kernel are collected in one status word that is looked at ONCE, after
     the last chunk: then everything is redone on the stage launches."""
     import ctypes as C
+    import time as _t0
     from concurrent.futures import ThreadPoolExecutor
     from . import ops
+    t_enter = _t0.perf_counter()
     chunk, block = chunk or STREAM_CHUNK, block or STREAM_BLOCK
     dev = speech.device
     T = speech.shape[1]
@@ -112,9 +114,14 @@ def _decode_to_bvh_streaming(decoder, pose0, rpos0, rrot0, gaze_row, speech, sty
     status = ops.new_status(dev)
     main = torch.cuda.current_stream()
 
-    tail_rows = max(1, min(chunk // 4, 2048))
+    # the last chunk is what nothing hides: its rows are converted, downloaded, formatted (36 us of host time per row: 18 ms for
+    # a 512-row task) and written AFTER the decode has ended -- so it is short and its formatting tasks are small
+    workers = threads or min(16, (__import__("os").cpu_count() or 4))
+    tail_rows = max(1, min(chunk // 16, 512))
     RING = 4                                             # pinned staging buffers in flight (page-locking 15 MB costs ~5 ms: not per chunk)
     ring = _pinned_ring(RING, min(chunk, T) + 1, cols)
+
+    marks = []
 
     def run(pool, fh):
         """decode chunk by chunk; chunk c's text is written while chunks c + 1 .. c + RING - 1 are queued on the device"""
@@ -168,17 +175,29 @@ def _decode_to_bvh_streaming(decoder, pose0, rpos0, rrot0, gaze_row, speech, sty
             def fmt(host=host, ev=ev, r0=0, r1=0):
                 ev.synchronize()
                 return anim.format_rows(host[r0:r1].numpy())
-            pending.append([pool.submit(fmt, r0=r0, r1=min(r0 + block, rows)) for r0 in range(0, rows, block)])
+            last = n == 0 or k + n >= T - 1
+            blk = block if not last else max(16, -(-rows // (2 * workers)))
+            pending.append([pool.submit(fmt, r0=r0, r1=min(r0 + blk, rows)) for r0 in range(0, rows, blk)])
             k += n
             c += 1
             if n == 0 or k >= T - 1:
                 break
+        marks.append(_t0.perf_counter())                 # everything is enqueued
         drain(0)
+        marks.append(_t0.perf_counter())                 # ... decoded, converted, downloaded, formatted and written
 
-    with ThreadPoolExecutor(max_workers=threads or min(16, (__import__("os").cpu_count() or 4))) as pool:
+    import time as _t
+    t_setup = _t.perf_counter()
+    with ThreadPoolExecutor(max_workers=workers) as pool:
         with open(path, "wb") as fh:
             fh.write(head.encode())
             run(pool, fh)
+            t_run = _t.perf_counter()
+        t_close = _t.perf_counter()
+        if PROFILE is not None:
+            PROFILE["  streaming_writer_breakdown_ms"] = {
+                "setup": round((t_setup - t_enter) * 1e3, 2), "enqueue_all_chunks": round((marks[0] - t_setup) * 1e3, 2),
+                "last_chunks_decoded_formatted_written": round((marks[1] - marks[0]) * 1e3, 2), "file_close": round((t_close - t_run) * 1e3, 2)}
         if ops._persistent_live(0) and int(status[0].item()):     # (every chunk has been downloaded by now: no extra wait)
             ops._warn_gave_up(int(status[0].item()), "the whole rollout")
             ops.set_option("persistent", 0)
