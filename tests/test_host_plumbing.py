@@ -2,6 +2,7 @@
 BVH parsing of a file written by the reference's bvh.save, BVH writing round trip; and of the NumPy oracle of the
 animation kernels (exemplar feature extraction, decoder output -> BVH channels) against the same fixtures."""
 import numpy as np
+import pytest
 
 from oracle import anim as oanim
 from zeggs import anim, generate, synth
@@ -198,3 +199,32 @@ def test_parse_table_text_is_exact_and_declines_malformed_tables(tmp_path):
     (tmp_path / "b.bvh").write_text("\n".join(raw))
     a, b = anim.bvh_load(tmp_path / "a.bvh"), anim.bvh_load(tmp_path / "b.bvh")
     assert np.array_equal(a["rotations"], b["rotations"]) and np.array_equal(a["positions"], b["positions"])
+
+
+@pytest.mark.parametrize("n,rate", [(6400, 16000), (160000, 16000), (123457, 16000), (28_800_000, 16000), (441000, 44100)])
+def test_loudness_gating_blocks_equal_the_reference_loop(n, rate):
+    """the vectorised gating-block table of the loudness pre-pass = pyloudnorm's per-block Python expressions, integer for integer"""
+    from zeggs import audio
+    lo, hi = audio.gating_blocks(n, rate)
+    T_g, step = 0.4, 1.0 - 0.75
+    nblocks = int(np.round(((n / rate - T_g) / (T_g * step))) + 1)
+    j = range(0, nblocks) if nblocks < 2000 else list(range(0, 500)) + list(range(nblocks - 500, nblocks)) + list(range(500, nblocks, 97))
+    assert len(lo) == nblocks == len(hi)
+    for jj in j:
+        assert lo[jj] == int(T_g * (jj * step) * rate)
+        assert hi[jj] == min(int(T_g * (jj * step + 1) * rate), n)
+
+
+def test_wav_reader_scaling_is_the_exact_division(tmp_path):
+    """16-bit PCM -> float32 / 32768 in one in-place pass: bit-identical to the division (the scale is a power of two)"""
+    import scipy.io.wavfile as wavfile
+    rng = np.random.default_rng(5)
+    x = rng.integers(-32768, 32768, 50000).astype(np.int16)
+    x[:4] = [-32768, 32767, 0, -1]
+    wavfile.write(tmp_path / "a.wav", 16000, x)
+    fs, y = generate.read_wav_mono16k(tmp_path / "a.wav")
+    assert fs == 16000 and y.dtype == np.float32
+    assert np.array_equal(y, x.astype(np.float32) / 32768.0)
+    wavfile.write(tmp_path / "b.wav", 8000, x)
+    with pytest.raises(ValueError):
+        generate.read_wav_mono16k(tmp_path / "b.wav")

@@ -168,6 +168,18 @@ def _kweighting(rate):
     return out
 
 
+def gating_blocks(n, rate):
+    """[lo, hi) sample bounds of the 400 ms gating blocks with 75 % overlap of an n-sample signal (pyloudnorm 0.1.0 meter.py:
+    `l = int(T_g * (j * step) * rate)`, `u = int(T_g * (j * step + 1) * rate)`): the same float64 operations in the same order on
+    the whole index vector (18 000 blocks for 30 minutes: 34 ms as a Python loop, 0.3 ms so), truncated like int()."""
+    T_g, step = 0.4, 1.0 - 0.75
+    nblocks = int(np.round(((n / rate - T_g) / (T_g * step))) + 1)
+    j = np.arange(nblocks)
+    lo = np.trunc(T_g * (j * step) * rate).astype(np.int64)
+    hi = np.minimum(np.trunc(T_g * (j * step + 1) * rate).astype(np.int64), n)
+    return lo, hi
+
+
 def normalize_loudness_device(wav, rate, target=-20.0, device="cuda", chunk=4096):
     """Loudness normalisation of a MONO signal on the device (zeggs_loudness_gain): chunk-parallel K-weighting filters,
     gating-block energies, gates and gain; returns (normalised float32 tensor on `device`, LUFS).  The only host work is
@@ -180,13 +192,8 @@ def normalize_loudness_device(wav, rate, target=-20.0, device="cuda", chunk=4096
         raise ValueError("normalize_loudness_device: mono signals only")
     if n < 0.4 * rate:
         raise ValueError("Audio must have length greater than the block size.")       # pyloudnorm.util.valid_audio
-    T_g, step = 0.4, 1.0 - 0.75
-    nblocks = int(np.round(((n / rate - T_g) / (T_g * step))) + 1)
-    # pyloudnorm's bounds int(T_g * (j * step) * rate) / int(T_g * (j * step + 1) * rate): the same float64 operations in the same
-    # order on the whole index vector (18 000 blocks for 30 minutes: 34 ms as a Python loop, 0.3 ms so), truncated like int()
-    j = np.arange(nblocks)
-    lo = np.trunc(T_g * (j * step) * rate).astype(np.int64)
-    hi = np.minimum(np.trunc(T_g * (j * step + 1) * rate).astype(np.int64), n)
+    lo, hi = gating_blocks(n, rate)
+    nblocks = len(lo)
     coef, trans = [], []
     for b, a in _kweighting(rate):
         coef += [b[0], b[1], b[2], a[1], a[2]]
