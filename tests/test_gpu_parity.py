@@ -1161,6 +1161,32 @@ def test_gru_style_encoder_forward_backward(golden_dir):
         assert relerr(p.grad, w64[k].grad) < 3e-4, k
 
 
+@pytest.mark.parametrize("B,T", [(1, 101), (3, 70)])
+def test_film_decoder_inference_modulation_blocks(golden_dir, B, T):
+    """FiLM inference over more frames than one block of modulation vectors (decoder_ws.h FILM_GB = 32: the ring of 2 x 32 frames
+    wraps twice at T = 101) with a style that changes every frame: the stage path (B = 1: GEMV launches, B = 3: matrix-core
+    launches) against the generic per-step path, which evaluates the two predictors frame by frame"""
+    gd, _, s = _golden_nets(golden_dir)
+    de, _ = _variant_nets()
+    de_g = de.to(DEV).eval()
+    torch.manual_seed(7 * B + T)
+    speech, style = torch.randn(B, T, 64) * 0.5, torch.randn(B, T, 64) * 0.5
+    rep = lambda x: x.repeat((B + 1) // 2, *([1] * (x.dim() - 1)))[:B].clone()  # noqa: E731
+    fp = [rep(x) for x in _first_pose(gd)]
+    gaze = rep(torch.as_tensor(gd["in_Y_gaze_pos"])[:, :1]).repeat(1, T, 1)
+    stat = [g(s[k]) for k in ("in_mean", "in_std", "out_mean", "out_std")]
+    with torch.no_grad():
+        out = de_g(*[g(x) for x in fp], g(gaze), g(speech), g(style), None, *stat, synth.DT)
+        try:
+            ops.set_option("decoder_fast", 0)
+            ref = de_g(*[g(x) for x in fp], g(gaze), g(speech), g(style), None, *stat, synth.DT)
+        finally:
+            ops.set_option("decoder_fast", 1)
+    for n, o, r in zip(NAMES, out, ref):
+        assert bool(torch.isfinite(o).all()), n
+        assert float((o - r).abs().max()) < 5e-4 * max(1.0, float(r.abs().max())), n
+
+
 def test_film_and_gru_variants_batch_vs_reference(golden_dir):
     """The stage-kernel path of rnn_cond = "film" and style type = "gru" against the REFERENCE at a batch of two 16-row blocks
     (B = 19, T = 12, exemplar 33, a style that changes every frame; variants_batch.npz: the reference's outputs, its autograd's

@@ -1293,14 +1293,22 @@ int dec_fast_fwd_steps(const ZeggsDecDims& d, const ZeggsDecParams* P, const Zeg
     const float *gam_n = nullptr, *bet_n = nullptr;   // ... and those of step t + 1 (merged launch: layer0 of the next step)
     if (d.film) {
       const long sg = (long)B * 2 * H;
-      if (!training) {   // ring path: the modulation vectors of step u from style[:, u] into slot u & 1 (training: every step's, decoder.hip)
-        for (int u = (t == 1 ? 1 : t + 1); u <= t + 1 && u < T; ++u) {
-          ZTRY(gemm_nt(style + (long)u * d.ST, (long)T * d.ST, P->g_w, d.ST, w.GAM + (u & 1) * sg, 2 * H, P->g_b, B, 2 * H, d.ST, ACT_NONE, 0.f, s));
-          ZTRY(gemm_nt(style + (long)u * d.ST, (long)T * d.ST, P->be_w, d.ST, w.BET + (u & 1) * sg, 2 * H, P->be_b, B, 2 * H, d.ST, ACT_NONE, 0.f, s));
+      // ring path: frame u's vectors live in slot (u - 1) % (2 FILM_GB); block i = frames [1 + i GB, 1 + (i + 1) GB) fills half
+      // i & 1 of the ring with ONE batched product per predictor (rows = frames, batch = batch rows of style [B, T, ST]) when
+      // the step in front of it is reached -- its other half still holds the current block (training: every frame's, decoder.hip)
+      auto gslot = [&](int u) { return training ? (long)u : (long)((u - 1) % (2 * FILM_GB)); };
+      if (!training && (t == 1 || (t % FILM_GB == 0 && t + 1 < T))) {
+        const int f0 = t == 1 ? 1 : t + 1;                 // first frame of the block to compute
+        const int nfr = (T - f0) < FILM_GB ? (T - f0) : FILM_GB;
+        for (int which = 0; which < 2 && nfr > 0; ++which) {
+          GemmArgs g = gemm_args(style + (long)f0 * d.ST, which ? P->be_w : P->g_w, (which ? w.BET : w.GAM) + gslot(f0) * sg, nfr, 2 * H, d.ST);
+          g.sam = d.ST; g.sak = 1; g.sbk = 1; g.sbn = d.ST; g.scm = sg; g.scn = 1;
+          g.bsA0 = (long)T * d.ST; g.bsC0 = 2 * H; g.nb1 = 1; g.bias = which ? P->be_b : P->g_b;
+          ZTRY(launch_gemm(g, B, s));
         }
       }
-      gam = w.GAM + cs(t) * sg; bet = w.BET + cs(t) * sg;
-      gam_n = w.GAM + cs(t + 1) * sg; bet_n = w.BET + cs(t + 1) * sg;
+      gam = w.GAM + gslot(t) * sg; bet = w.BET + gslot(t) * sg;
+      gam_n = w.GAM + gslot(t + 1) * sg; bet_n = w.BET + gslot(t + 1) * sg;
     }
     if (t == 1 || !merged) {
       // S1: hid = ELU(W0 x + b0)   [film: modulated]

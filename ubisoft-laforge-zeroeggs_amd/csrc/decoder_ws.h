@@ -51,6 +51,7 @@ struct DecWs {
 };
 
 inline int round4(int x) { return (x + 3) / 4 * 4; }
+constexpr int FILM_GB = 32;     // frames per block of inference-time FiLM modulation vectors
 
 inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
   DecWs w;
@@ -81,7 +82,10 @@ inline DecWs carve_dec(const ZeggsDecDims& d, int training, Arena& a) {
   }
   if (d.film) {
     w.A0 = a.f(TS * B * H); w.A2 = a.f(TS * B * H); w.F2 = a.f(TS * B * H);
-    w.GAM = a.f(TS * B * 2 * H); w.BET = a.f(TS * B * 2 * H);
+    // modulation vectors: every frame's in training; in inference a ring of 2 x FILM_GB frames, filled a block of FILM_GB frames at a
+    // time by one batched GEMM (decoder_fast.hip; the generic path uses slot 0 only, per frame)
+    const long TSG = training ? T : 2 * FILM_GB;
+    w.GAM = a.f(TSG * B * 2 * H); w.BET = a.f(TSG * B * 2 * H);
     if (training) {
       w.DGAM = a.f(T * B * 2 * H); w.DBET = a.f(T * B * 2 * H); w.D2 = a.f(T * B * H); w.dF2 = a.f(B * H);
       w.STm = a.f(T * B * (long)d.ST); w.dSTm = a.f(T * B * (long)d.ST);
