@@ -500,6 +500,114 @@ def gold_train_iter_fp64(ref):
     np.savez_compressed(GOLD / "train_iter_fp64.npz", **out)
 
 
+def gold_train_iter_perturb(ref, n_seeds=10, rel=1e-7):
+    """is iteration 1 of train_iter.npz ill-conditioned in the REFERENCE itself?  The two recorded
+    iterations are replayed through the unmodified reference train() in float32, `n_seeds` times, with every floating-point
+    batch tensor of ITERATION 1 multiplied by (1 + rel * N(0, 1)) (iteration 0 untouched, so the weights iteration 1 starts
+    from are the recorded ones bit for bit).  Per tensor and seed: length ratio |g32| / |g64| and 1 - cosine against the float64
+    replay (train_iter_fp64.npz); also the same two numbers for a float64 replay of the perturbed inputs (what the
+    perturbation itself does to the true gradient).  -> tests/golden/train_iter_perturb.npz: the measured spread the
+    reference-side test derives its iteration-1 bound from."""
+    import torch.nn.functional as F
+    gd = np.load(GOLD / "train_iter.npz")
+    g64 = np.load(GOLD / "train_iter_fp64.npz")
+    window, B, n_it = int(gd["window"]), int(gd["batch"]), len(gd["loss"])
+    se, de, st = build_ref_nets(ref)
+    sizes = [len(sample_idx(p.numel())) for m in (se, de, st) for p in m.parameters()]
+    ref64 = g64["it1_grad_samples64"]
+
+    def replay(seed, double):
+        tmp = Path(tempfile.mkdtemp(prefix="zeggs_goldp_"))
+        (tmp / "data").mkdir(), (tmp / "models").mkdir(), (tmp / "logs").mkdir()
+        npz, jsn = tmp / "data" / "processed_data.npz", tmp / "data" / "data_definition.json"
+        np.savez(npz, **{k[5:]: gd[k] for k in gd.files if k.startswith("data_")})
+        json.dump(synth.data_definition(), open(jsn, "w"))
+        rec, state = dict(grads=[]), dict(it=0)
+        rng = np.random.default_rng(1000 + seed) if seed is not None else None
+
+        class ReplayDL:
+            def __init__(self, ds, **kw):
+                pass
+
+            def __iter__(self):
+                for it in range(n_it):
+                    b = []
+                    for j in range(11):
+                        a = gd[f"it{it}_batch{j}"]
+                        if it == 1 and rng is not None and a.dtype.kind == "f":
+                            a = (a.astype(np.float64) * (1.0 + rel * rng.standard_normal(a.shape))).astype(a.dtype)
+                        t = torch.as_tensor(a)
+                        b.append(t.double() if double and t.is_floating_point() else t)
+                    yield b
+
+        def fake_randn_like(x, *a, **k):
+            if tuple(x.shape) == (B, 64):
+                return torch.as_tensor(gd[f"it{min(state['it'], n_it - 1)}_eps"]).to(x.dtype)
+            return torch.zeros_like(x)
+
+        def double_module(cls):
+            def make(*a, **k):
+                m = cls(*a, **k).double()
+                m.register_forward_pre_hook(lambda mod, args: tuple(x.double() if torch.is_tensor(x) and x.is_floating_point()
+                                                                    else x for x in args))
+                return m
+            return make
+
+        orig_step = ref.optimizers.RAdam.step
+
+        def rec_step(self, closure=None):
+            ps = [p for g in self.param_groups for p in g["params"]]
+            rec["grads"].append(np.concatenate([p.grad.flatten()[sample_idx(p.numel())].double().numpy() for p in ps]))
+            state["it"] += 1
+            return orig_step(self, closure)
+
+        rt = ref.train
+        saved = (rt.DataLoader, torch.randn_like, F.dropout, rt.SpeechEncoder, rt.Decoder, rt.StyleEncoder, torch.save)
+        rt.DataLoader, torch.randn_like = ReplayDL, fake_randn_like
+        F.dropout = lambda x, p=0.5, training=True, inplace=False: x
+        if double:
+            rt.SpeechEncoder, rt.Decoder, rt.StyleEncoder = (double_module(c) for c in saved[3:6])
+        torch.save = lambda *a, **k: None
+        ref.optimizers.RAdam.step = rt.RAdam.step = rec_step
+        random.seed(0)
+        train_opt = dict(niterations=0.001, batchsize=B, window=window, change_pace=True, learning_rate=1e-4,
+                         learning_rate_decay=0.995, eps=1e-5, resume=False, use_gpu=False, thread_count=1, seed=SEED,
+                         use_tensorboard=False, style_encoding_type="example", generate_samples_step=10 ** 9,
+                         use_script=False)
+        try:
+            rt.train(tmp / "models", tmp / "logs", npz, jsn, train_opt, NET_OPT)
+        finally:
+            (rt.DataLoader, torch.randn_like, F.dropout, rt.SpeechEncoder, rt.Decoder, rt.StyleEncoder, torch.save) = saved
+            ref.optimizers.RAdam.step = rt.RAdam.step = orig_step
+        return rec["grads"]
+
+    def per_tensor(g, r):
+        ratio, cosd, off = [], [], 0
+        for n in sizes:
+            a, b = g[off:off + n], r[off:off + n]
+            ratio.append(np.linalg.norm(a) / max(1e-300, np.linalg.norm(b)))
+            cosd.append(1.0 - float(np.dot(a, b) / max(1e-300, np.linalg.norm(a) * np.linalg.norm(b))))
+            off += n
+        return np.array(ratio), np.array(cosd)
+
+    base32 = replay(None, False)
+    assert np.array_equal(base32[1].astype(np.float32), gd["it1_grad_samples"]), "the unperturbed fp32 replay must reproduce the fixture"
+    out = dict(rel=np.float64(rel))
+    out["base_ratio"], out["base_cosd"] = per_tensor(base32[1], ref64)
+    R32, C32, R64, C64 = [], [], [], []
+    for sd in range(n_seeds):
+        r, c = per_tensor(replay(sd, False)[1], ref64)
+        R32.append(r), C32.append(c)
+        r, c = per_tensor(replay(sd, True)[1], ref64)
+        R64.append(r), C64.append(c)
+        print(f"train_iter_perturb seed {sd}: fp32 length ratio {R32[-1].min():.5f} .. {R32[-1].max():.5f} (1-cos <= {C32[-1].max():.1e}); "
+              f"fp64 on the same perturbed inputs {R64[-1].min():.7f} .. {R64[-1].max():.7f} (1-cos <= {C64[-1].max():.1e})", flush=True)
+    out.update(ratio32=np.array(R32), cosd32=np.array(C32), ratio64=np.array(R64), cosd64=np.array(C64))
+    np.savez_compressed(GOLD / "train_iter_perturb.npz", **out)
+    print("train_iter_perturb.npz: fp32 ratio over seeds and tensors", out["ratio32"].min(), out["ratio32"].max(),
+          "base", out["base_ratio"].min(), out["base_ratio"].max())
+
+
 def gold_variants_batch(ref):
     """The same two nets (seed 4321) at a batch the stage kernels split into two 16-row blocks, with a style that changes every
     frame: reference forward outputs AND the reference's own autograd gradients (fp32, as the reference trains) of a seeded
@@ -629,6 +737,8 @@ def main():
         gold_train_iter(ref)
     if "train" in which or "train_fp64" in which:
         gold_train_iter_fp64(ref)
+    if "train_perturb" in which:
+        gold_train_iter_perturb(ref)
 
 
 if __name__ == "__main__":

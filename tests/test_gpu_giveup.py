@@ -74,6 +74,51 @@ def test_training_giveup_is_skipped_on_device_and_replayed_on_the_stage_kernels(
     assert np.abs(w - w_ref).max() <= 5e-6, np.abs(w - w_ref).max()
 
 
+def test_persistent_sweeps_are_rearmed_after_a_giveup_and_back_off(restore_options):
+    """a give-up must not switch the persistent sweeps off for the life of the process.  Give-up at
+    iteration 2 (persistent_spin = 0) -> skipped on the device, noticed STATUS_LAG later, replayed on the stage kernels; after
+    `rearm_after` clean iterations (counted from the first lost step, so every data-parallel rank gets the same number) the
+    sweeps are back ON -- proven by forcing a second give-up, which only a running persistent kernel can produce -- and that
+    second give-up, coming right after the re-arm, doubles the probation.  The weights end up those of an undisturbed run."""
+    steps, B, T, L = 14, 32, 64, 96
+    ref = _train(steps, -1, persistent=False)
+    w_ref = ref.flat_p.detach().cpu().numpy().copy()
+    for k in ("train_persistent", "bwd_persistent"):
+        ops.set_option(k, 1)
+    ops.set_option("persistent_spin", SPIN)
+    ops.manual_seed(99)
+    eng, ds = _engine(B, T, T + 200)
+    eng.rearm_after = eng._rearm_wait = 4
+    perm = np.random.default_rng(5).permutation(len(ds))
+    lag = engine.TrainEngine.STATUS_LAG
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for k in range(steps):
+            if k in (2, 8):
+                torch.cuda.synchronize()
+                ops.set_option("persistent_spin", 0)
+            eng.step(engine.shard_indices(perm, k, B, 1, 0), L)
+            if k in (2, 8):
+                torch.cuda.synchronize()
+                st = eng.status.cpu().numpy()
+                assert st[0] & 2 and st[1] == 1, (k, st)      # a persistent rollout ran and gave up: the step was skipped on the device
+                ops.set_option("persistent_spin", SPIN)
+            if k == 2 + lag:        # the host has just noticed: sweeps off, probation of 4 iterations from the first lost step
+                assert ops._OPTIONS["train_persistent"] == 0 and eng._rearm_at == 2 + 4 and eng.rearm_count == 0
+            if k == 6:              # ... over: back on (and validated as before)
+                assert ops._OPTIONS["train_persistent"] == 1 and ops._OPTIONS["bwd_persistent"] == 1 and eng.rearm_count == 1
+                assert ops.lib().zeggs_persistent_state(1) == 1 and ops.lib().zeggs_persistent_state(2) == 1
+            if k == 8 + lag:        # second give-up within the probation window of the re-arm: the wait doubles
+                assert ops._OPTIONS["train_persistent"] == 0 and eng._rearm_wait == 8 and eng._rearm_at == 8 + 8
+        eng.flush()
+    torch.cuda.synchronize()
+    assert sum("gave up" in str(w.message) for w in rec) == 2
+    assert eng.recovered_steps == 2 * lag and eng.iteration == steps == eng.opt._step and eng.rearm_count == 1
+    w = eng.flat_p.detach().cpu().numpy()
+    assert np.isfinite(w).all()
+    assert np.abs(w - w_ref).max() <= 1e-5, np.abs(w - w_ref).max()      # (four of the 14 steps ran on the persistent kernels)
+
+
 def _rollout(de, T, seed=4242):
     W, speech, style = helpers.full_decoder_inputs(helpers.real_stats("v1"), 1, T, seed)
     s = helpers.real_stats_tensors("v1", device=DEV)

@@ -116,19 +116,40 @@ __device__ __forceinline__ Q4 quat_mul(Q4 x, Q4 y) {
             y.w * x.z - y.x * x.y + y.y * x.x + y.z * x.w};
 }
 
-// counter-based RNG for dropout masks: same (seed, index) -> same bit in fwd and bwd
+// counter-based RNG for dropout masks / the VAE noise: same (seed, index) -> same bits in fwd and bwd.
+// Round 5: 32-bit arithmetic.  The round-1..4 form was a 64-bit splitmix finaliser -- three 64 x 64 multiplies = ~8 quarter-rate
+// v_mul_lo / v_mul_hi + 64-bit shifts, ~60 VALU instructions per element -- and the fused attention kernels draw one mask value
+// per probability: the hash cost more issue time than their matrix-core products.  Now: the seed is mixed down to a 32-bit key
+// on the SCALAR unit (it is wave-uniform), the element index is folded to 32 bits (the high word rotated in: indices 2^32 apart
+// may share a value, which no mask of this library is long enough to notice) and goes through the three multiply-xorshift rounds
+// of `triple32` (C. Wellons' hash-prospector search: bias 0.0208) -- 3 multiplies + 9 cheap ops.  Statistical quality on
+// sequential counters (keep rates, neighbour / neighbouring-seed correlation, byte chi-squares, Box-Muller moments): tools/hash_quality.py.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 17; x *= 0xed5ad4bbu;
+  x ^= x >> 11; x *= 0xac4c1b51u;
+  x ^= x >> 15; x *= 0x31848babu;
+  x ^= x >> 14;
+  return x;
+}
+__device__ __forceinline__ uint32_t hash_key(uint64_t seed) {      // wave-uniform: lives in SGPRs
+  return mix32(((uint32_t)seed * 0x9E3779B1u) ^ (uint32_t)(seed >> 32));
+}
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  return mix32((lo ^ ((hi << 16) | (hi >> 16))) + hash_key(seed));
 }
 // keep-scale for element idx: 0 (dropped) or 1/(1-p)
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
   if (p <= 0.f) return 1.f;
   float u = (float)(hash_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
   return u < p ? 0.f : 1.f / (1.f - p);
+}
+// the same value without the branch and with the loop invariants hoisted by the caller (key = hash_key(seed), the element index
+// as two words, inv_keep = 1 / (1 - p)): the form the fused attention kernels use, one mask value per probability
+__device__ __forceinline__ float dropout_scale_fast(uint32_t key, uint32_t lo, uint32_t hi, float p, float inv_keep) {
+  const uint32_t hsh = mix32((lo ^ ((hi << 16) | (hi >> 16))) + key);
+  const float u = (float)(hsh >> 8) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : inv_keep;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

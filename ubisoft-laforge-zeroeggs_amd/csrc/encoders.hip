@@ -43,6 +43,14 @@ int conv_gemm(const float* xp, long xp_bstride, int C, const float* Wf, int Ktot
   g.bias = bias; g.act = act;
   return launch_gemm(g, B, s);
 }
+// the same convolution over ALL batches as one product: xp [B][LP][C] read as a [B LP - (taps - 1), taps C] matrix with
+// overlapping rows (lda = C), y row r = b LP + t (the rows t >= LP - taps + 1 of a batch mix two batches: never read); no bias /
+// activation, so launch_gemm may split K (stream-K when the output has few tiles)
+int conv_flat(const float* xp, int C, const float* Wf, int Ktot, int Co, float* y, int Mrows, hipStream_t s) {
+  GemmArgs g = gemm_args(xp, Wf, y, Mrows, Co, Ktot);
+  g.sam = C; g.sak = 1; g.sbk = Co; g.sbn = 1; g.scm = Co; g.scn = 1; g.nb1 = 1;
+  return launch_gemm(g, 1, s);
+}
 // dWf[k][co] = sum_b sum_t xp_b[t*C + k] * dy_b[t][co]
 int conv_dw_gemm(const float* xp, long xp_bstride, int C, const float* dy, long lddy, long dy_bstride, float* dWf,
                  int Ktot, int Co, int B, int T, hipStream_t s) {
@@ -167,9 +175,10 @@ StyleWs carve_style(const ZeggsStyleDims& d, Arena& a) {
   w.wff0 = a.f(3L * E * E); w.wfb0 = a.f(3L * E * E);
   w.wff2 = a.f(3L * E * E); w.wfb2 = a.f(3L * E * E);
   w.xp = a.f(B * LP * C);
-  w.c1 = a.f(BL * H); w.m1 = a.f(BL); w.r1 = a.f(BL);
+  w.c1 = a.f(B * LP * H); w.m1 = a.f(BL); w.r1 = a.f(BL);      // c1, c2: rows b * LP + t (t < L valid), see conv_flat
+
   w.a1p = a.f(B * LP * H);
-  w.c2 = a.f(BL * E); w.m2 = a.f(BL); w.r2 = a.f(BL);
+  w.c2 = a.f(B * LP * E); w.m2 = a.f(BL); w.r2 = a.f(BL);
   w.h = a.f(BL * E);
   w.qkv = a.f(BL * 3 * E);
   // (the choice depends on the dimensions and a process-wide tuning switch only: forward and backward of one call pair carve
@@ -224,32 +233,46 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
   const long BL = (long)B * L;
   const float p2 = d.dropout ? 0.2f : 0.f, p1 = d.dropout ? 0.1f : 0.f;
   const float eps = 1e-5f;
-  // conv stack
+  // the four convolutions' weights -> k-major packs, one launch
+  {
+    const PackConvW items[4] = {{w.wf0, nullptr, P->c0_w, H, C, 3}, {w.wf4, w.wb4, P->c4_w, E, H, 3},
+                                {w.wff0, w.wfb0, P->ff0_w, E, E, 3}, {w.wff2, w.wfb2, P->ff2_w, E, E, 3}};
+    ZTRY(k_pack_conv_w_multi(items, 4, s));
+  }
+  // conv stack.  Round 5: the first two convolutions run as ONE product over all batches (conv_flat: the padded input [B][LP][C] is
+  // one [B LP, C] matrix whose rows overlap; output row b LP + t, the two rows per batch that straddle a boundary are never read)
+  // WITHOUT bias / activation, so that the product may split K (stream-K: every CU the same share -- the batched form had 24
+  // tiles per batch entry at full K, 1.5 rounds of tiles on half the CUs, and at N = 128 split + zero fill + bias pass); bias and
+  // ReLU are folded into the LayerNorm pass that reads the result anyway (LnFwdFused.pre_bias, written back: the backward's
+  // LayerNorm input and ReLU mask).
+  const RowView c1v = rv(w.c1, L, (long)LP * H), c2v = rv(w.c2, L, (long)LP * E);
   ZTRY(k_pad_rows(w.xp, x, B, L, C, 1, 1, 0, s));
-  ZTRY(k_pack_conv_w(w.wf0, nullptr, P->c0_w, H, C, 3, s));
-  ZTRY(conv_gemm(w.xp, (long)LP * C, C, w.wf0, 3 * C, H, w.c1, H, (long)L * H, P->c0_b, B, L, ACT_RELU, s));
+  const bool fuse0 = H <= 512, fuse = E <= 512;
+  if (fuse0) ZTRY(conv_flat(w.xp, C, w.wf0, 3 * C, H, w.c1, B * LP - 2, s));
+  else ZTRY(conv_gemm(w.xp, (long)LP * C, C, w.wf0, 3 * C, H, w.c1, H, (long)LP * H, P->c0_b, B, L, ACT_RELU, s));
   // LN1 -> interior of padded a1p, dropout, zero edges
-  if (H <= 512) {     // LayerNorm + dropout + the zero edge rows of the next conv's input in one row pass
+  if (fuse0) {     // bias + ReLU + LayerNorm + dropout + the zero edge rows of the next conv's input in one row pass
     LnFwdFused q = ln_fwd_fused_args((int)BL, H, eps);
-    q.x = rv(w.c1); q.y = rv(w.a1p + H, L, (long)LP * H); q.gamma = P->ln0_g; q.beta = P->ln0_b; q.mean = w.m1; q.rstd = w.r1;
+    q.x = c1v; q.pre_bias = P->c0_b; q.pre_act = ACT_RELU;
+    q.y = rv(w.a1p + H, L, (long)LP * H); q.gamma = P->ln0_g; q.beta = P->ln0_b; q.mean = w.m1; q.rstd = w.r1;
     q.p_post = p2; q.seed_post = d.seed + 1; q.pad_L = L;
     ZTRY(k_ln_fwd_fused(q, s));
   } else {
-  ZTRY(k_layernorm_fwd_v(rv(w.a1p + H, L, (long)LP * H), rv(w.c1), rv(nullptr), P->ln0_g, P->ln0_b, w.m1, w.r1,
+  ZTRY(k_layernorm_fwd_v(rv(w.a1p + H, L, (long)LP * H), c1v, rv(nullptr), P->ln0_g, P->ln0_b, w.m1, w.r1,
                           (int)BL, H, eps, s));
   ZTRY(k_dropout_rows(w.a1p + H, (int)BL, H, H, L, (long)LP * H, p2, d.seed + 1, s));
   ZTRY(k_pad_edges(w.a1p, B, L, H, 1, 1, 0, s));
   }
-  ZTRY(k_pack_conv_w(w.wf4, w.wb4, P->c4_w, E, H, 3, s));
-  ZTRY(conv_gemm(w.a1p, (long)LP * H, H, w.wf4, 3 * H, E, w.c2, E, (long)L * E, P->c4_b, B, L, ACT_RELU, s));
-  const bool fuse = E <= 512;
-  if (fuse) {         // h = dropout(LayerNorm(c2)) + positional table
+  if (fuse) ZTRY(conv_flat(w.a1p, H, w.wf4, 3 * H, E, w.c2, B * LP - 2, s));
+  else ZTRY(conv_gemm(w.a1p, (long)LP * H, H, w.wf4, 3 * H, E, w.c2, E, (long)LP * E, P->c4_b, B, L, ACT_RELU, s));
+  if (fuse) {         // h = dropout(LayerNorm(ReLU(c2 + bias))) + positional table
     LnFwdFused q = ln_fwd_fused_args((int)BL, E, eps);
-    q.x = rv(w.c2); q.y = rv(w.h); q.gamma = P->ln1_g; q.beta = P->ln1_b; q.mean = w.m2; q.rstd = w.r2;
+    q.x = c2v; q.pre_bias = P->c4_b; q.pre_act = ACT_RELU;
+    q.y = rv(w.h); q.gamma = P->ln1_g; q.beta = P->ln1_b; q.mean = w.m2; q.rstd = w.r2;
     q.p_post = p2; q.seed_post = d.seed + 2; q.table = pos; q.table_L = L;
     ZTRY(k_ln_fwd_fused(q, s));
   } else {
-  ZTRY(k_layernorm_fwd(w.h, w.c2, nullptr, P->ln1_g, P->ln1_b, w.m2, w.r2, (int)BL, E, eps, s));
+  ZTRY(k_layernorm_fwd_v(rv(w.h), c2v, rv(nullptr), P->ln1_g, P->ln1_b, w.m2, w.r2, (int)BL, E, eps, s));
   ZTRY(k_dropout(w.h, BL * E, p2, d.seed + 2, s));
   ZTRY(k_add_rows_bcast(w.h, pos, B, L, E, s));
   }
@@ -289,14 +312,13 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
   ZTRY(k_pad_edges(w.ap, B, L, E, 1, 1, 0, s));
   }
   // position-wise conv feed-forward
-  ZTRY(k_pack_conv_w(w.wff0, w.wfb0, P->ff0_w, E, E, 3, s));
-  ZTRY(k_pack_conv_w(w.wff2, w.wfb2, P->ff2_w, E, E, 3, s));
   ZTRY(conv_gemm(w.ap, (long)LP * E, E, w.wff0, 3 * E, E, w.f1p + E, E, (long)LP * E, P->ff0_b, B, L, ACT_RELU, s));
   ZTRY(k_pad_edges(w.f1p, B, L, E, 1, 1, 0, s));
-  ZTRY(conv_gemm(w.f1p, (long)LP * E, E, w.wff2, 3 * E, E, w.f2, E, (long)L * E, P->ff2_b, B, L, ACT_NONE, s));
-  if (fuse) {         // f2 = dropout(f2), f = LN(f2 + a)
+  // (ff2's bias: folded into the LayerNorm pass when that is the fused one -- the product then needs no bias pass behind its K split)
+  ZTRY(conv_gemm(w.f1p, (long)LP * E, E, w.wff2, 3 * E, E, w.f2, E, (long)L * E, fuse ? nullptr : P->ff2_b, B, L, ACT_NONE, s));
+  if (fuse) {         // f2 = dropout(f2 + bias), f = LN(f2 + a)
     LnFwdFused q = ln_fwd_fused_args((int)BL, E, eps);
-    q.x = rv(w.f2); q.res = rv(w.ap + E, L, (long)LP * E); q.y = rv(w.f); q.gamma = P->lnf_g; q.beta = P->lnf_b;
+    q.x = rv(w.f2); q.pre_bias = P->ff2_b; q.pre_act = ACT_NONE; q.res = rv(w.ap + E, L, (long)LP * E); q.y = rv(w.f); q.gamma = P->lnf_g; q.beta = P->lnf_b;
     q.mean = w.mf; q.rstd = w.rf; q.p_pre = p1; q.seed_pre = d.seed + 5;
     ZTRY(k_ln_fwd_fused(q, s));
   } else {
@@ -412,8 +434,8 @@ extern "C" int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims* dp, const ZeggsS
   {
     LnBwdFused q = ln_bwd_fused_args((int)BL, E);
     q.dyA = rv(t1); q.dyB = rv(t3); q.p_pre = p2; q.seed_pre = d.seed + 2;
-    q.x = rv(w.c2); q.gamma = P->ln1_g; q.mean = w.m2; q.rstd = w.r2; q.dgamma = G->ln1_g; q.dbeta = G->ln1_b;
-    q.out = t0in; q.pad_L = L; q.ysave = rv(w.c2); q.act = ACT_RELU; q.dbias = G->c4_b;
+    q.x = rv(w.c2, L, (long)LP * E); q.gamma = P->ln1_g; q.mean = w.m2; q.rstd = w.r2; q.dgamma = G->ln1_g; q.dbeta = G->ln1_b;
+    q.out = t0in; q.pad_L = L; q.ysave = rv(w.c2, L, (long)LP * E); q.act = ACT_RELU; q.dbias = G->c4_b;
     ZTRY(k_ln_bwd_fused(q, s));
   }
   ZTRY(conv_dw_gemm(w.a1p, (long)LP * H, H, t0 + E, E, (long)LP * E, w.dwf, 3 * H, E, B, L, s));
@@ -423,8 +445,8 @@ extern "C" int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims* dp, const ZeggsS
   {
     LnBwdFused q = ln_bwd_fused_args((int)BL, H);
     q.dyA = rv(t1); q.p_pre = p2; q.seed_pre = d.seed + 1;
-    q.x = rv(w.c1); q.gamma = P->ln0_g; q.mean = w.m1; q.rstd = w.r1; q.dgamma = G->ln0_g; q.dbeta = G->ln0_b;
-    q.out = rv(t2); q.ysave = rv(w.c1); q.act = ACT_RELU; q.dbias = G->c0_b;
+    q.x = rv(w.c1, L, (long)LP * H); q.gamma = P->ln0_g; q.mean = w.m1; q.rstd = w.r1; q.dgamma = G->ln0_g; q.dbeta = G->ln0_b;
+    q.out = rv(t2); q.ysave = rv(w.c1, L, (long)LP * H); q.act = ACT_RELU; q.dbias = G->c0_b;
     ZTRY(k_ln_bwd_fused(q, s));
   }
   ZTRY(conv_dw_gemm(w.xp, (long)LP * C, C, t2, H, (long)L * H, w.dwf, 3 * C, H, B, L, s));

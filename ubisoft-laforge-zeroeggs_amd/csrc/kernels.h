@@ -37,10 +37,13 @@ struct LnBwdFused {
 };
 LnBwdFused ln_bwd_fused_args(int R, int C);
 // ... and the forward twin: y = (LayerNorm(x * mask(seed_pre) + res) * gamma + beta) * mask(seed_post) + table[row % table_L]
-// in one pass (the masked x is written back when p_pre > 0: the backward's LayerNorm input is the post-dropout tensor);
+// in one pass (the masked x is written back when p_pre > 0: the backward's LayerNorm input is the post-dropout tensor; with pre_bias
+// x is act(x + pre_bias) before anything else, also written back);
 // pad_L > 0: y is the interior of a [B, pad_L + 2, C] buffer whose edge rows are zeroed here.  C <= 512.
 struct LnFwdFused {
   RowView x, res, y;
+  const float* pre_bias;      // != null: x = act(x + pre_bias) first, written back (the bias / activation epilogue of the product that
+  int pre_act;                //          made x, folded into this pass: that product can then split K freely)
   const float *gamma, *beta, *table;
   float *mean, *rstd;
   float p_pre, p_post, eps;
@@ -85,6 +88,10 @@ int k_pad_edges(float* buf, int B, int T, int C, int pl, int pr, int mode, hipSt
 int k_unpad_fold(float* dx, const float* dpad, int B, int T, int C, int pl, int pr, int mode, hipStream_t s);
 // conv weight [Co, Ci, Kw] -> fwd-packed [(j,ci), co] and bwd-packed [(j',co), ci] (flipped taps)
 int k_pack_conv_w(float* wf, float* wb, const float* w, int Co, int Ci, int Kw, hipStream_t s);
+// up to four of them in ONE launch (the style encoder packs its four convolutions at the top of its forward: one dispatch on the
+// serial chain instead of four)
+struct PackConvW { float *wf, *wb; const float* w; int Co, Ci, Kw; };
+int k_pack_conv_w_multi(const PackConvW* items, int n, hipStream_t s);
 // dW[co,ci,j] = dWf[(j,ci), co]
 int k_unpack_conv_dw(float* dw, const float* dwf, int Co, int Ci, int Kw, hipStream_t s);
 // h[b,l,c] += table[l,c]

@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256) void ln_fwd_fused_k(LnFwdFused a) {
     v[j] = 0.f;
     if (c < C) {
       float xv = xr[c];
-      if (a.p_pre > 0.f) { xv *= dropout_scale(a.seed_pre, (uint64_t)((long)row * C + c), a.p_pre); xr[c] = xv; }
+      if (a.pre_bias) xv = d_act(xv + a.pre_bias[c], a.pre_act);
+      if (a.p_pre > 0.f) xv *= dropout_scale(a.seed_pre, (uint64_t)((long)row * C + c), a.p_pre);
+      if (a.pre_bias || a.p_pre > 0.f) xr[c] = xv;
       v[j] = xv + (rr ? rr[c] : 0.f);
       s += v[j];
     }
@@ -256,6 +258,121 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_k(LnBwdFused a, int rows_per
       atomicAdd(a.dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
     }
     if (a.dbias) atomicAdd(a.dbias + c, sc[0][c] + sc[1][c] + sc[2][c] + sc[3][c]);
+  }
+}
+
+// Round 5: the same pass with 16-byte lanes.  The kernel above gives a wave one row at a time with 4-byte lanes (C = 128: two
+// floats per lane, five dependent row visits per wave, a 64-bit division per operand view and row) and ends every block of 16 rows
+// in 3 C atomics: 121 us alone for 12 288 x 128 -- 44 MB that the memory system moves in ~7 us.  Here a row is LPR lanes x VJ
+// float4 (C <= 128: half a wave per row, two rows per wave and pass; C <= 256: a wave, one float4; C <= 512: a wave, two), a block
+// walks its rows in passes of 4 * (64 / LPR) rows with everything of a pass in flight at once, the row statistics are reduced
+// inside the LPR lanes, and the column sums (dgamma, dbeta, dbias) stay in registers over the passes, meet in LDS once and
+// leave as one atomic per column and block (grid ~ 2 blocks per CU).  Row views by 32-bit arithmetic.
+__device__ __forceinline__ float* rv_row32(const RowView& v, unsigned r, int C) {
+  if (v.rpb == 0) return v.p + (size_t)r * C;
+  const unsigned b = r / (unsigned)v.rpb;
+  return v.p + (size_t)b * v.bstride + (size_t)(r - b * (unsigned)v.rpb) * C;
+}
+template <int LPR, int VJ>
+__global__ __launch_bounds__(256) void ln_bwd_fused4_k(LnBwdFused a, int rows_per_block) {
+  constexpr int RPW = 64 / LPR, RPP = 4 * RPW, NE = 4 * VJ, CW = LPR * NE;      // rows per wave / per pass, floats per lane, padded width
+  __shared__ float sred[3][RPP][CW];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sub = lane / LPR, l = lane % LPR, slot = wave * RPW + sub;
+  const int C = a.C, R = a.R;
+  const bool ln = a.gamma != nullptr;
+  float pg[NE], pb[NE], pc[NE], gam[NE];
+  bool cok[VJ];
+#pragma unroll
+  for (int j = 0; j < VJ; ++j) {
+    cok[j] = 4 * (l + LPR * j) < C;
+    const f4 gv = (ln && cok[j]) ? *(const f4*)(a.gamma + 4 * (l + LPR * j)) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gam[4 * j + e] = gv[e]; pg[4 * j + e] = pb[4 * j + e] = pc[4 * j + e] = 0.f; }
+  }
+  const float invC = 1.f / C, dscale = a.dy_pool ? 1.f / a.pool_L : 1.f;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, R);
+  for (int rb = r0; rb < r1; rb += RPP) {
+    const int row = rb + slot;
+    const bool rok = row < r1;
+    const unsigned rr = rok ? row : r1 - 1;          // (idle slots shadow the block's last row: loads stay in bounds, nothing is stored / summed)
+    const float mu = ln ? a.mean[rr] : 0.f, rs = ln ? a.rstd[rr] : 1.f;
+    const float* x = ln ? rv_row32(a.x, rr, C) : nullptr;
+    const float* res = (ln && a.res.p) ? rv_row32(a.res, rr, C) : nullptr;
+    const float* dyA = a.dy_pool ? a.dy_pool + (size_t)(rr / (unsigned)a.pool_L) * C : rv_row32(a.dyA, rr, C);
+    const float* dyB = a.dyB.p ? rv_row32(a.dyB, rr, C) : nullptr;
+    const float* ys = a.ysave.p ? rv_row32(a.ysave, rr, C) : nullptr;
+    float d[NE], xh[NE], g[NE], yv[NE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VJ; ++j) {
+      const int c0 = 4 * (l + LPR * j);
+      f4 va = f4{0.f, 0.f, 0.f, 0.f}, vb = va, vx = va, vr = va, vy = va;
+      if (cok[j]) {
+        va = *(const f4*)(dyA + c0);
+        if (dyB) vb = *(const f4*)(dyB + c0);
+        if (ln) vx = *(const f4*)(x + c0);
+        if (res) vr = *(const f4*)(res + c0);
+        if (ys) vy = *(const f4*)(ys + c0);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * j + e;
+        float dv = va[e] * dscale + vb[e];
+        dv *= dropout_scale(a.seed_pre, (uint64_t)((size_t)rr * C + c0 + e), a.p_pre);
+        d[i] = dv; yv[i] = vy[e];
+        xh[i] = (vx[e] + vr[e] - mu) * rs;
+        g[i] = dv * gam[i];
+        s1 += g[i];
+        s2 += g[i] * xh[i];
+      }
+    }
+    if (ln) {
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      s1 *= invC; s2 *= invC;
+    }
+    float* outr = rv_row32(a.out, rr, C);
+    float* rawr = a.dx_raw.p ? rv_row32(a.dx_raw, rr, C) : nullptr;
+    const int pl = a.pad_L > 0 ? (int)(rr % (unsigned)a.pad_L) : -2;
+#pragma unroll
+    for (int j = 0; j < VJ; ++j) {
+      const int c0 = 4 * (l + LPR * j);
+      f4 vraw, vout;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * j + e;
+        const float dx = ln ? rs * (g[i] - s1 - xh[i] * s2) : d[i];
+        float o = dx * dropout_scale(a.seed_post, (uint64_t)((size_t)rr * C + c0 + e), a.p_post);
+        if (ys) o = a.act == ACT_ELU ? o * d_elu_grad_from_out(yv[i]) : a.act == ACT_RELU ? (yv[i] > 0.f ? o : 0.f) : o;
+        vraw[e] = dx; vout[e] = o;
+        if (rok && cok[j]) {
+          if (ln) { pg[i] += d[i] * xh[i]; pb[i] += d[i]; }
+          pc[i] += o;
+        }
+      }
+      if (rok && cok[j]) {
+        if (rawr) *(f4*)(rawr + c0) = vraw;
+        *(f4*)(outr + c0) = vout;
+        if (pl == 0) *(f4*)(outr + c0 - C) = f4{0.f, 0.f, 0.f, 0.f};      // edge rows of the padded buffer this row sits in
+        if (pl == a.pad_L - 1) *(f4*)(outr + c0 + C) = f4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+  // column sums: registers -> LDS [3][slot][column] -> one atomic per column and block
+#pragma unroll
+  for (int j = 0; j < VJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * (l + LPR * j) + e, i = 4 * j + e;
+      sred[0][slot][c] = pg[i]; sred[1][slot][c] = pb[i]; sred[2][slot][c] = pc[i];
+    }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float tg = 0.f, tb = 0.f, tc = 0.f;
+#pragma unroll
+    for (int q = 0; q < RPP; ++q) { tg += sred[0][q][c]; tb += sred[1][q][c]; tc += sred[2][q][c]; }
+    if (ln) { atomicAdd(a.dgamma + c, tg); atomicAdd(a.dbeta + c, tb); }
+    if (a.dbias) atomicAdd(a.dbias + c, tc);
   }
 }
 
@@ -408,6 +525,22 @@ __global__ void pack_conv_w_k(float* wf, float* wb, const float* w, int Co, int 
   }
 }
 
+struct PackConvW4 { PackConvW it[4]; long end[4]; int n; };
+__global__ void pack_conv_w_multi_k(PackConvW4 q) {
+  GS_LOOP(g, q.end[q.n - 1]) {
+    int k = 0;
+    while (g >= q.end[k]) ++k;
+    const PackConvW& p = q.it[k];
+    const long i = g - (k ? q.end[k - 1] : 0);
+    const int j = (int)(i % p.Kw);
+    const long r = i / p.Kw;
+    const int ci = (int)(r % p.Ci), co = (int)(r / p.Ci);
+    const float v = p.w[i];
+    p.wf[((long)j * p.Ci + ci) * p.Co + co] = v;
+    if (p.wb) p.wb[((long)(p.Kw - 1 - j) * p.Co + co) * p.Ci + ci] = v;
+  }
+}
+
 __global__ void unpack_conv_dw_k(float* dw, const float* dwf, int Co, int Ci, int Kw) {
   long n = (long)Co * Ci * Kw;
   GS_LOOP(i, n) {
@@ -524,10 +657,24 @@ LnBwdFused ln_bwd_fused_args(int R, int C) {
   a.R = R; a.C = C; a.pool_L = 1;
   return a;
 }
+int g_ln_bwd4 = 1;      // zeggs_set_option("ln_bwd4", 0/1): the 16-byte-lane form of the fused LayerNorm backward pass (A/B switch)
+static bool rv_al16(const RowView& v) { return v.p == nullptr || ((((size_t)v.p) & 15) == 0 && (v.rpb == 0 || v.bstride % 4 == 0)); }
 int k_ln_bwd_fused(const LnBwdFused& a, hipStream_t s) {
-  const int rpb = 16;
   ZCHECK(a.C <= 512, "ln_bwd_fused: C=%d > 512 unsupported", a.C);
   ZCHECK(a.out.p != nullptr && (a.dy_pool != nullptr || a.dyA.p != nullptr), "ln_bwd_fused: missing operand");
+  const bool al = a.C % 4 == 0 && rv_al16(a.dyA) && rv_al16(a.dyB) && rv_al16(a.x) && rv_al16(a.res) && rv_al16(a.dx_raw) &&
+                  rv_al16(a.out) && rv_al16(a.ysave) && (((size_t)a.dy_pool) & 15) == 0 && (((size_t)a.gamma) & 15) == 0 &&
+                  a.R > 0 && (long)a.R * a.C < (1L << 31);
+  if (g_ln_bwd4 && al) {
+    // ~512 blocks (2 per CU), whole passes per block
+    auto rows_per_block = [&](int rpp) { const int per = cdiv(a.R, 512); return cdiv(per, rpp) * rpp; };
+    if (a.C <= 128) { const int rpb = rows_per_block(8); hipLaunchKernelGGL((ln_bwd_fused4_k<32, 1>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb); }
+    else if (a.C <= 256) { const int rpb = rows_per_block(4); hipLaunchKernelGGL((ln_bwd_fused4_k<64, 1>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb); }
+    else { const int rpb = rows_per_block(4); hipLaunchKernelGGL((ln_bwd_fused4_k<64, 2>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb); }
+    ZLAUNCH_CHECK("ln_bwd_fused4");
+    return 0;
+  }
+  const int rpb = 16;
   if (a.C <= 128) hipLaunchKernelGGL((ln_bwd_fused_k<2>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb);
   else hipLaunchKernelGGL((ln_bwd_fused_k<8>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb);
   ZLAUNCH_CHECK("ln_bwd_fused");
@@ -595,6 +742,16 @@ int k_unpad_fold(float* dx, const float* dpad, int B, int T, int C, int pl, int 
 int k_pack_conv_w(float* wf, float* wb, const float* w, int Co, int Ci, int Kw, hipStream_t s) {
   long n = (long)Co * Ci * Kw;
   L1D(pack_conv_w_k, n, s, wf, wb, w, Co, Ci, Kw);
+  return 0;
+}
+int k_pack_conv_w_multi(const PackConvW* items, int n, hipStream_t s) {
+  ZCHECK(n >= 1 && n <= 4, "pack_conv_w_multi: %d items", n);
+  PackConvW4 q;
+  memset(&q, 0, sizeof(q));
+  long tot = 0;
+  for (int k = 0; k < n; ++k) { q.it[k] = items[k]; tot += (long)items[k].Co * items[k].Ci * items[k].Kw; q.end[k] = tot; }
+  q.n = n;
+  L1D(pack_conv_w_multi_k, tot, s, q);
   return 0;
 }
 int k_unpack_conv_dw(float* dw, const float* dwf, int Co, int Ci, int Kw, hipStream_t s) {

@@ -54,8 +54,18 @@ inline long stft_frames(long n, int n_fft, int hop) {
 
 // STFT frames m0 .. m0 + gridDim.x - 1.  n = signal length for the reflect rule, n_avail = samples present in `wav`
 // (streaming: n is unknown yet and passed as a huge value; the caller only asks for frames that end before n_avail)
+// The clipped mel amplitude s -> what the reference stores: v = (20 log10 s + range) / range (spectrograms.py:121-129), then
+// data_pipeline.py:62-63 takes ln(10^(v / 20)).  Round 5: that last pair is the affine map v ln(10) / 20 -- the same number to a
+// relative 2e-16 in float64 (the features are float32) -- which halves the float64 transcendentals per mel value (log10 + the exp
+// of the energy instead of log10, pow, log, exp: the kernel is bound by them, not by memory).  zeggs_set_option("mel_exact_log", 1)
+// evaluates the literal chain.
+__device__ __forceinline__ double mel_logamp(double s, double rng, int exact) {
+  const double v = (20.0 * log10(s) + rng) / rng;
+  return exact ? log(pow(10.0, v / 20.0)) : v * (2.302585092994046 / 20.0);
+}
+
 __global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* wav, long n, long n_avail, const double* fb,
-                                                   double* logmel, double* energy, long m0) {
+                                                   double* logmel, double* energy, long m0, int exact) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int NF = d.n_fft, NBIN = NF / 2 + 1;
   double* xw = sm;              // [NF] windowed samples
@@ -97,8 +107,7 @@ __global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* w
     for (int k = 0; k < NBIN; ++k) s = fma(f[k], amp[k], s);
     s = fabs(s);
     if (s < amin) s = amin;
-    const double v = (20.0 * log10(s) + rng) / rng;    // spectrograms.py:121-129
-    const double y = log(pow(10.0, v / 20.0));          // data_pipeline.py:62-63
+    const double y = mel_logamp(s, rng, exact);
     melv[m] = y;
     logmel[slot * d.n_mels + m] = y;
   }
@@ -143,7 +152,7 @@ __host__ __device__ inline size_t mel_fast_lds(int NF, int hop, int n_mels) {
 // (fp64, k in steps of 4) instead of one fma chain per bin.
 __global__ __launch_bounds__(MWAVES * 64) void mel_stft_mfma_k(ZeggsMelDims d, const float* wav, long n, long n_avail,
                                                                 const double* fb, const double* table, const double* wintab,
-                                                                double* logmel, double* energy, long m0, long nfr) {
+                                                                double* logmel, double* energy, long m0, long nfr, int exact) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int NF = d.n_fft, NBIN = NF / 2 + 1, hop = d.hop, NM = d.n_mels;
   const int ns = (MF - 1) * hop + NF;
@@ -244,8 +253,7 @@ __global__ __launch_bounds__(MWAVES * 64) void mel_stft_mfma_k(ZeggsMelDims d, c
     }
     s = fabs(s);
     if (s < amin) s = amin;
-    const double v = (20.0 * log10(s) + rng) / rng;
-    const double y = log(pow(10.0, v / 20.0));
+    const double y = mel_logamp(s, rng, exact);
     melv[it] = y;                                   // (the sample area: the products are done)
     if (slot0 + f < nfr) logmel[(slot0 + f) * NM + m] = y;
   }
@@ -320,7 +328,7 @@ __host__ __device__ inline size_t mel_fft_lds(int NF, int n_mels) {
 
 __global__ __launch_bounds__(FTHR) void mel_stft_fft_k(ZeggsMelDims d, FftPlan plan, const float* wav, long n, long n_avail,
                                                       const double* fb, const c2* __restrict__ TW, const int* bands,
-                                                      const double* fbp, double* logmel, double* energy, long m0, long nfr) {
+                                                      const double* fbp, double* logmel, double* energy, long m0, long nfr, int exact) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int NF = d.n_fft, M = NF / 2, NBIN = M + 1, hop = d.hop, NM = d.n_mels;
   c2* bufA = (c2*)smem;                               // [FFB][M]
@@ -417,8 +425,7 @@ __global__ __launch_bounds__(FTHR) void mel_stft_fft_k(ZeggsMelDims d, FftPlan p
     }
     sacc = fabs(sacc);
     if (sacc < amin) sacc = amin;
-    const double v = (20.0 * log10(sacc) + rng) / rng;
-    const double yv = log(pow(10.0, v / 20.0));
+    const double yv = mel_logamp(sacc, rng, exact);
     const double z = exp(yv);
     melv[it] = z * z;                                 // (every thread its own exp; the frame's thread only adds, in mel order)
     if (slot0 + f < nfr) logmel[(slot0 + f) * NM + m] = yv;
@@ -462,6 +469,7 @@ __global__ void mel_resample_k(ZeggsMelDims d, const double* logmel, const doubl
 }  // namespace
 
 int g_mel_mfma = 1;      // zeggs_set_option("mel_mfma", 0/1): matrix-core DFT / one workgroup per frame, direct DFT (when the FFT form is off)
+int g_mel_exact_log = 0;      // zeggs_set_option("mel_exact_log", 0/1): see mel_logamp
 int g_mel_fft = 1;       // zeggs_set_option("mel_fft", 0/1): the FFT form (default; n_fft / 2 must factor into 4, 5, 2)
 
 // radices of the half-length transform: 4s first, then 5s, then a 2 (400 = 4 4 5 5); nst = 0: not this path
@@ -497,7 +505,7 @@ static int launch_stft(const ZeggsMelDims& d, const MelWs& w, const float* wav, 
     hipLaunchKernelGGL(mel_fft_table_k, dim3(16), dim3(256), 0, s, (c2*)w.ftw, d.n_fft / 2, fb, d.n_mels, w.bands, w.fbp);
     ZLAUNCH_CHECK("mel_fft_table");
     hipLaunchKernelGGL(mel_stft_fft_k, dim3((unsigned)((nfr + FFB - 1) / FFB)), dim3(FTHR), fft_lds, s, d, plan, wav, n, n_avail, fb,
-                       (const c2*)w.ftw, w.bands, w.fbp, w.logmel, w.energy, m0, nfr);
+                       (const c2*)w.ftw, w.bands, w.fbp, w.logmel, w.energy, m0, nfr, g_mel_exact_log);
     ZLAUNCH_CHECK("mel_stft_fft");
     return 0;
   }
@@ -511,12 +519,12 @@ static int launch_stft(const ZeggsMelDims& d, const MelWs& w, const float* wav, 
     hipLaunchKernelGGL(mel_table_k, dim3(1024), dim3(256), 0, s, w.table, w.win, d.n_fft, NBIN);
     ZLAUNCH_CHECK("mel_table");
     hipLaunchKernelGGL(mel_stft_mfma_k, dim3((unsigned)((nfr + MF - 1) / MF)), dim3(MWAVES * 64), fast_lds, s, d, wav, n, n_avail,
-                       fb, w.table, w.win, w.logmel, w.energy, m0, nfr);
+                       fb, w.table, w.win, w.logmel, w.energy, m0, nfr, g_mel_exact_log);
     ZLAUNCH_CHECK("mel_stft_mfma");
     return 0;
   }
   const size_t lds = sizeof(double) * (3 * (size_t)d.n_fft + d.n_fft / 2 + 1 + d.n_mels);
-  hipLaunchKernelGGL(mel_stft_k, dim3((unsigned)nfr), dim3(256), lds, s, d, wav, n, n_avail, fb, w.logmel, w.energy, m0);
+  hipLaunchKernelGGL(mel_stft_k, dim3((unsigned)nfr), dim3(256), lds, s, d, wav, n, n_avail, fb, w.logmel, w.energy, m0, g_mel_exact_log);
   ZLAUNCH_CHECK("mel_stft");
   return 0;
 }

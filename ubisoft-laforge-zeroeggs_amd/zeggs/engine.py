@@ -260,6 +260,16 @@ class TrainEngine:
         self._history = collections.deque(maxlen=8)
         self.recovered_steps = 0
         self.replayed = []                  # (iteration, loss, terms) of steps re-run by _recover(): for the caller's log
+        # Re-arming (round 5).  A give-up is usually a TRANSIENT (a co-tenant held CUs for a while: RCCL kernels on an 8-GPU node,
+        # another process's launch); until round 4 it switched the persistent sweeps off for the life of the process -- a permanent
+        # 1.3x slowdown for one bad moment.  Now the sweeps come back after `rearm_after` clean iterations on the stage kernels
+        # (every rank reaches that iteration together: all ranks skip and replay the same steps, so the schedule needs no extra
+        # exchange); a give-up soon after a re-arm doubles the wait (`rearm_backoff`), up to `rearm_max`.  0 = never re-arm.
+        self.rearm_after = self.REARM_AFTER
+        self._rearm_wait = self.rearm_after
+        self._rearm_at = None               # iteration at which the persistent sweeps are switched back on
+        self._rearmed_at = None             # iteration of the last re-arm (a give-up within `_rearm_wait` of it backs off)
+        self.rearm_count = 0
         import os
         if torch.device(dev).type == "cuda" and not os.environ.get("ZEGGS_NO_GUARD"):     # (env: A/B measurement of its cost)
             self.status = ops.new_status(dev)
@@ -321,6 +331,20 @@ class TrainEngine:
         self._prefetched = ((np.asarray(idx).tobytes(), ex_len), b, ev)
 
     STATUS_LAG = 3       # iterations between a step and the host's look at its skip counter (identical on every rank)
+    REARM_AFTER = 200    # clean stage-kernel iterations before the persistent sweeps are tried again (rearm_after; 0: never)
+    REARM_MAX = 20000
+
+    def _maybe_rearm(self):
+        """Top of a (non-replay) step: switch the persistent sweeps back on when their probation is over.  The library
+        re-validates a re-enabled kernel on its first launch (zeggs_set_option: state -1), and a give-up of that launch is
+        handled like any other (skipped on the device, replayed)."""
+        if self._rearm_at is None or self.iteration < self._rearm_at:
+            return
+        self._rearm_at = None
+        self._rearmed_at = self.iteration
+        self.rearm_count += 1
+        ops.set_option("train_persistent", 1)
+        ops.set_option("bwd_persistent", 1)
 
     def _post_status(self):
         """After the optimizer step: copy the status words to a pinned slot (asynchronous) for the look STATUS_LAG steps on."""
@@ -350,9 +374,17 @@ class TrainEngine:
         torch.cuda.synchronize()
         st = self.status.cpu()
         bits, n = int(st[0]), int(st[1])
+        if self.rearm_after > 0:
+            # probation: back on after `_rearm_wait` clean iterations; a give-up that follows a re-arm closely doubles the wait
+            if self._rearmed_at is not None and self.iteration - n - self._rearmed_at <= self._rearm_wait:
+                self._rearm_wait = min(2 * self._rearm_wait, self.REARM_MAX)
+            else:
+                self._rearm_wait = self.rearm_after
+            self._rearm_at = self.iteration - n + self._rearm_wait      # (counted from the first lost step: the same on every rank)
         warnings.warn(f"zeggs: persistent sweep gave up on this rank: {[v for b, v in ops.GAVE_UP.items() if bits & b]}; "
                       f"{n} optimizer step(s) were skipped on the device and are re-run on the stage kernels "
-                      "(train_persistent / bwd_persistent disabled for this process)")
+                      "(train_persistent / bwd_persistent off"
+                      + (f", back on after {self._rearm_wait} clean iterations)" if self.rearm_after > 0 else " for this process)"))
         ops.set_option("train_persistent", 0)
         ops.set_option("bwd_persistent", 0)
         ops.fill_(self.status.view(torch.float32))
@@ -393,6 +425,7 @@ class TrainEngine:
         """One training iteration on window indices `idx` (this rank's slice). Returns the loss tensor (device)."""
         if self.status is not None and not _replay:
             self._check_status()
+            self._maybe_rearm()
             self._history.append(dict(idx=np.array(idx, copy=True), example_len=example_len, eps=eps, labels=labels,
                                       seed_state=copy.deepcopy(self.ctx.rng().bit_generator.state)))
         ds, T = self.ds, self.ds.window
