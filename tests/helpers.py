@@ -161,3 +161,51 @@ def width512_inputs(gd):
     gen = torch.Generator().manual_seed(int(gd["weight_seed"]))
     wts = [torch.randn(tuple(gd["O_" + n].shape), generator=gen) for n in names]
     return first, W["Y_gaze_pos"], wts
+
+
+# ----------------------------------------------------------------------------- iteration 1 of train_iter.npz (round 5)
+POSE_SPLIT = (3, 3, 225, 450, 225, 225)       # root_vel, root_vrt, lpos, ltxy, lvel, lvrt in the packed pose row
+
+
+def unpack_pose(pose):
+    """[B, T, 1131] packed decoder output -> (root_vel, root_vrt, lpos, ltxy, lvel, lvrt) in the reference's shapes."""
+    B, T = pose.shape[:2]
+    vel, vrt, lpos, ltxy, lvel, lvrt = torch.split(pose, POSE_SPLIT, dim=-1)
+    return vel, vrt, lpos.reshape(B, T, 75, 3), ltxy.reshape(B, T, 75, 2, 3), lvel.reshape(B, T, 75, 3), lvrt.reshape(B, T, 75, 3)
+
+
+def grads_at_forward_point(g, it, state_dicts, O_point, kl_iteration=None):
+    """The float64 arbiter for an iteration whose loss gradient is ill-conditioned in the FORWARD POINT (train_iter.npz,
+    iteration 1: one root joint's predicted x / y axes are 0.86 degrees from antiparallel, so d loss / d output ~ 1 / |x cross y| and
+    an output deviation of 5e-6 -- float32 forward rounding -- moves the length of the WHOLE gradient by 0.5 %: measured on the
+    reference itself, oracle/make_golden.py: gold_train_iter_perturb and DESIGN.md section 4).  An fp32 implementation cannot be
+    held to the fp64 gradient at the fp64 forward point closer than the reference's own fp32 run is; it CAN be held to
+
+        G* = J64(theta)^T . grad_O loss64(O_point)          (+ the KL path through mu, logvar)
+
+    i.e. the float64 network Jacobian applied to the float64 loss gradient evaluated AT THE IMPLEMENTATION'S OWN OUTPUTS O_point.
+    state_dicts: (speech, decoder, style) float32 state dicts = the weights the implementation ran the iteration with;
+    O_point: its 8 decoder outputs (root_pos, root_rot, root_vel, root_vrt, lpos, ltxy, lvel, lvrt), any float dtype.
+    Returns (list of float64 gradient tensors in the reference optimizer's parameter order, float64 outputs of the oracle,
+    float64 loss gradient w.r.t. the outputs at O_point)."""
+    from oracle import loss as oloss
+    from oracle import nets as onets
+    from zeggs import synth
+    dt = torch.float64
+    s = {k: v.to(dt) for k, v in stats_tensors().items()}
+    ws = [{k: v.detach().cpu().to(dt).clone().requires_grad_(True) for k, v in w.items()} for w in state_dicts]
+    b = [torch.as_tensor(g[f"it{it}_batch{j}"]).to(dt) for j in range(11)]
+    audio, rpos, rrot, rvel, rvrt, lpos, ltxy, lvel, lvrt, gaze, wstyle = b
+    speech = onets.speech_encoder(ws[0], (audio - s["a_mean"]) / s["a_std"])
+    z, mu, logvar = onets.style_encoder(ws[2], (wstyle - s["in_mean"]) / s["in_std"], torch.as_tensor(g[f"it{it}_eps"]).to(dt))
+    T = audio.shape[1]
+    O64 = onets.decoder_rollout(ws[1], rpos[:, 0], rrot[:, 0], rvel[:, 0], rvrt[:, 0], lpos[:, 0], ltxy[:, 0], lvel[:, 0],
+                                lvrt[:, 0], gaze, speech, z.unsqueeze(1).repeat(1, T, 1), s["in_mean"], s["in_std"],
+                                s["out_mean"], s["out_std"], synth.DT)
+    Oe = [o.detach().cpu().to(dt).reshape(r.shape).clone().requires_grad_(True) for o, r in zip(O_point, O64)]
+    loss_e, _ = oloss.training_loss(Oe, (rpos, rrot, rvel, rvrt, lpos, ltxy, lvel, lvrt), gaze, synth.PARENTS, synth.DT, mu,
+                                    logvar, iteration=it if kl_iteration is None else kl_iteration)
+    g_e = torch.autograd.grad(loss_e, Oe, retain_graph=True)
+    (loss_e + sum((o * ge.detach()).sum() for o, ge in zip(O64, g_e))).backward()
+    grads = [v.grad if v.grad is not None else torch.zeros_like(v) for w in (ws[0], ws[1], ws[2]) for v in w.values()]
+    return grads, [o.detach() for o in O64], [x.detach() for x in g_e]

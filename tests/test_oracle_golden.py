@@ -236,3 +236,79 @@ def test_oracle_width512_vs_reference(golden_dir):
         ref = torch.as_tensor(g[k])
         assert float((got - ref).abs().max()) < 1e-4 * float(ref.abs().max()), k
     helpers.assert_grad_samples(g, "decoder", [(k, v.grad) for k, v in wd.items() if v.grad is not None], 1e-4)
+
+
+def test_iteration1_conditioning_and_the_forward_point_arbiter(golden_dir):
+    """VERDICT r4 item 4.  (a) The measured answer to "does the REFERENCE spread by percent at iteration 1 of train_iter.npz":
+    no -- ten 1e-7-relative perturbations of its fp32 inputs move its gradient length by < 3e-4 (train_iter_perturb.npz), while
+    its fp32 run sits a STABLE 0.08-0.7 % above its own fp64 run; the fp64 run on the same perturbed inputs moves by ~1e-4: the
+    iteration amplifies input changes ~1000x but is not chaotic.  (b) Where the 0.5 % comes from: ONE joint (batch row 1, frame 4,
+    root joint) whose predicted x / y axes are nearly antiparallel -- the loss gradient through xform_orthogonalize_from_xy
+    (anim/txform.py:23-34) scales with 1 / |x cross y| there and dominates the whole gradient, so the fp32 forward's 5e-6 output error
+    re-scales every parameter gradient.  (c) Hence the arbiter the GPU tests use (helpers.grads_at_forward_point): the fp64
+    Jacobian applied to the fp64 loss gradient at the implementation's OWN outputs.  Checked here with the fp32 oracle in the
+    implementation's seat: against the fp64 gradients at the fp64 point it is percent-level off, against the arbiter 2e-4."""
+    g, g64 = np.load(golden_dir / "train_iter.npz"), np.load(golden_dir / "train_iter_fp64.npz")
+    pt = np.load(golden_dir / "train_iter_perturb.npz")
+    # (a) the reference's own spread under input perturbation, recorded from the unmodified reference
+    assert pt["ratio32"].shape[0] >= 10
+    spread = pt["ratio32"].max(axis=0) - pt["ratio32"].min(axis=0)            # per tensor, over the seeds
+    assert spread.max() < 5e-4, spread.max()
+    assert 1.0005 < pt["base_ratio"].min() and pt["base_ratio"].max() < 1.008  # stable fp32 bias: 0.08 .. 0.7 % long
+    assert np.abs(pt["ratio64"] - 1.0).max() < 3e-4 and pt["cosd32"].max() < 1e-5
+    # iteration 0 in fp32 (the "implementation"), full RAdam step, iteration 1
+    nets = helpers.build_nets()
+    s = helpers.stats_tensors()
+    _, _, ws0 = _oracle_iteration(g, 0, nets, s, torch.float32)
+    for m, w in zip(nets, ws0):
+        sdm = m.state_dict()
+        for k, v in w.items():
+            pn, gn = v.detach().numpy().copy(), v.grad.numpy()
+            oradam.radam_step(pn, gn, np.zeros_like(pn), np.zeros_like(pn), 1, 1e-4, 1e-5)
+            sdm[k].copy_(torch.as_tensor(pn))
+    # the weights iteration 1 starts from = the reference's (samples): 3e-7
+    w1 = np.concatenate([p.detach().flatten()[helpers.sample_idx(p.numel())].numpy() for m in nets for p in m.parameters()])
+    np.testing.assert_allclose(w1, g["it0_weight_samples"], atol=3e-7)
+    # the implementation's iteration 1 (outputs + gradients)
+    b = [torch.as_tensor(g[f"it1_batch{j}"]) for j in range(11)]
+    audio, rpos, rrot, rvel, rvrt, lpos, ltxy, lvel, lvrt, gaze, wstyle = b
+    ws = [helpers.sd(m) for m in nets]
+    for w in ws:
+        for v in w.values():
+            v.requires_grad_(True)
+    speech = onets.speech_encoder(ws[0], (audio - s["a_mean"]) / s["a_std"])
+    z, mu, logvar = onets.style_encoder(ws[2], (wstyle - s["in_mean"]) / s["in_std"], torch.as_tensor(g["it1_eps"]))
+    T = audio.shape[1]
+    O = onets.decoder_rollout(ws[1], rpos[:, 0], rrot[:, 0], rvel[:, 0], rvrt[:, 0], lpos[:, 0], ltxy[:, 0], lvel[:, 0],
+                              lvrt[:, 0], gaze, speech, z.unsqueeze(1).repeat(1, T, 1), s["in_mean"], s["in_std"],
+                              s["out_mean"], s["out_std"], synth.DT)
+    loss, _ = oloss.training_loss(O, (rpos, rrot, rvel, rvrt, lpos, ltxy, lvel, lvrt), gaze, synth.PARENTS, synth.DT, mu,
+                                  logvar, iteration=1)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), g["loss"][1], rtol=2e-5)
+    got = [v.grad for w in ws for v in w.values()]
+    # (b) the degenerate joint
+    x, y = O[5][1, 4, 0, 0].detach().double(), O[5][1, 4, 0, 1].detach().double()
+    cosxy = float(torch.dot(x, y) / (x.norm() * y.norm()))
+    assert cosxy < -0.9995, cosxy
+    # (c) the arbiter
+    Gs, O64, gO = helpers.grads_at_forward_point(g, 1, [helpers.sd(m) for m in nets], [o.detach() for o in O])
+    share = float(gO[5][1, 4, 0].norm() / torch.cat([x.flatten() for x in gO]).norm())
+    assert share > 0.85, share                    # that one joint carries the loss gradient
+    assert max(float((a.detach().double() - b_).abs().max()) for a, b_ in zip(O, O64)) < 1e-4
+    off, worst_arb, worst64, ratios = 0, 0.0, 0.0, []
+    ref64 = g64["it1_grad_samples64"]
+    for a, r in zip(got, Gs):
+        idx = helpers.sample_idx(a.numel())
+        scale = max(1e-12, float(r.abs().max()))
+        worst_arb = max(worst_arb, float((a.double() - r).abs().max()) / scale)
+        a_s, r_s = a.flatten()[idx].double().numpy(), ref64[off:off + len(idx)]
+        worst64 = max(worst64, float(np.abs(a_s - r_s).max()) / max(1e-12, float(np.abs(r_s).max())))
+        ratios.append(np.linalg.norm(a_s) / max(1e-300, np.linalg.norm(r_s)))
+        off += len(idx)
+    assert off == len(ref64)
+    print(f"\niteration 1, fp32 oracle: vs fp64 at the fp64 point {worst64:.2e} of max|g| (length ratio {min(ratios):.4f} .. "
+          f"{max(ratios):.4f}); vs the forward-point arbiter {worst_arb:.2e}; cos(x, y) of joint (1, 4, 0) = {cosxy:.6f}; its share "
+          f"of |dL/dO| = {share:.3f}")
+    assert worst_arb < 5e-4, worst_arb
+    assert worst64 > 5 * worst_arb                # the fp64-point comparison is the ill-conditioned one

@@ -12,6 +12,7 @@
 // Tiles are staged global -> registers -> LDS (k-major, so MFMA operand reads are
 // conflict-free ds_read_b32 of 32 consecutive floats) and the next tile's global
 // loads are in flight while the current one feeds the MFMAs.
+#include <type_traits>
 #include "common.h"
 #include "gemm.h"
 #include "kernels.h"
@@ -547,6 +548,185 @@ int launch_tn_dma(GemmArgs g, hipStream_t s) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: stream-K TN product WITHOUT LDS and WITHOUT barriers ("direct" form).  v_mfma_f32_32x32x2_f32 takes 64 cycles and one
+// float per lane and operand, and in a TN product (weight gradients: A(m,k) = dy[k][m], B(k,n) = x[k][n], both rows contiguous)
+// that float is row 2 kp + (lane >> 5), column tile + (lane & 31) of the operand as it lies in memory: ONE coalesced
+// global_load_dword per operand fragment (two full 128-byte segments per wave-instruction), no transposition, no staging.  At the
+// fp32 matrix rate a CU consumes ~16 bytes per clock of such loads (0.75 loads per product with 128 x 64 wave tiles) -- a quarter
+// of what its L1 delivers -- so the operands can be fed from L1 / L2 directly, a few k-pairs ahead in registers, and the waves
+// of a workgroup never wait for each other: no s_barrier per k-tile (the LDS-tiled kernel above loses 0.22-0.37 of the matrix-pipe
+// cycles with the four co-resident workgroups of a CU in lockstep around their barriers: profiles/r04_gemm_mfma_util.json), no
+// LDS write pass, no alignment conditions (4-byte loads).  The 2 x 2 waves of a workgroup still share a (2 * 32 MT) x (2 * 32 NT) tile so
+// that the wave pairs that read the same A / B fragments hit the CU's L1.  Stream-K as above: equal contiguous ranges of the
+// (tile, k-chunk) space per workgroup, partial tiles combined by fp32 atomics onto the zeroed / accumulating C.  K even.
+template <int MT, int NT, int D>
+__global__ __launch_bounds__(256, 2) void gemm_tn_direct_kernel(GemmArgs g, int tiles_x, int tiles_y, int chunks_per_batch) {
+  constexpr int CH = 8;                                        // k-pairs per chunk of the stream-K iteration space
+  constexpr int BM = 64 * MT, BN = 64 * NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+  const int kh = lane >> 5, l31 = lane & 31;
+  const int kt = chunks_per_batch * g.kbatch;                  // chunks of one output tile
+  const long total = (long)tiles_x * tiles_y * kt;
+  const unsigned nwg = gridDim.x, w = blockIdx.x, xcd = w & 7, idx = w >> 3, q = nwg >> 3, r = nwg & 7;
+  const unsigned wl = xcd * q + (xcd < r ? xcd : r) + idx;
+  long it = total * wl / nwg;
+  const long it_end = total * (wl + 1) / nwg;
+  const int npairs = g.K >> 1;                                 // per batch segment
+  while (it < it_end) {
+    const int tile = (int)(it / kt), c0 = (int)(it % kt);
+    const long left = it_end - it;
+    const int c1 = (long)(kt - c0) < left ? kt : c0 + (int)left;
+    constexpr int GM = 4;
+    const int width = GM * tiles_x, group = tile / width, first = group * GM, gsz = tiles_y - first < GM ? tiles_y - first : GM;
+    const int m_base = (first + (tile % width) % gsz) * BM + wm * 32 * MT, n_base = ((tile % width) / gsz) * BN + wn * 32 * NT;
+    int mo[MT], no[NT];                                        // this lane's column of every fragment (clamped: duplicates are not stored)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { const int m = m_base + 32 * i + l31; mo[i] = m < g.M ? m : g.M - 1; }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { const int n = n_base + 32 * j + l31; no[j] = n < g.N ? n : g.N - 1; }
+    unsigned voa[MT], vob[NT];                                // byte offsets of this lane's operand entries within a k-pair's two rows
+#pragma unroll
+    for (int i = 0; i < MT; ++i) voa[i] = (unsigned)(((long)mo[i] + (long)kh * g.sak) * 4);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) vob[j] = (unsigned)(((long)no[j] + (long)kh * g.sbk) * 4);
+    f16v acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // the chunk range [c0, c1) batch segment by batch segment
+    int c = c0;
+    while (c < c1) {
+      const int kb = c / chunks_per_batch, cb = c - kb * chunks_per_batch;
+      int ce = c1 - kb * chunks_per_batch;
+      ce = ce < chunks_per_batch ? ce : chunks_per_batch;
+      const int p0 = cb * CH, p1 = ce * CH < npairs ? ce * CH : npairs, n = p1 - p0;
+      // operand addresses = wave-uniform row base (SGPR pair, advanced per pair) + this lane's 32-bit byte offset (column, k-half):
+      // one VGPR per fragment instead of a 64-bit pointer each
+      const float* Ab = g.A + (long)kb * g.kbsA + (long)(2 * p0) * g.sak;
+      const float* Bb = g.B + (long)kb * g.kbsB + (long)(2 * p0) * g.sbk;
+      const long a2 = 2 * g.sak, b2 = 2 * g.sbk;
+      float ra[D][MT], rb[D][NT];
+      // The refills are inline-asm loads: the compiler's own wait insertion cannot count loads across the loop's back edge (it
+      // emits vmcnt(0) at the top of every iteration: the whole refill latency in the open per D pairs); these it does not see,
+      // and the waits are placed by hand: at the products of slot u the D - 1 younger refill groups stay in flight
+      // (cdna_hip_programming.md section 5.7, form (ii): "=v" loads, then a wait statement that names every destination "+v").
+      auto fetch = [&](int slot, int pair) {
+        const unsigned long long ap = (unsigned long long)(Ab + (long)pair * a2), bp = (unsigned long long)(Bb + (long)pair * b2);
+        const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)ap), ahi = __builtin_amdgcn_readfirstlane((unsigned)(ap >> 32));
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bp), bhi = __builtin_amdgcn_readfirstlane((unsigned)(bp >> 32));
+        const unsigned long long as = ((unsigned long long)ahi << 32) | alo, bs = ((unsigned long long)bhi << 32) | blo;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("global_load_dword %0, %1, %2" : "=v"(ra[slot][i]) : "v"(voa[i]), "s"(as) : "memory");
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("global_load_dword %0, %1, %2" : "=v"(rb[slot][j]) : "v"(vob[j]), "s"(bs) : "memory");
+      };
+      // the loads of slot S have landed; Y (a constant) later ones may still fly
+#define ZG_LANDED(S, Y)                                                                                                       \
+  do {                                                                                                                         \
+    if constexpr (MT == 4)                                                                                                     \
+      asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[S][0]), "+v"(ra[S][1]), "+v"(ra[S][MT > 2 ? 2 : 0]), "+v"(ra[S][MT > 3 ? 3 : 1]), \
+                   "+v"(rb[S][0]), "+v"(rb[S][1]) : "n"(Y) : "memory");                                                       \
+    else                                                                                                                       \
+      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[S][0]), "+v"(ra[S][1]), "+v"(rb[S][0]), "+v"(rb[S][1]) : "n"(Y) : "memory"); \
+  } while (0)
+      static_assert((MT == 4 || MT == 2) && NT == 2, "direct kernel: wave tiles 128 x 64 and 64 x 64");
+      constexpr int LG = MT + NT;                                // loads per refill group
+      auto mma = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[slot][i], rb[slot][j], acc[i][j], 0, 0, 0);
+      };
+#pragma unroll
+      for (int u = 0; u < D; ++u)
+        if (u < n) fetch(u, u);
+      int p = 0;
+      for (; p + 2 * D <= n; p += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+          ZG_LANDED(u, (D - 1) * LG);
+          mma(u);
+          __builtin_amdgcn_sched_barrier(0);      // (keeps the refill behind its slot's products and ahead of the next slot's)
+          fetch(u, p + u + D);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // the last < 2 D pairs: everything in flight lands, one guarded refill round, the rest
+#pragma unroll
+      for (int u = 0; u < D; ++u) ZG_LANDED(u, 0);
+#pragma unroll
+      for (int u = 0; u < D; ++u)
+        if (p + u < n) {
+          mma(u);
+          if (p + u + D < n) { fetch(u, p + u + D); ZG_LANDED(u, 0); }
+        }
+      p += D;
+#pragma unroll
+      for (int u = 0; u < D; ++u)
+        if (p + u < n) mma(u);
+#undef ZG_LANDED
+      c = (kb + 1) * chunks_per_batch < c1 ? (kb + 1) * chunks_per_batch : c1;
+    }
+    // partial sums -> fp32 atomics onto C (D layout of 32x32x2: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5))
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int nn = n_base + 32 * j + l31;
+        if (nn >= g.N) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m_base + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * kh;
+          if (m < g.M) atomicAdd(g.C + (long)m * g.scm + nn, g.alpha * acc[i][j][e]);
+        }
+      }
+    it += c1 - c0;
+  }
+}
+// NOTE on the operand roles above: the matrix instruction computes D[m][n] += A[m][k] B[k][n] with lane = (k-half, m) for A and
+// (k-half, n) for B, and D's lane index is the COLUMN n -- the A fragment's lane index is its row.  A(m, k) = A[k * sak + m]
+// is what `ap[mo[i]]` reads for lane (kh, l31): row 2 pair + kh, column m.
+int g_gemm_direct = 1;         // zeggs_set_option("gemm_direct", v): 0 off (the LDS-tiled stream-K kernel), 1 on (wave tile by output size),
+                               // 2 / 3: always the 128 x 64 / the 64 x 64 wave tile (A/B), 5: only the small / batch-reduce products (what
+                               // zeggs.engine.TrainEngine sets when it runs its three-stream schedule: see direct_ok)
+int g_gemm_direct_depth = 4;   // zeggs_set_option("gemm_direct_depth", 4 / 6 / 8): k-pairs of operands in flight per wave
+int g_gemm_direct_wgs = 0;     // zeggs_set_option("gemm_direct_wgs", n): workgroups per CU (0: 1 for the 128 x 64 wave tile, 2 for 64 x 64)
+bool direct_ok(const GemmArgs& g) {
+  // 5: only the products of the encoders' backward chains (batch-reduce convolution weight gradients, small outputs): they run
+  // BESIDE the decoder's resident LDS-tiled stream-K workgroups (101 VGPRs x 4 per SIMD, 135 of 160 KB LDS), where a kernel that
+  // needs no LDS and <= 108 VGPRs is the one that still gets a wave per SIMD
+  if (g_gemm_direct == 5 && !(g.kbatch > 1 || (long)g.M * g.N < 400000)) return false;
+  return g_gemm_direct && g.sam == 1 && g.sbn == 1 && g.scn == 1 && g.K % 2 == 0 && g.K >= 64 && g.M >= 64 && g.N >= 64 &&
+         ((long)g.M + g.sak) * 4 < (1L << 31) && ((long)g.N + g.sbk) * 4 < (1L << 31);
+}
+// Measured (tools/gemm_direct_probe.py, TFLOP/s incl. the zero fill of C; LDS-tiled stream-K kernel -> direct): dW_hh 3072 x 1024 x 8160
+// 95.5 -> 134.9, dW_ih0 3072 x 2286 108.4 -> 134.9, dW_l2 1131 x 1024 97.6 -> 117.7, dW_l0 1024 x 1262 94.5 -> 113.0, style conv0
+// dW 3402 x 512 x 12288 107.3 -> 128.1, 4096^3 124.6 -> 140.8.  Big outputs (>= 384 tiles of 128 x 128) take the 128 x 64 wave
+// tile with one workgroup per CU (fewer operand bytes per product), the others 64 x 64 wave tiles, two workgroups per CU (finer
+// grain at the ends of the stream-K ranges).
+int launch_tn_direct(GemmArgs g, hipStream_t s) {
+  const bool big = g_gemm_direct == 2 || (g_gemm_direct == 1 && (long)cdiv(g.M, 128) * cdiv(g.N, 128) >= 384);      // (3, 5: 64 x 64)
+  const int mt = big ? 4 : 2, nt = 2;
+  const int tx = cdiv(g.N, 64 * nt), ty = cdiv(g.M, 64 * mt);
+  const int cpb = cdiv(g.K / 2, 8);
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  long nwg = (long)ncu * (g_gemm_direct_wgs > 0 ? g_gemm_direct_wgs : (big ? 1 : 2));
+  const long total = (long)tx * ty * cpb * g.kbatch;
+  if (nwg > total / 4) nwg = total / 4 > 0 ? total / 4 : 1;     // at least 4 chunks (64 k) per workgroup
+  const int dep = g_gemm_direct_depth;
+#define ZG_DIRECT(MT_, D_) hipLaunchKernelGGL((gemm_tn_direct_kernel<MT_, 2, D_>), dim3((unsigned)nwg), dim3(256), 0, s, g, tx, ty, cpb)
+  if (mt == 4) { if (dep >= 8) ZG_DIRECT(4, 8); else if (dep >= 6) ZG_DIRECT(4, 6); else ZG_DIRECT(4, 4); }
+  else { if (dep >= 8) ZG_DIRECT(2, 8); else if (dep >= 6) ZG_DIRECT(2, 6); else ZG_DIRECT(2, 4); }
+#undef ZG_DIRECT
+  ZLAUNCH_CHECK("gemm_tn_direct");
+  return 0;
+}
+
 #ifndef ZEGGS_GEMM_SK256
 #define ZEGGS_GEMM_SK256 2      // 2: by output size (default)
 #endif
@@ -573,6 +753,7 @@ int launch_streamk_cfg(GemmArgs g, hipStream_t s) {
   return 0;
 }
 int launch_streamk(GemmArgs g, hipStream_t s) {
+  if (direct_ok(g)) return launch_tn_direct(g, s);
   if (dma_ok(g)) return launch_tn_dma(g, s);
   // 256 x 128 tiles (8 waves, 2 workgroups per CU: 3/4 of the operand bytes per product) pay on the big outputs only: +5 .. +8 %
   // on dW_ih0 (432 tiles of 128 x 128), -4 .. -6 % at 72 .. 200 tiles where the coarser grain costs balance
@@ -711,6 +892,8 @@ SkinnyArgs skinny_args(const GemmArgs& g) {
 }  // namespace
 
 void zeggs_gemm_set_dma(int on) { g_gemm_dma = on; }
+void zeggs_gemm_set_direct(int mode, int wgs) { if (mode >= 0) g_gemm_direct = mode; if (wgs >= 0) g_gemm_direct_wgs = wgs; }
+void zeggs_gemm_set_direct_depth(int d) { g_gemm_direct_depth = d; }
 int g_gemm_skinny = 1;          // zeggs_set_option("gemm_skinny", 0/1): batch-sized NT products in one launch
 int g_gemm_streamk = 1;        // zeggs_set_option("gemm_streamk", 0/1): stream-K instead of the many-workgroup split-K
 int g_gemm_mid_split = 1;      // zeggs_set_option("gemm_mid_split", 0/1): split K of the latency-bound narrow-output products

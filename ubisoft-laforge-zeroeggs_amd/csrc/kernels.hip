@@ -285,9 +285,11 @@ __global__ __launch_bounds__(256) void ln_bwd_fused4_k(LnBwdFused a, int rows_pe
 #pragma unroll
   for (int j = 0; j < VJ; ++j) {
     cok[j] = 4 * (l + LPR * j) < C;
-    const f4 gv = (ln && cok[j]) ? *(const f4*)(a.gamma + 4 * (l + LPR * j)) : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { gam[4 * j + e] = gv[e]; pg[4 * j + e] = pb[4 * j + e] = pc[4 * j + e] = 0.f; }
+    for (int e = 0; e < 4; ++e) {      // (gamma is a view into the flat parameter buffer: 4-byte aligned only)
+      gam[4 * j + e] = (ln && cok[j]) ? a.gamma[4 * (l + LPR * j) + e] : 0.f;
+      pg[4 * j + e] = pb[4 * j + e] = pc[4 * j + e] = 0.f;
+    }
   }
   const float invC = 1.f / C, dscale = a.dy_pool ? 1.f / a.pool_L : 1.f;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, R);
@@ -663,7 +665,7 @@ int k_ln_bwd_fused(const LnBwdFused& a, hipStream_t s) {
   ZCHECK(a.C <= 512, "ln_bwd_fused: C=%d > 512 unsupported", a.C);
   ZCHECK(a.out.p != nullptr && (a.dy_pool != nullptr || a.dyA.p != nullptr), "ln_bwd_fused: missing operand");
   const bool al = a.C % 4 == 0 && rv_al16(a.dyA) && rv_al16(a.dyB) && rv_al16(a.x) && rv_al16(a.res) && rv_al16(a.dx_raw) &&
-                  rv_al16(a.out) && rv_al16(a.ysave) && (((size_t)a.dy_pool) & 15) == 0 && (((size_t)a.gamma) & 15) == 0 &&
+                  rv_al16(a.out) && rv_al16(a.ysave) && (((size_t)a.dy_pool) & 15) == 0 &&
                   a.R > 0 && (long)a.R * a.C < (1L << 31);
   if (g_ln_bwd4 && al) {
     // ~512 blocks (2 per CU), whole passes per block

@@ -224,6 +224,13 @@ class TrainEngine:
         # the decoder's weight-gradient GEMMs on the library's second stream, beside the encoders' backward
         on_gpu = overlap_wgrads and torch.device(dataset.device).type == "cuda"
         self.wgrad_stream = ops.side_stream(dataset.device) if on_gpu else None
+        if on_gpu and "gemm_direct" not in ops._OPTIONS:
+            # Three queues share the chip in the iteration's tail: there the barrier-free stream-K product (gemm.hip:
+            # gemm_tn_direct_kernel, +25-40 % on a weight-gradient product that has the chip to itself) is kept for the encoders'
+            # chain products only -- the decoder's weight gradients stay on the LDS-tiled kernel, whose resident workgroups shield
+            # them from the other queues (measured: 17.3 ms per iteration either way with mode 5, 17.6-18.4 ms with the direct
+            # kernel everywhere; single-stream schedule 18.1 -> 17.8 ms with it: profiles/r05_gemm_direct_ab.txt)
+            ops.set_option("gemm_direct", 5)
         # the speech encoder (a short chain of small launches, forward and -- autograd replays a node on the stream of its
         # forward -- backward) beside the style encoder
         self.aux_stream = torch.cuda.Stream(device=dataset.device) if on_gpu else None
