@@ -129,7 +129,11 @@ def test_reference_train_loop_runs_on_dropin_modules(golden_dir, tmp_path, monke
     npz, jsn = tmp_path / "data" / "processed_data.npz", tmp_path / "data" / "data_definition.json"
     np.savez(npz, **data)
     json.dump(synth.data_definition(), open(jsn, "w"))
-    rec = dict(loss=[], grads=[], weights=[])
+    rec = dict(loss=[], grads=[], weights=[], full_grads=[], sd=[], outs=[])
+
+    def capture(mod, args, out):      # what the decoder returned and the weights it ran with, per iteration (the arbiter's inputs)
+        if isinstance(mod, zmod.Decoder) and torch.is_grad_enabled() and len(rec["outs"]) == state["it"]:
+            rec["outs"].append([o.detach().cpu() for o in out])
 
     class ReplayDL:          # the recorded batches of the fixture run (the reference's DataLoader shuffles with the global RNG)
         def __init__(self, ds, **kw):
@@ -150,6 +154,8 @@ def test_reference_train_loop_runs_on_dropin_modules(golden_dir, tmp_path, monke
 
     def rec_step(self, closure=None):
         ps = [p for grp in self.param_groups for p in grp["params"]]
+        rec["full_grads"].append([p.grad.detach().cpu().double() for p in ps])
+        rec["sd"].append([p.detach().cpu().clone() for p in ps])          # the weights this iteration ran with
         rec["grads"].append(torch.cat([p.grad.flatten()[torch.as_tensor(helpers.sample_idx(p.numel()), device=p.device)]
                                        for p in ps]).cpu().numpy())
         r = orig_step(self, closure)
@@ -164,6 +170,7 @@ def test_reference_train_loop_runs_on_dropin_modules(golden_dir, tmp_path, monke
         rec["loss"].append(float(self.detach()))
         return orig_backward(self, *a, **k)
 
+    hook = torch.nn.modules.module.register_module_forward_hook(capture)
     monkeypatch.setattr(rt, "DataLoader", ReplayDL)
     monkeypatch.setattr(ops, "randn", fake_randn)
     monkeypatch.setattr(rt.RAdam, "step", rec_step)
@@ -185,45 +192,63 @@ def test_reference_train_loop_runs_on_dropin_modules(golden_dir, tmp_path, monke
         rt.train(tmp_path / "models", tmp_path / "logs", npz, jsn, train_opt, net_opt)
     finally:
         torch.set_num_threads(nthreads)
+        hook.remove()
     assert len(rec["loss"]) == n_it
     np.testing.assert_allclose(rec["loss"], gd["loss"], rtol=2e-5)
-    # Gradients: against the reference run in FLOAT64 (train_iter_fp64.npz: the same two iterations through the unmodified
-    # reference with .double() modules).  Iteration 0: every tensor within 5e-4 of its largest fp64 entry.  Iteration 1 of this
-    # fixture is ILL-CONDITIONED IN MAGNITUDE: the reference's own fp32 gradients keep the fp64 direction to 4e-6 (1 - cosine)
-    # but are 0.1-0.7 % longer, all 44 tensors by nearly the same factor (measured, oracle/make_golden.py:gold_train_iter_fp64)
-    # -- the signature of a gradient dominated by one term whose magnitude is a difference of nearly equal fp32 numbers (the
-    # loss normalises predicted axes by their norms, txform.py:23-34; not traced further).  Any other fp32 evaluation lands on
-    # another common length (this engine: between 3 % shorter and 2 % longer from build to build, the same factor on all 44
-    # tensors).  So iteration 1 asserts what IS determined: the direction of every tensor's gradient (1 - cosine < 1e-4
-    # against fp64; measured 3e-5, the reference's own fp32 run 4e-6), a length within 6 %, and ONE common factor.
+    # Gradients.  Iteration 0: every tensor within 5e-4 of its largest entry of the reference run in FLOAT64 (train_iter_fp64.npz:
+    # the same two iterations through the unmodified reference with .double() modules).  Iteration 1 (round 5):
+    # its loss gradient is dominated by ONE joint (batch row 1, frame 4, root joint) whose predicted x / y axes are 0.86 degrees from
+    # antiparallel: d loss / d output ~ 1 / |x cross y| there (xform_orthogonalize_from_xy, anim/txform.py:23-34), so the last bits of
+    # the FORWARD outputs re-scale the whole gradient -- the reference's own fp32 run is a stable 0.08-0.7 % longer than its fp64 run
+    # (ten perturbed replays: train_iter_perturb.npz, spread < 5e-4), the fp32 oracle 0.2-1.8 %
+    # (tests/test_oracle_golden.py::test_iteration1_conditioning_and_the_forward_point_arbiter), this engine whatever its own forward
+    # rounding gives.  What IS determined: the gradient at the implementation's OWN forward point.  So iteration 1 is held, entry by
+    # entry (5e-4 of the tensor's largest, the iteration-0 bound), to helpers.grads_at_forward_point -- the float64 Jacobian applied
+    # to the float64 loss gradient at the outputs the drop-in decoder actually returned --, its forward outputs to 1e-4 of float64, and
+    # the direction to the reference's float64 run (1 - cos < 1e-4).  The +-6 % length band of round 4 is gone.
     g64 = np.load(golden_dir / "train_iter_fp64.npz")
-    names = [f"{t}.{n}" for t, m in zip(("speech", "decoder", "style"), helpers.build_nets()) for n, _ in m.named_parameters()]
-    sizes = [len(helpers.sample_idx(p.numel())) for m in helpers.build_nets() for p in m.parameters()]
+    nets0 = helpers.build_nets()
+    names = [f"{t}.{n}" for t, m in zip(("speech", "decoder", "style"), nets0) for n, _ in m.named_parameters()]
+    sizes = [len(helpers.sample_idx(p.numel())) for m in nets0 for p in m.parameters()]
+    assert len(rec["outs"]) == n_it and len(rec["sd"]) == n_it
     bad, rows = [], []
     for it in range(n_it):
         ref64, ref32, got = g64[f"it{it}_grad_samples64"], gd[f"it{it}_grad_samples"].astype(np.float64), rec["grads"][it]
         assert got.shape == ref64.shape == (sum(sizes),)
+        arb = None
+        if it == 1:
+            flat, sds = list(rec["sd"][1]), []
+            for m in nets0:                                   # the optimizer's parameter order = speech, decoder, style
+                sds.append({n: flat.pop(0) for n, _ in m.named_parameters()})
+            arb, O64, _ = helpers.grads_at_forward_point(gd, 1, sds, rec["outs"][1])
+            dev_out = max(float((a.double().reshape(b_.shape) - b_).abs().max()) for a, b_ in zip(rec["outs"][1], O64))
+            assert dev_out < 1e-4, dev_out
         off = 0
-        for name, n in zip(names, sizes):
+        for k, (name, n) in enumerate(zip(names, sizes)):
             sl = slice(off, off + n)
             g_, r_ = got[sl].astype(np.float64), ref64[sl]
             scale = max(1e-6, float(np.abs(r_).max()))
             err = float(np.abs(g_ - r_).max()) / scale
             cosd = 1.0 - float(np.dot(g_, r_) / max(1e-300, np.linalg.norm(g_) * np.linalg.norm(r_)))
             ratio = float(np.linalg.norm(g_) / max(1e-300, np.linalg.norm(r_)))
-            rows.append((it, name, err, cosd, ratio, float(np.abs(ref32[sl] - r_).max()) / scale))
-            ok = err < 5e-4 + 1e-8 if it == 0 else (cosd < 1e-4 and abs(ratio - 1.0) < 0.06)
+            err_arb = 0.0
+            if arb is not None:
+                full = rec["full_grads"][1][k]
+                err_arb = float((full - arb[k].reshape(full.shape)).abs().max()) / max(1e-12, float(arb[k].abs().max()))
+            rows.append((it, name, err, cosd, ratio, float(np.abs(ref32[sl] - r_).max()) / scale, err_arb))
+            ok = err < 5e-4 + 1e-8 if it == 0 else (cosd < 1e-4 and err_arb < 5e-4)
             if not ok:
                 bad.append(rows[-1])
             off += n
         # (iteration 1: lr x the gradient deviation discussed above, 1e-4 x 0.5 x 1e-2 x 0.36, is itself 2e-7)
         np.testing.assert_allclose(rec["weights"][it], gd[f"it{it}_weight_samples"], atol=3e-7 if it == 0 else 1e-6)
     import os
-    if os.environ.get("ZEGGS_TEST_DUMP"):          # diagnostics: (iteration, tensor, max error, 1 - cosine, length ratio, ref32-vs-ref64)
+    if os.environ.get("ZEGGS_TEST_DUMP"):          # diagnostics: (iteration, tensor, max error vs fp64, 1 - cosine, length ratio, ref32-vs-ref64, error vs the arbiter)
         json.dump(rows, open(os.environ["ZEGGS_TEST_DUMP"], "w"), indent=0)
     r1 = [r[4] for r in rows if r[0] == 1]
+    print(f"\niteration 1 on the drop-in modules: length vs the reference's float64 run {min(r1):.4f} .. {max(r1):.4f}, worst entry vs the "
+          f"forward-point arbiter {max(r[6] for r in rows if r[0] == 1):.1e} of the tensor's largest, 1 - cos <= {max(r[3] for r in rows if r[0] == 1):.1e}")
     assert not bad, bad
-    assert max(r1) - min(r1) < 0.03, (min(r1), max(r1))      # ONE common factor (what a single dominating term produces)
     # what the loop wrote at iteration 0 (train.py:470-760): whole-module pickles of the DROP-IN classes + six sample clips
     for f in ("speech_encoder.pt", "decoder.pt", "style_encoder.pt", "checkpoints.pt", "0/decoder.pt"):
         assert (tmp_path / "models" / f).exists(), f

@@ -1113,6 +1113,11 @@ struct LaunchWindow {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   int n = 0, steps = 0, dev = -1;
   bool on = false;
+  // thread_local instance: the events go when the host thread does (programs that create many threads leaked three per thread)
+  ~LaunchWindow() {
+    for (hipEvent_t& e : ev)
+      if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  }
   int begin(hipStream_t s) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;

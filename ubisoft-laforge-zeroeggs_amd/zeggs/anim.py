@@ -25,9 +25,12 @@ def bvh_load(filename):
     stack, order, end_site = [], None, False
     with open(filename, "rb") as f:
         raw = f.read()
-    mpos = raw.find(b"MOTION")
-    head = raw[:mpos] if mpos >= 0 else raw
-    lines = iter(raw.decode().splitlines() if mpos < 0 else (head.decode().splitlines() + ["MOTION"]))
+    # the MOTION section starts at a line that holds nothing but the keyword (a joint called LOCOMOTION_root is not it: ADVICE r4)
+    msec = re.search(rb"(?m)^[ \t]*MOTION[ \t]*\r?$", raw)
+    if msec is None:
+        raise ValueError(f"{filename}: no MOTION section (a line holding only the keyword MOTION)")
+    mpos, mend = msec.start(), msec.end()
+    lines = iter(raw[:mpos].decode().splitlines() + ["MOTION"])
     for line in lines:
         tok = line.split()
         if not tok:
@@ -58,11 +61,15 @@ def bvh_load(filename):
     # MOTION block: "Frames: N", "Frame Time: dt", then N rows of numbers -- parsed by the library's host helper (strtod on a few
     # threads: 7 200 rows x 228 numbers in ~8 ms, numpy.loadtxt 76 ms), numpy.loadtxt when it declines (ragged rows: loadtxt
     # raises the error the caller expects)
-    off = mpos + len(b"MOTION")
+    off = mend
     probe = raw[off:off + 256]
     m1 = re.match(rb"\s*Frames:\s+(\d+)\s*?\n", probe)
+    if m1 is None:
+        raise ValueError(f"{filename}: the MOTION section does not start with 'Frames: <count>'")
     nframes = int(m1.group(1))
-    m2 = re.match(rb"\s*Frame Time:\s+([\d\.eE\-]+)[^\n]*\n?", probe[m1.end():])
+    m2 = re.match(rb"\s*Frame Time:\s+([\d\.eE\-\+]+)[^\n]*\n?", probe[m1.end():])
+    if m2 is None:
+        raise ValueError(f"{filename}: no 'Frame Time: <seconds>' line after 'Frames:'")
     frametime = float(m2.group(1))
     off += m1.end() + m2.end()                          # the rows start here; `raw` (a bytes object) ends in a NUL
     ncols = sum(chans)

@@ -264,6 +264,7 @@ class TrainEngine:
         # re-runs the lost steps on the stage kernels (_recover).
         self.status = self._status_host = None
         self._status_ring = []
+        self._status_stream = None
         self._history = collections.deque(maxlen=8)
         self.recovered_steps = 0
         self.replayed = []                  # (iteration, loss, terms) of steps re-run by _recover(): for the caller's log
@@ -359,6 +360,21 @@ class TrainEngine:
         while len(self._status_ring) <= self.STATUS_LAG:
             self._status_ring.append([torch.zeros(ops.STATUS_WORDS, dtype=torch.int32).pin_memory(), None])
         slot = self._status_ring[k]
+        if self.aux_stream is not None:
+            # on a stream of its own: a device-to-host copy ends in a system-scope release (the L2s write back what RAdam has just
+            # dirtied), and on the main stream the next iteration's first kernel waited for it -- ~75 us of an idle chip per
+            # iteration in the round-4 timeline (between the copy and fill_k2).  (Not the third stream: the next batch's gathers
+            # queue there and must not wait for the end of this iteration.)
+            if self._status_stream is None:
+                self._status_stream = torch.cuda.Stream(device=self.status.device)
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._status_stream):
+                self._status_stream.wait_event(ev)
+                slot[0].copy_(self.status, non_blocking=True)
+                slot[1] = torch.cuda.Event()
+                slot[1].record(self._status_stream)
+            return
         slot[0].copy_(self.status, non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record()
@@ -406,10 +422,19 @@ class TrainEngine:
         self.recovered_steps += n
         rng = self.ctx.rng()
         after = copy.deepcopy(rng.bit_generator.state)       # the stream continues where the (skipped) steps left it
-        for h in redo:
-            rng.bit_generator.state = copy.deepcopy(h["seed_state"])
-            loss = self.step(h["idx"], h["example_len"], eps=h["eps"], labels=h["labels"], _replay=True)
-            self.replayed.append((self.iteration - 1, loss, self.last_terms))
+        # a replayed step runs with the learning rate it had when it was first tried (the caller may have applied the
+        # (iteration + 1) % 1000 decay since -- zeggs.train does it before the lagged look at the skip counter)
+        lr_now = [grp["lr"] for grp in self.opt.param_groups]
+        try:
+            for h in redo:
+                rng.bit_generator.state = copy.deepcopy(h["seed_state"])
+                for grp, lr in zip(self.opt.param_groups, h.get("lr", lr_now)):
+                    grp["lr"] = lr
+                loss = self.step(h["idx"], h["example_len"], eps=h["eps"], labels=h["labels"], _replay=True)
+                self.replayed.append((self.iteration - 1, loss, self.last_terms))
+        finally:
+            for grp, lr in zip(self.opt.param_groups, lr_now):
+                grp["lr"] = lr
         rng.bit_generator.state = after
 
     def flush(self):
@@ -434,7 +459,8 @@ class TrainEngine:
             self._check_status()
             self._maybe_rearm()
             self._history.append(dict(idx=np.array(idx, copy=True), example_len=example_len, eps=eps, labels=labels,
-                                      seed_state=copy.deepcopy(self.ctx.rng().bit_generator.state)))
+                                      seed_state=copy.deepcopy(self.ctx.rng().bit_generator.state),
+                                      lr=[grp["lr"] for grp in self.opt.param_groups]))
         ds, T = self.ds, self.ds.window
         ex_len = example_len if self.style_type == "example" else None
         pre, self._prefetched = self._prefetched, None

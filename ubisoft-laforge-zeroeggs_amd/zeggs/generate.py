@@ -200,24 +200,41 @@ def _decode_to_bvh_streaming(decoder, pose0, rpos0, rrot0, gaze_row, speech, sty
                 "last_chunks_decoded_formatted_written": round((marks[1] - marks[0]) * 1e3, 2), "file_close": round((t_close - t_run) * 1e3, 2)}
         if ops._persistent_live(0) and int(status[0].item()):     # (every chunk has been downloaded by now: no extra wait)
             ops._warn_gave_up(int(status[0].item()), "the whole rollout")
+            # redo on the stage launches -- for THIS call only: the process-wide switch is restored afterwards (a
+            # give-up here used to turn the persistent decode off for every later caller without a word)
+            was = ops._OPTIONS.get("persistent", 1)
             ops.set_option("persistent", 0)
-            ops.fill_(status.view(torch.float32))
-            with open(path, "wb") as fh:
-                fh.write(head.encode())
-                run(pool, fh)
+            try:
+                ops.fill_(status.view(torch.float32))
+                with open(path, "wb") as fh:
+                    fh.write(head.encode())
+                    run(pool, fh)
+            finally:
+                ops.set_option("persistent", was)
+    _pinned_release(ring)
 
 
-_PINNED = {}
+_PINNED = {}                      # (count, cols) -> list of free rings: a ring is CHECKED OUT for the duration of one call
+_PINNED_LOCK = __import__("threading").Lock()
 
 
 def _pinned_ring(count, rows, cols):
-    """`count` page-locked float64 staging buffers [rows, cols], kept for the life of the process (page-locking is the expensive
-    part; 4 x 15 MB for the default chunk)"""
+    """`count` page-locked float64 staging buffers [rows, cols].  Page-locking is the expensive part (4 x 15 MB for the default
+    chunk), so rings are pooled for the life of the process -- but a ring belongs to ONE call at a time (two
+    generate_gesture() calls on two threads shared the buffers and corrupted each other's rows): take one with this function,
+    give it back with _pinned_release()."""
     key = (count, cols)
-    ring = _PINNED.get(key)
-    if ring is None or ring[0].shape[0] < rows:
-        ring = _PINNED[key] = [torch.empty(rows, cols, dtype=torch.float64).pin_memory() for _ in range(count)]
-    return ring
+    with _PINNED_LOCK:
+        free = _PINNED.setdefault(key, [])
+        for i, ring in enumerate(free):
+            if ring[0].shape[0] >= rows:
+                return free.pop(i)
+    return [torch.empty(rows, cols, dtype=torch.float64).pin_memory() for _ in range(count)]
+
+
+def _pinned_release(ring):
+    with _PINNED_LOCK:
+        _PINNED.setdefault((len(ring), ring[0].shape[1]), []).append(ring)
 
 
 def generate_gesture(audio_file, styles, network_path, data_path, results_path, style_encoding_type="example",
@@ -359,20 +376,19 @@ def generate_gesture(audio_file, styles, network_path, data_path, results_path, 
             if T > STREAM_MIN_FRAMES and not film:
                 # long clip: chunked persistent decode with the BVH text formatted and written underneath it
                 pose0 = torch.cat([g(x).reshape(1, -1) for x in (root_vel, root_vrt, lpos, ltxy, lvel, lvrt)], dim=1)
-                copier = None
-                try:
-                    import threading
-                    copier = threading.Thread(target=copyfile, args=(audio_file, str(results_path / (file_name + ".wav"))))
-                    copier.start()
-                    with _stage("decode+pose_to_bvh_device_with_bvh_text_write_host_underneath"):
-                        _decode_to_bvh_streaming(decoder, pose0, g(root_pos), g(root_rot), g(gaze_pos), speech,
-                                                 final.contiguous(), (in_mean, in_std, out_mean, out_std), dt,
-                                                 str(results_path / (file_name + ".bvh")), parents, bone_names)
-                except (PermissionError, OSError) as e:
-                    print(e)
-                finally:
-                    if copier is not None:
-                        copier.join()
+                # the WAV copy runs beside the decode; its errors surface where the one-launch path's do (a bare Thread
+                # sent a PermissionError to threading.excepthook instead of the `except` below)
+                from concurrent.futures import ThreadPoolExecutor as _TPE
+                with _TPE(max_workers=1) as copy_pool:
+                    try:
+                        copier = copy_pool.submit(copyfile, audio_file, str(results_path / (file_name + ".wav")))
+                        with _stage("decode+pose_to_bvh_device_with_bvh_text_write_host_underneath"):
+                            _decode_to_bvh_streaming(decoder, pose0, g(root_pos), g(root_rot), g(gaze_pos), speech,
+                                                     final.contiguous(), (in_mean, in_std, out_mean, out_std), dt,
+                                                     str(results_path / (file_name + ".bvh")), parents, bone_names)
+                        copier.result()
+                    except (PermissionError, OSError) as e:
+                        print(e)
                 return final
             gaze = g(gaze_pos).repeat(T, 1)[None]
             with _stage("decode_device"):

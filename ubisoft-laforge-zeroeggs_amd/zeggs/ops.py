@@ -202,7 +202,6 @@ def side_stream(device=None):
     return _SIDE_STREAMS[idx]
 
 
-_PLAIN_STATUS = {}       # per device: status words of decoder calls made outside an engine context (inspected right away)
 
 
 def new_status(device):
@@ -212,11 +211,22 @@ def new_status(device):
     return t
 
 
+_PLAIN_TLS = threading.local()
+
+
 def _plain_status(dev):
-    key = (dev.index, threading.get_ident())       # one word per device AND host thread: concurrent rollouts do not share it
-    st = _PLAIN_STATUS.get(key)
+    """Status words of a decoder call made OUTSIDE an engine context: one per device and host thread (concurrent rollouts do not
+    share it), held in thread-local storage so that it is freed with the thread (a dict keyed by thread id grew for
+    ever in programs that spawn threads).  Cost to know about: the caller of such a call reads the word back right after the
+    rollout -- ONE 4-byte device-to-host read (a host synchronisation) per rollout, forward and backward, and only once a
+    persistent kernel has been validated on this process; an engine (ops.use(EngineContext) with a status of its own, as
+    zeggs.engine.TrainEngine) never pays it -- it reads its words with a lag of three iterations."""
+    per_dev = getattr(_PLAIN_TLS, "words", None)
+    if per_dev is None:
+        per_dev = _PLAIN_TLS.words = {}
+    st = per_dev.get(dev.index)
     if st is None:
-        st = _PLAIN_STATUS[key] = new_status(dev)
+        st = per_dev[dev.index] = new_status(dev)
     return st
 
 
