@@ -40,7 +40,12 @@ const char* zeggs_last_error(void);
 /* process-wide TUNING switches: "decoder_fast" 1 (default) = fragment-packed stage kernels, 0 = generic GEMM path;
  * "persistent" / "train_persistent" / "bwd_persistent" 0/1 = the three weight-stationary persistent kernels;
  * "persistent_spin" = bound of their device-side waits (polls; 0: the first unsatisfied wait gives up -- test hook);
- * "timing" 1 = HIP events on the caller's stream around the decoder's steady-state stage sweeps */
+ * "timing" 1 = HIP events on the caller's stream around the decoder's steady-state stage sweeps;
+ * round 5: "gemm_direct" 0 / 1 (default) / 2 / 3 / 5 = the barrier-free, LDS-free stream-K form of the TN (weight-gradient)
+ * products: off / on / 128x64 / 64x64 wave tiles / only the small and batch-reduce products (what a caller that runs several
+ * streams beside each other should pick: zeggs.engine.TrainEngine does), "gemm_direct_wgs", "gemm_direct_depth" (4 / 6 / 8 k-pairs
+ * in flight); "ln_bwd4" 0 / 1 = the 16-byte-lane LayerNorm-backward pass; "mel_exact_log" 1 = the literal log / pow chain of
+ * data_pipeline.py:62-63 instead of the affine map */
 int zeggs_set_option(const char* name, int value);
 /* elapsed ms of the last recorded stage sweep: which = 0 forward (T-1 steps x 3 launches), 1 backward; blocks on
  * the end event.  Measurement hook of bench.py (roofline figures); there is no reference counterpart. */
@@ -51,6 +56,10 @@ int zeggs_timing_ms(int which, float* ms);
 int zeggs_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                long sam, long sak, long sbk, long sbn, long scm, long scn, int nbatch, long bsA,
                long bsB, long bsC, float alpha, float beta, int act, void* stream);
+/* batch-reduce form (the weight gradient of a batched convolution, ZEGGS/modules.py:346-420 through autograd):
+ * C(m,n) = beta * C(m,n) + sum_b sum_k A_b(m,k) B_b(k,n), A_b = A + b kbsA, B_b = B + b kbsB; beta 0 or 1. */
+int zeggs_gemm_kbatch(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk, long sbn,
+                      long scm, long scn, int kbatch, long kbsA, long kbsB, float beta, void* stream);
 
 /* ---------------------------------------------------------------- SpeechEncoder
  * replaces SpeechEncoder.forward, ZEGGS/modules.py:265-272 (+ autograd backward).
@@ -312,7 +321,15 @@ int zeggs_radam_step(float* p, const float* g, float* m, float* v, long n, float
                      float step_scale, int rectified, void* stream);
 /* the same step, skipped on the DEVICE (p, m, v untouched, status[1] += 1) when status[0] != 0 (a persistent sweep of this
  * rank gave up: ZeggsDecCall.status) or gflag != NULL and gflag[0] != 0 (the flag of all ranks, summed by the gradient
- * all-reduce: zeggs_status_flag writes this rank's 0 / 1 into the float that travels with the gradients) */
+ * all-reduce: zeggs_status_flag writes this rank's 0 / 1 into the float that travels with the gradients).
+ * CALLER'S OBLIGATION (the flush protocol).  A skipped step is invisible in the weights -- they simply stay what they were -- so a
+ * caller of the guarded step that READS THE WEIGHTS FOR KEEPS (a checkpoint, rendered samples, the end of training) must first
+ * (1) synchronise the stream, (2) read status[1]: if it is > 0, that many optimizer steps did not happen; (3) switch the persistent
+ * sweeps off (zeggs_set_option), zero the status words, rewind its step count by status[1] (the RAdam bias corrections) and re-run
+ * those iterations -- same batches, same noise seeds -- before it saves anything; (4) optionally switch the sweeps back on after a
+ * probation.  zeggs/engine.py: TrainEngine.flush() is exactly this (and _check_status() the lagged, stall-free version of it that
+ * runs every iteration; re-arming: TrainEngine._maybe_rearm); zeggs.train() calls flush() before every checkpoint and at the end.
+ * Nothing in the library can enforce it: the status words are the caller's, and so are the weights. */
 int zeggs_radam_step_guarded(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
                              float step_scale, int rectified, unsigned* status, const float* gflag, void* stream);
 /* a step applied in PIECES (slices of the flat buffers, each as soon as its gradients are final -- zeggs/engine.py runs the

@@ -116,7 +116,8 @@ def test_persistent_sweeps_are_rearmed_after_a_giveup_and_back_off(restore_optio
     assert eng.recovered_steps == 2 * lag and eng.iteration == steps == eng.opt._step and eng.rearm_count == 1
     w = eng.flat_p.detach().cpu().numpy()
     assert np.isfinite(w).all()
-    assert np.abs(w - w_ref).max() <= 1e-5, np.abs(w - w_ref).max()      # (four of the 14 steps ran on the persistent kernels)
+    # (four of the 14 steps ran on the persistent kernels, 1e-6 apart per gradient; an early RAdam step moves an entry by up to lr = 1e-4)
+    assert np.abs(w - w_ref).max() <= 3e-5, np.abs(w - w_ref).max()
 
 
 def _rollout(de, T, seed=4242):

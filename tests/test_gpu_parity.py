@@ -49,6 +49,63 @@ def test_gemm_layouts(M, N, K):
     assert relerr(C, 2.0 * ref + 0.5 * C0.double()) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K,lda,ldb,kbatch", [(3072, 1024, 2040, 3072, 1024, 1), (1131, 1262, 1022, 1132, 2288, 1),
+                                                  (197, 333, 1026, 200, 340, 1), (384, 128, 192, 384, 128, 7),
+                                                  (3402, 512, 208, 1134, 512, 5), (130, 70, 2048, 131, 73, 1)])
+def test_gemm_direct_stream_k_vs_float64_and_the_lds_kernel(M, N, K, lda, ldb, kbatch):
+    """Round 5: the barrier-free / LDS-free stream-K TN product (gemm.hip: gemm_tn_direct_kernel -- operands straight from memory
+    into the matrix-core operand registers, inline-asm loads with hand-counted vmcnt) on weight-gradient shapes: aligned and odd
+    extents / strides, the batch-reduce form of the convolution weight gradients (kbatch > 1, overlapping A rows as conv_dw_gemm
+    passes them), both wave tiles, three prefetch depths, accumulation onto an existing C -- every output entry against float64,
+    and against the LDS-tiled stream-K kernel it replaces."""
+    torch.manual_seed(M + N + K)
+    overlap = kbatch > 1 and lda < M                       # conv weight gradient: A(m, k) = xp[k * lda + m], m < taps * lda
+    rowsA = K + (M + lda - 1) // lda if overlap else K
+    A = torch.randn(kbatch, rowsA, lda)
+    B = torch.randn(kbatch, K, ldb)
+    C0 = torch.randn(M, N)
+    if overlap:
+        Am = torch.stack([A[b].flatten()[(torch.arange(K)[:, None] * lda + torch.arange(M)[None, :])] for b in range(kbatch)])
+    else:
+        Am = A[:, :, :M]
+    ref = torch.einsum("bkm,bkn->mn", Am.double(), B[:, :, :N].double())
+    L = ops.lib()
+    import ctypes as C
+
+    def run(beta):
+        Cd = g(C0.clone())
+        Ad, Bd = g(A), g(B)
+        if kbatch == 1:
+            ops.gemm(Ad, Bd, Cd, M, N, K, (1, lda), (ldb, 1), (N, 1), beta=beta)
+        else:       # the batch-reduce form has no Python wrapper: through the style encoder's own call shape (zeggs_gemm_kbatch)
+            rc = L.zeggs_gemm_kbatch(ops._p(Ad), ops._p(Bd), ops._p(Cd), M, N, K, C.c_long(1), C.c_long(lda), C.c_long(ldb), C.c_long(1),
+                                     C.c_long(N), C.c_long(1), kbatch, C.c_long(rowsA * lda), C.c_long(K * ldb), C.c_float(beta),
+                                     ops._stream())
+            assert rc == 0, L.zeggs_last_error()
+        return Cd.cpu().double()
+
+    outs = {}
+    try:
+        for mode, wgs, depth in ((0, 0, 4), (2, 1, 4), (2, 2, 8), (3, 2, 4), (3, 3, 6), (1, 0, 8)):
+            ops.set_option("gemm_direct", mode)
+            ops.set_option("gemm_direct_wgs", wgs)
+            ops.set_option("gemm_direct_depth", depth)
+            for beta in (0.0, 1.0):
+                got = run(beta)
+                want = ref + beta * C0.double()
+                err = float((got - want).abs().max() / want.abs().max())
+                assert err < 3e-6, (mode, wgs, depth, beta, err)
+                outs[(mode, wgs, depth, beta)] = got
+    finally:
+        ops.set_option("gemm_direct", 1)
+        ops.set_option("gemm_direct_wgs", 0)
+        ops.set_option("gemm_direct_depth", 4)
+    base = outs[(0, 0, 4, 0.0)]
+    for k, v in outs.items():
+        if k[3] == 0.0:
+            assert float((v - base).abs().max() / base.abs().max()) < 3e-6, k
+
+
 @pytest.mark.parametrize("M,N,K", [(32, 1024, 1198), (32, 3072, 1131), (64, 1024, 1024), (33, 1000, 67), (17, 70, 64),
                                    (1, 2262, 1262), (48, 64, 4097)])
 def test_gemm_skinny_nt_one_launch(M, N, K):
@@ -554,9 +611,20 @@ def test_mel_fft_form_equals_the_dft_forms(golden_dir):
             ops.set_option("mel_fft", fft)
             outs.append(audio.mel_features(short, audio.n_anim_frames(len(short))).cpu().numpy())
         np.testing.assert_allclose(outs[0], outs[1], atol=1e-6, equal_nan=True)
+        # round 5: ln(10^(v / 20)) as the affine map v ln(10) / 20 (default) against the literal log / pow chain of
+        # data_pipeline.py:62-63 (option mel_exact_log): float64 values 2e-16 apart, float32 features equal to the last bit or two
+        ops.set_option("mel_fft", 1)
+        for tag, (wav, nfr, ref) in wavs.items():
+            ops.set_option("mel_exact_log", 0)
+            fa = audio.mel_features(wav, nfr).cpu().numpy()
+            ops.set_option("mel_exact_log", 1)
+            fe = audio.mel_features(wav, nfr).cpu().numpy()
+            np.testing.assert_allclose(fe, ref, atol=2e-6, equal_nan=True)
+            np.testing.assert_allclose(fa, fe, atol=2.5e-7, rtol=2.5e-7, equal_nan=True, err_msg=tag)
     finally:
         ops.set_option("mel_fft", 1)
         ops.set_option("mel_mfma", 1)
+        ops.set_option("mel_exact_log", 0)
 
 
 # ----------------------------------------------------------------------------- drop-in API end to end

@@ -1051,3 +1051,11 @@ extern "C" int zeggs_gemm(const float* A, const float* B, float* C, const float*
   g.bias = bias; g.alpha = alpha; g.beta = beta; g.act = act;
   return launch_gemm(g, nbatch, (hipStream_t)stream);
 }
+
+extern "C" int zeggs_gemm_kbatch(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk,
+                                 long sbn, long scm, long scn, int kbatch, long kbsA, long kbsB, float beta, void* stream) {
+  GemmArgs g = gemm_args(A, B, C, M, N, K);
+  g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.scm = scm; g.scn = scn;
+  g.kbatch = kbatch; g.kbsA = kbsA; g.kbsB = kbsB; g.beta = beta;
+  return launch_gemm(g, 1, (hipStream_t)stream);
+}
