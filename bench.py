@@ -195,13 +195,13 @@ def cpu_baselines(data):
     if ref_shims.available():
         # the reference ITSELF on this box's host cores (on the GPU box: the byte-for-byte snapshot oracle/build_ref.py left in
         # oracle/_ref/): train() with every core (the headline baseline) and with thread_count = 1 (the shipped config value,
-        # configs_v1.json:37); bounded samples (4 + 1 steady iterations; iteration 0 = checkpoint + sample rendering is skipped)
+        # configs_v1.json:37); bounded samples (5 + 1 steady iterations; iteration 0 = checkpoint + sample rendering is skipped)
         from oracle import ref_timing
         ncpu = os.cpu_count() or 1
         # "all cores" = the physical cores, capped at 32 threads: torch's intra-op pool gets SLOWER beyond that on this
         # workload (hundreds of sub-millisecond ops per decoder step, each a fork-join over the pool)
         nthr = max(1, min(physical_cores(), 32))
-        r = ref_timing.measure(iters=4, frames=600, train_threads=(nthr,), legs=("train", "decode", "mel"))      # ~25 s of CPU work
+        r = ref_timing.measure(iters=5, frames=600, train_threads=(nthr,), legs=("train", "decode", "mel"))      # ~30 s of CPU work
         tr = next(iter(r["train"].values()))
         train = {"value": tr["frames_per_s"], "unit": "frames/s", "cores": tr["threads"], "kind": "reference",
                  "sample": f"{tr['iterations_timed']} steady iterations of the unmodified reference train() "
@@ -746,7 +746,7 @@ def main():
         nst = WINDOW - 1
         f_us, b_us = float(np.mean(fw)) * 1e3 / nst, float(np.mean(bw)) * 1e3 / nst
         pmc = None
-        for name in ("r04_decoder_step_pmc.json", "r03_decoder_step_pmc.json", "r02_decoder_step_pmc.json", "r01_decoder_step_pmc.json"):
+        for name in ("r05_decoder_step_pmc.json", "r04_decoder_step_pmc.json", "r03_decoder_step_pmc.json", "r02_decoder_step_pmc.json", "r01_decoder_step_pmc.json"):
             if (ROOT / "profiles" / name).exists():
                 pmc = json.load(open(ROOT / "profiles" / name))
                 pmc["file"] = "profiles/" + name
@@ -771,7 +771,7 @@ def main():
                          "us_per_step_in_timed_region": round(bwd_in * 1e3 / nst, 2),
                          "traffic": pmc.get("traffic_bytes_per_step_backward") if pmc else None},
             "mfma_frac_at_b32": round(step_flops(BATCH) / (f_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-            "dominant_kernel": "train_bwd_persistent_k (27 % of kernel time, profiles/r04_train_only_kernel_stats_12steps.csv): "
+            "dominant_kernel": "train_bwd_persistent_k (27 % of kernel time, profiles/r05_train_only_kernel_stats_12steps.csv): "
                                "its figures are roofline.backward; train_fwd_persistent_k (21 %) is the top-level entry",
             "note": "HIP events (library hook zeggs_timing_ms, recorded on the stream the kernels run on) around the "
                     "255-step stage sweeps: the last timed iteration + 3 more; traffic = FETCH_SIZE(x2)+WRITE_SIZE "

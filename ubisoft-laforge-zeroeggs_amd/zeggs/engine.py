@@ -264,7 +264,6 @@ class TrainEngine:
         # re-runs the lost steps on the stage kernels (_recover).
         self.status = self._status_host = None
         self._status_ring = []
-        self._status_stream = None
         self._history = collections.deque(maxlen=8)
         self.recovered_steps = 0
         self.replayed = []                  # (iteration, loss, terms) of steps re-run by _recover(): for the caller's log
@@ -360,21 +359,9 @@ class TrainEngine:
         while len(self._status_ring) <= self.STATUS_LAG:
             self._status_ring.append([torch.zeros(ops.STATUS_WORDS, dtype=torch.int32).pin_memory(), None])
         slot = self._status_ring[k]
-        if self.aux_stream is not None:
-            # on a stream of its own: a device-to-host copy ends in a system-scope release (the L2s write back what RAdam has just
-            # dirtied), and on the main stream the next iteration's first kernel waited for it -- ~75 us of an idle chip per
-            # iteration in the round-4 timeline (between the copy and fill_k2).  (Not the third stream: the next batch's gathers
-            # queue there and must not wait for the end of this iteration.)
-            if self._status_stream is None:
-                self._status_stream = torch.cuda.Stream(device=self.status.device)
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(self._status_stream):
-                self._status_stream.wait_event(ev)
-                slot[0].copy_(self.status, non_blocking=True)
-                slot[1] = torch.cuda.Event()
-                slot[1].record(self._status_stream)
-            return
+        # (round 5: moving this copy to a stream of its own was tried -- the ~75 us between the optimizer's last kernel and the next
+        #  iteration's first are not the copy's: they stayed -- and cost the data-parallel schedule 2.7 ms: a fifth stream beside
+        #  RCCL's oversubscribes the hardware queues, bench.launch_env)
         slot[0].copy_(self.status, non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record()
