@@ -273,9 +273,9 @@ __device__ __forceinline__ float* rv_row32(const RowView& v, unsigned r, int C) 
   const unsigned b = r / (unsigned)v.rpb;
   return v.p + (size_t)b * v.bstride + (size_t)(r - b * (unsigned)v.rpb) * C;
 }
-template <int LPR, int VJ>
-__global__ __launch_bounds__(256) void ln_bwd_fused4_k(LnBwdFused a, int rows_per_block) {
-  constexpr int RPW = 64 / LPR, RPP = 4 * RPW, NE = 4 * VJ, CW = LPR * NE;      // rows per wave / per pass, floats per lane, padded width
+template <int LPR, int VJ, int NW>
+__global__ __launch_bounds__(64 * NW) void ln_bwd_fused4_k(LnBwdFused a, int rows_per_block) {
+  constexpr int RPW = 64 / LPR, RPP = NW * RPW, NE = 4 * VJ, CW = LPR * NE;      // rows per wave / per pass, floats per lane, padded width
   __shared__ float sred[3][RPP][CW];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, sub = lane / LPR, l = lane % LPR, slot = wave * RPW + sub;
   const int C = a.C, R = a.R;
@@ -293,36 +293,55 @@ __global__ __launch_bounds__(256) void ln_bwd_fused4_k(LnBwdFused a, int rows_pe
   }
   const float invC = 1.f / C, dscale = a.dy_pool ? 1.f / a.pool_L : 1.f;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, R);
-  for (int rb = r0; rb < r1; rb += RPP) {
+  // the operands of the NEXT pass are fetched before this pass's reductions and stores (two passes of loads in flight per wave:
+  // the pass is a chain load -> row reduction -> store, and 8 waves per CU alone do not cover its latency)
+  struct Pass { f4 va[VJ], vb[VJ], vx[VJ], vr[VJ], vy[VJ]; float mu, rs; unsigned rr; bool rok; };
+  auto fetch = [&](int rb, Pass& P) {
     const int row = rb + slot;
-    const bool rok = row < r1;
-    const unsigned rr = rok ? row : r1 - 1;          // (idle slots shadow the block's last row: loads stay in bounds, nothing is stored / summed)
-    const float mu = ln ? a.mean[rr] : 0.f, rs = ln ? a.rstd[rr] : 1.f;
+    P.rok = row < r1;
+    P.rr = P.rok ? row : r1 - 1;          // (idle slots shadow the block's last row: loads stay in bounds, nothing is stored / summed)
+    const unsigned rr = P.rr;
+    P.mu = ln ? a.mean[rr] : 0.f; P.rs = ln ? a.rstd[rr] : 1.f;
     const float* x = ln ? rv_row32(a.x, rr, C) : nullptr;
     const float* res = (ln && a.res.p) ? rv_row32(a.res, rr, C) : nullptr;
     const float* dyA = a.dy_pool ? a.dy_pool + (size_t)(rr / (unsigned)a.pool_L) * C : rv_row32(a.dyA, rr, C);
     const float* dyB = a.dyB.p ? rv_row32(a.dyB, rr, C) : nullptr;
     const float* ys = a.ysave.p ? rv_row32(a.ysave, rr, C) : nullptr;
+#pragma unroll
+    for (int j = 0; j < VJ; ++j) {
+      const int c0 = 4 * (l + LPR * j);
+      const f4 z4 = f4{0.f, 0.f, 0.f, 0.f};
+      P.va[j] = P.vb[j] = P.vx[j] = P.vr[j] = P.vy[j] = z4;
+      if (cok[j]) {
+        P.va[j] = *(const f4*)(dyA + c0);
+        if (dyB) P.vb[j] = *(const f4*)(dyB + c0);
+        if (ln) P.vx[j] = *(const f4*)(x + c0);
+        if (res) P.vr[j] = *(const f4*)(res + c0);
+        if (ys) P.vy[j] = *(const f4*)(ys + c0);
+      }
+    }
+  };
+  Pass cur, nxt;
+  fetch(r0, cur);
+  for (int rb = r0; rb < r1; rb += RPP) {
+    const bool more = rb + RPP < r1;
+    if (more) fetch(rb + RPP, nxt);
+    const bool rok = cur.rok;
+    const unsigned rr = cur.rr;
+    const float mu = cur.mu, rs = cur.rs;
+    const bool ys = a.ysave.p != nullptr;
     float d[NE], xh[NE], g[NE], yv[NE];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < VJ; ++j) {
       const int c0 = 4 * (l + LPR * j);
-      f4 va = f4{0.f, 0.f, 0.f, 0.f}, vb = va, vx = va, vr = va, vy = va;
-      if (cok[j]) {
-        va = *(const f4*)(dyA + c0);
-        if (dyB) vb = *(const f4*)(dyB + c0);
-        if (ln) vx = *(const f4*)(x + c0);
-        if (res) vr = *(const f4*)(res + c0);
-        if (ys) vy = *(const f4*)(ys + c0);
-      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * j + e;
-        float dv = va[e] * dscale + vb[e];
+        float dv = cur.va[j][e] * dscale + cur.vb[j][e];
         dv *= dropout_scale(a.seed_pre, (uint64_t)((size_t)rr * C + c0 + e), a.p_pre);
-        d[i] = dv; yv[i] = vy[e];
-        xh[i] = (vx[e] + vr[e] - mu) * rs;
+        d[i] = dv; yv[i] = cur.vy[j][e];
+        xh[i] = (cur.vx[j][e] + cur.vr[j][e] - mu) * rs;
         g[i] = dv * gam[i];
         s1 += g[i];
         s2 += g[i] * xh[i];
@@ -359,6 +378,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused4_k(LnBwdFused a, int rows_pe
         if (pl == a.pad_L - 1) *(f4*)(outr + c0 + C) = f4{0.f, 0.f, 0.f, 0.f};
       }
     }
+    if (more) cur = nxt;
   }
   // column sums: registers -> LDS [3][slot][column] -> one atomic per column and block
 #pragma unroll
@@ -369,7 +389,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused4_k(LnBwdFused a, int rows_pe
       sred[0][slot][c] = pg[i]; sred[1][slot][c] = pb[i]; sred[2][slot][c] = pc[i];
     }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += 64 * NW) {
     float tg = 0.f, tb = 0.f, tc = 0.f;
 #pragma unroll
     for (int q = 0; q < RPP; ++q) { tg += sred[0][q][c]; tb += sred[1][q][c]; tc += sred[2][q][c]; }
@@ -668,11 +688,13 @@ int k_ln_bwd_fused(const LnBwdFused& a, hipStream_t s) {
                   rv_al16(a.out) && rv_al16(a.ysave) && (((size_t)a.dy_pool) & 15) == 0 &&
                   a.R > 0 && (long)a.R * a.C < (1L << 31);
   if (g_ln_bwd4 && al) {
-    // ~512 blocks (2 per CU), whole passes per block
-    auto rows_per_block = [&](int rpp) { const int per = cdiv(a.R, 512); return cdiv(per, rpp) * rpp; };
-    if (a.C <= 128) { const int rpb = rows_per_block(8); hipLaunchKernelGGL((ln_bwd_fused4_k<32, 1>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb); }
-    else if (a.C <= 256) { const int rpb = rows_per_block(4); hipLaunchKernelGGL((ln_bwd_fused4_k<64, 1>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb); }
-    else { const int rpb = rows_per_block(4); hipLaunchKernelGGL((ln_bwd_fused4_k<64, 2>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb); }
+    // 16-wave blocks, ~1 per CU (the column sums of a block end in 3 C atomics: with 512 four-wave blocks those 196 k atomics onto
+    // 24 cache lines were half of the kernel's 20 us), whole passes per block
+    // (wider rows keep 4-wave blocks: two pipelined passes of 8 float4 operands do not fit 16 waves' register budget)
+    auto rows_per_block = [&](int rpp, int blocks) { const int per = cdiv(a.R, blocks); return cdiv(per, rpp) * rpp; };
+    if (a.C <= 128) { const int rpb = rows_per_block(32, 256); hipLaunchKernelGGL((ln_bwd_fused4_k<32, 1, 16>), dim3(cdiv(a.R, rpb)), dim3(1024), 0, s, a, rpb); }
+    else if (a.C <= 256) { const int rpb = rows_per_block(8, 256); hipLaunchKernelGGL((ln_bwd_fused4_k<64, 1, 8>), dim3(cdiv(a.R, rpb)), dim3(512), 0, s, a, rpb); }
+    else { const int rpb = rows_per_block(4, 512); hipLaunchKernelGGL((ln_bwd_fused4_k<64, 2, 4>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb); }
     ZLAUNCH_CHECK("ln_bwd_fused4");
     return 0;
   }
