@@ -611,20 +611,22 @@ def test_mel_fft_form_equals_the_dft_forms(golden_dir):
             ops.set_option("mel_fft", fft)
             outs.append(audio.mel_features(short, audio.n_anim_frames(len(short))).cpu().numpy())
         np.testing.assert_allclose(outs[0], outs[1], atol=1e-6, equal_nan=True)
-        # round 5: ln(10^(v / 20)) as the affine map v ln(10) / 20 (default) against the literal log / pow chain of
-        # data_pipeline.py:62-63 (option mel_exact_log): float64 values 2e-16 apart, float32 features equal to the last bit or two
+        # round 5: ln(10^(v / 20)) is the affine map v ln(10) / 20 = ln(s) / range + ln(10) / 20; mode 2 (default): that map in float64;
+        # mode 0: ln(s) and the energy's exp(2 y) on the hardware log2 / exp2; mode 1: the literal log / pow chain of
+        # data_pipeline.py:62-63.  All three against the reference fixtures (2e-6) and against the literal chain
         ops.set_option("mel_fft", 1)
         for tag, (wav, nfr, ref) in wavs.items():
-            ops.set_option("mel_exact_log", 0)
-            fa = audio.mel_features(wav, nfr).cpu().numpy()
-            ops.set_option("mel_exact_log", 1)
-            fe = audio.mel_features(wav, nfr).cpu().numpy()
-            np.testing.assert_allclose(fe, ref, atol=2e-6, equal_nan=True)
-            np.testing.assert_allclose(fa, fe, atol=2.5e-7, rtol=2.5e-7, equal_nan=True, err_msg=tag)
+            f = {}
+            for mode in (0, 1, 2):
+                ops.set_option("mel_exact_log", mode)
+                f[mode] = audio.mel_features(wav, nfr).cpu().numpy()
+                np.testing.assert_allclose(f[mode], ref, atol=2e-6, equal_nan=True, err_msg=f"{tag} mode {mode}")
+            np.testing.assert_allclose(f[2], f[1], atol=2.5e-7, rtol=2.5e-7, equal_nan=True, err_msg=tag)
+            np.testing.assert_allclose(f[0], f[1], atol=1e-6, rtol=1e-6, equal_nan=True, err_msg=tag)
     finally:
         ops.set_option("mel_fft", 1)
         ops.set_option("mel_mfma", 1)
-        ops.set_option("mel_exact_log", 0)
+        ops.set_option("mel_exact_log", 2)
 
 
 # ----------------------------------------------------------------------------- drop-in API end to end

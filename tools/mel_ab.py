@@ -33,3 +33,19 @@ for a, b in (("direct", "mfma"), ("direct", "fft"), ("mfma", "fft")):
     d = (outs[a] - outs[b]).abs()
     print(f"max |{a} - {b}|: {float(d[torch.isfinite(d)].max()):.3e}   NaN pattern equal: "
           f"{bool((torch.isnan(outs[a]) == torch.isnan(outs[b])).all())}")
+# round 5: the log chain (option mel_exact_log: 0 hardware log2 / exp2 (default), 2 float64 affine, 1 literal float64 chain)
+for mode in (1, 2, 0):
+    ops.set_option("mel_exact_log", mode)
+    audio.mel_features(wav[:16000], 60)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        o = audio.mel_features(wav, T)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    outs[f"log{mode}"] = o.cpu()
+    print(f"fft, mel_exact_log={mode}: {min(ts) * 1e3:8.3f} ms", flush=True)
+for m in (2, 0):
+    d = (outs[f"log{m}"] - outs["log1"]).abs()
+    print(f"max |mode {m} - literal chain|: {float(d[torch.isfinite(d)].max()):.3e}")

@@ -55,13 +55,23 @@ inline long stft_frames(long n, int n_fft, int hop) {
 // STFT frames m0 .. m0 + gridDim.x - 1.  n = signal length for the reflect rule, n_avail = samples present in `wav`
 // (streaming: n is unknown yet and passed as a huge value; the caller only asks for frames that end before n_avail)
 // The clipped mel amplitude s -> what the reference stores: v = (20 log10 s + range) / range (spectrograms.py:121-129), then
-// data_pipeline.py:62-63 takes ln(10^(v / 20)).  Round 5: that last pair is the affine map v ln(10) / 20 -- the same number to a
-// relative 2e-16 in float64 (the features are float32) -- which halves the float64 transcendentals per mel value (log10 + the exp
-// of the energy instead of log10, pow, log, exp: the kernel is bound by them, not by memory).  zeggs_set_option("mel_exact_log", 1)
-// evaluates the literal chain.
+// data_pipeline.py:62-63 takes y = ln(10^(v / 20)), and the frame's energy is || exp(y) ||_2 (data_pipeline.py:28-30,75).  Four
+// float64 transcendentals per mel value (log10, pow, log, exp) bounded the front-end in round 4 (not memory).  Round 5:
+//   y = v ln(10) / 20 = ln(s) / range + ln(10) / 20   -- the pow / log pair is an affine map -- and exp(y)^2 = exp(2 y);
+//   mode 0: ln(s) and exp(2 y) on the hardware log2 / exp2 (v_log_f32 / v_exp_f32, 1 ulp of float32): the error of y is
+//     <= 6e-8 |log2 s| ln 2 / range ~ 1e-8 absolute (range = -20 log10(min amplitude) ~ 10^2), of the energy 1e-7 relative -- the
+//     features are float32 and the reference fixtures are matched at 2e-6;
+//   mode 2 (default): the affine map in float64 (log10 + exp per value): float32 features bit-identical to mode 1, the literal
+//   float64 chain (zeggs_set_option("mel_exact_log", m)).
 __device__ __forceinline__ double mel_logamp(double s, double rng, int exact) {
+  if (exact == 0) return (double)(__builtin_amdgcn_logf((float)s) * 0.6931471805599453f) / rng + (2.302585092994046 / 20.0);
   const double v = (20.0 * log10(s) + rng) / rng;
-  return exact ? log(pow(10.0, v / 20.0)) : v * (2.302585092994046 / 20.0);
+  return exact == 1 ? log(pow(10.0, v / 20.0)) : v * (2.302585092994046 / 20.0);
+}
+__device__ __forceinline__ double mel_exp_sq(double y, int exact) {      // exp(y)^2
+  if (exact == 0) return (double)__builtin_amdgcn_exp2f((float)(y * (2.0 * 1.4426950408889634)));
+  const double z = exp(y);
+  return z * z;
 }
 
 __global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* wav, long n, long n_avail, const double* fb,
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* w
   __syncthreads();
   if (threadIdx.x == 0) {                               // energy = || exp(mel) ||_2 (data_pipeline.py:28-30,75)
     double e = 0.0;
-    for (int m = 0; m < d.n_mels; ++m) { const double z = exp(melv[m]); e += z * z; }
+    for (int m = 0; m < d.n_mels; ++m) e += mel_exp_sq(melv[m], exact);
     energy[slot] = sqrt(e);
   }
 }
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(MWAVES * 64) void mel_stft_mfma_k(ZeggsMelDims d, c
   __syncthreads();
   if (tid < MF && slot0 + tid < nfr) {
     double e = 0.0;
-    for (int m = 0; m < NM; ++m) { const double z = exp(melv[tid * NM + m]); e += z * z; }
+    for (int m = 0; m < NM; ++m) e += mel_exp_sq(melv[tid * NM + m], exact);
     energy[slot0 + tid] = sqrt(e);
   }
 }
@@ -426,8 +436,7 @@ __global__ __launch_bounds__(FTHR) void mel_stft_fft_k(ZeggsMelDims d, FftPlan p
     sacc = fabs(sacc);
     if (sacc < amin) sacc = amin;
     const double yv = mel_logamp(sacc, rng, exact);
-    const double z = exp(yv);
-    melv[it] = z * z;                                 // (every thread its own exp; the frame's thread only adds, in mel order)
+    melv[it] = mel_exp_sq(yv, exact);                                 // (every thread its own exp; the frame's thread only adds, in mel order)
     if (slot0 + f < nfr) logmel[(slot0 + f) * NM + m] = yv;
   }
   __syncthreads();
@@ -469,7 +478,8 @@ __global__ void mel_resample_k(ZeggsMelDims d, const double* logmel, const doubl
 }  // namespace
 
 int g_mel_mfma = 1;      // zeggs_set_option("mel_mfma", 0/1): matrix-core DFT / one workgroup per frame, direct DFT (when the FFT form is off)
-int g_mel_exact_log = 0;      // zeggs_set_option("mel_exact_log", 0/1): see mel_logamp
+int g_mel_exact_log = 2;      // zeggs_set_option("mel_exact_log", 0 / 1 / 2): see mel_logamp (measured on 30 min of audio: 1.61 / 1.50 / 1.46 ms for
+                              // modes 1 / 2 / 0 -- the transcendentals are NOT what bounds the kernel; mode 2 equals the literal chain bit for bit in float32)
 int g_mel_fft = 1;       // zeggs_set_option("mel_fft", 0/1): the FFT form (default; n_fft / 2 must factor into 4, 5, 2)
 
 // radices of the half-length transform: 4s first, then 5s, then a 2 (400 = 4 4 5 5); nst = 0: not this path
