@@ -740,7 +740,10 @@ int launch_streamk_cfg(GemmArgs g, hipStream_t s) {
   constexpr int resident = WM * WN > 4 ? 2 : ZEGGS_GEMM_MINB;
   long nwg = (long)ncu * (g_gemm_streamk_wgs > 0 ? g_gemm_streamk_wgs : resident);
   const long total = (long)tx * ty * kt;
-  if (nwg > total / 8) nwg = total / 8 > 0 ? total / 8 : 1;     // at least 8 k-tiles per workgroup
+  // at least 16 k-tiles per workgroup: every workgroup ends in one or two partial-tile epilogues of 64 atomics per lane, and with
+  // 9 k-tiles each (the style encoder's second convolution: 97 tiles x 96 k-tiles over 1 024 workgroups) those were the kernel:
+  // 87.7 us at 4 workgroups per CU, 71.8 us at 2 (tools/style_prof.sh)
+  if (nwg > total / 16) nwg = total / 16 > 0 ? total / 16 : 1;
   dim3 grid((unsigned)nwg), block(WM * WN * 64);
   const bool akc = (g.sak == 1), bkc = (g.sbk == 1) && (g.sbn != 1 || g.N == 1);
   if (!akc && g.sam != 1) { zeggs_set_error("gemm: A has no unit stride (sam=%ld sak=%ld)", g.sam, g.sak); return -1; }

@@ -18,6 +18,9 @@ __device__ __forceinline__ float* rv_row(const RowView& v, long r, int C) {
 }
 
 __global__ void fill_k(float* p, long n, float v) { GS_LOOP(i, n) p[i] = v; }
+// 16-byte stores (p 16-byte aligned, n4 = n / 4 float4s): the zero fills in front of the split / stream-K products and of the flat
+// gradient buffer sit on the serial chains of the iteration
+__global__ void fill4_k(f4* p, long n4, float v) { const f4 vv = f4{v, v, v, v}; GS_LOOP(i, n4) p[i] = vv; }
 __global__ void copy_k(float* d, const float* s, long n) { GS_LOOP(i, n) d[i] = s[i]; }
 __global__ void add_k(float* d, const float* s, long n) { GS_LOOP(i, n) d[i] += s[i]; }
 
@@ -181,6 +184,76 @@ __global__ __launch_bounds__(256) void ln_fwd_fused_k(LnFwdFused a) {
     }
   }
   if (lane == 0) { a.mean[row] = mu; a.rstd[row] = rs; }
+}
+
+// The same pass with 16-byte lanes (round 5; as ln_bwd_fused4_k below): a row is LPR lanes x VJ float4, 64 / LPR rows per wave.
+// C % 4 == 0, every row view 16-byte aligned (k_ln_fwd_fused checks; gamma / beta / table / pre_bias are read 4 bytes at a time:
+// parameter views are only 4-byte aligned).
+template <int LPR, int VJ>
+__global__ __launch_bounds__(256) void ln_fwd_fused4_k(LnFwdFused a) {
+  constexpr int RPW = 64 / LPR, NE = 4 * VJ;
+  const int tid = threadIdx.x, lane = tid & 63, sub = lane / LPR, l = lane % LPR, C = a.C;
+  const int row = (blockIdx.x * 4 + (tid >> 6)) * RPW + sub;
+  const bool rok = row < a.R;
+  const unsigned rr = rok ? row : a.R - 1;
+  float* xr = a.x.rpb == 0 ? a.x.p + (size_t)rr * C : a.x.p + (size_t)(rr / (unsigned)a.x.rpb) * a.x.bstride + (size_t)(rr % (unsigned)a.x.rpb) * C;
+  const float* rp = !a.res.p ? nullptr : a.res.rpb == 0 ? a.res.p + (size_t)rr * C
+                                       : a.res.p + (size_t)(rr / (unsigned)a.res.rpb) * a.res.bstride + (size_t)(rr % (unsigned)a.res.rpb) * C;
+  float* yr = a.y.rpb == 0 ? a.y.p + (size_t)rr * C : a.y.p + (size_t)(rr / (unsigned)a.y.rpb) * a.y.bstride + (size_t)(rr % (unsigned)a.y.rpb) * C;
+  float v[NE];
+  float s = 0.f;
+  const bool wb = a.pre_bias != nullptr || a.p_pre > 0.f;
+#pragma unroll
+  for (int j = 0; j < VJ; ++j) {
+    const int c0 = 4 * (l + LPR * j);
+    const bool ok = c0 < C;
+    f4 xv = ok ? *(const f4*)(xr + c0) : f4{0.f, 0.f, 0.f, 0.f};
+    const f4 rv4 = (ok && rp) ? *(const f4*)(rp + c0) : f4{0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (a.pre_bias) xv[e] = d_act(xv[e] + a.pre_bias[c0 + e], a.pre_act);
+        if (a.p_pre > 0.f) xv[e] *= dropout_scale(a.seed_pre, (uint64_t)((size_t)rr * C + c0 + e), a.p_pre);
+      }
+      if (wb && rok) *(f4*)(xr + c0) = xv;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[4 * j + e] = ok ? xv[e] + rv4[e] : 0.f; s += v[4 * j + e]; }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mu = s / C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < VJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * (l + LPR * j) < C) { const float d = v[4 * j + e] - mu; q += d * d; }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rs = 1.0f / sqrtf(q / C + a.eps);   // biased variance, as torch
+  const float* tb = a.table ? a.table + (size_t)(rr % (unsigned)a.table_L) * C : nullptr;
+  const int pl = a.pad_L > 0 ? (int)(rr % (unsigned)a.pad_L) : -2;
+  if (rok) {
+#pragma unroll
+    for (int j = 0; j < VJ; ++j) {
+      const int c0 = 4 * (l + LPR * j);
+      if (c0 < C) {
+        f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = (v[4 * j + e] - mu) * rs * a.gamma[c0 + e] + a.beta[c0 + e];
+          t *= dropout_scale(a.seed_post, (uint64_t)((size_t)rr * C + c0 + e), a.p_post);
+          if (tb) t += tb[c0 + e];
+          o[e] = t;
+        }
+        *(f4*)(yr + c0) = o;
+        if (pl == 0) *(f4*)(yr + c0 - C) = f4{0.f, 0.f, 0.f, 0.f};
+        if (pl == a.pad_L - 1) *(f4*)(yr + c0 + C) = f4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (l == 0) { a.mean[rr] = mu; a.rstd[rr] = rs; }
+  }
 }
 
 // see kernels.h (LnBwdFused).  One wave per row, 16 rows per block (as layernorm_bwd_k)
@@ -563,6 +636,29 @@ __global__ void pack_conv_w_multi_k(PackConvW4 q) {
   }
 }
 
+// the same through LDS tiles (Kw <= 4): a block moves [Kw][32 ci][32 co]; reads run along co (contiguous in dWf), writes along
+// (ci, j) (contiguous in dW) -- the gather above touches one cache line per element on the read side (1.7 M elements of the style
+// encoder's first convolution: 36 us at the very end of the iteration, behind the last GEMM)
+__global__ __launch_bounds__(256) void unpack_conv_dw_t_k(float* dw, const float* dwf, int Co, int Ci, int Kw) {
+  __shared__ float t[4][32][33];
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8 threads
+  for (int j = 0; j < Kw; ++j)
+    for (int r = ty; r < 32; r += 8) {
+      const int ci = ci0 + r, co = co0 + tx;
+      t[j][r][tx] = (ci < Ci && co < Co) ? dwf[((long)j * Ci + ci) * Co + co] : 0.f;
+    }
+  __syncthreads();
+  const int run = 32 * Kw;                                     // floats of one co row of this tile in dW: (ci0 .. ci0 + 31) x Kw
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r;
+    if (co >= Co) continue;
+    for (int e = tx; e < run; e += 32) {
+      const int cl = e / Kw, j = e - cl * Kw, ci = ci0 + cl;
+      if (ci < Ci) dw[((long)co * Ci + ci) * Kw + j] = t[j][cl][r];
+    }
+  }
+}
+
 __global__ void unpack_conv_dw_k(float* dw, const float* dwf, int Co, int Ci, int Kw) {
   long n = (long)Co * Ci * Kw;
   GS_LOOP(i, n) {
@@ -616,7 +712,16 @@ __global__ void meanpool_bwd_k(float* df, const float* dout, int B, int L, int C
     }                                                                                 \
   } while (0)
 
-int k_fill(float* p, long n, float v, hipStream_t s) { L1D(fill_k, n, s, p, n, v); return 0; }
+int k_fill(float* p, long n, float v, hipStream_t s) {
+  // unaligned head, 16-byte body, tail (one launch when the buffer is aligned and a multiple of four floats: the usual case)
+  const long head = (((size_t)p & 15) && n > 0) ? ((16 - ((size_t)p & 15)) / 4 < (size_t)n ? (long)((16 - ((size_t)p & 15)) / 4) : n) : 0;
+  const long n4 = (n - head) / 4, tail = n - head - 4 * n4;
+  if (n4 < 1024) { L1D(fill_k, n, s, p, n, v); return 0; }
+  if (head) L1D(fill_k, head, s, p, head, v);
+  L1D(fill4_k, n4, s, (f4*)(p + head), n4, v);
+  if (tail) L1D(fill_k, tail, s, p + head + 4 * n4, tail, v);
+  return 0;
+}
 int k_copy(float* d, const float* src, long n, hipStream_t s) { L1D(copy_k, n, s, d, src, n); return 0; }
 int k_add_inplace(float* d, const float* src, long n, hipStream_t s) { L1D(add_k, n, s, d, src, n); return 0; }
 int k_act_bwd(float* dx, const float* dy, const float* y, long n, int act, float ys, hipStream_t s) {
@@ -666,8 +771,17 @@ LnFwdFused ln_fwd_fused_args(int R, int C, float eps) {
   a.R = R; a.C = C; a.eps = eps; a.table_L = 1;
   return a;
 }
+static bool rv_al16_(const RowView& v) { return v.p == nullptr || ((((size_t)v.p) & 15) == 0 && (v.rpb == 0 || v.bstride % 4 == 0)); }
+extern int g_ln_bwd4;
 int k_ln_fwd_fused(const LnFwdFused& a, hipStream_t s) {
   ZCHECK(a.C <= 512, "ln_fwd_fused: C=%d > 512 unsupported", a.C);
+  if (g_ln_bwd4 && a.C % 4 == 0 && a.R > 0 && rv_al16_(a.x) && rv_al16_(a.res) && rv_al16_(a.y) && (long)a.R * a.C < (1L << 31)) {
+    if (a.C <= 128) hipLaunchKernelGGL((ln_fwd_fused4_k<32, 1>), dim3(cdiv(a.R, 8)), dim3(256), 0, s, a);
+    else if (a.C <= 256) hipLaunchKernelGGL((ln_fwd_fused4_k<64, 1>), dim3(cdiv(a.R, 4)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ln_fwd_fused4_k<64, 2>), dim3(cdiv(a.R, 4)), dim3(256), 0, s, a);
+    ZLAUNCH_CHECK("ln_fwd_fused4");
+    return 0;
+  }
   if (a.C <= 128) hipLaunchKernelGGL((ln_fwd_fused_k<2>), dim3(cdiv(a.R, 4)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((ln_fwd_fused_k<8>), dim3(cdiv(a.R, 4)), dim3(256), 0, s, a);
   ZLAUNCH_CHECK("ln_fwd_fused");
@@ -780,6 +894,11 @@ int k_pack_conv_w_multi(const PackConvW* items, int n, hipStream_t s) {
 }
 int k_unpack_conv_dw(float* dw, const float* dwf, int Co, int Ci, int Kw, hipStream_t s) {
   long n = (long)Co * Ci * Kw;
+  if (Kw <= 4 && n >= 65536) {
+    hipLaunchKernelGGL(unpack_conv_dw_t_k, dim3(cdiv(Ci, 32), cdiv(Co, 32)), dim3(256), 0, s, dw, dwf, Co, Ci, Kw);
+    ZLAUNCH_CHECK("unpack_conv_dw_t");
+    return 0;
+  }
   L1D(unpack_conv_dw_k, n, s, dw, dwf, Co, Ci, Kw);
   return 0;
 }

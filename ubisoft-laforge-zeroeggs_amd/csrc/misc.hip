@@ -117,9 +117,6 @@ __global__ void scale_copy_k(float* dst, const float* src, long n, const float* 
   const float a = dev_scale ? alpha * dev_scale[0] : alpha;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = a * src[i];
 }
-__global__ void fill_k2(float* dst, long n, float v) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = v;
-}
 // standard normal samples from the counter hash (two 24-bit uniforms -> Box-Muller); element i depends on (seed, i) only
 __global__ void randn_k(float* out, long n, uint64_t seed) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -236,9 +233,7 @@ extern "C" int zeggs_normalize_rows(float* x, long rows, int width, long ld, con
 
 extern "C" int zeggs_fill(float* dst, long n, float value, void* stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(fill_k2, dim3(g1(n)), dim3(256), 0, (hipStream_t)stream, dst, n, value);
-  ZLAUNCH_CHECK("fill");
-  return 0;
+  return k_fill(dst, n, value, (hipStream_t)stream);      // 16-byte stores (kernels.hip)
 }
 extern "C" int zeggs_scale_copy(float* dst, const float* src, long n, const float* dev_scale, float alpha, void* stream) {
   if (n <= 0) return 0;
