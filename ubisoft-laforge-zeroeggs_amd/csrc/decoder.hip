@@ -81,7 +81,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "poll_stagger") == 0) { g_poll_stagger = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "poll_sleep") == 0) { g_poll_sleep = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "persistent_spin") == 0) { g_persistent_spin = value < 0 ? 0 : value; return 0; }
-  if (strcmp(name, "ln_bwd4") == 0) { g_ln_bwd4 = value != 0; return 0; }
+  if (strcmp(name, "ln_bwd4") == 0) { g_ln_bwd4 = value; return 0; }
   if (strcmp(name, "mel_exact_log") == 0) { g_mel_exact_log = value; return 0; }
   zeggs_set_error("unknown option %s", name);
   return -1;

@@ -806,7 +806,8 @@ int k_ln_bwd_fused(const LnBwdFused& a, hipStream_t s) {
     // 24 cache lines were half of the kernel's 20 us), whole passes per block
     // (wider rows keep 4-wave blocks: two pipelined passes of 8 float4 operands do not fit 16 waves' register budget)
     auto rows_per_block = [&](int rpp, int blocks) { const int per = cdiv(a.R, blocks); return cdiv(per, rpp) * rpp; };
-    if (a.C <= 128) { const int rpb = rows_per_block(32, 256); hipLaunchKernelGGL((ln_bwd_fused4_k<32, 1, 16>), dim3(cdiv(a.R, rpb)), dim3(1024), 0, s, a, rpb); }
+    if (a.C <= 128 && g_ln_bwd4 == 2) { const int rpb = rows_per_block(8, 512); hipLaunchKernelGGL((ln_bwd_fused4_k<32, 1, 4>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb); }
+    else if (a.C <= 128) { const int rpb = rows_per_block(32, 256); hipLaunchKernelGGL((ln_bwd_fused4_k<32, 1, 16>), dim3(cdiv(a.R, rpb)), dim3(1024), 0, s, a, rpb); }
     else if (a.C <= 256) { const int rpb = rows_per_block(8, 256); hipLaunchKernelGGL((ln_bwd_fused4_k<64, 1, 8>), dim3(cdiv(a.R, rpb)), dim3(512), 0, s, a, rpb); }
     else { const int rpb = rows_per_block(4, 512); hipLaunchKernelGGL((ln_bwd_fused4_k<64, 2, 4>), dim3(cdiv(a.R, rpb)), dim3(256), 0, s, a, rpb); }
     ZLAUNCH_CHECK("ln_bwd_fused4");
