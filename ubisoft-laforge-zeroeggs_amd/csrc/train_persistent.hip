@@ -589,7 +589,13 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       wait_phase(p1 - 1);
       TP_FAIL_AT_WAIT;
       TPT(1);
+#ifdef ZEGGS_TP_L2HIT      // (timing experiment, results wrong: the "fresh" blocks are read from the PREVIOUS step's operand -- lines this XCD's L2
+      // already holds -- to measure what the first touch of freshly published data costs a phase: the upper bound of ANY scheme
+      // that would place the hand-off data in the consumer's L2 ahead of the wait; HISTORY round 5)
+      TP_MMA0(TNO0, TNF0, (t > 1 ? x0 - (long)a.KB0 * XB / 4 : x0), wave, TFRW, acc1);
+#else
       TP_MMA0(TNO0, TNF0, x0, wave, TFRW, acc1);  // fresh part
+#endif
     } else {
       zero_g(accg);
       const f4* x0 = (const f4*)(a.G0 + (long)t * a.KB0 * XB) + lane;
@@ -688,7 +694,11 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       wait_phase(p2 - 1);
       TP_FAIL_AT_WAIT;
       TPT(6);
+#ifdef ZEGGS_TP_L2HIT
+      TP_MMA1(TNO1, TNF1, (t > 1 ? x1 - 128L * XB / 4 : x1), wave, 64, acc2);
+#else
       TP_MMA1(TNO1, TNF1, x1, wave, 64, acc2);               // h0_t
+#endif
     } else {
       zero_g(accg);
       const f4* x1 = (const f4*)(a.G1 + (long)t * 128 * XB) + lane;
@@ -787,7 +797,11 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       wait_phase(p3 - 1);
       TP_FAIL_AT_WAIT;
       TPT(11);
+#ifdef ZEGGS_TP_L2HIT
+      tp_mma<NB, TJ0 - TL0, TNO3, TNF3, true>(wr0, wl3, (t > 1 ? x3 - (long)a.KB3 * XB / 4 : x3), wave, 64, acc);
+#else
       tp_mma<NB, TJ0 - TL0, TNO3, TNF3, true>(wr0, wl3, x3, wave, 64, acc);               // h1_t
+#endif
     }
     TPT(12);
     reduce(acc);
