@@ -684,9 +684,10 @@ def main():
             eng.step(indices(it), EXAMPLE_LEN)
             if it + 1 < last and not (a.no_wgrad_overlap or a.no_prefetch):
                 eng.prefetch(indices(it + 1), EXAMPLE_LEN)
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            step_events.append(e)
+            if not os.environ.get("ZEGGS_BENCH_NO_STEP_EVENTS"):      # (tools/gap_probe.sh: does the per-step event cost the iteration anything?)
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                step_events.append(e)
 
     run(0, a.warmup)
     sync()
