@@ -464,6 +464,12 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     return o;
   };
   auto reduce_gate4 = [&](f4 (&acc)[4][NT], f4 (&out)[4]) {
+#ifdef ZEGGS_TP_NORED      // (timing experiment, results wrong: no cross-wave reduction -- every gate thread takes its own wave's partial sums;
+    // what the LDS round trip + barrier + 16 serial reads of the reducing threads cost a GRU phase)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) out[g] = acc[g][0];
+    return;
+#endif
     // one v_permlane32_swap folds the k-halves of TWO values: swap(a, b) = ([a_lo | b_lo], [a_hi | b_hi]), whose sum holds the folded a
     // in lanes < 32 and the folded b in lanes >= 32 -- gates (0, 2) and (1, 3) pair up, every lane has something to store
 #pragma unroll
