@@ -428,7 +428,9 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
 #ifdef ZEGGS_BPSTAT
       const unsigned long long w0 = wall_clock64();
 #endif
+#ifndef ZEGGS_BP_NOPOLL      // (timing experiment, results wrong: nobody waits for anybody -- the step as pure per-CU work)
       if (wave == 1 && !(a.stag ? bp_wait2(a.cnt, (unsigned)(p + 1), a.spin, a.stag) : bp_wait(a.cnt, (unsigned)(p + 1), a.spin, a.nap))) fail = 1;     // (wave 0 of workgroup 0 prepares the root frame meanwhile)
+#endif
 #ifdef ZEGGS_BPSTAT
       wsum[(p + 1) & 3] += wall_clock64() - w0;
 #endif

@@ -90,7 +90,11 @@ __device__ __forceinline__ void stp(float* p, float v) {       // published: wri
 // operand layout.  The "memory" clobber is required (results are corrupted without it) and makes the compiler drain the stores
 // it knows about first, so stp4 goes BEFORE the plain stores of an epilogue (train_bwd_persistent.hip).
 __device__ __forceinline__ void stp4(float* p, f4 v) {
+#ifdef ZEGGS_TP_NOSTP      // (timing experiment, results wrong: nothing is published)
+  asm volatile("" ::"v"(p), "v"(v) : "memory");
+#else
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#endif
 }
 __device__ __forceinline__ long xfi(int b, int k, int NB) {   // B-fragment position of (batch row, k)
   return ((((long)(k >> 4) * NB + (b >> 4)) * 64 + ((((k >> 2) & 3) << 4) | (b & 15))) << 2) | (k & 3);
@@ -538,7 +542,9 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
       // phase's reduction barrier (`fail` is checked there: all waves of a workgroup must meet the same barriers)
       if (!tp_wait(a.cnt, (unsigned)(p + 1), a.spin, (lane & 7) == wave)) fail = 1;
 #else
+#ifndef ZEGGS_TP_NOPOLL      // (timing experiment, results wrong: nobody waits for anybody -- the step as pure per-CU work)
       if (wave == 0 && !(a.stag ? tp_wait2(a.cnt, (unsigned)(p + 1), a.spin, a.stag) : tp_wait(a.cnt, (unsigned)(p + 1), a.spin, true, a.nap))) fail = 1;
+#endif
 #endif
 #ifdef ZEGGS_TPSTAT
       wsum[(p + 1) % 3] += wall_clock64() - w0;
