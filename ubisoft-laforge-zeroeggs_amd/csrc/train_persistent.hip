@@ -287,6 +287,9 @@ __device__ __forceinline__ void tp_mma4(const float (&wq)[NW], const float* wl, 
 #define TPT(i)
 #endif
 
+#ifndef ZEGGS_TP_W0ARRIVE
+#define ZEGGS_TP_W0ARRIVE 0      // (experiment: see arrive_gru)
+#endif
 #ifndef ZEGGS_TP_WAVEWAIT
 #define ZEGGS_TP_WAVEWAIT 0      // (measured: every wave polling for its own producers = 8x the polls: 22.5 -> 24.1 us per step)
 #endif
@@ -489,6 +492,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
         red4[wave][lane < 32 ? g : g + 2][nt][lane & 31] = v;
       }
     __syncthreads();
+    if (ZEGGS_TP_W0ARRIVE == 2 && wave == 0) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int g = 0; g < 4; ++g) out[g] = f4{0.f, 0.f, 0.f, 0.f};
     if (tid < 64 * NT) {
@@ -558,6 +562,18 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store((gu32*)(a.cnt + c), (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // GRU phases in the 4-row form with one batch tile: wave 0 is the only publisher.  Experiment (-DZEGGS_TP_W0ARRIVE=1 / 2): it raises
+  // the flag alone, without the workgroup barrier, so that the other seven waves run the next phase's old-operand products beside
+  // its reduction / gate math / publishes (2: wave 0 at raised priority meanwhile).  Round 3 measured form 1 at +0.5 us per step.
+  auto arrive_gru = [&](long p) {
+    if constexpr (ZEGGS_TP_W0ARRIVE != 0 && T4 && NT == 1) {
+      if (wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) __hip_atomic_store((gu32*)(a.cnt + c), (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ZEGGS_TP_W0ARRIVE == 2) __builtin_amdgcn_s_setprio(0);
+      }
+    } else arrive(p);
   };
 
   GAcc acc1, acc2;              // accumulators of GRU layer 0 / 1: started in the windows of earlier phases
@@ -695,7 +711,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     }
     }
     TPT(4);
-    arrive(p1);
+    arrive_gru(p1);
     TPT(5);
     // ================================================================ GRU layer 1 : [h0_t | h1_{t-1}]
     if constexpr (SPREAD) {
@@ -783,7 +799,7 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_persistent_k(TArgs a) {
     }
     }
     TPT(9);
-    arrive(p2);
+    arrive_gru(p2);
     TPT(10);
     // ================================================================ output stage : [h1_t | cond_{t+1}]
     float gz_[3] = {0.f, 0.f, 0.f};          // gaze target of frame t+1 (an input): in flight under the products
