@@ -250,6 +250,40 @@ def decode_args(de, dev, T):
             st["anim_output_mean"], st["anim_output_std"], synth.DT)
 
 
+def wgrad_gemm_alone(dev, reps=8):
+    """The decoder's two largest weight-gradient products ALONE on the chip, through the LDS-tiled stream-K kernel (round 4) and the
+    barrier-free direct kernel (round 5; csrc/gemm.hip: gemm_tn_direct_kernel): TFLOP/s of fp32 MFMA from HIP events, the zero fill of
+    the output included.  (In the training iteration these products share the chip with two other queues: DESIGN section 3.2.)"""
+    shapes = {"dW_hh 3072x1024 K=8160": (3072, 1024, 8160), "dW_ih0 3072x2286 K=8160": (3072, 2286, 8160)}
+    before = {k: ops._OPTIONS.get(k) for k in ("gemm_direct", "gemm_direct_wgs")}
+    out = {"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "kernels": {}}
+    try:
+        for tag, mode in (("lds_tiled_streamk", 0), ("direct", 1)):
+            ops.set_option("gemm_direct", mode)
+            ops.set_option("gemm_direct_wgs", 0)
+            res = {}
+            for name, (M, N, K) in shapes.items():
+                A, B = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev)
+                Cm = torch.zeros(M, N, device=dev)
+                f = lambda: ops.gemm(A, B, Cm, M, N, K, (1, M), (N, 1), (N, 1))  # noqa: E731
+                f()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    f()
+                e1.record()
+                e1.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / reps
+                res[name] = {"us": round(us, 1), "achieved": round(2.0 * M * N * K / us / 1e6, 1),
+                             "frac": round(2.0 * M * N * K / us / 1e6 / MFMA_F32_PEAK_TFLOPS, 3)}
+            out["kernels"][tag] = res
+    finally:
+        for k, v in before.items():
+            if v is not None:
+                ops.set_option(k, v)
+    return out
+
+
 def decode_rate(de, dev, T=1801):
     """second half of BASELINE.json's metric: autoregressive decode frames/s (B=1, no_grad ring path, speech/style
     already encoded; 30 s of 60-fps frames), with its own roofline entry (75.7 MB of weights per frame)."""
@@ -799,6 +833,7 @@ def main():
                           + ("" if not a.no_prefetch else " (no batch prefetch)"))
         out["cpu_baseline"] = None
         if world == 1 and not a.no_extras:
+            out["wgrad_gemm_alone"] = wgrad_gemm_alone(dev)
             out["decode"] = decode_rate(de, dev)
             out["roofline"]["decode_b1"] = out["decode"]["roofline"]
             out["decode_30min"] = decode_30min(se, de, dev)
