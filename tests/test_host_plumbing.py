@@ -228,3 +228,35 @@ def test_wav_reader_scaling_is_the_exact_division(tmp_path):
     wavfile.write(tmp_path / "b.wav", 8000, x)
     with pytest.raises(ValueError):
         generate.read_wav_mono16k(tmp_path / "b.wav")
+
+
+def test_bvh_load_motion_section_is_found_by_its_own_line(tmp_path):
+    """the MOTION section starts at a LINE that holds only the keyword -- a joint called LOCOMOTION_root (the bytes
+    'MOTION' inside a name) must not cut the header short; a file without the section, or without its Frames / Frame Time lines,
+    raises a ValueError that says so (not an AttributeError on a failed regular expression)."""
+    import pytest
+    names = ["LOCOMOTION_root", "Spine_MOTION", "Head"]
+    parents = np.array([-1, 0, 1])
+    offsets = np.array([[0.0, 90.0, 0.0], [0.0, 10.0, 0.0], [0.0, 20.0, 1.5]], np.float32)
+    rng = np.random.default_rng(2)
+    F = 5
+    pos = np.repeat(offsets[None], F, 0).copy()
+    pos[:, 0] += rng.standard_normal((F, 3)).astype(np.float32)
+    rot = (30 * rng.standard_normal((F, 3, 3))).astype(np.float32)
+    anim.bvh_save(tmp_path / "m.bvh", dict(rotations=rot, positions=pos, offsets=offsets, parents=parents, names=names,
+                                           order="zyx", frametime=1 / 60))
+    clip = anim.bvh_load(tmp_path / "m.bvh")
+    assert list(clip["names"]) == names and clip["rotations"].shape == (F, 3, 3)
+    np.testing.assert_allclose(clip["rotations"], rot, atol=2e-4)
+    np.testing.assert_allclose(clip["positions"][:, 0], pos[:, 0], atol=2e-4)
+    text = (tmp_path / "m.bvh").read_text()
+    head = text[:text.index("\nMOTION")]
+    (tmp_path / "nomotion.bvh").write_text(head + "\n")
+    with pytest.raises(ValueError, match="MOTION"):
+        anim.bvh_load(tmp_path / "nomotion.bvh")
+    (tmp_path / "noframes.bvh").write_text(head + "\nMOTION\nFrame Time: 0.016\n0 0 0\n")
+    with pytest.raises(ValueError, match="Frames"):
+        anim.bvh_load(tmp_path / "noframes.bvh")
+    (tmp_path / "notime.bvh").write_text(head + "\nMOTION\nFrames: 1\n0 0 0\n")
+    with pytest.raises(ValueError, match="Frame Time"):
+        anim.bvh_load(tmp_path / "notime.bvh")
