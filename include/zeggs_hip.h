@@ -115,6 +115,11 @@ typedef struct {
 size_t zeggs_style_encoder_workspace_bytes(const ZeggsStyleDims*);
 int zeggs_style_encoder_fwd(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* x, const float* pos,
                             float* out, void* ws, size_t ws_bytes, void* stream);
+/* the same in two calls: part 1 = the head (weight packs, input padding, the first convolution -- one chip-filling product),
+ * part 2 = the rest, part 3 = both.  For callers that run other streams beside the encoder and want to release them between the
+ * two (zeggs/engine.py); same workspace, same stream, part 1 before part 2. */
+int zeggs_style_encoder_fwd_part(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* x, const float* pos, float* out,
+                                 void* ws, size_t ws_bytes, void* stream, int part);
 int zeggs_style_encoder_bwd(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* dout,
                             const ZeggsStyleGrads*, void* ws, size_t ws_bytes, void* stream);
 int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* dout,

@@ -31,6 +31,9 @@ def _run(overlap, steps=4, B=8, T=24, L=32, clip=None):
     torch.cuda.synchronize()
     # with the side streams the decoder's slice of every optimizer step runs early, on the weight-gradient stream
     assert eng.opt.early_pieces == (steps if overlap else 0), eng.opt.early_pieces
+    # ... and the two side queues are released from INSIDE the style encoder's forward, behind its first convolution (the speech
+    # encoder's graph is still built: its weights above move exactly as in the single-stream schedule)
+    assert eng.head_first_releases == (steps if overlap else 0), eng.head_first_releases
     _run.last_engine = eng
     return eng.flat_p.detach().cpu().numpy().copy(), [float(x.detach()) for x in losses]
 

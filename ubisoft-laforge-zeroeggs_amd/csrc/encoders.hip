@@ -223,6 +223,14 @@ extern "C" size_t zeggs_style_encoder_workspace_bytes(const ZeggsStyleDims* d) {
 // x: [B, L, C] normalised exemplar features; pos: [>=L, E] sinusoidal table; out: [B, E]
 extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyleParams* P, const float* x,
                                        const float* pos, float* out, void* ws, size_t ws_bytes, void* stream) {
+  return zeggs_style_encoder_fwd_part(dp, P, x, pos, out, ws, ws_bytes, stream, 3);
+}
+// part: 1 = the head (weight packs, input padding, the first convolution's product: 43 of the encoder's 52 forward GFLOP, one
+// chip-filling launch), 2 = everything behind it, 3 = both.  A training loop that runs other queues beside the encoder calls the
+// two parts separately and releases those queues BETWEEN them (zeggs/engine.py): the head then has the chip to itself, and the other
+// queues' work runs under the chain of small dependent launches that follows, instead of under the one launch that could use it all.
+extern "C" int zeggs_style_encoder_fwd_part(const ZeggsStyleDims* dp, const ZeggsStyleParams* P, const float* x, const float* pos,
+                                            float* out, void* ws, size_t ws_bytes, void* stream, int part) {
   const ZeggsStyleDims& d = *dp;
   hipStream_t s = (hipStream_t)stream;
   Arena a(ws, ws_bytes);
@@ -233,6 +241,9 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
   const long BL = (long)B * L;
   const float p2 = d.dropout ? 0.2f : 0.f, p1 = d.dropout ? 0.1f : 0.f;
   const float eps = 1e-5f;
+  const bool fuse0 = H <= 512, fuse = E <= 512;
+  const RowView c1v = rv(w.c1, L, (long)LP * H), c2v = rv(w.c2, L, (long)LP * E);
+  if (part & 1) {
   // the four convolutions' weights -> k-major packs, one launch
   {
     const PackConvW items[4] = {{w.wf0, nullptr, P->c0_w, H, C, 3}, {w.wf4, w.wb4, P->c4_w, E, H, 3},
@@ -245,11 +256,11 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
   // tiles per batch entry at full K, 1.5 rounds of tiles on half the CUs, and at N = 128 split + zero fill + bias pass); bias and
   // ReLU are folded into the LayerNorm pass that reads the result anyway (LnFwdFused.pre_bias, written back: the backward's
   // LayerNorm input and ReLU mask).
-  const RowView c1v = rv(w.c1, L, (long)LP * H), c2v = rv(w.c2, L, (long)LP * E);
   ZTRY(k_pad_rows(w.xp, x, B, L, C, 1, 1, 0, s));
-  const bool fuse0 = H <= 512, fuse = E <= 512;
   if (fuse0) ZTRY(conv_flat(w.xp, C, w.wf0, 3 * C, H, w.c1, B * LP - 2, s));
   else ZTRY(conv_gemm(w.xp, (long)LP * C, C, w.wf0, 3 * C, H, w.c1, H, (long)LP * H, P->c0_b, B, L, ACT_RELU, s));
+  }
+  if (!(part & 2)) return 0;
   // LN1 -> interior of padded a1p, dropout, zero edges
   if (fuse0) {     // bias + ReLU + LayerNorm + dropout + the zero edge rows of the next conv's input in one row pass
     LnFwdFused q = ln_fwd_fused_args((int)BL, H, eps);

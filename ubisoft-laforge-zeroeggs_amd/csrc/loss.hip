@@ -11,6 +11,7 @@
 #include "../../include/zeggs_hip.h"
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 // waves of a frame workgroup (64 frames = the lanes; the waves share the joints of a tree level)
 #ifndef ZEGGS_LOSS_WAVES
@@ -157,21 +158,22 @@ __global__ __launch_bounds__(256) void transpose_k(float* dst, const float* src,
 // of a workgroup walk the tree level by level (critical path = tree depth, ~13 for the 75-joint rig, instead of J).
 // Built in LDS by every workgroup (J is small): lvl_start[l] .. lvl_start[l+1] index lvl_joint[].
 constexpr int MAXJ = 256;
-struct Levels { int start[MAXJ + 1]; int joint[MAXJ]; int depth[MAXJ]; int nlevels; };
+struct Levels { int start[MAXJ + 1]; int joint[MAXJ]; int depth[MAXJ]; int par[MAXJ]; int pos[MAXJ]; int nlevels; int maxw; };
 __device__ void build_levels(Levels& L, const int* parents, int J) {
   for (int j = threadIdx.x; j <= J; j += blockDim.x) L.start[j] = 0;
+  for (int j = threadIdx.x; j < J; j += blockDim.x) L.par[j] = parents[j];      // one coalesced load; the chains are walked in LDS
   __syncthreads();
   for (int j = threadIdx.x; j < J; j += blockDim.x) {
     int dpt = 0;
-    for (int p = parents[j]; p >= 0; p = parents[p]) ++dpt;
+    for (int p = L.par[j]; p >= 0; p = L.par[p]) ++dpt;
     L.depth[j] = dpt;
     atomicAdd(&L.start[dpt + 1], 1);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int nl = 0;
-    for (int l = 0; l < J; ++l) { if (L.start[l + 1] > 0) nl = l + 1; L.start[l + 1] += L.start[l]; }
-    L.nlevels = nl;
+    int nl = 0, mw = 0;
+    for (int l = 0; l < J; ++l) { if (L.start[l + 1] > 0) nl = l + 1; mw = max(mw, L.start[l + 1]); L.start[l + 1] += L.start[l]; }
+    L.nlevels = nl; L.maxw = mw;
   }
   __syncthreads();
   for (int j = threadIdx.x; j < J; j += blockDim.x) {   // index order within a level (deterministic)
@@ -179,9 +181,20 @@ __device__ void build_levels(Levels& L, const int* parents, int J) {
     int pos = L.start[dj];
     for (int q = 0; q < j; ++q) pos += (L.depth[q] == dj);
     L.joint[pos] = j;
+    L.pos[j] = pos - L.start[dj];
   }
   __syncthreads();
 }
+// Round 5: the transforms a level hands to the next one (forward: a joint's character-space matrix / position / velocities for
+// its children; backward: a joint's message to its parent) travel through LDS, 18 floats x 64 frames per joint, two level buffers,
+// when no level of the skeleton is wider than LOSS_LW joints (a wider one walks the tables in global memory as before).  The walk's
+// critical path is the tree depth (13 levels for the 75-joint rig, most of them 3-5 joints wide: the waves have little to do and
+// a lot to wait for): through global memory every level paid the write acknowledgement of its stores (the barrier's vmcnt(0)) and
+// an L2 round trip for the loads behind it.  The barrier of the LDS walk waits for LDS only; the table stores drain on their own.
+constexpr int LOSS_LW = 16, LOSS_MSG = 18 * 64;
+constexpr size_t LOSS_LDS_BYTES = (size_t)2 * LOSS_LW * LOSS_MSG * sizeof(float);      // 147 456
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+extern __shared__ float loss_msg[];
 
 // forward per frame; side 0 = prediction (also stores local matrices LM), side 1 = ground truth.
 // One workgroup = 64 consecutive frames (lanes) x 8 waves sharing the joints of each tree level.
@@ -189,7 +202,7 @@ __device__ void build_levels(Levels& L, const int* parents, int J) {
 // depends on the batch only: zeggs_loss_prepare_truth runs it ahead of the step)
 __global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_fwd_k(ZeggsLossDims d, const int* parents, FrameIO io0, FrameIO io1,
                                                         const float* PT0, const float* PT1, const float* gaze, float* F0,
-                                                        float* F1, float* LM, long gid0, long gid_end) {
+                                                        float* F1, float* LM_, long gid0, long gid_end) {
   __shared__ Levels lv;
   const long NF = (long)d.B * d.T;
   build_levels(lv, parents, d.J);
@@ -223,12 +236,42 @@ __global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_fwd_k(ZeggsL
     if (live && wave == 0) FE(F, o.gaze) = gd.x; if (live && wave == 0) FE(F, o.gaze + 1) = gd.y; if (live && wave == 0) FE(F, o.gaze + 2) = gd.z;
   }
   const Col lpos = p + 6, ltxy = p + (6 + 3 * J), lvel = p + (6 + 9 * J), lvrt = p + (6 + 12 * J);
+  const int lane = threadIdx.x & 63;
+  struct FIn { V3 x, yi, lp, lv, lw; };      // a joint's reads from the pose table: independent of the level above it
+  auto fetch = [&](int i) {
+    FIn a;
+    a.x = v3(ltxy[6 * i], ltxy[6 * i + 1], ltxy[6 * i + 2]); a.yi = v3(ltxy[6 * i + 3], ltxy[6 * i + 4], ltxy[6 * i + 5]);
+    a.lp = v3(lpos[3 * i], lpos[3 * i + 1], lpos[3 * i + 2]);
+    a.lv = v3(lvel[3 * i], lvel[3 * i + 1], lvel[3 * i + 2]);
+    a.lw = v3(lvrt[3 * i], lvrt[3 * i + 1], lvrt[3 * i + 2]);
+    return a;
+  };
+  auto walk = [&](auto lm_) {
+  constexpr bool LM = decltype(lm_)::value;
+  FIn cur;
+  bool have = false;
   for (int l = 0; l < lv.nlevels; ++l) {
+   float* mine = loss_msg + (l & 1) * (LOSS_LW * LOSS_MSG) + lane;
+   const float* prev = loss_msg + ((l & 1) ^ 1) * (LOSS_LW * LOSS_MSG) + lane;
    for (int kk = lv.start[l] + wave; kk < lv.start[l + 1]; kk += nwaves) {
     const int i = lv.joint[kk];
+    if (!have) cur = fetch(i);
+    // the LDS walk fetches this wave's NEXT joint (next round of the level, or its first one of the level below) before it
+    // reads the parent's transforms: the table reads are in flight across the barrier
+    FIn nxt;
+    bool nv = false;
+    if constexpr (LM) {
+      int nk = kk + nwaves;
+      nv = nk < lv.start[l + 1];
+      if (!nv && l + 1 < lv.nlevels) { nk = lv.start[l + 1] + wave; nv = nk < lv.start[l + 2]; }
+      if (nv) nxt = fetch(lv.joint[nk]);
+    }
     // orthogonalise (txform.py:23-34): columns x^, y^, z^
-    V3 x = v3(ltxy[6 * i], ltxy[6 * i + 1], ltxy[6 * i + 2]), yi = v3(ltxy[6 * i + 3], ltxy[6 * i + 4], ltxy[6 * i + 5]);
-    for (int k = 0; k < 6; ++k) if (live) FE(F, o.ltxy + 6 * i + k) = ltxy[6 * i + k];
+    V3 x = cur.x, yi = cur.yi;
+    V3 lp = cur.lp, lv_ = cur.lv, lw = cur.lw;
+    cur = nxt; have = nv;
+    if (live) { FE(F, o.ltxy + 6 * i) = x.x; FE(F, o.ltxy + 6 * i + 1) = x.y; FE(F, o.ltxy + 6 * i + 2) = x.z;
+                FE(F, o.ltxy + 6 * i + 3) = yi.x; FE(F, o.ltxy + 6 * i + 4) = yi.y; FE(F, o.ltxy + 6 * i + 5) = yi.z; }
     V3 z = cross(x, yi), y = cross(z, x);
     V3 xn = (1.f / (vnorm(x) + 1e-10f)) * x, yn = (1.f / (vnorm(y) + 1e-10f)) * y, zn = (1.f / (vnorm(z) + 1e-10f)) * z;
     M3 L;
@@ -236,41 +279,59 @@ __global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_fwd_k(ZeggsL
     L.m[3] = xn.y; L.m[4] = yn.y; L.m[5] = zn.y;
     L.m[6] = xn.z; L.m[7] = yn.z; L.m[8] = zn.z;
     if (side == 0)
-      for (int k = 0; k < 9; ++k) if (live) FE(LM, 9 * i + k) = L.m[k];
-    V3 lp = v3(lpos[3 * i], lpos[3 * i + 1], lpos[3 * i + 2]);
-    V3 lv = v3(lvel[3 * i], lvel[3 * i + 1], lvel[3 * i + 2]);
-    V3 lw = v3(lvrt[3 * i], lvrt[3 * i + 1], lvrt[3 * i + 2]);
+      for (int k = 0; k < 9; ++k) if (live) FE(LM_, 9 * i + k) = L.m[k];
     M3 cm; V3 cp, cv, cw;
     if (i == 0) {                               // train.py:296-303: first joint to world space
       V3 rl = quat_mul_vec(q, lp);
       cp = rl + rpos;
       cm = mm(R, L);
-      cv = rvel + quat_mul_vec(q, lv) + cross(rvrt, rl);
+      cv = rvel + quat_mul_vec(q, lv_) + cross(rvrt, rl);
       cw = rvrt + quat_mul_vec(q, lw);
-      lp = cp; lv = cv; lw = cw;               // the "local" loss terms use the replaced joint 0 (train.py:305-308)
+      lp = cp; lv_ = cv; lw = cw;               // the "local" loss terms use the replaced joint 0 (train.py:305-308)
     } else {
-      const int pa = parents[i];
+      const int pa = lv.par[i];
       M3 pm; V3 pp, pv, pw;
+      if constexpr (LM) {                       // the parent's level left them in LDS
+        const float* m = prev + lv.pos[pa] * LOSS_MSG;
+        for (int k = 0; k < 9; ++k) pm.m[k] = m[k * 64];
+        pp = v3(m[9 * 64], m[10 * 64], m[11 * 64]);
+        pv = v3(m[12 * 64], m[13 * 64], m[14 * 64]);
+        pw = v3(m[15 * 64], m[16 * 64], m[17 * 64]);
+      } else {
       for (int k = 0; k < 9; ++k) pm.m[k] = FE(F, o.cmat + 9 * pa + k);
       pp = v3(FE(F, o.cpos + 3 * pa), FE(F, o.cpos + 3 * pa + 1), FE(F, o.cpos + 3 * pa + 2));
       pv = v3(FE(F, o.cvel + 3 * pa), FE(F, o.cvel + 3 * pa + 1), FE(F, o.cvel + 3 * pa + 2));
       pw = v3(FE(F, o.cvrt + 3 * pa), FE(F, o.cvrt + 3 * pa + 1), FE(F, o.cvrt + 3 * pa + 2));
+      }
       V3 rp = mv(pm, lp);
       cp = pp + rp;
       cm = mm(pm, L);
       cw = pw + mv(pm, lw);
-      cv = pv + mv(pm, lv) + cross(pw, rp);
+      cv = pv + mv(pm, lv_) + cross(pw, rp);
     }
-    if (live) FE(F, o.lpos + 3 * i) = lp.x; if (live) FE(F, o.lpos + 3 * i + 1) = lp.y; if (live) FE(F, o.lpos + 3 * i + 2) = lp.z;
-    if (live) FE(F, o.lvel + 3 * i) = lv.x; if (live) FE(F, o.lvel + 3 * i + 1) = lv.y; if (live) FE(F, o.lvel + 3 * i + 2) = lv.z;
-    if (live) FE(F, o.lvrt + 3 * i) = lw.x; if (live) FE(F, o.lvrt + 3 * i + 1) = lw.y; if (live) FE(F, o.lvrt + 3 * i + 2) = lw.z;
-    if (live) FE(F, o.cpos + 3 * i) = cp.x; if (live) FE(F, o.cpos + 3 * i + 1) = cp.y; if (live) FE(F, o.cpos + 3 * i + 2) = cp.z;
-    if (live) FE(F, o.cvel + 3 * i) = cv.x; if (live) FE(F, o.cvel + 3 * i + 1) = cv.y; if (live) FE(F, o.cvel + 3 * i + 2) = cv.z;
-    if (live) FE(F, o.cvrt + 3 * i) = cw.x; if (live) FE(F, o.cvrt + 3 * i + 1) = cw.y; if (live) FE(F, o.cvrt + 3 * i + 2) = cw.z;
-    for (int k = 0; k < 9; ++k) if (live) FE(F, o.cmat + 9 * i + k) = cm.m[k];
+    if constexpr (LM) {
+      float* m = mine + (kk - lv.start[l]) * LOSS_MSG;
+      for (int k = 0; k < 9; ++k) m[k * 64] = cm.m[k];
+      m[9 * 64] = cp.x; m[10 * 64] = cp.y; m[11 * 64] = cp.z;
+      m[12 * 64] = cv.x; m[13 * 64] = cv.y; m[14 * 64] = cv.z;
+      m[15 * 64] = cw.x; m[16 * 64] = cw.y; m[17 * 64] = cw.z;
+    }
+    if (live) {
+    FE(F, o.lpos + 3 * i) = lp.x; FE(F, o.lpos + 3 * i + 1) = lp.y; FE(F, o.lpos + 3 * i + 2) = lp.z;
+    FE(F, o.lvel + 3 * i) = lv_.x; FE(F, o.lvel + 3 * i + 1) = lv_.y; FE(F, o.lvel + 3 * i + 2) = lv_.z;
+    FE(F, o.lvrt + 3 * i) = lw.x; FE(F, o.lvrt + 3 * i + 1) = lw.y; FE(F, o.lvrt + 3 * i + 2) = lw.z;
+    FE(F, o.cpos + 3 * i) = cp.x; FE(F, o.cpos + 3 * i + 1) = cp.y; FE(F, o.cpos + 3 * i + 2) = cp.z;
+    FE(F, o.cvel + 3 * i) = cv.x; FE(F, o.cvel + 3 * i + 1) = cv.y; FE(F, o.cvel + 3 * i + 2) = cv.z;
+    FE(F, o.cvrt + 3 * i) = cw.x; FE(F, o.cvrt + 3 * i + 1) = cw.y; FE(F, o.cvrt + 3 * i + 2) = cw.z;
+    for (int k = 0; k < 9; ++k) FE(F, o.cmat + 9 * i + k) = cm.m[k];
+    }
    }
-   __syncthreads();   // the next level reads these joints' transforms (same CU: L1 is coherent within the workgroup)
+   if constexpr (LM) lds_barrier();   // the next level reads these joints' transforms from LDS; the table stores drain on their own
+   else __syncthreads();              // ... from the tables (same CU: L1 is coherent within the workgroup)
   }
+  };
+  if (lv.maxw <= LOSS_LW) walk(std::true_type{});
+  else walk(std::false_type{});
 }
 
 // term of a feature row e: id/weight of the plain term and of the finite-difference term (id2 < 0: none)
@@ -401,7 +462,7 @@ __global__ __launch_bounds__(256) void loss_terms4_k(ZeggsLossDims d, const floa
 // table DPT), drpos, DQ (grad wrt rrot_f from everything except the root-velocity rotation) and leaves the total grads
 // wrt rvel / rvrt in G's rvel / rvrt rows.
 struct Children { int start[MAXJ + 1]; int idx[MAXJ]; };
-__device__ void build_children(Children& Cn, const int* parents, int J) {
+__device__ void build_children(Children& Cn, const int* parents, int J) {      // parents: the LDS copy (Levels.par)
   for (int j = threadIdx.x; j <= J; j += blockDim.x) Cn.start[j] = 0;
   __syncthreads();
   for (int j = threadIdx.x; j < J; j += blockDim.x)
@@ -420,6 +481,10 @@ __device__ void build_children(Children& Cn, const int* parents, int J) {
   __syncthreads();
 }
 
+// what a joint's backward reads from the tables: nothing of it depends on the level below, so the LDS walk fetches the NEXT
+// joint's while it waits for this one's messages (JIn of joint i of the next level in flight across the barrier)
+struct JIn { M3 pm, L, gcm; V3 pw, lp, lv, lw, gcp, gcv, gcw, glp, glv, glw, x, yi, gx, gyi; };
+
 __global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_bwd_k(ZeggsLossDims d, const int* parents, FrameIO io, const float* gaze,
                                                          const float* PT, const float* F, const float* LM, float* G,
                                                          float* DPT, float* drpos, float* DQ) {
@@ -427,9 +492,9 @@ __global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_bwd_k(ZeggsL
   __shared__ Children ch;
   const long NF = (long)d.B * d.T;
   build_levels(lv, parents, d.J);
-  build_children(ch, parents, d.J);
-  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const long gid = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+  build_children(ch, lv.par, d.J);
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, lane = threadIdx.x & 63;
+  const long gid = (long)blockIdx.x * 64 + lane;
   const bool live = gid < NF;
   const long f = live ? gid : 0;
   const int J = d.J;
@@ -447,9 +512,24 @@ __global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_bwd_k(ZeggsL
   auto st9 = [&](float* A, int e, const M3& m) { if (live) for (int k = 0; k < 9; ++k) A[(long)(e + k) * NF + f] = m.m[k]; };
   auto put3 = [&](const ColW& c, int e, V3 v) { if (live) { c[e] = v.x; c[e + 1] = v.y; c[e + 2] = v.z; } };
 
+  // a joint's table reads (pa < 0, joint 0: no parent rows)
+  auto fetch = [&](int i) {
+    JIn a;
+    const int pa = lv.par[i];
+    if (pa >= 0) { a.pm = ld9(F, o.cmat + 9 * pa); a.pw = ld3(F, o.cvrt + 3 * pa); }
+    a.lp = v3(lpos[3 * i], lpos[3 * i + 1], lpos[3 * i + 2]);
+    a.lv = v3(lvel[3 * i], lvel[3 * i + 1], lvel[3 * i + 2]);
+    a.lw = v3(lvrt[3 * i], lvrt[3 * i + 1], lvrt[3 * i + 2]);
+    a.L = ld9(LM, 9 * i);
+    a.gcp = ld3(G, o.cpos + 3 * i); a.gcv = ld3(G, o.cvel + 3 * i); a.gcw = ld3(G, o.cvrt + 3 * i); a.gcm = ld9(G, o.cmat + 9 * i);
+    a.glp = ld3(G, o.lpos + 3 * i); a.glv = ld3(G, o.lvel + 3 * i); a.glw = ld3(G, o.lvrt + 3 * i);
+    a.x = v3(ltxy[6 * i], ltxy[6 * i + 1], ltxy[6 * i + 2]); a.yi = v3(ltxy[6 * i + 3], ltxy[6 * i + 4], ltxy[6 * i + 5]);
+    a.gx = ld3(G, o.ltxy + 6 * i); a.gyi = ld3(G, o.ltxy + 6 * i + 3);
+    return a;
+  };
   // orthogonalisation backward for joint i given the grad of its local matrix; adds the direct ltxy-term grad
-  auto orth_bwd = [&](int i, const M3& gL) {
-    V3 x = v3(ltxy[6 * i], ltxy[6 * i + 1], ltxy[6 * i + 2]), yi = v3(ltxy[6 * i + 3], ltxy[6 * i + 4], ltxy[6 * i + 5]);
+  auto orth_bwd = [&](int i, const M3& gL, const JIn& a) {
+    V3 x = a.x, yi = a.yi;
     V3 z = cross(x, yi), y = cross(z, x);
     V3 gxn = v3(gL.m[0], gL.m[3], gL.m[6]), gyn = v3(gL.m[1], gL.m[4], gL.m[7]), gzn = v3(gL.m[2], gL.m[5], gL.m[8]);
     V3 gx = normalize_bwd(x, gxn, 1e-10f);
@@ -459,78 +539,114 @@ __global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_bwd_k(ZeggsL
     gx = gx + cross(gy, z);
     gx = gx + cross(yi, gz);         // z = x x yi
     V3 gyi = cross(gz, x);
-    put3(dltxy, 6 * i, gx + ld3(G, o.ltxy + 6 * i));
-    put3(dltxy, 6 * i + 3, gyi + ld3(G, o.ltxy + 6 * i + 3));
+    put3(dltxy, 6 * i, gx + a.gx);
+    put3(dltxy, 6 * i + 3, gyi + a.gyi);
   };
-  // totals of joint i's character-space gradients: own rows + children's messages
-  auto gather = [&](int i, V3& gcp, V3& gcv, V3& gcw, M3& gcm) {
-    gcp = ld3(G, o.cpos + 3 * i); gcv = ld3(G, o.cvel + 3 * i); gcw = ld3(G, o.cvrt + 3 * i); gcm = ld9(G, o.cmat + 9 * i);
+  // totals of joint i's character-space gradients: own rows (already in a) + children's messages (msgs != nullptr: the
+  // children's level left them in LDS -- (dm, gcp, gcv, dw), 18 rows of 64 frames per joint -- instead of in their c* rows of G)
+  auto gather = [&](int i, JIn& a, const float* msgs) {
     for (int c = ch.start[i]; c < ch.start[i + 1]; ++c) {
       const int j = ch.idx[c];
-      gcp = gcp + ld3(G, o.cpos + 3 * j); gcv = gcv + ld3(G, o.cvel + 3 * j); gcw = gcw + ld3(G, o.cvrt + 3 * j);
-      const M3 m = ld9(G, o.cmat + 9 * j);
-      for (int k = 0; k < 9; ++k) gcm.m[k] += m.m[k];
+      if (msgs) {
+        const float* m = msgs + lv.pos[j] * LOSS_MSG;
+        a.gcp = a.gcp + v3(m[9 * 64], m[10 * 64], m[11 * 64]); a.gcv = a.gcv + v3(m[12 * 64], m[13 * 64], m[14 * 64]);
+        a.gcw = a.gcw + v3(m[15 * 64], m[16 * 64], m[17 * 64]);
+        for (int k = 0; k < 9; ++k) a.gcm.m[k] += m[k * 64];
+      } else {
+        a.gcp = a.gcp + ld3(G, o.cpos + 3 * j); a.gcv = a.gcv + ld3(G, o.cvel + 3 * j); a.gcw = a.gcw + ld3(G, o.cvrt + 3 * j);
+        const M3 m = ld9(G, o.cmat + 9 * j);
+        for (int k = 0; k < 9; ++k) a.gcm.m[k] += m.m[k];
+      }
     }
   };
-
-  for (int l = lv.nlevels - 1; l >= 1; --l) {
-    for (int kk = lv.start[l] + wave; kk < lv.start[l + 1]; kk += nwaves) {
-      const int i = lv.joint[kk];
-      const int pa = parents[i];
-      M3 pm = ld9(F, o.cmat + 9 * pa);
-      V3 pw = ld3(F, o.cvrt + 3 * pa);
-      V3 lp = v3(lpos[3 * i], lpos[3 * i + 1], lpos[3 * i + 2]);
-      V3 lv_ = v3(lvel[3 * i], lvel[3 * i + 1], lvel[3 * i + 2]);
-      V3 lw = v3(lvrt[3 * i], lvrt[3 * i + 1], lvrt[3 * i + 2]);
-      M3 L = ld9(LM, 9 * i);
-      V3 rp = mv(pm, lp);
-      V3 gcp, gcv, gcw;
-      M3 gcm;
-      gather(i, gcp, gcv, gcw, gcm);
-      // message to the parent: (dm, gcp, gcv, dw)
-      M3 dm;
-      for (int k = 0; k < 9; ++k) dm.m[k] = 0.f;
-      // cvel_i = cvel_p + pm lv + pw x rp
-      add_outer(dm, gcv, lv_);
-      V3 glv = mtv(pm, gcv);
-      V3 dw = cross(rp, gcv);
-      V3 grp = cross(gcv, pw);
-      // cvrt_i = cvrt_p + pm lw
-      dw = dw + gcw;
-      add_outer(dm, gcw, lw);
-      V3 glw = mtv(pm, gcw);
-      // cmat_i = pm L
-      M3 t1 = mmt(gcm, L);
-      for (int k = 0; k < 9; ++k) dm.m[k] += t1.m[k];
-      M3 gL = mtm(pm, gcm);
-      // cpos_i = cpos_p + rp
-      grp = grp + gcp;
-      add_outer(dm, grp, lp);
-      V3 glp = mtv(pm, grp);
+  // joint i (not the root joint): message to the parent (dm, gcp, gcv, dw) -> `mine` (LDS) or its own c* rows of G; local gradients
+  auto joint = [&](int i, JIn& a, const float* below, float* mine) {
+    const V3 rp = mv(a.pm, a.lp);
+    gather(i, a, below);
+    M3 dm;
+    for (int k = 0; k < 9; ++k) dm.m[k] = 0.f;
+    // cvel_i = cvel_p + pm lv + pw x rp
+    add_outer(dm, a.gcv, a.lv);
+    V3 glv = mtv(a.pm, a.gcv);
+    V3 dw = cross(rp, a.gcv);
+    V3 grp = cross(a.gcv, a.pw);
+    // cvrt_i = cvrt_p + pm lw
+    dw = dw + a.gcw;
+    add_outer(dm, a.gcw, a.lw);
+    V3 glw = mtv(a.pm, a.gcw);
+    // cmat_i = pm L
+    M3 t1 = mmt(a.gcm, a.L);
+    for (int k = 0; k < 9; ++k) dm.m[k] += t1.m[k];
+    M3 gL = mtm(a.pm, a.gcm);
+    // cpos_i = cpos_p + rp
+    grp = grp + a.gcp;
+    add_outer(dm, grp, a.lp);
+    V3 glp = mtv(a.pm, grp);
+    if (mine) {
+      for (int k = 0; k < 9; ++k) mine[k * 64] = dm.m[k];
+      mine[9 * 64] = a.gcp.x; mine[10 * 64] = a.gcp.y; mine[11 * 64] = a.gcp.z;
+      mine[12 * 64] = a.gcv.x; mine[13 * 64] = a.gcv.y; mine[14 * 64] = a.gcv.z;
+      mine[15 * 64] = dw.x; mine[16 * 64] = dw.y; mine[17 * 64] = dw.z;
+    } else {
       st9(G, o.cmat + 9 * i, dm);
-      st3(G, o.cpos + 3 * i, gcp); st3(G, o.cvel + 3 * i, gcv); st3(G, o.cvrt + 3 * i, dw);
-      // local features (direct "local" loss terms + FK)
-      put3(dlpos, 3 * i, glp + ld3(G, o.lpos + 3 * i));
-      put3(dlvel, 3 * i, glv + ld3(G, o.lvel + 3 * i));
-      put3(dlvrt, 3 * i, glw + ld3(G, o.lvrt + 3 * i));
-      orth_bwd(i, gL);
+      st3(G, o.cpos + 3 * i, a.gcp); st3(G, o.cvel + 3 * i, a.gcv); st3(G, o.cvrt + 3 * i, dw);
     }
-    __syncthreads();
+    // local features (direct "local" loss terms + FK)
+    put3(dlpos, 3 * i, glp + a.glp);
+    put3(dlvel, 3 * i, glv + a.glv);
+    put3(dlvrt, 3 * i, glw + a.glw);
+    orth_bwd(i, gL, a);
+  };
+
+  const bool lds_walk = lv.maxw <= LOSS_LW;
+  JIn root;                                   // joint 0's reads (wave 0): fetched under the walk as well
+  if (lds_walk) {
+    JIn cur;
+    bool have = false;
+    for (int l = lv.nlevels - 1; l >= 1; --l) {
+      float* mine = loss_msg + (l & 1) * (LOSS_LW * LOSS_MSG) + lane;
+      const float* below = loss_msg + ((l & 1) ^ 1) * (LOSS_LW * LOSS_MSG) + lane;
+      for (int kk = lv.start[l] + wave; kk < lv.start[l + 1]; kk += nwaves) {
+        const int i = lv.joint[kk];
+        if (!have) cur = fetch(i);
+        // this wave's next joint: the next round of this level, or its first one of the level above (wave 0 at level 1: the root)
+        int nk = kk + nwaves;
+        bool nv = nk < lv.start[l + 1];
+        if (!nv) { nk = lv.start[l - 1] + wave; nv = nk < lv.start[l]; }
+        JIn nxt;
+        if (nv) nxt = fetch(lv.joint[nk]);
+        joint(i, cur, below, mine + (kk - lv.start[l]) * LOSS_MSG);
+        cur = nxt; have = nv;
+      }
+      lds_barrier();
+    }
+    if (wave != 0) return;
+    root = have ? cur : fetch(0);             // (level 0 is the root joint alone: wave 0's "next" at level 1 was joint 0)
+  } else {
+    for (int l = lv.nlevels - 1; l >= 1; --l) {
+      for (int kk = lv.start[l] + wave; kk < lv.start[l + 1]; kk += nwaves) {
+        const int i = lv.joint[kk];
+        JIn a = fetch(i);
+        joint(i, a, nullptr, nullptr);
+      }
+      __syncthreads();
+    }
+    if (wave != 0) return;
+    root = fetch(0);
   }
-  if (wave != 0) return;
   // ---- joint 0: world-space replacement (train.py:296-308)
   {
     V3 rvrt = ld3(F, o.rvrt);
     M3 R = quat_to_xform(q);
-    M3 L = ld9(LM, 0);
-    V3 lp = v3(lpos[0], lpos[1], lpos[2]), lv_ = v3(lvel[0], lvel[1], lvel[2]), lw = v3(lvrt[0], lvrt[1], lvrt[2]);
+    M3 L = root.L;
+    V3 lp = root.lp, lv_ = root.lv, lw = root.lw;
     V3 rl = quat_mul_vec(q, lp);
-    V3 gcp, gcv, gcw;
-    M3 gcm;
-    gather(0, gcp, gcv, gcw, gcm);
-    gcp = gcp + ld3(G, o.lpos);      // joint 0 appears in the c* and in the "local" terms
-    gcv = gcv + ld3(G, o.lvel);
-    gcw = gcw + ld3(G, o.lvrt);
+    gather(0, root, lds_walk ? loss_msg + (LOSS_LW * LOSS_MSG) + lane : nullptr);      // level 1's messages: buffer 1
+    V3 gcp = root.gcp, gcv = root.gcv, gcw = root.gcw;
+    M3 gcm = root.gcm;
+    gcp = gcp + root.glp;      // joint 0 appears in the c* and in the "local" terms
+    gcv = gcv + root.glv;
+    gcw = gcw + root.glw;
     V3 g_rpos = ld3(G, o.rpos) + gcp;
     V3 g_rvel = ld3(G, o.rvel) + gcv;
     V3 g_rvrt = ld3(G, o.rvrt) + gcw + cross(rl, gcv);
@@ -548,7 +664,7 @@ __global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_bwd_k(ZeggsL
     // lmat0w = R L
     M3 gR = mmt(gcm, L);
     M3 gL = mtm(R, gcm);
-    orth_bwd(0, gL);
+    orth_bwd(0, gL, root);
     M3 gRm = ld9(G, o.rmat);
     for (int k = 0; k < 9; ++k) gR.m[k] += gRm.m[k];
     dqt = quat_to_xform_bwd(q, gR);
@@ -611,11 +727,26 @@ __global__ __launch_bounds__(1024) void loss_kl_final_k(const float* mu, const f
   if (partial) {        // term sums of loss_terms4_k's workgroups (LDS atomics: 18 words, one workgroup)
     if (threadIdx.x < 18) tsum[threadIdx.x] = 0.f;
     __syncthreads();
-    for (int i = threadIdx.x; i < nrows * LOSS_TSPLIT; i += blockDim.x) {
-      int id, id2, size; float w, w2;
-      term_of(i / LOSS_TSPLIT, J, id, w, id2, w2, size);
-      atomicAdd(&tsum[id], partial[2 * i]);
-      if (id2 >= 0) atomicAdd(&tsum[id2], partial[2 * i + 1]);
+    // consecutive rows belong to the same term (a wave sees one to three of them): summed per term across the wave first -- 64 lanes'
+    // atomics onto ONE LDS word serialise, which made this reduction 13 of the kernel's 18 us
+    const int lane = threadIdx.x & 63, total = nrows * LOSS_TSPLIT;
+    auto add_by_key = [&](int key, float v) {       // key < 0: lane takes no part
+      unsigned long long todo = __ballot(key >= 0);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader, 64);
+        const bool mine = key == k;
+        const float sum = wave_sum(mine ? v : 0.f);
+        if (lane == leader) atomicAdd(&tsum[k], sum);
+        todo &= ~__ballot(mine);
+      }
+    };
+    for (int i0 = threadIdx.x - lane; i0 < total; i0 += blockDim.x) {
+      const int i = i0 + lane;
+      int id = -1, id2 = -1, size; float w, w2;
+      if (i < total) term_of(i / LOSS_TSPLIT, J, id, w, id2, w2, size);
+      add_by_key(id, i < total ? partial[2 * i] : 0.f);
+      add_by_key(id2, id2 >= 0 ? partial[2 * i + 1] : 0.f);
     }
     __syncthreads();
     if (threadIdx.x < 17) terms[threadIdx.x] += tsum[threadIdx.x];
@@ -644,6 +775,16 @@ __global__ __launch_bounds__(1024) void loss_kl_final_k(const float* mu, const f
 
 }  // namespace
 
+// the frame kernels' message buffers (dynamic LDS above the 64 KB default)
+static int loss_lds_ready() {
+  static int ok = -1;
+  if (ok < 0) {
+    ok = hipFuncSetAttribute((const void*)loss_frame_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LOSS_LDS_BYTES) == hipSuccess &&
+         hipFuncSetAttribute((const void*)loss_frame_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LOSS_LDS_BYTES) == hipSuccess;
+  }
+  return ok;
+}
+
 extern "C" size_t zeggs_loss_workspace_bytes(const ZeggsLossDims* d) {
   Arena a(nullptr, 0);
   carve_loss(*d, a);
@@ -661,11 +802,12 @@ extern "C" int zeggs_loss_prepare_truth(const ZeggsLossDims* dp, const int* pare
   LossWs w = carve_loss(d, a);
   ZCHECK(a.ok(), "loss: workspace too small (%zu < %zu)", ws_bytes, a.off);
   ZCHECK(d.J >= 1 && d.J <= MAXJ && d.T >= 1 && d.B >= 1, "loss: bad dims");
+  ZCHECK(loss_lds_ready(), "loss: the frame kernels' LDS size was refused");
   const long NF = (long)d.B * d.T;
   const int PO = 6 + 15 * d.J;
   FrameIO ioW{w_pose, w_rpos, w_rrot};
   hipLaunchKernelGGL(transpose_k, dim3((unsigned)cdiv(NF, 64), (unsigned)cdiv(PO, 64)), dim3(256), 0, s, w.PT1, w_pose, NF, PO);
-  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(NF, 64)), dim3(64 * ZEGGS_LOSS_WAVES), 0, s, d, parents, ioW, ioW, w.PT1, w.PT1, gaze, w.FW, w.FW,
+  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(NF, 64)), dim3(64 * ZEGGS_LOSS_WAVES), LOSS_LDS_BYTES, s, d, parents, ioW, ioW, w.PT1, w.PT1, gaze, w.FW, w.FW,
                      w.LM, NF, 2 * NF);
   ZLAUNCH_CHECK("loss_prepare_truth");
   return 0;
@@ -690,6 +832,7 @@ extern "C" int zeggs_loss_fwd_bwd_ex(const ZeggsLossDims* dp, const int* parents
   LossWs w = carve_loss(d, a);
   ZCHECK(a.ok(), "loss: workspace too small (%zu < %zu)", ws_bytes, a.off);
   ZCHECK(d.J >= 1 && d.T >= 1 && d.B >= 1, "loss: bad dims");
+  ZCHECK(loss_lds_ready(), "loss: the frame kernels' LDS size was refused");
   const long NF = (long)d.B * d.T;
   const Off o = offsets(d.J);
   FrameIO ioO{o_pose, o_rpos, o_rrot}, ioW{w_pose, w_rpos, w_rrot};
@@ -701,7 +844,7 @@ extern "C" int zeggs_loss_fwd_bwd_ex(const ZeggsLossDims* dp, const int* parents
   ZCHECK(d.J <= MAXJ, "loss: more than %d joints", MAXJ);
   // (truth_prepared: zeggs_loss_prepare_truth has filled PT1 / FW of THIS workspace; only the prediction side is left)
   const long gend = truth_prepared ? NF : 2 * NF;
-  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(gend, 64)), dim3(64 * ZEGGS_LOSS_WAVES), 0, s, d, parents, ioO, ioW, w.PT0, w.PT1, gaze, w.FO,
+  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(gend, 64)), dim3(64 * ZEGGS_LOSS_WAVES), LOSS_LDS_BYTES, s, d, parents, ioO, ioW, w.PT0, w.PT1, gaze, w.FO,
                      w.FW, w.LM, 0L, gend);
   ZLAUNCH_CHECK("loss_frame_fwd");
   if (d.T % 4 == 0 && ((uintptr_t)w.FO % 16 == 0) && ((uintptr_t)w.FW % 16 == 0) && ((uintptr_t)w.G % 16 == 0))      // (= vec4 below)
@@ -714,7 +857,7 @@ extern "C" int zeggs_loss_fwd_bwd_ex(const ZeggsLossDims* dp, const int* parents
                      gscale, vec4 ? w.PS : (const float*)nullptr, o.n, d.J);
   ZLAUNCH_CHECK("loss_kl_final");
   if (dpose) {
-    hipLaunchKernelGGL(loss_frame_bwd_k, dim3(cdiv(NF, 64)), dim3(64 * ZEGGS_LOSS_WAVES), 0, s, d, parents, ioO, gaze, w.PT0, w.FO, w.LM, w.G,
+    hipLaunchKernelGGL(loss_frame_bwd_k, dim3(cdiv(NF, 64)), dim3(64 * ZEGGS_LOSS_WAVES), LOSS_LDS_BYTES, s, d, parents, ioO, gaze, w.PT0, w.FO, w.LM, w.G,
                        w.DPT, drpos, w.DQ);
     ZLAUNCH_CHECK("loss_frame_bwd");
     // back to [frame][PO] (columns 0..5 hold nothing yet: the root-velocity kernel below writes them)

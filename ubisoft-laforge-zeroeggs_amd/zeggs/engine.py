@@ -10,6 +10,7 @@ contiguous slice of the global batch; gradients are averaged with ONE all-reduce
 """
 import collections
 import copy
+import os
 import warnings
 
 import numpy as np
@@ -207,7 +208,8 @@ def flatten_parameters(modules):
 class TrainEngine:
     def __init__(self, speech_encoder, decoder, style_encoder, dataset, parents, dt, lr=1e-4, eps=1e-5,
                  style_encoding_type="example", world_size=1, rank=0, process_group=None, force_allreduce=False,
-                 overlap_allreduce=True, overlap_wgrads=True, early_decoder_step=True, noise_seed=None):
+                 overlap_allreduce=True, overlap_wgrads=True, early_decoder_step=True, noise_seed=None,
+                 style_head_first=3):
         self.se, self.de, self.st = speech_encoder, decoder, style_encoder
         # everything the binding needs beyond the arguments of a call (gradient targets, side stream, status words, hooks,
         # the prepared decoder workspace, optionally an own noise-seed stream) travels in THIS engine's context object --
@@ -216,6 +218,8 @@ class TrainEngine:
         if noise_seed is not None:
             self.ctx.seed_rng = np.random.default_rng(int(noise_seed))
         self.early_decoder_step = early_decoder_step
+        self.head_first_releases = 0        # steps whose side queues were released from inside the style encoder's forward
+        self.style_head_first = int(os.environ.get("ZEGGS_STYLE_HEAD_FIRST", style_head_first))
         self.ds = dataset
         self.dt = float(dt)
         self.world, self.rank, self.pg = world_size, rank, process_group
@@ -277,7 +281,6 @@ class TrainEngine:
         self._rearm_at = None               # iteration at which the persistent sweeps are switched back on
         self._rearmed_at = None             # iteration of the last re-arm (a give-up within `_rearm_wait` of it backs off)
         self.rearm_count = 0
-        import os
         if torch.device(dev).type == "cuda" and not os.environ.get("ZEGGS_NO_GUARD"):     # (env: A/B measurement of its cost)
             self.status = ops.new_status(dev)
             self.opt.attach_guard(self.status, self._gflag if (world_size > 1 or force_allreduce) else None)
@@ -481,23 +484,50 @@ class TrainEngine:
         try:
             with ops.use(ctx):
                 cur = torch.cuda.current_stream() if self.aux_stream is not None else None
-                if self.wgrad_stream is not None and self._dec_shape is not None and self._dec_shape[0] == len(idx):
-                    # the weight-only packs of the decoder sweeps, beside the encoders' forward
-                    Bd, SP, ST = self._dec_shape
-                    ops.decoder_prepare(self.de, Bd, T, SP, ST, ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, self.dt,
-                                        self.wgrad_stream)
-                if self.aux_stream is not None:
-                    self.aux_stream.wait_stream(cur)            # the batch was gathered on the current stream
-                    b["audio"].record_stream(self.aux_stream)
-                    with torch.cuda.stream(self.aux_stream):
-                        speech = self.se(b["audio"])
-                else:
-                    speech = self.se(b["audio"])
+                box = {}
+
+                def launch_prepare():
+                    if self.wgrad_stream is not None and self._dec_shape is not None and self._dec_shape[0] == len(idx):
+                        # the weight-only packs of the decoder sweeps, beside the encoders' forward
+                        Bd, SP, ST = self._dec_shape
+                        ops.decoder_prepare(self.de, Bd, T, SP, ST, ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, self.dt,
+                                            self.wgrad_stream)
+
+                def launch_speech():
+                    if self.aux_stream is not None:
+                        self.aux_stream.wait_stream(cur)            # the batch was gathered on the current stream
+                        b["audio"].record_stream(self.aux_stream)
+                        with torch.cuda.stream(self.aux_stream):
+                            box["speech"] = self.se(b["audio"])
+                    else:
+                        box["speech"] = self.se(b["audio"])
+
+                # style_head_first (bit 0: the decoder's packs, bit 1: the speech encoder): these queues are released only BEHIND
+                # the style encoder's first convolution (ops._StyleFn calls the hook between the two parts of
+                # zeggs_style_encoder_fwd_part), which fills the chip on its own and heads the longest chain before the sweep
+                held = []
+                example = self.style_type == "example"
+                side = self.aux_stream is not None and self.wgrad_stream is not None
+                for bit, fn in ((1, launch_prepare), (2, launch_speech)):
+                    if example and side and self.style_head_first & bit:
+                        held.append(fn)
+                    else:
+                        fn()
+
+                def release(inside=False):
+                    ctx.after_style_head = None
+                    self.head_first_releases += bool(held and inside)
+                    with torch.enable_grad():       # (called from inside an autograd.Function's forward, where grad mode is off)
+                        while held:
+                            held.pop(0)()
+                ctx.after_style_head = (lambda: release(True)) if held else None
                 mu = logvar = None
-                if self.style_type == "example":
+                if example:
                     z, mu, logvar = self.st(b["example"], 1.0, eps=eps)
                 else:
                     z = labels
+                release()                   # (a style module that did not go through ops.style_encoder: nothing was held back)
+                speech = box["speech"]
                 style = ops.broadcast_time(z, T)
                 if self.aux_stream is not None:
                     cur.wait_stream(self.aux_stream)
@@ -527,6 +557,7 @@ class TrainEngine:
                     self.decoder_bwd_events.append((e2, e3))
             done = True
         finally:
+            ctx.after_style_head = None
             if not done:
                 # the step did not complete (OOM, an error in a backward, KeyboardInterrupt): forget the slices the optimizer
                 # may already have applied early -- a stale list would make the NEXT step() skip the decoder slice -- and give

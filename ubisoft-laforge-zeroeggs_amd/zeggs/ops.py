@@ -148,6 +148,7 @@ class EngineContext:
         self.direct_grads = False          # *_bwd kernels write parameter gradients straight into the parameters' .grad
         self.wgrad_stream = None           # torch stream of the decoder's deferred weight-gradient GEMMs (ZeggsDecCall)
         self.status = None                 # device status words of the training-mode decoder calls (ZeggsDecCall.status)
+        self.after_style_head = None       # hook fn(): the style encoder's first product is enqueued (engine.style_head_first)
         self.after_decoder_backward = None # hook fn(part): decoder gradients final in stream order (data-parallel exchange)
         self.decoder_grads_final = None    # hook fn(): runs on wgrad_stream behind ALL decoder gradients (early RAdam slice)
         self.prepared = None               # (key, workspace, event, mask) of decoder_prepare, until a forward picks it up
@@ -396,8 +397,16 @@ class _StyleFn(torch.autograd.Function):
         ws = _ws(L.zeggs_style_encoder_workspace_bytes(C.byref(d)), x.device)
         out = torch.empty(B, E, device=x.device, dtype=torch.float32)
         P = _ptrs(StylePtrs, STYLE_FIELDS, params)
-        _check(L.zeggs_style_encoder_fwd(C.byref(d), C.byref(P), _p(x), _p(pos), _p(out), _p(ws),
-                                         C.c_size_t(ws.numel()), _stream()), "style_encoder_fwd")
+        hook = getattr(ctx.ectx, "after_style_head", None)
+        if hook is not None:       # (an engine that releases its other queues once the chip-filling first product is enqueued)
+            _check(L.zeggs_style_encoder_fwd_part(C.byref(d), C.byref(P), _p(x), _p(pos), _p(out), _p(ws),
+                                                  C.c_size_t(ws.numel()), _stream(), 1), "style_encoder_fwd (head)")
+            hook()
+            _check(L.zeggs_style_encoder_fwd_part(C.byref(d), C.byref(P), _p(x), _p(pos), _p(out), _p(ws),
+                                                  C.c_size_t(ws.numel()), _stream(), 2), "style_encoder_fwd (rest)")
+        else:
+            _check(L.zeggs_style_encoder_fwd(C.byref(d), C.byref(P), _p(x), _p(pos), _p(out), _p(ws),
+                                             C.c_size_t(ws.numel()), _stream()), "style_encoder_fwd")
         ctx.d, ctx.ws = d, ws
         ctx.save_for_backward(*params)
         return out
