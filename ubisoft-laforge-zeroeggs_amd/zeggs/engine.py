@@ -218,6 +218,7 @@ class TrainEngine:
         if noise_seed is not None:
             self.ctx.seed_rng = np.random.default_rng(int(noise_seed))
         self.early_decoder_step = early_decoder_step
+        self.prepare_ahead = bool(int(os.environ.get("ZEGGS_PREPARE_AHEAD", "1")))
         self.head_first_releases = 0        # steps whose side queues were released from inside the style encoder's forward
         self.style_head_first = int(os.environ.get("ZEGGS_STYLE_HEAD_FIRST", style_head_first))
         self.ds = dataset
@@ -487,6 +488,8 @@ class TrainEngine:
                 box = {}
 
                 def launch_prepare():
+                    if ctx.prepared is not None and ctx.prepared[0][0] == len(idx):
+                        return              # made at the end of the previous step (prepare_ahead)
                     if self.wgrad_stream is not None and self._dec_shape is not None and self._dec_shape[0] == len(idx):
                         # the weight-only packs of the decoder sweeps, beside the encoders' forward
                         Bd, SP, ST = self._dec_shape
@@ -595,6 +598,14 @@ class TrainEngine:
             a1.record()
             self.allreduce_events.append((a0, a1))
         self.opt.step()
+        if self.prepare_ahead and self.wgrad_stream is not None and self._dec_shape is not None and not _replay:
+            # the NEXT step's weight-only packs, as soon as the optimizer is through: the second queue does the fold products in
+            # the gap between two iterations and under the style encoder's input staging instead of beside its tail (the
+            # forward checks shape, weight pointers and version counters before it picks the workspace up)
+            Bd, SP, ST = self._dec_shape
+            with ops.use(ctx):
+                ops.decoder_prepare(self.de, Bd, T, SP, ST, ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, self.dt,
+                                    self.wgrad_stream)
         if self.status is not None:
             self._post_status()
         self.iteration += 1

@@ -529,6 +529,13 @@ def _drop_prepared(ectx):
         torch.cuda.current_stream().wait_event(prep[2])
 
 
+def _versions(params):
+    """autograd version counters of the weights a preparation was made from: an in-place torch operation on them in between (a
+    loaded checkpoint, a replayed snapshot, a hand edit) makes the forward ignore the packs and make its own.  (The engine's
+    own optimizer kernels write through raw pointers and do not count -- they run BEFORE the preparation.)"""
+    return tuple(int(t._version) for t in params)
+
+
 def decoder_prepare(dec, B, T, SP, ST, in_mean, in_std, out_mean, out_std, dt, stream):
     """Weight-only preparation of the NEXT training-mode decoder_core call of THIS context (ops.use) with these dimensions
     (zeggs_decoder_prepare) on `stream`, beside whatever the current stream does meanwhile (the encoders' forward); that
@@ -554,7 +561,7 @@ def decoder_prepare(dec, B, T, SP, ST, in_mean, in_std, out_mean, out_std, dt, s
         ev = torch.cuda.Event()
         ev.record(stream)
     if mask > 0:
-        key = (d.B, d.T, d.PI, d.PO, d.SP, d.ST, d.H, d.film, tuple(t.data_ptr() for t in params))
+        key = (d.B, d.T, d.PI, d.PO, d.SP, d.ST, d.H, d.film, tuple(t.data_ptr() for t in params), _versions(params))
         ectx.prepared = (key, ws, ev, int(mask))
     return int(mask)
 
@@ -585,7 +592,7 @@ class _DecoderFn(torch.autograd.Function):
         prep = ectx.prepared
         mask = 0
         if prep is not None and training and prep[0] == (d.B, d.T, d.PI, d.PO, d.SP, d.ST, d.H, d.film,
-                                                         tuple(t.data_ptr() for t in params)):
+                                                         tuple(t.data_ptr() for t in params), _versions(params)):
             ectx.prepared = None
             _, ws, ev, mask = prep                          # packs of this step's weights, made on a second stream
             ectx.prepared_hits += 1
