@@ -10,13 +10,13 @@ from zeggs import engine, synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(overlap, steps=4, B=8, T=24, L=32, clip=None):
+def _run(overlap, steps=4, B=8, T=24, L=32, clip=None, edit_after=None, **kw):
     dev = torch.device("cuda:0")
     se, de, st = helpers.build_nets()
     se, de, st = se.to(dev).eval(), de.to(dev).eval(), st.to(dev).eval()        # eval: no dropout masks to agree on
     data = synth.make_processed(3, 0, clip or T + 40, seed=11)
     ds = engine.DeviceDataset(data, T, dev)
-    eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, overlap_wgrads=overlap)
+    eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT, overlap_wgrads=overlap, **kw)
     assert (eng.wgrad_stream is not None) == overlap and (eng.aux_stream is not None) == overlap
     perm = np.random.default_rng(5).permutation(len(ds))
     gen = torch.Generator().manual_seed(3)
@@ -25,6 +25,13 @@ def _run(overlap, steps=4, B=8, T=24, L=32, clip=None):
         eps = torch.randn(B, 64, generator=gen).to(dev)
         idx = engine.shard_indices(perm, k, B, 1, 0)
         losses.append(eng.step(idx, L, eps=eps))
+        if edit_after is not None and edit_after[0] == k:     # somebody edits the weights between two steps
+            with torch.no_grad():
+                if edit_after[1] == "flat":
+                    eng.flat_p.mul_(1.001)
+                else:
+                    for p in eng.params:
+                        p.mul_(1.001)
         if overlap and k + 1 < steps:
             eng.prefetch(engine.shard_indices(perm, k + 1, B, 1, 0), L)      # picked up by the next step
             assert eng._prefetched is not None
@@ -33,7 +40,7 @@ def _run(overlap, steps=4, B=8, T=24, L=32, clip=None):
     assert eng.opt.early_pieces == (steps if overlap else 0), eng.opt.early_pieces
     # ... and the two side queues are released from INSIDE the style encoder's forward, behind its first convolution (the speech
     # encoder's graph is still built: its weights above move exactly as in the single-stream schedule)
-    assert eng.head_first_releases == (steps if overlap else 0), eng.head_first_releases
+    assert eng.head_first_releases == (steps if overlap and eng.style_head_first else 0), eng.head_first_releases
     _run.last_engine = eng
     return eng.flat_p.detach().cpu().numpy().copy(), [float(x.detach()) for x in losses]
 
@@ -46,6 +53,20 @@ def test_side_streams_give_the_single_stream_weights():
     assert np.allclose(l1, l0, rtol=1e-5, atol=1e-6), (l1, l0)
     p2, _ = _run(True)                                            # and run to run
     assert np.abs(p1 - p2).max() <= 2e-6
+
+
+@pytest.mark.parametrize("how", ["flat", "param"])
+def test_packs_made_ahead_are_not_used_after_the_weights_were_edited(how):
+    """prepare_ahead: the next step's weight-only packs are made right behind the optimizer.  An in-place torch edit of the weights
+    between two steps -- of the engine's flat buffer, or of the modules' parameters (views of it with version counters of their
+    own: what load_state_dict does) -- must make the next step pack again: five steps with such an edit end in the weights of an
+    engine that prepares nothing ahead (stale packs = the unscaled weights in the sweeps: off by 1e-3, not 5e-6)."""
+    kw = dict(steps=5, B=32, T=256, L=384, clip=900, edit_after=(2, how))
+    p1, l1 = _run(True, **kw)
+    assert _run.last_engine.prepare_ahead and _run.last_engine.ctx.prepared_hits >= 3
+    p0, l0 = _run(True, prepare_ahead=False, style_head_first=0, **kw)
+    assert np.abs(p1 - p0).max() <= 5e-6, np.abs(p1 - p0).max()
+    assert np.allclose(l1, l0, rtol=2e-5, atol=1e-6), (l1, l0)
 
 
 def test_side_streams_at_the_bench_shape():

@@ -209,7 +209,7 @@ class TrainEngine:
     def __init__(self, speech_encoder, decoder, style_encoder, dataset, parents, dt, lr=1e-4, eps=1e-5,
                  style_encoding_type="example", world_size=1, rank=0, process_group=None, force_allreduce=False,
                  overlap_allreduce=True, overlap_wgrads=True, early_decoder_step=True, noise_seed=None,
-                 style_head_first=3):
+                 style_head_first=3, prepare_ahead=True):
         self.se, self.de, self.st = speech_encoder, decoder, style_encoder
         # everything the binding needs beyond the arguments of a call (gradient targets, side stream, status words, hooks,
         # the prepared decoder workspace, optionally an own noise-seed stream) travels in THIS engine's context object --
@@ -218,7 +218,8 @@ class TrainEngine:
         if noise_seed is not None:
             self.ctx.seed_rng = np.random.default_rng(int(noise_seed))
         self.early_decoder_step = early_decoder_step
-        self.prepare_ahead = bool(int(os.environ.get("ZEGGS_PREPARE_AHEAD", "1")))
+        self.prepare_ahead = bool(int(os.environ.get("ZEGGS_PREPARE_AHEAD", int(prepare_ahead))))
+        self._ahead_version = None
         self.head_first_releases = 0        # steps whose side queues were released from inside the style encoder's forward
         self.style_head_first = int(os.environ.get("ZEGGS_STYLE_HEAD_FIRST", style_head_first))
         self.ds = dataset
@@ -489,7 +490,12 @@ class TrainEngine:
 
                 def launch_prepare():
                     if ctx.prepared is not None and ctx.prepared[0][0] == len(idx):
-                        return              # made at the end of the previous step (prepare_ahead)
+                        if self._ahead_version == self.flat_p._version:
+                            return          # made at the end of the previous step (prepare_ahead)
+                        # the flat weight buffer was edited in place since (the parameters are views of it with version counters
+                        # of their own, which ops checks): those packs are stale
+                        with ops.use(ctx):
+                            ops._drop_prepared(ctx)
                     if self.wgrad_stream is not None and self._dec_shape is not None and self._dec_shape[0] == len(idx):
                         # the weight-only packs of the decoder sweeps, beside the encoders' forward
                         Bd, SP, ST = self._dec_shape
@@ -606,6 +612,7 @@ class TrainEngine:
             with ops.use(ctx):
                 ops.decoder_prepare(self.de, Bd, T, SP, ST, ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, self.dt,
                                     self.wgrad_stream)
+            self._ahead_version = self.flat_p._version
         if self.status is not None:
             self._post_status()
         self.iteration += 1
