@@ -517,8 +517,11 @@ class TrainEngine:
                 held = []
                 example = self.style_type == "example"
                 side = self.aux_stream is not None and self.wgrad_stream is not None
+                # (only the attention encoder's op has the two-part forward that calls the hook: with the GRU style encoder nothing
+                #  is held back -- held work would start BEHIND that encoder instead of beside it)
+                hooked = example and side and type(getattr(self.st, "encoder", None)).__name__ == "StyleEncoderAttn"
                 for bit, fn in ((1, launch_prepare), (2, launch_speech)):
-                    if example and side and self.style_head_first & bit:
+                    if hooked and self.style_head_first & bit:
                         held.append(fn)
                     else:
                         fn()
