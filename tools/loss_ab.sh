@@ -1,5 +1,8 @@
 #!/bin/bash
 # loss kernels A/B: the library as built vs zeggs/libzeggs_lossold.so (the previous loss.hip), isolated call + kernel trace
+# the comparison library (CPU container, from csrc/ after build.sh):  git show 1859741:ubisoft-laforge-zeroeggs_amd/csrc/loss.hip > /tmp/loss_old.hip
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I. -I../../include -c /tmp/loss_old.hip -o /tmp/loss_old.o
+#   hipcc --offload-arch=gfx950 -shared -fPIC -o ../zeggs/libzeggs_lossold.so $(ls build/*.o | grep -v /loss.o) /tmp/loss_old.o
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; : > $O/loss_ab.log
 Z=$R/ubisoft-laforge-zeroeggs_amd/zeggs
