@@ -255,12 +255,16 @@ def wgrad_gemm_alone(dev, reps=8):
     barrier-free direct kernel (round 5; csrc/gemm.hip: gemm_tn_direct_kernel): TFLOP/s of fp32 MFMA from HIP events, the zero fill of
     the output included.  (In the training iteration these products share the chip with two other queues: DESIGN section 3.2.)"""
     shapes = {"dW_hh 3072x1024 K=8160": (3072, 1024, 8160), "dW_ih0 3072x2286 K=8160": (3072, 2286, 8160)}
-    before = {k: ops._OPTIONS.get(k) for k in ("gemm_direct", "gemm_direct_wgs")}
+    before = {k: ops._OPTIONS.get(k) for k in ("gemm_direct", "gemm_direct_wgs", "gemm_direct_shield", "gemm_direct_depth")}
     out = {"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "kernels": {}}
     try:
-        for tag, mode in (("lds_tiled_streamk", 0), ("direct", 1)):
+        # direct_shield: the variant that owns its SIMDs' register files, 8 operand pairs in flight -- what the engine's
+        # three-queue schedule runs (alone on the chip it has nothing to be shielded from: the same rate as `direct`)
+        for tag, mode, shield, depth in (("lds_tiled_streamk", 0, 0, 4), ("direct", 1, 0, 4), ("direct_shield", 1, 1, 8)):
             ops.set_option("gemm_direct", mode)
             ops.set_option("gemm_direct_wgs", 0)
+            ops.set_option("gemm_direct_shield", shield)
+            ops.set_option("gemm_direct_depth", depth)
             res = {}
             for name, (M, N, K) in shapes.items():
                 A, B = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev)

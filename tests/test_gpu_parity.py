@@ -86,21 +86,28 @@ def test_gemm_direct_stream_k_vs_float64_and_the_lds_kernel(M, N, K, lda, ldb, k
 
     outs = {}
     try:
-        for mode, wgs, depth in ((0, 0, 4), (2, 1, 4), (2, 2, 8), (3, 2, 4), (3, 3, 6), (1, 0, 8)):
+        # (mode, workgroups per CU, pairs in flight, shield: the variant that allocates its SIMDs' whole register files -- what
+        #  zeggs.engine.TrainEngine runs in its three-queue schedule)
+        for mode, wgs, depth, shield in ((0, 0, 4, 0), (2, 1, 4, 0), (2, 2, 8, 0), (3, 2, 4, 0), (3, 3, 6, 0), (1, 0, 8, 0),
+                                         (1, 0, 8, 1), (2, 0, 4, 1), (3, 0, 6, 1), (1, 0, 8, 2)):
             ops.set_option("gemm_direct", mode)
             ops.set_option("gemm_direct_wgs", wgs)
             ops.set_option("gemm_direct_depth", depth)
+            ops.set_option("gemm_direct_shield", shield)
             for beta in (0.0, 1.0):
                 got = run(beta)
                 want = ref + beta * C0.double()
                 err = float((got - want).abs().max() / want.abs().max())
-                assert err < 3e-6, (mode, wgs, depth, beta, err)
-                outs[(mode, wgs, depth, beta)] = got
+                assert err < 3e-6, (mode, wgs, depth, shield, beta, err)
+                outs[(mode, wgs, depth, beta, shield)] = got
     finally:
         ops.set_option("gemm_direct", 1)
         ops.set_option("gemm_direct_wgs", 0)
         ops.set_option("gemm_direct_depth", 4)
-    base = outs[(0, 0, 4, 0.0)]
+        ops.set_option("gemm_direct_shield", 0)
+        for k in ("gemm_direct", "gemm_direct_wgs", "gemm_direct_depth", "gemm_direct_shield"):
+            ops._OPTIONS.pop(k, None)          # back to "not chosen by the caller": a TrainEngine built later picks its own
+    base = outs[(0, 0, 4, 0.0, 0)]
     for k, v in outs.items():
         if k[3] == 0.0:
             assert float((v - base).abs().max() / base.abs().max()) < 3e-6, k

@@ -561,7 +561,7 @@ int launch_tn_dma(GemmArgs g, hipStream_t s) {
 // that the wave pairs that read the same A / B fragments hit the CU's L1.  Stream-K as above: equal contiguous ranges of the
 // (tile, k-chunk) space per workgroup, partial tiles combined by fp32 atomics onto the zeroed / accumulating C.  K even.
 template <int MT, int NT, int D>
-__global__ __launch_bounds__(256, 2) void gemm_tn_direct_kernel(GemmArgs g, int tiles_x, int tiles_y, int chunks_per_batch) {
+__device__ __forceinline__ void tn_direct_body(const GemmArgs& g, int tiles_x, int tiles_y, int chunks_per_batch) {
   constexpr int CH = 8;                                        // k-pairs per chunk of the stream-K iteration space
   constexpr int BM = 64 * MT, BN = 64 * NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
@@ -687,6 +687,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_direct_kernel(GemmArgs g, int 
     it += c1 - c0;
   }
 }
+template <int MT, int NT, int D>
+__global__ __launch_bounds__(256, 2) void gemm_tn_direct_kernel(GemmArgs g, int tiles_x, int tiles_y, int chunks_per_batch) {
+  tn_direct_body<MT, NT, D>(g, tiles_x, tiles_y, chunks_per_batch);
+}
+// The same with the WHOLE register file of its SIMDs to itself (option "gemm_direct_shield"): one workgroup per CU, one wave per
+// SIMD, 512 registers allocated per wave (the clobbers below; the body needs ~200), so that no wave of another queue becomes
+// resident beside it.  The LDS-tiled kernel is shielded like that by its own footprint (2 x 256 registers per SIMD, 135 KB of LDS),
+// which is why it beats this kernel inside the three-queue tail of a training iteration and loses to it alone on the chip.
+template <int MT, int NT, int D>
+__global__ __launch_bounds__(256, 1) void gemm_tn_direct_shield_kernel(GemmArgs g, int tiles_x, int tiles_y, int chunks_per_batch) {
+  asm volatile("" ::: "v255", "a255");
+  tn_direct_body<MT, NT, D>(g, tiles_x, tiles_y, chunks_per_batch);
+}
 // NOTE on the operand roles above: the matrix instruction computes D[m][n] += A[m][k] B[k][n] with lane = (k-half, m) for A and
 // (k-half, n) for B, and D's lane index is the COLUMN n -- the A fragment's lane index is its row.  A(m, k) = A[k * sak + m]
 // is what `ap[mo[i]]` reads for lane (kh, l31): row 2 pair + kh, column m.
@@ -694,6 +707,7 @@ int g_gemm_direct = 1;         // zeggs_set_option("gemm_direct", v): 0 off (the
                                // 2 / 3: always the 128 x 64 / the 64 x 64 wave tile (A/B), 5: only the small / batch-reduce products (what
                                // zeggs.engine.TrainEngine sets when it runs its three-stream schedule: see direct_ok)
 int g_gemm_direct_depth = 4;   // zeggs_set_option("gemm_direct_depth", 4 / 6 / 8): k-pairs of operands in flight per wave
+int g_gemm_direct_shield = 0;  // zeggs_set_option("gemm_direct_shield", 0 / 1 / 2): the variant that owns its SIMDs' register files (2: big products only)
 int g_gemm_direct_wgs = 0;     // zeggs_set_option("gemm_direct_wgs", n): workgroups per CU (0: 1 for the 128 x 64 wave tile, 2 for 64 x 64)
 bool direct_ok(const GemmArgs& g) {
   // 5: only the products of the encoders' backward chains (batch-reduce convolution weight gradients, small outputs): they run
@@ -715,11 +729,19 @@ int launch_tn_direct(GemmArgs g, hipStream_t s) {
   const int cpb = cdiv(g.K / 2, 8);
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  long nwg = (long)ncu * (g_gemm_direct_wgs > 0 ? g_gemm_direct_wgs : (big ? 1 : 2));
+  // shield = 2: only the big single-segment products (the decoder's weight gradients on the second queue); the encoders' chain
+  // products stay the kind that fits in beside other queues' workgroups
+  const bool shield = g_gemm_direct_shield == 1 || (g_gemm_direct_shield == 2 && g.kbatch == 1 && (long)g.M * g.N >= 400000);
+  long nwg = (long)ncu * (shield ? 1 : g_gemm_direct_wgs > 0 ? g_gemm_direct_wgs : (big ? 1 : 2));
   const long total = (long)tx * ty * cpb * g.kbatch;
   if (nwg > total / 4) nwg = total / 4 > 0 ? total / 4 : 1;     // at least 4 chunks (64 k) per workgroup
   const int dep = g_gemm_direct_depth;
-#define ZG_DIRECT(MT_, D_) hipLaunchKernelGGL((gemm_tn_direct_kernel<MT_, 2, D_>), dim3((unsigned)nwg), dim3(256), 0, s, g, tx, ty, cpb)
+#define ZG_DIRECT(MT_, D_)                                                                                                    \
+  do {                                                                                                                         \
+    if (shield) hipLaunchKernelGGL((gemm_tn_direct_shield_kernel<MT_, 2, D_>), dim3((unsigned)nwg), dim3(256), 0, s, g, tx, ty, cpb); \
+    else hipLaunchKernelGGL((gemm_tn_direct_kernel<MT_, 2, D_>), dim3((unsigned)nwg), dim3(256), 0, s, g, tx, ty, cpb);      \
+  } while (0)
+  // (deeper than 8 was measured under the shield -- 10 / 12 / 16 pairs: nothing; the wait counter's 6 bits end at (D - 1) x 6 <= 63)
   if (mt == 4) { if (dep >= 8) ZG_DIRECT(4, 8); else if (dep >= 6) ZG_DIRECT(4, 6); else ZG_DIRECT(4, 4); }
   else { if (dep >= 8) ZG_DIRECT(2, 8); else if (dep >= 6) ZG_DIRECT(2, 6); else ZG_DIRECT(2, 4); }
 #undef ZG_DIRECT
@@ -897,6 +919,7 @@ SkinnyArgs skinny_args(const GemmArgs& g) {
 void zeggs_gemm_set_dma(int on) { g_gemm_dma = on; }
 void zeggs_gemm_set_direct(int mode, int wgs) { if (mode >= 0) g_gemm_direct = mode; if (wgs >= 0) g_gemm_direct_wgs = wgs; }
 void zeggs_gemm_set_direct_depth(int d) { g_gemm_direct_depth = d; }
+void zeggs_gemm_set_direct_shield(int on) { g_gemm_direct_shield = on; }
 int g_gemm_skinny = 1;          // zeggs_set_option("gemm_skinny", 0/1): batch-sized NT products in one launch
 int g_gemm_streamk = 1;        // zeggs_set_option("gemm_streamk", 0/1): stream-K instead of the many-workgroup split-K
 int g_gemm_mid_split = 1;      // zeggs_set_option("gemm_mid_split", 0/1): split K of the latency-bound narrow-output products

@@ -230,13 +230,16 @@ class TrainEngine:
         # the decoder's weight-gradient GEMMs on the library's second stream, beside the encoders' backward
         on_gpu = overlap_wgrads and torch.device(dataset.device).type == "cuda"
         self.wgrad_stream = ops.side_stream(dataset.device) if on_gpu else None
-        if on_gpu and "gemm_direct" not in ops._OPTIONS:
-            # Three queues share the chip in the iteration's tail: there the barrier-free stream-K product (gemm.hip:
-            # gemm_tn_direct_kernel, +25-40 % on a weight-gradient product that has the chip to itself) is kept for the encoders'
-            # chain products only -- the decoder's weight gradients stay on the LDS-tiled kernel, whose resident workgroups shield
-            # them from the other queues (measured: 17.3 ms per iteration either way with mode 5, 17.6-18.4 ms with the direct
-            # kernel everywhere; single-stream schedule 18.1 -> 17.8 ms with it: profiles/r05_gemm_direct_ab.txt)
-            ops.set_option("gemm_direct", 5)
+        if on_gpu and not any(k in ops._OPTIONS for k in ("gemm_direct", "gemm_direct_shield", "gemm_direct_depth")):
+            # Three queues share the chip in the iteration's tail.  The barrier-free stream-K product (gemm.hip:
+            # gemm_tn_direct_kernel, +25-40 % on a weight-gradient product that has the chip to itself) LOSES there as it stands --
+            # it needs no LDS and half the registers, so other queues' waves move in beside it (17.9 ms per iteration against 17.2
+            # with the LDS-tiled kernel, whose footprint keeps a CU to itself).  Its "shield" variant allocates the whole register
+            # file of its SIMDs (one wave per SIMD, 512 registers, 8 operand pairs in flight): the same isolation, the direct
+            # kernel's rate -- 16.8 ms (profiles/r05_gemm_direct_ab.txt)
+            ops.set_option("gemm_direct", 1)
+            ops.set_option("gemm_direct_shield", 1)
+            ops.set_option("gemm_direct_depth", 8)
         # the speech encoder (a short chain of small launches, forward and -- autograd replays a node on the stream of its
         # forward -- backward) beside the style encoder
         self.aux_stream = torch.cuda.Stream(device=dataset.device) if on_gpu else None
