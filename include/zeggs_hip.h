@@ -42,9 +42,11 @@ const char* zeggs_last_error(void);
  * "persistent_spin" = bound of their device-side waits (polls; 0: the first unsatisfied wait gives up -- test hook);
  * "timing" 1 = HIP events on the caller's stream around the decoder's steady-state stage sweeps;
  * round 5: "gemm_direct" 0 / 1 (default) / 2 / 3 / 5 = the barrier-free, LDS-free stream-K form of the TN (weight-gradient)
- * products: off / on / 128x64 / 64x64 wave tiles / only the small and batch-reduce products (what a caller that runs several
- * streams beside each other should pick: zeggs.engine.TrainEngine does), "gemm_direct_wgs", "gemm_direct_depth" (4 / 6 / 8 k-pairs
- * in flight); "ln_bwd4" 0 / 1 = the 16-byte-lane LayerNorm-backward pass; "mel_exact_log" 1 = the literal log / pow chain of
+ * products: off / on / 128x64 / 64x64 wave tiles / only the small and batch-reduce products, "gemm_direct_wgs",
+ * "gemm_direct_depth" (4 / 6 / 8 k-pairs in flight), "gemm_direct_shield" 0 (default) / 1 / 2 = the variant that allocates the
+ * whole register file of its SIMDs, so that no wave of another stream becomes resident beside it (2: big products only) -- what a
+ * caller that runs several streams beside each other should pick (zeggs.engine.TrainEngine: 1, depth 8), "gemm_direct_reserve" n =
+ * CUs that variant's grids leave out (for a collective's resident workgroups in data-parallel runs); "ln_bwd4" 0 / 1 = the 16-byte-lane LayerNorm-backward pass; "mel_exact_log" 1 = the literal log / pow chain of
  * data_pipeline.py:62-63 instead of the affine map */
 int zeggs_set_option(const char* name, int value);
 /* elapsed ms of the last recorded stage sweep: which = 0 forward (T-1 steps x 3 launches), 1 backward; blocks on

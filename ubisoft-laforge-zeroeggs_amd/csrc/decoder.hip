@@ -34,6 +34,7 @@ void zeggs_gemm_set_dma(int on);
 void zeggs_gemm_set_direct(int mode, int wgs);
 void zeggs_gemm_set_direct_depth(int d);
 void zeggs_gemm_set_direct_shield(int on);
+void zeggs_gemm_set_direct_reserve(int n);
 extern int g_gemm_mid_split;
 extern int g_gemm_streamk_wgs;
 extern int g_mel_mfma;
@@ -73,6 +74,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "gemm_direct_wgs") == 0) { zeggs_gemm_set_direct(-1, value); return 0; }
   if (strcmp(name, "gemm_direct_depth") == 0) { zeggs_gemm_set_direct_depth(value); return 0; }
   if (strcmp(name, "gemm_direct_shield") == 0) { zeggs_gemm_set_direct_shield(value); return 0; }
+  if (strcmp(name, "gemm_direct_reserve") == 0) { zeggs_gemm_set_direct_reserve(value); return 0; }
   if (strcmp(name, "gemm_skinny") == 0) { g_gemm_skinny = value != 0; return 0; }
   if (strcmp(name, "gemm_streamk") == 0) { g_gemm_streamk = value != 0; return 0; }
   if (strcmp(name, "fused_attention") == 0) { g_fused_attention = value != 0; return 0; }

@@ -708,6 +708,7 @@ int g_gemm_direct = 1;         // zeggs_set_option("gemm_direct", v): 0 off (the
                                // zeggs.engine.TrainEngine sets when it runs its three-stream schedule: see direct_ok)
 int g_gemm_direct_depth = 4;   // zeggs_set_option("gemm_direct_depth", 4 / 6 / 8): k-pairs of operands in flight per wave
 int g_gemm_direct_shield = 0;  // zeggs_set_option("gemm_direct_shield", 0 / 1 / 2): the variant that owns its SIMDs' register files (2: big products only)
+int g_gemm_direct_reserve = 0; // zeggs_set_option("gemm_direct_reserve", n): CUs the shield variant's grid leaves out
 int g_gemm_direct_wgs = 0;     // zeggs_set_option("gemm_direct_wgs", n): workgroups per CU (0: 1 for the 128 x 64 wave tile, 2 for 64 x 64)
 bool direct_ok(const GemmArgs& g) {
   // 5: only the products of the encoders' backward chains (batch-reduce convolution weight gradients, small outputs): they run
@@ -733,6 +734,11 @@ int launch_tn_direct(GemmArgs g, hipStream_t s) {
   // products stay the kind that fits in beside other queues' workgroups
   const bool shield = g_gemm_direct_shield == 1 || (g_gemm_direct_shield == 2 && g.kbatch == 1 && (long)g.M * g.N >= 400000);
   long nwg = (long)ncu * (shield ? 1 : g_gemm_direct_wgs > 0 ? g_gemm_direct_wgs : (big ? 1 : 2));
+  // option "gemm_direct_reserve": CUs a shielded product leaves free.  For data-parallel runs: the collective's workgroups live for
+  // the whole exchange, and a stream-K product whose equal-share workgroups do not ALL become resident takes twice as long (the
+  // stragglers start when the first ones end); with the CUs of the collective left out of the grid nobody waits for anybody.
+  // (On one GPU, where nothing else is resident: 8 / 16 / 32 reserved CUs measured 17.13 / 17.17 / 17.02 ms against 17.03.)
+  if (shield && g_gemm_direct_reserve > 0 && g_gemm_direct_reserve < ncu / 2) nwg = ncu - g_gemm_direct_reserve;
   const long total = (long)tx * ty * cpb * g.kbatch;
   if (nwg > total / 4) nwg = total / 4 > 0 ? total / 4 : 1;     // at least 4 chunks (64 k) per workgroup
   const int dep = g_gemm_direct_depth;
@@ -920,6 +926,7 @@ void zeggs_gemm_set_dma(int on) { g_gemm_dma = on; }
 void zeggs_gemm_set_direct(int mode, int wgs) { if (mode >= 0) g_gemm_direct = mode; if (wgs >= 0) g_gemm_direct_wgs = wgs; }
 void zeggs_gemm_set_direct_depth(int d) { g_gemm_direct_depth = d; }
 void zeggs_gemm_set_direct_shield(int on) { g_gemm_direct_shield = on; }
+void zeggs_gemm_set_direct_reserve(int n) { g_gemm_direct_reserve = n; }
 int g_gemm_skinny = 1;          // zeggs_set_option("gemm_skinny", 0/1): batch-sized NT products in one launch
 int g_gemm_streamk = 1;        // zeggs_set_option("gemm_streamk", 0/1): stream-K instead of the many-workgroup split-K
 int g_gemm_mid_split = 1;      // zeggs_set_option("gemm_mid_split", 0/1): split K of the latency-bound narrow-output products

@@ -230,7 +230,7 @@ class TrainEngine:
         # the decoder's weight-gradient GEMMs on the library's second stream, beside the encoders' backward
         on_gpu = overlap_wgrads and torch.device(dataset.device).type == "cuda"
         self.wgrad_stream = ops.side_stream(dataset.device) if on_gpu else None
-        if on_gpu and not any(k in ops._OPTIONS for k in ("gemm_direct", "gemm_direct_shield", "gemm_direct_depth")):
+        if on_gpu and not any(k in ops._OPTIONS for k in ("gemm_direct", "gemm_direct_shield", "gemm_direct_depth", "gemm_direct_reserve")):
             # Three queues share the chip in the iteration's tail.  The barrier-free stream-K product (gemm.hip:
             # gemm_tn_direct_kernel, +25-40 % on a weight-gradient product that has the chip to itself) LOSES there as it stands --
             # it needs no LDS and half the registers, so other queues' waves move in beside it (17.9 ms per iteration against 17.2
@@ -240,6 +240,10 @@ class TrainEngine:
             ops.set_option("gemm_direct", 1)
             ops.set_option("gemm_direct_shield", 1)
             ops.set_option("gemm_direct_depth", 8)
+            if world_size > 1:
+                # ... and leaves the CUs of the gradient exchange out of its grids: RCCL's workgroups are resident for the whole
+                # all-reduce, and a stream-K product whose workgroups cannot all be resident waits for its stragglers (gemm.hip)
+                ops.set_option("gemm_direct_reserve", 32)
         # the speech encoder (a short chain of small launches, forward and -- autograd replays a node on the stream of its
         # forward -- backward) beside the style encoder
         self.aux_stream = torch.cuda.Stream(device=dataset.device) if on_gpu else None
