@@ -60,6 +60,11 @@ int zeggs_gemm(const float* A, const float* B, float* C, const float* bias, int 
                long bsB, long bsC, float alpha, float beta, int act, void* stream);
 /* batch-reduce form (the weight gradient of a batched convolution, ZEGGS/modules.py:346-420 through autograd):
  * C(m,n) = beta * C(m,n) + sum_b sum_k A_b(m,k) B_b(k,n), A_b = A + b kbsA, B_b = B + b kbsB; beta 0 or 1. */
+/* a weight gradient and its bias gradient in one call: dW[N, K] (+)= dy[M, N]^T x[M, K], db[N] (+)= column sums of dy; beta = 1:
+ * both accumulate -- then the sums come out of the product kernel's own operand fragments (GemmArgs.asum), else a separate launch.
+ * (What the decoder's deferred weight-gradient products call; exported for tests/test_gpu_parity.py.) */
+int zeggs_gemm_tn_bias(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M_contract, int N, int K,
+                       float beta, float* db, void* stream);
 int zeggs_gemm_kbatch(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk, long sbn,
                       long scm, long scn, int kbatch, long kbsA, long kbsB, float beta, void* stream);
 

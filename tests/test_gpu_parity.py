@@ -49,6 +49,42 @@ def test_gemm_layouts(M, N, K):
     assert relerr(C, 2.0 * ref + 0.5 * C0.double()) < 2e-6
 
 
+@pytest.mark.parametrize("Mc,N,K,lddy,ldx", [(8160, 1024, 1262, 1024, 2286), (8160, 3072, 1024, 3072, 1024),
+                                             (8160, 1131, 1024, 1136, 1024), (2040, 2048, 1024, 3072, 1024), (70, 96, 80, 96, 80)])
+def test_weight_gradient_with_bias_sums_in_one_launch(Mc, N, K, lddy, ldx):
+    """zeggs_gemm_tn_bias (round 5): dW += dy^T x and db += column sums of dy -- where the barrier-free kernel takes the product, the
+    sums come out of its own operand fragments (GemmArgs.asum: added inside the inline-asm wait statement; a compiler-level add on
+    the asm loads' destination registers made the allocator copy them before the data had arrived, caught at K = 8160), else by a
+    separate launch (the last shape).  The decoder's four weight-gradient shapes, both kernel variants, sums in the product / apart;
+    accumulation onto existing values; against float64."""
+    import ctypes as C
+    torch.manual_seed(Mc + N)
+    dy, x = torch.randn(Mc, lddy), torch.randn(Mc, ldx)
+    W0, b0 = torch.randn(N, K), torch.randn(N)
+    ref_w = W0.double() + dy[:, :N].double().T @ x[:, :K].double()
+    ref_b = b0.double() + dy[:, :N].double().sum(0)
+    L = ops.lib()
+    dyd, xd = g(dy), g(x)
+    try:
+        for shield, asum in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            ops.set_option("gemm_direct_shield", shield)
+            ops.set_option("gemm_direct_depth", 8 if shield else 4)
+            ops.set_option("gemm_asum", asum)
+            dW, db = g(W0.clone()), g(b0.clone())
+            rc = L.zeggs_gemm_tn_bias(ops._p(dyd), C.c_long(lddy), ops._p(xd), C.c_long(ldx), ops._p(dW), C.c_long(K), Mc, N, K,
+                                      C.c_float(1.0), ops._p(db), ops._stream())
+            assert rc == 0, L.zeggs_last_error()
+            ew = float((dW.cpu().double() - ref_w).abs().max() / ref_w.abs().max())
+            eb = float((db.cpu().double() - ref_b).abs().max() / ref_b.abs().max())
+            assert ew < 4e-6 and eb < 4e-6, (shield, asum, ew, eb)
+    finally:
+        ops.set_option("gemm_direct_shield", 0)
+        ops.set_option("gemm_direct_depth", 4)
+        ops.set_option("gemm_asum", 1)
+        for k in ("gemm_direct_shield", "gemm_direct_depth", "gemm_asum"):
+            ops._OPTIONS.pop(k, None)
+
+
 @pytest.mark.parametrize("M,N,K,lda,ldb,kbatch", [(3072, 1024, 2040, 3072, 1024, 1), (1131, 1262, 1022, 1132, 2288, 1),
                                                   (197, 333, 1026, 200, 340, 1), (384, 128, 192, 384, 128, 7),
                                                   (3402, 512, 208, 1134, 512, 5), (130, 70, 2048, 131, 73, 1)])

@@ -35,6 +35,7 @@ void zeggs_gemm_set_direct(int mode, int wgs);
 void zeggs_gemm_set_direct_depth(int d);
 void zeggs_gemm_set_direct_shield(int on);
 void zeggs_gemm_set_direct_reserve(int n);
+void zeggs_gemm_set_asum(int on);
 extern int g_gemm_mid_split;
 extern int g_gemm_streamk_wgs;
 extern int g_mel_mfma;
@@ -75,6 +76,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "gemm_direct_depth") == 0) { zeggs_gemm_set_direct_depth(value); return 0; }
   if (strcmp(name, "gemm_direct_shield") == 0) { zeggs_gemm_set_direct_shield(value); return 0; }
   if (strcmp(name, "gemm_direct_reserve") == 0) { zeggs_gemm_set_direct_reserve(value); return 0; }
+  if (strcmp(name, "gemm_asum") == 0) { zeggs_gemm_set_asum(value); return 0; }
   if (strcmp(name, "gemm_skinny") == 0) { g_gemm_skinny = value != 0; return 0; }
   if (strcmp(name, "gemm_streamk") == 0) { g_gemm_streamk = value != 0; return 0; }
   if (strcmp(name, "fused_attention") == 0) { g_fused_attention = value != 0; return 0; }
@@ -427,33 +429,35 @@ int dec_recurrent_wgrads(const ZeggsDecDims& d, const DecWs& w, const ZeggsDecGr
     if (what & 1) ZTRY(gemm_tn(w.DBET + o * sg, 2 * H, w.STm + o * sS, d.ST, G->be_w, d.ST, M, 2 * H, d.ST, beta, s));
     if (what & 2) ZTRY(k_colsum(G->be_b, w.DBET + o * sg, M, 2 * H, 2 * H, beta, s));
   } else {
+    if ((what & 3) == 3) ZTRY(gemm_tn_bias(w.DY + o * sY, POL, w.H1 + o * sH, H, G->l2_w, H, M, d.PO, H, beta, G->l2_b, s));
+    else {
     if (what & 1) ZTRY(gemm_tn(w.DY + o * sY, POL, w.H1 + o * sH, H, G->l2_w, H, M, d.PO, H, beta, s));
     if (what & 2) ZTRY(k_colsum(G->l2_b, w.DY + o * sY, M, d.PO, POL, beta, s));
+    }
   }
-  if (what & 1) ZTRY(gemm_tn(w.DI1 + o * s3, 3 * H, w.H0 + o * sH, H, G->w_ih1, H, M, 3 * H, H, beta, s));
-  if (what & 2) ZTRY(k_colsum(G->b_ih1, w.DI1 + o * s3, M, 3 * H, 3 * H, beta, s));
+  // a weight-gradient product and the bias column sums of the same dy: ONE launch where both are asked for in this call and the
+  // direct kernel takes the product (gemm_tn_bias: round 5, the sums were a dozen launches of 4-18 workgroups between the products)
+  auto tn = [&](int gbit, const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int N, int K, float* db) -> int {
+    if ((what & gbit) && (what & 2)) return gemm_tn_bias(dy, lddy, x, ldx, dW, lddw, M, N, K, beta, db, s);
+    if (what & gbit) ZTRY(gemm_tn(dy, lddy, x, ldx, dW, lddw, M, N, K, beta, s));
+    if (what & 2) ZTRY(k_colsum(db, dy, M, N, lddy, beta, s));
+    return 0;
+  };
+  ZTRY(tn(1, w.DI1 + o * s3, 3 * H, w.H0 + o * sH, H, G->w_ih1, H, 3 * H, H, G->b_ih1));
   if (compact) {
-    if (what & 1) ZTRY(gemm_tn(w.DI1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, M, 2 * H, H, beta, s));
-    if (what & 1) ZTRY(gemm_tn(w.DH1 + o * sH, H, w.H1 + (o - 1) * sH, H, G->w_hh1 + 2L * H * H, H, M, H, H, beta, s));
-    if (what & 2) ZTRY(k_colsum(G->b_hh1, w.DI1 + o * s3, M, 2 * H, 3 * H, beta, s));
-    if (what & 2) ZTRY(k_colsum(G->b_hh1 + 2 * H, w.DH1 + o * sH, M, H, H, beta, s));
+    ZTRY(tn(1, w.DI1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, 2 * H, H, G->b_hh1));
+    ZTRY(tn(1, w.DH1 + o * sH, H, w.H1 + (o - 1) * sH, H, G->w_hh1 + 2L * H * H, H, H, H, G->b_hh1 + 2 * H));
   } else {
-    if (what & 1) ZTRY(gemm_tn(w.DH1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, M, 3 * H, H, beta, s));
-    if (what & 2) ZTRY(k_colsum(G->b_hh1, w.DH1 + o * s3, M, 3 * H, 3 * H, beta, s));
+    ZTRY(tn(1, w.DH1 + o * s3, 3 * H, w.H1 + (o - 1) * sH, H, G->w_hh1, H, 3 * H, H, G->b_hh1));
   }
-  if (what & 4) ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.Gin + o * sG, GL, G->w_ih0, H + XD, M, 3 * H, H + XD, beta, s));
-  if (what & 2) ZTRY(k_colsum(G->b_ih0, w.DI0 + o * s3, M, 3 * H, 3 * H, beta, s));
+  ZTRY(tn(4, w.DI0 + o * s3, 3 * H, w.Gin + o * sG, GL, G->w_ih0, H + XD, 3 * H, H + XD, G->b_ih0));
   if (compact) {
-    if (what & 4) ZTRY(gemm_tn(w.DI0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 2 * H, H, beta, s));
-    if (what & 4) ZTRY(gemm_tn(w.DH0 + o * sH, H, w.H0 + (o - 1) * sH, H, G->w_hh0 + 2L * H * H, H, M, H, H, beta, s));
-    if (what & 2) ZTRY(k_colsum(G->b_hh0, w.DI0 + o * s3, M, 2 * H, 3 * H, beta, s));
-    if (what & 2) ZTRY(k_colsum(G->b_hh0 + 2 * H, w.DH0 + o * sH, M, H, H, beta, s));
+    ZTRY(tn(4, w.DI0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, 2 * H, H, G->b_hh0));
+    ZTRY(tn(4, w.DH0 + o * sH, H, w.H0 + (o - 1) * sH, H, G->w_hh0 + 2L * H * H, H, H, H, G->b_hh0 + 2 * H));
   } else {
-    if (what & 4) ZTRY(gemm_tn(w.DH0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, M, 3 * H, H, beta, s));
-    if (what & 2) ZTRY(k_colsum(G->b_hh0, w.DH0 + o * s3, M, 3 * H, 3 * H, beta, s));
+    ZTRY(tn(4, w.DH0 + o * s3, 3 * H, w.H0 + (o - 1) * sH, H, G->w_hh0, H, 3 * H, H, G->b_hh0));
   }
-  if (what & 4) ZTRY(gemm_tn(w.D0 + o * sH, H, w.Gin + o * sG + H, GL, G->l0_w, XD, M, H, XD, beta, s));
-  if (what & 2) ZTRY(k_colsum(G->l0_b, w.D0 + o * sH, M, H, H, beta, s));
+  ZTRY(tn(4, w.D0 + o * sH, H, w.Gin + o * sG + H, GL, G->l0_w, XD, H, XD, G->l0_b));
   return 0;
 }
 

@@ -16,6 +16,8 @@ struct GemmArgs {
   int splitk;                                  // set by launch_gemm (split-K with atomic accumulation)
   float alpha, beta;
   int act;
+  float* asum;                                 // TN direct kernel only, may be null: asum[m] += alpha * sum_k A(m, k) (the bias gradient that goes with
+                                               // a weight gradient dW = dy^T x: the column sums of dy, from the operand fragments the product loads anyway)
 };
 
 GemmArgs gemm_args(const float* A, const float* B, float* C, int M, int N, int K);
@@ -28,3 +30,7 @@ int gemm_nn_actbwd(const float* dy, long lddy, const float* W, long ldw, float* 
                    int K_out, float beta, const float* ysave, long ldys, int act, hipStream_t s);
 int gemm_tn(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M_contract, int N,
             int K, float beta, hipStream_t s);
+// ... and db[N] (+)= column sums of dy in the same launch where the direct kernel takes the product (beta == 1: both outputs
+// accumulate), by a separate column-sum launch otherwise
+int gemm_tn_bias(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M_contract, int N,
+                 int K, float beta, float* db, hipStream_t s);

@@ -597,6 +597,12 @@ __device__ __forceinline__ void tn_direct_body(const GemmArgs& g, int tiles_x, i
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // GemmArgs.asum: the A fragments pass through this wave's registers anyway -- their sums over k are the bias gradient of the
+    // layer whose weight gradient this product is.  Kept by every wave (MT adds per 2 MT NT matrix instructions), used by the
+    // waves of the first column of output tiles only: each (row block, k chunk) is then counted exactly once.
+    float sa[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) sa[i] = 0.f;
     // the chunk range [c0, c1) batch segment by batch segment
     int c = c0;
     while (c < c1) {
@@ -625,13 +631,19 @@ __device__ __forceinline__ void tn_direct_body(const GemmArgs& g, int tiles_x, i
         for (int j = 0; j < NT; ++j) asm volatile("global_load_dword %0, %1, %2" : "=v"(rb[slot][j]) : "v"(vob[j]), "s"(bs) : "memory");
       };
       // the loads of slot S have landed; Y (a constant) later ones may still fly
+// (GemmArgs.asum: the row sums of A are taken INSIDE the wait statement -- a compiler-level add on the asm loads' destinations
+//  lengthens their live ranges, and the register allocator then copies them between the load and the wait, i.e. before the data
+//  has arrived: measured, wrong results at K = 8160)
 #define ZG_LANDED(S, Y)                                                                                                       \
   do {                                                                                                                         \
     if constexpr (MT == 4)                                                                                                     \
-      asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[S][0]), "+v"(ra[S][1]), "+v"(ra[S][MT > 2 ? 2 : 0]), "+v"(ra[S][MT > 3 ? 3 : 1]), \
-                   "+v"(rb[S][0]), "+v"(rb[S][1]) : "n"(Y) : "memory");                                                       \
+      asm volatile("s_waitcnt vmcnt(%10)\n\tv_add_f32 %6, %6, %0\n\tv_add_f32 %7, %7, %1\n\tv_add_f32 %8, %8, %2\n\tv_add_f32 %9, %9, %3" \
+                   : "+v"(ra[S][0]), "+v"(ra[S][1]), "+v"(ra[S][MT > 2 ? 2 : 0]), "+v"(ra[S][MT > 3 ? 3 : 1]),              \
+                     "+v"(rb[S][0]), "+v"(rb[S][1]), "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[MT > 2 ? 2 : 0]), "+v"(sa[MT > 3 ? 3 : 1]) \
+                   : "n"(Y) : "memory");                                                                                       \
     else                                                                                                                       \
-      asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[S][0]), "+v"(ra[S][1]), "+v"(rb[S][0]), "+v"(rb[S][1]) : "n"(Y) : "memory"); \
+      asm volatile("s_waitcnt vmcnt(%6)\n\tv_add_f32 %4, %4, %0\n\tv_add_f32 %5, %5, %1"                                       \
+                   : "+v"(ra[S][0]), "+v"(ra[S][1]), "+v"(rb[S][0]), "+v"(rb[S][1]), "+v"(sa[0]), "+v"(sa[1]) : "n"(Y) : "memory"); \
   } while (0)
       static_assert((MT == 4 || MT == 2) && NT == 2, "direct kernel: wave tiles 128 x 64 and 64 x 64");
       constexpr int LG = MT + NT;                                // loads per refill group
@@ -657,7 +669,8 @@ __device__ __forceinline__ void tn_direct_body(const GemmArgs& g, int tiles_x, i
       }
       // the last < 2 D pairs: everything in flight lands, one guarded refill round, the rest
 #pragma unroll
-      for (int u = 0; u < D; ++u) ZG_LANDED(u, 0);
+      for (int u = 0; u < D; ++u)
+        if (p + u < n) ZG_LANDED(u, 0);       // (only slots that hold a pair: the statement also adds the slot's A fragments to the row sums)
 #pragma unroll
       for (int u = 0; u < D; ++u)
         if (p + u < n) {
@@ -684,6 +697,14 @@ __device__ __forceinline__ void tn_direct_body(const GemmArgs& g, int tiles_x, i
           if (m < g.M) atomicAdd(g.C + (long)m * g.scm + nn, g.alpha * acc[i][j][e]);
         }
       }
+    if (g.asum != nullptr && (tile % width) / gsz == 0 && wn == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float v = sa[i] + __shfl_xor(sa[i], 32, 64);      // the two k-halves of row m
+        const int m = m_base + 32 * i + l31;
+        if (kh == 0 && m < g.M) atomicAdd(g.asum + m, g.alpha * v);
+      }
+    }
     it += c1 - c0;
   }
 }
@@ -708,6 +729,7 @@ int g_gemm_direct = 1;         // zeggs_set_option("gemm_direct", v): 0 off (the
                                // zeggs.engine.TrainEngine sets when it runs its three-stream schedule: see direct_ok)
 int g_gemm_direct_depth = 4;   // zeggs_set_option("gemm_direct_depth", 4 / 6 / 8): k-pairs of operands in flight per wave
 int g_gemm_direct_shield = 0;  // zeggs_set_option("gemm_direct_shield", 0 / 1 / 2): the variant that owns its SIMDs' register files (2: big products only)
+int g_gemm_asum = 1;           // zeggs_set_option("gemm_asum", 0/1): bias column sums inside the weight-gradient product (A/B)
 int g_gemm_direct_reserve = 0; // zeggs_set_option("gemm_direct_reserve", n): CUs the shield variant's grid leaves out
 int g_gemm_direct_wgs = 0;     // zeggs_set_option("gemm_direct_wgs", n): workgroups per CU (0: 1 for the 128 x 64 wave tile, 2 for 64 x 64)
 bool direct_ok(const GemmArgs& g) {
@@ -723,7 +745,9 @@ bool direct_ok(const GemmArgs& g) {
 // dW 3402 x 512 x 12288 107.3 -> 128.1, 4096^3 124.6 -> 140.8.  Big outputs (>= 384 tiles of 128 x 128) take the 128 x 64 wave
 // tile with one workgroup per CU (fewer operand bytes per product), the others 64 x 64 wave tiles, two workgroups per CU (finer
 // grain at the ends of the stream-K ranges).
+static thread_local bool tl_asum_consumed = false;      // set by launch_tn_direct when it was given GemmArgs.asum (gemm_tn_bias)
 int launch_tn_direct(GemmArgs g, hipStream_t s) {
+  if (g.asum) tl_asum_consumed = true;
   const bool big = g_gemm_direct == 2 || (g_gemm_direct == 1 && (long)cdiv(g.M, 128) * cdiv(g.N, 128) >= 384);      // (3, 5: 64 x 64)
   const int mt = big ? 4 : 2, nt = 2;
   const int tx = cdiv(g.N, 64 * nt), ty = cdiv(g.M, 64 * mt);
@@ -927,6 +951,7 @@ void zeggs_gemm_set_direct(int mode, int wgs) { if (mode >= 0) g_gemm_direct = m
 void zeggs_gemm_set_direct_depth(int d) { g_gemm_direct_depth = d; }
 void zeggs_gemm_set_direct_shield(int on) { g_gemm_direct_shield = on; }
 void zeggs_gemm_set_direct_reserve(int n) { g_gemm_direct_reserve = n; }
+void zeggs_gemm_set_asum(int on) { g_gemm_asum = on; }
 int g_gemm_skinny = 1;          // zeggs_set_option("gemm_skinny", 0/1): batch-sized NT products in one launch
 int g_gemm_streamk = 1;        // zeggs_set_option("gemm_streamk", 0/1): stream-K instead of the many-workgroup split-K
 int g_gemm_mid_split = 1;      // zeggs_set_option("gemm_mid_split", 0/1): split K of the latency-bound narrow-output products
@@ -1073,6 +1098,22 @@ int gemm_tn(const float* dy, long lddy, const float* x, long ldx, float* dW, lon
   GemmArgs g = gemm_args(dy, x, dW, N, K, M_contract);
   g.sam = 1; g.sak = lddy; g.sbk = ldx; g.sbn = 1; g.scm = lddw; g.scn = 1; g.beta = beta;
   return launch_gemm(g, 1, s);
+}
+
+int gemm_tn_bias(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M_contract, int N,
+                 int K, float beta, float* db, hipStream_t s) {
+  GemmArgs g = gemm_args(dy, x, dW, N, K, M_contract);
+  g.sam = 1; g.sak = lddy; g.sbk = ldx; g.sbn = 1; g.scm = lddw; g.scn = 1; g.beta = beta;
+  g.asum = (beta == 1.f && g_gemm_asum) ? db : nullptr;       // (beta == 0 would need db zeroed first: the separate launch does that)
+  tl_asum_consumed = false;
+  ZTRY(launch_gemm(g, 1, s));
+  if (!tl_asum_consumed) ZTRY(k_colsum(db, dy, M_contract, N, lddy, beta, s));
+  return 0;
+}
+
+extern "C" int zeggs_gemm_tn_bias(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M_contract, int N,
+                                  int K, float beta, float* db, void* stream) {
+  return gemm_tn_bias(dy, lddy, x, ldx, dW, lddw, M_contract, N, K, beta, db, (hipStream_t)stream);
 }
 
 extern "C" int zeggs_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
