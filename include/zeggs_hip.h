@@ -217,6 +217,10 @@ int zeggs_persistent_state(int which /* 0: B=1 decode kernel, 1: training-forwar
 int zeggs_tp_stamps(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned long long* out /* host [4][2][32] */);
 /* -DZEGGS_TPSTAT builds: 100 MHz ticks every workgroup spent polling for the hand-off into phase 1..3 of the rollout */
 int zeggs_tp_waits(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned long long* out /* host [256][4] */);
+/* Batch 17..32: the rollout runs as TWO independent 16-row dependency chains in one launch by default (option "tp_dual",
+ * csrc/train_dual.hip: one chain's epilogue and grid hand-off under the other chain's matrix products; same packs, operands and
+ * canonical saves; replaces the same loop, ZEGGS/modules.py:100-151).  -DZEGGS_DCTIME builds: slot stamps of workgroups 0 / 255. */
+int zeggs_tp_dual_stamps(const ZeggsDecDims*, void* ws, size_t ws_bytes, unsigned long long* out /* host [2][8][6][6] */);
 /* Training backward with batch <= 64 (33..64: two sweeps of 32 rows): the BPTT sweep of zeggs_decoder_bwd (replaces the per-step autograd of
  * ZEGGS/train.py:425 through modules.py:100-151) runs as ONE persistent launch by default (option "bwd_persistent",
  * csrc/train_bwd_persistent.hip: transposed weights resident as 4-row v_mfma_f32_4x4x1 tiles, four grid hand-offs per step).

@@ -15,6 +15,9 @@ from zeggs import ops, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
 ops.set_option("timing", 1)
+import os  # noqa: E402
+if "TP_DUAL" in os.environ:      # batch 17..32: two 16-row chains in one launch (csrc/train_dual.hip) or the single-chain sweep
+    ops.set_option("tp_dual", int(os.environ["TP_DUAL"]))
 B, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32, 256)
 _, de, _ = bench.build_nets(dev)
 stats = synth.make_stats()

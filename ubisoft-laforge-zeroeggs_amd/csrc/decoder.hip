@@ -30,6 +30,7 @@ extern int g_fused_attention;
 extern int g_gemm_streamk;
 extern int g_gemm_skinny;
 extern int g_tp_tiles4;
+extern int g_tp_dual;
 void zeggs_gemm_set_dma(int on);
 void zeggs_gemm_set_direct(int mode, int wgs);
 void zeggs_gemm_set_direct_depth(int d);
@@ -84,6 +85,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   // bound of every device-side wait of the persistent kernels (polls); 0 makes the first unsatisfied wait give up: the
   // tests use it to drive the give-up path (tests/test_gpu_giveup.py)
   if (strcmp(name, "tp_tiles4") == 0) { g_tp_tiles4 = value != 0; return 0; }
+  if (strcmp(name, "tp_dual") == 0) { g_tp_dual = value != 0; return 0; }
   if (strcmp(name, "poll_stagger") == 0) { g_poll_stagger = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "poll_sleep") == 0) { g_poll_sleep = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "persistent_spin") == 0) { g_persistent_spin = value < 0 ? 0 : value; return 0; }

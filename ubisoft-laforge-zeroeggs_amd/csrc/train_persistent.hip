@@ -19,8 +19,7 @@
 //   * canonical copies (Gin, H0, H1, saved gates, pose / root outputs) are written exactly where the stage kernels write
 //     them, so the BPTT sweep and the weight-gradient GEMMs are unchanged.
 // Every wait is bounded; on give-up the error word is set and the host redoes the rollout with the stage kernels.
-#include "decoder_ws.h"
-#include "dec_math.h"
+#include "tp_common.h"
 #include "gemm.h"
 #include "kernels.h"
 
@@ -28,83 +27,13 @@ int g_train_persistent = 1;      // zeggs_set_option("train_persistent", 0/1)
 int g_tp_tiles4 = 1;             // zeggs_set_option("tp_tiles4", 0/1): the GRU phases of the training rollout on 4-row tiles (even batch-tile counts)
 static int g_tp_ok = -1;
 
+using namespace zeggs_tp;
 namespace {
-
-typedef __attribute__((address_space(1))) unsigned gu32;
-constexpr int TH = 1024, TTHR = 512, TNCU = 256;
-// k-blocks of a wave per phase: first the OLD part of the operand (known one phase earlier: previous hidden state,
-// speech / style columns), then the FRESH part (produced by the preceding phase).  Block j of a part is k-block
-// lo + wave + 8 j: the parts are interleaved over the 8 waves so that every wave owns old work to do before the hand-off.
-constexpr int TNO0 = 17, TNF0 = 8, TNO1 = 8, TNF1 = 8, TNO3 = 1, TNF3 = 8;
-constexpr int TJ0 = TNO0 + TNF0, TJ1 = TNO1 + TNF1, TJ3 = TNO3 + TNF3;
-// GRU layer 0 operand of a step, in k-blocks: [hid_t (64) | gaze direction of x_t (1) | speech / style of x_t (TKC, zero
-// padded) | h0_{t-1} (64) | h1_{t-1} (64)].  The POSE columns of x_t are not an operand: between the output stage of step t-1
-// and this product the reference only de-normalises / re-normalises them (modules.py:60-76), so
-//   W_ih0[:, pose] x_t[pose] = N0 h1_{t-1} + cv0,  N0 = W_ih0[:, pose] diag(sigma_o / sigma_i) W2  (re-derived per optimizer step),
-// which turns 71 blocks that had to wait for the output stage into 64 that are old by then.  (Step 1 takes x_1 from the given
-// first pose instead: its product comes from a small prologue GEMM and the h1 slot of that step stays zero.)
-// Only k-blocks [0, TFR0) are fresh; the old ones are ordered [cond | h0 | h1]: h0_{t-1} is two hand-offs old when the previous
-// output stage waits, h1_{t-1} one.
-constexpr int TKC = 8, TFR0 = 65, TKH0 = TFR0 + TKC, TKH1 = TKH0 + 64, TKB0 = TKH1 + 64;      // 65, 73, 137, 201
-// ... of which only the 64 blocks of hid_t are walked: the gaze block would give ONE wave a ninth fresh block (every workgroup
-// waits for it: +1/8 on the matrix-core time of the phase's critical part) for three columns -- the gate threads add them instead
-// (9 FMAs each; every workgroup has the normalised gaze direction in LDS anyway, from its own root integration).  The block keeps
-// its place in the operand layout (unread).
-constexpr int TFRW = 64;
-// old blocks of GRU layer 0 done one window early (cond + h0_{t-1}: in front of the previous output stage) / of GRU layer 1 done
-// in layer 0's window (batch <= 32; the wider variants have no registers to spare for a second live accumulator)
-constexpr int ts0(int nb) { return nb <= 2 ? 9 : 0; }
-constexpr int ts1(int nb) { return 0 * nb; }
-// old-part k-blocks of GRU layer 0 parked in LDS instead of registers (as many as the LDS budget of the variant allows)
-constexpr int tl0(int nb) { return nb <= 2 ? 8 : nb == 3 ? 6 : 5; }
-__host__ __device__ inline int tp_kb(int i, int wave, int NO, int old_lo, int old_hi, int fresh_hi) {
-  if (i < NO) { const int kb = old_lo + wave + 8 * i; return kb < old_hi ? kb : -1; }
-  const int kb = wave + 8 * (i - NO);
-  return kb < fresh_hi ? kb : -1;
-}
-constexpr int TSH = 8, TSTR = 32, TRING = 4;
-
-struct TArgs {
-  ZeggsDecDims d;
-  ZeggsDecStats st;
-  int XD, GL, KBX, KBC, KB0, KB3, POL;
-  const f4 *PW0, *PW1, *PW3;                 // per-workgroup fragment packs [256][KB][64]
-  float *G0, *G1, *G3;                       // operand fragments, time-major [T][KB*][NB][64][4]
-  float *Gin, *H0, *H1, *GT0, *GT1;          // canonical saves (time-major)
-  const float *b_ih0, *b_hh0, *b_ih1, *b_hh1, *cvec, *l0_w, *l2_b;
-  const float* w_ih0;                        // [3H][H + XD]: its three gaze columns (H + PO ..) are applied by the gate threads
-  const float *cv0, *p1x;                    // folded pose term of GRU layer 0: constant [3H], step-1 product [B][3H]
-  const float* gaze;
-  float *pose, *rpos, *rrot;
-  unsigned *cnt, *err;
-  unsigned* status;                          // caller-owned sticky give-up flags (ZeggsDecCall.status), may be null
-  unsigned spin;                             // bound of every wait (option "persistent_spin")
-  unsigned nap;                              // s_sleep units between two polls (option "poll_sleep")
-  unsigned stag;                             // != 0: two staggered polls in flight (option "poll_stagger")
-};
-
-__device__ __forceinline__ void stp(float* p, float v) {       // published: write-through
-  __hip_atomic_store((gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// 16 bytes, write-through: the four hidden units of this workgroup are four consecutive k of one batch row = one float4 of the
-// operand layout.  The "memory" clobber is required (results are corrupted without it) and makes the compiler drain the stores
-// it knows about first, so stp4 goes BEFORE the plain stores of an epilogue (train_bwd_persistent.hip).
-__device__ __forceinline__ void stp4(float* p, f4 v) {
-#ifdef ZEGGS_TP_NOSTP      // (timing experiment, results wrong: nothing is published)
-  asm volatile("" ::"v"(p), "v"(v) : "memory");
-#else
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#endif
-}
-__device__ __forceinline__ long xfi(int b, int k, int NB) {   // B-fragment position of (batch row, k)
-  return ((((long)(k >> 4) * NB + (b >> 4)) * 64 + ((((k >> 2) & 3) << 4) | (b & 15))) << 2) | (k & 3);
-}
 
 // Arrival slots: workgroup c publishes "I have finished phase instance p" by storing p + 1 into slot[c] (a write-through
 // store, no read-modify-write to serialise); a consumer's wave 0 loads all 256 slots with one 16-byte load per lane and
 // waits until every slot has reached p + 1.  Epochs are monotonic and a workgroup can run at most one phase ahead of the
 // slowest one, so one 1 KB array serves every phase.  Returns false on give-up.
-typedef __attribute__((address_space(1))) unsigned long long gu64t;
 // `mine` (per lane): this lane's four slots = the four workgroups that produce k-block `lane` of every exchanged vector (workgroup c
 // owns hidden units 4c .. 4c+3 = a quarter of block c / 4) matter to the calling wave; a wave waits for the producers of ITS
 // k-blocks only (wave + 8 j: the lanes with lane % 8 == wave), the eight waves of a workgroup together for everybody.
@@ -206,15 +135,6 @@ __device__ __forceinline__ void tp_mma(const f4 (&wr)[NJT], const f4* wl, const 
 // cbsz = 3 is a [4 rows x 2 k x 32 batch] product per instruction (train_bwd_persistent.hip): three row groups (r, z, n of the 4
 // units) per k-block, 24 x 8 cycles instead of 8 x 32 per 32 batch rows, one VGPR per [4 rows x 16 k] weight tile (3 per block
 // instead of 4).  The n group of a block accumulates into the input- or the hidden-side n sum, by block.
-// Operand position of (batch row, k) for that instruction form: lane 32 * ((k >> 3) & 1) + (b & 31) reads float4 q = (k >> 2) & 1
-// of block k >> 4 (batch tile b >> 5), element k & 3 = abid & 3.  A block is 512 floats per 32 batch rows: the same size as two
-// 16-row tiles of the 16x16x4 layout, so the block offsets of the operand buffers do not change.
-__host__ __device__ inline long xf4(int b, int k, int NT) {
-  return (((((long)(k >> 4) * NT + (b >> 5)) * 2 + ((k >> 2) & 1)) * 64 + ((((k >> 3) & 1) << 5) | (b & 31))) << 2) | (k & 3);
-}
-// block i (position in the wave's list: old part first) of phase ph has hidden-side n rows: layer 0 = [cond | 8 x h0_{t-1} |
-// 8 x h1_{t-1} through the fold (input side: pose columns) | 8 x hid_t], layer 1 = [8 x h1_{t-1} | 8 x h0_t]
-__host__ __device__ constexpr bool tp4_hidden_side(int ph, int i) { return ph == 0 ? (i >= 1 && i <= 8) : (i < TNO1); }
 template <int NT, int NW, int OFF, int NJ, bool WLDS, int PH, int IABS>
 __device__ __forceinline__ void tp_mma4(const float (&wq)[NW], const float* wl, const f4* __restrict__ xb, int kb0, int hi,
                                         f4 (&acc)[4][NT]) {
@@ -1039,7 +959,14 @@ int dec_tp_supported(const ZeggsDecDims& d, const DecWs& w) {
   return !d.film && d.H == TH && d.B <= 64 && d.T >= 4 && d.PI == d.PO + 3 && d.SP + d.ST <= 16 * TKC && w.KBC >= 1 &&
          w.KBC <= 8 * TNO3 && d.PO <= 5 * TNCU && d.PO >= 16 && w.G0xf != nullptr;
 }
-static bool tp_use_t4(const DecWs& w) { return g_tp_tiles4 && w.NB % 2 == 0; }
+namespace zeggs_tp {
+int tp_dual_supported(int NB);                                   // train_dual.hip: two 16-row chains in one launch (batch 17..32)
+void tp_dual_launch(const TArgs& a, hipStream_t s);
+}
+// weight packs of the GRU phases as 4-row tiles (the dual-chain kernel uses them too) / activation operands in the 4-row form's
+// 32-row layout (the dual-chain kernel reads 16-row tiles: tile = chain)
+static bool tp_pack_t4(const DecWs& w) { return tp_dual_supported(w.NB) || (g_tp_tiles4 && w.NB % 2 == 0); }
+static bool tp_use_t4(const DecWs& w) { return !tp_dual_supported(w.NB) && g_tp_tiles4 && w.NB % 2 == 0; }
 int dec_tp_state() { return g_tp_ok; }
 void dec_tp_set_state(int v) { g_tp_ok = v; }
 
@@ -1056,7 +983,7 @@ int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSt
     ZTRY(gemm_nn(w.tp_n0s, w.POL, P->l2_w, H, w.tp_n0, H, 3 * H, d.PO, H, 0.f, s));
     ZTRY(gemm_nt(w.vvec, w.POL, P->w_ih0 + H, KIN, w.tp_cv0, 3 * H, nullptr, 1, 3 * H, d.PO, ACT_NONE, 0.f, s));
   }
-  TPackArgs p{tp_use_t4(w) ? 1 : 0, (f4*)w.tp_w0, (f4*)w.tp_w1, (f4*)w.tp_w3, P->w_ih0, P->w_hh0, P->w_ih1, P->w_hh1, P->l2_w, P->l0_w, w.Mc, w.tp_n0,
+  TPackArgs p{tp_pack_t4(w) ? 1 : 0, (f4*)w.tp_w0, (f4*)w.tp_w1, (f4*)w.tp_w3, P->w_ih0, P->w_hh0, P->w_ih1, P->w_hh1, P->l2_w, P->l0_w, w.Mc, w.tp_n0,
               w.XD, w.KBX, w.KBC, TKB0, 64 + w.KBC, d.PO, d.PI, d.SP + d.ST};
   hipLaunchKernelGGL(tp_pack_k, dim3(8192), dim3(256), 0, s, p);
   ZLAUNCH_CHECK("tp_pack");
@@ -1113,6 +1040,11 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   a.l2_b = P->l2_b; a.w_ih0 = P->w_ih0; a.cv0 = w.tp_cv0; a.p1x = w.tp_p1x; a.gaze = gaze; a.pose = pose; a.rpos = rpos; a.rrot = rrot;
   a.cnt = w.tp_cnt; a.err = w.tp_cnt + TRING * TSH * TSTR;
   a.status = status; a.spin = (unsigned)g_persistent_spin; a.nap = (unsigned)g_poll_sleep; a.stag = (unsigned)g_poll_stagger;
+  if (tp_dual_supported(NB)) {
+    tp_dual_launch(a, s);
+    ZLAUNCH_CHECK("train_fwd_dual");
+    return 0;
+  }
   switch (NB) {
     case 1: hipLaunchKernelGGL((train_fwd_persistent_k<1>), dim3(TNCU), dim3(TTHR), 0, s, a); break;
     case 2:
