@@ -32,109 +32,60 @@
 
 using namespace zeggs_tp;
 
-int g_tp_dual = 1;      // zeggs_set_option("tp_dual", 0/1)
+int g_tp_dual = 0;      // zeggs_set_option("tp_dual", 0/1)
 
 namespace {
 
 constexpr int DL0 = 8;      // old-part k-blocks of GRU layer 0 parked in LDS (as the 4-row form of train_persistent.hip)
-constexpr int DGU = 4;      // k-blocks per operand-prefetch group (one float4 per block and chain)
+constexpr int DR = 8;       // operand ring of a wave: float4 (one k-block of one chain) slots in flight
 constexpr long DXB = 512;   // floats per k-block of an operand: two 16-row tiles (chain A, chain B)
 // lane row (16 lanes) that holds gate g after the fold (tools/dual_lane_probe.hip: rows hold gates 0 2 1 3)
 __device__ __forceinline__ constexpr int drow(int g) { return g == 1 ? 2 : g == 2 ? 1 : g; }
 
-// products of one part of a GRU slot for ONE chain: blocks j = 0..NJ-1 of this wave are k-blocks kb0 + 8 j (clamped to hi - 1:
-// blocks past the operand have zero weights), weights wq[3 (OFF + j) + (r, z, n)] (registers) or wl[(3 (OFF + j) + .) * 64] (LDS).
-// xb points at this lane's float4 of the chain's tile in k-block 0; a k-block is 128 float4.
-template <int NW, int OFF, int NJ, bool WLDS, int PH, int IABS>
-__device__ __forceinline__ void dc_mma4(const float (&wq)[NW], const float* wl, const f4* __restrict__ xb, int kb0, int hi,
-                                        f4 (&acc)[4]) {
-  if constexpr (NJ <= 0) return;
-  constexpr int NG = (NJ + DGU - 1) / DGU;
-  asm volatile("" : "+s"(kb0));
-  f4 xa[DGU], xq[DGU];
-  auto load = [&](f4 (&x)[DGU], int g) {
-#pragma unroll
-    for (int u = 0; u < DGU; ++u) {
-      if (DGU * g + u < NJ) {
-        int kb = kb0 + 8 * (DGU * g + u);
-        kb = kb < hi ? kb : hi - 1;
-        x[u] = xb[(long)kb * 128];
-      }
-    }
-  };
-  auto comp = [&](const f4 (&x)[DGU], int g) {
-#pragma unroll
-    for (int u = 0; u < DGU; ++u) {
-      const int i = DGU * g + u;
-      if (i < NJ) {
-        const int nd = tp4_hidden_side(PH, IABS + i) ? 3 : 2;
-        const int wi = 3 * (OFF + i);
-        const float w0 = WLDS ? wl[(wi + 0) * 64] : wq[wi + 0 < NW ? wi + 0 : 0];
-        const float w1 = WLDS ? wl[(wi + 1) * 64] : wq[wi + 1 < NW ? wi + 1 : 0];
-        const float w2 = WLDS ? wl[(wi + 2) * 64] : wq[wi + 2 < NW ? wi + 2 : 0];
-#define DC4_STEP(A)                                                                          \
-  acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0, x[u][A], acc[0], 2, A, 0);                 \
-  acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1, x[u][A], acc[1], 2, A, 0);                 \
-  acc[nd] = __builtin_amdgcn_mfma_f32_4x4x1f32(w2, x[u][A], acc[nd], 2, A, 0);
-        DC4_STEP(0) DC4_STEP(1) DC4_STEP(2) DC4_STEP(3)
+// block list of a wave per phase (0 / 1: GRU layers, 2: output stage): NO old blocks, then 8 fresh ones (tp_common.h)
+template <int PH> struct dcp { static constexpr int NO = PH == 0 ? TNO0 : PH == 1 ? TNO1 : TNO3; };
+// k-block of position I of that list (only the output stage's conditioning block can lie past the operand: clamped, zero weights)
+template <int PH, int I>
+__device__ __forceinline__ int dc_kb(int wave, int KB3) {
+  if constexpr (PH == 0) return I < TNO0 ? TFR0 + wave + 8 * I : wave + 8 * (I - TNO0);
+  else if constexpr (PH == 1) return I < TNO1 ? 64 + wave + 8 * I : wave + 8 * (I - TNO1);
+  else if constexpr (I < TNO3) { const int kb = 64 + wave + 8 * I; return kb < KB3 ? kb : KB3 - 1; }
+  else return wave + 8 * (I - TNO3);
+}
+// one k-block of one chain into a ring slot: uniform base (operand of the step + chain tile) + uniform block offset + 16 bytes per lane
+template <int PH, int I>
+__device__ __forceinline__ void dc_issue(f4& dst, const char* base, unsigned loff, int wave, int KB3) {
+  dst = *(const f4*)(base + (size_t)dc_kb<PH, I>(wave, KB3) * (DXB * 4) + loff);
+}
+// 4-row products of block position I of GRU layer PH for one chain: v_mfma_f32_4x4x1 with cbsz = 2 (12 instructions)
+template <int PH, int I, int NW0, int NW1>
+__device__ __forceinline__ void dc_comp4(const f4& x, const float (&wq0)[NW0], const float (&wq1)[NW1], const float* w0l_lane, f4 (&acc)[4]) {
+  constexpr int nd = tp4_hidden_side(PH, I) ? 3 : 2;
+  float w0, w1, w2;
+  if constexpr (PH == 0 && I < DL0) { w0 = w0l_lane[(3 * I + 0) * 64]; w1 = w0l_lane[(3 * I + 1) * 64]; w2 = w0l_lane[(3 * I + 2) * 64]; }
+  else if constexpr (PH == 0) { w0 = wq0[3 * (I - DL0)]; w1 = wq0[3 * (I - DL0) + 1]; w2 = wq0[3 * (I - DL0) + 2]; }
+  else { w0 = wq1[3 * I]; w1 = wq1[3 * I + 1]; w2 = wq1[3 * I + 2]; }
+#define DC4_STEP(A)                                                                       \
+  acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0, x[A], acc[0], 2, A, 0);                 \
+  acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1, x[A], acc[1], 2, A, 0);                 \
+  acc[nd] = __builtin_amdgcn_mfma_f32_4x4x1f32(w2, x[A], acc[nd], 2, A, 0);
+  DC4_STEP(0) DC4_STEP(1) DC4_STEP(2) DC4_STEP(3)
 #undef DC4_STEP
-      }
-    }
-  };
-  load(xa, 0);
-#pragma unroll
-  for (int g = 0; g < NG; g += 2) {
-    if (g + 1 < NG) load(xq, g + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    comp(xa, g);
-    __builtin_amdgcn_sched_barrier(0);
-    if (g + 2 < NG) load(xa, g + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (g + 1 < NG) comp(xq, g + 1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
 }
-// output stage of one chain: 16-row tile of v_mfma_f32_16x16x4, weights wl[(OFF + j) * 64] (LDS), two accumulators by block parity
-template <int OFF, int NJ>
-__device__ __forceinline__ void dc_mma16(const f4* wl, const f4* __restrict__ xb, int kb0, int hi, f4 (&acc)[2]) {
-  if constexpr (NJ <= 0) return;
-  constexpr int NG = (NJ + DGU - 1) / DGU;
-  asm volatile("" : "+s"(kb0));
-  f4 xa[DGU], xq[DGU];
-  auto load = [&](f4 (&x)[DGU], int g) {
+// output stage, block position I: 16-row tile of v_mfma_f32_16x16x4, weights in LDS, two accumulators by block parity
+template <int I>
+__device__ __forceinline__ void dc_comp16(const f4& x, const f4* wl3, f4 (&acc)[2]) {
+  const f4 wv = wl3[I * 64];
 #pragma unroll
-    for (int u = 0; u < DGU; ++u) {
-      if (DGU * g + u < NJ) {
-        int kb = kb0 + 8 * (DGU * g + u);
-        kb = kb < hi ? kb : hi - 1;
-        x[u] = xb[(long)kb * 128];
-      }
-    }
-  };
-  auto comp = [&](const f4 (&x)[DGU], int g) {
-#pragma unroll
-    for (int u = 0; u < DGU; ++u) {
-      const int i = DGU * g + u;
-      if (i < NJ) {
-        const f4 wv = wl[(OFF + i) * 64];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) acc[i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[cc], x[u][cc], acc[i & 1], 0, 0, 0);
-      }
-    }
-  };
-  load(xa, 0);
-#pragma unroll
-  for (int g = 0; g < NG; g += 2) {
-    if (g + 1 < NG) load(xq, g + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    comp(xa, g);
-    __builtin_amdgcn_sched_barrier(0);
-    if (g + 2 < NG) load(xa, g + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (g + 1 < NG) comp(xq, g + 1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  for (int cc = 0; cc < 4; ++cc) acc[I & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[cc], x[cc], acc[I & 1], 0, 0, 0);
 }
+template <int K> struct dci { static constexpr int value = K; };
+// compile-time loop: f(dci<I0>{}), ..., f(dci<I0 + N - 1>{})
+template <int I0, int N, typename F>
+__device__ __forceinline__ void dc_for(F&& f) {
+  if constexpr (N > 0) { f(dci<I0>{}); dc_for<I0 + 1, N - 1>(f); }
+}
+
 // fold of the four k-quarters (lane rows) of the four gate sums: acc[g][e] at lane (kq, b) -> out[e] at lane (row drow(g), b)
 __device__ __forceinline__ f4 dc_fold(const f4 (&acc)[4]) {
   f4 o;
@@ -149,8 +100,6 @@ __device__ __forceinline__ f4 dc_fold(const f4 (&acc)[4]) {
   }
   return o;
 }
-
-template <int K> struct dci { static constexpr int value = K; };
 
 // -DZEGGS_DCTIME: wall-clock (100 MHz) stamps of every wave of workgroups 0 and 255 in step T - 2: [wg][wave][slot][6]
 // (slot start, old products done, arrival seen, fresh products done, partial sums signalled, epilogue done); tools/dc_time.py
@@ -287,36 +236,74 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_dual_k(TArgs a) {
       __hip_atomic_store((gu32*)(a.cnt + X * 256 + fcls * 32 + fidx), (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
+  // operand of (phase, step, chain) as a uniform byte address; the ring of the wave and the poll sample travel from slot to slot
+  auto opnd = [&](int ph, int t, int X) -> const char* {
+    const float* g = ph == 0 ? a.G0 + (long)t * a.KB0 * DXB : ph == 1 ? a.G1 + (long)t * 128 * DXB : a.G3 + (long)t * a.KB3 * DXB;
+    return (const char*)(g + X * 256);
+  };
+  f4 xr[DR];
+  unsigned long long fa = 0, fb = 0;      // sample of the arrival flags the NEXT slot waits for (taken under this slot's fresh products)
+  const float* const w0l_lane = w0l + wave * 3 * DL0 * 64 + lane;
+  const f4* const wl3 = w3 + wave * TJ3 * 64 + lane;
+  // Product part of a slot (phase PH, chain X, step t), followed by slot (PHN, XN, tn).  On entry the ring holds the slot's first
+  // min(NO, DR) old blocks (in flight since the previous slot's fresh products); old blocks are computed as they land and their slots
+  // refilled with the rest of the old part; then the wait for the chain's previous phase; the eight fresh blocks are fetched at once
+  // and computed as they land, each freed slot taking one of the NEXT slot's old blocks -- so the next slot starts with its operands
+  // already in flight under this slot's fold / signal / epilogue.
+  auto products = [&](auto PHC, auto XC, auto PHNC, auto XNC, int t, int tn, auto& acc, int SL) -> bool {
+    constexpr int PH = decltype(PHC)::value, X = decltype(XC)::value, PHN = decltype(PHNC)::value, XN = decltype(XNC)::value;
+    constexpr int NO = dcp<PH>::NO, NON = dcp<PHN>::NO;
+    const long p = 3L * (t - 1) + PH;
+    unsigned loff = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(loff));
+    int wv = wave;                       // (opaque copies: the block offsets are cheap scalar arithmetic, not 50 live scalar pairs)
+    asm volatile("" : "+s"(wv));
+    const char* base = opnd(PH, t, X);
+    DCT(SL, 0);
+    dc_for<0, NO>([&](auto IC) {
+      constexpr int I = decltype(IC)::value;
+      if constexpr (PH == 2) dc_comp16<I>(xr[I % DR], wl3, acc);
+      else dc_comp4<PH, I>(xr[I % DR], wq0, wq1, w0l_lane, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (I + DR < NO) dc_issue<PH, I + DR>(xr[I % DR], base, loff, wv, a.KB3);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    DCT(SL, 1);
+    const gu64t* q = (const gu64t*)(a.cnt + X * 256 + wv * 32 + 4 * (loff >> 4 & 7));
+    if (p > 0 && !wait_arrival(X, q, p - 1, fa, fb)) return false;
+    DCT(SL, 2);
+    dc_for<0, 8>([&](auto JC) {
+      constexpr int J = decltype(JC)::value;
+      dc_issue<PH, NO + J>(xr[(NO + J) % DR], base, loff, wv, a.KB3);
+    });
+    {     // the next slot's poll: in flight under the fresh products (instance p of the other chain, or p + 1 of this one's pair)
+      const gu64t* qn = (const gu64t*)(a.cnt + XN * 256 + wv * 32 + 4 * (loff >> 4 & 7));
+      ld_flags(qn, fa, fb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const char* basen = opnd(PHN, tn, XN);
+    dc_for<0, 8>([&](auto JC) {
+      constexpr int J = decltype(JC)::value, I = NO + J, JN = I % DR;
+      if constexpr (PH == 2) dc_comp16<I>(xr[I % DR], wl3, acc);
+      else dc_comp4<PH, I>(xr[I % DR], wq0, wq1, w0l_lane, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (JN < NON) dc_issue<PHN, JN>(xr[JN], basen, loff, wv, a.KB3);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    DCT(SL, 3);
+    return true;
+  };
+
   // ================================================================ GRU slot of chain X, layer L
   auto gru_slot = [&](auto LC, auto XC, int t) -> bool {
     constexpr int L = decltype(LC)::value, X = decltype(XC)::value, SL = 2 * L + X;
+    constexpr int LN = X == 0 ? L : L + 1, XN = 1 - X;      // the slot that follows: A0 B0 A1 B1 A2 B2
     const long p = 3L * (t - 1) + L;
     const bool next = t + 1 < T;
-    // (per-lane addresses from an opaque copy of the lane index: recomputed where they are used -- hoisted out of the time loop they
-    //  would each cost a register pair for the whole rollout, train_persistent.hip)
-    int lx = lane;
-    asm volatile("" : "+v"(lx));
-    const f4* xb = (const f4*)(L == 0 ? a.G0 + (long)t * a.KB0 * DXB : a.G1 + (long)t * 128 * DXB) + X * 64 + lx;
-    const gu64t* q = (const gu64t*)(a.cnt + X * 256 + wave * 32 + 4 * (lx & 7));
-    unsigned long long fa = 0, fb = 0;
-    DCT(SL, 0);
-    if (p > 0) ld_flags(q, fa, fb);            // sample of the arrival flags: in flight under the old-operand products
-    __builtin_amdgcn_sched_barrier(0);
     f4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = f4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (L == 0) {     // [cond | h0_{t-1} | h1_{t-1} through the fold]
-      dc_mma4<3 * (TJ0 - DL0), 0, DL0, true, 0, 0>(wq0, w0l + wave * 3 * DL0 * 64 + lane, xb, TFR0 + wave, a.KB0, acc);
-      dc_mma4<3 * (TJ0 - DL0), 0, TNO0 - DL0, false, 0, DL0>(wq0, nullptr, xb, TFR0 + wave + 8 * DL0, a.KB0, acc);
-    } else {                    // h1_{t-1}
-      dc_mma4<3 * TJ1, 0, TNO1, false, 1, 0>(wq1, nullptr, xb, 64 + wave, 128, acc);
-    }
-    DCT(SL, 1);
-    if (p > 0 && !wait_arrival(X, q, p - 1, fa, fb)) return false;
-    DCT(SL, 2);
-    if constexpr (L == 0) dc_mma4<3 * (TJ0 - DL0), TNO0 - DL0, TNF0, false, 0, TNO0>(wq0, nullptr, xb, wave, TFRW, acc);      // hid_t
-    else dc_mma4<3 * TJ1, TNO1, TNF1, false, 1, TNO1>(wq1, nullptr, xb, wave, 64, acc);                                        // h0_t
-    DCT(SL, 3);
+    if (!products(dci<L>{}, dci<X>{}, dci<LN>{}, dci<XN>{}, t, t, acc, SL)) return false;
     red[X][wave][lane] = dc_fold(acc);
     signal(X);
     DCT(SL, 4);
@@ -391,29 +378,21 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_dual_k(TArgs a) {
   // ================================================================ output-stage slot of chain X : [h1_t | cond_{t+1}]
   auto out_slot = [&](auto XC, int t) -> bool {
     constexpr int X = decltype(XC)::value, SL = 4 + X;
+    constexpr int LN = X == 0 ? 2 : 0, XN = 1 - X;          // B2 is followed by A0 of the next step
     const long p = 3L * (t - 1) + 2;
     const bool next = t + 1 < T;
-    int lx = lane;
-    asm volatile("" : "+v"(lx));
-    const f4* x3 = (const f4*)(a.G3 + (long)t * a.KB3 * DXB) + X * 64 + lx;
-    const f4* wl3 = w3 + wave * TJ3 * 64 + lx;
-    const gu64t* q = (const gu64t*)(a.cnt + X * 256 + wave * 32 + 4 * (lx & 7));
-    unsigned long long fa, fb;
-    DCT(SL, 0);
-    ld_flags(q, fa, fb);
     float gz_[3] = {0.f, 0.f, 0.f};          // gaze target of frame t+1 (an input): in flight under the products
-    if (wave == SL && lx < 16 && 16 * X + lx < B && next) {
-      const float* gz = a.gaze + ((long)(16 * X + lx) * T + t + 1) * 3;
-      gz_[0] = gz[0]; gz_[1] = gz[1]; gz_[2] = gz[2];
+    {
+      int lx = lane;
+      asm volatile("" : "+v"(lx));
+      if (wave == SL && lx < 16 && 16 * X + lx < B && next) {
+        const float* gz = a.gaze + ((long)(16 * X + lx) * T + t + 1) * 3;
+        gz_[0] = gz[0]; gz_[1] = gz[1]; gz_[2] = gz[2];
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
     f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-    dc_mma16<0, TNO3>(wl3, x3, 64 + wave, a.KB3, acc);          // cond_{t+1}
-    DCT(SL, 1);
-    if (!wait_arrival(X, q, p - 1, fa, fb)) return false;
-    DCT(SL, 2);
-    dc_mma16<TNO3, TNF3>(wl3, x3, wave, 64, acc);               // h1_t
-    DCT(SL, 3);
+    // (the last step prefetches its own operands again instead of a step that does not exist: never computed)
+    if (!products(dci<2>{}, dci<X>{}, dci<LN>{}, dci<XN>{}, t, X == 0 ? t : (next ? t + 1 : t), acc, SL)) return false;
     red[X][wave][lane] = acc[0] + acc[1];
     signal(X);
     DCT(SL, 4);
@@ -494,6 +473,13 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_dual_k(TArgs a) {
     return true;
   };
 
+  {     // the ring of the very first slot (A0 of step 1)
+    const char* base1 = opnd(0, 1, 0);
+    dc_for<0, DR>([&](auto IC) {
+      constexpr int I = decltype(IC)::value;
+      dc_issue<0, I>(xr[I], base1, (unsigned)lane * 16u, wave, a.KB3);
+    });
+  }
   bool okrun = true;
   for (int t = 1; t < T; ++t) {
     okrun = gru_slot(dci<0>{}, dci<0>{}, t) && gru_slot(dci<0>{}, dci<1>{}, t) && gru_slot(dci<1>{}, dci<0>{}, t) &&
