@@ -1001,6 +1001,67 @@ def test_persistent_training_forward_matches_stage_launches(B, T, tiles4):
         assert relerr(g1[k], g0[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("B,T,style_dim", [(32, 12, 64), (17, 6, 64), (20, 5, 9), (32, 4, 64), (27, 40, 64)])
+def test_dual_chain_training_forward_matches_stage_launches(B, T, style_dim):
+    """option "tp_dual" (off by default: measured slower than the single-chain sweep, profiles/r06_dual_chain_forward.txt): the
+    forward rollout of batch 17..32 as TWO independent 16-row dependency chains in one launch (csrc/train_dual.hip -- per-wave class
+    polls, LDS-counter reductions, every published vector loaded once, no workgroup barrier in the time loop).  Outputs and, through the
+    unchanged BPTT that consumes what the forward saved, every gradient must agree with the stage-launch forward; a second run
+    (steady state, no validation sync) too.  style_dim 9 = label conditioning (fewer conditioning k-blocks than waves)."""
+    torch.manual_seed(77)
+    from zeggs import modules
+    if style_dim == 64:
+        _, de, _ = helpers.build_nets()
+    else:
+        de = modules.Decoder(synth.POSE_IN, synth.POSE_OUT, 64, style_dim, 1024, 2)
+    de = de.to(DEV).train()
+    try:
+        ops.set_option("train_persistent", 0)
+        out0, g0, ds0, dy0 = _rollout_with_grads(de, B, T, 21, style_dim)
+        ops.set_option("tp_dual", 1)
+        ops.set_option("train_persistent", 1)
+        out1, g1, ds1, dy1 = _rollout_with_grads(de, B, T, 21, style_dim)
+        assert ops.lib().zeggs_persistent_state(1) == 1            # it really ran (validated, not fallen back)
+        out2, g2, ds2, dy2 = _rollout_with_grads(de, B, T, 21, style_dim)
+    finally:
+        ops.set_option("tp_dual", 0)
+        ops.set_option("train_persistent", 1)
+    for outx, gx, dsx, dyx in ((out1, g1, ds1, dy1), (out2, g2, ds2, dy2)):
+        for a, b in zip(out0, outx):
+            assert float((a - b).abs().max()) < 2e-5
+        assert relerr(dsx, ds0) < 1e-4 and relerr(dyx, dy0) < 1e-4
+        for k in g0:
+            assert relerr(gx[k], g0[k]) < 1e-4, k
+
+
+def test_dual_chain_training_forward_gives_up_cleanly():
+    """the dual-chain sweep under "persistent_spin" = 0 (the first unsatisfied wait runs out): error word set, the validated first
+    use falls back to the stage launches, results equal theirs."""
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).train()
+    try:
+        ops.set_option("train_persistent", 0)
+        out0, g0, ds0, dy0 = _rollout_with_grads(de, 32, 8, 21)
+        ops.set_option("tp_dual", 1)
+        ops.set_option("train_persistent", 1)          # (re-enabling resets the validation state: the next use is checked)
+        ops.set_option("persistent_spin", 0)
+        import warnings
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            out1, g1, ds1, dy1 = _rollout_with_grads(de, 32, 8, 21)
+        # gave up either way: on a first (validated) use the library disables the kernel silently (state 0), after a validated use
+        # earlier in the process the sticky status word reports it and ops warns; both redo the rollout on the stage launches
+        assert ops.lib().zeggs_persistent_state(1) == 0 or any("training rollout" in str(w.message) for w in seen)
+    finally:
+        ops.set_option("persistent_spin", 1 << 21)
+        ops.set_option("tp_dual", 0)
+        ops.set_option("train_persistent", 1)
+    for a, b in zip(out0, out1):
+        assert torch.isfinite(b).all() and float((a - b).abs().max()) < 2e-5
+    for k in g0:
+        assert relerr(g1[k], g0[k]) < 1e-4, k
+
+
 @pytest.mark.parametrize("B,T,style_dim", [(32, 12, 64), (17, 6, 64), (5, 9, 64), (1, 7, 64), (32, 3, 64), (20, 5, 9), (64, 6, 9),
                                            (40, 5, 64)])
 def test_persistent_bptt_sweep_matches_stage_launches(B, T, style_dim):

@@ -14,9 +14,11 @@
 //     chains, the operand of a chain is the 16-row tile of the v_mfma_f32_16x16x4 B layout (xfi with NB = 2, tile = chain) -- lane l
 //     reads k = 4 (l / 16) + abid of batch row l % 16 -- and the result registers hold the partial sums of k-quarter l / 16
 //     (tools/dual_lane_probe.hip pins these lane semantics on the hardware).
-//   * A wave walks the slots A0 B0 A1 B1 A2 B2 of a step in order (0 / 1: GRU layers, 2: output stage).  A slot is: old-operand
-//     products, wait for the chain's previous phase, fresh products, fold of the k-quarters (v_permlane32_swap + v_permlane16_swap),
-//     partial sums to LDS, one LDS counter increment.  NO workgroup barrier anywhere in the time loop.
+//   * A wave walks the slots A0 B0 A1 B1 A2 B2 of a step in order (0 / 1: GRU layers, 2: output stage).  A slot is: wait for the
+//     chain's previous phase, its eight fresh k-blocks into the ring, ALL products that consume that vector (this step's and the
+//     next step's: every published vector is loaded once -- half the operand stream of the single-chain sweep), fold of the
+//     k-quarters (v_permlane32_swap + v_permlane16_swap), partial sums to LDS, one LDS counter increment.  NO workgroup barrier
+//     anywhere in the time loop.
 //   * The epilogue of slot (chain X, phase L) belongs to ONE wave, 2 L + X (waves 6, 7 have none): it waits on the LDS counter for the
 //     eight partial sums, adds them, does the gate math / root integration for the 16 rows of its chain (64 lanes = 16 rows x 4
 //     units), publishes with 16-byte write-through stores, drains and raises the chain's arrival flag -- while the other seven waves
@@ -236,76 +238,94 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_dual_k(TArgs a) {
       __hip_atomic_store((gu32*)(a.cnt + X * 256 + fcls * 32 + fidx), (unsigned)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
-  // operand of (phase, step, chain) as a uniform byte address; the ring of the wave and the poll sample travel from slot to slot
+  // operand of (phase, step, chain) as a uniform byte address
   auto opnd = [&](int ph, int t, int X) -> const char* {
     const float* g = ph == 0 ? a.G0 + (long)t * a.KB0 * DXB : ph == 1 ? a.G1 + (long)t * 128 * DXB : a.G3 + (long)t * a.KB3 * DXB;
     return (const char*)(g + X * 256);
   };
-  f4 xr[DR];
-  unsigned long long fa = 0, fb = 0;      // sample of the arrival flags the NEXT slot waits for (taken under this slot's fresh products)
+  f4 xr[DR];                              // the eight fresh k-blocks of the slot in flight
+  unsigned long long fa = 0, fb = 0;      // sample of the arrival flags the NEXT slot waits for (taken under this slot's products)
+  f4 pend0[2], pend1[2];                  // folded sums of the GRU layers' NEXT step, per chain: the products with vectors published earlier
   const float* const w0l_lane = w0l + wave * 3 * DL0 * 64 + lane;
   const f4* const wl3 = w3 + wave * TJ3 * 64 + lane;
-  // Product part of a slot (phase PH, chain X, step t), followed by slot (PHN, XN, tn).  On entry the ring holds the slot's first
-  // min(NO, DR) old blocks (in flight since the previous slot's fresh products); old blocks are computed as they land and their slots
-  // refilled with the rest of the old part; then the wait for the chain's previous phase; the eight fresh blocks are fetched at once
-  // and computed as they land, each freed slot taking one of the NEXT slot's old blocks -- so the next slot starts with its operands
-  // already in flight under this slot's fold / signal / epilogue.
-  auto products = [&](auto PHC, auto XC, auto PHNC, auto XNC, int t, int tn, auto& acc, int SL) -> bool {
-    constexpr int PH = decltype(PHC)::value, X = decltype(XC)::value, PHN = decltype(PHNC)::value, XN = decltype(XNC)::value;
-    constexpr int NO = dcp<PH>::NO, NON = dcp<PHN>::NO;
-    const long p = 3L * (t - 1) + PH;
+  auto zero4 = [&](f4 (&acc)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f4{0.f, 0.f, 0.f, 0.f};
+  };
+  // EVERY PUBLISHED VECTOR IS LOADED ONCE.  In the single-chain sweep h0_t is read twice (layer 1 now, layer 0's hidden side next
+  // step) and h1_t three times (output stage, layer 1's hidden side, layer 0's pose fold), because the second and third use are
+  // what fills its hand-off windows.  Here the other chain fills them, so a slot takes the eight fresh k-blocks of its vector into
+  // the ring once and runs ALL products that consume them -- 821 -> 430 KB of operands per CU and step -- and what belongs to the
+  // next step's GRU sums waits in folded form (pend0 / pend1: one float4 per lane) until that step's slot adds it.
+  // Slot head: the chain's previous phase has arrived -> the fresh blocks (positions NO .. NO + 7 of phase PH's list) into the ring,
+  // the next slot's flag sample behind them.
+  auto fetch = [&](auto PHC, auto XC, auto XNC, int t, long p, int SL) -> bool {
+    constexpr int PH = decltype(PHC)::value, X = decltype(XC)::value, XN = decltype(XNC)::value, NO = dcp<PH>::NO;
     unsigned loff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(loff));
-    int wv = wave;                       // (opaque copies: the block offsets are cheap scalar arithmetic, not 50 live scalar pairs)
+    int wv = wave;                       // (opaque copies: the block offsets are cheap scalar arithmetic, not live scalar pairs)
     asm volatile("" : "+s"(wv));
-    const char* base = opnd(PH, t, X);
-    DCT(SL, 0);
-    dc_for<0, NO>([&](auto IC) {
-      constexpr int I = decltype(IC)::value;
-      if constexpr (PH == 2) dc_comp16<I>(xr[I % DR], wl3, acc);
-      else dc_comp4<PH, I>(xr[I % DR], wq0, wq1, w0l_lane, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (I + DR < NO) dc_issue<PH, I + DR>(xr[I % DR], base, loff, wv, a.KB3);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    DCT(SL, 1);
     const gu64t* q = (const gu64t*)(a.cnt + X * 256 + wv * 32 + 4 * (loff >> 4 & 7));
+    DCT(SL, 1);
     if (p > 0 && !wait_arrival(X, q, p - 1, fa, fb)) return false;
     DCT(SL, 2);
+    const char* base = opnd(PH, t, X);
     dc_for<0, 8>([&](auto JC) {
       constexpr int J = decltype(JC)::value;
-      dc_issue<PH, NO + J>(xr[(NO + J) % DR], base, loff, wv, a.KB3);
+      dc_issue<PH, NO + J>(xr[J], base, loff, wv, a.KB3);
     });
-    {     // the next slot's poll: in flight under the fresh products (instance p of the other chain, or p + 1 of this one's pair)
-      const gu64t* qn = (const gu64t*)(a.cnt + XN * 256 + wv * 32 + 4 * (loff >> 4 & 7));
-      ld_flags(qn, fa, fb);
-    }
+    const gu64t* qn = (const gu64t*)(a.cnt + XN * 256 + wv * 32 + 4 * (loff >> 4 & 7));
+    ld_flags(qn, fa, fb);
     __builtin_amdgcn_sched_barrier(0);
-    const char* basen = opnd(PHN, tn, XN);
-    dc_for<0, 8>([&](auto JC) {
-      constexpr int J = decltype(JC)::value, I = NO + J, JN = I % DR;
-      if constexpr (PH == 2) dc_comp16<I>(xr[I % DR], wl3, acc);
-      else dc_comp4<PH, I>(xr[I % DR], wq0, wq1, w0l_lane, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (JN < NON) dc_issue<PHN, JN>(xr[JN], basen, loff, wv, a.KB3);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    DCT(SL, 3);
     return true;
+  };
+  // the conditioning block of a slot (position 0 of phase PH's list: speech / style columns, known before the rollout)
+  auto fetch_cond = [&](auto PHC, auto XC, int t, f4& xc) {
+    constexpr int PH = decltype(PHC)::value, X = decltype(XC)::value;
+    unsigned loff = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(loff));
+    int wv = wave;
+    asm volatile("" : "+s"(wv));
+    dc_issue<PH, 0>(xc, opnd(PH, t, X), loff, wv, a.KB3);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   // ================================================================ GRU slot of chain X, layer L
   auto gru_slot = [&](auto LC, auto XC, int t) -> bool {
     constexpr int L = decltype(LC)::value, X = decltype(XC)::value, SL = 2 * L + X;
-    constexpr int LN = X == 0 ? L : L + 1, XN = 1 - X;      // the slot that follows: A0 B0 A1 B1 A2 B2
     const long p = 3L * (t - 1) + L;
     const bool next = t + 1 < T;
     f4 acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = f4{0.f, 0.f, 0.f, 0.f};
-    if (!products(dci<L>{}, dci<X>{}, dci<LN>{}, dci<XN>{}, t, t, acc, SL)) return false;
-    red[X][wave][lane] = dc_fold(acc);
-    signal(X);
+    zero4(acc);
+    DCT(SL, 0);
+    if constexpr (L == 0) {       // [cond_t | hid_t]; the h0_{t-1} / h1_{t-1} parts were added up when those vectors were fresh (pend0)
+      f4 xc;
+      fetch_cond(dci<0>{}, dci<X>{}, t, xc);
+      if (!fetch(dci<0>{}, dci<X>{}, dci<1 - X>{}, t, p, SL)) return false;
+      dc_comp4<0, 0>(xc, wq0, wq1, w0l_lane, acc);
+      dc_for<0, 8>([&](auto JC) {
+        constexpr int J = decltype(JC)::value;
+        dc_comp4<0, TNO0 + J>(xr[J], wq0, wq1, w0l_lane, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      DCT(SL, 3);
+      red[X][wave][lane] = dc_fold(acc) + pend0[X];
+      signal(X);
+    } else {                      // h0_t: layer 1's input side now, layer 0's hidden side of step t + 1 (-> pend0)
+      f4 acc0[4];
+      zero4(acc0);
+      if (!fetch(dci<1>{}, dci<X>{}, dci<1 - X>{}, t, p, SL)) return false;
+      dc_for<0, 8>([&](auto JC) {
+        constexpr int J = decltype(JC)::value;
+        dc_comp4<1, TNO1 + J>(xr[J], wq0, wq1, w0l_lane, acc);
+        dc_comp4<0, 1 + J>(xr[J], wq0, wq1, w0l_lane, acc0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      DCT(SL, 3);
+      red[X][wave][lane] = dc_fold(acc) + pend1[X];
+      signal(X);
+      pend0[X] = dc_fold(acc0);
+    }
     DCT(SL, 4);
     if (wave != SL) return true;
     // ---------------------------------------------------------------- epilogue (this wave only)
@@ -357,15 +377,10 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_dual_k(TArgs a) {
       const f4 hv = f4{h, h1, h2, h3};
       const long o = xfi(gb, 4 * c, 2);
       if constexpr (L == 0) {
-        stp4(a.G1 + (long)t * 128 * DXB + o, hv);                                                 // [h0_t | .] of layer 1
-        if (next) stp4(a.G0 + (long)(t + 1) * a.KB0 * DXB + (long)TKH0 * DXB + o, hv);            // h0 slot of layer 0, step t+1
+        stp4(a.G1 + (long)t * 128 * DXB + o, hv);                                                 // h0_t: the one operand every consumer reads
         *(f4*)(a.H0 + (long)t * sH + (long)gb * H + 4 * c) = hv;
       } else {
-        stp4(a.G3 + (long)t * a.KB3 * DXB + o, hv);                                               // [h1_t | .] of the output stage
-        if (next) {
-          stp4(a.G1 + (long)(t + 1) * 128 * DXB + 64 * DXB + o, hv);                              // [. | h1_t] of t+1
-          stp4(a.G0 + (long)(t + 1) * a.KB0 * DXB + (long)TKH1 * DXB + o, hv);                    // h1 slot of layer 0, step t+1 (fold)
-        }
+        stp4(a.G3 + (long)t * a.KB3 * DXB + o, hv);                                               // h1_t: the one operand every consumer reads
         *(f4*)(a.H1 + (long)t * sH + (long)gb * H + 4 * c) = hv;
       }
     }
@@ -376,9 +391,9 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_dual_k(TArgs a) {
   };
 
   // ================================================================ output-stage slot of chain X : [h1_t | cond_{t+1}]
+  // h1_t also feeds layer 1's hidden side (-> pend1) and, through the pose fold, layer 0's input side (-> pend0) of step t + 1
   auto out_slot = [&](auto XC, int t) -> bool {
     constexpr int X = decltype(XC)::value, SL = 4 + X;
-    constexpr int LN = X == 0 ? 2 : 0, XN = 1 - X;          // B2 is followed by A0 of the next step
     const long p = 3L * (t - 1) + 2;
     const bool next = t + 1 < T;
     float gz_[3] = {0.f, 0.f, 0.f};          // gaze target of frame t+1 (an input): in flight under the products
@@ -390,11 +405,27 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_dual_k(TArgs a) {
         gz_[0] = gz[0]; gz_[1] = gz[1]; gz_[2] = gz[2];
       }
     }
-    f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-    // (the last step prefetches its own operands again instead of a step that does not exist: never computed)
-    if (!products(dci<2>{}, dci<X>{}, dci<LN>{}, dci<XN>{}, t, X == 0 ? t : (next ? t + 1 : t), acc, SL)) return false;
-    red[X][wave][lane] = acc[0] + acc[1];
-    signal(X);
+    DCT(SL, 0);
+    {
+      f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, acc1[4], acc0[4], xc;
+      zero4(acc1);
+      zero4(acc0);
+      fetch_cond(dci<2>{}, dci<X>{}, t, xc);
+      if (!fetch(dci<2>{}, dci<X>{}, dci<1 - X>{}, t, p, SL)) return false;
+      dc_comp16<0>(xc, wl3, acc);
+      dc_for<0, 8>([&](auto JC) {
+        constexpr int J = decltype(JC)::value;
+        dc_comp16<TNO3 + J>(xr[J], wl3, acc);
+        dc_comp4<1, J>(xr[J], wq0, wq1, w0l_lane, acc1);
+        dc_comp4<0, 9 + J>(xr[J], wq0, wq1, w0l_lane, acc0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      DCT(SL, 3);
+      red[X][wave][lane] = acc[0] + acc[1];
+      signal(X);
+      pend1[X] = dc_fold(acc1);
+      pend0[X] += dc_fold(acc0);
+    }
     DCT(SL, 4);
     if (wave != SL) return true;
     // ---------------------------------------------------------------- epilogue (this wave only)
@@ -473,13 +504,33 @@ __global__ __launch_bounds__(TTHR, 2) void train_fwd_dual_k(TArgs a) {
     return true;
   };
 
-  {     // the ring of the very first slot (A0 of step 1)
-    const char* base1 = opnd(0, 1, 0);
-    dc_for<0, DR>([&](auto IC) {
-      constexpr int I = decltype(IC)::value;
-      dc_issue<0, I>(xr[I], base1, (unsigned)lane * 16u, wave, a.KB3);
+  // pending sums of step 1: W_hh0 h0_0 (layer 0's operand of step 1 carries h0_0 in its h0 slot and zeros in its h1 slot: the pose
+  // columns of x_1 come from the given first pose, p1x) and W_hh1 h1_0 (the second half of layer 1's operand of step 1)
+  dc_for<0, 2>([&](auto XC) {
+    constexpr int X = decltype(XC)::value;
+    f4 acc0[4], acc1[4];
+    zero4(acc0);
+    zero4(acc1);
+    const unsigned loff = (unsigned)lane * 16u;
+    dc_for<0, 8>([&](auto JC) {
+      constexpr int J = decltype(JC)::value;
+      dc_issue<0, 1 + J>(xr[J], opnd(0, 1, X), loff, wave, a.KB3);
     });
-  }
+    dc_for<0, 8>([&](auto JC) {
+      constexpr int J = decltype(JC)::value;
+      dc_comp4<0, 1 + J>(xr[J], wq0, wq1, w0l_lane, acc0);
+    });
+    dc_for<0, 8>([&](auto JC) {
+      constexpr int J = decltype(JC)::value;
+      dc_issue<1, J>(xr[J], opnd(1, 1, X), loff, wave, a.KB3);
+    });
+    dc_for<0, 8>([&](auto JC) {
+      constexpr int J = decltype(JC)::value;
+      dc_comp4<1, J>(xr[J], wq0, wq1, w0l_lane, acc1);
+    });
+    pend0[X] = dc_fold(acc0);
+    pend1[X] = dc_fold(acc1);
+  });
   bool okrun = true;
   for (int t = 1; t < T; ++t) {
     okrun = gru_slot(dci<0>{}, dci<0>{}, t) && gru_slot(dci<0>{}, dci<1>{}, t) && gru_slot(dci<1>{}, dci<0>{}, t) &&
