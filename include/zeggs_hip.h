@@ -65,6 +65,12 @@ int zeggs_gemm(const float* A, const float* B, float* C, const float* bias, int 
  * (What the decoder's deferred weight-gradient products call; exported for tests/test_gpu_parity.py.) */
 int zeggs_gemm_tn_bias(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M_contract, int N, int K,
                        float beta, float* db, void* stream);
+/* The direct (LDS-free, barrier-free) TN kernel behind zeggs_gemm_tn / zeggs_gemm_tn_bias issues its operand loads as inline asm with
+ * hand-counted waits; every variant (wave tile 64x64 / 128x64, 4 / 6 / 8 operand pairs in flight, plain / "shield") is therefore
+ * CHECKED on its first use per process against a float64 host sum (ragged 293 x 155 x 346 product with row sums; synchronises; never
+ * inside a stream capture) and the kernel is disabled for the process -- the LDS-tiled stream-K kernel takes its products -- if the
+ * check fails.  This entry point runs that check for one variant on demand: 1 = agrees, 0 = does not (tests, toolchain bumps). */
+int zeggs_gemm_direct_selftest(int big, int depth, int shield);
 int zeggs_gemm_kbatch(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk, long sbn,
                       long scm, long scn, int kbatch, long kbsA, long kbsB, float beta, void* stream);
 
@@ -354,6 +360,12 @@ int zeggs_radam_step_guarded(float* p, const float* g, float* m, float* v, long 
 int zeggs_radam_step_guarded_part(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
                                   float step_scale, int rectified, unsigned* status, const float* gflag, int count_skip,
                                   void* stream);
+/* the general form: the step above with RAdam's weight_decay (ZEGGS/optimizers.py:88-95: p += -weight_decay * lr * p before the
+ * update, in the two branches that apply a step) -- decay = weight_decay * lr, 0 when the step is not applied; status may be NULL
+ * (unguarded).  The entry points above are this one with decay = 0. */
+int zeggs_radam_step_wd(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
+                        float step_scale, int rectified, float decay, unsigned* status, const float* gflag, int count_skip,
+                        void* stream);
 int zeggs_status_flag(const unsigned* status, float* dst /* device float */, void* stream);
 
 /* ---------------------------------------------------------------- batch gather

@@ -291,6 +291,17 @@ def gold_radam(ref):
         ps.append(p.detach().clone().numpy())
     np.savez_compressed(GOLD / "radam.npz", grads=np.stack(gs), params=np.stack(ps), lr=1e-2, eps=1e-5)
     print("radam.npz")
+    # the weight_decay branch (optimizers.py:88-95), same gradients: decay before the update, in both step branches
+    torch.manual_seed(3)
+    p = torch.nn.Parameter(torch.randn(257))
+    opt = ref.optimizers.RAdam([p], lr=1e-2, eps=1e-5, weight_decay=0.05)
+    ps = [p.detach().clone().numpy()]
+    for g in gs:
+        p.grad = torch.as_tensor(g).clone()
+        opt.step()
+        ps.append(p.detach().clone().numpy())
+    np.savez_compressed(GOLD / "radam_wd.npz", grads=np.stack(gs), params=np.stack(ps), lr=1e-2, eps=1e-5, weight_decay=0.05)
+    print("radam_wd.npz")
 
 
 def gold_generate(ref):

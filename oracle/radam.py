@@ -22,14 +22,17 @@ def radam_scalars(step, lr, beta1=0.9, beta2=0.999):
     return False, lr / (1 - beta1 ** step)
 
 
-def radam_step(p, g, m, v, step, lr, eps, beta1=0.9, beta2=0.999):
-    """In-place update of float32 arrays p, m, v with gradient g (step is 1-based)."""
+def radam_step(p, g, m, v, step, lr, eps, beta1=0.9, beta2=0.999, weight_decay=0.0):
+    """In-place update of float32 arrays p, m, v with gradient g (step is 1-based).  weight_decay: optimizers.py:88-95
+    (p += -weight_decay * lr * p before the update; degenerated_to_sgd=True applies a step in both branches)."""
     f = np.float32
     v *= f(beta2)
     v += f(1 - beta2) * g * g                       # addcmul_(grad, grad, value=1-beta2)
     m *= f(beta1)
     m += f(1 - beta1) * g                           # add_(grad, alpha=1-beta1)
     rect, scale = radam_scalars(step, lr, beta1, beta2)
+    if weight_decay != 0:
+        p += f(-weight_decay * lr) * p                # add_(p, alpha=-weight_decay * lr)
     if rect:
         p += f(-scale) * (m / (np.sqrt(v) + f(eps)))  # addcdiv_(m, sqrt(v)+eps, value=-step*lr)
     else:

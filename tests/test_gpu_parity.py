@@ -450,6 +450,34 @@ def test_radam_vs_reference(golden_dir):
         np.testing.assert_allclose(p.cpu().numpy(), gd["params"][i + 1], atol=2e-7)
 
 
+@pytest.mark.parametrize("big,depth,shield", [(b, d, sh) for b in (0, 1) for d in (4, 6, 8) for sh in (0, 1)])
+def test_direct_gemm_variant_selftest(big, depth, shield):
+    """Every variant of the direct TN kernel (inline-asm operand loads with hand-counted waits: correctness depends on the compiler
+    that built the library) against a float64 host sum -- the check the library itself runs at a variant's first use per process."""
+    assert ops.lib().zeggs_gemm_direct_selftest(big, depth, shield) == 1
+
+
+def test_radam_weight_decay_vs_reference(golden_dir):
+    """RAdam(weight_decay=0.05) of the reference (optimizers.py:88-95; radam_wd.npz) through the drop-in optimizer class: per-tensor
+    launches and the flat-buffer form."""
+    from zeggs import optimizers
+    gd = np.load(golden_dir / "radam_wd.npz")
+    for flat in (False, True):
+        p = torch.nn.Parameter(g(torch.as_tensor(gd["params"][0].copy())))
+        if flat:
+            fp, fg = p.data.clone(), torch.zeros_like(p.data)
+            p.data = fp.view_as(p)
+        opt = optimizers.RAdam([p], lr=float(gd["lr"]), eps=float(gd["eps"]), weight_decay=float(gd["weight_decay"]))
+        if flat:
+            opt.attach_flat(fp, fg)
+        for i, gr in enumerate(gd["grads"]):
+            if flat:
+                fg.copy_(g(torch.as_tensor(gr)))
+            p.grad = g(torch.as_tensor(gr))
+            opt.step()
+            np.testing.assert_allclose(p.detach().cpu().numpy(), gd["params"][i + 1], atol=2e-7, err_msg=f"flat={flat} step {i + 1}")
+
+
 def _engine_iteration(gd, it, nets, s):
     """One iteration of train_iter.npz through the engine's own fused loss: loss, terms, decoder outputs (pose, root pos, root rot)."""
     se, de, st = nets

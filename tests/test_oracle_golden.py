@@ -127,6 +127,12 @@ def test_oracle_radam_vs_reference(golden_dir):
         oradam.radam_step(p, gr, m, v, i + 1, float(g["lr"]), float(g["eps"]))
         np.testing.assert_allclose(p, g["params"][i + 1], atol=2e-7, err_msg=f"step {i + 1}")
     assert oradam.radam_scalars(5, 1.0)[0] is False and oradam.radam_scalars(6, 1.0)[0] is True
+    g = np.load(golden_dir / "radam_wd.npz")          # RAdam(weight_decay=0.05) of the reference, same gradients
+    p = g["params"][0].copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    for i, gr in enumerate(g["grads"]):
+        oradam.radam_step(p, gr, m, v, i + 1, float(g["lr"]), float(g["eps"]), weight_decay=float(g["weight_decay"]))
+        np.testing.assert_allclose(p, g["params"][i + 1], atol=2e-7, err_msg=f"step {i + 1} (weight decay)")
 
 
 def test_oracle_mel_vs_reference(golden_dir):

@@ -14,6 +14,8 @@
 // loads are in flight while the current one feeds the MFMAs.
 #include <type_traits>
 #include "common.h"
+#include <vector>
+
 #include "gemm.h"
 #include "kernels.h"
 
@@ -807,8 +809,75 @@ int launch_streamk_cfg(GemmArgs g, hipStream_t s) {
   ZLAUNCH_CHECK("gemm_streamk");
   return 0;
 }
+// First use of a direct-kernel variant on this process: a small ragged product with row sums against a float64 host sum.  The
+// variant's operand loads are inline asm the compiler cannot see into ("=v" destinations that are only valid after a hand-placed
+// wait): its correctness rests on the register allocation of the compiler that built the library -- so it is CHECKED
+// where it runs instead of trusted, like the persistent kernels' first use; a mismatch disables the direct kernel for the process
+// (the LDS-tiled stream-K kernel takes over) and says so on stderr.  Never inside a stream capture (the check synchronises).
+static int g_direct_checked[2][3][2];      // [128 x 64 wave tile][depth 4 / 6 / 8][shield]: 0 not yet, 1 ok
+static bool direct_selftest(bool big, int dep, bool shield) {
+  const int M = big ? 64 * 4 * 2 + 37 : 64 * 2 * 2 + 21, N = 128 + 27, K = 2 * 173;      // ragged tiles, odd pair count
+  const long ldA = M + 3, ldB = N + 5;
+  std::vector<float> hA((size_t)K * ldA), hB((size_t)K * ldB), hC((size_t)M * N), hS(M);
+  unsigned lcg = 12345u;
+  auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((int)(lcg >> 9) - (1 << 22)) * (1.f / (1 << 22)); };
+  for (auto& v : hA) v = rnd();
+  for (auto& v : hB) v = rnd();
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr, *dS = nullptr;
+  bool ok = hipMalloc(&dA, hA.size() * 4) == hipSuccess && hipMalloc(&dB, hB.size() * 4) == hipSuccess &&
+            hipMalloc(&dC, hC.size() * 4) == hipSuccess && hipMalloc(&dS, hS.size() * 4) == hipSuccess;
+  ok = ok && hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemset(dC, 0, hC.size() * 4) == hipSuccess && hipMemset(dS, 0, hS.size() * 4) == hipSuccess;
+  if (ok) {
+    GemmArgs g = gemm_args(dA, dB, dC, M, N, K);      // C(m, n) = sum_k A[k][m] B[k][n]
+    g.sam = 1; g.sak = ldA; g.sbk = ldB; g.sbn = 1; g.scm = N; g.scn = 1; g.asum = dS;
+    const int sv_direct = g_gemm_direct, sv_dep = g_gemm_direct_depth, sv_sh = g_gemm_direct_shield, sv_res = g_gemm_direct_reserve;
+    g_gemm_direct = big ? 2 : 3; g_gemm_direct_depth = dep; g_gemm_direct_shield = shield ? 1 : 0; g_gemm_direct_reserve = 0;
+    ok = launch_tn_direct(g, (hipStream_t)0) == 0;
+    tl_asum_consumed = false;
+    g_gemm_direct = sv_direct; g_gemm_direct_depth = sv_dep; g_gemm_direct_shield = sv_sh; g_gemm_direct_reserve = sv_res;
+    ok = ok && hipStreamSynchronize((hipStream_t)0) == hipSuccess &&
+         hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(hS.data(), dS, hS.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  if (ok) {
+    double worst = 0.0;
+    for (int m = 0; m < M; ++m) {
+      double sa = 0.0;
+      for (int k = 0; k < K; ++k) sa += hA[(size_t)k * ldA + m];
+      worst = fmax(worst, fabs(sa - hS[m]));
+    }
+    for (int m = 0; m < M; m += 3)          // (every third row: the columns cover every lane of every fragment)
+      for (int n = 0; n < N; ++n) {
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) acc += (double)hA[(size_t)k * ldA + m] * hB[(size_t)k * ldB + n];
+        worst = fmax(worst, fabs(acc - hC[(size_t)m * N + n]));
+      }
+    ok = worst < 2e-3;      // sums of 346 products of magnitude <= 1: fp32 rounding is ~1e-5; a stale operand is O(1)
+    if (!ok) fprintf(stderr, "zeggs: direct TN GEMM self-test (wave tile %s, depth %d%s) is off by %.3g\n", big ? "128x64" : "64x64",
+                     dep, shield ? ", shield" : "", worst);
+  }
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dS);
+  return ok;
+}
+// true: the variant launch_tn_direct would pick for g is checked (or cannot be checked right now: stream capture)
+static bool direct_checked(const GemmArgs& g, hipStream_t s) {
+  const bool big = g_gemm_direct == 2 || (g_gemm_direct == 1 && (long)cdiv(g.M, 128) * cdiv(g.N, 128) >= 384);
+  const bool shield = g_gemm_direct_shield == 1 || (g_gemm_direct_shield == 2 && g.kbatch == 1 && (long)g.M * g.N >= 400000);
+  const int di = g_gemm_direct_depth >= 8 ? 2 : g_gemm_direct_depth >= 6 ? 1 : 0;
+  int& st = g_direct_checked[big][di][shield];
+  if (st == 1) return true;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return true;
+  if (direct_selftest(big, di == 2 ? 8 : di == 1 ? 6 : 4, shield)) { st = 1; return true; }
+  fprintf(stderr, "zeggs: the direct TN GEMM kernel is DISABLED for this process (self-test failed: built with another compiler?); "
+                  "the LDS-tiled stream-K kernel takes its products\n");
+  g_gemm_direct = 0;
+  return false;
+}
 int launch_streamk(GemmArgs g, hipStream_t s) {
-  if (direct_ok(g)) return launch_tn_direct(g, s);
+  if (direct_ok(g) && direct_checked(g, s)) return launch_tn_direct(g, s);
   if (dma_ok(g)) return launch_tn_dma(g, s);
   // 256 x 128 tiles (8 waves, 2 workgroups per CU: 3/4 of the operand bytes per product) pay on the big outputs only: +5 .. +8 %
   // on dW_ih0 (432 tiles of 128 x 128), -4 .. -6 % at 72 .. 200 tiles where the coarser grain costs balance
@@ -1111,6 +1180,9 @@ int gemm_tn_bias(const float* dy, long lddy, const float* x, long ldx, float* dW
   return 0;
 }
 
+extern "C" int zeggs_gemm_direct_selftest(int big, int depth, int shield) {
+  return direct_selftest(big != 0, depth >= 8 ? 8 : depth >= 6 ? 6 : 4, shield != 0) ? 1 : 0;
+}
 extern "C" int zeggs_gemm_tn_bias(const float* dy, long lddy, const float* x, long ldx, float* dW, long lddw, int M_contract, int N,
                                   int K, float beta, float* db, void* stream) {
   return gemm_tn_bias(dy, lddy, x, ldx, dW, lddw, M_contract, N, K, beta, db, (hipStream_t)stream);

@@ -19,9 +19,10 @@ extern "C" int zeggs_version() { return 100; }
 namespace {
 
 // RAdam (reference optimizers.py:59-97): v = b2 v + (1-b2) g^2 ; m = b1 m + (1-b1) g ; p -= scale * m/(sqrt(v)+eps)
+// decay = weight_decay * lr (optimizers.py:88-95: p += -weight_decay * lr * p BEFORE the update, only when the step is applied)
 // 16-byte vector accesses: 16 B read x4 + 12 B written per parameter = the algorithmic 28 B/param.
 __global__ __launch_bounds__(256) void radam_k(float* p, const float* g, float* m, float* v, long n4, long n,
-                                                float b1, float b2, float eps, float scale, int rect,
+                                                float b1, float b2, float eps, float scale, int rect, float decay,
                                                 unsigned* status, const float* gflag, int count_skip) {
   // guarded step (zeggs_radam_step_guarded): a persistent sweep of this iteration gave up on this rank (sticky status word) or
   // on another one (gflag: the all-reduced flag) -> the gradients are invalid, the whole step is a no-op and is counted
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(256) void radam_k(float* p, const float* g, float* 
     for (int k = 0; k < 4; ++k) {
       vv[k] = vv[k] * b2 + (1.f - b2) * gv[k] * gv[k];
       mv[k] = mv[k] * b1 + (1.f - b1) * gv[k];
+      if (decay != 0.f) pv[k] += -decay * pv[k];
       pv[k] += rect ? -scale * (mv[k] / (sqrtf(vv[k]) + eps)) : -scale * mv[k];
     }
     ((f4*)p)[i] = pv; ((f4*)m)[i] = mv; ((f4*)v)[i] = vv;
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(256) void radam_k(float* p, const float* g, float* 
     long i = n4 * 4 + threadIdx.x;
     float vv = v[i] * b2 + (1.f - b2) * g[i] * g[i];
     float mv = m[i] * b1 + (1.f - b1) * g[i];
+    if (decay != 0.f) p[i] += -decay * p[i];
     p[i] += rect ? -scale * (mv / (sqrtf(vv) + eps)) : -scale * mv;
     m[i] = mv; v[i] = vv;
   }
@@ -161,21 +164,26 @@ extern "C" int zeggs_radam_step(float* p, const float* g, float* m, float* v, lo
   if (n <= 0) return 0;
   long n4 = n / 4;
   hipLaunchKernelGGL(radam_k, dim3(g1(n4 > 0 ? n4 : 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
-                     beta2, eps, step_scale, rectified, (unsigned*)nullptr, (const float*)nullptr, 0);
+                     beta2, eps, step_scale, rectified, 0.f, (unsigned*)nullptr, (const float*)nullptr, 0);
+  ZLAUNCH_CHECK("radam");
+  return 0;
+}
+extern "C" int zeggs_radam_step_wd(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2, float eps,
+                                   float step_scale, int rectified, float decay, unsigned* status, const float* gflag,
+                                   int count_skip, void* stream) {
+  ZCHECK(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "radam: buffers must be 16-byte aligned");
+  if (n <= 0) return 0;
+  long n4 = n / 4;
+  hipLaunchKernelGGL(radam_k, dim3(g1(n4 > 0 ? n4 : 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
+                     beta2, eps, step_scale, rectified, decay, status, status ? gflag : (const float*)nullptr, count_skip);
   ZLAUNCH_CHECK("radam");
   return 0;
 }
 extern "C" int zeggs_radam_step_guarded_part(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2,
                                              float eps, float step_scale, int rectified, unsigned* status,
                                              const float* gflag, int count_skip, void* stream) {
-  ZCHECK(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "radam: buffers must be 16-byte aligned");
   ZCHECK(status != nullptr, "radam (guarded): the status words are required");
-  if (n <= 0) return 0;
-  long n4 = n / 4;
-  hipLaunchKernelGGL(radam_k, dim3(g1(n4 > 0 ? n4 : 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, beta1,
-                     beta2, eps, step_scale, rectified, status, gflag, count_skip);
-  ZLAUNCH_CHECK("radam");
-  return 0;
+  return zeggs_radam_step_wd(p, g, m, v, n, beta1, beta2, eps, step_scale, rectified, 0.f, status, gflag, count_skip, stream);
 }
 extern "C" int zeggs_radam_step_guarded(float* p, const float* g, float* m, float* v, long n, float beta1, float beta2,
                                         float eps, float step_scale, int rectified, unsigned* status, const float* gflag,

@@ -976,11 +976,17 @@ def training_loss(o_pose, o_rpos, o_rrot, w_pose, w_rpos, w_rrot, gaze, parents,
 
 
 # ----------------------------------------------------------------------------- optimizer / data
-def radam_step(p, g, m, v, beta1, beta2, eps, step_scale, rectified, status=None, gflag=None, count=True):
+def radam_step(p, g, m, v, beta1, beta2, eps, step_scale, rectified, status=None, gflag=None, count=True, decay=0.0):
     """status (int32[STATUS_WORDS], device): the guarded step -- a no-op on the device, counted in status[1], when a
     persistent sweep of the iteration gave up here (status[0]) or on another rank (gflag, a device float).  A step applied in
-    pieces (slices of the flat buffers) counts its skip in ONE of them: count=False for the others."""
-    if status is None:
+    pieces (slices of the flat buffers) counts its skip in ONE of them: count=False for the others.
+    decay = weight_decay * lr (reference optimizers.py:88-95), 0 when the step is not applied."""
+    if decay != 0.0:
+        _check(lib().zeggs_radam_step_wd(_p(p), _p(g), _p(m), _p(v), C.c_long(p.numel()), C.c_float(beta1), C.c_float(beta2),
+                                         C.c_float(eps), C.c_float(step_scale), int(rectified), C.c_float(decay),
+                                         C.c_void_p(status.data_ptr()) if status is not None else None,
+                                         _p(gflag) if gflag is not None else None, int(bool(count)), _stream()), "radam_step_wd")
+    elif status is None:
         _check(lib().zeggs_radam_step(_p(p), _p(g), _p(m), _p(v), C.c_long(p.numel()), C.c_float(beta1),
                                       C.c_float(beta2), C.c_float(eps), C.c_float(step_scale), int(rectified),
                                       _stream()), "radam_step")

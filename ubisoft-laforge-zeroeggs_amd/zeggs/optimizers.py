@@ -35,8 +35,8 @@ class RAdam(Optimizer):
             raise ValueError("Invalid epsilon value: {}".format(eps))
         if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
             raise ValueError("Invalid beta parameters: {}".format(betas))
-        if weight_decay != 0:
-            raise NotImplementedError("weight_decay != 0 is never used by the reference configs")
+        if not 0.0 <= weight_decay:
+            raise ValueError("Invalid weight_decay value: {}".format(weight_decay))
         self.degenerated_to_sgd = degenerated_to_sgd
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                         buffer=[[None, None, None] for _ in range(10)])
@@ -84,7 +84,8 @@ class RAdam(Optimizer):
         rect, scale, active = radam_scalars(step, group["lr"], beta1, beta2, self.degenerated_to_sgd)
         p, g, m, v = (t[lo:hi] for t in self._flat)
         st, gf = self._guard if self._guard is not None else (None, None)
-        ops.radam_step(p, g, m, v, beta1, beta2, group["eps"], scale if active else 0.0, rect, st, gf, count=count)
+        ops.radam_step(p, g, m, v, beta1, beta2, group["eps"], scale if active else 0.0, rect, st, gf, count=count,
+                       decay=group["weight_decay"] * group["lr"] if active else 0.0)
 
     @torch.no_grad()
     def early(self, lo, hi):
@@ -130,5 +131,5 @@ class RAdam(Optimizer):
                 rect, scale, active = radam_scalars(st["step"], group["lr"], beta1, beta2, self.degenerated_to_sgd)
                 pd, gd = p.data.view(-1), p.grad.data.contiguous().view(-1)
                 ops.radam_step(pd, gd, st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1), beta1, beta2, group["eps"],
-                               scale if active else 0.0, rect)
+                               scale if active else 0.0, rect, decay=group["weight_decay"] * group["lr"] if active else 0.0)
         return loss

@@ -134,6 +134,14 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     window, batchsize = train_options["window"], train_options["batchsize"]
+    if batchsize * world == 3 or window == 3:
+        # torch.cross without `dim` takes the FIRST axis of size 3 (ZEGGS/anim/txform.py:25-26, ZEGGS/train.py:301,315): with a
+        # batch of 3 clips or a window of 3 frames the reference crosses along the batch / time axis.  The kernels always cross
+        # along the coordinate axis -- the intended value -- so THIS is the one configuration whose losses differ from the reference's.
+        import warnings
+        warnings.warn("zeggs.train: batchsize == 3 or window == 3 -- the reference's torch.cross (no dim) crosses along that axis "
+                      "instead of the coordinate axis there; this engine computes the intended cross product, so its loss and "
+                      "gradients differ from the reference's for this configuration")
     se_opt, st_opt, de_opt = (network_options["speech_encoder"], network_options["style_encoder"],
                               network_options["decoder"])
     with open(path_data_definition) as f:
