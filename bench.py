@@ -95,6 +95,47 @@ def build_nets(device, style=ST, with_style_encoder=True):
     return se.to(device).train(), de.to(device).train(), (st.to(device).train() if st is not None else None)
 
 
+def profile_stamp(path):
+    """Short git-style identity of a committed profile file a bench figure is read from (sha1 of its bytes, first 12 hex digits) and
+    its modification date: a stale figure is visible in the line itself."""
+    import hashlib
+    p = ROOT / path
+    if not p.exists():
+        return None
+    return {"file": path, "sha1_12": hashlib.sha1(p.read_bytes()).hexdigest()[:12],
+            "mtime": time.strftime("%Y-%m-%d", time.gmtime(p.stat().st_mtime))}
+
+
+def kernel_shares(path, names):
+    """Share of the kernel time of each kernel whose name contains one of `names`, read from a kernel-statistics csv under profiles/
+    (rocprofv3 --stats: columns Name, ..., Percentage; the tools/rocpd_stats.py summaries: kernel, calls, total_us, avg_us, pct);
+    None if the file or a kernel is missing."""
+    import csv
+    p = ROOT / path
+    if not p.exists():
+        return None
+    out = {}
+    with open(p, newline="") as f:
+        for row in csv.DictReader(f):
+            nm, pct = row.get("Name") or row.get("kernel") or "", row.get("Percentage") or row.get("pct")
+            for n in names:
+                if n in nm and pct is not None:
+                    out[n] = round(out.get(n, 0.0) + float(pct), 1)
+    return out if all(n in out for n in names) else None
+
+
+KERNEL_STATS_CSV = ("profiles/r06_train_only_kernel_stats_12steps.csv", "profiles/r05_train_only_kernel_stats_12steps.csv")
+
+
+def dominant_kernel_note():
+    for path in KERNEL_STATS_CSV:
+        sh = kernel_shares(path, ("train_bwd_persistent_k", "train_fwd_persistent_k"))
+        if sh:
+            return (f"train_bwd_persistent_k ({sh['train_bwd_persistent_k']} % of kernel time, read from {path}): its figures are "
+                    f"roofline.backward; train_fwd_persistent_k ({sh['train_fwd_persistent_k']} %) is the top-level entry")
+    return "train_bwd_persistent_k (no kernel-statistics csv found under profiles/): its figures are roofline.backward"
+
+
 def sweep_ms(which):
     import ctypes as C
     ms = C.c_float(0)
@@ -350,7 +391,7 @@ def decode_30min(se, de, dev, minutes=30.0, reps=3):
             ts.append(t_dec)
         finite = bool(torch.isfinite(out[0]).all() and torch.isfinite(feats).all())
     se.train(), de.train()
-    t_dec = min(ts)
+    t_dec = float(np.mean(ts))                        # (mean of the repetitions; decode_s_all lists them)
     n_stft = audio.stft_frame_count(n)
     mel_bytes = n * 4 + T * 81 * 4                   # 200 new samples in per STFT frame, (80 + 1) x 60/80 floats out
     return {"frames": T, "mel_ms": round(t_mel * 1e3, 2), "speech_encoder_ms": round(t_se * 1e3, 2),
@@ -433,11 +474,11 @@ def generate_30min(dev, minutes=30.0, exemplar_frames=CLIP_FRAMES):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def time_regions(step, first, steps, regions=2):
-    """Seconds per step of the extras' engines: `regions` consecutive timed regions of `steps` steps each (synchronised on both
-    sides), the FASTEST reported and all of them listed -- the extras run first, in fresh processes on a box whose files are still
-    paging in, and one host stall in a region of five steps is a 10 % outlier (measured: 462 k six times in a row alone, 413 k
-    once inside the full run).  The headline keeps the contract's single region of exactly K steps."""
+def time_regions(step, first, steps, regions=3):
+    """Seconds per step of the extras' engines: `regions` (>= 3) consecutive timed regions of `steps` steps each (synchronised on
+    both sides); the MEAN over the regions is what is reported, every region is listed beside it (ms_per_step_regions: the spread is
+    visible -- the extras run first, in fresh processes on a box whose files are still paging in, and one host stall in a region of
+    five steps is a 10 % outlier).  The headline keeps the contract's single region of exactly K steps."""
     per = []
     for r in range(regions):
         torch.cuda.synchronize()
@@ -447,7 +488,7 @@ def time_regions(step, first, steps, regions=2):
             out = step(it)
         torch.cuda.synchronize()
         per.append((time.perf_counter() - t0) / steps)
-    return min(per), [round(x * 1e3, 3) for x in per], out
+    return float(np.mean(per)), [round(x * 1e3, 3) for x in per], out
 
 
 def v2_label_b64(ds, dev, steps=10, warmup=3, batch=64, nlabels=9):
@@ -791,7 +832,7 @@ def main():
         nst = WINDOW - 1
         f_us, b_us = float(np.mean(fw)) * 1e3 / nst, float(np.mean(bw)) * 1e3 / nst
         pmc = None
-        for name in ("r05_decoder_step_pmc.json", "r04_decoder_step_pmc.json", "r03_decoder_step_pmc.json", "r02_decoder_step_pmc.json", "r01_decoder_step_pmc.json"):
+        for name in ("r06_decoder_step_pmc.json", "r05_decoder_step_pmc.json", "r04_decoder_step_pmc.json", "r03_decoder_step_pmc.json", "r02_decoder_step_pmc.json", "r01_decoder_step_pmc.json"):
             if (ROOT / "profiles" / name).exists():
                 pmc = json.load(open(ROOT / "profiles" / name))
                 pmc["file"] = "profiles/" + name
@@ -806,6 +847,7 @@ def main():
                                        "integration + next step's layer0)") + ", per-step figures at B=32",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": pmc.get("traffic_bytes_per_step") if pmc else None,
+            "traffic_source": profile_stamp(pmc["file"]) if pmc else None,
             "us_per_step": round(f_us, 2), "us_per_step_in_timed_region": round(fwd_in * 1e3 / nst, 2),
             "algorithmic_bytes_per_step": step_bytes(BATCH),
             "backward": {"kernel": ("train_bwd_persistent_k: the 255 BPTT steps of a window as ONE weight-stationary launch "
@@ -816,8 +858,7 @@ def main():
                          "us_per_step_in_timed_region": round(bwd_in * 1e3 / nst, 2),
                          "traffic": pmc.get("traffic_bytes_per_step_backward") if pmc else None},
             "mfma_frac_at_b32": round(step_flops(BATCH) / (f_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-            "dominant_kernel": "train_bwd_persistent_k (27 % of kernel time, profiles/r05_train_only_kernel_stats_12steps.csv): "
-                               "its figures are roofline.backward; train_fwd_persistent_k (21 %) is the top-level entry",
+            "dominant_kernel": dominant_kernel_note(),
             "note": "HIP events (library hook zeggs_timing_ms, recorded on the stream the kernels run on) around the "
                     "255-step stage sweeps: the last timed iteration + 3 more; traffic = FETCH_SIZE(x2)+WRITE_SIZE "
                     f"from {pmc['file'] if pmc else 'n/a'}; at B=32 the step is also at the fp32 MFMA ridge"}

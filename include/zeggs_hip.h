@@ -71,6 +71,12 @@ int zeggs_gemm_tn_bias(const float* dy, long lddy, const float* x, long ldx, flo
  * inside a stream capture) and the kernel is disabled for the process -- the LDS-tiled stream-K kernel takes its products -- if the
  * check fails.  This entry point runs that check for one variant on demand: 1 = agrees, 0 = does not (tests, toolchain bumps). */
 int zeggs_gemm_direct_selftest(int big, int depth, int shield);
+/* Routing of the TN products launched BY THE CALLING THREAD from now on: the values of the options "gemm_direct", "gemm_direct_shield",
+ * "gemm_direct_depth", "gemm_direct_reserve" for this thread's launches, -1 = the process-wide option (zeggs_set_option).  The way
+ * a caller with preferences of its own (zeggs/engine.py: TrainEngine wants the shield variant for its three-queue tail) states them
+ * without changing what other engines or plain callers in the process get: per call, like ZeggsDecCall, not per process. */
+int zeggs_gemm_route(int direct, int shield, int depth, int reserve);
+int zeggs_gemm_route_get(int* out4);      /* the EFFECTIVE values for the calling thread (route, else process-wide option); host only */
 int zeggs_gemm_kbatch(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak, long sbk, long sbn,
                       long scm, long scn, int kbatch, long kbsA, long kbsB, float beta, void* stream);
 

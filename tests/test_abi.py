@@ -36,6 +36,44 @@ def test_workspace_queries_run_on_host():
     assert L.zeggs_loss_workspace_bytes(ctypes.byref(ld)) > 0
 
 
+def test_gemm_routing_is_per_thread_not_per_process():
+    """zeggs_gemm_route: a caller's routing of the TN products (what TrainEngine wants for its three-queue tail) is the calling
+    THREAD's; the process-wide options stay what they were for every other thread, and -1 falls back to them (host-only check)."""
+    import threading
+    L = ops.lib()
+    out = (ctypes.c_int * 4)()
+    L.zeggs_gemm_route_get(out)
+    base = list(out)
+    L.zeggs_gemm_route(1, 1, 8, 32)
+    L.zeggs_gemm_route_get(out)
+    assert list(out) == [1, 1, 8, 32]
+    seen = []
+
+    def other():
+        o = (ctypes.c_int * 4)()
+        L.zeggs_gemm_route_get(o)
+        seen.append(list(o))
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert seen == [base]                       # another thread: untouched
+    L.zeggs_gemm_route(-1, -1, 6, -1)
+    L.zeggs_gemm_route_get(out)
+    assert list(out) == [base[0], base[1], 6, base[3]]
+    L.zeggs_gemm_route(-1, -1, -1, -1)
+    L.zeggs_gemm_route_get(out)
+    assert list(out) == base
+    # the Python side: a context's route becomes the thread's at the entry of its calls, the default context resets it
+    ctx = ops.EngineContext()
+    ctx.gemm_route = (1, 2, 4, 16)
+    ops._route(ctx)
+    L.zeggs_gemm_route_get(out)
+    assert list(out) == [1, 2, 4, 16]
+    ops._route(ops._DEFAULT_CTX)
+    L.zeggs_gemm_route_get(out)
+    assert list(out) == base
+
+
 def test_no_cpu_fallback():
     se = modules.SpeechEncoder(synth.N_AUDIO, 64, 64)
     with pytest.raises(RuntimeError, match="GPU"):

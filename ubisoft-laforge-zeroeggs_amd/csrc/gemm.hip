@@ -734,12 +734,20 @@ int g_gemm_direct_shield = 0;  // zeggs_set_option("gemm_direct_shield", 0 / 1 /
 int g_gemm_asum = 1;           // zeggs_set_option("gemm_asum", 0/1): bias column sums inside the weight-gradient product (A/B)
 int g_gemm_direct_reserve = 0; // zeggs_set_option("gemm_direct_reserve", n): CUs the shield variant's grid leaves out
 int g_gemm_direct_wgs = 0;     // zeggs_set_option("gemm_direct_wgs", n): workgroups per CU (0: 1 for the 128 x 64 wave tile, 2 for 64 x 64)
+// Routing of the TN products is per CALLING THREAD (zeggs_gemm_route: what an engine wants for ITS launches travels with its calls,
+// a second engine or a plain caller in the same process keeps the process-wide options above); -1 = the process-wide option.
+static thread_local int tl_route[4] = {-1, -1, -1, -1};
+static bool g_direct_failed = false;       // a variant's first-use check failed: off for the process, whatever a route says
+static inline int rt_direct() { return g_direct_failed ? 0 : tl_route[0] >= 0 ? tl_route[0] : g_gemm_direct; }
+static inline int rt_shield() { return tl_route[1] >= 0 ? tl_route[1] : g_gemm_direct_shield; }
+static inline int rt_depth() { return tl_route[2] >= 0 ? tl_route[2] : g_gemm_direct_depth; }
+static inline int rt_reserve() { return tl_route[3] >= 0 ? tl_route[3] : g_gemm_direct_reserve; }
 bool direct_ok(const GemmArgs& g) {
   // 5: only the products of the encoders' backward chains (batch-reduce convolution weight gradients, small outputs): they run
   // BESIDE the decoder's resident LDS-tiled stream-K workgroups (101 VGPRs x 4 per SIMD, 135 of 160 KB LDS), where a kernel that
   // needs no LDS and <= 108 VGPRs is the one that still gets a wave per SIMD
-  if (g_gemm_direct == 5 && !(g.kbatch > 1 || (long)g.M * g.N < 400000)) return false;
-  return g_gemm_direct && g.sam == 1 && g.sbn == 1 && g.scn == 1 && g.K % 2 == 0 && g.K >= 64 && g.M >= 64 && g.N >= 64 &&
+  if (rt_direct() == 5 && !(g.kbatch > 1 || (long)g.M * g.N < 400000)) return false;
+  return rt_direct() && g.sam == 1 && g.sbn == 1 && g.scn == 1 && g.K % 2 == 0 && g.K >= 64 && g.M >= 64 && g.N >= 64 &&
          ((long)g.M + g.sak) * 4 < (1L << 31) && ((long)g.N + g.sbk) * 4 < (1L << 31);
 }
 // Measured (tools/gemm_direct_probe.py, TFLOP/s incl. the zero fill of C; LDS-tiled stream-K kernel -> direct): dW_hh 3072 x 1024 x 8160
@@ -750,7 +758,7 @@ bool direct_ok(const GemmArgs& g) {
 static thread_local bool tl_asum_consumed = false;      // set by launch_tn_direct when it was given GemmArgs.asum (gemm_tn_bias)
 int launch_tn_direct(GemmArgs g, hipStream_t s) {
   if (g.asum) tl_asum_consumed = true;
-  const bool big = g_gemm_direct == 2 || (g_gemm_direct == 1 && (long)cdiv(g.M, 128) * cdiv(g.N, 128) >= 384);      // (3, 5: 64 x 64)
+  const bool big = rt_direct() == 2 || (rt_direct() == 1 && (long)cdiv(g.M, 128) * cdiv(g.N, 128) >= 384);      // (3, 5: 64 x 64)
   const int mt = big ? 4 : 2, nt = 2;
   const int tx = cdiv(g.N, 64 * nt), ty = cdiv(g.M, 64 * mt);
   const int cpb = cdiv(g.K / 2, 8);
@@ -758,16 +766,16 @@ int launch_tn_direct(GemmArgs g, hipStream_t s) {
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   // shield = 2: only the big single-segment products (the decoder's weight gradients on the second queue); the encoders' chain
   // products stay the kind that fits in beside other queues' workgroups
-  const bool shield = g_gemm_direct_shield == 1 || (g_gemm_direct_shield == 2 && g.kbatch == 1 && (long)g.M * g.N >= 400000);
+  const bool shield = rt_shield() == 1 || (rt_shield() == 2 && g.kbatch == 1 && (long)g.M * g.N >= 400000);
   long nwg = (long)ncu * (shield ? 1 : g_gemm_direct_wgs > 0 ? g_gemm_direct_wgs : (big ? 1 : 2));
   // option "gemm_direct_reserve": CUs a shielded product leaves free.  For data-parallel runs: the collective's workgroups live for
   // the whole exchange, and a stream-K product whose equal-share workgroups do not ALL become resident takes twice as long (the
   // stragglers start when the first ones end); with the CUs of the collective left out of the grid nobody waits for anybody.
   // (On one GPU, where nothing else is resident: 8 / 16 / 32 reserved CUs measured 17.13 / 17.17 / 17.02 ms against 17.03.)
-  if (shield && g_gemm_direct_reserve > 0 && g_gemm_direct_reserve < ncu / 2) nwg = ncu - g_gemm_direct_reserve;
+  if (shield && rt_reserve() > 0 && rt_reserve() < ncu / 2) nwg = ncu - rt_reserve();
   const long total = (long)tx * ty * cpb * g.kbatch;
   if (nwg > total / 4) nwg = total / 4 > 0 ? total / 4 : 1;     // at least 4 chunks (64 k) per workgroup
-  const int dep = g_gemm_direct_depth;
+  const int dep = rt_depth();
 #define ZG_DIRECT(MT_, D_)                                                                                                    \
   do {                                                                                                                         \
     if (shield) hipLaunchKernelGGL((gemm_tn_direct_shield_kernel<MT_, 2, D_>), dim3((unsigned)nwg), dim3(256), 0, s, g, tx, ty, cpb); \
@@ -832,11 +840,15 @@ static bool direct_selftest(bool big, int dep, bool shield) {
   if (ok) {
     GemmArgs g = gemm_args(dA, dB, dC, M, N, K);      // C(m, n) = sum_k A[k][m] B[k][n]
     g.sam = 1; g.sak = ldA; g.sbk = ldB; g.sbn = 1; g.scm = N; g.scn = 1; g.asum = dS;
-    const int sv_direct = g_gemm_direct, sv_dep = g_gemm_direct_depth, sv_sh = g_gemm_direct_shield, sv_res = g_gemm_direct_reserve;
-    g_gemm_direct = big ? 2 : 3; g_gemm_direct_depth = dep; g_gemm_direct_shield = shield ? 1 : 0; g_gemm_direct_reserve = 0;
+    int sv[4];
+    for (int i = 0; i < 4; ++i) sv[i] = tl_route[i];
+    tl_route[0] = big ? 2 : 3; tl_route[1] = shield ? 1 : 0; tl_route[2] = dep; tl_route[3] = 0;
+    const bool sv_failed = g_direct_failed;
+    g_direct_failed = false;
     ok = launch_tn_direct(g, (hipStream_t)0) == 0;
     tl_asum_consumed = false;
-    g_gemm_direct = sv_direct; g_gemm_direct_depth = sv_dep; g_gemm_direct_shield = sv_sh; g_gemm_direct_reserve = sv_res;
+    g_direct_failed = sv_failed;
+    for (int i = 0; i < 4; ++i) tl_route[i] = sv[i];
     ok = ok && hipStreamSynchronize((hipStream_t)0) == hipSuccess &&
          hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost) == hipSuccess &&
          hipMemcpy(hS.data(), dS, hS.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
@@ -863,9 +875,9 @@ static bool direct_selftest(bool big, int dep, bool shield) {
 }
 // true: the variant launch_tn_direct would pick for g is checked (or cannot be checked right now: stream capture)
 static bool direct_checked(const GemmArgs& g, hipStream_t s) {
-  const bool big = g_gemm_direct == 2 || (g_gemm_direct == 1 && (long)cdiv(g.M, 128) * cdiv(g.N, 128) >= 384);
-  const bool shield = g_gemm_direct_shield == 1 || (g_gemm_direct_shield == 2 && g.kbatch == 1 && (long)g.M * g.N >= 400000);
-  const int di = g_gemm_direct_depth >= 8 ? 2 : g_gemm_direct_depth >= 6 ? 1 : 0;
+  const bool big = rt_direct() == 2 || (rt_direct() == 1 && (long)cdiv(g.M, 128) * cdiv(g.N, 128) >= 384);
+  const bool shield = rt_shield() == 1 || (rt_shield() == 2 && g.kbatch == 1 && (long)g.M * g.N >= 400000);
+  const int di = rt_depth() >= 8 ? 2 : rt_depth() >= 6 ? 1 : 0;
   int& st = g_direct_checked[big][di][shield];
   if (st == 1) return true;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -873,7 +885,7 @@ static bool direct_checked(const GemmArgs& g, hipStream_t s) {
   if (direct_selftest(big, di == 2 ? 8 : di == 1 ? 6 : 4, shield)) { st = 1; return true; }
   fprintf(stderr, "zeggs: the direct TN GEMM kernel is DISABLED for this process (self-test failed: built with another compiler?); "
                   "the LDS-tiled stream-K kernel takes its products\n");
-  g_gemm_direct = 0;
+  g_direct_failed = true;
   return false;
 }
 int launch_streamk(GemmArgs g, hipStream_t s) {
@@ -1020,6 +1032,14 @@ void zeggs_gemm_set_direct(int mode, int wgs) { if (mode >= 0) g_gemm_direct = m
 void zeggs_gemm_set_direct_depth(int d) { g_gemm_direct_depth = d; }
 void zeggs_gemm_set_direct_shield(int on) { g_gemm_direct_shield = on; }
 void zeggs_gemm_set_direct_reserve(int n) { g_gemm_direct_reserve = n; }
+extern "C" int zeggs_gemm_route(int direct, int shield, int depth, int reserve) {
+  tl_route[0] = direct; tl_route[1] = shield; tl_route[2] = depth; tl_route[3] = reserve;
+  return 0;
+}
+extern "C" int zeggs_gemm_route_get(int* out4) {      // what this thread's next TN product would be routed by
+  out4[0] = rt_direct(); out4[1] = rt_shield(); out4[2] = rt_depth(); out4[3] = rt_reserve();
+  return 0;
+}
 void zeggs_gemm_set_asum(int on) { g_gemm_asum = on; }
 int g_gemm_skinny = 1;          // zeggs_set_option("gemm_skinny", 0/1): batch-sized NT products in one launch
 int g_gemm_streamk = 1;        // zeggs_set_option("gemm_streamk", 0/1): stream-K instead of the many-workgroup split-K

@@ -236,14 +236,12 @@ class TrainEngine:
             # it needs no LDS and half the registers, so other queues' waves move in beside it (17.9 ms per iteration against 17.2
             # with the LDS-tiled kernel, whose footprint keeps a CU to itself).  Its "shield" variant allocates the whole register
             # file of its SIMDs (one wave per SIMD, 512 registers, 8 operand pairs in flight): the same isolation, the direct
-            # kernel's rate -- 16.8 ms (profiles/r05_gemm_direct_ab.txt)
-            ops.set_option("gemm_direct", 1)
-            ops.set_option("gemm_direct_shield", 1)
-            ops.set_option("gemm_direct_depth", 8)
-            if world_size > 1:
-                # ... and leaves the CUs of the gradient exchange out of its grids: RCCL's workgroups are resident for the whole
-                # all-reduce, and a stream-K product whose workgroups cannot all be resident waits for its stragglers (gemm.hip)
-                ops.set_option("gemm_direct_reserve", 32)
+            # kernel's rate -- 16.8 ms (profiles/r05_gemm_direct_ab.txt).  With more than one rank it leaves the CUs of the gradient
+            # exchange out of its grids: RCCL's workgroups are resident for the whole all-reduce, and a stream-K product whose
+            # workgroups cannot all be resident waits for its stragglers (gemm.hip; profiles/r06_reserve_ab.txt).
+            # The routing belongs to THIS engine's calls (zeggs_gemm_route through ops.EngineContext): another engine or a plain
+            # caller in the process keeps the library's defaults; a caller who set the options himself keeps his.
+            self.ctx.gemm_route = (1, 1, 8, int(os.environ.get("ZEGGS_GEMM_RESERVE", 32)) if world_size > 1 else 0)
         # the speech encoder (a short chain of small launches, forward and -- autograd replays a node on the stream of its
         # forward -- backward) beside the style encoder
         self.aux_stream = torch.cuda.Stream(device=dataset.device) if on_gpu else None
@@ -362,8 +360,8 @@ class TrainEngine:
         self._rearm_at = None
         self._rearmed_at = self.iteration
         self.rearm_count += 1
-        ops.set_option("train_persistent", 1)
-        ops.set_option("bwd_persistent", 1)
+        for k in getattr(self, "_rearm_what", ("train_persistent", "bwd_persistent")):
+            ops.set_option(k, 1)
 
     def _post_status(self):
         """After the optimizer step: copy the status words to a pinned slot (asynchronous) for the look STATUS_LAG steps on."""
@@ -407,6 +405,8 @@ class TrainEngine:
                       f"{n} optimizer step(s) were skipped on the device and are re-run on the stage kernels "
                       "(train_persistent / bwd_persistent off"
                       + (f", back on after {self._rearm_wait} clean iterations)" if self.rearm_after > 0 else " for this process)"))
+        # (what the caller had on before: only that is re-armed later -- a sweep he switched off for an A/B stays off)
+        self._rearm_what = [k for k in ("train_persistent", "bwd_persistent") if ops._OPTIONS.get(k, 1)]
         ops.set_option("train_persistent", 0)
         ops.set_option("bwd_persistent", 0)
         ops.fill_(self.status.view(torch.float32))

@@ -155,6 +155,7 @@ class EngineContext:
         self.prepared_hits = 0
         self.wgrad_keepalive = []          # workspaces the deferred GEMMs still read, until the caller joined wgrad_stream
         self.seed_rng = None               # own noise-seed generator (None: the process-wide stream of ops.manual_seed)
+        self.gemm_route = None             # (direct, shield, depth, reserve) of THIS context's weight-gradient products (zeggs_gemm_route)
 
     def release_wgrad_workspaces(self):
         """After the caller has made its stream wait for wgrad_stream: the decoder workspaces the deferred weight-gradient
@@ -167,6 +168,16 @@ class EngineContext:
 
 _DEFAULT_CTX = EngineContext()          # plain autograd use (tests, the reference's own loop): nothing special
 _tls = threading.local()
+
+
+def _route(ectx):
+    """Entry of every call that launches matrix products: the GEMM routing of the context the call belongs to becomes the calling
+    thread's (forward: the thread inside `ops.use`, backward: autograd's worker thread, with the context its forward captured).  One
+    ctypes call when the thread's route changes, nothing otherwise."""
+    r = ectx.gemm_route or (-1, -1, -1, -1)
+    if getattr(_tls, "route", (-1, -1, -1, -1)) != r:
+        lib().zeggs_gemm_route(*[int(x) for x in r])
+        _tls.route = r
 
 
 def current():
@@ -319,6 +330,7 @@ class _SpeechFn(torch.autograd.Function):
     def forward(ctx, x, w0, b0, w1, b1, w2, b2, p, seed):
         x = _f32c(x)
         ctx.ectx = current()
+        _route(ctx.ectx)
         ctx.orig = (w0, b0, w1, b1, w2, b2)
         params = [_f32c(t) for t in (w0, b0, w1, b1, w2, b2)]
         B, T, F = x.shape
@@ -337,6 +349,7 @@ class _SpeechFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, out, *params = ctx.saved_tensors
         L = lib()
+        _route(ctx.ectx)
         grads, rets = _grad_targets(ctx.orig, params, ctx.ectx)
         P = _ptrs(SpeechPtrs, SPEECH_FIELDS, params)
         G = _ptrs(SpeechPtrs, SPEECH_FIELDS, grads)
@@ -388,6 +401,7 @@ class _StyleFn(torch.autograd.Function):
     def forward(ctx, x, pos, dropout, seed, nheads, *params):
         x = _f32c(x)
         ctx.ectx = current()
+        _route(ctx.ectx)
         ctx.orig = params
         params = [_f32c(t) for t in params]
         B, Lx, Cx = x.shape
@@ -415,6 +429,7 @@ class _StyleFn(torch.autograd.Function):
     def backward(ctx, dout):
         params = list(ctx.saved_tensors)
         L = lib()
+        _route(ctx.ectx)
         grads, rets = _grad_targets(ctx.orig, params, ctx.ectx)
         P = _ptrs(StylePtrs, STYLE_FIELDS, params)
         G = _ptrs(StylePtrs, STYLE_FIELDS, grads)
@@ -438,6 +453,7 @@ class _StyleGruFn(torch.autograd.Function):
     def forward(ctx, x, *params):
         x = _f32c(x)
         ctx.ectx = current()
+        _route(ctx.ectx)
         ctx.orig = params
         params = [_f32c(t) for t in params]
         B, Lx, Cx = x.shape
@@ -456,6 +472,7 @@ class _StyleGruFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         params = list(ctx.saved_tensors)
+        _route(ctx.ectx)
         grads, rets = _grad_targets(ctx.orig, params, ctx.ectx)
         P = _ptrs(StyleGruPtrs, STYLE_GRU_FIELDS, params)
         G = _ptrs(StyleGruPtrs, STYLE_GRU_FIELDS, grads)
@@ -541,6 +558,7 @@ def decoder_prepare(dec, B, T, SP, ST, in_mean, in_std, out_mean, out_std, dt, s
     (zeggs_decoder_prepare) on `stream`, beside whatever the current stream does meanwhile (the encoders' forward); that
     call picks the prepared workspace up and waits for it.  The weights must not change in between."""
     ectx = current()
+    _route(ectx)
     _drop_prepared(ectx)
     params = [_f32c(t) for t in decoder_param_list(dec)]
     stats = [_f32c(t) for t in (in_mean, in_std, out_mean, out_std)]
@@ -580,6 +598,7 @@ class _DecoderFn(torch.autograd.Function):
         pose0, rpos0, rrot0, gaze, speech, style = (_f32c(t) for t in (pose0, rpos0, rrot0, gaze, speech, style))
         stats = [_f32c(t) for t in (in_mean, in_std, out_mean, out_std)]
         ectx = ctx.ectx = current()
+        _route(ctx.ectx)
         ctx.orig = params
         params = [_f32c(t) for t in params]
         B, T, SP = speech.shape
@@ -654,6 +673,7 @@ class _DecoderFn(torch.autograd.Function):
         stats, params = rest[:4], rest[4:]
         d = ctx.d
         ectx = ctx.ectx
+        _route(ectx)
         L = lib()
         dev = pose.device
         z = lambda g, ref: fill_(torch.empty_like(ref)) if g is None else _f32c(g)  # noqa: E731
