@@ -247,6 +247,16 @@ def gold_mel(ref):
         out[f"{tag}_nframes"] = np.int64(nfr)
     np.savez_compressed(GOLD / "mel.npz", **out)
     print("mel.npz", {k: v.shape for k, v in out.items() if k.endswith("feat")})
+    # audio_conf.normalize_mel_bins = false (spectrograms.py:431-440: the filterbank's rows keep unit peaks), same signals
+    conf["audio_conf"]["normalize_mel_bins"] = False
+    ac = ref.DictConfig(conf["audio_conf"])
+    out2 = {}
+    for tag in "ab":
+        wav, nfr = out[f"{tag}_wav"], int(out[f"{tag}_nframes"])
+        out2[f"{tag}_wav"], out2[f"{tag}_nframes"] = wav, np.int64(nfr)
+        out2[f"{tag}_feat"] = ref.data_pipeline.preprocess_audio(wav, 60, nfr, ac, feature_type=conf["audio_feature_type"])
+    np.savez_compressed(GOLD / "mel_nonorm.npz", **out2)
+    print("mel_nonorm.npz")
 
 
 def gold_dataset(ref):

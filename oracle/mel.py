@@ -71,7 +71,7 @@ def mel_filterbank(n_fft=800, fs=16000, n_mels=80, fmin=20.0, fmax=7600.0, norma
 
 
 def mel_spectrogram(wav, n_fft=800, hop=200, fs=16000, n_mels=80, fmin=20.0, fmax=7600.0,
-                    min_clip=1e-5):
+                    min_clip=1e-5, normalize_mel_bins=True):
     """extract_mel_spectrogram_for_tts (spectrograms.py:8-54) with the shipped
     conf (centered, real_amplitude, normalize_mel_bins, normalize_range, no
     pre-emphasis): returns [n_mels, M] in [0, ~1]."""
@@ -83,7 +83,7 @@ def mel_spectrogram(wav, n_fft=800, hop=200, fs=16000, n_mels=80, fmin=20.0, fma
     idx = np.arange(M)[:, None] * hop + np.arange(n_fft)[None, :]
     frames = x[idx] * hann_symmetric(n_fft)[None, :]
     amp = np.abs(np.fft.rfft(frames, axis=1)).T / n_fft            # [401, M]
-    mel = mel_filterbank(n_fft, fs, n_mels, fmin, fmax) @ amp      # [80, M]
+    mel = mel_filterbank(n_fft, fs, n_mels, fmin, fmax, normalize_mel_bins) @ amp      # [80, M]
     amin = min_clip / n_fft
     mel = np.clip(np.abs(mel), amin, None)
     db = 20.0 * np.log10(mel)

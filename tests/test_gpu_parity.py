@@ -657,6 +657,24 @@ def test_mel_features_vs_reference(golden_dir):
         np.testing.assert_allclose(feat, ref, atol=2e-6, equal_nan=True)
 
 
+def test_mel_unnormalised_bins_vs_reference(golden_dir):
+    """audio_conf.normalize_mel_bins = false (ZEGGS/audio/spectrograms.py:431-440) through the drop-in preprocess_audio: the one
+    non-shipped audio option value that has a device path (the filterbank is a host table either way)."""
+    import json
+    from zeggs import audio
+    gd = np.load(golden_dir / "mel_nonorm.npz")
+    conf = dict(sampling_rate=16000, filter_length=800, hop_length=200, n_mel_channels=80, mel_fmin=20, mel_fmax=7600,
+                min_clipping=1e-5, pre_emphasis=False, pre_emph_coeff=0.97, real_amplitude=True, centered=True,
+                normalize_mel_bins=False, normalize_range=True, normalize_loudness=False, resample_method="linear")
+    for tag in "ab":
+        wav, nfr = gd[f"{tag}_wav"], int(gd[f"{tag}_nframes"])
+        feat = audio.preprocess_audio(wav, 60, nfr, conf, ["mel_spec", "energy"])
+        ref = gd[f"{tag}_feat"]
+        np.testing.assert_array_equal(np.isnan(feat), np.isnan(ref))
+        np.testing.assert_allclose(feat, ref, atol=2e-6, equal_nan=True)
+    json.dumps(conf)
+
+
 def test_mel_fft_form_equals_the_dft_forms(golden_dir):
     """Round 4: the STFT as a real FFT (half-length complex mixed-radix Stockham transform in LDS + split, what the reference's
     np.fft.rfft computes) is the default; the fp64 matrix-core DFT (round 3) and the direct DFT stay behind options.  All three

@@ -146,6 +146,11 @@ def test_oracle_mel_vs_reference(golden_dir):
         feat = omel.preprocess_audio(wav, int(g[f"{tag}_nframes"]))
         np.testing.assert_array_equal(np.isnan(feat), np.isnan(g[f"{tag}_feat"]))
         np.testing.assert_allclose(feat, g[f"{tag}_feat"], atol=1e-6, equal_nan=True)
+    g = np.load(golden_dir / "mel_nonorm.npz")          # audio_conf.normalize_mel_bins = false
+    for tag in "ab":
+        feat = omel.preprocess_audio(g[f"{tag}_wav"], int(g[f"{tag}_nframes"]), normalize_mel_bins=False)
+        np.testing.assert_array_equal(np.isnan(feat), np.isnan(g[f"{tag}_feat"]))
+        np.testing.assert_allclose(feat, g[f"{tag}_feat"], atol=1e-6, equal_nan=True)
 
 
 def test_oracle_dataset_indices_vs_reference(golden_dir):
