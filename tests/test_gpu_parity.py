@@ -402,7 +402,18 @@ def _pack_pose(vel, vrt, lpos, ltxy, lvel, lvrt):
                       lvrt.reshape(B, T, -1)], dim=-1)
 
 
-def test_loss_forward_backward_vs_oracle():
+@pytest.mark.parametrize("loss_lds", [1, 0])
+def test_loss_forward_backward_vs_oracle(loss_lds):
+    """loss_lds = 0: the frame kernels without their LDS message buffers (the level hand-off through the global tables: what a part
+    that refuses 147 KB of dynamic LDS gets, and what skeletons with a level wider than 16 joints get anyway)."""
+    ops.set_option("loss_lds", loss_lds)
+    try:
+        _loss_forward_backward_vs_oracle()
+    finally:
+        ops.set_option("loss_lds", 1)
+
+
+def _loss_forward_backward_vs_oracle():
     stats = synth.make_stats()
     B, T = 3, 7
     rng = np.random.default_rng(4)

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs a) {
   load_row_slots(qf, base, ld, cq, a.scale * LOG2E, kh);
   const uint64_t prow64 = (uint64_t)((long)bh * L + myq) * (uint64_t)L;      // element index of P[bh][myq][0]
   const uint32_t prow = (uint32_t)prow64, phi = (uint32_t)(prow64 >> 32);
-  const uint32_t hkey = hash_key(a.seed);
+  const HKey hkey = hash_key(a.seed);
   const float inv_keep = 1.f / (1.f - a.p);
   f16v o;
 #pragma unroll
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_k(AttnArgs a) {
   const float lse = myq < L ? a.lse[(long)bh * L + cq] : INFINITY;      // rows beyond L: every probability 2^(-inf) = 0
   const uint64_t prow64 = (uint64_t)((long)bh * L + myq) * (uint64_t)L;      // element index of P[bh][myq][0]
   const uint32_t prow = (uint32_t)prow64, phi = (uint32_t)(prow64 >> 32);
-  const uint32_t hkey = hash_key(a.seed);
+  const HKey hkey = hash_key(a.seed);
   const float inv_keep = 1.f / (1.f - a.p);
   f16v dqT;
 #pragma unroll
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_k(AttnArgs a) {
   if (tid < 32) { ls[0][tid] = ln; dsm[0][tid] = dn; }
   __syncthreads();
   const uint32_t koff = (uint32_t)mykey + (uint32_t)(4 * kh) * (uint32_t)L;      // this lane's share of the element index
-  const uint32_t hkey = hash_key(a.seed);
+  const HKey hkey = hash_key(a.seed);
   const float inv_keep = 1.f / (1.f - a.p);
   const int nt = (L + 31) >> 5;
   for (int t = 0; t < nt; ++t) {

@@ -131,12 +131,27 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 14;
   return x;
 }
-__device__ __forceinline__ uint32_t hash_key(uint64_t seed) {      // wave-uniform: lives in SGPRs
-  return mix32(((uint32_t)seed * 0x9E3779B1u) ^ (uint32_t)(seed >> 32));
+// Round 6: the seed keys TWO places.  With the key only added to the counter, every seed walks the SAME 2^32-long
+// sequence from another offset, and two masks are shifted copies of each other whenever their keys lie closer than the mask is
+// long (2^25 attention probabilities: ~1 % of the seed pairs of a run).  A second word derived from the seed, added between the
+// first and the second multiply, makes the sequences of two seeds different functions of the counter (tools/hash_quality.py:
+// window-overlap check); cost: one add.  Both words are wave-uniform: scalar registers.
+struct HKey { uint32_t a, b; };
+__device__ __forceinline__ HKey hash_key(uint64_t seed) {
+  const uint32_t k = mix32(((uint32_t)seed * 0x9E3779B1u) ^ (uint32_t)(seed >> 32));
+  return HKey{k, mix32(k ^ 0x85ebca6bu)};
+}
+__device__ __forceinline__ uint32_t mix32k(uint32_t x, uint32_t k2) {
+  x ^= x >> 17; x *= 0xed5ad4bbu;
+  x ^= x >> 11; x += k2; x *= 0xac4c1b51u;
+  x ^= x >> 15; x *= 0x31848babu;
+  x ^= x >> 14;
+  return x;
 }
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
   const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-  return mix32((lo ^ ((hi << 16) | (hi >> 16))) + hash_key(seed));
+  const HKey k = hash_key(seed);
+  return mix32k((lo ^ ((hi << 16) | (hi >> 16))) + k.a, k.b);
 }
 // keep-scale for element idx: 0 (dropped) or 1/(1-p)
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
@@ -146,8 +161,8 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, floa
 }
 // the same value without the branch and with the loop invariants hoisted by the caller (key = hash_key(seed), the element index
 // as two words, inv_keep = 1 / (1 - p)): the form the fused attention kernels use, one mask value per probability
-__device__ __forceinline__ float dropout_scale_fast(uint32_t key, uint32_t lo, uint32_t hi, float p, float inv_keep) {
-  const uint32_t hsh = mix32((lo ^ ((hi << 16) | (hi >> 16))) + key);
+__device__ __forceinline__ float dropout_scale_fast(HKey key, uint32_t lo, uint32_t hi, float p, float inv_keep) {
+  const uint32_t hsh = mix32k((lo ^ ((hi << 16) | (hi >> 16))) + key.a, key.b);
   const float u = (float)(hsh >> 8) * (1.0f / 16777216.0f);
   return u < p ? 0.f : inv_keep;
 }

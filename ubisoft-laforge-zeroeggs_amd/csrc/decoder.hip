@@ -31,6 +31,7 @@ extern int g_gemm_streamk;
 extern int g_gemm_skinny;
 extern int g_tp_tiles4;
 extern int g_tp_dual;
+extern int g_loss_lds;
 void zeggs_gemm_set_dma(int on);
 void zeggs_gemm_set_direct(int mode, int wgs);
 void zeggs_gemm_set_direct_depth(int d);
@@ -86,6 +87,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   // tests use it to drive the give-up path (tests/test_gpu_giveup.py)
   if (strcmp(name, "tp_tiles4") == 0) { g_tp_tiles4 = value != 0; return 0; }
   if (strcmp(name, "tp_dual") == 0) { g_tp_dual = value != 0; return 0; }
+  if (strcmp(name, "loss_lds") == 0) { g_loss_lds = value != 0; return 0; }
   if (strcmp(name, "poll_stagger") == 0) { g_poll_stagger = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "poll_sleep") == 0) { g_poll_sleep = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "persistent_spin") == 0) { g_persistent_spin = value < 0 ? 0 : value; return 0; }

@@ -202,7 +202,7 @@ extern __shared__ float loss_msg[];
 // depends on the batch only: zeggs_loss_prepare_truth runs it ahead of the step)
 __global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_fwd_k(ZeggsLossDims d, const int* parents, FrameIO io0, FrameIO io1,
                                                         const float* PT0, const float* PT1, const float* gaze, float* F0,
-                                                        float* F1, float* LM_, long gid0, long gid_end) {
+                                                        float* F1, float* LM_, long gid0, long gid_end, int lds_ok) {
   __shared__ Levels lv;
   const long NF = (long)d.B * d.T;
   build_levels(lv, parents, d.J);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_fwd_k(ZeggsL
    else __syncthreads();              // ... from the tables (same CU: L1 is coherent within the workgroup)
   }
   };
-  if (lv.maxw <= LOSS_LW) walk(std::true_type{});
+  if (lv.maxw <= LOSS_LW && lds_ok) walk(std::true_type{});      // (lds_ok == 0: launched without the message buffers)
   else walk(std::false_type{});
 }
 
@@ -487,7 +487,7 @@ struct JIn { M3 pm, L, gcm; V3 pw, lp, lv, lw, gcp, gcv, gcw, glp, glv, glw, x, 
 
 __global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_bwd_k(ZeggsLossDims d, const int* parents, FrameIO io, const float* gaze,
                                                          const float* PT, const float* F, const float* LM, float* G,
-                                                         float* DPT, float* drpos, float* DQ) {
+                                                         float* DPT, float* drpos, float* DQ, int lds_ok) {
   __shared__ Levels lv;
   __shared__ Children ch;
   const long NF = (long)d.B * d.T;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(64 * ZEGGS_LOSS_WAVES) void loss_frame_bwd_k(ZeggsL
     orth_bwd(i, gL, a);
   };
 
-  const bool lds_walk = lv.maxw <= LOSS_LW;
+  const bool lds_walk = lv.maxw <= LOSS_LW && lds_ok;
   JIn root;                                   // joint 0's reads (wave 0): fetched under the walk as well
   if (lds_walk) {
     JIn cur;
@@ -775,14 +775,20 @@ __global__ __launch_bounds__(1024) void loss_kl_final_k(const float* mu, const f
 
 }  // namespace
 
-// the frame kernels' message buffers (dynamic LDS above the 64 KB default)
+int g_loss_lds = 1;      // zeggs_set_option("loss_lds", 0): the table walk in global memory (what a part without 160 KB of LDS gets; tests)
+// the frame kernels' message buffers (dynamic LDS above the 64 KB default): per DEVICE (the function attribute is), and a part
+// that refuses them (less than 160 KB of LDS per workgroup) walks the tables in global memory instead (lds_ok = 0, no dynamic LDS)
 static int loss_lds_ready() {
-  static int ok = -1;
-  if (ok < 0) {
-    ok = hipFuncSetAttribute((const void*)loss_frame_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LOSS_LDS_BYTES) == hipSuccess &&
-         hipFuncSetAttribute((const void*)loss_frame_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LOSS_LDS_BYTES) == hipSuccess;
+  static int ok[64];      // 0 unknown, 1 granted, 2 refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (ok[dev] == 0) {
+    const bool g = hipFuncSetAttribute((const void*)loss_frame_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LOSS_LDS_BYTES) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)loss_frame_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LOSS_LDS_BYTES) == hipSuccess;
+    if (!g) (void)hipGetLastError();
+    ok[dev] = g ? 1 : 2;
   }
-  return ok;
+  return ok[dev] == 1;
 }
 
 extern "C" size_t zeggs_loss_workspace_bytes(const ZeggsLossDims* d) {
@@ -802,13 +808,13 @@ extern "C" int zeggs_loss_prepare_truth(const ZeggsLossDims* dp, const int* pare
   LossWs w = carve_loss(d, a);
   ZCHECK(a.ok(), "loss: workspace too small (%zu < %zu)", ws_bytes, a.off);
   ZCHECK(d.J >= 1 && d.J <= MAXJ && d.T >= 1 && d.B >= 1, "loss: bad dims");
-  ZCHECK(loss_lds_ready(), "loss: the frame kernels' LDS size was refused");
+  const int lds_ok = g_loss_lds ? loss_lds_ready() : 0;
   const long NF = (long)d.B * d.T;
   const int PO = 6 + 15 * d.J;
   FrameIO ioW{w_pose, w_rpos, w_rrot};
   hipLaunchKernelGGL(transpose_k, dim3((unsigned)cdiv(NF, 64), (unsigned)cdiv(PO, 64)), dim3(256), 0, s, w.PT1, w_pose, NF, PO);
-  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(NF, 64)), dim3(64 * ZEGGS_LOSS_WAVES), LOSS_LDS_BYTES, s, d, parents, ioW, ioW, w.PT1, w.PT1, gaze, w.FW, w.FW,
-                     w.LM, NF, 2 * NF);
+  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(NF, 64)), dim3(64 * ZEGGS_LOSS_WAVES), lds_ok ? LOSS_LDS_BYTES : 0, s, d, parents, ioW, ioW, w.PT1, w.PT1, gaze, w.FW, w.FW,
+                     w.LM, NF, 2 * NF, lds_ok);
   ZLAUNCH_CHECK("loss_prepare_truth");
   return 0;
 }
@@ -832,7 +838,7 @@ extern "C" int zeggs_loss_fwd_bwd_ex(const ZeggsLossDims* dp, const int* parents
   LossWs w = carve_loss(d, a);
   ZCHECK(a.ok(), "loss: workspace too small (%zu < %zu)", ws_bytes, a.off);
   ZCHECK(d.J >= 1 && d.T >= 1 && d.B >= 1, "loss: bad dims");
-  ZCHECK(loss_lds_ready(), "loss: the frame kernels' LDS size was refused");
+  const int lds_ok = g_loss_lds ? loss_lds_ready() : 0;
   const long NF = (long)d.B * d.T;
   const Off o = offsets(d.J);
   FrameIO ioO{o_pose, o_rpos, o_rrot}, ioW{w_pose, w_rpos, w_rrot};
@@ -844,8 +850,8 @@ extern "C" int zeggs_loss_fwd_bwd_ex(const ZeggsLossDims* dp, const int* parents
   ZCHECK(d.J <= MAXJ, "loss: more than %d joints", MAXJ);
   // (truth_prepared: zeggs_loss_prepare_truth has filled PT1 / FW of THIS workspace; only the prediction side is left)
   const long gend = truth_prepared ? NF : 2 * NF;
-  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(gend, 64)), dim3(64 * ZEGGS_LOSS_WAVES), LOSS_LDS_BYTES, s, d, parents, ioO, ioW, w.PT0, w.PT1, gaze, w.FO,
-                     w.FW, w.LM, 0L, gend);
+  hipLaunchKernelGGL(loss_frame_fwd_k, dim3(cdiv(gend, 64)), dim3(64 * ZEGGS_LOSS_WAVES), lds_ok ? LOSS_LDS_BYTES : 0, s, d, parents, ioO, ioW, w.PT0, w.PT1, gaze, w.FO,
+                     w.FW, w.LM, 0L, gend, lds_ok);
   ZLAUNCH_CHECK("loss_frame_fwd");
   if (d.T % 4 == 0 && ((uintptr_t)w.FO % 16 == 0) && ((uintptr_t)w.FW % 16 == 0) && ((uintptr_t)w.G % 16 == 0))      // (= vec4 below)
     hipLaunchKernelGGL(loss_terms4_k, dim3(o.n, LOSS_TSPLIT), dim3(256), 0, s, d, w.FO, w.FW, w.G, w.PS, gscale);
@@ -857,8 +863,8 @@ extern "C" int zeggs_loss_fwd_bwd_ex(const ZeggsLossDims* dp, const int* parents
                      gscale, vec4 ? w.PS : (const float*)nullptr, o.n, d.J);
   ZLAUNCH_CHECK("loss_kl_final");
   if (dpose) {
-    hipLaunchKernelGGL(loss_frame_bwd_k, dim3(cdiv(NF, 64)), dim3(64 * ZEGGS_LOSS_WAVES), LOSS_LDS_BYTES, s, d, parents, ioO, gaze, w.PT0, w.FO, w.LM, w.G,
-                       w.DPT, drpos, w.DQ);
+    hipLaunchKernelGGL(loss_frame_bwd_k, dim3(cdiv(NF, 64)), dim3(64 * ZEGGS_LOSS_WAVES), lds_ok ? LOSS_LDS_BYTES : 0, s, d, parents, ioO, gaze, w.PT0, w.FO, w.LM, w.G,
+                       w.DPT, drpos, w.DQ, lds_ok);
     ZLAUNCH_CHECK("loss_frame_bwd");
     // back to [frame][PO] (columns 0..5 hold nothing yet: the root-velocity kernel below writes them)
     hipLaunchKernelGGL(transpose_k, dim3((unsigned)cdiv(PO, 64), (unsigned)cdiv(NF, 64)), dim3(256), 0, s, dpose, w.DPT,

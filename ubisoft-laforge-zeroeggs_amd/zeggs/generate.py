@@ -186,32 +186,34 @@ def _decode_to_bvh_streaming(decoder, pose0, rpos0, rrot0, gaze_row, speech, sty
         drain(0)
         marks.append(_t0.perf_counter())                 # ... decoded, converted, downloaded, formatted and written
 
-    import time as _t
-    t_setup = _t.perf_counter()
-    with ThreadPoolExecutor(max_workers=workers) as pool:
-        with open(path, "wb") as fh:
-            fh.write(head.encode())
-            run(pool, fh)
-            t_run = _t.perf_counter()
-        t_close = _t.perf_counter()
-        if PROFILE is not None:
-            PROFILE["  streaming_writer_breakdown_ms"] = {
-                "setup": round((t_setup - t_enter) * 1e3, 2), "enqueue_all_chunks": round((marks[0] - t_setup) * 1e3, 2),
-                "last_chunks_decoded_formatted_written": round((marks[1] - marks[0]) * 1e3, 2), "file_close": round((t_close - t_run) * 1e3, 2)}
-        if ops._persistent_live(0) and int(status[0].item()):     # (every chunk has been downloaded by now: no extra wait)
-            ops._warn_gave_up(int(status[0].item()), "the whole rollout")
-            # redo on the stage launches -- for THIS call only: the process-wide switch is restored afterwards (a
-            # give-up here used to turn the persistent decode off for every later caller without a word)
-            was = ops._OPTIONS.get("persistent", 1)
-            ops.set_option("persistent", 0)
-            try:
-                ops.fill_(status.view(torch.float32))
-                with open(path, "wb") as fh:
-                    fh.write(head.encode())
-                    run(pool, fh)
-            finally:
-                ops.set_option("persistent", was)
-    _pinned_release(ring)
+    try:      # (the ring goes back to the pool whatever happens in between: ADVICE r5)
+        import time as _t
+        t_setup = _t.perf_counter()
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            with open(path, "wb") as fh:
+                fh.write(head.encode())
+                run(pool, fh)
+                t_run = _t.perf_counter()
+            t_close = _t.perf_counter()
+            if PROFILE is not None:
+                PROFILE["  streaming_writer_breakdown_ms"] = {
+                    "setup": round((t_setup - t_enter) * 1e3, 2), "enqueue_all_chunks": round((marks[0] - t_setup) * 1e3, 2),
+                    "last_chunks_decoded_formatted_written": round((marks[1] - marks[0]) * 1e3, 2), "file_close": round((t_close - t_run) * 1e3, 2)}
+            if ops._persistent_live(0) and int(status[0].item()):     # (every chunk has been downloaded by now: no extra wait)
+                ops._warn_gave_up(int(status[0].item()), "the whole rollout")
+                # redo on the stage launches -- for THIS call only: the process-wide switch is restored afterwards (a
+                # give-up here used to turn the persistent decode off for every later caller without a word)
+                was = ops._OPTIONS.get("persistent", 1)
+                ops.set_option("persistent", 0)
+                try:
+                    ops.fill_(status.view(torch.float32))
+                    with open(path, "wb") as fh:
+                        fh.write(head.encode())
+                        run(pool, fh)
+                finally:
+                    ops.set_option("persistent", was)
+    finally:
+        _pinned_release(ring)
 
 
 _PINNED = {}                      # (count, cols) -> list of free rings: a ring is CHECKED OUT for the duration of one call
@@ -233,8 +235,13 @@ def _pinned_ring(count, rows, cols):
 
 
 def _pinned_release(ring):
+    """Back to the pool -- which keeps ONE free ring per (count, cols), the largest: a smaller one can serve nobody the larger
+    cannot, and page-locked memory that only accumulates with varying clip / chunk sizes is memory the system cannot page."""
     with _PINNED_LOCK:
-        _PINNED.setdefault((len(ring), ring[0].shape[1]), []).append(ring)
+        free = _PINNED.setdefault((len(ring), ring[0].shape[1]), [])
+        free.append(ring)
+        free.sort(key=lambda r: -r[0].shape[0])
+        del free[1:]
 
 
 def generate_gesture(audio_file, styles, network_path, data_path, results_path, style_encoding_type="example",
