@@ -373,6 +373,10 @@ int zeggs_radam_step_wd(float* p, const float* g, float* m, float* v, long n, fl
                         float step_scale, int rectified, float decay, unsigned* status, const float* gflag, int count_skip,
                         void* stream);
 int zeggs_status_flag(const unsigned* status, float* dst /* device float */, void* stream);
+/* measurement / test hook (no reference counterpart): `workgroups` x `threads` resident for `ms` milliseconds of wall clock on
+ * `stream`, touching `scratch[0..n)` lightly (may be NULL) -- the stand-in for a collective's resident workgroups that
+ * tools/cotenant_probe.py puts beside the iteration's tail and tests/test_gpu_giveup.py across a sweep boundary */
+int zeggs_test_cotenant(int workgroups, int threads, float ms, float* scratch, long n, void* stream);
 
 /* ---------------------------------------------------------------- batch gather
  * replaces SGDataset.__getitem__/get_example + default collate, ZEGGS/dataset.py:110-204, reading

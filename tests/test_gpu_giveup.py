@@ -120,6 +120,60 @@ def test_persistent_sweeps_are_rearmed_after_a_giveup_and_back_off(restore_optio
     assert np.abs(w - w_ref).max() <= 3e-5, np.abs(w - w_ref).max()
 
 
+def _cotenant(workgroups, ms, stream, scratch):
+    import ctypes as C
+    ops._check(ops.lib().zeggs_test_cotenant(int(workgroups), 256, C.c_float(ms), C.c_void_p(scratch.data_ptr()),
+                                             C.c_long(scratch.numel()), C.c_void_p(stream.cuda_stream)), "test_cotenant")
+
+
+def test_giveup_under_a_resident_cotenant_is_replayed_and_rearmed(restore_options):
+    """the give-up path driven by a RESIDENT co-tenant, not by the persistent_spin = 0 hook.  64 stand-in
+    workgroups (zeggs_test_cotenant: what a collective's resident workgroups are to the chip) sit on 64 CUs for 60 ms across the
+    sweep boundary of iteration 3: the forward sweep needs all 256 CUs to itself, 64 of its workgroups cannot be placed, the
+    bounded waits of the 192 that can run out (persistent_spin lowered to ~4 ms of polls for the WHOLE run: nothing is forced) --
+    the step is skipped on the device, noticed STATUS_LAG iterations later, replayed on the stage kernels, and after the probation
+    the sweeps are back on (validated again) for the rest of the run.  Weights = those of an undisturbed run."""
+    steps, B, T, L, at = 12, 32, 64, 96, 3
+    spin = 4096
+    ref = _train(steps, -1, persistent=False)
+    w_ref = ref.flat_p.detach().cpu().numpy().copy()
+    for k in ("train_persistent", "bwd_persistent"):
+        ops.set_option(k, 1)
+    ops.set_option("persistent_spin", spin)
+    ops.manual_seed(99)
+    eng, ds = _engine(B, T, T + 200)
+    eng.rearm_after = eng._rearm_wait = 4
+    perm = np.random.default_rng(5).permutation(len(ds))
+    lag = engine.TrainEngine.STATUS_LAG
+    side = torch.cuda.Stream()
+    scratch = torch.zeros(1 << 16, device=DEV)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for k in range(steps):
+            if k == at:
+                torch.cuda.synchronize()
+                assert ops.lib().zeggs_persistent_state(1) == 1 and ops.lib().zeggs_persistent_state(2) == 1   # validated by now
+                _cotenant(64, 60.0, side, scratch)          # resident from here, across this iteration's sweeps
+            eng.step(engine.shard_indices(perm, k, B, 1, 0), L)
+            if k == at:
+                torch.cuda.synchronize()
+                st = eng.status.cpu().numpy()
+                assert st[0] & (2 | 4) and st[1] == 1, st          # a sweep gave up under the co-tenant: the step was skipped on the device
+            if k == at + lag:
+                assert ops._OPTIONS["train_persistent"] == 0 and eng._rearm_at == at + 4 and eng.rearm_count == 0
+            if k == at + 4:
+                assert ops._OPTIONS["train_persistent"] == 1 and ops._OPTIONS["bwd_persistent"] == 1 and eng.rearm_count == 1
+        eng.flush()
+    torch.cuda.synchronize()
+    assert ops.lib().zeggs_persistent_state(1) == 1 and ops.lib().zeggs_persistent_state(2) == 1       # back on and validated
+    assert sum("gave up" in str(w.message) for w in rec) == 1
+    assert eng.recovered_steps == lag and eng.iteration == steps == eng.opt._step and eng.rearm_count == 1
+    assert int(eng.status.cpu()[0]) == 0 and int(eng.status.cpu()[1]) == 0
+    w = eng.flat_p.detach().cpu().numpy()
+    assert np.isfinite(w).all()
+    assert np.abs(w - w_ref).max() <= 3e-5, np.abs(w - w_ref).max()
+
+
 def _rollout(de, T, seed=4242):
     W, speech, style = helpers.full_decoder_inputs(helpers.real_stats("v1"), 1, T, seed)
     s = helpers.real_stats_tensors("v1", device=DEV)

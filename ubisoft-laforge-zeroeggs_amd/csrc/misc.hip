@@ -154,6 +154,20 @@ __global__ void sum_time_k(float* dz, const float* dout, int B, int T, int S) {
   }
 }
 
+// Measurement / test hook: a stand-in CO-TENANT -- what a collective's workgroups are to the other kernels on the chip: resident for
+// a stretch of wall-clock time on their CUs (so a kernel that needs whole CUs cannot be placed there, and a stream-K product whose
+// equal-share workgroups cannot ALL be resident waits for its stragglers), with light memory traffic.  Bounded by the 100 MHz wall
+// clock, whatever happens around it.  tools/cotenant_probe.py, tests/test_gpu_giveup.py.
+__global__ void cotenant_k(float* buf, long n, unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) % (n > 0 ? n : 1);
+  float v = 0.f;
+  while (wall_clock64() - t0 < ticks) {
+    if (n > 0) { v += buf[i]; buf[i] = v * 0.5f; i = (i + 4099) % n; }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 inline int g1(long n) { long g = (n + 255) / 256; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 
 }  // namespace
@@ -189,6 +203,14 @@ extern "C" int zeggs_radam_step_guarded(float* p, const float* g, float* m, floa
                                         float eps, float step_scale, int rectified, unsigned* status, const float* gflag,
                                         void* stream) {
   return zeggs_radam_step_guarded_part(p, g, m, v, n, beta1, beta2, eps, step_scale, rectified, status, gflag, 1, stream);
+}
+extern "C" int zeggs_test_cotenant(int workgroups, int threads, float ms, float* scratch, long n, void* stream) {
+  ZCHECK(workgroups >= 1 && workgroups <= 4096 && threads >= 64 && threads <= 1024 && ms > 0.f && ms <= 500.f,
+         "test_cotenant: bad shape (%d x %d for %g ms)", workgroups, threads, ms);
+  hipLaunchKernelGGL(cotenant_k, dim3(workgroups), dim3(threads), 0, (hipStream_t)stream, scratch, scratch ? n : 0,
+                     (unsigned long long)(ms * 1e5f));
+  ZLAUNCH_CHECK("test_cotenant");
+  return 0;
 }
 extern "C" int zeggs_status_flag(const unsigned* status, float* dst, void* stream) {
   hipLaunchKernelGGL(status_flag_k, dim3(1), dim3(64), 0, (hipStream_t)stream, status, dst);
