@@ -49,8 +49,9 @@ def fake_all_reduce(tensor, op=None, group=None, async_op=False):
     STATE["windows_ms"].append(ms)
     comm.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(comm):
-        ops._check(ops.lib().zeggs_test_cotenant(STATE["W"], 256, C.c_float(ms), C.c_void_p(scratch.data_ptr()),
-                                                 C.c_long(scratch.numel()), C.c_void_p(comm.cuda_stream)), "test_cotenant")
+        if STATE["W"] > 0:      # (W = 0: the exchange's stream dependencies without anything resident -- what the ORDER alone costs)
+            ops._check(ops.lib().zeggs_test_cotenant(STATE["W"], 256, C.c_float(ms), C.c_void_p(scratch.data_ptr()),
+                                                     C.c_long(scratch.numel()), C.c_void_p(comm.cuda_stream)), "test_cotenant")
         ev = torch.cuda.Event()
         ev.record(comm)
     w = FakeWork(ev)
@@ -79,9 +80,15 @@ def run(reserve, W, fake=True):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for it in range(STEPS):
-                eng.step(idx(6 + r * STEPS + it), bench.EXAMPLE_LEN)
+                k = 6 + r * STEPS + it
+                h0 = time.perf_counter()
+                eng.step(idx(k), bench.EXAMPLE_LEN)
+                STATE["host_ms"] = STATE.get("host_ms", 0.0) + (time.perf_counter() - h0) * 1e3 / (3 * STEPS)
+                if it + 1 < STEPS:
+                    eng.prefetch(idx(k + 1), bench.EXAMPLE_LEN)      # (the next batch's gather on the third stream, as bench.py's loop)
             torch.cuda.synchronize()
             per.append((time.perf_counter() - t0) / STEPS * 1e3)
+        print(f"   (host time inside eng.step: {STATE.pop('host_ms', 0.0):.2f} ms per iteration)", flush=True)
         nwin = len(STATE["windows_ms"]) // max(1, 6 + 3 * STEPS)
         win = STATE["windows_ms"][-nwin:] if nwin else []
         del eng
