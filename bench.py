@@ -607,7 +607,49 @@ def nhidden_512_b32(ds, dev, steps=5, warmup=2):
     return out
 
 
-EXTRA_ENGINES = {"v2_label_b64": v2_label_b64, "variants_film_gru_b32": variants_b32, "nhidden_512_b32": nhidden_512_b32}
+def tail_split_bf16(ds, dev, steps=10, warmup=4, nplanes=6):
+    """EXPERIMENT, reported BESIDE the headline, never as it: the headline configuration (configs[1], B = 32 x 256)
+    with the fp32 TN products of the tail on the bf16 matrix cores through the fp32-exact three-plane operand split (csrc/gemm_split.hip,
+    option "gemm_split_bf16" = 6 plane products; default off; acceptance record profiles/r06_gemm_split_bf16.txt: error against float64
+    <= the native fp32 MFMA kernel's on all five weight-gradient shapes).  roofline: the decoder's two largest weight-gradient
+    products alone on the chip, priced against 2 500 / n TFLOP/s fp32-EQUIVALENT (n bf16 matrix instructions per fp32 product)."""
+    se, de, st = build_nets(dev)
+    ops.set_option("gemm_split_bf16", nplanes)
+    try:
+        eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT)
+        perm = np.random.default_rng(42).permutation(len(ds))
+        idx = lambda it: engine.shard_indices(perm, it % (len(ds) // BATCH), BATCH, 1, 0)  # noqa: E731
+        loss = None
+        for it in range(warmup):
+            loss = eng.step(idx(it), EXAMPLE_LEN)
+        dt_, regions_ms, loss = time_regions(lambda it: eng.step(idx(it), EXAMPLE_LEN), warmup, steps)
+        del eng
+        peak = 2500.0 / nplanes
+        kern = {}
+        for name, (M, N, K) in {"dW_hh 3072x1024 K=8160": (3072, 1024, 8160), "dW_ih0 3072x2286 K=8160": (3072, 2288, 8160)}.items():
+            A, B = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev)
+            Cm = torch.zeros(M, N, device=dev)
+            f = lambda: ops.gemm(A, B, Cm, M, N, K, (1, M), (N, 1), (N, 1))  # noqa: E731
+            f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                f()
+            e1.record()
+            e1.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 8
+            kern[name] = {"us": round(us, 1), "achieved": round(2.0 * M * N * K / us / 1e6, 1), "frac": round(2.0 * M * N * K / us / 1e6 / peak, 3)}
+    finally:
+        ops.set_option("gemm_split_bf16", 0)
+    return {"value": round(BATCH * WINDOW / dt_, 1), "unit": "frames/s", "ms_per_step": round(dt_ * 1e3, 3), "ms_per_step_regions": regions_ms,
+            "final_loss": round(float(loss.detach()), 4), "option": f"gemm_split_bf16={nplanes}", "default": "off (the headline is the native fp32 run)",
+            "roofline": {"bound": "mfma", "peak": round(peak, 1), "unit": "TFLOP/s fp32-equivalent (2 M N K / time; 2 500 dense bf16 / n plane products)",
+                         "kernel": f"gemm_tn_split_kernel<{nplanes}>: v_mfma_f32_32x32x16_bf16 on three truncated bf16 planes per fp32 operand, alone on the chip",
+                         "kernels": kern, "acceptance": profile_stamp("profiles/r06_gemm_split_bf16.txt")}}
+
+
+EXTRA_ENGINES = {"v2_label_b64": v2_label_b64, "variants_film_gru_b32": variants_b32, "nhidden_512_b32": nhidden_512_b32,
+                 "tail_split_bf16": tail_split_bf16}
 
 
 def extra_in_fresh_process(key, timeout=240):

@@ -179,6 +179,16 @@ def test_train_iteration_b32_t256_ex384_vs_reference(golden_dir):
     _check_engine_iteration(np.load(golden_dir / "full_train32.npz"), "v1")
 
 
+def test_train_iteration_b32_t256_ex384_vs_reference_with_the_bf16_split_products(golden_dir):
+    """the same iteration, unchanged bounds, with the tail's fp32 TN products on the bf16 matrix cores through the fp32-exact
+    three-plane split (experiment, option "gemm_split_bf16" = 6, default off; csrc/gemm_split.hip)"""
+    ops.set_option("gemm_split_bf16", 6)
+    try:
+        _check_engine_iteration(np.load(golden_dir / "full_train32.npz"), "v1")
+    finally:
+        ops.set_option("gemm_split_bf16", 0)
+
+
 def test_train_iteration_v2_label_b64_vs_reference(golden_dir):
     """configs_v2 (label conditioning, no style encoder), B=64: the MFMA-bound NB=4 stage kernels."""
     _check_engine_iteration(np.load(golden_dir / "full_trainv2.npz"), "v2")

@@ -468,6 +468,38 @@ def test_direct_gemm_variant_selftest(big, depth, shield):
     assert ops.lib().zeggs_gemm_direct_selftest(big, depth, shield) == 1
 
 
+@pytest.mark.parametrize("nplanes", [6, 9])
+def test_bf16_split_tn_product_is_at_least_as_exact_as_the_fp32_matrix_cores(nplanes):
+    """EXPERIMENT (option "gemm_split_bf16", default off; csrc/gemm_split.hip): the fp32 TN products of the training tail on the bf16
+    matrix cores with an fp32-exact three-plane operand split.  Acceptance rule: on all five weight-gradient
+    shapes the split's max AND RMS error against a float64 product is <= the native fp32 MFMA kernel's (the shielded direct kernel).
+    (conv0 FORWARD is an NN product: this kernel is TN only -- it keeps the native path.)"""
+    shapes = [("dW_hh", 3072, 1024, 8160, 3072, 1024), ("dW_ih0", 3072, 2286, 8160, 3072, 2288), ("dW_l2", 1131, 1024, 8160, 1132, 1024),
+              ("dW_l0", 1024, 1262, 8160, 1024, 2288), ("conv0 dW", 3402, 512, 12288, 3404, 512)]
+    keep = {k: ops._OPTIONS.get(k) for k in ("gemm_direct", "gemm_direct_shield", "gemm_direct_depth")}
+    try:
+        ops.set_option("gemm_direct", 1)
+        ops.set_option("gemm_direct_shield", 1)
+        ops.set_option("gemm_direct_depth", 8)
+        for name, M, N, K, lda, ldb in shapes:
+            torch.manual_seed(1)
+            A, B = torch.randn(K, lda, device=DEV), torch.randn(K, ldb, device=DEV)
+            ref = A[:, :M].double().t() @ B[:, :N].double()
+            err = {}
+            for npl in (0, nplanes):
+                ops.set_option("gemm_split_bf16", npl)
+                C = torch.zeros(M, N, device=DEV)
+                ops.gemm(A, B, C, M, N, K, (1, lda), (ldb, 1), (N, 1))
+                d = C.double() - ref
+                err[npl] = (float(d.abs().max()), float(d.pow(2).mean().sqrt()))
+            assert err[nplanes][0] <= err[0][0] and err[nplanes][1] <= err[0][1], (name, err)
+    finally:
+        ops.set_option("gemm_split_bf16", 0)
+        for k, v in keep.items():
+            if v is not None:
+                ops.set_option(k, v)
+
+
 def test_radam_weight_decay_vs_reference(golden_dir):
     """RAdam(weight_decay=0.05) of the reference (optimizers.py:88-95; radam_wd.npz) through the drop-in optimizer class: per-tensor
     launches and the flat-buffer form."""

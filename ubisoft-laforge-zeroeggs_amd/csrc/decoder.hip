@@ -32,6 +32,7 @@ extern int g_gemm_skinny;
 extern int g_tp_tiles4;
 extern int g_tp_dual;
 extern int g_loss_lds;
+extern int g_gemm_split_bf16;
 void zeggs_gemm_set_dma(int on);
 void zeggs_gemm_set_direct(int mode, int wgs);
 void zeggs_gemm_set_direct_depth(int d);
@@ -88,6 +89,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "tp_tiles4") == 0) { g_tp_tiles4 = value != 0; return 0; }
   if (strcmp(name, "tp_dual") == 0) { g_tp_dual = value != 0; return 0; }
   if (strcmp(name, "loss_lds") == 0) { g_loss_lds = value != 0; return 0; }
+  if (strcmp(name, "gemm_split_bf16") == 0) { g_gemm_split_bf16 = (value == 3 || value == 6 || value == 9) ? value : 0; return 0; }
   if (strcmp(name, "poll_stagger") == 0) { g_poll_stagger = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "poll_sleep") == 0) { g_poll_sleep = value < 0 ? 0 : value; return 0; }
   if (strcmp(name, "persistent_spin") == 0) { g_persistent_spin = value < 0 ? 0 : value; return 0; }

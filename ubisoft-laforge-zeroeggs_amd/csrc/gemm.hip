@@ -19,6 +19,10 @@
 #include "gemm.h"
 #include "kernels.h"
 
+extern int g_gemm_split_bf16;                          // gemm_split.hip: the fp32-exact bf16 split (experiment, option "gemm_split_bf16", default off)
+bool gemm_split_ok(const GemmArgs& g);
+int launch_tn_split(GemmArgs g, hipStream_t s);
+
 int g_gemm_streamk_wgs = 0;     // zeggs_set_option("gemm_streamk_wgs", n): stream-K workgroups per CU (0: as many as are resident)
 int g_gemm_wg_target = 6144;   // split-K aims at this many workgroups (24 per CU = 6 rounds of 4 resident ones; sweep 1536..12288 in
                                // tools/gemm_bench.py: 3072 -> 6144 is 10-14 % on the weight-gradient shapes, flat beyond)
@@ -889,6 +893,7 @@ static bool direct_checked(const GemmArgs& g, hipStream_t s) {
   return false;
 }
 int launch_streamk(GemmArgs g, hipStream_t s) {
+  if (gemm_split_ok(g)) return launch_tn_split(g, s);
   if (direct_ok(g) && direct_checked(g, s)) return launch_tn_direct(g, s);
   if (dma_ok(g)) return launch_tn_dma(g, s);
   // 256 x 128 tiles (8 waves, 2 workgroups per CU: 3/4 of the operand bytes per product) pay on the big outputs only: +5 .. +8 %
@@ -1193,7 +1198,8 @@ int gemm_tn_bias(const float* dy, long lddy, const float* x, long ldx, float* dW
                  int K, float beta, float* db, hipStream_t s) {
   GemmArgs g = gemm_args(dy, x, dW, N, K, M_contract);
   g.sam = 1; g.sak = lddy; g.sbk = ldx; g.sbn = 1; g.scm = lddw; g.scn = 1; g.beta = beta;
-  g.asum = (beta == 1.f && g_gemm_asum) ? db : nullptr;       // (beta == 0 would need db zeroed first: the separate launch does that)
+  // (beta == 0 would need db zeroed first: the separate launch does that; the bf16-split experiment has no row sums either)
+  g.asum = (beta == 1.f && g_gemm_asum && !g_gemm_split_bf16) ? db : nullptr;
   tl_asum_consumed = false;
   ZTRY(launch_gemm(g, 1, s));
   if (!tl_asum_consumed) ZTRY(k_colsum(db, dy, M_contract, N, lddy, beta, s));
