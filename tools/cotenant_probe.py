@@ -29,7 +29,7 @@ dev = torch.device("cuda:0")
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 BUS_GBS = float(os.environ.get("BUS_GBS", 300.0))          # assumed bus bandwidth of an 8-rank ring all-reduce over xGMI (RCCL, large messages)
 GRID = [(int(w), int(r)) for w, r in (x.split(":") for x in os.environ.get("GRID", "32:0,32:16,32:32,32:48,48:0,48:16,48:32,48:48").split(","))]
-comm = torch.cuda.Stream()
+COMM = torch.cuda.Stream(priority=-1) if int(os.environ.get("COMM_HIGH", "0")) else torch.cuda.Stream()
 scratch = torch.zeros(1 << 18, device=dev)
 STATE = {"W": 32, "windows_ms": []}
 
@@ -47,6 +47,7 @@ def fake_all_reduce(tensor, op=None, group=None, async_op=False):
     2 (n - 1) / n x bytes / bus rate (n = 8) + 20 us"""
     ms = 1.75 * tensor.numel() * 4 / (BUS_GBS * 1e9) * 1e3 + 0.02
     STATE["windows_ms"].append(ms)
+    comm = STATE.get("comm") or COMM      # COMM_REUSE=1: the engine's third stream instead of a stream of its own (stream-count A/B)
     comm.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(comm):
         if STATE["W"] > 0:      # (W = 0: the exchange's stream dependencies without anything resident -- what the ORDER alone costs)
@@ -69,8 +70,11 @@ def run(reserve, W, fake=True):
     if fake:
         torch.distributed.all_reduce = fake_all_reduce
     try:
-        eng = engine.TrainEngine(se, de, st, ds, bench.synth.PARENTS, bench.synth.DT, force_allreduce=fake, overlap_allreduce=True)
+        eng = engine.TrainEngine(se, de, st, ds, bench.synth.PARENTS, bench.synth.DT, force_allreduce=fake,
+                                 overlap_allreduce=bool(int(os.environ.get("OVERLAP", "1"))),
+                                 early_decoder_step=bool(int(os.environ.get("EARLY", "1"))))
         eng.ctx.gemm_route = (1, 1, 8, int(reserve))
+        STATE["comm"] = eng.aux_stream if int(os.environ.get("COMM_REUSE", "0")) else None
         perm = np.random.default_rng(0).permutation(len(ds))
         idx = lambda it: engine.shard_indices(perm, it % (len(ds) // bench.BATCH), bench.BATCH, 1, 0)  # noqa: E731
         for it in range(6):
@@ -99,7 +103,9 @@ def run(reserve, W, fake=True):
 
 lines = [f"# tools/cotenant_probe.py {STEPS}: ms per iteration (three regions of {STEPS} steps), B = 32 x 256, one MI355X; stand-in collective of W x 256 "
          f"threads resident per exchanged slice for 1.75 x bytes / {BUS_GBS:g} GB/s + 20 us on its own stream"]
-per, _ = run(0, 32, fake=False)
+per = [0.0]
+if not int(os.environ.get("SKIP_BASE", "1" if len(GRID) == 1 else "0")):
+    per, _ = run(0, 32, fake=False)
 lines.append(f"no exchange (single-rank schedule), reserve 0                       {np.mean(per):7.3f}   regions {[round(x, 3) for x in per]}")
 print(lines[-1], flush=True)
 for W, reserve in GRID:
