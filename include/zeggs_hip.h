@@ -396,6 +396,8 @@ int zeggs_gather_rows(const float* frames, int width, const int64_t* rows, long 
 typedef struct {
   int n_fft, hop, n_mels, fs;
   float fps, min_clip;
+  double pre_emph;      /* audio_conf.pre_emphasis ? audio_conf.pre_emph_coeff : 0 (spectrograms.py:35; round 6: the struct grew by this
+                           field -- zeggs_version() >= 101) */
 } ZeggsMelDims;
 long zeggs_mel_stft_frames(const ZeggsMelDims*, long n_samples); /* integer rule of spectrograms.py:242-245 */
 size_t zeggs_mel_workspace_bytes(const ZeggsMelDims*, long n_samples);

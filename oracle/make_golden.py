@@ -257,6 +257,18 @@ def gold_mel(ref):
         out2[f"{tag}_feat"] = ref.data_pipeline.preprocess_audio(wav, 60, nfr, ac, feature_type=conf["audio_feature_type"])
     np.savez_compressed(GOLD / "mel_nonorm.npz", **out2)
     print("mel_nonorm.npz")
+    # audio_conf.pre_emphasis = true (spectrograms.py:35) and audio_conf.real_amplitude = false (:266-267, :81-88), one at a time and together
+    out3 = {}
+    for name, pe, ra in (("pre", True, True), ("raw", False, False), ("preraw", True, False)):
+        conf["audio_conf"].update(normalize_mel_bins=True, pre_emphasis=pe, real_amplitude=ra)
+        ac = ref.DictConfig(conf["audio_conf"])
+        for tag in "ab":
+            wav, nfr = out[f"{tag}_wav"], int(out[f"{tag}_nframes"])
+            out3[f"{tag}_wav"], out3[f"{tag}_nframes"] = wav, np.int64(nfr)
+            out3[f"{tag}_feat_{name}"] = ref.data_pipeline.preprocess_audio(wav, 60, nfr, ac, feature_type=conf["audio_feature_type"])
+    out3["pre_emph_coeff"] = np.float64(conf["audio_conf"]["pre_emph_coeff"])
+    np.savez_compressed(GOLD / "mel_options.npz", **out3)
+    print("mel_options.npz")
 
 
 def gold_dataset(ref):

@@ -71,20 +71,22 @@ def mel_filterbank(n_fft=800, fs=16000, n_mels=80, fmin=20.0, fmax=7600.0, norma
 
 
 def mel_spectrogram(wav, n_fft=800, hop=200, fs=16000, n_mels=80, fmin=20.0, fmax=7600.0,
-                    min_clip=1e-5, normalize_mel_bins=True):
+                    min_clip=1e-5, normalize_mel_bins=True, pre_emph=0.0, real_amplitude=True):
     """extract_mel_spectrogram_for_tts (spectrograms.py:8-54) with the shipped
     conf (centered, real_amplitude, normalize_mel_bins, normalize_range, no
     pre-emphasis): returns [n_mels, M] in [0, ~1]."""
     x = np.asarray(wav, dtype=np.float64)
+    if pre_emph:                                                   # signal_manipulation.py:4-12: lfilter([1, -c], [1], x)
+        x = np.concatenate([x[:1], x[1:] - pre_emph * x[:-1]])
     if len(x) < n_fft:
         x = np.pad(x, (0, n_fft - len(x)))
     x = np.pad(x, (n_fft // 2, n_fft // 2), mode="reflect")
     M = stft_frame_count(len(wav), n_fft, hop)
     idx = np.arange(M)[:, None] * hop + np.arange(n_fft)[None, :]
     frames = x[idx] * hann_symmetric(n_fft)[None, :]
-    amp = np.abs(np.fft.rfft(frames, axis=1)).T / n_fft            # [401, M]
+    amp = np.abs(np.fft.rfft(frames, axis=1)).T / (n_fft if real_amplitude else 1)            # [401, M]
     mel = mel_filterbank(n_fft, fs, n_mels, fmin, fmax, normalize_mel_bins) @ amp      # [80, M]
-    amin = min_clip / n_fft
+    amin = min_clip / (n_fft if real_amplitude else 1)              # spectrograms.py:81-88
     mel = np.clip(np.abs(mel), amin, None)
     db = 20.0 * np.log10(mel)
     rng = -20.0 * np.log10(amin)

@@ -109,7 +109,7 @@ def test_streaming_frame_accounting_is_consistent_host_only():
     from zeggs import audio, ops
     L = ops.lib()
     L.zeggs_mel_frames_ready.restype = C.c_long
-    d = audio.MelDims(800, 200, 80, 16000, 60.0, 1e-5)
+    d = audio.MelDims(800, 200, 80, 16000, 60.0, 1e-5, 0.0)
     prev = 0
     for n in list(range(0, 3000, 37)) + [16000, 16001, 48000, 480000]:
         k = int(L.zeggs_mel_frames_ready(C.byref(d), C.c_long(n)))

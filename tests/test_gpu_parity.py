@@ -718,6 +718,31 @@ def test_mel_unnormalised_bins_vs_reference(golden_dir):
     json.dumps(conf)
 
 
+@pytest.mark.parametrize("mel_fft", [1, 0])
+def test_mel_pre_emphasis_and_raw_amplitude_vs_reference(golden_dir, mel_fft):
+    """audio_conf.pre_emphasis = true (the high-pass inside the kernels' sample fetch, float64) and audio_conf.real_amplitude = false
+    (filterbank and clip floor x n_fft on the host), one at a time and together, through the drop-in preprocess_audio against the
+    reference's (mel_options.npz); mel_fft = 0: the direct-DFT kernel (the matrix-core DFT stages float32 samples and steps aside
+    when the pre-emphasis is on)."""
+    from zeggs import audio
+    gd = np.load(golden_dir / "mel_options.npz")
+    base = dict(sampling_rate=16000, filter_length=800, hop_length=200, n_mel_channels=80, mel_fmin=20, mel_fmax=7600,
+                min_clipping=1e-5, pre_emph_coeff=float(gd["pre_emph_coeff"]), centered=True, normalize_mel_bins=True,
+                normalize_range=True, normalize_loudness=False, resample_method="linear")
+    ops.set_option("mel_fft", mel_fft)
+    try:
+        for name, pe, ra in (("pre", True, True), ("raw", False, False), ("preraw", True, False)):
+            conf = dict(base, pre_emphasis=pe, real_amplitude=ra)
+            for tag in "ab":
+                wav, nfr = gd[f"{tag}_wav"], int(gd[f"{tag}_nframes"])
+                feat = audio.preprocess_audio(wav, 60, nfr, conf, ["mel_spec", "energy"])
+                ref = gd[f"{tag}_feat_{name}"]
+                np.testing.assert_array_equal(np.isnan(feat), np.isnan(ref))
+                np.testing.assert_allclose(feat, ref, atol=3e-6, equal_nan=True, err_msg=f"{name} {tag}")
+    finally:
+        ops.set_option("mel_fft", 1)
+
+
 def test_mel_fft_form_equals_the_dft_forms(golden_dir):
     """Round 4: the STFT as a real FFT (half-length complex mixed-radix Stockham transform in LDS + split, what the reference's
     np.fft.rfft computes) is the default; the fp64 matrix-core DFT (round 3) and the direct DFT stay behind options.  All three
@@ -1816,7 +1841,7 @@ def test_c_abi_rejects_bad_arguments_loudly():
     # unknown option, bad mel dims, streaming range ahead of the received samples
     assert L.zeggs_set_option(b"no_such_option", 1) == -1 and b"unknown option" in L.zeggs_last_error()
     from zeggs import audio
-    d = audio.MelDims(800, 200, 80, 16000, 60.0, 1e-5)
+    d = audio.MelDims(800, 200, 80, 16000, 60.0, 1e-5, 0.0)
     rc = L.zeggs_mel_features_range(C.byref(d), p(dev_buf), C.c_long(3000), 0, p(dev_buf), C.c_long(0), C.c_long(50),
                                     p(dev_buf), p(dev_buf), C.c_size_t(1 << 18), stream)
     assert rc == -1 and b"not received yet" in L.zeggs_last_error()

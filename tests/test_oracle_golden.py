@@ -146,6 +146,13 @@ def test_oracle_mel_vs_reference(golden_dir):
         feat = omel.preprocess_audio(wav, int(g[f"{tag}_nframes"]))
         np.testing.assert_array_equal(np.isnan(feat), np.isnan(g[f"{tag}_feat"]))
         np.testing.assert_allclose(feat, g[f"{tag}_feat"], atol=1e-6, equal_nan=True)
+    g = np.load(golden_dir / "mel_options.npz")         # audio_conf.pre_emphasis = true / real_amplitude = false
+    for name, pe, ra in (("pre", float(g["pre_emph_coeff"]), True), ("raw", 0.0, False), ("preraw", float(g["pre_emph_coeff"]), False)):
+        for tag in "ab":
+            feat = omel.preprocess_audio(g[f"{tag}_wav"], int(g[f"{tag}_nframes"]), pre_emph=pe, real_amplitude=ra)
+            ref = g[f"{tag}_feat_{name}"]
+            np.testing.assert_array_equal(np.isnan(feat), np.isnan(ref))
+            np.testing.assert_allclose(feat, ref, atol=1e-6, equal_nan=True, err_msg=f"{name} {tag}")
     g = np.load(golden_dir / "mel_nonorm.npz")          # audio_conf.normalize_mel_bins = false
     for tag in "ab":
         feat = omel.preprocess_audio(g[f"{tag}_wav"], int(g[f"{tag}_nframes"]), normalize_mel_bins=False)

@@ -74,6 +74,15 @@ __device__ __forceinline__ double mel_exp_sq(double y, int exact) {      // exp(
   return z * z;
 }
 
+// sample `src` of the signal the STFT sees: the wav, zero beyond its end, high-pass filtered first when audio_conf.pre_emphasis is on
+// (spectrograms.py:35 -> signal_manipulation.preemphasis = lfilter([1, -c], [1], x): y[n] = x[n] - c x[n-1], y[0] = x[0], in float64)
+__device__ __forceinline__ double mel_sample(const float* wav, long src, long n, long n_avail, double pe) {
+  if (!(src >= 0 && src < n && src < n_avail)) return 0.0;
+  double x = (double)wav[src];
+  if (pe != 0.0 && src > 0) x -= pe * (double)wav[src - 1];
+  return x;
+}
+
 __global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* wav, long n, long n_avail, const double* fb,
                                                    double* logmel, double* energy, long m0, int exact) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* w
   for (int j = threadIdx.x; j < NF; j += blockDim.x) {
     const long p = fr * d.hop + j - NF / 2;          // index into the (zero-extended) signal before reflect padding
     long src = p < 0 ? -p : (p >= neff ? 2 * (neff - 1) - p : p);
-    const double x = (src >= 0 && src < n && src < n_avail) ? (double)wav[src] : 0.0;
+    const double x = mel_sample(wav, src, n, n_avail, d.pre_emph);
     const double win = 0.5 - 0.5 * cos(2.0 * M_PI * (double)j / (double)(NF - 1));   // scipy hann(sym=True)
     xw[j] = x * win;
     const double ang = 2.0 * M_PI * (double)j / (double)NF;
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(FTHR) void mel_stft_fft_k(ZeggsMelDims d, FftPlan p
       const int j = 2 * m + h;
       const long p = (fr0 + f) * hop + j - NF / 2;
       const long src = p < 0 ? -p : (p >= neff ? 2 * (neff - 1) - p : p);
-      const double x = (src >= 0 && src < n && src < n_avail) ? (double)wav[src] : 0.0;
+      const double x = mel_sample(wav, src, n, n_avail, d.pre_emph);
       v[h] = x * WIN[j].x;
     }
     bufA[i] = c2{v[0], v[1]};
@@ -520,7 +529,7 @@ static int launch_stft(const ZeggsMelDims& d, const MelWs& w, const float* wav, 
     return 0;
   }
   const size_t fast_lds = mel_fast_lds(d.n_fft, d.hop, d.n_mels);
-  if (g_mel_mfma && d.n_fft % 4 == 0 && 2 * NBIN <= MCOLP && fast_lds <= 160 * 1024 && nfr >= 1) {
+  if (g_mel_mfma && d.pre_emph == 0.0 && d.n_fft % 4 == 0 && 2 * NBIN <= MCOLP && fast_lds <= 160 * 1024 && nfr >= 1) {   // (stages float32 samples)
     static bool attr_set = false;
     if (!attr_set) {       // more than 64 KB of dynamic LDS needs the opt-in
       (void)hipFuncSetAttribute((const void*)mel_stft_mfma_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

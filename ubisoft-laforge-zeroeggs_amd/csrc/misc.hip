@@ -14,7 +14,7 @@ void zeggs_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* zeggs_last_error() { return g_err; }
-extern "C" int zeggs_version() { return 100; }
+extern "C" int zeggs_version() { return 101; }
 
 namespace {
 

@@ -15,7 +15,7 @@ from . import ops
 
 class MelDims(C.Structure):
     _fields_ = [("n_fft", C.c_int), ("hop", C.c_int), ("n_mels", C.c_int), ("fs", C.c_int), ("fps", C.c_float),
-                ("min_clip", C.c_float)]
+                ("min_clip", C.c_float), ("pre_emph", C.c_double)]
 
 
 def n_anim_frames(n_samples, fs=16000, fps=60.0):
@@ -53,17 +53,26 @@ def mel_filterbank(n_fft, fs, n_mels, fmin, fmax, normalize=True):
 _FB_CACHE = {}
 
 
+def mel_tables(n_fft, fs, n_mels, fmin, fmax, min_clip, normalize_mel_bins=True, real_amplitude=True, device="cuda"):
+    """-> (filterbank on `device`, the min_clip the kernel is given).  The kernel divides amplitudes and the clip floor by n_fft
+    (audio_conf.real_amplitude, spectrograms.py:266-267, 81-88); real_amplitude = false is the same arithmetic with the filterbank
+    and the floor multiplied by n_fft on the host (exact for the float64 table)."""
+    dev = torch.device(device)
+    key = (n_fft, fs, n_mels, fmin, fmax, normalize_mel_bins, bool(real_amplitude), str(dev))
+    if key not in _FB_CACHE:
+        fb = mel_filterbank(n_fft, fs, n_mels, fmin, fmax, normalize_mel_bins)
+        _FB_CACHE[key] = torch.as_tensor(fb if real_amplitude else fb * float(n_fft)).to(dev)
+    return _FB_CACHE[key], (float(min_clip) if real_amplitude else float(min_clip) * float(n_fft))
+
+
 def mel_features(wav, n_frames, n_fft=800, hop=200, n_mels=80, fs=16000, fps=60.0, fmin=20.0, fmax=7600.0,
-                 min_clip=1e-5, normalize_mel_bins=True, device="cuda"):
+                 min_clip=1e-5, normalize_mel_bins=True, device="cuda", pre_emph=0.0, real_amplitude=True):
     """wav: float array/tensor [n] -> torch float32 [n_frames, n_mels + 1] on `device` (HIP kernel)."""
     dev = torch.device(device)
-    key = (n_fft, fs, n_mels, fmin, fmax, normalize_mel_bins, str(dev))
-    if key not in _FB_CACHE:
-        _FB_CACHE[key] = torch.as_tensor(mel_filterbank(n_fft, fs, n_mels, fmin, fmax, normalize_mel_bins)).to(dev)
-    fb = _FB_CACHE[key]
+    fb, min_clip = mel_tables(n_fft, fs, n_mels, fmin, fmax, min_clip, normalize_mel_bins, real_amplitude, dev)
     w = torch.as_tensor(np.asarray(wav, dtype=np.float32) if not torch.is_tensor(wav) else wav,
                         dtype=torch.float32).to(dev).contiguous()
-    d = MelDims(n_fft, hop, n_mels, fs, float(fps), float(min_clip))
+    d = MelDims(n_fft, hop, n_mels, fs, float(fps), float(min_clip), float(pre_emph))
     L = ops.lib()
     L.zeggs_mel_workspace_bytes.restype = C.c_size_t
     ws = torch.empty(int(L.zeggs_mel_workspace_bytes(C.byref(d), C.c_long(w.numel()))), dtype=torch.uint8, device=dev)
@@ -77,7 +86,7 @@ def mel_features(wav, n_frames, n_fft=800, hop=200, n_mels=80, fs=16000, fps=60.
 
 
 def stft_frame_count(n_samples, n_fft=800, hop=200):
-    d = MelDims(n_fft, hop, 80, 16000, 60.0, 1e-5)
+    d = MelDims(n_fft, hop, 80, 16000, 60.0, 1e-5, 0.0)
     L = ops.lib()
     L.zeggs_mel_stft_frames.restype = C.c_long
     return int(L.zeggs_mel_stft_frames(C.byref(d), C.c_long(n_samples)))
@@ -234,15 +243,16 @@ def preprocess_audio_device(audio_data, anim_fs, anim_length, params, feature_ty
             audio_data, _ = normalize_loudness_device(audio_data, g("sampling_rate"), -20.0, device)   # no host pass
         else:
             audio_data = normalize_loudness(audio_data, g("sampling_rate"), -20.0)
-    if g("pre_emphasis") or not (g("centered") and g("real_amplitude") and g("normalize_range")):
-        raise NotImplementedError("only the shipped audio_conf (centered, real_amplitude, normalize_range, "
-                                  "no pre-emphasis) has a HIP path")
+    if not (g("centered") and g("normalize_range")):
+        raise NotImplementedError("audio_conf.centered = false / normalize_range = false have no HIP path (every other audio_conf "
+                                  "value has: pre_emphasis, real_amplitude, normalize_mel_bins either way)")
     if g("resample_method") != "linear":
         raise NotImplementedError("resample_method must be 'linear' (the shipped conf)")
     feat = mel_features(audio_data, anim_length, n_fft=g("filter_length"), hop=g("hop_length"),
                         n_mels=g("n_mel_channels"), fs=g("sampling_rate"), fps=float(anim_fs), fmin=g("mel_fmin"),
                         fmax=g("mel_fmax"), min_clip=g("min_clipping"), normalize_mel_bins=g("normalize_mel_bins"),
-                        device=device)
+                        device=device, pre_emph=float(g("pre_emph_coeff")) if g("pre_emphasis") else 0.0,
+                        real_amplitude=bool(g("real_amplitude")))
     cols = []
     if "mel_spec" in feature_type:
         cols.append(feat[:, :-1])
