@@ -492,6 +492,8 @@ int zeggs_mask_from_lengths(const int64_t* lengths, int B, int max_len, uint8_t*
 typedef struct {
   int N, J, hips, spine2, head;
   double dt;
+  int order;       /* channel order of euler_deg, packed: axis of channel i (0 x, 1 y, 2 z) in bits 2i..2i+1; 0 = "zyx" (round 6: any
+                      order, as quat.from_euler, ZEGGS/anim/quat.py:154-163; the struct grew by this field: zeggs_version() >= 101) */
 } ZeggsAnimDims;
 typedef struct {
   double *root_pos, *root_rot, *root_vel, *root_vrt; /* [N,3] [N,4] [N,3] [N,3] */
@@ -511,6 +513,8 @@ int zeggs_anim_features(const ZeggsAnimDims*, const int* parents, const double* 
 typedef struct {
   int T, J, rebase;            /* rebase != 0: start_position / start_rotation given */
   double start_pos[3], start_rot[4];
+  int order;                   /* channel order of the euler output, packed as ZeggsAnimDims.order; 0 = "zyx"; "zyx" and "xzy" are what
+                                  quat.to_euler (ZEGGS/anim/quat.py:111-127) implements (round 6; zeggs_version() >= 101) */
 } ZeggsBvhDims;
 int zeggs_pose_to_bvh(const ZeggsBvhDims*, const float* root_pos, const float* root_rot, const float* lpos,
                       const float* ltxy, double* positions, double* euler_deg, void* stream);

@@ -70,9 +70,14 @@ def q_from_euler(e, order="zyx"):
 
 
 def q_to_euler(q, order="zyx"):
-    if order != "zyx":
-        raise NotImplementedError("only the 'zyx' channel order of the ZeroEGGS rigs is supported")
+    """quat.to_euler (ZEGGS/anim/quat.py:111-127): the two orders the reference implements"""
     w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    if order == "xzy":
+        return np.stack([np.arctan2(2.0 * (x * w - y * z), -x * x + y * y - z * z + w * w),
+                         np.arctan2(2.0 * (y * w - x * z), x * x - y * y - z * z + w * w),
+                         np.arcsin(np.clip(2.0 * (x * y + z * w), -1.0, 1.0))], axis=-1)
+    if order != "zyx":
+        raise NotImplementedError("Cannot convert to ordering %s" % order)
     return np.stack([np.arctan2(2.0 * (w * z + x * y), 1.0 - 2.0 * (y * y + z * z)),
                      np.arcsin(np.clip(2.0 * (w * y - z * x), -1.0, 1.0)),
                      np.arctan2(2.0 * (w * x + y * z), 1.0 - 2.0 * (x * x + y * y))], axis=-1)

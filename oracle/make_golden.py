@@ -271,6 +271,31 @@ def gold_mel(ref):
     print("mel_options.npz")
 
 
+def gold_anim_orders(ref):
+    """BVH channel orders other than the rigs' "zyx": preprocess_animation of the reference on clips whose rotation channels are
+    declared (and meant) in other orders -- quat.from_euler takes any (anim/quat.py:154-163) -- and the euler channels utils.write_bvh /
+    quat.to_euler produce for order "xzy" (the second order quat.to_euler implements, anim/quat.py:120-125)."""
+    out = {}
+    names16 = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "lrot", "ltxy", "lvel", "lvrt", "cpos", "crot", "ctxy", "cvel",
+               "cvrt", "gaze_pos", "gaze_dir")
+    for order in ("xyz", "yzx", "xzy"):
+        clip = synth.make_bvh_clip(24, seed=31)
+        clip["order"] = order
+        feats = ref.data_pipeline.preprocess_animation(dict(clip))
+        for n, v in zip(names16, feats):
+            out[f"{order}_{n}"] = np.asarray(v)
+    # write side: a short synthetic decoder output -> the reference's euler channels in order "xzy"
+    rng = np.random.default_rng(7)
+    T, J = 12, 75
+    lrot = rng.standard_normal((T, J, 4))
+    lrot /= np.linalg.norm(lrot, axis=-1, keepdims=True)
+    out["w_lrot"] = lrot
+    out["w_euler_xzy"] = np.degrees(ref.quat.to_euler(lrot, order="xzy"))
+    out["w_euler_zyx"] = np.degrees(ref.quat.to_euler(lrot, order="zyx"))
+    np.savez_compressed(GOLD / "anim_orders.npz", **out)
+    print("anim_orders.npz")
+
+
 def gold_dataset(ref):
     """Window table and style-example row sources from the reference SGDataset;
     Y_root_vel[f] = (f, f, f) encodes the source frame of every returned row."""
@@ -747,7 +772,7 @@ def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     ref = ref_shims.load()
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["nets", "train", "mel", "dataset", "radam", "generate", "variants", "generate_branches"]
+    which = sys.argv[1:] or ["nets", "train", "mel", "dataset", "radam", "generate", "variants", "generate_branches", "anim_orders"]
     if "variants" in which:
         gold_variants(ref)
     if "variants" in which or "variants_batch" in which:
@@ -762,6 +787,8 @@ def main():
         gold_dataset(ref)
     if "radam" in which:
         gold_radam(ref)
+    if "anim_orders" in which:
+        gold_anim_orders(ref)
     if "generate" in which:
         gold_generate(ref)
     if "generate_branches" in which:

@@ -1313,6 +1313,48 @@ def test_anim_features_vs_oracle_and_reference(golden_dir, tmp_path):
         np.testing.assert_allclose(a.cpu().numpy(), gd["feat_" + n], atol=2e-4, rtol=1e-4, err_msg=n)
 
 
+@pytest.mark.parametrize("order", ["xyz", "yzx", "xzy"])
+def test_anim_features_other_channel_orders_vs_oracle_and_reference(golden_dir, order):
+    """BVH rotation channels in an order other than the rigs' "zyx" (ZEGGS/anim/bvh.py:54-60 reads it from the file, quat.from_euler
+    takes any): the device features against the oracle (float64) and the reference's own output (anim_orders.npz)."""
+    from zeggs import anim
+    gd = np.load(golden_dir / "anim_orders.npz")
+    clip = synth.make_bvh_clip(24, seed=31)
+    clip["order"] = order
+    dev = anim.preprocess_animation(clip, DEV)
+    ora = oanim.preprocess_animation(clip)
+    for n, a, b in zip(FEAT_NAMES, dev, ora):
+        tol = 1e-6 if a.dtype == torch.float32 else 1e-9
+        np.testing.assert_allclose(a.cpu().numpy(), np.asarray(b), atol=tol, rtol=tol, err_msg=n)
+        np.testing.assert_allclose(a.cpu().numpy(), gd[f"{order}_{n}"], atol=1e-3 if "v" in n[1:] else 2e-4, rtol=1e-4, err_msg=n)
+
+
+def test_pose_to_bvh_channel_order_xzy_vs_reference(golden_dir):
+    """quat.to_euler's second order (ZEGGS/anim/quat.py:120-125) on the device: the same rotations as the reference's channels
+    (compared as quaternions: euler angles are not unique at the poles); any other order raises as the reference does."""
+    from zeggs import anim
+    gd = np.load(golden_dir / "anim_orders.npz")
+    lrot = gd["w_lrot"]
+    T, J = lrot.shape[:2]
+    # two-axis encoding of the rotations (what the decoder emits): the first two columns of the rotation matrix, as rows
+    m = oanim.q_to_xform(lrot) if hasattr(oanim, "q_to_xform") else None
+    if m is None:
+        w, x, y, z = (lrot[..., i] for i in range(4))
+        m = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+                      np.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], -1),
+                      np.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)], -2)
+    ltxy = np.stack([m[..., :, 0], m[..., :, 1]], axis=-2).astype(np.float32)
+    g32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=DEV)  # noqa: E731
+    rp, rr = np.zeros((T, 3)), np.tile(np.array([1.0, 0, 0, 0]), (T, 1))
+    for order in ("xzy", "zyx"):
+        _, eul = anim.bvh_channels(g32(rp), g32(rr), g32(np.zeros((T, J, 3))), g32(ltxy), order=order)
+        qa = oanim.q_from_euler(np.radians(eul.cpu().numpy()), order)
+        qb = oanim.q_from_euler(np.radians(gd[f"w_euler_{order}"]), order)
+        assert np.abs(np.abs(np.sum(qa * qb, axis=-1)) - 1.0).max() < 1e-6, order       # (the two-axis rows went through float32)
+    with pytest.raises(NotImplementedError, match="Cannot convert to ordering"):
+        anim.bvh_channels(g32(rp), g32(rr), g32(np.zeros((T, J, 3))), g32(ltxy), order="yxz")
+
+
 @pytest.mark.parametrize("nframes", [4, 5, 257, 1000])
 def test_anim_features_sizes_and_median(nframes):
     """odd / even frame counts exercise both np.median branches of the gaze target; long clips the sign unrolling

@@ -1,6 +1,7 @@
 """CPU tests: the oracle restatement (oracle/) reproduces golden vectors that
 were produced by the UNMODIFIED reference (oracle/make_golden.py)."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import dataset as ods
@@ -158,6 +159,26 @@ def test_oracle_mel_vs_reference(golden_dir):
         feat = omel.preprocess_audio(g[f"{tag}_wav"], int(g[f"{tag}_nframes"]), normalize_mel_bins=False)
         np.testing.assert_array_equal(np.isnan(feat), np.isnan(g[f"{tag}_feat"]))
         np.testing.assert_allclose(feat, g[f"{tag}_feat"], atol=1e-6, equal_nan=True)
+
+
+def test_oracle_bvh_channel_orders_vs_reference(golden_dir):
+    """anim_orders.npz: preprocess_animation of the reference on clips declared in channel orders "xyz", "yzx", "xzy" (quat.from_euler
+    takes any order), and quat.to_euler's second order "xzy"."""
+    from oracle import anim as oanim
+    from zeggs import synth
+    g = np.load(golden_dir / "anim_orders.npz")
+    names16 = ("root_pos", "root_rot", "root_vel", "root_vrt", "lpos", "lrot", "ltxy", "lvel", "lvrt", "cpos", "crot", "ctxy", "cvel",
+               "cvrt", "gaze_pos", "gaze_dir")
+    for order in ("xyz", "yzx", "xzy"):
+        clip = synth.make_bvh_clip(24, seed=31)
+        clip["order"] = order
+        for n, v in zip(names16, oanim.preprocess_animation(clip)):
+            # (the reference computes the rotations of these clips in float32: its velocities -- differences x 60 -- carry 4e-4)
+            np.testing.assert_allclose(np.asarray(v), g[f"{order}_{n}"], atol=1e-3 if "v" in n[1:] else 2e-4, rtol=1e-4, err_msg=f"{order} {n}")
+    for order in ("xzy", "zyx"):
+        np.testing.assert_allclose(np.degrees(oanim.q_to_euler(g["w_lrot"], order)), g[f"w_euler_{order}"], atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        oanim.q_to_euler(g["w_lrot"], "yxz")            # as the reference: "Cannot convert to ordering yxz"
 
 
 def test_oracle_dataset_indices_vs_reference(golden_dir):

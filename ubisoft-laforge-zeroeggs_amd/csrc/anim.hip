@@ -42,14 +42,26 @@ __device__ __forceinline__ DQ dq_axis(double angle, int axis) {
   const double h = 0.5 * angle, s = sin(h), c = cos(h);
   return DQ{c, axis == 0 ? s : 0.0, axis == 1 ? s : 0.0, axis == 2 ? s : 0.0};
 }
-// channel order "zyx": q = qz(e0) * (qy(e1) * qx(e2)), angles in degrees (quat.py from_euler)
-__device__ __forceinline__ DQ dq_from_euler_zyx_deg(const double* e) {
+// Channel order of the BVH rotation channels, packed: axis of channel i (0 x, 1 y, 2 z) in bits 2 i .. 2 i + 1; 0 = "zyx" (every
+// ZeroEGGS rig).  from_euler takes any order (quat.py:154-163: q = q(e0, axis0) * (q(e1, axis1) * q(e2, axis2))), to_euler the two
+// the reference implements (quat.py:111-127: "zyx", "xzy"; it raises for the others, and so does the host side here).
+constexpr int ORDER_ZYX = 2 | (1 << 2) | (0 << 4), ORDER_XZY = 0 | (2 << 2) | (1 << 4);
+__host__ __device__ inline int order_code(int order) { return order == 0 ? ORDER_ZYX : order; }
+__device__ __forceinline__ DQ dq_from_euler_deg(const double* e, int order) {
   const double r = 0.017453292519943295;
-  return dq_mul(dq_axis(e[0] * r, 2), dq_mul(dq_axis(e[1] * r, 1), dq_axis(e[2] * r, 0)));
+  return dq_mul(dq_axis(e[0] * r, order & 3), dq_mul(dq_axis(e[1] * r, (order >> 2) & 3), dq_axis(e[2] * r, (order >> 4) & 3)));
 }
-__device__ __forceinline__ void dq_to_euler_zyx_deg(DQ q, double* e) {
+__device__ __forceinline__ void dq_to_euler_deg(DQ q, double* e, int order) {
   const double d = 57.29577951308232;
-  double sy = 2.0 * (q.w * q.y - q.z * q.x);
+  if (order == ORDER_XZY) {      // quat.py:120-125
+    double sz = 2.0 * (q.x * q.y + q.z * q.w);
+    sz = sz > 1.0 ? 1.0 : (sz < -1.0 ? -1.0 : sz);
+    e[0] = d * atan2(2.0 * (q.x * q.w - q.y * q.z), -q.x * q.x + q.y * q.y - q.z * q.z + q.w * q.w);
+    e[1] = d * atan2(2.0 * (q.y * q.w - q.x * q.z), q.x * q.x - q.y * q.y - q.z * q.z + q.w * q.w);
+    e[2] = d * asin(sz);
+    return;
+  }
+  double sy = 2.0 * (q.w * q.y - q.z * q.x);      // "zyx", quat.py:114-119
   sy = sy > 1.0 ? 1.0 : (sy < -1.0 ? -1.0 : sy);
   e[0] = d * atan2(2.0 * (q.w * q.z + q.x * q.y), 1.0 - 2.0 * (q.y * q.y + q.z * q.z));
   e[1] = d * asin(sy);
@@ -98,14 +110,14 @@ __device__ __forceinline__ void stq(double* p, DQ q) { p[0] = q.w; p[1] = q.x; p
 
 // ------------------------------------------------------------------ feature extraction
 // 1. euler channels -> raw local quaternions and the dot product with the previous frame's raw quaternion
-__global__ void anim_quat_k(const double* euler, double* lrot, double* dprev, int N, int J) {
+__global__ void anim_quat_k(const double* euler, double* lrot, double* dprev, int N, int J, int order) {
   const long n = (long)N * J;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const DQ q = dq_from_euler_zyx_deg(euler + i * 3);
+    const DQ q = dq_from_euler_deg(euler + i * 3, order);
     stq(lrot + i * 4, q);
     double d = 1.0;
     if (i >= J) {
-      const DQ p = dq_from_euler_zyx_deg(euler + (i - J) * 3);
+      const DQ p = dq_from_euler_deg(euler + (i - J) * 3, order);
       d = q.w * p.w + q.x * p.x + q.y * p.y + q.z * p.z;
     }
     dprev[i] = d;
@@ -332,7 +344,7 @@ __global__ void pose_to_bvh_k(ZeggsBvhDims d, const float* root_pos, const float
       q = dq_mul(rr, q);
     }
     st3(positions + i * 3, p);
-    dq_to_euler_zyx_deg(q, euler + i * 3);
+    dq_to_euler_deg(q, euler + i * 3, order_code(d.order));
   }
 }
 
@@ -367,7 +379,7 @@ __global__ void pose_to_bvh_table_k(ZeggsBvhDims d, const float* root_pos, const
       q = dq_mul(rr, q);
       st3(table + f * cols, p);
     }
-    dq_to_euler_zyx_deg(q, table + f * cols + 3 + 3 * k);
+    dq_to_euler_deg(q, table + f * cols + 3 + 3 * k, order_code(d.order));
   }
 }
 
@@ -405,7 +417,7 @@ extern "C" int zeggs_anim_features(const ZeggsAnimDims* dp, const int* parents, 
   AnimWs w = carve_anim(d, a);
   ZCHECK(a.ok(), "anim_features: workspace too small (%zu < %zu)", ws_bytes, a.off);
   const long NJ = (long)d.N * d.J;
-  hipLaunchKernelGGL(anim_quat_k, grid_for(NJ, 256), dim3(256), 0, s, euler_deg, w.lrot_raw, w.dprev, d.N, d.J);
+  hipLaunchKernelGGL(anim_quat_k, grid_for(NJ, 256), dim3(256), 0, s, euler_deg, w.lrot_raw, w.dprev, d.N, d.J, order_code(d.order));
   hipLaunchKernelGGL(anim_unroll_k, dim3((d.J + 63) / 64), dim3(64), 0, s, w.dprev, w.sign, d.N, d.J);
   hipLaunchKernelGGL(anim_root_k, dim3((d.N + 63) / 64), dim3(64), 0, s, d, parents, w.lrot_raw, positions, w.sign,
                      out->root_pos, out->root_rot, w.gz);

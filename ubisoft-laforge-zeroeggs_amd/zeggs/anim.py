@@ -170,7 +170,14 @@ def format_rows(table):
 # ----------------------------------------------------------------------------- device kernels (csrc/anim.hip)
 class AnimDims(C.Structure):       # mirrors ZeggsAnimDims
     _fields_ = [("N", C.c_int), ("J", C.c_int), ("hips", C.c_int), ("spine2", C.c_int), ("head", C.c_int),
-                ("dt", C.c_double)]
+                ("dt", C.c_double), ("order", C.c_int)]
+
+
+def order_code(order):
+    """'zyx' -> the packed channel order of ZeggsAnimDims / ZeggsBvhDims (axis of channel i in bits 2i..2i+1)"""
+    if sorted(order) != ["x", "y", "z"]:
+        raise ValueError(f"not a rotation channel order: {order!r}")
+    return sum("xyz".index(c) << (2 * i) for i, c in enumerate(order))
 
 
 ANIM_OUT = (("root_pos", 3, torch.float64), ("root_rot", 4, torch.float64), ("root_vel", 3, torch.float64),
@@ -184,7 +191,7 @@ AnimOut = type("AnimOut", (C.Structure,), {"_fields_": [(n, C.c_void_p) for n, _
 
 class BvhDims(C.Structure):        # mirrors ZeggsBvhDims
     _fields_ = [("T", C.c_int), ("J", C.c_int), ("rebase", C.c_int), ("start_pos", C.c_double * 3),
-                ("start_rot", C.c_double * 4)]
+                ("start_rot", C.c_double * 4), ("order", C.c_int)]
 
 
 def _stream():
@@ -196,14 +203,13 @@ def preprocess_animation(anim, device=None):
     (root_pos, root_rot, root_vel, root_vrt, lpos, lrot, ltxy, lvel, lvrt, cpos, crot, ctxy, cvel, cvrt, gaze_pos,
     gaze_dir) as DEVICE tensors (float64; ltxy / ctxy float32)."""
     device = torch.device(device or "cuda")
-    if anim["order"] != "zyx":
-        raise NotImplementedError("only the 'zyx' channel order of the ZeroEGGS rigs is supported")
     names = list(anim["names"])
     rot = torch.as_tensor(np.ascontiguousarray(anim["rotations"], dtype=np.float64), device=device)
     pos = torch.as_tensor(np.ascontiguousarray(anim["positions"], dtype=np.float64), device=device)
     parents = torch.as_tensor(np.ascontiguousarray(anim["parents"], dtype=np.int32), device=device)
     N, J = rot.shape[0], rot.shape[1]
-    d = AnimDims(N, J, names.index("Hips"), names.index("Spine2"), names.index("Head"), float(anim["frametime"]))
+    d = AnimDims(N, J, names.index("Hips"), names.index("Spine2"), names.index("Head"), float(anim["frametime"]),
+                 order_code(anim["order"]))      # any channel order (quat.from_euler takes any)
     L = ops.lib()
     L.zeggs_anim_features_workspace_bytes.restype = C.c_size_t
     ws = torch.empty(int(L.zeggs_anim_features_workspace_bytes(C.byref(d))), dtype=torch.uint8, device=device)
@@ -222,11 +228,18 @@ def preprocess_animation(anim, device=None):
     return tuple(out[k] for k in order)
 
 
-def bvh_channels(root_pos, root_rot, lpos, ltxy, start_position=None, start_rotation=None):
+def _to_euler_order(order):
+    if order not in ("zyx", "xzy"):      # what quat.to_euler implements (ZEGGS/anim/quat.py:111-127); the reference raises the same
+        raise NotImplementedError("Cannot convert to ordering %s" % order)
+    return order_code(order)
+
+
+def bvh_channels(root_pos, root_rot, lpos, ltxy, start_position=None, start_rotation=None, order="zyx"):
     """decoder output (device float32: [T,3], [T,4], [T,J,3], [T,J,2,3]) -> (positions, euler degrees) float64
-    device tensors [T,J,3], channel order zyx, root folded into joint 0 (reference generate.py:389, utils.py:47-87)."""
+    device tensors [T,J,3], channel order `order`, root folded into joint 0 (reference generate.py:389, utils.py:47-87)."""
     T, J = lpos.shape[0], lpos.shape[1]
     d = BvhDims(T, J, 0)
+    d.order = _to_euler_order(order)
     if start_position is not None and start_rotation is not None:
         d.rebase = 1
         d.start_pos[:] = [float(v) for v in start_position]
@@ -248,9 +261,7 @@ def write_bvh(filename, root_pos, root_rot, lpos, ltxy, parents, names, order, d
               start_rotation=None):
     """reference utils.write_bvh, fed with the decoder's two-axis rotations (the quaternion / euler conversion of
     generate.py:389 happens on the device)."""
-    if order != "zyx":
-        raise NotImplementedError("only the 'zyx' channel order of the ZeroEGGS rigs is supported")
-    positions, euler = bvh_channels(root_pos, root_rot, lpos, ltxy, start_position, start_rotation)
+    positions, euler = bvh_channels(root_pos, root_rot, lpos, ltxy, start_position, start_rotation, order)
     write_bvh_channels(filename, positions, euler, parents, names, order, dt)
 
 
