@@ -397,7 +397,9 @@ typedef struct {
   int n_fft, hop, n_mels, fs;
   float fps, min_clip;
   double pre_emph;      /* audio_conf.pre_emphasis ? audio_conf.pre_emph_coeff : 0 (spectrograms.py:35; round 6: the struct grew by this
-                           field -- zeggs_version() >= 101) */
+                           field and the next -- zeggs_version() >= 101) */
+  int flags;            /* bit 0: audio_conf.centered is FALSE (spectrograms.py:237-239); bit 1: audio_conf.normalize_range is FALSE
+                           (spectrograms.py:123-129); 0 = the shipped configuration */
 } ZeggsMelDims;
 long zeggs_mel_stft_frames(const ZeggsMelDims*, long n_samples); /* integer rule of spectrograms.py:242-245 */
 size_t zeggs_mel_workspace_bytes(const ZeggsMelDims*, long n_samples);

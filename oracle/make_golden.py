@@ -266,6 +266,13 @@ def gold_mel(ref):
             wav, nfr = out[f"{tag}_wav"], int(out[f"{tag}_nframes"])
             out3[f"{tag}_wav"], out3[f"{tag}_nframes"] = wav, np.int64(nfr)
             out3[f"{tag}_feat_{name}"] = ref.data_pipeline.preprocess_audio(wav, 60, nfr, ac, feature_type=conf["audio_feature_type"])
+    # audio_conf.centered = false (no reflect padding: other frame count, spectrograms.py:237-245) and normalize_range = false (:123-129)
+    for name, ce, nr in (("unc", False, True), ("rawdb", True, False), ("uncrawdb", False, False)):
+        conf["audio_conf"].update(normalize_mel_bins=True, pre_emphasis=False, real_amplitude=True, centered=ce, normalize_range=nr)
+        ac = ref.DictConfig(conf["audio_conf"])
+        for tag in "ab":
+            wav, nfr = out[f"{tag}_wav"], int(out[f"{tag}_nframes"])
+            out3[f"{tag}_feat_{name}"] = ref.data_pipeline.preprocess_audio(wav, 60, nfr, ac, feature_type=conf["audio_feature_type"])
     out3["pre_emph_coeff"] = np.float64(conf["audio_conf"]["pre_emph_coeff"])
     np.savez_compressed(GOLD / "mel_options.npz", **out3)
     print("mel_options.npz")

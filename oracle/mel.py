@@ -20,9 +20,9 @@ def hann_symmetric(n):
     return 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / (n - 1))
 
 
-def stft_frame_count(n_samples, n_fft=800, hop=200):
+def stft_frame_count(n_samples, n_fft=800, hop=200, centered=True):
     """spectrograms.py:233-246 (integer rule, bit-exact)."""
-    n = max(n_samples, n_fft) + 2 * (n_fft // 2)
+    n = max(n_samples, n_fft) + (2 * (n_fft // 2) if centered else 0)
     if n % hop == 0:
         return int((n - n_fft) // hop)
     return 1 + int((n - n_fft) // hop)
@@ -71,7 +71,7 @@ def mel_filterbank(n_fft=800, fs=16000, n_mels=80, fmin=20.0, fmax=7600.0, norma
 
 
 def mel_spectrogram(wav, n_fft=800, hop=200, fs=16000, n_mels=80, fmin=20.0, fmax=7600.0,
-                    min_clip=1e-5, normalize_mel_bins=True, pre_emph=0.0, real_amplitude=True):
+                    min_clip=1e-5, normalize_mel_bins=True, pre_emph=0.0, real_amplitude=True, centered=True, normalize_range=True):
     """extract_mel_spectrogram_for_tts (spectrograms.py:8-54) with the shipped
     conf (centered, real_amplitude, normalize_mel_bins, normalize_range, no
     pre-emphasis): returns [n_mels, M] in [0, ~1]."""
@@ -80,8 +80,9 @@ def mel_spectrogram(wav, n_fft=800, hop=200, fs=16000, n_mels=80, fmin=20.0, fma
         x = np.concatenate([x[:1], x[1:] - pre_emph * x[:-1]])
     if len(x) < n_fft:
         x = np.pad(x, (0, n_fft - len(x)))
-    x = np.pad(x, (n_fft // 2, n_fft // 2), mode="reflect")
-    M = stft_frame_count(len(wav), n_fft, hop)
+    if centered:
+        x = np.pad(x, (n_fft // 2, n_fft // 2), mode="reflect")
+    M = stft_frame_count(len(wav), n_fft, hop, centered)
     idx = np.arange(M)[:, None] * hop + np.arange(n_fft)[None, :]
     frames = x[idx] * hann_symmetric(n_fft)[None, :]
     amp = np.abs(np.fft.rfft(frames, axis=1)).T / (n_fft if real_amplitude else 1)            # [401, M]
@@ -90,7 +91,7 @@ def mel_spectrogram(wav, n_fft=800, hop=200, fs=16000, n_mels=80, fmin=20.0, fma
     mel = np.clip(np.abs(mel), amin, None)
     db = 20.0 * np.log10(mel)
     rng = -20.0 * np.log10(amin)
-    return (db + rng) / rng
+    return (db + rng) / rng if normalize_range else db
 
 
 def preprocess_audio(wav, n_frames, fs=16000, hop=200, fps=60.0, **kw):

@@ -109,7 +109,14 @@ def test_streaming_frame_accounting_is_consistent_host_only():
     from zeggs import audio, ops
     L = ops.lib()
     L.zeggs_mel_frames_ready.restype = C.c_long
-    d = audio.MelDims(800, 200, 80, 16000, 60.0, 1e-5, 0.0)
+    for flags in (0, 1):        # centered (the shipped configuration) / uncentered frames (audio_conf.centered = false)
+        _frame_accounting(L, audio.MelDims(800, 200, 80, 16000, 60.0, 1e-5, 0.0, flags), flags)
+
+
+def _frame_accounting(L, d, flags):
+    import ctypes as C
+    import math
+    from zeggs import audio
     prev = 0
     for n in list(range(0, 3000, 37)) + [16000, 16001, 48000, 480000]:
         k = int(L.zeggs_mel_frames_ready(C.byref(d), C.c_long(n)))
@@ -118,6 +125,6 @@ def test_streaming_frame_accounting_is_consistent_host_only():
         for kk in (k - 1,):
             if kk >= 0:
                 hi = max(math.ceil((80.0 / 60.0) * kk), 1)          # last STFT frame that animation frame kk interpolates
-                assert 200 * hi + 400 <= n, (n, kk, hi)              # its window ends inside the received samples
+                assert 200 * hi + (800 if flags & 1 else 400) <= n, (n, kk, hi)      # its window ends inside the received samples
         assert k <= audio.n_anim_frames(n) + 1
     assert int(L.zeggs_mel_frames_ready(C.byref(d), C.c_long(480000))) >= audio.n_anim_frames(480000) - 3

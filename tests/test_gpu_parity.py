@@ -720,9 +720,9 @@ def test_mel_unnormalised_bins_vs_reference(golden_dir):
 
 @pytest.mark.parametrize("mel_fft", [1, 0])
 def test_mel_pre_emphasis_and_raw_amplitude_vs_reference(golden_dir, mel_fft):
-    """audio_conf.pre_emphasis = true (the high-pass inside the kernels' sample fetch, float64) and audio_conf.real_amplitude = false
-    (filterbank and clip floor x n_fft on the host), one at a time and together, through the drop-in preprocess_audio against the
-    reference's (mel_options.npz); mel_fft = 0: the direct-DFT kernel (the matrix-core DFT stages float32 samples and steps aside
+    """audio_conf.pre_emphasis = true (the high-pass inside the kernels' sample fetch, float64), real_amplitude = false (filterbank
+    and clip floor x n_fft on the host), centered = false (no reflect padding, other frame count) and normalize_range = false (the
+    stored value is 20 log10 s), alone and in pairs, through the drop-in preprocess_audio against the reference's (mel_options.npz); mel_fft = 0: the direct-DFT kernel (the matrix-core DFT stages float32 samples and steps aside
     when the pre-emphasis is on)."""
     from zeggs import audio
     gd = np.load(golden_dir / "mel_options.npz")
@@ -731,16 +731,57 @@ def test_mel_pre_emphasis_and_raw_amplitude_vs_reference(golden_dir, mel_fft):
                 normalize_range=True, normalize_loudness=False, resample_method="linear")
     ops.set_option("mel_fft", mel_fft)
     try:
-        for name, pe, ra in (("pre", True, True), ("raw", False, False), ("preraw", True, False)):
-            conf = dict(base, pre_emphasis=pe, real_amplitude=ra)
+        for name, over in (("pre", dict(pre_emphasis=True)), ("raw", dict(real_amplitude=False)),
+                           ("preraw", dict(pre_emphasis=True, real_amplitude=False)), ("unc", dict(centered=False)),
+                           ("rawdb", dict(normalize_range=False)), ("uncrawdb", dict(centered=False, normalize_range=False))):
+            conf = dict(base, pre_emphasis=False, real_amplitude=True)
+            conf.update(over)
             for tag in "ab":
                 wav, nfr = gd[f"{tag}_wav"], int(gd[f"{tag}_nframes"])
                 feat = audio.preprocess_audio(wav, 60, nfr, conf, ["mel_spec", "energy"])
                 ref = gd[f"{tag}_feat_{name}"]
                 np.testing.assert_array_equal(np.isnan(feat), np.isnan(ref))
-                np.testing.assert_allclose(feat, ref, atol=3e-6, equal_nan=True, err_msg=f"{name} {tag}")
+                np.testing.assert_allclose(feat, ref, atol=3e-6, rtol=3e-6, equal_nan=True, err_msg=f"{name} {tag}")
     finally:
         ops.set_option("mel_fft", 1)
+
+
+@pytest.mark.parametrize("pre,real,centered,norm", [(0.0, True, True, True), (0.97, True, True, True), (0.0, False, False, True),
+                                                    (0.97, True, False, False), (0.0, True, True, False)])
+def test_mel_streaming_ranges_equal_offline_for_every_audio_option(pre, real, centered, norm):
+    """the streaming form (zeggs_mel_features_range: rows [k0, k1) from the samples received so far, k1 bounded by
+    zeggs_mel_frames_ready) against the offline table, for the shipped audio_conf and the option values that got a device path in round 6
+    (pre-emphasis, raw amplitude, uncentered frames, raw dB range)"""
+    import ctypes as C
+    from zeggs import audio
+    L = ops.lib()
+    L.zeggs_mel_frames_ready.restype = C.c_long
+    L.zeggs_mel_range_workspace_bytes.restype = C.c_size_t
+    n = 40000
+    wav = synth.synth_wav(n, seed=17).astype(np.float32) / 32768.0
+    nfr = audio.n_anim_frames(n)
+    full = audio.mel_features(wav, nfr, pre_emph=pre, real_amplitude=real, centered=centered, normalize_range=norm)
+    fb, min_clip = audio.mel_tables(800, 16000, 80, 20.0, 7600.0, 1e-5, True, real, DEV)
+    d = audio.MelDims(800, 200, 80, 16000, 60.0, float(min_clip), float(pre), audio.mel_flags(centered, norm))
+    w = g(torch.as_tensor(wav))
+    rows, k0 = [], 0
+    for got in (9000, 17000, 31000, n):
+        final = got == n
+        k1 = nfr if final else int(L.zeggs_mel_frames_ready(C.byref(d), C.c_long(got)))
+        if k1 <= k0:
+            continue
+        ws = torch.empty(int(L.zeggs_mel_range_workspace_bytes(C.byref(d), C.c_long(k0), C.c_long(k1))), dtype=torch.uint8, device=DEV)
+        out = torch.empty(k1 - k0, 81, device=DEV)
+        part = w[:got].contiguous()
+        ops._check(L.zeggs_mel_features_range(C.byref(d), C.c_void_p(part.data_ptr()), C.c_long(got), int(final), C.c_void_p(fb.data_ptr()),
+                                              C.c_long(k0), C.c_long(k1), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                              C.c_size_t(ws.numel()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mel_features_range")
+        rows.append(out)
+        k0 = k1
+    st = torch.cat(rows).cpu().numpy()
+    fu = full.cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(st), np.isnan(fu))
+    np.testing.assert_allclose(st, fu, atol=1e-6, rtol=1e-6, equal_nan=True)
 
 
 def test_mel_fft_form_equals_the_dft_forms(golden_dir):
@@ -1883,7 +1924,7 @@ def test_c_abi_rejects_bad_arguments_loudly():
     # unknown option, bad mel dims, streaming range ahead of the received samples
     assert L.zeggs_set_option(b"no_such_option", 1) == -1 and b"unknown option" in L.zeggs_last_error()
     from zeggs import audio
-    d = audio.MelDims(800, 200, 80, 16000, 60.0, 1e-5, 0.0)
+    d = audio.MelDims(800, 200, 80, 16000, 60.0, 1e-5, 0.0, 0)
     rc = L.zeggs_mel_features_range(C.byref(d), p(dev_buf), C.c_long(3000), 0, p(dev_buf), C.c_long(0), C.c_long(50),
                                     p(dev_buf), p(dev_buf), C.c_size_t(1 << 18), stream)
     assert rc == -1 and b"not received yet" in L.zeggs_last_error()

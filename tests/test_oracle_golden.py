@@ -154,6 +154,12 @@ def test_oracle_mel_vs_reference(golden_dir):
             ref = g[f"{tag}_feat_{name}"]
             np.testing.assert_array_equal(np.isnan(feat), np.isnan(ref))
             np.testing.assert_allclose(feat, ref, atol=1e-6, equal_nan=True, err_msg=f"{name} {tag}")
+    for name, ce, nr in (("unc", False, True), ("rawdb", True, False), ("uncrawdb", False, False)):      # centered / normalize_range = false
+        for tag in "ab":
+            feat = omel.preprocess_audio(g[f"{tag}_wav"], int(g[f"{tag}_nframes"]), centered=ce, normalize_range=nr)
+            ref = g[f"{tag}_feat_{name}"]
+            np.testing.assert_array_equal(np.isnan(feat), np.isnan(ref))
+            np.testing.assert_allclose(feat, ref, rtol=2e-6, atol=1e-6, equal_nan=True, err_msg=f"{name} {tag}")
     g = np.load(golden_dir / "mel_nonorm.npz")          # audio_conf.normalize_mel_bins = false
     for tag in "ab":
         feat = omel.preprocess_audio(g[f"{tag}_wav"], int(g[f"{tag}_nframes"]), normalize_mel_bins=False)

@@ -47,8 +47,12 @@ MelWs carve_mel(const ZeggsMelDims& d, long M, Arena& a) {
 }
 
 // spectrograms.py:233-246 (integer rule)
-inline long stft_frames(long n, int n_fft, int hop) {
-  long np = (n > n_fft ? n : n_fft) + 2 * (long)(n_fft / 2);
+// ZeggsMelDims.flags: bit 0 = audio_conf.centered is FALSE (no reflect padding: frame m starts at sample m hop, spectrograms.py:237-239),
+// bit 1 = audio_conf.normalize_range is FALSE (the stored value is 20 log10 s, not mapped to [0, 1], spectrograms.py:123-129)
+#define MEL_UNCENTERED 1
+#define MEL_RAW_RANGE 2
+inline long stft_frames(long n, int n_fft, int hop, int flags = 0) {
+  long np = (n > n_fft ? n : n_fft) + ((flags & MEL_UNCENTERED) ? 0 : 2 * (long)(n_fft / 2));
   return (np % hop == 0) ? (np - n_fft) / hop : 1 + (np - n_fft) / hop;
 }
 
@@ -63,7 +67,9 @@ inline long stft_frames(long n, int n_fft, int hop) {
 //     features are float32 and the reference fixtures are matched at 2e-6;
 //   mode 2 (default): the affine map in float64 (log10 + exp per value): float32 features bit-identical to mode 1, the literal
 //   float64 chain (zeggs_set_option("mel_exact_log", m)).
-__device__ __forceinline__ double mel_logamp(double s, double rng, int exact) {
+__device__ __forceinline__ double mel_logamp(double s, double rng, int exact, int flags = 0) {
+  if (flags & MEL_RAW_RANGE)      // normalize_range = false: v = 20 log10 s, y = ln(10^(v / 20)) = ln s
+    return exact == 0 ? (double)(__builtin_amdgcn_logf((float)s) * 0.6931471805599453f) : exact == 1 ? log(pow(10.0, (20.0 * log10(s)) / 20.0)) : log(s);
   if (exact == 0) return (double)(__builtin_amdgcn_logf((float)s) * 0.6931471805599453f) / rng + (2.302585092994046 / 20.0);
   const double v = (20.0 * log10(s) + rng) / rng;
   return exact == 1 ? log(pow(10.0, v / 20.0)) : v * (2.302585092994046 / 20.0);
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* w
   const long fr = m0 + blockIdx.x, slot = blockIdx.x;
   const long neff = n > NF ? n : NF;   // zero-extended to n_fft when shorter (spectrograms.py:233-234)
   for (int j = threadIdx.x; j < NF; j += blockDim.x) {
-    const long p = fr * d.hop + j - NF / 2;          // index into the (zero-extended) signal before reflect padding
+    const long p = fr * d.hop + j - ((d.flags & MEL_UNCENTERED) ? 0 : NF / 2);          // index into the (zero-extended) signal before reflect padding
     long src = p < 0 ? -p : (p >= neff ? 2 * (neff - 1) - p : p);
     const double x = mel_sample(wav, src, n, n_avail, d.pre_emph);
     const double win = 0.5 - 0.5 * cos(2.0 * M_PI * (double)j / (double)(NF - 1));   // scipy hann(sym=True)
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256) void mel_stft_k(ZeggsMelDims d, const float* w
     for (int k = 0; k < NBIN; ++k) s = fma(f[k], amp[k], s);
     s = fabs(s);
     if (s < amin) s = amin;
-    const double y = mel_logamp(s, rng, exact);
+    const double y = mel_logamp(s, rng, exact, d.flags);
     melv[m] = y;
     logmel[slot * d.n_mels + m] = y;
   }
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(MWAVES * 64) void mel_stft_mfma_k(ZeggsMelDims d, c
   const long fr0 = m0 + (long)blockIdx.x * MF, slot0 = (long)blockIdx.x * MF;
   const long neff = n > NF ? n : NF;
   for (int i = tid; i < ns; i += blockDim.x) {
-    const long p = fr0 * hop + i - NF / 2;
+    const long p = fr0 * hop + i - ((d.flags & MEL_UNCENTERED) ? 0 : NF / 2);
     const long src = p < 0 ? -p : (p >= neff ? 2 * (neff - 1) - p : p);
     xs[i] = (src >= 0 && src < n && src < n_avail) ? wav[src] : 0.f;
   }
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(MWAVES * 64) void mel_stft_mfma_k(ZeggsMelDims d, c
     }
     s = fabs(s);
     if (s < amin) s = amin;
-    const double y = mel_logamp(s, rng, exact);
+    const double y = mel_logamp(s, rng, exact, d.flags);
     melv[it] = y;                                   // (the sample area: the products are done)
     if (slot0 + f < nfr) logmel[(slot0 + f) * NM + m] = y;
   }
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(FTHR) void mel_stft_fft_k(ZeggsMelDims d, FftPlan p
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int j = 2 * m + h;
-      const long p = (fr0 + f) * hop + j - NF / 2;
+      const long p = (fr0 + f) * hop + j - ((d.flags & MEL_UNCENTERED) ? 0 : NF / 2);
       const long src = p < 0 ? -p : (p >= neff ? 2 * (neff - 1) - p : p);
       const double x = mel_sample(wav, src, n, n_avail, d.pre_emph);
       v[h] = x * WIN[j].x;
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(FTHR) void mel_stft_fft_k(ZeggsMelDims d, FftPlan p
     }
     sacc = fabs(sacc);
     if (sacc < amin) sacc = amin;
-    const double yv = mel_logamp(sacc, rng, exact);
+    const double yv = mel_logamp(sacc, rng, exact, d.flags);
     melv[it] = mel_exp_sq(yv, exact);                                 // (every thread its own exp; the frame's thread only adds, in mel order)
     if (slot0 + f < nfr) logmel[(slot0 + f) * NM + m] = yv;
   }
@@ -549,12 +555,12 @@ static int launch_stft(const ZeggsMelDims& d, const MelWs& w, const float* wav, 
 }
 
 extern "C" long zeggs_mel_stft_frames(const ZeggsMelDims* d, long n_samples) {
-  return stft_frames(n_samples, d->n_fft, d->hop);
+  return stft_frames(n_samples, d->n_fft, d->hop, d->flags);
 }
 
 extern "C" size_t zeggs_mel_workspace_bytes(const ZeggsMelDims* d, long n_samples) {
   Arena a(nullptr, 0);
-  carve_mel(*d, stft_frames(n_samples, d->n_fft, d->hop), a);
+  carve_mel(*d, stft_frames(n_samples, d->n_fft, d->hop, d->flags), a);
   return a.off + 256;
 }
 
@@ -564,7 +570,7 @@ extern "C" int zeggs_mel_features(const ZeggsMelDims* dp, const float* wav, long
   hipStream_t s = (hipStream_t)stream;
   ZCHECK(d.n_fft >= 2 && d.n_fft % 2 == 0 && d.hop > 0 && d.n_mels > 0, "mel: bad dims");
   ZCHECK(n_samples > 0 && n_frames >= 0, "mel: empty input");
-  const long M = stft_frames(n_samples, d.n_fft, d.hop);
+  const long M = stft_frames(n_samples, d.n_fft, d.hop, d.flags);
   Arena a(ws, ws_bytes);
   MelWs w = carve_mel(d, M, a);
   ZCHECK(a.ok(), "mel: workspace too small (%zu < %zu)", ws_bytes, a.off);
@@ -584,7 +590,8 @@ extern "C" int zeggs_mel_features(const ZeggsMelDims* dp, const float* wav, long
 //   final != 0: n_samples is the whole signal: identical to rows k0..k1-1 of zeggs_mel_features.
 extern "C" long zeggs_mel_frames_ready(const ZeggsMelDims* d, long n_samples) {
   // STFT frame m is complete when 200 m + 400 <= n; animation frame k interpolates STFT frames ceil(t)-1, ceil(t)
-  const long mmax = (n_samples - d->n_fft / 2) / d->hop;           // last complete STFT frame (may be < 1)
+  // (uncentered: frame m covers samples m hop .. m hop + n_fft - 1)
+  const long mmax = (d->flags & MEL_UNCENTERED) ? (n_samples - d->n_fft) / d->hop : (n_samples - d->n_fft / 2) / d->hop;      // last complete STFT frame (may be < 1)
   if (mmax < 1) return 0;
   const double r = ((double)d->fs / (double)d->hop) / (double)d->fps;
   long k = (long)floor((double)mmax / r);                           // largest k with t_k <= mmax
@@ -606,7 +613,7 @@ extern "C" int zeggs_mel_features_range(const ZeggsMelDims* dp, const float* wav
   ZCHECK(d.n_fft >= 2 && d.n_fft % 2 == 0 && d.hop > 0 && d.n_mels > 0, "mel: bad dims");
   ZCHECK(n_samples > 0 && k0 >= 0 && k1 > k0, "mel range: empty input");
   if (!final) ZCHECK(k1 <= zeggs_mel_frames_ready(dp, n_samples), "mel range: frames %ld..%ld need samples not received yet", k0, k1);
-  const long M = final ? stft_frames(n_samples, d.n_fft, d.hop) : (1L << 40);
+  const long M = final ? stft_frames(n_samples, d.n_fft, d.hop, d.flags) : (1L << 40);
   const double r = ((double)d.fs / (double)d.hop) / (double)d.fps;
   long m0 = (long)ceil(r * (double)k0) - 1, m1 = (long)ceil(r * (double)(k1 - 1)) + 1;   // [m0, m1)
   if (m0 < 0) m0 = 0;

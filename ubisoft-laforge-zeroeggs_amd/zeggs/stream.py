@@ -36,8 +36,6 @@ class GestureStream:
         g = audio_conf
         if g.get("normalize_loudness"):
             raise ValueError("loudness normalisation needs the whole signal: apply audio.normalize_loudness() first")
-        if not (g["centered"] and g["normalize_range"]):
-            raise NotImplementedError("audio_conf.centered = false / normalize_range = false have no HIP path")
         if tuple(feature_type) != ("mel_spec", "energy"):
             raise NotImplementedError("streaming supports the shipped feature set [mel_spec, energy]")
         self.dev = torch.device(device)
@@ -47,7 +45,8 @@ class GestureStream:
         self.fb, min_clip = audio.mel_tables(g["filter_length"], self.fs, g["n_mel_channels"], g["mel_fmin"], g["mel_fmax"],
                                              g["min_clipping"], g["normalize_mel_bins"], g.get("real_amplitude", True), self.dev)
         self.mel = audio.MelDims(g["filter_length"], g["hop_length"], g["n_mel_channels"], self.fs, self.fps, float(min_clip),
-                                 float(g.get("pre_emph_coeff", 0.97)) if g.get("pre_emphasis") else 0.0)
+                                 float(g.get("pre_emph_coeff", 0.97)) if g.get("pre_emphasis") else 0.0,
+                                 audio.mel_flags(g.get("centered", True), g.get("normalize_range", True)))
         f32 = lambda a: a[0:1].to(self.dev, torch.float32).contiguous()  # noqa: E731
         root_pos, root_rot, root_vel, root_vrt, lpos, lrot, ltxy, lvel, lvrt = first_pose[:9]
         self.gaze = f32(first_pose[14])                                   # [1, 3] constant gaze target
