@@ -1099,7 +1099,16 @@ def test_decoder_gemv_decode_path_matches_mfma_path(B):
 def test_chained_decode_launches_match_plain_launches(B):
     """option "chain": consecutive stage launches alternate between two streams and hand over through device-side
     arrival counters (every launch fetches its weights while its predecessor runs).  Same arithmetic per stage up to the
-    summation order of the dot products; every bounded wait must have been satisfied."""
+    summation order of the dot products; every bounded wait must have been satisfied.  Since round 6 the chained kernels
+    are part of measurement builds only (-DZEGGS_CHAIN: they spill at the occupancy run-ahead needs and lost to the persistent
+    decode kernel): the default library must refuse the option instead of accepting and ignoring it."""
+    try:
+        ops.set_option("chain", 1)
+    except RuntimeError as e:
+        assert "ZEGGS_CHAIN" in str(e)
+        ops.set_option("chain", 0)
+        pytest.skip("chained launches are not part of this build")
+    ops.set_option("chain", 0)
     _, de, _ = helpers.build_nets()
     de = de.to(DEV).eval()
     T = 400

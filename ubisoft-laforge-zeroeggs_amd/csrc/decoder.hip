@@ -51,7 +51,13 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   if (strcmp(name, "stage_variant") == 0) { g_stage_variant = value; return 0; }
   if (strcmp(name, "gemm_wg_target") == 0) { g_gemm_wg_target = value; return 0; }
   if (strcmp(name, "timing") == 0) { g_timing = value; return 0; }
-  if (strcmp(name, "chain") == 0) { g_chain = value; return 0; }
+  if (strcmp(name, "chain") == 0) {
+#ifndef ZEGGS_CHAIN
+    if (value) { zeggs_set_error("option chain: the chained (run-ahead) stage launches lost to the persistent decode kernel and are "
+                                 "compiled in measurement builds only (-DZEGGS_CHAIN)"); return -1; }
+#endif
+    g_chain = value; return 0;
+  }
   if (strcmp(name, "sweep_graphs") == 0) { g_sweep_graphs = value != 0; return 0; }
   if (strcmp(name, "launch_window") == 0) { g_launch_window = value < 0 ? 0 : value; return 0; }
   // (re-)enabling gives a kernel that was disabled after a failed validation another chance

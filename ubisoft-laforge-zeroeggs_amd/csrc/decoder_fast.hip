@@ -185,7 +185,8 @@ __device__ __forceinline__ long xf_index(int b, int k, int NB) {
 #define ZMAC(A, w, x) A = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x, A, 0, 0, 0)
 #endif
 
-template <int NB>   // NB here = batch blocks handled by this workgroup; LNB = batch blocks in the fragment layout
+// UG = k-blocks per register buffer (0: the build's default ZEGGS_U)
+template <int NB, int UG = 0>   // NB here = batch blocks handled by this workgroup; LNB = batch blocks in the fragment layout
 __device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* __restrict__ xp, int lo, int hi,
                                            f4 (&acc)[NB], int LNB) {
   // Software pipeline with two register buffers: the loads of group g+1 are in flight while group g feeds the
@@ -194,7 +195,7 @@ __device__ __forceinline__ void run_blocks(const f4* __restrict__ wp, const f4* 
 #ifndef ZEGGS_U
 #define ZEGGS_U 2
 #endif
-  constexpr int U = ZEGGS_U;
+  constexpr int U = UG ? UG : ZEGGS_U;
   const int n = hi - lo, ng = n / U;
   f4 w0[U], x0[U][NB], w1[U], x1[U][NB];
 #define ZLOAD(W, X, G)                                                                         \
@@ -613,8 +614,11 @@ __global__ __launch_bounds__(WAVES * 64, CH ? 4 : WAVES / 4) void stage_k(StageA
       if (lo < hi) {
         const f4* wp = (const f4*)G.seg[s].w + ((long)(G.seg[s].fixed ? 0 : tile) * (G.seg[s].tkb ? G.seg[s].tkb : kbs)) * 64 + lane;
         const f4* xp = (const f4*)G.seg[s].x + nb0 * 64 + lane;
-        if (G.seg[s].acc == 0) run_blocks<NB>(wp, xp, lo, hi, acc[0], LNB);
-        else run_blocks<NB>(wp, xp, lo, hi, acc[1], LNB);
+        // the forward stage of 49-64 rows: one k-block per buffer (two would be 80 operand registers beside 32 accumulators
+        // and the epilogue operands: 67 spilled at the 128 registers a 16-wave workgroup leaves a wave)
+        constexpr int UG = (NB == 4 && FAM == 0) ? 1 : 0;
+        if (G.seg[s].acc == 0) run_blocks<NB, UG>(wp, xp, lo, hi, acc[0], LNB);
+        else run_blocks<NB, UG>(wp, xp, lo, hi, acc[1], LNB);
       }
       base += kbs;
     }
@@ -992,6 +996,7 @@ int stage_wgs(const StageArgs& a) { return (a.g[0].tiles + a.g[1].tiles) * stage
 int launch_stage_gemv(const StageArgs& a, hipStream_t s) {
   const int wgs = a.g[0].tiles + a.g[1].tiles;
   if (a.ch_arrive) {
+#ifdef ZEGGS_CHAIN   // measurement builds only (profiles/r02_chained_launch_*): the parked weights spill 167 / 316 registers at 4 waves per SIMD
     switch (a.d.B) {
       case 1: hipLaunchKernelGGL((stage_k<1, 0, 8, 1, 1>), dim3(wgs), dim3(512), 0, s, a); break;
       case 2: hipLaunchKernelGGL((stage_k<1, 0, 8, 2, 1>), dim3(wgs), dim3(512), 0, s, a); break;
@@ -999,6 +1004,10 @@ int launch_stage_gemv(const StageArgs& a, hipStream_t s) {
     }
     ZLAUNCH_CHECK("decoder_stage_gemv_chained");
     return 0;
+#else
+    zeggs_set_error("chained stage launches are not part of this build (-DZEGGS_CHAIN)");
+    return -1;
+#endif
   }
   switch (a.d.B) {
     case 1: hipLaunchKernelGGL((stage_k<1, 0, 8, 1>), dim3(wgs), dim3(512), 0, s, a); break;

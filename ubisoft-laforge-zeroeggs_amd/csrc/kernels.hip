@@ -412,7 +412,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_fused4_k(LnBwdFused a, int row
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * j + e;
         float dv = cur.va[j][e] * dscale + cur.vb[j][e];
-        dv *= dropout_scale(a.seed_pre, (uint64_t)((size_t)rr * C + c0 + e), a.p_pre);
+        dv *= dropout_scale(a.seed_pre, (uint64_t)(rr * (unsigned)C + (unsigned)(c0 + e)), a.p_pre);      // (R C < 2^31: checked by the host)
         d[i] = dv; yv[i] = cur.vy[j][e];
         xh[i] = (cur.vx[j][e] + cur.vr[j][e] - mu) * rs;
         g[i] = dv * gam[i];
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * NW) void ln_bwd_fused4_k(LnBwdFused a, int row
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * j + e;
         const float dx = ln ? rs * (g[i] - s1 - xh[i] * s2) : d[i];
-        float o = dx * dropout_scale(a.seed_post, (uint64_t)((size_t)rr * C + c0 + e), a.p_post);
+        float o = dx * dropout_scale(a.seed_post, (uint64_t)(rr * (unsigned)C + (unsigned)(c0 + e)), a.p_post);
         if (ys) o = a.act == ACT_ELU ? o * d_elu_grad_from_out(yv[i]) : a.act == ACT_RELU ? (yv[i] > 0.f ? o : 0.f) : o;
         vraw[e] = dx; vout[e] = o;
         if (rok && cok[j]) {

@@ -131,7 +131,11 @@ __device__ __forceinline__ bool bp_wait2(const unsigned* slots, unsigned expect,
 // SKIPN: the part walks the list [0..127] + [192..255] of the operand's blocks (carry products: the n rows of DI are not theirs)
 template <int NRG, int NJ, int OFF, bool LDS, bool SKIPN = false>
 __device__ __forceinline__ void bp_mma(const float (&wr)[NWR], const float* wl, const f4* __restrict__ xb, int wave, int kb0,
-                                       int nblk, f4* acc) {
+                                       int nblk, f4* acc, long twin = 0) {
+#ifdef ZEGGS_BP_TWICE   // (timing experiment, results wrong: every part walks a SECOND operand -- the same blocks of a neighbouring time step,
+                        // other lines -- into the same accumulators: the product stream of a 64-row step without its registers / epilogues)
+  for (int rep = 0; rep < 2; ++rep, xb += twin) {
+#endif
   constexpr int GU = NRG >= 3 ? 1 : 2, NG = (NJ + GU - 1) / GU;     // operand blocks per group (matrix-core bound parts: 1)
   // the block offsets are cheap scalar arithmetic; hidden from the optimiser's loop-invariant code motion, which otherwise
   // keeps ~100 of them (one per block of every part) live across the whole time loop and spills registers for it
@@ -181,6 +185,9 @@ __device__ __forceinline__ void bp_mma(const float (&wr)[NWR], const float* wl, 
     if (g + 1 < NG) comp(xq, g + 1);
     __builtin_amdgcn_sched_barrier(0);
   }
+#ifdef ZEGGS_BP_TWICE
+  }
+#endif
 }
 
 // inputs of the root-integration backward of frame f (forward outputs and upstream gradients: old data).  NRI items per
@@ -489,6 +496,11 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
   };
 
   const long OPS = 4L * H * 32;       // floats per step of OP1 / OP0
+#ifdef ZEGGS_BP_TWICE
+#define BPTW(x) (t + 2 < T ? (long)(x) : 0L)      // the second operand of the timing build: the same part of step t + 1 (written, L2-resident)
+#else
+#define BPTW(x) 0L
+#endif
   f4 w0[1] = {f4{0.f, 0.f, 0.f, 0.f}}, w1[1] = {f4{0.f, 0.f, 0.f, 0.f}};      // window partial sums of carry0 / carry1 (see P1)
   for (int t = T - 1; t >= 1; --t) {
     const long sidx = T - 1 - t, pA = 4 * sidx, pB = pA + 1, pC = pA + 2, pD = pA + 3;
@@ -510,13 +522,13 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       // of their own in any window
       w0[0] = f4{0.f, 0.f, 0.f, 0.f};
 #ifndef ZEGGS_BP_NOWIN      // (timing experiment: the hand-off latency with empty windows; results are wrong)
-      if (t < T - 1) bp_mma<1, NJC, OC0A, false, true>(wr, nullptr, (const f4*)(a.OP0 + (long)(t + 1) * OPS) + lane, wave, 0, 96, w0);
+      if (t < T - 1) bp_mma<1, NJC, OC0A, false, true>(wr, nullptr, (const f4*)(a.OP0 + (long)(t + 1) * OPS) + lane, wave, 0, 96, w0, BPTW(OPS / 4));
 #endif
       f4 acc[1] = {w1[0]};
       wait_phase(pA - 1);
       if (fail) break;
       BPT(1);
-      bp_mma<1, NJ1, O1, false>(wr, nullptr, (const f4*)(a.OPY + (long)t * a.KBY * 512) + lane, wave, 0, a.KBY, acc);
+      bp_mma<1, NJ1, O1, false>(wr, nullptr, (const f4*)(a.OPY + (long)t * a.KBY * 512) + lane, wave, 0, a.KBY, acc, BPTW(a.KBY * 128L));
       BPT(2);
       BPS0();
       put(acc[0], 0);
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       }
       // window: carry0 += second half of W_hh0^T (.) of step t+1
 #ifndef ZEGGS_BP_NOWIN      // (timing experiment: the hand-off latency with empty windows; results are wrong)
-      if (t < T - 1) bp_mma<1, NJC, OC0B, false, true>(wr, nullptr, (const f4*)(a.OP0 + (long)(t + 1) * OPS) + lane, wave, 96, 96, w0);
+      if (t < T - 1) bp_mma<1, NJC, OC0B, false, true>(wr, nullptr, (const f4*)(a.OP0 + (long)(t + 1) * OPS) + lane, wave, 96, 96, w0, BPTW(OPS / 4));
 #endif
       f4 acc[1] = {w0[0]};
       wait_phase(pB - 1);
@@ -558,8 +570,8 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
             rv[q] = root_item(a.drpos, a.drrot, a.rrot, a.rpos, a.gaze, a.pose, a.dpose, T, PO, eb, t - 1, true, item);
         }
       }
-      bp_mma<1, NJ2A, 0, true>(wr, wl + L3A * 64, op1, wave, 0, 128, acc);
-      bp_mma<1, NJ2B, O2B, false>(wr, nullptr, op1, wave, 128, 64, acc);
+      bp_mma<1, NJ2A, 0, true>(wr, wl + L3A * 64, op1, wave, 0, 128, acc, BPTW(OPS / 4));
+      bp_mma<1, NJ2B, O2B, false>(wr, nullptr, op1, wave, 128, 64, acc, BPTW(OPS / 4));
       if (rfetch) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -587,7 +599,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       // window: carry1 += first half of W_hh1^T (DI1_t r,z | dn_h1) -- the operand is one phase old
       w1[0] = f4{0.f, 0.f, 0.f, 0.f};
 #ifndef ZEGGS_BP_NOWIN      // (timing experiment: the hand-off latency with empty windows; results are wrong)
-      bp_mma<1, NJC, OC1A, false, true>(wr, nullptr, op1, wave, 0, 96, w1);
+      bp_mma<1, NJC, OC1A, false, true>(wr, nullptr, op1, wave, 0, 96, w1, BPTW(OPS / 4));
 #endif
       if (ract && t > 1) {      // root thread: the gradient-independent half of the root backward of frame t-1 (in place)
         RootIn ri;
@@ -604,8 +616,8 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       wait_phase(pC - 1);
       if (fail) break;
       BPT(9);
-      bp_mma<3, NJA, 0, true>(wr, wl, op0, wave, 0, 128, acc);          // dhid | dXa slots 0..3 | dXa slots 4..7
-      bp_mma<3, NJB, O3B, false>(wr, nullptr, op0, wave, 128, 64, acc);
+      bp_mma<3, NJA, 0, true>(wr, wl, op0, wave, 0, 128, acc, BPTW(OPS / 4));          // dhid | dXa slots 0..3 | dXa slots 4..7
+      bp_mma<3, NJB, O3B, false>(wr, nullptr, op0, wave, 128, 64, acc, BPTW(OPS / 4));
       BPT(10);
       BPS0();
       put(acc[0], 0); put(acc[1], 4); put(acc[2], 8);
@@ -636,7 +648,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       if (t > 1 && bact && row4 >= 6 && row4 < PO) dpo = a.dpose[((long)eb * T + t - 1) * PO + row4];
       // window: carry1 += second half of W_hh1^T (DI1_t r,z | dn_h1)
 #ifndef ZEGGS_BP_NOWIN      // (timing experiment: the hand-off latency with empty windows; results are wrong)
-      bp_mma<1, NJC, OC1B, false, true>(wr, nullptr, op1, wave, 96, 96, w1);
+      bp_mma<1, NJC, OC1B, false, true>(wr, nullptr, op1, wave, 96, 96, w1, BPTW(OPS / 4));
 #endif
       f4 acc[3] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
       wait_phase(pD - 1);
@@ -644,7 +656,7 @@ __global__ __launch_bounds__(BTHR, 2) void train_bwd_persistent_k(BArgs a) {
       BPT(13);
       float spv = 0.f;                                     // workgroup 0: dXa of the root / gaze columns (other owners)
       if (c == 0 && er >= 4 && bact && (s4 < 6 || (s4 >= 8 && s4 < 11))) spv = a.SP[((long)t * NSP + (s4 < 6 ? s4 : s4 - 2)) * 32 + eb];
-      bp_mma<3, NJ4, O4, false>(wr, nullptr, (const f4*)(a.OPD + (long)t * (H * 32L)) + lane, wave, 0, 64, acc);
+      bp_mma<3, NJ4, O4, false>(wr, nullptr, (const f4*)(a.OPD + (long)t * (H * 32L)) + lane, wave, 0, 64, acc, BPTW(H * 8L));
       BPT(14);
       BPS0();
       BPQ0();
