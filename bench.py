@@ -555,8 +555,8 @@ def variants_b32(ds, dev, steps=5, warmup=2):
            "finite": bool(torch.isfinite(loss)), "algorithmic_bytes_per_step": abytes,
            "config": "FiLM decoder + GRU style encoder (VAE), batch 32 x 256, example 384: fragment-packed stage kernels"}
     pmc = None
-    if (ROOT / "profiles" / "r04_film_step_pmc.json").exists():      # counter passes of tools/pmc_variants.sh (separate runs)
-        pmc = json.load(open(ROOT / "profiles" / "r04_film_step_pmc.json"))
+    if (ROOT / "profiles" / "r06_film_step_pmc.json").exists():      # counter passes of tools/pmc_variants.sh (separate runs)
+        pmc = json.load(open(ROOT / "profiles" / "r06_film_step_pmc.json"))
     if fwd_us:
         out["roofline"] = {"bound": "hbm", "kernel": "stage_k (4 launches per FiLM decoder step and direction)",
                            "us_per_step": round(fwd_us, 2), "achieved": round(abytes / fwd_us / 1e3, 1), "peak": HBM_PEAK_GBS,
@@ -565,7 +565,7 @@ def variants_b32(ds, dev, steps=5, warmup=2):
                            "backward_frac": round(abytes / bwd_us / 1e3 / HBM_PEAK_GBS, 4) if bwd_us else None,
                            "traffic": pmc["forward"]["traffic_bytes_per_step"] if pmc else None,
                            "backward_traffic": pmc["backward"]["traffic_bytes_per_step"] if pmc else None,
-                           "traffic_source": "profiles/r04_film_step_pmc.json (FETCH_SIZE x2 + WRITE_SIZE)" if pmc else None}
+                           "traffic_source": "profiles/r06_film_step_pmc.json (FETCH_SIZE x2 + WRITE_SIZE)" if pmc else None}
     return out
 
 

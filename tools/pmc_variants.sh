@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: HBM traffic of the FiLM decoder step on the stage kernels (FETCH_SIZE / WRITE_SIZE, separate --pmc passes with
-# --kernel-trace only) -> gpurun_out/r04_film_step_pmc.json.  The style encoder is the attention one here, so that every stage_k
+# --kernel-trace only) -> gpurun_out/r06_film_step_pmc.json.  The style encoder is the attention one here, so that every stage_k
 # launch of the trace is a decoder launch.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -31,7 +31,7 @@ for name, f in (("forward", 0), ("backward", 1)):
     fb, wb = 2 * 1024 * kf / steps, 1024 * kw / steps
     out[name] = {"launches_per_step": round(nf / steps, 3), "fetch_bytes_per_step": int(fb), "write_bytes_per_step": int(wb),
                  "traffic_bytes_per_step": int(fb + wb), "traffic_over_algorithmic": round((fb + wb) / ALGO, 3)}
-json.dump(out, open("$O/r04_film_step_pmc.json", "w"), indent=1)
+json.dump(out, open("$O/r06_film_step_pmc.json", "w"), indent=1)
 print(json.dumps(out))
 PY
 rm -rf $O/vpmc_FETCH_SIZE $O/vpmc_WRITE_SIZE
