@@ -399,7 +399,9 @@ typedef struct {
   double pre_emph;      /* audio_conf.pre_emphasis ? audio_conf.pre_emph_coeff : 0 (spectrograms.py:35; round 6: the struct grew by this
                            field and the next -- zeggs_version() >= 101) */
   int flags;            /* bit 0: audio_conf.centered is FALSE (spectrograms.py:237-239); bit 1: audio_conf.normalize_range is FALSE
-                           (spectrograms.py:123-129); 0 = the shipped configuration */
+                           (spectrograms.py:123-129); bits 2-3: audio_conf.resample_method (data_pipeline.py:65-79) -- 0 "linear",
+                           4 "nearest", 8 "cubic" (not-a-knot spline over the whole signal: zeggs_mel_features only, the streaming
+                           range call refuses it); 0 = the shipped configuration */
 } ZeggsMelDims;
 long zeggs_mel_stft_frames(const ZeggsMelDims*, long n_samples); /* integer rule of spectrograms.py:242-245 */
 size_t zeggs_mel_workspace_bytes(const ZeggsMelDims*, long n_samples);

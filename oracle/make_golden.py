@@ -276,6 +276,19 @@ def gold_mel(ref):
     out3["pre_emph_coeff"] = np.float64(conf["audio_conf"]["pre_emph_coeff"])
     np.savez_compressed(GOLD / "mel_options.npz", **out3)
     print("mel_options.npz")
+    # audio_conf.resample_method = "nearest" / "cubic" (data_pipeline.py:65-79: griddata / interp1d kinds), centered and not (the
+    # uncentered table is shorter than the animation: NaN rows / extrapolated energy at the end)
+    out4 = {}
+    for name, rm, ce in (("nearest", "nearest", True), ("cubic", "cubic", True), ("unc_nearest", "nearest", False), ("unc_cubic", "cubic", False)):
+        conf["audio_conf"].update(normalize_mel_bins=True, pre_emphasis=False, real_amplitude=True, centered=ce, normalize_range=True,
+                                  resample_method=rm)
+        ac = ref.DictConfig(conf["audio_conf"])
+        for tag in "abc":
+            wav, nfr = out[f"{tag}_wav"], int(out[f"{tag}_nframes"])
+            out4[f"{tag}_wav"], out4[f"{tag}_nframes"] = wav, np.int64(nfr)
+            out4[f"{tag}_feat_{name}"] = ref.data_pipeline.preprocess_audio(wav, 60, nfr, ac, feature_type=conf["audio_feature_type"])
+    np.savez_compressed(GOLD / "mel_resample.npz", **out4)
+    print("mel_resample.npz", {k: int(np.isnan(v).sum()) for k, v in out4.items() if "feat" in k})
 
 
 def gold_anim_orders(ref):

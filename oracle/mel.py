@@ -94,24 +94,71 @@ def mel_spectrogram(wav, n_fft=800, hop=200, fs=16000, n_mels=80, fmin=20.0, fma
     return (db + rng) / rng if normalize_range else db
 
 
-def preprocess_audio(wav, n_frames, fs=16000, hop=200, fps=60.0, **kw):
-    """data_pipeline.py:33-84 with feature_type = [mel_spec, energy], linear
-    resampling, normalize_loudness = false.  -> [n_frames, 81] float32"""
+def _notaknot_second_derivatives(y):
+    """Second derivatives S_i of the cubic spline through (i, y_i), i = 0..M-1, with not-a-knot ends -- what
+    scipy.interpolate.interp1d(kind="cubic") = make_interp_spline(k=3, bc_type=None) interpolates with (reference
+    data_pipeline.py:65-79 through griddata / interp1d).  y: [M, C] float64.  Interior equations
+    S_{i-1} + 4 S_i + S_{i+1} = 6 (y_{i-1} - 2 y_i + y_{i+1}); the end conditions S_0 - 2 S_1 + S_2 = 0 (and its mirror)
+    reduce the first and last equation to S_1 = d_1, S_{M-2} = d_{M-2}; the rest is eliminated by the Thomas recurrence."""
+    M = len(y)
+    if M < 4:
+        raise ValueError("cubic interpolation needs at least 4 points")
+    d = np.zeros_like(y)
+    d[1:-1] = (y[:-2] - y[1:-1]) - (y[1:-1] - y[2:])
+    S = np.zeros_like(y)
+    S[1], S[M - 2] = d[1], d[M - 2]
+    lo, hi = 2, M - 3
+    if hi >= lo:
+        rhs = 6.0 * d[lo:hi + 1].copy()
+        rhs[0] -= S[1]
+        rhs[-1] -= S[M - 2]
+        n = hi - lo + 1
+        cp = np.zeros(n)
+        dp = np.zeros_like(rhs)
+        cp[0] = 0.25
+        dp[0] = rhs[0] / 4.0
+        for i in range(1, n):
+            den = 4.0 - cp[i - 1]
+            cp[i] = 1.0 / den
+            dp[i] = (rhs[i] - dp[i - 1]) / den
+        S[hi] = dp[-1]
+        for i in range(n - 2, -1, -1):
+            S[lo + i] = dp[i] - cp[i] * S[lo + i + 1]
+    S[0] = 2.0 * S[1] - S[2]
+    S[M - 1] = 2.0 * S[M - 2] - S[M - 3]
+    return S
+
+
+def _resample(y, t, method, extrapolate):
+    """y [M, C] float64 on the integer grid -> values at t; outside [0, M-1]: NaN (griddata) or, with `extrapolate`
+    (interp1d(fill_value="extrapolate")), the end pieces continued.  "nearest" always clamps (griddata switches its fill value to
+    "extrapolate" for that method), halves go DOWN (interp1d searches its bounds x_i + 1/2 from the left)."""
+    M = len(y)
+    if method == "nearest":
+        return y[np.clip(np.ceil(t - 0.5).astype(np.int64), 0, M - 1)]
+    lo = np.clip(np.ceil(t).astype(np.int64) - 1, 0, M - 2)
+    u = (t - lo)[:, None]
+    if method == "linear":
+        out = (y[lo + 1] - y[lo]) * u + y[lo]
+    elif method == "cubic":
+        S = _notaknot_second_derivatives(y)
+        v = 1.0 - u
+        out = y[lo] * v + y[lo + 1] * u + ((v ** 3 - v) * S[lo] + (u ** 3 - u) * S[lo + 1]) / 6.0
+    else:
+        raise ValueError(f"Unknown interpolation method {method!r} for 1 dimensional data")
+    if not extrapolate:
+        out = out.copy()
+        out[(t < 0) | (t > M - 1)] = np.nan
+    return out
+
+
+def preprocess_audio(wav, n_frames, fs=16000, hop=200, fps=60.0, resample_method="linear", **kw):
+    """data_pipeline.py:33-84 with feature_type = [mel_spec, energy], normalize_loudness = false; resample_method as
+    audio_conf.resample_method ("linear" in every shipped configuration).  -> [n_frames, 81] float32"""
     mel = mel_spectrogram(wav, hop=hop, fs=fs, **kw).T              # [M, 80]
     mel = np.log(10.0 ** (mel / 20.0))
-    M = len(mel)
     t = ((fs / hop) / fps) * np.arange(n_frames)
-    i0 = np.floor(t).astype(np.int64)
-    fr = t - i0
-    # griddata(linear) -> NaN outside the hull [0, M-1]
-    inside = (t >= 0) & (t <= M - 1)
-    i0c = np.clip(i0, 0, M - 1)
-    i1c = np.clip(i0 + 1, 0, M - 1)
-    mel_i = mel[i0c] * (1.0 - fr)[:, None] + mel[i1c] * fr[:, None]
-    mel_i[~inside] = np.nan
+    mel_i = _resample(mel, t, resample_method, extrapolate=False)      # griddata: NaN outside the hull [0, M-1]
     energy = np.linalg.norm(np.exp(mel), axis=1)                     # [M]
-    # interp1d(linear, fill_value="extrapolate")
-    j0 = np.clip(i0, 0, M - 2)
-    slope = energy[j0 + 1] - energy[j0]
-    en_i = energy[j0] + slope * (t - j0)
+    en_i = _resample(energy[:, None], t, resample_method, extrapolate=True)[:, 0]
     return np.concatenate([mel_i.astype(np.float32), en_i.astype(np.float32)[:, None]], axis=1)

@@ -746,6 +746,73 @@ def test_mel_pre_emphasis_and_raw_amplitude_vs_reference(golden_dir, mel_fft):
         ops.set_option("mel_fft", 1)
 
 
+def test_mel_resample_methods_vs_reference(golden_dir):
+    """audio_conf.resample_method = "nearest" and "cubic" (the other two kinds scipy.interpolate.griddata takes for 1-D points, reference
+    data_pipeline.py:65-79; "cubic" = not-a-knot spline over the whole table, solved on the device per column) through the drop-in
+    preprocess_audio against the reference's (mel_resample.npz), centered and uncentered (NaN rows / extrapolated energy at the end);
+    any other kind raises as griddata does; the streaming front-end takes "nearest" and refuses "cubic"."""
+    import ctypes as C
+    from zeggs import audio
+    gd = np.load(golden_dir / "mel_resample.npz")
+    base = dict(sampling_rate=16000, filter_length=800, hop_length=200, n_mel_channels=80, mel_fmin=20, mel_fmax=7600, min_clipping=1e-5,
+                pre_emph_coeff=0.97, pre_emphasis=False, real_amplitude=True, normalize_mel_bins=True, normalize_range=True,
+                normalize_loudness=False)
+    for name, rm, ce in (("nearest", "nearest", True), ("cubic", "cubic", True), ("unc_nearest", "nearest", False), ("unc_cubic", "cubic", False)):
+        conf = dict(base, resample_method=rm, centered=ce)
+        for tag in "abc":
+            wav, nfr = gd[f"{tag}_wav"], int(gd[f"{tag}_nframes"])
+            feat = audio.preprocess_audio(wav, 60, nfr, conf, ["mel_spec", "energy"])
+            ref = gd[f"{tag}_feat_{name}"]
+            np.testing.assert_array_equal(np.isnan(feat), np.isnan(ref), err_msg=f"{name} {tag}")
+            np.testing.assert_allclose(feat, ref, atol=3e-6, rtol=3e-6, equal_nan=True, err_msg=f"{name} {tag}")
+    with pytest.raises(ValueError, match="Unknown interpolation method"):
+        audio.preprocess_audio(gd["a_wav"], 60, 60, dict(base, resample_method="quadratic", centered=True), ["mel_spec", "energy"])
+    # a long table (the elimination runs in batches of eight rows: every remainder of the row count), against the oracle's recurrence
+    from oracle import mel as omel
+    for n in (16000 * 7 + 200 * r + 13 for r in range(9)):
+        wav = synth.synth_wav(n, seed=n).astype(np.float32) / 32768.0
+        nfr = audio.n_anim_frames(n)
+        feat = audio.mel_features(wav, nfr, resample_method="cubic").cpu().numpy()
+        ref = omel.preprocess_audio(wav, nfr, resample_method="cubic")
+        np.testing.assert_array_equal(np.isnan(feat), np.isnan(ref))
+        np.testing.assert_allclose(feat, ref, atol=3e-6, rtol=3e-6, equal_nan=True)
+    # streaming ranges: "nearest" equals the offline table, "cubic" is refused by the C ABI
+    L = ops.lib()
+    L.zeggs_mel_frames_ready.restype = C.c_long
+    L.zeggs_mel_range_workspace_bytes.restype = C.c_size_t
+    n = 40000
+    wav = synth.synth_wav(n, seed=23).astype(np.float32) / 32768.0
+    nfr = audio.n_anim_frames(n)
+    fb, min_clip = audio.mel_tables(800, 16000, 80, 20.0, 7600.0, 1e-5, True, True, DEV)
+    w = g(torch.as_tensor(wav))
+
+    def ranges(method):
+        d = audio.MelDims(800, 200, 80, 16000, 60.0, float(min_clip), 0.0, audio.mel_flags(True, True, method))
+        rows, k0 = [], 0
+        for got in (9000, 17000, 31000, n):
+            final = got == n
+            k1 = nfr if final else int(L.zeggs_mel_frames_ready(C.byref(d), C.c_long(got)))
+            if k1 <= k0:
+                continue
+            ws = torch.empty(int(L.zeggs_mel_range_workspace_bytes(C.byref(d), C.c_long(k0), C.c_long(k1))), dtype=torch.uint8, device=DEV)
+            out = torch.empty(k1 - k0, 81, device=DEV)
+            part = w[:got].contiguous()
+            rc = L.zeggs_mel_features_range(C.byref(d), C.c_void_p(part.data_ptr()), C.c_long(got), int(final), C.c_void_p(fb.data_ptr()),
+                                            C.c_long(k0), C.c_long(k1), C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                            C.c_size_t(ws.numel()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            if rc != 0:
+                return rc, L.zeggs_last_error().decode()
+            rows.append(out)
+            k0 = k1
+        return 0, torch.cat(rows).cpu().numpy()
+
+    rc, st = ranges("nearest")
+    assert rc == 0
+    np.testing.assert_allclose(st, audio.mel_features(wav, nfr, resample_method="nearest").cpu().numpy(), atol=1e-6, rtol=1e-6)
+    rc, msg = ranges("cubic")
+    assert rc != 0 and "WHOLE signal" in msg
+
+
 @pytest.mark.parametrize("pre,real,centered,norm", [(0.0, True, True, True), (0.97, True, True, True), (0.0, False, False, True),
                                                     (0.97, True, False, False), (0.0, True, True, False)])
 def test_mel_streaming_ranges_equal_offline_for_every_audio_option(pre, real, centered, norm):

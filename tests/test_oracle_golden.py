@@ -160,6 +160,13 @@ def test_oracle_mel_vs_reference(golden_dir):
             ref = g[f"{tag}_feat_{name}"]
             np.testing.assert_array_equal(np.isnan(feat), np.isnan(ref))
             np.testing.assert_allclose(feat, ref, rtol=2e-6, atol=1e-6, equal_nan=True, err_msg=f"{name} {tag}")
+    g = np.load(golden_dir / "mel_resample.npz")        # audio_conf.resample_method = "nearest" / "cubic" (griddata / interp1d kinds)
+    for name, rm, ce in (("nearest", "nearest", True), ("cubic", "cubic", True), ("unc_nearest", "nearest", False), ("unc_cubic", "cubic", False)):
+        for tag in "abc":
+            feat = omel.preprocess_audio(g[f"{tag}_wav"], int(g[f"{tag}_nframes"]), resample_method=rm, centered=ce)
+            ref = g[f"{tag}_feat_{name}"]
+            np.testing.assert_array_equal(np.isnan(feat), np.isnan(ref))
+            np.testing.assert_allclose(feat, ref, rtol=1e-6, atol=1e-6, equal_nan=True, err_msg=f"{name} {tag}")
     g = np.load(golden_dir / "mel_nonorm.npz")          # audio_conf.normalize_mel_bins = false
     for tag in "ab":
         feat = omel.preprocess_audio(g[f"{tag}_wav"], int(g[f"{tag}_nframes"]), normalize_mel_bins=False)

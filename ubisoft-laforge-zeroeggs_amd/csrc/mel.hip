@@ -33,6 +33,8 @@ struct MelWs {
   double* ftw;      // FFT form: [n_fft / 2 + n_fft / 2 + 1 + n_fft] complex (twiddles of the half-length transform, of the split, window)
   double* fbp;      // FFT form: the filterbank's non-zeros, band after band [MFB_CAP]
   int* bands;       // FFT form: [3 n_mels] first bin | one past the last bin | offset in fbp
+  double* spl;      // resample_method = "cubic": second derivatives of the interpolating splines [M, n_mels + 1]
+  double* cp;       //   ... and the elimination coefficients of their tridiagonal system [M]
 };
 MelWs carve_mel(const ZeggsMelDims& d, long M, Arena& a) {
   MelWs w;
@@ -43,14 +45,23 @@ MelWs carve_mel(const ZeggsMelDims& d, long M, Arena& a) {
   w.ftw = (double*)a.raw(sizeof(double) * 2 * ((size_t)2 * d.n_fft + 1));
   w.fbp = (double*)a.raw(sizeof(double) * MFB_CAP);
   w.bands = (int*)a.raw(sizeof(int) * 3 * (size_t)d.n_mels);
+  w.spl = w.cp = nullptr;
+  if (d.flags & 8) {      // MEL_CUBIC
+    w.spl = (double*)a.raw(sizeof(double) * M * (d.n_mels + 1));
+    w.cp = (double*)a.raw(sizeof(double) * M);
+  }
   return w;
 }
 
 // spectrograms.py:233-246 (integer rule)
 // ZeggsMelDims.flags: bit 0 = audio_conf.centered is FALSE (no reflect padding: frame m starts at sample m hop, spectrograms.py:237-239),
 // bit 1 = audio_conf.normalize_range is FALSE (the stored value is 20 log10 s, not mapped to [0, 1], spectrograms.py:123-129)
+// bits 2-3 = audio_conf.resample_method (data_pipeline.py:65-79: scipy.interpolate.griddata for the mel table, interp1d for the energy):
+// 0 "linear" (the shipped configurations), 4 "nearest", 8 "cubic"
 #define MEL_UNCENTERED 1
 #define MEL_RAW_RANGE 2
+#define MEL_NEAREST 4
+#define MEL_CUBIC 8
 inline long stft_frames(long n, int n_fft, int hop, int flags = 0) {
   long np = (n > n_fft ? n : n_fft) + ((flags & MEL_UNCENTERED) ? 0 : 2 * (long)(n_fft / 2));
   return (np % hop == 0) ? (np - n_fft) / hop : 1 + (np - n_fft) / hop;
@@ -462,9 +473,87 @@ __global__ __launch_bounds__(FTHR) void mel_stft_fft_k(ZeggsMelDims d, FftPlan p
   }
 }
 
-// linear resampling at t_k = ((fs/hop)/fps) k : mel -> NaN outside the hull (griddata), energy extrapolates
+// resample_method = "cubic": interp1d(kind = "cubic") = the interpolating cubic spline with not-a-knot ends (make_interp_spline(k = 3)) over
+// the integer frame grid 0 .. M-1, one per column (80 mel channels, griddata's 1-D path, + the energy).  In terms of the second derivatives
+// S_i:  S_{i-1} + 4 S_i + S_{i+1} = 6 (y_{i-1} - 2 y_i + y_{i+1}) =: r_i  (i = 1 .. M-2), and the not-a-knot conditions S_0 - 2 S_1 + S_2 = 0,
+// S_{M-3} - 2 S_{M-2} + S_{M-1} = 0 turn the first and last equation into S_1 = r_1 / 6, S_{M-2} = r_{M-2} / 6.  What is left (i = 2 .. M-3) is a
+// diagonally dominant tridiagonal system: one thread per column eliminates forward and substitutes back (the columns of a row are contiguous:
+// coalesced), eight rows per batch of loads.  float64 throughout, as scipy.
+__global__ void mel_spline_rhs_k(ZeggsMelDims d, const double* logmel, const double* energy, long M, double* S) {
+  const int W = d.n_mels + 1;
+  const long n = M * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % W);
+    const long m = i / W;
+    auto y = [&](long q) { return c < d.n_mels ? logmel[q * d.n_mels + c] : energy[q]; };
+    S[i] = (m >= 1 && m <= M - 2) ? 6.0 * ((y(m - 1) - y(m)) - (y(m) - y(m + 1))) : 0.0;
+  }
+}
+__global__ __launch_bounds__(128) void mel_spline_solve_k(ZeggsMelDims d, long M, double* S, double* cp) {
+  const int W = d.n_mels + 1, c = threadIdx.x;
+  const bool on = c < W;
+  constexpr int UB = 8;
+  double s1 = 0.0, sl = 0.0;
+  if (on) { s1 = S[1 * W + c] / 6.0; sl = S[(M - 2) * W + c] / 6.0; }
+  // forward elimination over i = 2 .. M-3 (in place: S[i] <- d'_i); cp[i] is the same for every column, stored by column 0
+  double cprev = 0.0, dprev = 0.0;
+  for (long i0 = 2; i0 <= M - 3; i0 += UB) {
+    double r[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) r[u] = (on && i0 + u <= M - 3) ? S[(i0 + u) * W + c] : 0.0;
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const long i = i0 + u;
+      if (i <= M - 3) {
+        double rhs = r[u];
+        if (i == 2) rhs -= s1;
+        if (i == M - 3) rhs -= sl;
+        const double den = (i == 2) ? 4.0 : 4.0 - cprev;
+        cprev = 1.0 / den;
+        dprev = (rhs - ((i == 2) ? 0.0 : dprev)) / den;
+        r[u] = dprev;
+        if (c == 0) cp[i] = cprev;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) if (on && i0 + u <= M - 3) S[(i0 + u) * W + c] = r[u];
+  }
+  __threadfence_block();
+  __syncthreads();
+  // back substitution: S_{M-3} = d'_{M-3}; S_i = d'_i - cp_i S_{i+1}
+  double nxt = 0.0;
+  for (long i1 = M - 3; i1 >= 2; i1 -= UB) {
+    double r[UB], q[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const long i = i1 - u;
+      r[u] = (on && i >= 2) ? S[i * W + c] : 0.0;
+      q[u] = i >= 2 ? cp[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const long i = i1 - u;
+      if (i >= 2) {
+        nxt = (i == M - 3) ? r[u] : r[u] - q[u] * nxt;
+        r[u] = nxt;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) if (on && i1 - u >= 2) S[(i1 - u) * W + c] = r[u];
+  }
+  if (on) {
+    const double s2 = M > 4 ? S[2 * W + c] : sl, sm3 = M > 4 ? S[(M - 3) * W + c] : s1;
+    S[1 * W + c] = s1; S[(M - 2) * W + c] = sl;
+    S[c] = 2.0 * s1 - s2;                        // not-a-knot: the third derivative does not jump at frames 1 and M-2
+    S[(M - 1) * W + c] = 2.0 * sl - sm3;
+  }
+}
+
+// resampling at t_k = ((fs/hop)/fps) k.  "linear" / "cubic": mel -> NaN outside the hull (griddata's fill value), the energy extrapolates
+// (interp1d(fill_value = "extrapolate"): the end pieces continue); "nearest": both take the nearest frame, halves round DOWN, ends clamp
+// (interp1d's bounds x_i + 1/2 searched from the left; griddata sets fill_value = "extrapolate" for this method).
 // animation frames k0 .. k0 + n_frames - 1; logmel / energy hold the STFT frames m0 .. (indices relative to m0)
-__global__ void mel_resample_k(ZeggsMelDims d, const double* logmel, const double* energy, long M, long m0, long k0,
+__global__ void mel_resample_k(ZeggsMelDims d, const double* logmel, const double* energy, const double* spl, long M, long m0, long k0,
                                int n_frames, float* out) {
   const int W = d.n_mels + 1;
   const long n = (long)n_frames * W;
@@ -474,17 +563,23 @@ __global__ void mel_resample_k(ZeggsMelDims d, const double* logmel, const doubl
     const int c = (int)(i % W);
     const long k = k0 + i / W;
     const double t = (((double)d.fs / (double)d.hop) / (double)d.fps) * (double)k;
+    if (d.flags & MEL_NEAREST) {
+      long q = (long)ceil(t - 0.5);
+      q = q < 0 ? 0 : q > M - 1 ? M - 1 : q;
+      out[i] = (float)(c < d.n_mels ? logmel[q * d.n_mels + c] : energy[q]);
+      continue;
+    }
     long hi = (long)ceil(t);            // searchsorted(side=left) over the integer grid
     if (hi < 1) hi = 1;
     if (hi > M - 1) hi = M - 1;
     const long lo = hi - 1;
     if (M < 2) { out[i] = nanf(""); continue; }
-    if (c < d.n_mels) {
-      if (t < 0.0 || t > (double)(M - 1)) { out[i] = nanf(""); continue; }
-      const double ylo = logmel[lo * d.n_mels + c], yhi = logmel[hi * d.n_mels + c];
-      out[i] = (float)((yhi - ylo) * (t - (double)lo) + ylo);
+    if (c < d.n_mels && (t < 0.0 || t > (double)(M - 1))) { out[i] = nanf(""); continue; }
+    const double ylo = c < d.n_mels ? logmel[lo * d.n_mels + c] : energy[lo], yhi = c < d.n_mels ? logmel[hi * d.n_mels + c] : energy[hi];
+    if (d.flags & MEL_CUBIC) {
+      const double u = t - (double)lo, v = 1.0 - u;
+      out[i] = (float)(ylo * v + yhi * u + ((v * v * v - v) * spl[lo * W + c] + (u * u * u - u) * spl[hi * W + c]) / 6.0);
     } else {
-      const double ylo = energy[lo], yhi = energy[hi];
       out[i] = (float)((yhi - ylo) * (t - (double)lo) + ylo);
     }
   }
@@ -577,7 +672,15 @@ extern "C" int zeggs_mel_features(const ZeggsMelDims* dp, const float* wav, long
   ZTRY(launch_stft(d, w, wav, n_samples, n_samples, filterbank, 0L, M, s));
   if (n_frames > 0) {
     long n = (long)n_frames * (d.n_mels + 1), g = (n + 255) / 256;
-    hipLaunchKernelGGL(mel_resample_k, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, d, w.logmel, w.energy, M,
+    if (d.flags & MEL_CUBIC) {
+      ZCHECK(M >= 4, "mel: resample_method \"cubic\" needs at least 4 STFT frames (got %ld)", M);      // (scipy raises the same way)
+      ZCHECK(d.n_mels + 1 <= 128, "mel: resample_method \"cubic\" supports up to 127 mel channels");
+      const long nn = M * (d.n_mels + 1), gg = (nn + 255) / 256;
+      hipLaunchKernelGGL(mel_spline_rhs_k, dim3((unsigned)(gg > 4096 ? 4096 : gg)), dim3(256), 0, s, d, w.logmel, w.energy, M, w.spl);
+      hipLaunchKernelGGL(mel_spline_solve_k, dim3(1), dim3(128), 0, s, d, M, w.spl, w.cp);
+      ZLAUNCH_CHECK("mel_spline");
+    }
+    hipLaunchKernelGGL(mel_resample_k, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, d, w.logmel, w.energy, w.spl, M,
                        0L, 0L, n_frames, out);
     ZLAUNCH_CHECK("mel_resample");
   }
@@ -612,6 +715,7 @@ extern "C" int zeggs_mel_features_range(const ZeggsMelDims* dp, const float* wav
   hipStream_t s = (hipStream_t)stream;
   ZCHECK(d.n_fft >= 2 && d.n_fft % 2 == 0 && d.hop > 0 && d.n_mels > 0, "mel: bad dims");
   ZCHECK(n_samples > 0 && k0 >= 0 && k1 > k0, "mel range: empty input");
+  ZCHECK(!(d.flags & MEL_CUBIC), "mel range: resample_method \"cubic\" is a spline over the WHOLE signal -- use zeggs_mel_features");
   if (!final) ZCHECK(k1 <= zeggs_mel_frames_ready(dp, n_samples), "mel range: frames %ld..%ld need samples not received yet", k0, k1);
   const long M = final ? stft_frames(n_samples, d.n_fft, d.hop, d.flags) : (1L << 40);
   const double r = ((double)d.fs / (double)d.hop) / (double)d.fps;
@@ -625,7 +729,7 @@ extern "C" int zeggs_mel_features_range(const ZeggsMelDims* dp, const float* wav
   ZCHECK(a.ok(), "mel range: workspace too small (%zu < %zu)", ws_bytes, a.off);
   ZTRY(launch_stft(d, w, wav, final ? n_samples : (1L << 50), n_samples, filterbank, m0, m1 - m0, s));
   const long n = (k1 - k0) * (d.n_mels + 1), g = (n + 255) / 256;
-  hipLaunchKernelGGL(mel_resample_k, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, d, w.logmel, w.energy, M, m0, k0,
+  hipLaunchKernelGGL(mel_resample_k, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, d, w.logmel, w.energy, nullptr, M, m0, k0,
                      (int)(k1 - k0), out);
   ZLAUNCH_CHECK("mel_resample");
   return 0;

@@ -18,9 +18,15 @@ class MelDims(C.Structure):
                 ("min_clip", C.c_float), ("pre_emph", C.c_double), ("flags", C.c_int)]
 
 
-def mel_flags(centered=True, normalize_range=True):
-    """ZeggsMelDims.flags: bit 0 = NOT centered, bit 1 = NOT normalize_range"""
-    return (0 if centered else 1) | (0 if normalize_range else 2)
+RESAMPLE_FLAGS = {"linear": 0, "nearest": 4, "cubic": 8}
+
+
+def mel_flags(centered=True, normalize_range=True, resample_method="linear"):
+    """ZeggsMelDims.flags: bit 0 = NOT centered, bit 1 = NOT normalize_range, bits 2-3 = resample_method (the three kinds
+    scipy.interpolate.griddata takes for 1-D points, reference data_pipeline.py:65-70)"""
+    if resample_method not in RESAMPLE_FLAGS:
+        raise ValueError(f"Unknown interpolation method {resample_method!r} for 1 dimensional data")      # (griddata's own message)
+    return (0 if centered else 1) | (0 if normalize_range else 2) | RESAMPLE_FLAGS[resample_method]
 
 
 def n_anim_frames(n_samples, fs=16000, fps=60.0):
@@ -72,13 +78,13 @@ def mel_tables(n_fft, fs, n_mels, fmin, fmax, min_clip, normalize_mel_bins=True,
 
 def mel_features(wav, n_frames, n_fft=800, hop=200, n_mels=80, fs=16000, fps=60.0, fmin=20.0, fmax=7600.0,
                  min_clip=1e-5, normalize_mel_bins=True, device="cuda", pre_emph=0.0, real_amplitude=True, centered=True,
-                 normalize_range=True):
+                 normalize_range=True, resample_method="linear"):
     """wav: float array/tensor [n] -> torch float32 [n_frames, n_mels + 1] on `device` (HIP kernel)."""
     dev = torch.device(device)
     fb, min_clip = mel_tables(n_fft, fs, n_mels, fmin, fmax, min_clip, normalize_mel_bins, real_amplitude, dev)
     w = torch.as_tensor(np.asarray(wav, dtype=np.float32) if not torch.is_tensor(wav) else wav,
                         dtype=torch.float32).to(dev).contiguous()
-    d = MelDims(n_fft, hop, n_mels, fs, float(fps), float(min_clip), float(pre_emph), mel_flags(centered, normalize_range))
+    d = MelDims(n_fft, hop, n_mels, fs, float(fps), float(min_clip), float(pre_emph), mel_flags(centered, normalize_range, resample_method))
     L = ops.lib()
     L.zeggs_mel_workspace_bytes.restype = C.c_size_t
     ws = torch.empty(int(L.zeggs_mel_workspace_bytes(C.byref(d), C.c_long(w.numel()))), dtype=torch.uint8, device=dev)
@@ -249,14 +255,12 @@ def preprocess_audio_device(audio_data, anim_fs, anim_length, params, feature_ty
             audio_data, _ = normalize_loudness_device(audio_data, g("sampling_rate"), -20.0, device)   # no host pass
         else:
             audio_data = normalize_loudness(audio_data, g("sampling_rate"), -20.0)
-    if g("resample_method") != "linear":
-        raise NotImplementedError("resample_method must be 'linear' (the shipped conf)")
     feat = mel_features(audio_data, anim_length, n_fft=g("filter_length"), hop=g("hop_length"),
                         n_mels=g("n_mel_channels"), fs=g("sampling_rate"), fps=float(anim_fs), fmin=g("mel_fmin"),
                         fmax=g("mel_fmax"), min_clip=g("min_clipping"), normalize_mel_bins=g("normalize_mel_bins"),
                         device=device, pre_emph=float(g("pre_emph_coeff")) if g("pre_emphasis") else 0.0,
                         real_amplitude=bool(g("real_amplitude")), centered=bool(g("centered")),
-                        normalize_range=bool(g("normalize_range")))
+                        normalize_range=bool(g("normalize_range")), resample_method=g("resample_method"))
     cols = []
     if "mel_spec" in feature_type:
         cols.append(feat[:, :-1])

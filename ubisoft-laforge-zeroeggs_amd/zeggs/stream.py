@@ -38,6 +38,8 @@ class GestureStream:
             raise ValueError("loudness normalisation needs the whole signal: apply audio.normalize_loudness() first")
         if tuple(feature_type) != ("mel_spec", "energy"):
             raise NotImplementedError("streaming supports the shipped feature set [mel_spec, energy]")
+        if g.get("resample_method", "linear") == "cubic":
+            raise ValueError("resample_method 'cubic' is a spline over the whole signal: not available while the signal is still arriving")
         self.dev = torch.device(device)
         self.speech_net, self.decoder = speech_net.eval(), decoder.eval()
         self.stats = {k: v.to(self.dev, torch.float32) for k, v in stats.items()}
@@ -46,7 +48,7 @@ class GestureStream:
                                              g["min_clipping"], g["normalize_mel_bins"], g.get("real_amplitude", True), self.dev)
         self.mel = audio.MelDims(g["filter_length"], g["hop_length"], g["n_mel_channels"], self.fs, self.fps, float(min_clip),
                                  float(g.get("pre_emph_coeff", 0.97)) if g.get("pre_emphasis") else 0.0,
-                                 audio.mel_flags(g.get("centered", True), g.get("normalize_range", True)))
+                                 audio.mel_flags(g.get("centered", True), g.get("normalize_range", True), g.get("resample_method", "linear")))
         f32 = lambda a: a[0:1].to(self.dev, torch.float32).contiguous()  # noqa: E731
         root_pos, root_rot, root_vel, root_vrt, lpos, lrot, ltxy, lvel, lvrt = first_pose[:9]
         self.gaze = f32(first_pose[14])                                   # [1, 3] constant gaze target

@@ -235,7 +235,7 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
             if scalars is not None:
                 scalars.add(iteration, loss, eng.last_terms)
             if rank == 0 and iteration % 50 == 0:
-                sys.stdout.write(f"\r| epoch {epoch} | it {iteration} | batch {bi}/{nb} | loss {float(loss):.4f} "
+                sys.stdout.write(f"\r| epoch {epoch} | it {iteration} | batch {bi}/{nb} | loss {float(loss.detach()):.4f} "
                                  f"| {datetime.datetime.now() - start} |")
             if rank == 0 and checkpoint:
                 snap = [compact_copy(m) if m is not None else None for m in (se, de, st)]
