@@ -25,8 +25,12 @@ def _run(st, x, eps, w, fused, dropout):
     return [t.detach().clone() for t in (z, mu, lv)], {k: p.grad.detach().clone() for k, p in st.named_parameters()}
 
 
+@pytest.mark.parametrize("one_launch", [1, 0])
 @pytest.mark.parametrize("L,dropout", [(384, True), (77, True), (200, False), (33, False), (512, True)])
-def test_fused_attention_matches_the_gemm_softmax_path(L, dropout):
+def test_fused_attention_matches_the_gemm_softmax_path(L, dropout, one_launch):
+    """one_launch = 1 (default since round 6): the dQ and the dK / dV pass as ONE grid (blockIdx.z = pass; the dK / dV workgroups
+    form rowsum(dO . O) themselves); 0: two launches, the second reading what the first stored."""
+    ops.set_option("attn_bwd_one_launch", one_launch)
     _, _, st = helpers.build_nets()
     st = st.to(DEV)
     g = torch.Generator().manual_seed(L)
@@ -39,6 +43,7 @@ def test_fused_attention_matches_the_gemm_softmax_path(L, dropout):
         out0, g0 = _run(st, x, eps, w, 0, dropout)
     finally:
         ops.set_option("fused_attention", 1)
+        ops.set_option("attn_bwd_one_launch", 1)
     for a, b in zip(out1, out0):
         assert torch.isfinite(a).all()
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))

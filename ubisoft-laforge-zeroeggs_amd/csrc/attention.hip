@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(AttnArgs a) {
 
 // ------------------------------------------------------------------ backward: dQ (and dsum = rowsum(dO . O))
 template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_q_k(AttnArgs a) {
+__device__ __forceinline__ void attn_bwd_q_body(const AttnArgs& a) {
   __shared__ float Ks[2][32 * LD], Vs[2][32 * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.NH, h = bh % a.NH, L = a.L;
@@ -231,14 +231,17 @@ __global__ __launch_bounds__(256) void attn_bwd_q_k(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
-template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_kv_k(AttnArgs a) {
+// OWN: the workgroup forms rowsum(dO . O) of every query tile itself (one more float4 per thread and tile, a dot product over the eight
+// threads of a row) instead of reading what the dQ pass stored -- the two passes are then independent of each other (attn_bwd_k)
+template <bool DROP, bool OWN>
+__device__ __forceinline__ void attn_bwd_kv_body(const AttnArgs& a) {
   __shared__ float Qs[2][32 * LD], Gs[2][32 * LD], ls[2][32], dsm[2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.NH, h = bh % a.NH, L = a.L;
   const long ld = 3L * a.E;
   const float* base = a.qkv + (long)b * L * ld + h * HD;
   const float* dOb = a.dO + (long)b * L * a.E + h * HD;
+  const float* Ob = a.O + (long)b * L * a.E + h * HD;
   const int mykey = blockIdx.x * WQ + wave * 32 + l31, ck = mykey < L ? mykey : L - 1;
   const float qmul = a.scale * LOG2E;
   auto fetch_stats = [&](int q0, float& l, float& d) {
@@ -246,12 +249,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_k(AttnArgs a) {
       const int q = q0 + tid;
       const int qc = q < L ? q : L - 1;
       l = q < L ? a.lse[(long)bh * L + qc] : INFINITY;           // queries beyond L: probability 2^(-inf) = 0
-      d = a.dsum[(long)bh * L + qc];
+      if constexpr (!OWN) d = a.dsum[(long)bh * L + qc];
     }
   };
+  auto own_dsum = [&](int q0, const f4& g) {      // thread (row tid >> 3, quarter tid & 7) -> the row's sum in the quarter-0 thread
+    const f4 o = tile_fetch(Ob, a.E, q0, L, tid);
+    float v = g[0] * o[0] + g[1] * o[1] + g[2] * o[2] + g[3] * o[3];
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+  };
   f4 qn = tile_fetch(base, ld, 0, L, tid), gn = tile_fetch(dOb, a.E, 0, L, tid);
-  float ln = 0.f, dn = 0.f;
+  float ln = 0.f, dn = 0.f, dno = 0.f;
   fetch_stats(0, ln, dn);
+  if constexpr (OWN) dno = own_dsum(0, gn);
   float kf[16], vf[16];
   load_row_slots(kf, base + a.E, ld, ck, 1.f, kh);
   load_row_slots(vf, base + 2 * a.E, ld, ck, 1.f, kh);
@@ -260,7 +270,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_k(AttnArgs a) {
   for (int r = 0; r < 16; ++r) { dkT[r] = 0.f; dvT[r] = 0.f; }
   tile_put(Qs[0], qn, qmul, tid);
   tile_put(Gs[0], gn, 1.f, tid);
-  if (tid < 32) { ls[0][tid] = ln; dsm[0][tid] = dn; }
+  if (tid < 32) { ls[0][tid] = ln; if constexpr (!OWN) dsm[0][tid] = dn; }
+  if constexpr (OWN) { if ((tid & 7) == 0) dsm[0][tid >> 3] = dno; }
   __syncthreads();
   const uint32_t koff = (uint32_t)mykey + (uint32_t)(4 * kh) * (uint32_t)L;      // this lane's share of the element index
   const HKey hkey = hash_key(a.seed);
@@ -272,6 +283,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_k(AttnArgs a) {
       qn = tile_fetch(base, ld, q0 + 32, L, tid);
       gn = tile_fetch(dOb, a.E, q0 + 32, L, tid);
       fetch_stats(q0 + 32, ln, dn);
+      if constexpr (OWN) dno = own_dsum(q0 + 32, gn);
     }
     const float* Q = Qs[cur];
     const float* G = Gs[cur];
@@ -305,7 +317,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_k(AttnArgs a) {
     if (t + 1 < nt) {
       tile_put(Qs[cur ^ 1], qn, qmul, tid);
       tile_put(Gs[cur ^ 1], gn, 1.f, tid);
-      if (tid < 32) { ls[cur ^ 1][tid] = ln; dsm[cur ^ 1][tid] = dn; }
+      if (tid < 32) { ls[cur ^ 1][tid] = ln; if constexpr (!OWN) dsm[cur ^ 1][tid] = dn; }
+      if constexpr (OWN) { if ((tid & 7) == 0) dsm[cur ^ 1][tid >> 3] = dno; }
     }
     __syncthreads();
   }
@@ -328,8 +341,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_k(AttnArgs a) {
   }
 }
 
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_q_k(AttnArgs a) { attn_bwd_q_body<DROP>(a); }
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_kv_k(AttnArgs a) { attn_bwd_kv_body<DROP, false>(a); }
+// Round 6: both passes as ONE launch (blockIdx.z = pass).  Each pass alone is 384 workgroups of four waves at two waves per SIMD: 1 536
+// wave-tasks on 1 024 SIMDs, so half of the CUs hold two workgroups, run them at half speed each, and the pass lasts two workgroup-times
+// (profiles/r06_attention_backward_pipelining.txt); two passes = four.  768 workgroups in one grid fill 512 slots and hand the freed ones
+// to the rest: three workgroup-times.  The dQ workgroups come first in the dispatch order (z = 0).
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_k(AttnArgs a) {
+  if (blockIdx.z == 0) attn_bwd_q_body<DROP>(a);
+  else attn_bwd_kv_body<DROP, true>(a);
+}
+
 }  // namespace
 
+int g_attn_bwd_one_launch = 1;  // zeggs_set_option("attn_bwd_one_launch", 0/1): A/B switch of the merged backward launch
 int g_fused_attention = 1;      // zeggs_set_option("fused_attention", 0/1); 0 = GEMM + softmax + GEMM over [B*heads, L, L] matrices
 
 int attn_fused_supported(int E, int NH) { return g_fused_attention && NH > 0 && E % NH == 0 && E / NH == HD && E % 4 == 0; }
@@ -349,6 +377,12 @@ int k_attn_bwd(const float* qkv, const float* O, const float* lse, const float* 
   memset(&a, 0, sizeof(a));
   a.qkv = qkv; a.O = (float*)O; a.lse = (float*)lse; a.dO = dO; a.dqkv = dqkv; a.dsum = dsum; a.dbias = dbias;
   a.L = L; a.E = E; a.NH = NH; a.scale = 1.0f / sqrtf((float)HD); a.p = p; a.seed = seed;
+  if (g_attn_bwd_one_launch) {
+    if (p > 0.f) hipLaunchKernelGGL(attn_bwd_k<true>, dim3(cdiv(L, WQ), B * NH, 2), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(attn_bwd_k<false>, dim3(cdiv(L, WQ), B * NH, 2), dim3(256), 0, s, a);
+    ZLAUNCH_CHECK("attn_bwd");
+    return 0;
+  }
   if (p > 0.f) hipLaunchKernelGGL(attn_bwd_q_k<true>, dim3(cdiv(L, WQ), B * NH), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(attn_bwd_q_k<false>, dim3(cdiv(L, WQ), B * NH), dim3(256), 0, s, a);
   ZLAUNCH_CHECK("attn_bwd_q");

@@ -46,7 +46,9 @@ extern int g_mel_mfma;
 extern int g_mel_fft;
 extern int g_ln_bwd4;
 extern int g_mel_exact_log;
+extern int g_attn_bwd_one_launch;
 extern "C" int zeggs_set_option(const char* name, int value) {
+  if (strcmp(name, "attn_bwd_one_launch") == 0) { g_attn_bwd_one_launch = value != 0; return 0; }
   if (strcmp(name, "decoder_fast") == 0) { g_decoder_fast = value; return 0; }
   if (strcmp(name, "stage_variant") == 0) { g_stage_variant = value; return 0; }
   if (strcmp(name, "gemm_wg_target") == 0) { g_gemm_wg_target = value; return 0; }
