@@ -767,6 +767,8 @@ def test_mel_resample_methods_vs_reference(golden_dir):
             np.testing.assert_allclose(feat, ref, atol=3e-6, rtol=3e-6, equal_nan=True, err_msg=f"{name} {tag}")
     with pytest.raises(ValueError, match="Unknown interpolation method"):
         audio.preprocess_audio(gd["a_wav"], 60, 60, dict(base, resample_method="quadratic", centered=True), ["mel_spec", "energy"])
+    with pytest.raises(RuntimeError, match="at least 4 STFT frames"):      # (scipy's interp1d raises for fewer points than the order needs, too)
+        audio.mel_features(gd["a_wav"][:1300], 4, centered=False, resample_method="cubic")
     # a long table (the elimination runs in batches of eight rows: every remainder of the row count), against the oracle's recurrence
     from oracle import mel as omel
     for n in (16000 * 7 + 200 * r + 13 for r in range(9)):
