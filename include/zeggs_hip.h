@@ -47,7 +47,12 @@ const char* zeggs_last_error(void);
  * whole register file of its SIMDs, so that no wave of another stream becomes resident beside it (2: big products only) -- what a
  * caller that runs several streams beside each other should pick (zeggs.engine.TrainEngine: 1, depth 8), "gemm_direct_reserve" n =
  * CUs that variant's grids leave out (for a collective's resident workgroups in data-parallel runs); "ln_bwd4" 0 / 1 = the 16-byte-lane LayerNorm-backward pass; "mel_exact_log" 1 = the literal log / pow chain of
- * data_pipeline.py:62-63 instead of the affine map */
+ * data_pipeline.py:62-63 instead of the affine map;
+ * round 6 (A/B switches and experiments, each measured in profiles/r06_*): "tp_dual" 0 (default) / 1 = the forward sweep as two 16-row
+ * dependency chains in one launch; "gemm_split_bf16" 0 (default) / 6 / 9 = the TN products on the bf16 matrix cores through an fp32-exact
+ * three-plane split; "attn_bwd_one_launch" 1 (default) / 0 = the attention backward's two passes as one grid / two launches; "loss_lds"
+ * 1 (default) / 0 = the loss tree walk's level messages through LDS / through the tables; "wgrad_order"; "chain" = refused (-1) unless the
+ * library was built with -DZEGGS_CHAIN (measurement builds) */
 int zeggs_set_option(const char* name, int value);
 /* elapsed ms of the last recorded stage sweep: which = 0 forward (T-1 steps x 3 launches), 1 backward; blocks on
  * the end event.  Measurement hook of bench.py (roofline figures); there is no reference counterpart. */
