@@ -148,6 +148,11 @@ int zeggs_style_encoder_bwd(const ZeggsStyleDims*, const ZeggsStyleParams*, cons
                             const ZeggsStyleGrads*, void* ws, size_t ws_bytes, void* stream);
 int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* dout,
                                const ZeggsStyleGrads*, void* ws, size_t ws_bytes, void* stream, int grads_zeroed);
+/* part 1 = the chain of the backward (everything but the six weight-gradient products), 2 = those products (on `stream`; they read what
+ * part 1 left in the workspace, not `dout`), 3 = both interleaved (= zeggs_style_encoder_bwd_ex).  For callers with a second queue: part 1 on
+ * the caller's stream, part 2 on the other one behind it, join before the optimizer (round 6; zeggs/engine.py: defer_style_wgrads). */
+int zeggs_style_encoder_bwd_part(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* dout, const ZeggsStyleGrads*, void* ws,
+                                 size_t ws_bytes, void* stream, int grads_zeroed, int part);
 /* style_encoder.type "gru": replaces StyleEncoderGRU.forward, ZEGGS/modules.py:307-343 (conv3+ReLU x2, one
  * bidirectional GRU layer, projection of the last time step) and its backward.  x [B,L,C] -> out [B,O]. */
 typedef struct {

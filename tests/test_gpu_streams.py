@@ -55,6 +55,19 @@ def test_side_streams_give_the_single_stream_weights():
     assert np.abs(p1 - p2).max() <= 2e-6
 
 
+def test_deferred_style_weight_gradients_give_the_same_weights():
+    """defer_style_wgrads (off by default: measured slower): the style encoder's backward enqueues its chain only
+    (zeggs_style_encoder_bwd_part, part 1) and the engine runs the six weight-gradient products (part 2) on the third queue behind
+    it -- the operands are parked in buffers of their own -- and joins before the optimizer: the weights of the inline schedule."""
+    kw = dict(steps=3, B=8, T=64, L=128, clip=400)
+    p1, l1 = _run(True, defer_style_wgrads=True, **kw)
+    assert _run.last_engine.defer_style_wgrads and not _run.last_engine.ctx.deferred_wgrads
+    p0, l0 = _run(True, defer_style_wgrads=False, **kw)
+    assert np.isfinite(p1).all() and np.isfinite(l1).all()
+    assert np.abs(p1 - p0).max() <= 2e-6, np.abs(p1 - p0).max()
+    assert np.allclose(l1, l0, rtol=1e-5, atol=1e-6), (l1, l0)
+
+
 @pytest.mark.parametrize("how", ["flat", "param"])
 def test_packs_made_ahead_are_not_used_after_the_weights_were_edited(how):
     """prepare_ahead: the next step's weight-only packs are made right behind the optimizer.  An in-place torch edit of the weights

@@ -161,6 +161,7 @@ struct StyleWs {
   float *xp, *c1, *m1, *r1, *a1p, *c2, *m2, *r2, *h, *qkv, *P, *Pd, *O, *ao, *ma, *ra, *ap, *f1p, *f2, *mf, *rf, *f;
   // scratch (backward)
   float *S, *t0, *t1, *t2, *t3, *dqkv, *dwf;
+  float *t0a, *t0b, *t1a;      // the weight-gradient products' own copies of df2 / df1 / dao (they may run after the chain: bwd_part)
   // fused attention (attention.hip): row log-sum-exp (saved) and rowsum(dO . O) (backward scratch) instead of S / P / Pd
   float *lse, *dsum;
   int fused;
@@ -209,6 +210,7 @@ StyleWs carve_style(const ZeggsStyleDims& d, Arena& a) {
   w.t0 = a.f(B * LP * HE); w.t1 = a.f(big); w.t2 = a.f(big); w.t3 = a.f(B * LP * HE);
   w.dqkv = a.f(BL * 3 * E);
   w.dwf = a.f(3L * dw);
+  w.t0a = a.f(B * LP * E); w.t0b = a.f(B * LP * E); w.t1a = a.f(BL * E);
   return w;
 }
 
@@ -347,6 +349,19 @@ extern "C" int zeggs_style_encoder_bwd(const ZeggsStyleDims* dp, const ZeggsStyl
 }
 extern "C" int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims* dp, const ZeggsStyleParams* P, const float* dout,
                                           const ZeggsStyleGrads* G, void* ws, size_t ws_bytes, void* stream, int grads_zeroed) {
+  return zeggs_style_encoder_bwd_part(dp, P, dout, G, ws, ws_bytes, stream, grads_zeroed, 3);
+}
+// part: 1 = the CHAIN (input gradients, LayerNorm / activation passes, attention, bias and LayerNorm-parameter gradients),
+// 2 = the six WEIGHT-GRADIENT products (ff2, ff0, out-proj, in-proj, conv c4, conv c0) with their packs, 3 = both, each product right
+// behind the pass that makes its operand (what zeggs_style_encoder_bwd_ex does).  The products are chip-filling matrix work nothing in the
+// chain waits for, while the chain is ~25 small dependent launches: a training loop with a second queue calls part 1 on the caller's
+// stream and part 2 on the other one BEHIND it (the operands of the products -- df2, df1, dao -- are kept in buffers of their own for
+// that; part 2 reads `dout` not at all), and joins before the optimizer (zeggs/engine.py: defer_style_wgrads).
+extern "C" int zeggs_style_encoder_bwd_part(const ZeggsStyleDims* dp, const ZeggsStyleParams* P, const float* dout,
+                                            const ZeggsStyleGrads* G, void* ws, size_t ws_bytes, void* stream, int grads_zeroed,
+                                            int part) {
+  ZCHECK(part >= 1 && part <= 3, "style encoder bwd: part must be 1, 2 or 3");
+  const bool chain = part & 1, inl = part == 3, only_w = part == 2;
   const ZeggsStyleDims& d = *dp;
   const float gb = grads_zeroed ? 1.f : 0.f;      // (see zeggs_speech_encoder_bwd_ex)
   hipStream_t s = (hipStream_t)stream;
@@ -360,6 +375,31 @@ extern "C" int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims* dp, const ZeggsS
   // The elementwise work between the products is four passes, each fused around a LayerNorm backward (k_ln_bwd_fused): the
   // chain is the critical path of the iteration's tail, beside the decoder's weight-gradient GEMMs on the other stream, and every
   // separate small pass (pool, copy, mask, ReLU', bias sum, pad) waited for CU slots there.
+  float *t0a = w.t0a, *t0b = w.t0b, *t1a = w.t1a;
+  // the six products (each with the pack of its result); `q` = the stream they are launched on
+  auto dw_ff2 = [&](hipStream_t q) -> int {
+    ZTRY(conv_dw_gemm(w.f1p, (long)LP * E, E, t0a + E, E, (long)LP * E, w.dwf, 3 * E, E, B, L, q));
+    return k_unpack_conv_dw(G->ff2_w, w.dwf, E, E, 3, q);
+  };
+  auto dw_ff0 = [&](hipStream_t q) -> int {
+    ZTRY(conv_dw_gemm(w.ap, (long)LP * E, E, t0b + E, E, (long)LP * E, w.dwf, 3 * E, E, B, L, q));
+    return k_unpack_conv_dw(G->ff0_w, w.dwf, E, E, 3, q);
+  };
+  auto dw_out = [&](hipStream_t q) -> int { return gemm_tn(t1a, E, w.O, E, G->out_w, E, (int)BL, E, E, gb, q); };
+  auto dw_in = [&](hipStream_t q) -> int { return gemm_tn(w.dqkv, 3 * E, w.h, E, G->in_w, E, (int)BL, 3 * E, E, gb, q); };
+  auto dw_c4 = [&](hipStream_t q) -> int {
+    ZTRY(conv_dw_gemm(w.a1p, (long)LP * H, H, t0 + E, E, (long)LP * E, w.dwf, 3 * H, E, B, L, q));
+    return k_unpack_conv_dw(G->c4_w, w.dwf, E, H, 3, q);
+  };
+  auto dw_c0 = [&](hipStream_t q) -> int {
+    ZTRY(conv_dw_gemm(w.xp, (long)LP * C, C, t2, H, (long)L * H, w.dwf, 3 * C, H, B, L, q));
+    return k_unpack_conv_dw(G->c0_w, w.dwf, H, C, 3, q);
+  };
+  if (only_w) {
+    ZTRY(dw_ff2(s)); ZTRY(dw_ff0(s)); ZTRY(dw_out(s)); ZTRY(dw_in(s)); ZTRY(dw_c4(s)); ZTRY(dw_c0(s));
+    return 0;
+  }
+  (void)chain;
   if (!grads_zeroed) {
     ZTRY(k_fill(G->lnf_g, E, 0.f, s)); ZTRY(k_fill(G->lnf_b, E, 0.f, s)); ZTRY(k_fill(G->ff2_b, E, 0.f, s));
     ZTRY(k_fill(G->ff0_b, E, 0.f, s)); ZTRY(k_fill(G->lna_g, E, 0.f, s)); ZTRY(k_fill(G->lna_b, E, 0.f, s));
@@ -369,6 +409,7 @@ extern "C" int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims* dp, const ZeggsS
     if (w.fused) ZTRY(k_fill(G->in_b, 3 * E, 0.f, s));
   }
   const RowView t0in = rv(t0 + E, L, (long)LP * E);      // interior of the padded [B, LP, E] buffer the input-gradient convs read
+  const RowView t0ain = rv(t0a + E, L, (long)LP * E), t0bin = rv(t0b + E, L, (long)LP * E);
   // ---- mean pool, final LN (f = LN(f2 + a)), the mask of ff2's output: t2 = d(f2 + a) (the residual branch keeps it),
   //      t0 interior = df2 = t2 * mask, ff2_b += column sums
   {
@@ -376,32 +417,30 @@ extern "C" int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims* dp, const ZeggsS
     q.dy_pool = dout; q.pool_L = L;
     q.x = rv(w.f2); q.res = rv(w.ap + E, L, (long)LP * E); q.gamma = P->lnf_g; q.mean = w.mf; q.rstd = w.rf;
     q.dgamma = G->lnf_g; q.dbeta = G->lnf_b;
-    q.dx_raw = rv(t2); q.out = t0in; q.pad_L = L; q.p_post = p1; q.seed_post = d.seed + 5; q.dbias = G->ff2_b;
+    q.dx_raw = rv(t2); q.out = t0ain; q.pad_L = L; q.p_post = p1; q.seed_post = d.seed + 5; q.dbias = G->ff2_b;
     ZTRY(k_ln_bwd_fused(q, s));
   }
-  ZTRY(conv_dw_gemm(w.f1p, (long)LP * E, E, t0 + E, E, (long)LP * E, w.dwf, 3 * E, E, B, L, s));
-  ZTRY(k_unpack_conv_dw(G->ff2_w, w.dwf, E, E, 3, s));
+  if (inl) ZTRY(dw_ff2(s));
   // d f1 = conv_bwd(df2): the zero-padded df2 correlated with the flipped taps, then ReLU' (saved f1), ff0_b, padded again
-  ZTRY(conv_gemm(t0, (long)LP * E, E, w.wfb2, 3 * E, E, t1, E, (long)L * E, nullptr, B, L, ACT_NONE, s));
+  ZTRY(conv_gemm(t0a, (long)LP * E, E, w.wfb2, 3 * E, E, t1, E, (long)L * E, nullptr, B, L, ACT_NONE, s));
   {
     LnBwdFused q = ln_bwd_fused_args((int)BL, E);
-    q.dyA = rv(t1); q.out = t0in; q.pad_L = L; q.ysave = rv(w.f1p + E, L, (long)LP * E); q.act = ACT_RELU; q.dbias = G->ff0_b;
+    q.dyA = rv(t1); q.out = t0bin; q.pad_L = L; q.ysave = rv(w.f1p + E, L, (long)LP * E); q.act = ACT_RELU; q.dbias = G->ff0_b;
     ZTRY(k_ln_bwd_fused(q, s));
   }
-  ZTRY(conv_dw_gemm(w.ap, (long)LP * E, E, t0 + E, E, (long)LP * E, w.dwf, 3 * E, E, B, L, s));
-  ZTRY(k_unpack_conv_dw(G->ff0_w, w.dwf, E, E, 3, s));
-  ZTRY(conv_gemm(t0, (long)LP * E, E, w.wfb0, 3 * E, E, t1, E, (long)L * E, nullptr, B, L, ACT_NONE, s));
+  if (inl) ZTRY(dw_ff0(s));
+  ZTRY(conv_gemm(t0b, (long)LP * E, E, w.wfb0, 3 * E, E, t1, E, (long)L * E, nullptr, B, L, ACT_NONE, s));
   // ---- attention LN: a = LN(ao + h), da = t2 (residual) + t1 (conv path): t3 = d(ao + h) (h's residual share),
   //      t1 = dao = t3 * mask, out_b += column sums
   {
     LnBwdFused q = ln_bwd_fused_args((int)BL, E);
     q.dyA = rv(t2); q.dyB = rv(t1);
     q.x = rv(w.ao); q.res = rv(w.h); q.gamma = P->lna_g; q.mean = w.ma; q.rstd = w.ra; q.dgamma = G->lna_g; q.dbeta = G->lna_b;
-    q.dx_raw = rv(t3); q.out = rv(t1); q.p_post = p1; q.seed_post = d.seed + 4; q.dbias = G->out_b;
+    q.dx_raw = rv(t3); q.out = rv(t1a); q.p_post = p1; q.seed_post = d.seed + 4; q.dbias = G->out_b;
     ZTRY(k_ln_bwd_fused(q, s));
   }
-  ZTRY(gemm_tn(t1, E, w.O, E, G->out_w, E, (int)BL, E, E, gb, s));
-  ZTRY(gemm_nn(t1, E, P->out_w, E, t2, E, (int)BL, E, E, 0.f, s));              // t2 = dO [BL,E]
+  if (inl) ZTRY(dw_out(s));
+  ZTRY(gemm_nn(t1a, E, P->out_w, E, t2, E, (int)BL, E, E, 0.f, s));             // t2 = dO [BL,E]
   if (w.fused) {      // dQ, dK, dV with the probabilities recomputed from the saved row log-sum-exp (attention.hip)
     ZTRY(k_attn_bwd(w.qkv, w.O, w.lse, t2, w.dqkv, w.dsum, G->in_b, B, L, E, NH, p1, d.seed + 3, s));
   } else {
@@ -437,7 +476,7 @@ extern "C" int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims* dp, const ZeggsS
     ZTRY(launch_gemm(g, B * NH, s));
   }
   }
-  ZTRY(gemm_tn(w.dqkv, 3 * E, w.h, E, G->in_w, E, (int)BL, 3 * E, E, gb, s));
+  if (inl) ZTRY(dw_in(s));
   if (!w.fused) ZTRY(k_colsum(G->in_b, w.dqkv, BL, 3 * E, 3 * E, gb, s));          // (fused attention: summed by its kernels)
   ZTRY(gemm_nn(w.dqkv, 3 * E, P->in_w, E, t1, E, (int)BL, 3 * E, E, 0.f, s));   // t1 = dh (attention part; pos table: no grad)
   // ---- conv stack: h = dropout(LN(c2)) + pos, c2 = ReLU(conv): dh = (t1 + t3) * mask -> LN backward -> ReLU' -> t0 interior
@@ -449,8 +488,7 @@ extern "C" int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims* dp, const ZeggsS
     q.out = t0in; q.pad_L = L; q.ysave = rv(w.c2, L, (long)LP * E); q.act = ACT_RELU; q.dbias = G->c4_b;
     ZTRY(k_ln_bwd_fused(q, s));
   }
-  ZTRY(conv_dw_gemm(w.a1p, (long)LP * H, H, t0 + E, E, (long)LP * E, w.dwf, 3 * H, E, B, L, s));
-  ZTRY(k_unpack_conv_dw(G->c4_w, w.dwf, E, H, 3, s));
+  if (inl) ZTRY(dw_c4(s));
   ZTRY(conv_gemm(t0, (long)LP * E, E, w.wb4, 3 * E, H, t1, H, (long)L * H, nullptr, B, L, ACT_NONE, s));  // t1 = da1 [BL,H]
   // ---- a1 = dropout(LN(c1)), c1 = ReLU(conv): the same pass at width H, t2 = dc1
   {
@@ -460,7 +498,6 @@ extern "C" int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims* dp, const ZeggsS
     q.out = rv(t2); q.ysave = rv(w.c1, L, (long)LP * H); q.act = ACT_RELU; q.dbias = G->c0_b;
     ZTRY(k_ln_bwd_fused(q, s));
   }
-  ZTRY(conv_dw_gemm(w.xp, (long)LP * C, C, t2, H, (long)L * H, w.dwf, 3 * C, H, B, L, s));
-  ZTRY(k_unpack_conv_dw(G->c0_w, w.dwf, H, C, 3, s));
+  if (inl) ZTRY(dw_c0(s));
   return 0;
 }

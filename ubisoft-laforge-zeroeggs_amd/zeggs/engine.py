@@ -209,8 +209,13 @@ class TrainEngine:
     def __init__(self, speech_encoder, decoder, style_encoder, dataset, parents, dt, lr=1e-4, eps=1e-5,
                  style_encoding_type="example", world_size=1, rank=0, process_group=None, force_allreduce=False,
                  overlap_allreduce=True, overlap_wgrads=True, early_decoder_step=True, noise_seed=None,
-                 style_head_first=3, prepare_ahead=True):
+                 style_head_first=3, prepare_ahead=True, defer_style_wgrads=False):
         self.se, self.de, self.st = speech_encoder, decoder, style_encoder
+        # the attention style encoder's six weight-gradient products leave its backward chain for the third queue (ops._StyleFn,
+        # zeggs_style_encoder_bwd_part); ZEGGS_DEFER_STYLE_WGRADS=0/1 for the A/B.  OFF: measured 16.96 against 16.86 ms -- every queue is
+        # busy with chip-filling products until the chain ends, the total is conserved, and the shorter chain moves the attention
+        # backward into a collision with the second queue's last product (profiles/r06_style_wgrads_deferred.txt)
+        self.defer_style_wgrads = bool(int(os.environ.get("ZEGGS_DEFER_STYLE_WGRADS", int(defer_style_wgrads))))
         # everything the binding needs beyond the arguments of a call (gradient targets, side stream, status words, hooks,
         # the prepared decoder workspace, optionally an own noise-seed stream) travels in THIS engine's context object --
         # two engines stepping from two threads do not see each other's (ops.EngineContext)
@@ -479,6 +484,8 @@ class TrainEngine:
         self._dec_work = None
         ctx.after_decoder_backward = self._reduce_decoder_grads if overlap else None
         ctx.wgrad_stream = self.wgrad_stream
+        ctx.defer_style_wgrads = bool(self.defer_style_wgrads and self.aux_stream is not None)
+        ctx.deferred_wgrads = []
         # data-parallel twin of the early decoder step below: needs the two-halves exchange on the weight-gradient stream
         # (the slices are then updated there, behind their own all-reduce) and the device-side guard (flag first)
         self._early_dp = bool(self.early_decoder_step and overlap and self.wgrad_stream is not None and self.status is not None)
@@ -570,6 +577,15 @@ class TrainEngine:
                     e2 = ev()
                     e2.record()
                 loss.backward(self._one)
+                if ctx.deferred_wgrads:
+                    # the style encoder's weight-gradient products, enqueued LAST on the third queue (behind the speech encoder's
+                    # backward, which autograd has enqueued by now): they run beside the end of the chain and the second queue's last
+                    # work instead of inside the chain (joined below, with the speech encoder's gradients)
+                    with torch.cuda.stream(self.aux_stream):
+                        for evd, fn in ctx.deferred_wgrads:
+                            self.aux_stream.wait_event(evd)
+                            fn()
+                    ctx.deferred_wgrads = []
                 if self.decoder_bwd_events is not None:
                     e3 = ev()
                     e3.record()
@@ -577,6 +593,7 @@ class TrainEngine:
             done = True
         finally:
             ctx.after_style_head = None
+            ctx.deferred_wgrads = []
             if not done:
                 # the step did not complete (OOM, an error in a backward, KeyboardInterrupt): forget the slices the optimizer
                 # may already have applied early -- a stale list would make the NEXT step() skip the decoder slice -- and give

@@ -156,6 +156,8 @@ class EngineContext:
         self.wgrad_keepalive = []          # workspaces the deferred GEMMs still read, until the caller joined wgrad_stream
         self.seed_rng = None               # own noise-seed generator (None: the process-wide stream of ops.manual_seed)
         self.gemm_route = None             # (direct, shield, depth, reserve) of THIS context's weight-gradient products (zeggs_gemm_route)
+        self.defer_style_wgrads = False    # the attention style encoder's backward enqueues its chain only and leaves its six weight-
+        self.deferred_wgrads = []          # gradient products here as (event, fn()): the caller runs them on another stream and joins
 
     def release_wgrad_workspaces(self):
         """After the caller has made its stream wait for wgrad_stream: the decoder workspaces the deferred weight-gradient
@@ -434,7 +436,24 @@ class _StyleFn(torch.autograd.Function):
         P = _ptrs(StylePtrs, STYLE_FIELDS, params)
         G = _ptrs(StylePtrs, STYLE_FIELDS, grads)
         zeroed = int(ctx.ectx.direct_grads and all(r is None for r in rets))
-        _check(L.zeggs_style_encoder_bwd_ex(C.byref(ctx.d), C.byref(P), _p(_f32c(dout)), C.byref(G), _p(ctx.ws),
+        dout = _f32c(dout)
+        ectx = ctx.ectx
+        if ectx.defer_style_wgrads and zeroed:
+            # the chain now, on this stream; the six weight-gradient products later, where the caller puts them (they read the operands
+            # the chain parked in the workspace: zeggs_style_encoder_bwd_part)
+            _check(L.zeggs_style_encoder_bwd_part(C.byref(ctx.d), C.byref(P), _p(dout), C.byref(G), _p(ctx.ws),
+                                                  C.c_size_t(ctx.ws.numel()), _stream(), zeroed, 1), "style_encoder_bwd (chain)")
+            ev = torch.cuda.Event()
+            ev.record()
+            d, ws, keep = ctx.d, ctx.ws, (params, grads, dout)
+
+            def products():
+                _route(ectx)
+                _check(L.zeggs_style_encoder_bwd_part(C.byref(d), C.byref(P), _p(keep[2]), C.byref(G), _p(ws),
+                                                      C.c_size_t(ws.numel()), _stream(), zeroed, 2), "style_encoder_bwd (products)")
+            ectx.deferred_wgrads.append((ev, products))
+            return (None, None, None, None, None, *rets)
+        _check(L.zeggs_style_encoder_bwd_ex(C.byref(ctx.d), C.byref(P), _p(dout), C.byref(G), _p(ctx.ws),
                                             C.c_size_t(ctx.ws.numel()), _stream(), zeroed), "style_encoder_bwd")
         return (None, None, None, None, None, *rets)
 
