@@ -2,7 +2,8 @@
 """The style encoder (attention type) forward + backward ALONE on the chip at the headline shape (B = 32, example length 384,
 dropout on): the profiling target for its kernels' isolated durations (rocprofv3 --kernel-trace --stats; in the training
 iteration they run beside the decoder's weight-gradient GEMMs, where a duration mostly measures the wait for a CU slot).
-usage: [ZEGGS_OPTIONS=...] python tools/style_probe.py [reps]"""
+usage: [ZEGGS_OPTIONS=...] [STYLE_EVAL=1] python tools/style_probe.py [reps]      (STYLE_EVAL=1: eval mode, the kernels without dropout masks)"""
+import os
 import sys
 import time
 from pathlib import Path
@@ -16,7 +17,8 @@ from zeggs import modules, ops, synth  # noqa: E402
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = torch.device("cuda:0")
 torch.manual_seed(1234)
-st = modules.StyleEncoder(synth.POSE_IN, 512, 64, type="attn", use_vae=True).to(dev).train()
+st = modules.StyleEncoder(synth.POSE_IN, 512, 64, type="attn", use_vae=True).to(dev)
+st = st.eval() if os.environ.get("STYLE_EVAL") else st.train()
 B, L = 32, 384
 x = torch.randn(B, L, synth.POSE_IN, device=dev)
 eps = torch.randn(B, 64, device=dev)
