@@ -144,6 +144,11 @@ int zeggs_style_encoder_fwd(const ZeggsStyleDims*, const ZeggsStyleParams*, cons
  * two (zeggs/engine.py); same workspace, same stream, part 1 before part 2. */
 int zeggs_style_encoder_fwd_part(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* x, const float* pos, float* out,
                                  void* ws, size_t ws_bytes, void* stream, int part);
+/* `part | 4`: the padded input of the first convolution ([B][L + 2][C], one zero row either side of every batch entry) already
+ * lies in the workspace, at byte offset zeggs_style_encoder_input_offset() -- a caller that gathers the style example itself
+ * (zeggs_gather_example; reference ZEGGS/dataset.py:176-204 + the normalisation of train.py:239) writes it there and the encoder's
+ * own padding copy (2 x 56 MB at the head of the longest chain before the decoder sweep) is skipped; `x` is not read then. */
+size_t zeggs_style_encoder_input_offset(const ZeggsStyleDims*);
 int zeggs_style_encoder_bwd(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* dout,
                             const ZeggsStyleGrads*, void* ws, size_t ws_bytes, void* stream);
 int zeggs_style_encoder_bwd_ex(const ZeggsStyleDims*, const ZeggsStyleParams*, const float* dout,
@@ -437,6 +442,13 @@ int zeggs_loudness_gain(const float* wav, long n_samples, int rate, double targe
                         long chunk, const long* blk_lo, const long* blk_hi, int nblocks, int f32_stages, double* result,
                         float* gain32, void* ws, size_t ws_bytes, void* stream);
 
+/* the style example of a batch in one pass (replaces SGDataset.get_example, ZEGGS/dataset.py:176-204, + the input normalisation
+ * of ZEGGS/train.py:239): out [B][pad + L + pad][out_width], out[b][pad + l][c] = ((c < width ? frames[rows[b L + l]][c] : 0) -
+ * mean[c]) / stdv[c] (the gaze slot of the example is zero BEFORE the normalisation, dataset.py:194), the 2 pad edge rows of every
+ * batch entry zero.  mean / stdv: [out_width].  With pad = 1 and `out` = workspace + zeggs_style_encoder_input_offset() this is the
+ * padded input of the style encoder's first convolution. */
+int zeggs_gather_example(const float* frames, int width, const int64_t* rows, int B, int L, const float* mean, const float* stdv,
+                         float* out, int out_width, int pad, void* stream);
 /* in-place feature normalisation (x - mean) / std of ZEGGS/train.py:232-234,239 ; stdv == NULL -> scalar std */
 int zeggs_normalize_rows(float* x, long rows, int width, long ld, const float* mean, const float* stdv,
                          float std_scalar, void* stream);

@@ -23,6 +23,9 @@ if len(rad) < 2:
 # the shortest of the last few iterations (the bench's trailing iterations are separated by host-side event reads)
 pairs = list(zip(rad[:-1], rad[1:]))[-5:]
 lo, hi = min(pairs, key=lambda ab: rows[ab[1]][3] - rows[ab[0]][3])
+import os
+if os.environ.get("TL_PAIR"):       # TL_PAIR=-2: the second-to-last iteration (a MIDDLE one: the next batch's prefetch is in it), not the shortest
+    lo, hi = list(zip(rad[:-1], rad[1:]))[int(os.environ["TL_PAIR"])]
 it = rows[lo + 1: hi + 1]
 t0 = rows[lo][3]
 out = csv.writer(open(sys.argv[2], "w", newline="") if len(sys.argv) > 2 else sys.stdout)

@@ -231,6 +231,14 @@ extern "C" int zeggs_style_encoder_fwd(const ZeggsStyleDims* dp, const ZeggsStyl
 // chip-filling launch), 2 = everything behind it, 3 = both.  A training loop that runs other queues beside the encoder calls the
 // two parts separately and releases those queues BETWEEN them (zeggs/engine.py): the head then has the chip to itself, and the other
 // queues' work runs under the chain of small dependent launches that follows, instead of under the one launch that could use it all.
+// bit 4 of `part`: the padded input [B][L + 2][C] (one zero row either side of every batch entry) is already in the workspace at
+// zeggs_style_encoder_input_offset(): `x` is not read
+extern "C" size_t zeggs_style_encoder_input_offset(const ZeggsStyleDims* d) {
+  char base[1];
+  Arena a(base, ~(size_t)0);        // (a non-null base: pointers are base + offset; nothing is dereferenced)
+  StyleWs w = carve_style(*d, a);
+  return (size_t)((char*)w.xp - base);
+}
 extern "C" int zeggs_style_encoder_fwd_part(const ZeggsStyleDims* dp, const ZeggsStyleParams* P, const float* x, const float* pos,
                                             float* out, void* ws, size_t ws_bytes, void* stream, int part) {
   const ZeggsStyleDims& d = *dp;
@@ -258,7 +266,9 @@ extern "C" int zeggs_style_encoder_fwd_part(const ZeggsStyleDims* dp, const Zegg
   // tiles per batch entry at full K, 1.5 rounds of tiles on half the CUs, and at N = 128 split + zero fill + bias pass); bias and
   // ReLU are folded into the LayerNorm pass that reads the result anyway (LnFwdFused.pre_bias, written back: the backward's
   // LayerNorm input and ReLU mask).
-  ZTRY(k_pad_rows(w.xp, x, B, L, C, 1, 1, 0, s));
+  // (part & 4: the caller's batch gather wrote the padded input where this workspace keeps it -- zeggs_gather_example into
+  //  ws + zeggs_style_encoder_input_offset -- so the 2 x 56 MB padding copy at the head of the longest chain before the sweep is gone)
+  if (!(part & 4)) ZTRY(k_pad_rows(w.xp, x, B, L, C, 1, 1, 0, s));
   if (fuse0) ZTRY(conv_flat(w.xp, C, w.wf0, 3 * C, H, w.c1, B * LP - 2, s));
   else ZTRY(conv_gemm(w.xp, (long)LP * C, C, w.wf0, 3 * C, H, w.c1, H, (long)LP * H, P->c0_b, B, L, ACT_RELU, s));
   }

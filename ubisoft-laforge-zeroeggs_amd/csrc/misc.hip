@@ -102,6 +102,30 @@ __global__ __launch_bounds__(256) void gather_rows_k(const float* frames, int wi
   }
 }
 
+// the style example of a batch in ONE pass, written in the padded row order the style encoder's first convolution reads
+// ([B][pad + L + pad][ow]): out[b][pad + l][c] = ((c < width ? frames[rows[b L + l]][c] : 0) - mean[c]) / std[c], edge rows zero --
+// what fill + gather_rows + normalize_rows + the encoder's own padding copy did in four passes over the 56 MB (the same
+// arithmetic per element: bit-identical).  One wave per output row.
+__global__ __launch_bounds__(256) void gather_example_k(const float* frames, int width, const int64_t* rows, int B, int L,
+                                                        const float* mean, const float* stdv, float* out, int ow, int pad) {
+  const int lane = threadIdx.x & 63, LP = L + 2 * pad;
+  const long nrows = (long)B * LP;
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < nrows; r += (long)gridDim.x * 4) {
+    const long b = r / LP;
+    const int l = (int)(r - b * LP) - pad;
+    float* dst = out + r * ow;
+    if (l < 0 || l >= L) {
+      for (int c = lane; c < ow; c += 64) dst[c] = 0.f;
+      continue;
+    }
+    const float* src = frames + rows[b * L + l] * width;
+    for (int c = lane; c < ow; c += 64) {
+      const float x = c < width ? src[c] : 0.f;
+      dst[c] = (x - mean[c]) / stdv[c];
+    }
+  }
+}
+
 // x[r][c] = (x[r][c] - mean[c]) / std[c]   (std == null: scalar std)
 __global__ void normalize_rows_k(float* x, long rows, int width, long ld, const float* mean, const float* stdv,
                                  float std_scalar) {
@@ -248,6 +272,18 @@ extern "C" int zeggs_gather_rows(const float* frames, int width, const int64_t* 
   hipLaunchKernelGGL(gather_rows_k, dim3(g1(nrows * 64)), dim3(256), 0, (hipStream_t)stream, frames, width, rows, nrows, out,
                      out_ld);
   ZLAUNCH_CHECK("gather_rows");
+  return 0;
+}
+
+extern "C" int zeggs_gather_example(const float* frames, int width, const int64_t* rows, int B, int L, const float* mean,
+                                    const float* stdv, float* out, int out_width, int pad, void* stream) {
+  ZCHECK(B >= 0 && L >= 0 && pad >= 0 && out_width >= width && width > 0, "gather_example: B %d L %d pad %d width %d -> %d", B, L,
+         pad, width, out_width);
+  const long nrows = (long)B * (L + 2 * pad);
+  if (nrows <= 0) return 0;
+  hipLaunchKernelGGL(gather_example_k, dim3(g1(nrows * 64)), dim3(256), 0, (hipStream_t)stream, frames, width, rows, B, L, mean,
+                     stdv, out, out_width, pad);
+  ZLAUNCH_CHECK("gather_example");
   return 0;
 }
 

@@ -141,24 +141,39 @@ class DeviceDataset:
         ops.normalize_rows_(ex, self.in_mean, self.in_std)
         return ex
 
-    def batch(self, idx, example_len):
-        """Gather one batch (normalised where the reference normalises before the nets)."""
+    def batch(self, idx, example_len, bufs=None, style_encoder=None):
+        """Gather one batch (normalised where the reference normalises before the nets).
+        bufs: a dict of tensors of an earlier call with the same shapes to gather into (a caller that alternates two such sets
+        never hands a batch tensor back to the allocator: TrainEngine.prefetch).  style_encoder: the attention encoder that will
+        read the example -- the example is then gathered straight into the padded input region of a workspace of that encoder
+        (ops.style_input_buffer / gather_example: one pass instead of fill + gather + normalise + the encoder's padding copy)."""
         dev = self.device
         B, T = len(idx), self.window
+        bufs = {} if bufs is None else bufs
         starts = self._upload(self.win_start[idx])
-        out = dict(audio=ops.gather_windows(self.audio, starts, T), pose=ops.gather_windows(self.pose, starts, T),
-                   rpos=ops.gather_windows(self.rpos, starts, T), rrot=ops.gather_windows(self.rrot, starts, T),
-                   gaze=ops.gather_windows(self.gaze, starts, T),
+        def old(k, shape):       # the buffer of an earlier call, if it still has the shape
+            t = bufs.get(k)
+            return t if t is not None and tuple(t.shape) == shape and t.is_contiguous() else None
+        gw = lambda k, src: ops.gather_windows(src, starts, T, out=old(k, (B, T, src.shape[1])))  # noqa: E731
+        gr = lambda k, src: ops.gather_rows(src, starts, out=old(k, (B, src.shape[1])), out_ld=src.shape[1])  # noqa: E731
+        out = dict(audio=gw("audio", self.audio), pose=gw("pose", self.pose), rpos=gw("rpos", self.rpos),
+                   rrot=gw("rrot", self.rrot), gaze=gw("gaze", self.gaze),
                    # first frame of every window (the decoder's initial pose), gathered directly: no strided copies
-                   pose0=ops.gather_rows(self.pose, starts), rpos0=ops.gather_rows(self.rpos, starts),
-                   rrot0=ops.gather_rows(self.rrot, starts))
+                   pose0=gr("pose0", self.pose), rpos0=gr("rpos0", self.rpos), rrot0=gr("rrot0", self.rrot))
         ops.normalize_rows_(out["audio"], self.audio_mean, self.audio_std)
         if example_len is not None:
             rows = self._upload(self.example_rows(idx, example_len))
-            ex = ops.fill_(torch.empty(B, example_len, self.PO + 3, device=dev))      # gaze slot = 0 (dataset.py:194)
-            ops.gather_rows(self.pose, rows, out=ex, out_ld=self.PO + 3)
-            ops.normalize_rows_(ex, self.in_mean, self.in_std)
-            out["example"] = ex
+            if style_encoder is not None:
+                ws, xp = ops.style_input_buffer(style_encoder, B, example_len, self.PO + 3, style_encoder.training, dev,
+                                                ws=bufs.get("style_ws"))
+                ops.gather_example(self.pose, rows, self.in_mean, self.in_std, xp)
+                out["style_ws"] = ws
+                out["example"] = ops.example_view(ws, xp)
+            else:
+                ex = ops.fill_(torch.empty(B, example_len, self.PO + 3, device=dev))      # gaze slot = 0 (dataset.py:194)
+                ops.gather_rows(self.pose, rows, out=ex, out_ld=self.PO + 3)
+                ops.normalize_rows_(ex, self.in_mean, self.in_std)
+                out["example"] = ex
         return out
 
 
@@ -270,6 +285,12 @@ class TrainEngine:
         self._flag_sent = False
         self._dec_shape = None              # (B, speech width, style width) of the last decoder call: what to prepare for
         self._prefetched = None             # (key, batch, event): the next step's batch, gathered on the third stream
+        self._pf_sets, self._pf_n = ({}, {}), 0     # ... into two alternating sets of persistent buffers (prefetch)
+        self._pf_used = [None, None]        # number of the step that read a set last
+        self._step_no, self._last_sync_step = 0, -1     # steps started; the step in which the third stream last waited for the caller's
+        self._keep_next, self._keep_prev = [], []   # tensors of the third stream's pool read on the caller's stream (step)
+        # the style example gathered straight into the attention encoder's padded input (ZEGGS_EXAMPLE_IN_PLACE=0: A/B)
+        self.example_in_place = bool(int(os.environ.get("ZEGGS_EXAMPLE_IN_PLACE", 1)))
         self.prefetch_hits = 0
         self.opt = RAdam(self.params, lr=lr, eps=eps)
         self.opt.attach_flat(self.flat_p, self.flat_g)
@@ -343,14 +364,33 @@ class TrainEngine:
         if self.aux_stream is None:
             return
         ex_len = example_len if self.style_type == "example" else None
+        # Two alternating sets of batch buffers that live as long as the engine (round 6).  Set k is written here, on the third
+        # stream, for step n and again for step n + 2 -- behind step n + 1's work on that stream, which starts with a wait for the
+        # caller's stream (launch_speech), i.e. behind everything step n read it for.  Nothing goes back to the allocator, so
+        # nothing needs record_stream (whose events, recorded on the CALLER's stream when a batch died, were 60 us of barrier
+        # packets in front of every iteration), and the batch costs no allocation either.
+        self._pf_n += 1
+        k = self._pf_n % 2
+        bufs = self._pf_sets[k]
+        if self._pf_used[k] is not None and self._last_sync_step <= self._pf_used[k]:
+            # (two prefetches without a step in between: the third stream has not waited for the caller's since the step that read
+            #  this set -- do it now)
+            self.aux_stream.wait_stream(torch.cuda.current_stream())
+        self._pf_used[k] = None
+        enc = getattr(self.st, "encoder", None) if ex_len is not None else None
+        if type(enc).__name__ != "StyleEncoderAttn" or not self.example_in_place:
+            enc = None                  # (the GRU style encoder has no padded first convolution: plain example tensor)
         with torch.cuda.stream(self.aux_stream):
-            b = self.ds.batch(idx, ex_len)
+            b = self.ds.batch(idx, ex_len, bufs=bufs, style_encoder=enc)
             # ... and the half of the loss's feature pass that depends on the batch only (ground-truth rows transposed, their
             # forward kinematics): off the serial section between the two sweeps
-            b["loss_ws"] = ops.loss_prepare_truth(b["pose"], b["rpos"], b["rrot"], b["gaze"], self.parents, self.dt)
+            b["loss_ws"] = ops.loss_prepare_truth(b["pose"], b["rpos"], b["rrot"], b["gaze"], self.parents, self.dt,
+                                                  ws=bufs.get("loss_ws"))
             ev = torch.cuda.Event()
             ev.record(self.aux_stream)
-        self._prefetched = ((np.asarray(idx).tobytes(), ex_len), b, ev)
+        bufs.clear()
+        bufs.update(b)
+        self._prefetched = ((np.asarray(idx).tobytes(), ex_len), dict(b), ev, k)
 
     STATUS_LAG = 3       # iterations between a step and the host's look at its skip counter (identical on every rank)
     REARM_AFTER = 200    # clean stage-kernel iterations before the persistent sweeps are tried again (rearm_after; 0: never)
@@ -369,7 +409,8 @@ class TrainEngine:
             ops.set_option(k, 1)
 
     def _post_status(self):
-        """After the optimizer step: copy the status words to a pinned slot (asynchronous) for the look STATUS_LAG steps on."""
+        """After the optimizer step: copy the status words to a pinned slot (asynchronous, on the CURRENT stream: the caller's, or
+        the weight-gradient stream when the step hands this to decoder_prepare) for the look STATUS_LAG steps on."""
         k = self.iteration % (self.STATUS_LAG + 1)
         while len(self._status_ring) <= self.STATUS_LAG:
             self._status_ring.append([torch.zeros(ops.STATUS_WORDS, dtype=torch.int32).pin_memory(), None])
@@ -468,12 +509,16 @@ class TrainEngine:
         ds, T = self.ds, self.ds.window
         ex_len = example_len if self.style_type == "example" else None
         pre, self._prefetched = self._prefetched, None
-        if pre is not None and pre[0] == (np.asarray(idx).tobytes(), ex_len):
+        self._step_no += 1
+        hit = pre is not None and pre[0] == (np.asarray(idx).tobytes(), ex_len)
+        if hit:
             b = pre[1]
+            self._pf_used[pre[3]] = self._step_no
             self.prefetch_hits += 1
             torch.cuda.current_stream().wait_event(pre[2])
-            for t in b.values():
-                t.record_stream(torch.cuda.current_stream())
+            # (no record_stream: the tensors are views of this engine's two alternating buffer sets (prefetch), never returned to the
+            #  allocator.  Recorded, every one of the ten cost an event on THIS stream when the batch went out of scope -- 60 us of
+            #  barrier packets between the optimizer's last kernel and the next iteration's first, profiles/r06_iteration_head.txt)
         else:
             b = ds.batch(idx, ex_len)
         ops.fill_(self.flat_gx)
@@ -519,7 +564,13 @@ class TrainEngine:
                 def launch_speech():
                     if self.aux_stream is not None:
                         self.aux_stream.wait_stream(cur)            # the batch was gathered on the current stream
-                        b["audio"].record_stream(self.aux_stream)
+                        self._last_sync_step = self._step_no
+                        # (what the previous step parked: whatever takes these blocks from the third stream's pool from here on runs
+                        #  behind that wait, i.e. behind the last read on the caller's stream)
+                        self._keep_prev, self._keep_next = self._keep_next, []
+                        self._keep_prev.clear()
+                        if not hit:
+                            b["audio"].record_stream(self.aux_stream)
                         with torch.cuda.stream(self.aux_stream):
                             box["speech"] = self.se(b["audio"])
                     else:
@@ -557,7 +608,10 @@ class TrainEngine:
                 style = ops.broadcast_time(z, T)
                 if self.aux_stream is not None:
                     cur.wait_stream(self.aux_stream)
-                    speech.record_stream(cur)
+                    # (the encoding was allocated on the third stream and is read on this one: kept alive until that stream has
+                    #  waited for this one again -- launch_speech of the next step -- instead of a record_stream, whose event lands on
+                    #  this stream when the tensor dies)
+                    self._keep_next.append(speech)
                 ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
                 if self.decoder_fwd_events is not None:
                     e0 = ev()
@@ -636,11 +690,13 @@ class TrainEngine:
             # the gap between two iterations and under the style encoder's input staging instead of beside its tail (the
             # forward checks shape, weight pointers and version counters before it picks the workspace up)
             Bd, SP, ST = self._dec_shape
+            # (the status read-back rides on that queue too, behind the packs: it waits for this stream's optimizer kernels anyway,
+            #  and on the caller's stream the copy + its event stood in front of the next iteration's first kernel)
             with ops.use(ctx):
                 ops.decoder_prepare(self.de, Bd, T, SP, ST, ds.in_mean, ds.in_std, ds.out_mean, ds.out_std, self.dt,
-                                    self.wgrad_stream)
+                                    self.wgrad_stream, after=self._post_status if self.status is not None else None)
             self._ahead_version = self.flat_p._version
-        if self.status is not None:
+        elif self.status is not None:
             self._post_status()
         self.iteration += 1
         self.last_terms = terms

@@ -62,6 +62,7 @@ class DecCall(C.Structure):       # mirrors ZeggsDecCall: the per-call controls 
                 ("grads_zeroed", C.c_int)]
 
 
+COUNTERS = {}                                      # which optional paths ran (tests): "style_in_place"
 STATUS_WORDS = 4                                   # ZEGGS_STATUS_WORDS
 GAVE_UP = {1: "B=1 decode kernel", 2: "training rollout", 4: "BPTT sweep"}     # ZEGGS_GAVE_UP_* bits of status[0]
 
@@ -78,7 +79,7 @@ def lib():
     L = C.CDLL(str(_LIB_PATH))
     L.zeggs_last_error.restype = C.c_char_p
     for n in ("zeggs_speech_encoder_workspace_bytes", "zeggs_style_encoder_workspace_bytes",
-              "zeggs_decoder_workspace_bytes", "zeggs_loss_workspace_bytes"):
+              "zeggs_decoder_workspace_bytes", "zeggs_loss_workspace_bytes", "zeggs_style_encoder_input_offset"):
         getattr(L, n).restype = C.c_size_t
     _LIB = L
     # tuning switches for experiments, e.g. ZEGGS_OPTIONS="bwd_chunks=4,stage_variant=0" (see zeggs_set_option)
@@ -401,7 +402,6 @@ def style_param_list(enc):
 class _StyleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos, dropout, seed, nheads, *params):
-        x = _f32c(x)
         ctx.ectx = current()
         _route(ctx.ectx)
         ctx.orig = params
@@ -410,19 +410,30 @@ class _StyleFn(torch.autograd.Function):
         H, E = params[0].shape[0], params[4].shape[0]
         d = StyleDims(B, Lx, Cx, H, E, nheads, int(dropout), int(seed))
         L = lib()
-        ws = _ws(L.zeggs_style_encoder_workspace_bytes(C.byref(d)), x.device)
+        need = int(L.zeggs_style_encoder_workspace_bytes(C.byref(d)))
+        # an example that style_input_buffer() + gather_example() put where the workspace keeps the first convolution's padded input:
+        # the encoder runs IN that workspace and skips its own padding copy (zeggs_style_encoder_fwd_part, part | 4); anything that
+        # does not match exactly (another shape, a copy of the tensor, a workspace of another size) takes the ordinary path
+        ws, inplace = getattr(x, "_zeggs_style_ws", None), 0
+        if ws is not None and x.dtype == torch.float32 and ws.numel() == need and x.stride() == ((Lx + 2) * Cx, Cx, 1) and \
+                x.data_ptr() == ws.data_ptr() + int(L.zeggs_style_encoder_input_offset(C.byref(d))) + 4 * Cx:
+            inplace, xptr = 4, C.c_void_p(x.data_ptr())
+            COUNTERS["style_in_place"] = COUNTERS.get("style_in_place", 0) + 1
+        else:
+            x = _f32c(x)
+            ws, xptr = _ws(need, x.device), _p(x)
         out = torch.empty(B, E, device=x.device, dtype=torch.float32)
         P = _ptrs(StylePtrs, STYLE_FIELDS, params)
         hook = getattr(ctx.ectx, "after_style_head", None)
         if hook is not None:       # (an engine that releases its other queues once the chip-filling first product is enqueued)
-            _check(L.zeggs_style_encoder_fwd_part(C.byref(d), C.byref(P), _p(x), _p(pos), _p(out), _p(ws),
-                                                  C.c_size_t(ws.numel()), _stream(), 1), "style_encoder_fwd (head)")
+            _check(L.zeggs_style_encoder_fwd_part(C.byref(d), C.byref(P), xptr, _p(pos), _p(out), _p(ws),
+                                                  C.c_size_t(ws.numel()), _stream(), 1 | inplace), "style_encoder_fwd (head)")
             hook()
-            _check(L.zeggs_style_encoder_fwd_part(C.byref(d), C.byref(P), _p(x), _p(pos), _p(out), _p(ws),
-                                                  C.c_size_t(ws.numel()), _stream(), 2), "style_encoder_fwd (rest)")
+            _check(L.zeggs_style_encoder_fwd_part(C.byref(d), C.byref(P), xptr, _p(pos), _p(out), _p(ws),
+                                                  C.c_size_t(ws.numel()), _stream(), 2 | inplace), "style_encoder_fwd (rest)")
         else:
-            _check(L.zeggs_style_encoder_fwd(C.byref(d), C.byref(P), _p(x), _p(pos), _p(out), _p(ws),
-                                             C.c_size_t(ws.numel()), _stream()), "style_encoder_fwd")
+            _check(L.zeggs_style_encoder_fwd_part(C.byref(d), C.byref(P), xptr, _p(pos), _p(out), _p(ws),
+                                                  C.c_size_t(ws.numel()), _stream(), 3 | inplace), "style_encoder_fwd")
         ctx.d, ctx.ws = d, ws
         ctx.save_for_backward(*params)
         return out
@@ -509,6 +520,41 @@ def style_encoder_gru(x, enc):
                              pl.weight, pl.bias)
 
 
+def style_input_buffer(enc, B, L, Cx, training, device, ws=None):
+    """A workspace of the attention style encoder for a [B, L, Cx] example whose padded-input region the CALLER fills
+    (gather_example): -> (ws, xp [B, L + 2, Cx] view of it).  `xp[:, 1:-1]` carries the workspace with it (attribute
+    _zeggs_style_ws); style_encoder_attn() on that tensor runs in this workspace without its padding copy.  `ws`: a buffer of an
+    earlier call to use again when it still fits."""
+    params = style_param_list(enc)
+    d = StyleDims(int(B), int(L), int(Cx), params[0].shape[0], params[4].shape[0], 4, 1 if training else 0, 0)
+    Lb = lib()
+    need = int(Lb.zeggs_style_encoder_workspace_bytes(C.byref(d)))
+    if ws is None or ws.numel() != need or ws.device != torch.device(device):
+        ws = _ws(need, device)
+    off = int(Lb.zeggs_style_encoder_input_offset(C.byref(d)))
+    xp = ws[off:off + 4 * B * (L + 2) * Cx].view(torch.float32).view(B, L + 2, Cx)
+    return ws, xp
+
+
+def example_view(ws, xp):
+    """The [B, L, C] example inside the padded buffer `xp` of style_input_buffer(), tagged with its workspace."""
+    ex = xp[:, 1:-1]
+    ex._zeggs_style_ws = ws
+    return ex
+
+
+def gather_example(frames, rows, mean, std, out, pad=1):
+    """zeggs_gather_example: frames [N, W], rows int64 [B, L], mean / std [Wo] -> out [B, L + 2 pad, Wo] (contiguous):
+    normalised rows with the columns W.. zero BEFORE the normalisation (the example's empty gaze slot, reference dataset.py:194),
+    edge rows zero."""
+    B, Lr = rows.shape
+    Wo = out.shape[2]
+    assert out.shape == (B, Lr + 2 * pad, Wo) and out.is_contiguous() and mean.numel() == Wo and std.numel() == Wo
+    _check(lib().zeggs_gather_example(_p(frames), frames.shape[1], _p(rows.contiguous()), int(B), int(Lr), _p(_f32c(mean)),
+                                      _p(_f32c(std)), _p(out), int(Wo), int(pad), _stream()), "gather_example")
+    return out
+
+
 def style_encoder_attn(x, enc, training):
     pos = positional_table(x.shape[1], enc.convs[6].normalized_shape[0], x.device)
     return _StyleFn.apply(x, pos, 1 if training else 0, next_seed() if training else 0, 4, *style_param_list(enc))
@@ -572,7 +618,7 @@ def _versions(params):
     return tuple(int(t._version) for t in params)
 
 
-def decoder_prepare(dec, B, T, SP, ST, in_mean, in_std, out_mean, out_std, dt, stream):
+def decoder_prepare(dec, B, T, SP, ST, in_mean, in_std, out_mean, out_std, dt, stream, after=None):
     """Weight-only preparation of the NEXT training-mode decoder_core call of THIS context (ops.use) with these dimensions
     (zeggs_decoder_prepare) on `stream`, beside whatever the current stream does meanwhile (the encoders' forward); that
     call picks the prepared workspace up and waits for it.  The weights must not change in between."""
@@ -597,6 +643,8 @@ def decoder_prepare(dec, B, T, SP, ST, in_mean, in_std, out_mean, out_std, dt, s
         _check(min(mask, 0), "decoder_prepare")
         ev = torch.cuda.Event()
         ev.record(stream)
+        if after is not None:       # (more work of the caller for `stream`, behind the packs and outside what the forward waits for)
+            after()
     if mask > 0:
         key = (d.B, d.T, d.PI, d.PO, d.SP, d.ST, d.H, d.film, tuple(t.data_ptr() for t in params), _versions(params))
         ectx.prepared = (key, ws, ev, int(mask))
@@ -992,14 +1040,16 @@ class _LossFn(torch.autograd.Function):
         return (dpose, drpos, drrot, dmu, dlv, None, None, None, None, None, None, None, None, None, None)
 
 
-def loss_prepare_truth(w_pose, w_rpos, w_rrot, gaze, parents, dt):
+def loss_prepare_truth(w_pose, w_rpos, w_rrot, gaze, parents, dt, ws=None):
     """The ground-truth half of the loss's feature pass on the current stream (zeggs_loss_prepare_truth) -> the workspace to
-    hand to training_loss(truth_ws=...) for the same batch."""
+    hand to training_loss(truth_ws=...) for the same batch.  `ws`: a workspace of an earlier call to use again when it fits."""
     w_pose, w_rpos, w_rrot, gaze = (_f32c(t) for t in (w_pose, w_rpos, w_rrot, gaze))
     B, T, PO = w_pose.shape
     d = LossDims(B, T, (PO - 6) // 15, 0, float(dt))
     L = lib()
-    ws = _ws(L.zeggs_loss_workspace_bytes(C.byref(d)), w_pose.device)
+    need = int(L.zeggs_loss_workspace_bytes(C.byref(d)))
+    if ws is None or ws.numel() != need or ws.device != w_pose.device:
+        ws = _ws(need, w_pose.device)
     _check(L.zeggs_loss_prepare_truth(C.byref(d), _p(parents), _p(w_pose), _p(w_rpos), _p(w_rrot), _p(gaze), _p(ws),
                                       C.c_size_t(ws.numel()), _stream()), "loss_prepare_truth")
     return ws
@@ -1041,10 +1091,11 @@ def status_flag(status, dst):
     _check(lib().zeggs_status_flag(C.c_void_p(status.data_ptr()), _p(dst), _stream()), "status_flag")
 
 
-def gather_windows(frames, starts, T):
-    """frames [N, W] device, starts int64 [B] device -> [B, T, W]"""
+def gather_windows(frames, starts, T, out=None):
+    """frames [N, W] device, starts int64 [B] device -> [B, T, W] (into `out` when it has that shape)"""
     B, W = starts.shape[0], frames.shape[1]
-    out = torch.empty(B, T, W, device=frames.device, dtype=torch.float32)
+    if out is None or out.shape != (B, T, W) or not out.is_contiguous():
+        out = torch.empty(B, T, W, device=frames.device, dtype=torch.float32)
     _check(lib().zeggs_gather_windows(_p(frames), W, _p(starts), B, T, _p(out), _stream()), "gather_windows")
     return out
 
