@@ -51,8 +51,9 @@ const char* zeggs_last_error(void);
  * round 6 (A/B switches and experiments, each measured in profiles/r06_*): "tp_dual" 0 (default) / 1 = the forward sweep as two 16-row
  * dependency chains in one launch; "gemm_split_bf16" 0 (default) / 6 / 9 = the TN products on the bf16 matrix cores through an fp32-exact
  * three-plane split; "attn_bwd_one_launch" 1 (default) / 0 = the attention backward's two passes as one grid / two launches; "loss_lds"
- * 1 (default) / 0 = the loss tree walk's level messages through LDS / through the tables; "wgrad_order"; "chain" = refused (-1) unless the
- * library was built with -DZEGGS_CHAIN (measurement builds) */
+ * 1 (default) / 0 = the loss tree walk's level messages through LDS / through the tables; "wgrad_order"; "tp_prologue" 1 (default) / 0 = the
+ * training rollout's prologue (frame 0, CellStateEncoder, conditioning columns, step-1 products) in five launches / in ten; "chain" =
+ * refused (-1) unless the library was built with -DZEGGS_CHAIN (measurement builds) */
 int zeggs_set_option(const char* name, int value);
 /* elapsed ms of the last recorded stage sweep: which = 0 forward (T-1 steps x 3 launches), 1 backward; blocks on
  * the end event.  Measurement hook of bench.py (roofline figures); there is no reference counterpart. */

@@ -1234,6 +1234,29 @@ def test_persistent_training_forward_matches_stage_launches(B, T, tiles4):
         assert relerr(g1[k], g0[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("B,T", [(32, 6), (17, 5), (64, 4), (5, 4)])
+def test_training_rollout_prologue_in_five_launches(B, T):
+    """option "tp_prologue" (round 6, default on): in front of the persistent training rollout [dec_init | dec_fill_cond | tp_cond] run
+    as ONE launch, [CellStateEncoder layer 0 | hid_1 | the step-1 pose product] as one (gemm.hip: skinny_multi_k), the two halves of
+    the CellStateEncoder's last layer as one -- five launches instead of ten, the same arithmetic in the same order: outputs and
+    gradients equal up to the atomics of the stream-K products (the weight fold of the packs, the weight gradients; measured 5e-7)."""
+    _, de, _ = helpers.build_nets()
+    de = de.to(DEV).train()
+    try:
+        ops.set_option("tp_prologue", 0)
+        out0, g0, ds0, dy0 = _rollout_with_grads(de, B, T, 33)
+        ops.set_option("tp_prologue", 1)
+        out1, g1, ds1, dy1 = _rollout_with_grads(de, B, T, 33)
+        assert ops.lib().zeggs_persistent_state(1) == 1
+    finally:
+        ops.set_option("tp_prologue", 1)
+    for a, b in zip(out0, out1):
+        assert float((a - b).abs().max()) < 5e-6, float((a - b).abs().max())
+    assert relerr(ds1, ds0) < 1e-5 and relerr(dy1, dy0) < 1e-5
+    for k in g0:
+        assert relerr(g1[k], g0[k]) < 1e-5, k
+
+
 @pytest.mark.parametrize("B,T,style_dim", [(32, 12, 64), (17, 6, 64), (20, 5, 9), (32, 4, 64), (27, 40, 64)])
 def test_dual_chain_training_forward_matches_stage_launches(B, T, style_dim):
     """option "tp_dual" (off by default: measured slower than the single-chain sweep, profiles/r06_dual_chain_forward.txt): the

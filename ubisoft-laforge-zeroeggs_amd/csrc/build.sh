@@ -9,7 +9,7 @@ mkdir -p $BD
 pids=()
 SRC="gemm gemm_split kernels attention encoders decoder decoder_fast decode_persistent train_persistent train_dual train_bwd_persistent loudness loss misc mel anim style_gru hostio funcs"
 for f in $SRC; do
-  if [ ! -f $BD/$f.o ] || [ $f.hip -nt $BD/$f.o ] || [ common.h -nt $BD/$f.o ] || [ decoder_ws.h -nt $BD/$f.o ] || [ dec_math.h -nt $BD/$f.o ] || [ ../../include/zeggs_hip.h -nt $BD/$f.o ] || [ kernels.h -nt $BD/$f.o ] || [ gemm.h -nt $BD/$f.o ] || [ tp_common.h -nt $BD/$f.o ]; then
+  if [ ! -f $BD/$f.o ] || [ $f.hip -nt $BD/$f.o ] || [ common.h -nt $BD/$f.o ] || [ decoder_ws.h -nt $BD/$f.o ] || [ dec_math.h -nt $BD/$f.o ] || [ ../../include/zeggs_hip.h -nt $BD/$f.o ] || [ kernels.h -nt $BD/$f.o ] || [ gemm.h -nt $BD/$f.o ] || [ tp_common.h -nt $BD/$f.o ] || [ dec_prologue.h -nt $BD/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $ZEGGS_DEFS -c $f.hip -o $BD/$f.o &
     pids+=($!)
   fi

@@ -13,6 +13,7 @@
 #include "gemm.h"
 #include "kernels.h"
 #include "dec_math.h"
+#include "dec_prologue.h"
 #include "decoder_ws.h"
 
 int g_decoder_fast = 1;      // option "decoder_fast": 0 = generic per-step GEMM path everywhere (A/B reference of the stage kernels)
@@ -33,6 +34,7 @@ extern int g_tp_tiles4;
 extern int g_tp_dual;
 extern int g_loss_lds;
 extern int g_gemm_split_bf16;
+int g_tp_prologue = 1;      // zeggs_set_option("tp_prologue", 0 / 1): the training rollout's prologue in five launches instead of ten
 int g_wgrad_order = 0;      // zeggs_set_option("wgrad_order", 0 / 1 / 2): see dec_recurrent_wgrads
 void zeggs_gemm_set_dma(int on);
 void zeggs_gemm_set_direct(int mode, int wgs);
@@ -97,6 +99,7 @@ extern "C" int zeggs_set_option(const char* name, int value) {
   // tests use it to drive the give-up path (tests/test_gpu_giveup.py)
   if (strcmp(name, "tp_tiles4") == 0) { g_tp_tiles4 = value != 0; return 0; }
   if (strcmp(name, "tp_dual") == 0) { g_tp_dual = value != 0; return 0; }
+  if (strcmp(name, "tp_prologue") == 0) { g_tp_prologue = value != 0; return 0; }
   if (strcmp(name, "loss_lds") == 0) { g_loss_lds = value != 0; return 0; }
   if (strcmp(name, "wgrad_order") == 0) { g_wgrad_order = value; return 0; }
   if (strcmp(name, "gemm_split_bf16") == 0) { g_gemm_split_bf16 = (value == 3 || value == 6 || value == 9) ? value : 0; return 0; }
@@ -127,49 +130,13 @@ namespace {
 __global__ void dec_init_k(ZeggsDecDims d, ZeggsDecStats st, const float* pose0, const float* rp0, const float* rr0,
                            const float* gaze, const float* style, float* pose, float* rpos, float* rrot,
                            float* cse_in, float* gin1, int GL) {
-  const int b = blockIdx.x;
-  const float* p0 = pose0 + (long)b * d.PO;
-  for (int c = threadIdx.x; c < d.PO; c += blockDim.x) {
-    float v = p0[c];
-    pose[((long)b * d.T) * d.PO + c] = v;
-    float e = (v - st.in_mean[c]) / st.in_std[c];
-    cse_in[(long)b * (d.PI + d.ST) + c] = e;
-    if (d.T > 1) gin1[(long)b * GL + d.H + c] = e;
-  }
-  for (int c = threadIdx.x; c < d.ST; c += blockDim.x)
-    cse_in[(long)b * (d.PI + d.ST) + d.PI + c] = style[((long)b * d.T) * d.ST + c];
-  if (threadIdx.x == 0) {
-    Q4 q = Q4{rr0[b * 4], rr0[b * 4 + 1], rr0[b * 4 + 2], rr0[b * 4 + 3]};
-    V3 rp = v3(rp0[b * 3], rp0[b * 3 + 1], rp0[b * 3 + 2]);
-    float* o = rpos + ((long)b * d.T) * 3; o[0] = rp.x; o[1] = rp.y; o[2] = rp.z;
-    float* r = rrot + ((long)b * d.T) * 4; r[0] = q.w; r[1] = q.x; r[2] = q.y; r[3] = q.z;
-    for (int f = 0; f < 2 && f < d.T; ++f) {
-      const float* gz = gaze + ((long)b * d.T + f) * 3;
-      V3 gd = quat_mul_vec(quat_inv(q), v3(gz[0], gz[1], gz[2]) - rp);
-      float gv[3] = {gd.x, gd.y, gd.z};
-      for (int k = 0; k < 3; ++k) {
-        float e = (gv[k] - st.in_mean[d.PO + k]) / st.in_std[d.PO + k];
-        if (f == 0) cse_in[(long)b * (d.PI + d.ST) + d.PO + k] = e;
-        else gin1[(long)b * GL + d.H + d.PO + k] = e;
-      }
-    }
-  }
+  dec_init_body(blockIdx.x, d, st, pose0, rp0, rr0, gaze, style, pose, rpos, rrot, cse_in, gin1, GL);
 }
 
 // speech / style columns of x_t for one step (or all steps when nt > 1): Gin[t][b][H+PI ...]
 __global__ void dec_fill_cond_k(ZeggsDecDims d, const float* speech, const float* style, float* gin, int GL, int t0,
                                 int nt, long slot_stride, int ring) {
-  const int XC = d.SP + (d.film ? 0 : d.ST);
-  long n = (long)nt * d.B * XC;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i % XC);
-    long r = i / XC;
-    int b = (int)(r % d.B);
-    int t = t0 + (int)(r / d.B);
-    float v = c < d.SP ? speech[((long)b * d.T + t) * d.SP + c] : style[((long)b * d.T + t) * d.ST + (c - d.SP)];
-    int slot = ring ? (t & 1) : t;
-    gin[slot * slot_stride + (long)b * GL + d.H + d.PI + c] = v;
-  }
+  dec_fill_cond_body(blockIdx.x, gridDim.x, d, speech, style, gin, GL, t0, nt, slot_stride, ring);
 }
 
 // GRU cell gate math (nn.GRU, gate order r,z,n)
@@ -588,6 +555,30 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
   const int ring = training ? 0 : 1;
   auto slot = [&](int t) { return ring ? (t & 1) : t; };
   if (!training) ZTRY(k_fill(w.Gin, 2 * sG, 0.f, s));   // ring slots: pad columns must be finite (GEMV decode path)
+  const bool fast = g_decoder_fast && dec_fast_supported(d);
+  // ---- training, batch <= 64: will the forward rollout run as one persistent launch (train_persistent.hip)?  Then its whole prologue is
+  // five launches instead of ten (round 6; option "tp_prologue", default on): [dec_init | dec_fill_cond | tp_cond] in one,
+  // [CellStateEncoder layer 0 | hid_1 | the step-1 pose product] in one, CellStateEncoder layer 1, the two halves of its last layer
+  // in one, and the rollout's own operand fragments (dec_tp_run) -- every one of them was launch latency on an idle chip
+  bool tp_path = false;
+  if (fast && training && g_train_persistent && dec_tp_state() != 0 && dec_tp_supported(d, w)) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;   // a failed query must not read as "not capturing"
+    tp_path = cap == hipStreamCaptureStatusNone || dec_tp_state() == 1;
+  }
+  const bool tp_pro = tp_path && g_tp_prologue && !h_in && T > 1 && !d.film;
+  if (tp_pro) {
+    float* gin1 = w.Gin + sG;
+    ZTRY(dec_tp_prologue(d, st, w, pose0, rpos0, rrot0, gaze, speech, style, pose, rpos, rrot, s, fwd_prepared));
+    const GemmNtItem l1[3] = {{w.cse_in, CI, P->c0_w, CI, w.cse_a, H, P->c0_b, H, CI, ACT_ELU},
+                              {gin1 + H, GL, P->l0_w, XD, gin1, GL, P->l0_b, H, XD, ACT_ELU},          // hid_1 = ELU(W0 x_1 + b0)
+                              dec_tp_p1x_item(d, P, w)};
+    ZTRY(gemm_nt_multi(l1, 3, B, s));
+    ZTRY(gemm_nt(w.cse_a, H, P->c1_w, H, w.cse_b, H, P->c1_b, B, H, H, ACT_ELU, 0.f, s));
+    const GemmNtItem l3[2] = {{w.cse_b, H, P->c2_w, H, w.H0, H, P->c2_b, H, H, ACT_NONE},
+                              {w.cse_b, H, P->c2_w + (long)H * H, H, w.H1, H, P->c2_b + H, H, H, ACT_NONE}};
+    ZTRY(gemm_nt_multi(l3, 2, B, s));
+  } else {
   // frame 0 + CellStateEncoder
   hipLaunchKernelGGL(dec_init_k, dim3(B), dim3(256), 0, s, d, *st, pose0, rpos0, rrot0, gaze, style, pose, rpos, rrot,
                      w.cse_in, w.Gin + slot(1) * sG, GL);
@@ -601,6 +592,7 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
     ZTRY(gemm_nt(w.cse_b, H, P->c2_w, H, w.H0 + slot(0) * sH, H, P->c2_b, B, H, H, ACT_NONE, 0.f, s));
     ZTRY(gemm_nt(w.cse_b, H, P->c2_w + (long)H * H, H, w.H1 + slot(0) * sH, H, P->c2_b + H, B, H, H, ACT_NONE, 0.f, s));
   }
+  }
   auto save_state = [&]() -> int {
     if (h_out) {
       ZTRY(k_copy(h_out, w.H0 + slot(T - 1) * sH, sH, s));
@@ -609,9 +601,11 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
     return 0;
   };
   if (training && T > 1) {
-    hipLaunchKernelGGL(dec_fill_cond_k, g1((long)(T - 1) * B * (d.SP + d.ST)), dim3(256), 0, s, d, speech, style, w.Gin,
-                       GL, 1, T - 1, sG, 0);
-    ZLAUNCH_CHECK("dec_fill_cond");
+    if (!tp_pro) {
+      hipLaunchKernelGGL(dec_fill_cond_k, g1((long)(T - 1) * B * (d.SP + d.ST)), dim3(256), 0, s, d, speech, style, w.Gin,
+                         GL, 1, T - 1, sG, 0);
+      ZLAUNCH_CHECK("dec_fill_cond");
+    }
     if (d.film) {   // modulation vectors of every step in two GEMMs over the time-major style
       ZCHECK(P->l3_w && P->l3_b && P->g_w && P->g_b && P->be_w && P->be_b, "decoder: film parameters missing");
       hipLaunchKernelGGL(style_time_major_k, g1((long)T * B * d.ST), dim3(256), 0, s, d, style, w.STm);
@@ -620,7 +614,6 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
       ZTRY(gemm_nt(w.STm, d.ST, P->be_w, d.ST, w.BET, 2 * H, P->be_b, T * B, 2 * H, d.ST, ACT_NONE, 0.f, s));
     }
   }
-  const bool fast = g_decoder_fast && dec_fast_supported(d);
   // ---- batch-1 inference: the weight-stationary persistent kernel (one launch for all frames, decode_persistent.hip)
   if (fast && !training && g_persistent && dec_persistent_state() != 0 && dec_persistent_supported(d, w)) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -648,12 +641,10 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
     }
   }
   // ---- training, batch <= 32: the forward rollout as one persistent launch (train_persistent.hip)
-  if (fast && training && g_train_persistent && dec_tp_state() != 0 && dec_tp_supported(d, w)) {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;   // a failed query must not read as "not capturing"
-    if (cap == hipStreamCaptureStatusNone || dec_tp_state() == 1) {
+  if (tp_path) {
+    {
       float* gin1 = w.Gin + sG;
-      ZTRY(gemm_nt(gin1 + H, GL, P->l0_w, XD, gin1, GL, P->l0_b, B, H, XD, ACT_ELU, 0.f, s));   // hid_1 = ELU(W0 x_1 + b0)
+      if (!tp_pro) ZTRY(gemm_nt(gin1 + H, GL, P->l0_w, XD, gin1, GL, P->l0_b, B, H, XD, ACT_ELU, 0.f, s));   // hid_1 = ELU(W0 x_1 + b0)
       if (!fwd_prepared) {
         ZTRY(dec_fast_merge_prep(d, P, st, w, s));
         ZTRY(dec_tp_pack(d, P, st, w, s));
@@ -661,7 +652,7 @@ static int decoder_fwd_impl(const ZeggsDecDims* dp, const ZeggsDecParams* P, con
       dec_timing_mark(0, s);
       // (the first, validated use reports through the workspace's own error word: a give-up there is handled right below)
       ZTRY(dec_tp_run(d, P, st, w, gaze, speech, style, pose, rpos, rrot, s, fwd_prepared,
-                      dec_tp_state() == 1 ? status : nullptr));
+                      dec_tp_state() == 1 ? status : nullptr, tp_pro));
       dec_timing_mark(1, s);
       if (dec_tp_state() == 1) return save_state();
       unsigned perr = 1;

@@ -176,7 +176,12 @@ int dec_tp_pack(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSt
 int dec_tp_zero(const ZeggsDecDims& d, DecWs& w, hipStream_t s);
 int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s,
-               bool zeroed = false, unsigned* status = nullptr);
+               bool zeroed = false, unsigned* status = nullptr, bool prologue_done = false);
+int dec_tp_prologue(const ZeggsDecDims& d, const ZeggsDecStats* st, DecWs& w, const float* pose0, const float* rpos0,
+                    const float* rrot0, const float* gaze, const float* speech, const float* style, float* pose, float* rpos,
+                    float* rrot, hipStream_t s, bool zeroed);
+struct GemmNtItem;
+GemmNtItem dec_tp_p1x_item(const ZeggsDecDims& d, const ZeggsDecParams* P, const DecWs& w);
 int dec_tp_errors(const DecWs& w, unsigned* out);
 int dec_tp_errptr(const DecWs& w, unsigned** out);
 // persistent BPTT sweep (train_bwd_persistent.hip)

@@ -24,6 +24,9 @@ GemmArgs gemm_args(const float* A, const float* B, float* C, int M, int N, int K
 int launch_gemm(GemmArgs g, int nbatch, hipStream_t s);
 int gemm_nt(const float* x, long ldx, const float* W, long ldw, float* y, long ldy, const float* bias, int M,
             int N, int K, int act, float beta, hipStream_t s);
+// up to three independent y_i = act_i(x_i W_i^T + bias_i) of the same row count in ONE launch when they are batch-sized (gemm.hip: skinny_multi_k)
+struct GemmNtItem { const float* x; long ldx; const float* W; long ldw; float* y; long ldy; const float* bias; int N, K, act; };
+int gemm_nt_multi(const GemmNtItem* items, int n, int M, hipStream_t s);
 int gemm_nn(const float* dy, long lddy, const float* W, long ldw, float* dx, long lddx, int M, int N_contract,
             int K_out, float beta, hipStream_t s);
 int gemm_nn_actbwd(const float* dy, long lddy, const float* W, long ldw, float* dx, long lddx, int M, int N_contract,

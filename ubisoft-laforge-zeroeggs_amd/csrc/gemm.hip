@@ -926,11 +926,11 @@ struct SkinnyArgs {
   float beta;
 };
 template <int NBM, bool WKC>
-__global__ __launch_bounds__(512) void skinny_k(SkinnyArgs a) {
+__device__ __forceinline__ void skinny_body(const SkinnyArgs& a, int bx) {
   __shared__ f4 red[8][NBM][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
   const int M = a.M, N = a.N, K = a.K;
-  const int n0 = blockIdx.x * 16, nblk = (K + 15) >> 4;
+  const int n0 = bx * 16, nblk = (K + 15) >> 4;
   const int wcol = n0 + r < N ? n0 + r : N - 1;                 // (clamped columns compute garbage nobody stores)
   const float* wp = WKC ? a.W + (long)wcol * a.ldw + 4 * g : a.W + (long)(4 * g) * a.ldw + wcol;
   const float* xp[NBM];
@@ -998,6 +998,23 @@ __global__ __launch_bounds__(512) void skinny_k(SkinnyArgs a) {
       }
     }
   }
+}
+template <int NBM, bool WKC>
+__global__ __launch_bounds__(512) void skinny_k(SkinnyArgs a) {
+  skinny_body<NBM, WKC>(a, blockIdx.x);
+}
+// up to three INDEPENDENT batch-sized products in one launch (same row count, same weight layout): workgroups [0, nb[0]) take the
+// first, the next nb[1] the second ... -- the chains these products sit in are nothing but launch latency (round 6: the decoder's
+// prologue in front of the training rollout: CellStateEncoder layer 0 | hid_1 | the step-1 pose product, then the two halves of
+// the CellStateEncoder's last layer)
+struct SkinnyMulti { SkinnyArgs p[3]; int nb[3]; };
+template <int NBM, bool WKC>
+__global__ __launch_bounds__(512) void skinny_multi_k(SkinnyMulti m) {
+  int bx = blockIdx.x;
+  if (bx < m.nb[0]) { skinny_body<NBM, WKC>(m.p[0], bx); return; }
+  bx -= m.nb[0];
+  if (bx < m.nb[1]) { skinny_body<NBM, WKC>(m.p[1], bx); return; }
+  skinny_body<NBM, WKC>(m.p[2], bx - m.nb[1]);
 }
 
 int launch_skinny(const SkinnyArgs& a, bool wkc, hipStream_t s) {
@@ -1163,6 +1180,35 @@ int gemm_nt(const float* x, long ldx, const float* W, long ldw, float* y, long l
   g.sam = ldx; g.sak = 1; g.sbk = 1; g.sbn = ldw; g.scm = ldy; g.scn = 1;
   g.bias = bias; g.act = act; g.beta = beta;
   return launch_gemm(g, 1, s);
+}
+// n <= 3 independent nn.Linear forwards y_i = act_i(x_i W_i^T + bias_i) with the same row count M: ONE launch when every one of
+// them is a batch-sized product the one-launch kernel takes (skinny_ok), else one after the other
+int gemm_nt_multi(const GemmNtItem* it, int n, int M, hipStream_t s) {
+  bool one = g_gemm_skinny && n >= 2 && n <= 3 && M <= 64;
+  GemmArgs g[3];
+  for (int i = 0; i < n && i < 3; ++i) {
+    g[i] = gemm_args(it[i].x, it[i].W, it[i].y, M, it[i].N, it[i].K);
+    g[i].sam = it[i].ldx; g[i].sak = 1; g[i].sbk = 1; g[i].sbn = it[i].ldw; g[i].scm = it[i].ldy; g[i].scn = 1;
+    g[i].bias = it[i].bias; g[i].act = it[i].act;
+    one = one && skinny_ok(g[i], 1);
+  }
+  if (!one) {
+    for (int i = 0; i < n; ++i)
+      ZTRY(gemm_nt(it[i].x, it[i].ldx, it[i].W, it[i].ldw, it[i].y, it[i].ldy, it[i].bias, M, it[i].N, it[i].K, it[i].act, 0.f, s));
+    return 0;
+  }
+  SkinnyMulti m;
+  memset(&m, 0, sizeof(m));
+  int total = 0;
+  for (int i = 0; i < n; ++i) { m.p[i] = skinny_args(g[i]); m.nb[i] = cdiv(it[i].N, 16); total += m.nb[i]; }
+  const int nbm = cdiv(M, 16);
+  dim3 grid(total), block(512);
+  if (nbm == 1) hipLaunchKernelGGL((skinny_multi_k<1, true>), grid, block, 0, s, m);
+  else if (nbm == 2) hipLaunchKernelGGL((skinny_multi_k<2, true>), grid, block, 0, s, m);
+  else if (nbm == 3) hipLaunchKernelGGL((skinny_multi_k<3, true>), grid, block, 0, s, m);
+  else hipLaunchKernelGGL((skinny_multi_k<4, true>), grid, block, 0, s, m);
+  ZLAUNCH_CHECK("gemm_skinny_multi");
+  return 0;
 }
 // dx[M,K] = beta*dx + dy[M,N] W[N,K]          (input gradient of nn.Linear)
 int gemm_nn(const float* dy, long lddy, const float* W, long ldw, float* dx, long lddx, int M, int N_contract,

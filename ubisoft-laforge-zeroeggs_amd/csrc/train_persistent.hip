@@ -20,6 +20,7 @@
 //     them, so the BPTT sweep and the weight-gradient GEMMs are unchanged.
 // Every wait is bounded; on give-up the error word is set and the host redoes the rollout with the stage kernels.
 #include "tp_common.h"
+#include "dec_prologue.h"
 #include "gemm.h"
 #include "kernels.h"
 
@@ -927,12 +928,12 @@ __global__ void tp_xfrag_k(TXfrag x, int K, int B, int NB, int t4) {
     x.xf[j][t4 ? xf4(b, x.kofs[j] + k, NB / 2) : xfi(b, x.kofs[j] + k, NB)] = x.src[j][(long)b * x.ld[j] + k];
   }
 }
-// speech / style columns of every step: x part of G0[t] (t >= 1) and the cond part of G3[t] (cond_{t+1})
-__global__ void tp_cond_k(ZeggsDecDims d, const float* speech, const float* style, float* G0, float* G3, int KB0, int KB3,
-                          int NB, int t4) {
+// speech / style columns of every step: x part of G0[t] (t >= 1) and the cond part of G3[t] (cond_{t+1}); block `bid` of `nblocks`
+__device__ __forceinline__ void tp_cond_body(long bid, long nblocks, const ZeggsDecDims& d, const float* speech, const float* style,
+                                             float* G0, float* G3, int KB0, int KB3, int NB, int t4) {
   const int XC = d.SP + d.ST;
   const long XB = 256L * NB, n = (long)(d.T - 1) * d.B * XC;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  for (long i = bid * blockDim.x + threadIdx.x; i < n; i += nblocks * blockDim.x) {
     const int cc = (int)(i % XC);
     const long r = i / XC;
     const int b = (int)(r % d.B), t = 1 + (int)(r / d.B);
@@ -940,6 +941,34 @@ __global__ void tp_cond_k(ZeggsDecDims d, const float* speech, const float* styl
     G0[(long)t * KB0 * XB + (long)TFR0 * XB + (t4 ? xf4(b, cc, NB / 2) : xfi(b, cc, NB))] = v;      // (G3 keeps the 16-row form)
     if (t >= 2) G3[(long)(t - 1) * KB3 * XB + 64 * XB + xfi(b, cc, NB)] = v;
   }
+}
+__global__ void tp_cond_k(ZeggsDecDims d, const float* speech, const float* style, float* G0, float* G3, int KB0, int KB3,
+                          int NB, int t4) {
+  tp_cond_body(blockIdx.x, gridDim.x, d, speech, style, G0, G3, KB0, KB3, NB, t4);
+}
+// Round 6: everything elementwise in front of the training rollout in ONE launch -- frame 0 + CellStateEncoder input + the pose part
+// of x_1 (dec_init: blocks [0, B)), the speech / style columns of every canonical input row (dec_fill_cond: the next nfill blocks)
+// and of the rollout's own operand buffers (tp_cond: the rest).  The three write disjoint memory and read inputs only.
+struct TProArgs {
+  ZeggsDecDims d; ZeggsDecStats st;
+  const float *pose0, *rp0, *rr0, *gaze, *speech, *style;
+  float *pose, *rpos, *rrot, *cse_in, *gin;
+  int GL; long sG;
+  float *G0, *G3; int KB0, KB3, NB, t4;
+  int nfill, ncond;
+};
+__global__ __launch_bounds__(256) void tp_prologue_k(TProArgs a) {
+  int bx = blockIdx.x;
+  if (bx < a.d.B) {
+    dec_init_body(bx, a.d, a.st, a.pose0, a.rp0, a.rr0, a.gaze, a.style, a.pose, a.rpos, a.rrot, a.cse_in, a.gin + a.sG, a.GL);
+    return;
+  }
+  bx -= a.d.B;
+  if (bx < a.nfill) {
+    dec_fill_cond_body(bx, a.nfill, a.d, a.speech, a.style, a.gin, a.GL, 1, a.d.T - 1, a.sG, 0);
+    return;
+  }
+  tp_cond_body(bx - a.nfill, a.ncond, a.d, a.speech, a.style, a.G0, a.G3, a.KB0, a.KB3, a.NB, a.t4);
 }
 
 // S[r][c] = W[r * ld + c] * sigma_o[c] / sigma_i[c]  (c < PO; zero padded to POL columns): the pose columns of W_ih0, rescaled from
@@ -1003,9 +1032,32 @@ int dec_tp_zero(const ZeggsDecDims& d, DecWs& w, hipStream_t s) {
   ZTRY(k_fill((float*)w.tp_cnt, 2048, 0.f, s));
   return 0;
 }
+// the elementwise prologue as one launch (tp_prologue_k); the caller then runs the CellStateEncoder, hid_1 and the step-1 pose product
+// (dec_tp_p1x_item) and calls dec_tp_run(..., prologue_done = true)
+int dec_tp_prologue(const ZeggsDecDims& d, const ZeggsDecStats* st, DecWs& w, const float* pose0, const float* rpos0,
+                    const float* rrot0, const float* gaze, const float* speech, const float* style, float* pose, float* rpos,
+                    float* rrot, hipStream_t s, bool zeroed) {
+  if (!zeroed) ZTRY(dec_tp_zero(d, w, s));
+  TProArgs a;
+  memset(&a, 0, sizeof(a));
+  a.d = d; a.st = *st; a.pose0 = pose0; a.rp0 = rpos0; a.rr0 = rrot0; a.gaze = gaze; a.speech = speech; a.style = style;
+  a.pose = pose; a.rpos = rpos; a.rrot = rrot; a.cse_in = w.cse_in; a.gin = w.Gin; a.GL = w.GL; a.sG = (long)d.B * w.GL;
+  a.G0 = w.G0xf; a.G3 = w.G3xf; a.KB0 = TKB0; a.KB3 = 64 + w.KBC; a.NB = w.NB; a.t4 = tp_use_t4(w) ? 1 : 0;
+  const long nf = ((long)(d.T - 1) * d.B * (d.SP + d.ST) + 255) / 256;
+  a.nfill = (int)(nf > 2048 ? 2048 : (nf < 1 ? 1 : nf));
+  a.ncond = 1024;
+  hipLaunchKernelGGL(tp_prologue_k, dim3(d.B + a.nfill + a.ncond), dim3(256), 0, s, a);
+  ZLAUNCH_CHECK("tp_prologue");
+  return 0;
+}
+// the step-1 pose product p1x[b][3H] = x_1[b][pose] W_ih0[:, pose]^T as an item of a multi-product launch
+GemmNtItem dec_tp_p1x_item(const ZeggsDecDims& d, const ZeggsDecParams* P, const DecWs& w) {
+  const float* gin1 = w.Gin + (long)d.B * w.GL;
+  return GemmNtItem{gin1 + d.H, (long)w.GL, P->w_ih0 + d.H, (long)(d.H + w.XD), w.tp_p1x, 3L * d.H, nullptr, 3 * d.H, d.PO, ACT_NONE};
+}
 int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecStats* st, DecWs& w, const float* gaze,
                const float* speech, const float* style, float* pose, float* rpos, float* rrot, hipStream_t s, bool zeroed,
-               unsigned* status) {
+               unsigned* status, bool prologue_done) {
   const int B = d.B, H = d.H, NB = w.NB, KB0 = TKB0, KB3 = 64 + w.KBC;
   const long XB = 256L * NB, sG = (long)B * w.GL;
   int dev = 0, ncu = 0;
@@ -1014,9 +1066,9 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
   ZCHECK(ncu >= TNCU, "persistent training rollout needs %d CUs (device has %d)", TNCU, ncu);
   // operand buffers: zero (pad rows / pad columns must be finite), then the inputs that do not depend on the rollout
   // (only the blocks with pad columns: the gaze + speech / style blocks of G0, the cond blocks of G3, the h1 slot of step 1)
-  if (!zeroed) ZTRY(dec_tp_zero(d, w, s));
+  if (!zeroed && !prologue_done) ZTRY(dec_tp_zero(d, w, s));
   const int t4 = tp_use_t4(w) ? 1 : 0;
-  hipLaunchKernelGGL(tp_cond_k, dim3(1024), dim3(256), 0, s, d, speech, style, w.G0xf, w.G3xf, KB0, KB3, NB, t4);
+  if (!prologue_done) hipLaunchKernelGGL(tp_cond_k, dim3(1024), dim3(256), 0, s, d, speech, style, w.G0xf, w.G3xf, KB0, KB3, NB, t4);
   const float* gin1 = w.Gin + sG;
   {   // hid_1, h0_0 -> operand of GRU layer 0, step 1 (its h1 slot stays zero: the pose columns of x_1 are the given first pose; its
       // gaze block is not an operand any more: the gate threads read the gaze direction of x_1 from the canonical row); h1_0 -> layer 1
@@ -1028,7 +1080,7 @@ int dec_tp_run(const ZeggsDecDims& d, const ZeggsDecParams* P, const ZeggsDecSta
     hipLaunchKernelGGL(tp_xfrag_k, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, s, x, H, B, NB, t4);
   }
   // ... whose product with W_ih0 is one small GEMM: p1x[b][3H] = x_1[b][pose] W_ih0[:, pose]^T
-  ZTRY(gemm_nt(gin1 + H, w.GL, P->w_ih0 + H, H + w.XD, w.tp_p1x, 3 * H, nullptr, B, 3 * H, d.PO, ACT_NONE, 0.f, s));
+  if (!prologue_done) ZTRY(gemm_nt(gin1 + H, w.GL, P->w_ih0 + H, H + w.XD, w.tp_p1x, 3 * H, nullptr, B, 3 * H, d.PO, ACT_NONE, 0.f, s));
   ZLAUNCH_CHECK("tp_prologue");
   TArgs a;
   memset(&a, 0, sizeof(a));
