@@ -521,7 +521,12 @@ class TrainEngine:
             #  barrier packets between the optimizer's last kernel and the next iteration's first, profiles/r06_iteration_head.txt)
         else:
             b = ds.batch(idx, ex_len)
-        ops.fill_(self.flat_gx)
+        if self.aux_stream is None:
+            ops.fill_(self.flat_gx)
+        # (with the third stream the zero fill of the flat gradient buffer -- 100 MB, 18 us -- runs THERE, in front of the speech
+        #  encoder (launch_speech): behind that stream's wait for this one, i.e. behind the optimizer kernels that read the previous
+        #  gradients, and in front of every gradient write of this step: this stream joins the third one before the decoder's
+        #  forward, the weight-gradient stream joins this one after the BPTT sweep)
         ctx = self.ctx
         ctx.direct_grads = True             # *_bwd kernels write straight into the flat gradient buffer
         ctx.status = self.status
@@ -572,6 +577,7 @@ class TrainEngine:
                         if not hit:
                             b["audio"].record_stream(self.aux_stream)
                         with torch.cuda.stream(self.aux_stream):
+                            ops.fill_(self.flat_gx)
                             box["speech"] = self.se(b["audio"])
                     else:
                         box["speech"] = self.se(b["audio"])
