@@ -11,8 +11,11 @@ for n in 12 6; do
   python $R/tools/rocpd_stats.py $(find $O/ks -name "*.db" | head -1) $O/r06_train_only_kernel_stats_${n}steps.csv
 done
 rm -rf $O/ks
-rm -rf $O/tl; $T rocprofv3 --kernel-trace -d $O/tl -o k -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $O/tl.log 2>&1
-python $R/tools/rocpd_timeline.py $(find $O/tl -name "*.db" | head -1) $O/r06_iteration_timeline.csv 2> $O/r06_iteration_timeline_summary.txt
+# (second session: a STEADY window -- 22 iterations, so that the host is ahead of the GPU again under the tracer, and the window 8 from the
+#  end: it contains the next batch's prefetch, which the last iteration of a run does not; landmarks of the steady windows beside it)
+rm -rf $O/tl; $T rocprofv3 --kernel-trace -d $O/tl -o k -- python $R/bench.py --steps 16 --warmup 6 --no-cpu-baseline --no-extras > $O/tl.log 2>&1
+TL_PAIR=-8 python $R/tools/rocpd_timeline.py $(find $O/tl -name "*.db" | head -1) $O/r06_iteration_timeline.csv 2> $O/r06_iteration_timeline_summary.txt
+python $R/tools/r06_windows.py $(find $O/tl -name "*.db" | head -1) | head -10 | cut -c1-160 >> $O/r06_iteration_timeline_summary.txt
 cat $O/r06_iteration_timeline_summary.txt; rm -rf $O/tl
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$c; $T rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o p -- python $R/tools/fwdbwd_probe.py > $O/pmc_$c.log 2>&1
