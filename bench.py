@@ -474,11 +474,14 @@ def generate_30min(dev, minutes=30.0, exemplar_frames=CLIP_FRAMES):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def time_regions(step, first, steps, regions=3):
+def time_regions(step, first, steps, regions=3, after=None):
     """Seconds per step of the extras' engines: `regions` (>= 3) consecutive timed regions of `steps` steps each (synchronised on
-    both sides); the MEAN over the regions is what is reported, every region is listed beside it (ms_per_step_regions: the spread is
-    visible -- the extras run first, in fresh processes on a box whose files are still paging in, and one host stall in a region of
-    five steps is a 10 % outlier).  The headline keeps the contract's single region of exactly K steps."""
+    both sides); the MEDIAN of the regions is what is reported, every region is listed beside it (ms_per_step_regions: the spread is
+    visible -- the extras run first, in fresh processes on a box whose files are still paging in: in two of three full runs of the
+    second session the FIRST region of the first extra came out 4 % slow, 28.3 against 27.1 / 27.1 ms, and never when that extra was
+    run on a warm box -- five variants, fifteen regions, 26.89-27.03).  The headline keeps the contract's single region of exactly K steps.
+    after(it): called behind every step but a region's last (round 6, second session: the extras prefetch the next batch like the
+    headline loop; until then they gathered every batch at the head of its own step, 0.3 ms on the caller's queue)."""
     per = []
     for r in range(regions):
         torch.cuda.synchronize()
@@ -486,12 +489,14 @@ def time_regions(step, first, steps, regions=3):
         out = None
         for it in range(first + r * steps, first + (r + 1) * steps):
             out = step(it)
+            if after is not None and it + 1 < first + (r + 1) * steps:      # (the next batch's prefetch, as the headline loop and
+                after(it)                                                    #  zeggs.train() issue it: never across a region's end)
         torch.cuda.synchronize()
         per.append((time.perf_counter() - t0) / steps)
-    return float(np.mean(per)), [round(x * 1e3, 3) for x in per], out
+    return float(np.median(per)), [round(x * 1e3, 3) for x in per], out
 
 
-def v2_label_b64(ds, dev, steps=10, warmup=3, batch=64, nlabels=9):
+def v2_label_b64(ds, dev, steps=10, warmup=6, batch=64, nlabels=9):
     """BASELINE.json configs[3]: configs_v2.json = label conditioning (one-hot over 9 labels, no style encoder),
     batch 64 x 256-frame windows: the MFMA-bound regime of the stage kernels (B >= 40)."""
     se, de, _ = build_nets(dev, style=nlabels, with_style_encoder=False)
@@ -499,13 +504,20 @@ def v2_label_b64(ds, dev, steps=10, warmup=3, batch=64, nlabels=9):
     perm = np.random.default_rng(42).permutation(len(ds))
     table = torch.as_tensor(np.eye(nlabels, dtype=np.float32)[np.arange(len(ds)) % nlabels]).to(dev)
 
-    def step(it):
-        idx = engine.shard_indices(perm, it % (len(ds) // batch), batch, 1, 0)
-        return eng.step(idx, None, labels=ops.gather_rows(table, torch.as_tensor(idx.astype(np.int64)).to(dev)))
+    def indices(it):
+        return engine.shard_indices(perm, it % (len(ds) // batch), batch, 1, 0)
 
-    for it in range(warmup):
+    def step(it):
+        idx = indices(it)
+        # (the label rows through the dataset's pinned upload ring: a copy from pageable memory would put the host in line with the GPU
+        #  once per step -- engine._IndexUploader)
+        return eng.step(idx, None, labels=ops.gather_rows(table, ds.upload_indices(idx)))
+
+    for it in range(warmup):        # (with the prefetch: its two buffer sets are allocated here, not in the first timed region)
         step(it)
-    dt_, regions_ms, _ = time_regions(step, warmup, steps)
+        if it + 1 < warmup:
+            eng.prefetch(indices(it + 1), None)
+    dt_, regions_ms, _ = time_regions(step, warmup, steps, after=lambda it: eng.prefetch(indices(it + 1), None))
     fwd, bwd = sweep_ms(0) * 1e-3 / (WINDOW - 1), sweep_ms(1) * 1e-3 / (WINDOW - 1)
     fl = step_flops(batch, nlabels)
     return {"value": round(batch * WINDOW / dt_, 1), "unit": "frames/s", "ms_per_step": round(dt_ * 1e3, 3),
@@ -523,7 +535,7 @@ def v2_label_b64(ds, dev, steps=10, warmup=3, batch=64, nlabels=9):
             "config": "configs_v2.json shape: label conditioning (9 one-hot labels), no style encoder, batch 64 x 256"}
 
 
-def variants_b32(ds, dev, steps=5, warmup=2):
+def variants_b32(ds, dev, steps=5, warmup=3):
     """The option surface beyond the shipped configs: rnn_cond = "film" (RecurrentDecoderFiLM, ZEGGS/modules.py:188-227) and
     style_encoder.type = "gru" (StyleEncoderGRU, :307-343) at the headline shape.  Since round 4 both run on the fragment-packed
     stage kernels: the FiLM step is 4 launches per direction (its two modulated ELU layers add a dependent stage to the normal
@@ -536,10 +548,13 @@ def variants_b32(ds, dev, steps=5, warmup=2):
     eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT)
     perm = np.random.default_rng(42).permutation(len(ds))
     ops.set_option("timing", 1)
-    for it in range(warmup):
-        eng.step(engine.shard_indices(perm, it, BATCH, 1, 0), EXAMPLE_LEN)
-    dt_, regions_ms, loss = time_regions(lambda it: eng.step(engine.shard_indices(perm, it % (len(ds) // BATCH), BATCH, 1, 0), EXAMPLE_LEN),
-                                        warmup, steps)
+    ind = lambda it: engine.shard_indices(perm, it % (len(ds) // BATCH), BATCH, 1, 0)  # noqa: E731
+    for it in range(warmup):        # (with the prefetch: its two buffer sets are allocated here, not in the first timed region)
+        eng.step(ind(it), EXAMPLE_LEN)
+        if it + 1 < warmup:
+            eng.prefetch(ind(it + 1), EXAMPLE_LEN)
+    dt_, regions_ms, loss = time_regions(lambda it: eng.step(ind(it), EXAMPLE_LEN), warmup, steps,
+                                        after=lambda it: eng.prefetch(ind(it + 1), EXAMPLE_LEN))
     ms = ctypes.c_float(0.0)
     fwd_us = bwd_us = None
     if ops.lib().zeggs_timing_ms(0, ctypes.byref(ms)) == 0:
@@ -569,7 +584,7 @@ def variants_b32(ds, dev, steps=5, warmup=2):
     return out
 
 
-def nhidden_512_b32(ds, dev, steps=5, warmup=2):
+def nhidden_512_b32(ds, dev, steps=5, warmup=3):
     """configs_v1.json with decoder.nhidden = 512 (ZEGGS/train.py:129 honours the option): the persistent sweeps are built for
     H = 1024 and decline, the fragment-packed stage kernels serve it (3 launches per step and direction) -- the fall-back
     path, measured (parity at this width: tests/test_gpu_parity.py::test_decoder_other_hidden_width_vs_oracle)."""
@@ -581,10 +596,13 @@ def nhidden_512_b32(ds, dev, steps=5, warmup=2):
     eng = engine.TrainEngine(se, de, st, ds, synth.PARENTS, synth.DT)
     perm = np.random.default_rng(42).permutation(len(ds))
     ops.set_option("timing", 1)
-    for it in range(warmup):
-        eng.step(engine.shard_indices(perm, it, BATCH, 1, 0), EXAMPLE_LEN)
-    dt_, regions_ms, loss = time_regions(lambda it: eng.step(engine.shard_indices(perm, it % (len(ds) // BATCH), BATCH, 1, 0), EXAMPLE_LEN),
-                                        warmup, steps)
+    ind = lambda it: engine.shard_indices(perm, it % (len(ds) // BATCH), BATCH, 1, 0)  # noqa: E731
+    for it in range(warmup):        # (with the prefetch: its two buffer sets are allocated here, not in the first timed region)
+        eng.step(ind(it), EXAMPLE_LEN)
+        if it + 1 < warmup:
+            eng.prefetch(ind(it + 1), EXAMPLE_LEN)
+    dt_, regions_ms, loss = time_regions(lambda it: eng.step(ind(it), EXAMPLE_LEN), warmup, steps,
+                                        after=lambda it: eng.prefetch(ind(it + 1), EXAMPLE_LEN))
     ms = ctypes.c_float(0.0)
     fwd_us = bwd_us = None
     if ops.lib().zeggs_timing_ms(0, ctypes.byref(ms)) == 0:
@@ -620,9 +638,12 @@ def tail_split_bf16(ds, dev, steps=10, warmup=4, nplanes=6):
         perm = np.random.default_rng(42).permutation(len(ds))
         idx = lambda it: engine.shard_indices(perm, it % (len(ds) // BATCH), BATCH, 1, 0)  # noqa: E731
         loss = None
-        for it in range(warmup):
+        for it in range(warmup):        # (the headline's loop: the next batch prefetched behind every step)
             loss = eng.step(idx(it), EXAMPLE_LEN)
-        dt_, regions_ms, loss = time_regions(lambda it: eng.step(idx(it), EXAMPLE_LEN), warmup, steps)
+            if it + 1 < warmup:
+                eng.prefetch(idx(it + 1), EXAMPLE_LEN)
+        dt_, regions_ms, loss = time_regions(lambda it: eng.step(idx(it), EXAMPLE_LEN), warmup, steps,
+                                            after=lambda it: eng.prefetch(idx(it + 1), EXAMPLE_LEN))
         del eng
         peak = 2500.0 / nplanes
         kern = {}

@@ -95,6 +95,10 @@ class DeviceDataset:
     def __len__(self):
         return len(self.win_start)
 
+    def upload_indices(self, arr):
+        """An int64 index array on the device through the pinned staging ring (no host stall: _IndexUploader)."""
+        return self._upload(arr)
+
     def example_rows(self, idx, example_len):
         """Source frame of every row of the style example (dataset.py:176-204), int64 [B, example_len]."""
         W = self.window

@@ -207,8 +207,7 @@ def train(models_dir, logs_dir, path_processed_data, path_data_definition, train
             if st is not None:
                 st.train()
             idx = engine.shard_indices(perm, bi, batchsize, world, rank)
-            lab = ops.gather_rows(labels_onehot, torch.as_tensor(ds.win_sample[idx].astype(np.int64)).to(device)) \
-                if labels_onehot is not None else None
+            lab = ops.gather_rows(labels_onehot, ds.upload_indices(ds.win_sample[idx])) if labels_onehot is not None else None
             loss = eng.step(idx, example_len, labels=lab)
             # the example length of the NEXT iteration (train.py:228); seeded here so that all ranks agree
             example_len = 2 * random.Random(train_options["seed"] * 1000003 + iteration).randint(
