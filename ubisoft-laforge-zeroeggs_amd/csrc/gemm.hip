@@ -1067,6 +1067,11 @@ int g_gemm_skinny = 1;          // zeggs_set_option("gemm_skinny", 0/1): batch-s
 int g_gemm_streamk = 1;        // zeggs_set_option("gemm_streamk", 0/1): stream-K instead of the many-workgroup split-K
 int g_gemm_mid_split = 1;      // zeggs_set_option("gemm_mid_split", 0/1): split K of the latency-bound narrow-output products
 
+// stream-K pays from K = 1280 on.  Below, its equal-share workgroups spend their time on the fix-up atomics of tiles they share: the two
+// fold products of the decoder packs (3072 x 1024 and 1024 x 1024 at K = 1131, once per optimizer step) take 108 + 56 us alone as
+// stream-K and 93 + 39 us as plain split-K tiles (tools/fold_probe.py; round 6: the threshold was 1024, every other stream-K product of the
+// training step has K >= 1536)
+constexpr long SK_MIN_KTILES = 80;
 int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || nbatch <= 0) return 0;
   if (g.nb1 <= 0) g.nb1 = 1;
@@ -1116,7 +1121,7 @@ int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
     const bool plain_beta = g.beta == 0.f || (g.beta == 1.f && g.bias == nullptr && g.act == ACT_NONE);
     const long tiles64 = (long)cdiv(g.M, 64) * cdiv(g.N, 64) * nbatch;
     const bool streamk_case = g_gemm_streamk && nbatch == 1 && g.bias == nullptr && g.act == ACT_NONE && g.scm == g.N && big &&
-                              ktiles >= 64 && tiles < 1024 * 3;
+                              ktiles >= SK_MIN_KTILES && tiles < 1024 * 3;
     if (g_gemm_mid_split && flat_c && plain_beta && !streamk_case && tiles64 >= 32 && tiles64 < 768 && ktiles >= 16) {
       long sk = (1024 + tiles64 - 1) / tiles64;
       if (sk > ktiles / 6) sk = ktiles / 6;
@@ -1144,7 +1149,7 @@ int launch_gemm(GemmArgs g, int nbatch, hipStream_t s) {
   // few output tiles but a long contraction (weight gradients): split K over workgroups, combine with fp32 atomics
   const bool can_split = nbatch == 1 && (g.beta == 0.f || g.beta == 1.f) && g.bias == nullptr && g.act == ACT_NONE &&
                          g.scn == 1 && g.scm == g.N && ktiles >= 64;
-  if (g_gemm_streamk && can_split && big && g.nb1 == 1 && tiles < 1024 * 3 && ktiles >= 64) {
+  if (g_gemm_streamk && can_split && big && g.nb1 == 1 && tiles < 1024 * 3 && ktiles >= SK_MIN_KTILES) {
     if (g.beta == 0.f) ZTRY(k_fill(g.C, (long)g.M * g.N, 0.f, s));     // beta == 1: the atomics accumulate onto C
     return launch_streamk(g, s);
   }
