@@ -1089,6 +1089,26 @@ def test_generate_gesture_streaming_writer_equals_one_launch(golden_dir, tmp_pat
         assert (res / f"{tag}.wav").read_bytes() == (tmp_path / "a.wav").read_bytes()
 
 
+def test_train_api_label_conditioning_runs(tmp_path):
+    """train() with style_encoding_type = "label" (configs_v2.json): no style encoder, one-hot label rows gathered per window (the row
+    indices go through the dataset's pinned upload ring, engine.DeviceDataset.upload_indices), next batch prefetched behind every step."""
+    from zeggs import train as train_mod
+    from zeggs.train import train
+    npz, jsn = synth.write_dataset(tmp_path / "data", n_train=3, n_valid=1, nframes=40, seed=5)
+    net_opt = {"decoder": {"nhidden": 1024, "num_rnn_layers": 2, "rnn_cond": "normal"},
+               "speech_encoder": {"nhidden": 64, "speech_encoding_size": 64},
+               "style_encoder": {"nhidden": 512, "style_encoding_size": 64, "example_length": 16, "type": "attn", "use_vae": True}}
+    train_opt = dict(niterations=0.004, batchsize=4, window=8, change_pace=True, learning_rate=1e-4, learning_rate_decay=0.995,
+                     eps=1e-5, resume=False, use_gpu=True, thread_count=1, seed=1234, use_tensorboard=False,
+                     style_encoding_type="label", generate_samples_step=100, use_script=False)
+    (tmp_path / "models").mkdir(), (tmp_path / "logs").mkdir()
+    assert train(tmp_path / "models", tmp_path / "logs", npz, jsn, train_opt, net_opt) is None
+    eng = train_mod.last_engine
+    assert eng.iteration >= 4 and eng.st is None and torch.isfinite(eng.last_terms).all()
+    assert eng.prefetch_hits >= eng.iteration - 2            # every batch but an epoch's first came from the prefetch
+    assert (tmp_path / "models" / "decoder.pt").exists() and not (tmp_path / "models" / "style_encoder.pt").exists()
+
+
 def test_train_api_runs_and_checkpoints(tmp_path):
     """train() with the reference's option dictionaries on a tiny synthetic dataset: runs, loss finite, writes
     the reference's checkpoint layout (incl. iteration 0), and the checkpoints load back into generate-able nets."""
